@@ -1,0 +1,311 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference).
+
+Runs only in the build container (the reference does not exist on the GPU box and never
+travels).  The committed fixtures are pure data: inputs, explicit noise and the reference's
+outputs.  Full-size weights are NOT stored: both sides regenerate them from the name-seeded
+recipe in oracle/flow_oracle.py (synth_state_dict); tiny models store their state_dict.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+
+Import recipe: SURVEY.md appendix A (package symlink + 4 stub modules).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def import_reference():
+    link_dir = "/tmp/tw_oracle_ref"
+    os.makedirs(link_dir, exist_ok=True)
+    link = os.path.join(link_dir, "timewarp")
+    if not os.path.islink(link):
+        os.symlink(REF, link)
+    sys.path.insert(0, link_dir)
+    sys.path.append(REF)  # append: reference/profile.py shadows stdlib `profile`
+
+    class _Stub(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            m = _Stub(f"{self.__name__}.{k}")
+            setattr(self, k, m)
+            return m
+
+        def __call__(self, *a, **k):
+            return None
+
+    for n in ("mdtraj", "pymol2", "torch.utils.tensorboard", "tensorboard"):
+        sys.modules[n] = _Stub(n)
+
+
+import_reference()
+sys.path.insert(0, ROOT)
+
+from timewarp.model_constructor import (  # noqa: E402
+    custom_transformer_nvp_constructor,
+    transformer_nvp_constructor,
+    model_constructor,
+)
+from timewarp.model_configs import (  # noqa: E402
+    CustomAttentionTransformerNVPConfig,
+    TransformerNVPConfig,
+    ModelConfig,
+)
+from timewarp.modules.layers.custom_attention_encoder import CustomAttentionEncoderLayerConfig  # noqa: E402
+from timewarp.modules.layers.transformer_block import TransformerConfig  # noqa: E402
+from timewarp.modules.layers.rff_position_encoder import RFFPositionEncoderConfig  # noqa: E402
+from timewarp.modules.layers.kernel_attention import compute_kernel_attention_scores  # noqa: E402
+
+from oracle import flow_oracle as fo  # noqa: E402
+
+AD_NAMES = "1HH3 CH3 2HH3 3HH3 C O N H CA HA CB 1HB 2HB 3HB C O N H CH3 1HH3 2HH3 3HH3".split()
+VOCAB = {"C": 0, "H": 1, "N": 2, "O": 3, "S": 4}
+
+
+def ad_topology():
+    """simulation/testdata/alanine-dipeptide.pdb: coordinates (A -> nm) and element ids."""
+    coords, types = [], []
+    for line in open(os.path.join(REF, "simulation/testdata/alanine-dipeptide.pdb")):
+        if line.startswith("ATOM"):
+            name = line[12:16].strip()
+            el = next(ch for ch in name if ch.isalpha())
+            types.append(VOCAB[el])
+            coords.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+    return torch.tensor(coords, dtype=torch.float32) * 0.1, torch.tensor(types, dtype=torch.int64)
+
+
+def kernel_model(emb, d_model, ff, mlp_hidden, n_coupling, n_layers, lengthscales):
+    enc = CustomAttentionEncoderLayerConfig(
+        d_model=d_model, dim_feedforward=ff, dropout=0.0, num_heads=len(lengthscales),
+        attention_type="kernel", lengthscales=list(lengthscales), normalise_kernel_values=True,
+    )
+    cfg = CustomAttentionTransformerNVPConfig(
+        atom_embedding_dim=emb, latent_mlp_hidden_dims=list(mlp_hidden), num_coupling_layers=n_coupling,
+        num_transformer_layers=n_layers, encoder_layer_config=enc,
+    )
+    return custom_transformer_nvp_constructor(cfg).eval()
+
+
+def dense_model(emb, d_model, ff, mlp_hidden, n_coupling, n_layers, n_head, rff=None):
+    tc = TransformerConfig(n_head=n_head, dim_feedforward=ff, dropout=0.0)
+    cfg = TransformerNVPConfig(
+        atom_embedding_dim=emb, transformer_hidden_dim=d_model, latent_mlp_hidden_dims=list(mlp_hidden),
+        num_coupling_layers=n_coupling, num_transformer_layers=n_layers, transformer_config=tc,
+        rff_position_encoder_config=rff,
+    )
+    return transformer_nvp_constructor(cfg).eval()
+
+
+def np_sd(sd):
+    return {"sd::" + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def run_case(model, atom_types, x_c, x_v, mask, y_c, y_v, S, seed):
+    """Reference outputs for the three model calls of one MH iteration."""
+    B = x_c.shape[0]
+    none = torch.zeros((0, 2), dtype=torch.int64)
+    ebi = torch.zeros((0,), dtype=torch.int64)
+    out = {}
+    with torch.no_grad():
+        out["loglik"] = model.log_likelihood(
+            atom_types=atom_types, x_coords=x_c, x_velocs=x_v, y_coords=y_c, y_velocs=y_v,
+            adj_list=none, edge_batch_idx=ebi, masked_elements=mask,
+        ).numpy()
+        if B == 1:
+            # explicit latents: re-seed so the reference draws exactly these (flow.py:274-275)
+            torch.manual_seed(seed)
+            sc = torch.exp(model.coords_prior_log_scale)
+            sv = torch.exp(model.velocs_prior_log_scale)
+            z_c = torch.distributions.Normal(torch.zeros_like(x_c), sc).rsample((S,))
+            z_v = torch.distributions.Normal(torch.zeros_like(x_v), sv).rsample((S,))
+            torch.manual_seed(seed)
+            yy_c, yy_v, lp = model.conditional_sample_with_logp(
+                atom_types=atom_types, x_coords=x_c, x_velocs=x_v, adj_list=none, edge_batch_idx=ebi,
+                masked_elements=mask, num_samples=S,
+            )
+            out.update(z_coords=z_c.numpy(), z_velocs=z_v.numpy(), s_y_coords=yy_c.numpy(),
+                       s_y_velocs=yy_v.numpy(), s_logp=lp.numpy())
+            # the reverse-move density used by MH (evaluation_utils.py:648-657, velocities negated)
+            yc, yv = yy_c.squeeze(1), yy_v.squeeze(1)
+            out["logp_yx"] = model.log_likelihood(
+                atom_types=atom_types.repeat(S, 1), y_coords=x_c.repeat(S, 1, 1), y_velocs=-x_v.repeat(S, 1, 1),
+                x_coords=yc, x_velocs=-yv, adj_list=none, edge_batch_idx=ebi, masked_elements=mask.repeat(S, 1),
+            ).numpy()
+    return out
+
+
+def base_inputs(atom_types, x_c, x_v, mask, y_c, y_v):
+    return dict(atom_types=atom_types.numpy(), x_coords=x_c.numpy(), x_velocs=x_v.numpy(),
+                masked=mask.numpy(), y_coords=y_c.numpy(), y_velocs=y_v.numpy())
+
+
+def padded_batch(g, B, V, lens):
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.3
+    x_v = torch.randn(B, V, 3, generator=g)
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.05
+    y_v = torch.randn(B, V, 3, generator=g)
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    return at, x_c, x_v, mask, y_c, y_v
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ad_x, ad_t = ad_topology()
+
+    # ---- (1) tiny kernel model, reference-initialised weights stored in full ------------------
+    torch.manual_seed(1234)
+    tiny = kernel_model(emb=4, d_model=8, ff=16, mlp_hidden=[8], n_coupling=2, n_layers=2,
+                        lengthscales=[0.1, 0.5, 1.2])
+    with torch.no_grad():
+        tiny.coords_prior_log_scale.fill_(-0.3)
+        tiny.velocs_prior_log_scale.fill_(0.2)
+    g = torch.Generator().manual_seed(7)
+    at, x_c, x_v, mask, y_c, y_v = padded_batch(g, 3, 7, [7, 5, 6])
+    d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
+    d.update(run_case(tiny, at, x_c, x_v, mask, y_c, y_v, 0, 0))
+    d.update(np_sd(tiny.state_dict()))
+    # B=1 sampling case with padding (V=7, 5 real atoms)
+    at1, x1, v1, m1, yc1, yv1 = padded_batch(g, 1, 7, [5])
+    r = run_case(tiny, at1, x1, v1, m1, yc1, yv1, 4, 99)
+    d.update({"b1_" + k: v for k, v in base_inputs(at1, x1, v1, m1, yc1, yv1).items()})
+    d.update({"b1_" + k: v for k, v in r.items()})
+    np.savez_compressed(os.path.join(OUT, "kernel_tiny.npz"), **d)
+    print("kernel_tiny", {k: v.shape for k, v in d.items() if not k.startswith("sd::")})
+
+    # ---- (2) full-size kernel model on alanine dipeptide, name-seeded weights -------------------
+    full = kernel_model(emb=32, d_model=128, ff=2048, mlp_hidden=[256], n_coupling=8, n_layers=3,
+                        lengthscales=[0.1, 0.2, 0.5, 0.7, 1.0, 1.2])
+    for tag, calibrated in (("kernel_full_ad", False), ("kernel_full_ad_calibrated", True)):
+        sd = fo.synth_state_dict(full.state_dict(), base_seed=0, calibrated=calibrated)
+        full.load_state_dict(sd)
+        g = torch.Generator().manual_seed(11)
+        x_c = ad_x[None].clone()
+        x_v = torch.randn(1, 22, 3, generator=g) * 0.5
+        mask = torch.zeros(1, 22, dtype=torch.bool)
+        y_c = x_c + torch.randn(1, 22, 3, generator=g) * 0.01
+        y_v = torch.randn(1, 22, 3, generator=g) * 0.5
+        at = ad_t[None]
+        S = 8
+        d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
+        # layer trace of the first net evaluated in the reverse pass (chain[7].scale_transformer)
+        trace = {}
+
+        def saver(key):
+            def hook(m, i, o):  # must return None: a returned value would replace the module output
+                trace.setdefault(key, o[:2].detach().numpy().copy())
+            return hook
+
+        if not calibrated:
+            net = full.flow.chain[7].scale_transformer
+            hooks = [net.in_mlp.register_forward_hook(saver("tr_in_mlp"))]
+            for l in range(3):
+                hooks.append(net.encoder_layers[l].register_forward_hook(saver(f"tr_enc{l}")))
+            hooks.append(net.out_mlp.register_forward_hook(saver("tr_out_mlp")))
+        d.update(run_case(full, at, x_c, x_v, mask, y_c, y_v, S, 2024))
+        if not calibrated:
+            for h in hooks:
+                h.remove()
+            # the hooks fired first inside log_likelihood (forward pass, B=1): recompute for the
+            # reverse pass explicitly so the trace belongs to the sampling call
+            trace.clear()
+            hooks = [net.in_mlp.register_forward_hook(saver("tr_in_mlp"))]
+            for l in range(3):
+                hooks.append(net.encoder_layers[l].register_forward_hook(saver(f"tr_enc{l}")))
+            hooks.append(net.out_mlp.register_forward_hook(saver("tr_out_mlp")))
+            torch.manual_seed(2024)
+            with torch.no_grad():
+                full.conditional_sample_with_logp(
+                    atom_types=at, x_coords=x_c, x_velocs=x_v, adj_list=torch.zeros((0, 2), dtype=torch.int64),
+                    edge_batch_idx=torch.zeros((0,), dtype=torch.int64), masked_elements=mask, num_samples=S)
+            for h in hooks:
+                h.remove()
+            d.update(trace)
+            com = x_c.mean(dim=1, keepdim=True)
+            ls = torch.tensor([0.1, 0.2, 0.5, 0.7, 1.0, 1.2])
+            d["scores"] = compute_kernel_attention_scores(x_c - com, x_c - com, mask, ls).numpy()
+        np.savez_compressed(os.path.join(OUT, tag + ".npz"), **d)
+        print(tag, {k: v.shape for k, v in d.items()})
+
+    # ---- (3) V=60: pins the cdist matmul branch (kernel_attention.py:98-102) --------------------
+    sd = fo.synth_state_dict(full.state_dict(), base_seed=0)
+    full.load_state_dict(sd)
+    g = torch.Generator().manual_seed(60)
+    V = 60
+    x_c = torch.randn(1, V, 3, generator=g) * 0.45
+    x_v = torch.randn(1, V, 3, generator=g) * 0.5
+    at = torch.randint(0, 5, (1, V), generator=g)
+    mask = torch.zeros(1, V, dtype=torch.bool)
+    y_c = x_c + torch.randn(1, V, 3, generator=g) * 0.01
+    y_v = torch.randn(1, V, 3, generator=g) * 0.5
+    d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
+    d.update(run_case(full, at, x_c, x_v, mask, y_c, y_v, 4, 606))
+    com = x_c.mean(dim=1, keepdim=True)
+    d["scores"] = compute_kernel_attention_scores(
+        x_c - com, x_c - com, mask, torch.tensor([0.1, 0.2, 0.5, 0.7, 1.0, 1.2])).numpy()
+    np.savez_compressed(os.path.join(OUT, "kernel_full_v60.npz"), **d)
+    print("kernel_full_v60", {k: v.shape for k, v in d.items()})
+
+    # ---- (4) dense softmax variant: tiny (stored weights, padding, RFF) and full-size ------------
+    torch.manual_seed(4321)
+    dt = dense_model(emb=4, d_model=8, ff=16, mlp_hidden=[8], n_coupling=2, n_layers=2, n_head=2,
+                     rff=RFFPositionEncoderConfig(4, 1.0, 1.0))
+    g = torch.Generator().manual_seed(8)
+    at, x_c, x_v, mask, y_c, y_v = padded_batch(g, 3, 7, [7, 5, 6])
+    d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
+    d.update(run_case(dt, at, x_c, x_v, mask, y_c, y_v, 0, 0))
+    d.update(np_sd(dt.state_dict()))
+    at1, x1, v1, m1, yc1, yv1 = padded_batch(g, 1, 7, [5])
+    r = run_case(dt, at1, x1, v1, m1, yc1, yv1, 4, 98)
+    d.update({"b1_" + k: v for k, v in base_inputs(at1, x1, v1, m1, yc1, yv1).items()})
+    d.update({"b1_" + k: v for k, v in r.items()})
+    np.savez_compressed(os.path.join(OUT, "dense_tiny.npz"), **d)
+    print("dense_tiny ok")
+
+    dfull = dense_model(emb=32, d_model=128, ff=2048, mlp_hidden=[256], n_coupling=8, n_layers=3, n_head=8)
+    dfull.load_state_dict(fo.synth_state_dict(dfull.state_dict(), base_seed=0))
+    g = torch.Generator().manual_seed(12)
+    x_c = ad_x[None].clone()
+    x_v = torch.randn(1, 22, 3, generator=g) * 0.5
+    mask = torch.zeros(1, 22, dtype=torch.bool)
+    y_c = x_c + torch.randn(1, 22, 3, generator=g) * 0.01
+    y_v = torch.randn(1, 22, 3, generator=g) * 0.5
+    d = base_inputs(ad_t[None], x_c, x_v, mask, y_c, y_v)
+    d.update(run_case(dfull, ad_t[None], x_c, x_v, mask, y_c, y_v, 8, 2025))
+    np.savez_compressed(os.path.join(OUT, "dense_full_ad.npz"), **d)
+    print("dense_full_ad ok")
+
+    # ---- (5) EulerMaruyamaGaussian (cfg 1 plumbing) ----------------------------------------------
+    em = model_constructor(ModelConfig(model_type="euler_maruyama_gaussian")).eval()
+    g = torch.Generator().manual_seed(5)
+    at, x_c, x_v, mask, y_c, y_v = padded_batch(g, 2, 9, [9, 6])
+    f = torch.randn(2, 9, 3, generator=g) * 100.0
+    with torch.no_grad():
+        pc, pv = em._get_y_dist(atom_types=at, x_coords=x_c, x_velocs=x_v, x_forces=f)
+        ll = em.log_likelihood(atom_types=at, x_coords=x_c, x_velocs=x_v, x_forces=f, y_coords=y_c,
+                               y_velocs=y_v, adj_list=None, edge_batch_idx=None, masked_elements=mask)
+    d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
+    d.update(x_forces=f.numpy(), coord_mean=pc.loc.numpy(), coord_std=pc.scale.numpy(),
+             veloc_mean=pv.loc.numpy(), veloc_std=pv.scale.numpy(), loglik=ll.numpy())
+    d.update(np_sd(em.state_dict()))
+    np.savez_compressed(os.path.join(OUT, "euler_maruyama.npz"), **d)
+    print("euler_maruyama ok")
+
+    # ---- (6) alanine-dipeptide topology as data (22 atoms) ---------------------------------------
+    np.savez_compressed(os.path.join(OUT, "ad_topology.npz"), coords_nm=ad_x.numpy(), atom_types=ad_t.numpy(),
+                        atom_names=np.array(AD_NAMES))
+
+
+if __name__ == "__main__":
+    main()
