@@ -1,0 +1,205 @@
+/*
+ * timewarp_hip.h -- C ABI of libtimewarp_hip.so: the MI355X (gfx950) implementation of
+ * Timewarp's conditional-flow sampling hot path.
+ *
+ * The reference (microsoft/timewarp) is pure Python/PyTorch: it has no FFI of its own, so the
+ * "binding" a maintainer adds is a ctypes stub (INTEGRATION.md shows it).  Each entry point below
+ * names the reference function (file:line under the reference root) whose torch-op chain it
+ * replaces.  Conventions:
+ *
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
+ *   - all float tensors are contiguous fp32, index tensors int32, masks uint8 (1 = masked);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing synchronises;
+ *   - return value: 0 on success, a negative tw_status otherwise; tw_last_error() gives the
+ *     message of the last failure on the calling thread.  No entry point allocates or frees
+ *     caller memory; workspaces are caller-provided (tw_flow_workspace_bytes);
+ *   - thread-safety: re-entrant across streams; no global state except the error string.
+ */
+#ifndef TIMEWARP_HIP_H
+#define TIMEWARP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TW_ABI_VERSION 1
+
+typedef enum {
+  TW_OK = 0,
+  TW_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+  TW_ERR_HIP = -2,       /* a HIP runtime call failed */
+  TW_ERR_WORKSPACE = -3, /* workspace too small */
+  TW_ERR_NO_DEVICE = -4  /* no gfx950 device visible */
+} tw_status;
+
+/* Hyper-parameters of one flow (model_configs.py:51-76, custom_attention_encoder.py:126-137,
+ * transformer_block.py:11-15).  kernel variant: n_heads = len(lengthscales), value_dim = d_model. */
+typedef struct {
+  int32_t variant;      /* 0 = kernel (custom_attention_transformer_nvp), 1 = dense (transformer_nvp) */
+  int32_t n_coupling;   /* 8 */
+  int32_t n_layers;     /* 3 encoder layers per net */
+  int32_t d_model;      /* 128 */
+  int32_t d_ff;         /* 2048 */
+  int32_t d_hidden;     /* 256: the single hidden layer of in_mlp / out_mlp */
+  int32_t d_emb;        /* 32 */
+  int32_t n_heads;      /* 6 (kernel) / 8 (dense) */
+  int32_t d_rff;        /* dense only: RFF encoding dims (0 in transformer_nvp.yaml) */
+  int32_t n_elements;   /* 5 = len(ELEMENT_VOCAB) */
+  int32_t pos_mod2;     /* position_layer_index_mod_2 */
+  int32_t displacement; /* use_displacement_as_target */
+  int32_t ignore_cond_velocity;
+  int32_t normalise;    /* normalise_kernel_values */
+  float ln_eps;         /* 1e-5 */
+} tw_flow_desc;
+
+const char* tw_last_error(void);
+int tw_abi_version(void);
+/* Number of gfx950 devices visible (0 on a CPU-only box; never fails). */
+int tw_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weights.  The host packs the reference state_dict (SURVEY.md section 8b names) into ONE flat fp32
+ * device buffer in the canonical order documented in DESIGN.md ("raw layout"):
+ *   embedding[n_elements,d_emb], lengthscales[n_heads] (kernel) , prior log-scales[2],
+ *   then for c in coupling layers, net in (scale, shift):  [dense: rff vectors[3,d_rff/2] once per c]
+ *     in_mlp.0.{w[d_hidden,d_in],b}, in_mlp.2.{w[d_model,d_hidden],b},
+ *     per layer: kernel: values_proj.w[H*d_model,d_model], out_projection.w[d_model,H*d_model]
+ *                dense : in_proj.{w[3d,d],b[3d]}, out_proj.{w[d,d],b[d]}
+ *                linear1.{w,b}, linear2.{w,b}, norm1.{w,b}, norm2.{w,b}
+ *     out_mlp.0.{w[d_hidden,d_model],b}, out_mlp.2.{w[3,d_hidden],b}
+ * tw_flow_raw_floats returns the total so the host can check its packing.
+ * ------------------------------------------------------------------------------------------- */
+int64_t tw_flow_raw_floats(const tw_flow_desc* desc);
+/* Size (floats) of the MFMA-fragment-ordered weight stream used by the fused kernel path
+ * (kernel variant only; 0 for dense). */
+int64_t tw_flow_packed_floats(const tw_flow_desc* desc);
+/* Builds the fused-path weight stream from the raw buffer on the device (folds
+ * W_o[:,h] @ W_v[h] per head in fp64, re-tiles every matrix into 16x16 MFMA A-fragments). */
+int tw_flow_pack(const tw_flow_desc* desc, const float* raw, float* packed, void* stream);
+
+/* Bytes of scratch the flow entry points need for n_rows conformations of n_atoms atoms. */
+int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_t n_atoms);
+
+/* Execution path selector for the flow entry points. */
+#define TW_PATH_AUTO 0   /* fused MFMA path where supported, else simple */
+#define TW_PATH_FUSED 1  /* fused f32-MFMA net-block kernel (kernel variant, n_atoms <= 64) */
+#define TW_PATH_SIMPLE 2 /* one plain HIP kernel per reference op (all variants) */
+
+/* ConditionalSequentialFlow.forward (modules/model_wrappers/flow.py:51-103) over
+ * NVPCouplingLayer.forward (modules/layers/nvp.py:22-183) with
+ * CustomAttentionTransformerCouplingLayer._get_scale_and_shift (modules/custom_transformer_nvp.py:44-93)
+ * or TransformerCouplingLayer (modules/transformer_nvp.py:58-97).
+ *   x_coords/x_velocs/atom_types/masked: [n_cond, n_atoms, ...] conditioning rows; row n of z uses
+ *   conditioning row n % n_cond (the reference's .repeat(S,1,1) tiling, flow.py:284-296).
+ *   z_coords/z_velocs [n_rows,n_atoms,3] and delta_logp [n_rows] are updated in place.
+ *   x_coords must already be centred (flow.py:156-157 / 261-262).  `packed` may be NULL for
+ *   TW_PATH_SIMPLE. */
+int tw_flow_pass(const tw_flow_desc* desc, const float* raw, const float* packed,
+                 const int32_t* atom_types, const float* x_coords, const float* x_velocs,
+                 const uint8_t* masked, int64_t n_cond, float* z_coords, float* z_velocs,
+                 float* delta_logp, int64_t n_rows, int32_t n_atoms, int32_t reverse, int32_t path,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ConditionalFlowDensityModel.log_likelihood (modules/model_wrappers/flow.py:131-215).
+ * All inputs [n_rows,n_atoms,(3)]; out_logp [n_rows]. */
+int tw_flow_log_likelihood(const tw_flow_desc* desc, const float* raw, const float* packed,
+                           const int32_t* atom_types, const float* x_coords, const float* x_velocs,
+                           const float* y_coords, const float* y_velocs, const uint8_t* masked,
+                           float* out_logp, int64_t n_rows, int32_t n_atoms, int32_t path,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ConditionalFlowDensityModel.conditional_sample_with_logp (flow.py:242-336) with the latent
+ * noise passed in: z_* [n_samples,n_cond,n_atoms,3] ALREADY multiplied by exp(prior log-scale)
+ * (the reference draws Normal(0,scale).rsample((S,)), coords first, flow.py:274-275).
+ * Outputs y_* [n_samples,n_cond,n_atoms,3], out_logp [n_samples,n_cond].  The reference's mask
+ * broadcast (flow.py:326) only works for n_cond == 1 or n_samples == 1; same restriction here. */
+int tw_flow_sample_with_logp(const tw_flow_desc* desc, const float* raw, const float* packed,
+                             const int32_t* atom_types, const float* x_coords,
+                             const float* x_velocs, const uint8_t* masked, const float* z_coords,
+                             const float* z_velocs, float* y_coords, float* y_velocs,
+                             float* out_logp, int64_t n_samples, int64_t n_cond, int32_t n_atoms,
+                             int32_t path, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* compute_kernel_attention_scores (modules/layers/kernel_attention.py:69-121):
+ * out [n_cond, n_heads, n_atoms, n_atoms].  use_mm != 0 selects torch.cdist's matmul
+ * formulation (the reference gets it for n_atoms > 25). */
+int tw_kernel_scores(const float* x_coords, const uint8_t* masked, const float* lengthscales,
+                     int32_t n_heads, int64_t n_cond, int32_t n_atoms, int32_t normalise,
+                     int32_t use_mm, float* out, void* stream);
+
+/* get_centre_of_mass (utils/molecule_utils.py:15-29): out_centred = x - masked mean,
+ * out_com [n_rows,3] (either output may be NULL). */
+int tw_centre(const float* x_coords, const uint8_t* masked, float* out_centred, float* out_com,
+              int64_t n_rows, int32_t n_atoms, void* stream);
+
+/* compute_kinetic_energy (utils/evaluation_utils.py:416-436):
+ * random_velocs ? 0.5*sum v^2 : 0.5*sum m v^2 / kbT.  masses [n_atoms]; out [n_rows]. */
+int tw_kinetic_energy(const float* velocs, const float* masses, int32_t random_velocs, float kbT,
+                      float* out, int64_t n_rows, int32_t n_atoms, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Potential energy: replaces OpenmmPotentialEnergyTorch.forward
+ * (utils/openmm/openmm_bridge.py:281-294 -> bgflow -> OpenMM Context.getState(getEnergy)) for a
+ * System built by simulation/md.py:128-187 (HarmonicBond, HarmonicAngle, PeriodicTorsion,
+ * Nonbonded CutoffNonPeriodic with reaction field, GBSAOBC).  Parameter tables are what
+ * system.getForces() exposes (INTEGRATION.md has the extractor).  Units nm / kJ/mol / e.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_atoms;
+  int32_t n_bonds;      /* bond_idx [n_bonds,2] int32,  bond_par [n_bonds,2] = (r0, k)          */
+  int32_t n_angles;     /* angle_idx [n_angles,3],      angle_par [n_angles,2] = (theta0, k)    */
+  int32_t n_torsions;   /* torsion_idx [n_torsions,4],  torsion_par [n_torsions,3] = (n, phase, k) */
+  int32_t n_exceptions; /* exc_idx [n_exceptions,2],    exc_par [n_exceptions,3] = (qq, sigma, eps); 1-2/1-3 have zeros */
+  int32_t has_gbsa;     /* GBSAOBCForce present */
+  double cutoff;        /* nonbondedCutoff (nm); <= 0 means NoCutoff */
+  double rf_dielectric; /* reaction-field dielectric (78.3 default; OpenMM uses 1.0 when GBSA is present) */
+  double solute_dielectric, solvent_dielectric; /* GBSA: 1.0 / 78.5 */
+  double surface_area_energy;                   /* GBSA ACE term coefficient, 2.25936 kJ/mol/nm^2 */
+  const int32_t* bond_idx;    const double* bond_par;
+  const int32_t* angle_idx;   const double* angle_par;
+  const int32_t* torsion_idx; const double* torsion_par;
+  const int32_t* exc_idx;     const double* exc_par;
+  const double* atom_par;     /* [n_atoms,5] = (charge, sigma, epsilon, gb_radius, gb_scale) */
+} tw_forcefield;
+
+/* coords [n_rows,n_atoms,3] fp32 (nm) -> out_energy [n_rows] fp64 kJ/mol (fp64 like the bridge's
+ * numpy round trip, openmm_bridge.py:206-221).  All tw_forcefield pointers are device pointers.
+ * out_terms, if not NULL, receives [n_rows,5] = bond, angle, torsion, nonbonded, gbsa
+ * (the decomposition of simulation/md.py:288-413). */
+int tw_amber_energy(const tw_forcefield* ff, const float* coords, double* out_energy,
+                    double* out_terms, int64_t n_rows, void* stream);
+
+/* The accept step of sample_with_model (utils/evaluation_utils.py:659-713) for one chain:
+ *   exp_ = e_pot_y/kbT(scaled by caller) ...: exponent[s] = energy[s] + p_xy[s] - p_yx[s];
+ *   p_acc = min(1, e^-exponent); accepted[s] = u[s] < p_acc; k = first accepted index (or S-1);
+ *   if any accepted: x <- y[k].  result (device, int32[4]) = {k_unclipped, any_accepted, 0, 0}.
+ * energy = (e_pot_y - e_pot_x) + (e_kin_y - e_kin_x) is formed by the caller.
+ * x_coords/x_velocs [n_atoms,3] are the chain state, updated in place. */
+int tw_mh_accept(const float* energy, const float* p_xy, const float* p_yx, const float* u,
+                 const float* y_coords, const float* y_velocs, float* x_coords, float* x_velocs,
+                 float* out_exponent, float* out_p_acc, uint8_t* out_accepted, int32_t* result,
+                 int64_t n_proposals, int32_t n_atoms, void* stream);
+
+/* check_symmetry_change (utils/chirality.py:40-80): sign of the triple product at each
+ * chirality centre vs reference_signs; out_changed [n_rows] uint8.  centres [n_centres,4] int32. */
+int tw_chirality_changed(const float* coords, const int32_t* centres, const float* reference_signs,
+                         int32_t n_centres, uint8_t* out_changed, int64_t n_rows, int32_t n_atoms,
+                         void* stream);
+
+/* Debug/inspection: run ONE net-block of the fused path and dump the activation after every
+ * stage (in_mlp, each encoder layer, out_mlp) as [n_rows,n_atoms,d] row-major floats.
+ * dump must hold (n_layers+1)*n_rows*n_atoms*d_model + n_rows*n_atoms*3 floats.  Tests only. */
+int tw_debug_netblock(const tw_flow_desc* desc, const float* raw, const float* packed,
+                      int32_t coupling, int32_t net, const int32_t* atom_types,
+                      const float* x_coords, const float* x_velocs, const uint8_t* masked,
+                      int64_t n_cond, const float* z_other, int64_t n_rows, int32_t n_atoms,
+                      int32_t path, float* dump, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIMEWARP_HIP_H */

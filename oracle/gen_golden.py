@@ -35,6 +35,10 @@ def import_reference():
         def __getattr__(self, k):
             if k.startswith("__"):
                 raise AttributeError(k)
+            if k[:1].isupper():  # something that may be used as a base class
+                c = type(k, (), {"__init__": lambda self, *a, **kw: None})
+                setattr(self, k, c)
+                return c
             m = _Stub(f"{self.__name__}.{k}")
             setattr(self, k, m)
             return m
@@ -42,7 +46,13 @@ def import_reference():
         def __call__(self, *a, **k):
             return None
 
-    for n in ("mdtraj", "pymol2", "torch.utils.tensorboard", "tensorboard"):
+    # third-party packages that are absent here and only imported at module scope by the files
+    # we need (utils/evaluation_utils.py:4,13-15,23 for the MH loop).  None
+    # of their functionality is exercised: the energy is passed to sample_with_model as a callable.
+    for n in ("mdtraj", "pymol2", "torch.utils.tensorboard", "tensorboard", "git", "git.types", "openmm",
+              "openmm.app", "openmm.unit", "bgflow", "bgflow.distribution", "bgflow.distribution.energy",
+              "bgflow.distribution.energy.openmm", "bgflow.distribution.energy.base", "bgflow.utils",
+              "bgflow.utils.types", "matplotlib", "matplotlib.pyplot"):
         sys.modules[n] = _Stub(n)
 
 
@@ -157,6 +167,130 @@ def padded_batch(g, B, V, lens):
     for b, n in enumerate(lens):
         mask[b, n:] = True
     return at, x_c, x_v, mask, y_c, y_v
+
+
+class SyntheticEnergy:
+    """E(x) = k * sum_atoms |x - x_ref|^2 + w * sum_{i<j} exp(-|xi - xj|^2) in kJ/mol, [n,1]; `.kbT`.
+    Stands in for OpenmmPotentialEnergyTorch (openmm_bridge.py:252-307) in the MH scenarios: the
+    loop only needs a callable with that contract.  Restated in oracle/mh_oracle.py."""
+
+    def __init__(self, x_ref, k=40.0, w=3.0, kbT=2.5):
+        self.x_ref, self.k, self.w, self.kbT = x_ref, k, w, kbT
+
+    def __call__(self, coords):
+        c = coords.reshape(-1, self.x_ref.shape[-2], 3)
+        e = self.k * ((c - self.x_ref) ** 2).sum(dim=(-1, -2))
+        d2 = ((c[:, :, None, :] - c[:, None, :, :]) ** 2).sum(-1)
+        iu = torch.triu_indices(c.shape[1], c.shape[1], offset=1)
+        e = e + self.w * torch.exp(-d2[:, iu[0], iu[1]]).sum(-1)
+        return e[:, None]
+
+
+def gen_mh_goldens(model):
+    """Run the REAL sample_with_model (utils/evaluation_utils.py:468-745) on CPU with the tiny
+    kernel model, a synthetic energy and recorded noise; store inputs, noise and all outputs."""
+    from timewarp.utils import evaluation_utils as eu
+    from timewarp.dataloader import DenseMolDynBatch
+    import timewarp.utils.evaluation_utils as eu_mod
+
+    V = 7
+    g = torch.Generator().manual_seed(77)
+    at = torch.randint(0, 5, (1, V), generator=g)
+    x0 = torch.randn(1, V, 3, generator=g) * 0.3
+    v0 = torch.randn(1, V, 3, generator=g)
+    mask = torch.zeros(1, V, dtype=torch.bool)
+    masses = torch.tensor([12.01, 1.008, 14.01, 16.0, 12.01, 1.008, 1.008])
+    batch = DenseMolDynBatch(
+        names=["tiny"], atom_types=at, adj_list=torch.zeros((0, 2), dtype=torch.int64),
+        edge_batch_idx=torch.zeros((0,), dtype=torch.int64), atom_coords=x0, atom_velocs=v0,
+        atom_forces=torch.zeros_like(x0), atom_coord_targets=x0, atom_veloc_targets=v0,
+        atom_force_targets=torch.zeros_like(x0), masked_elements=mask)
+    energy = SyntheticEnergy(x0.clone())
+    centres = torch.tensor([[0, 1, 2, 3], [4, 5, 6, 1]])
+    # make proposals small enough that some are accepted: shrink the prior and the last layers
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        model.coords_prior_log_scale.fill_(-3.0)
+        model.velocs_prior_log_scale.fill_(-1.0)
+        for k, v in model.state_dict().items():
+            if ".out_mlp._layers.2." in k:
+                v.mul_(0.05)
+    ref_signs = None
+    scenarios = {
+        "s10": dict(accept=True, num_proposal_steps=10, num_samples=25),
+        "s10_randv": dict(accept=True, num_proposal_steps=10, num_samples=25, random_velocs=True, resample_velocs=True),
+        "adaptive": dict(accept=True, num_proposal_steps=10, num_samples=30, adaptive_parallelism=True),
+        "noaccept_s1": dict(accept=False, num_proposal_steps=1, num_samples=6),
+        "chirality": dict(accept=True, num_proposal_steps=10, num_samples=20, chirality=True),
+        "rotate": dict(accept=True, num_proposal_steps=5, num_samples=12, rotate=True),
+        "init_random": dict(accept=True, num_proposal_steps=4, num_samples=8, initialize_randomly=True),
+    }
+    out = dict(atom_types=at.numpy(), x0=x0.numpy(), v0=v0.numpy(), masses=masses.numpy(), centres=centres.numpy())
+    out.update(np_sd(model.state_dict()))
+    for name, kw in scenarios.items():
+        kw = dict(kw)
+        rec = {"normal": [], "rand": [], "randn_like": [], "rot": []}
+        orig_rsample = torch.distributions.Normal.rsample
+        orig_rand, orig_randn_like = torch.rand, torch.randn_like
+        orig_rot = eu_mod.random_rotation_matrix
+
+        def rsample(self, shape=torch.Size()):
+            r = orig_rsample(self, shape)
+            rec["normal"].append(r.detach().numpy().copy().reshape(-1))
+            return r
+
+        def rand(*a, **k):
+            r = orig_rand(*a, **k)
+            rec["rand"].append(r.numpy().copy().reshape(-1))
+            return r
+
+        def randn_like(t, **k):
+            r = orig_randn_like(t, **k)
+            rec["randn_like"].append(r.numpy().copy().reshape(-1))
+            return r
+
+        def rot(device=None, dtype=None):
+            gq = torch.Generator().manual_seed(1000 + len(rec["rot"]))
+            q, r_ = torch.linalg.qr(torch.randn(3, 3, generator=gq, dtype=torch.float64))
+            q = q * torch.sign(torch.diagonal(r_))
+            if torch.det(q) < 0:
+                q[:, 0] = -q[:, 0]
+            q = q.to(dtype or torch.float32)
+            rec["rot"].append(q.numpy().copy().reshape(-1))
+            return q
+
+        chir = kw.pop("chirality", False)
+        extra = {}
+        if chir:
+            from timewarp.utils.chirality import compute_chirality_sign
+            extra = dict(chirality_centers=centres, reference_signs=compute_chirality_sign(x0, centres))
+            out[name + "/reference_signs"] = extra["reference_signs"].numpy()
+        torch.distributions.Normal.rsample = rsample
+        torch.rand, torch.randn_like = rand, randn_like
+        eu_mod.random_rotation_matrix = rot
+        try:
+            torch.manual_seed(4242)
+            coords, velocs, accepted, stats = eu.sample_with_model(
+                batch, model, torch.device("cpu"), energy, masses, disable_tqdm=True, **kw, **extra)
+        finally:
+            torch.distributions.Normal.rsample = orig_rsample
+            torch.rand, torch.randn_like = orig_rand, orig_randn_like
+            eu_mod.random_rotation_matrix = orig_rot
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros((0,), np.float32)
+        out[name + "/coords"], out[name + "/velocs"] = coords, velocs
+        out[name + "/accepted"] = np.array(accepted)
+        for f in ("acceptance_indicator", "acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin",
+                  "energies_pot_delta", "energies_kin_delta"):
+            out[f"{name}/stats_{f}"] = np.asarray(getattr(stats, f))
+        out[name + "/noise_normal"] = cat(rec["normal"])
+        out[name + "/noise_normal_sizes"] = np.array([len(a) for a in rec["normal"]])
+        out[name + "/noise_rand"] = cat(rec["rand"])
+        out[name + "/noise_rand_sizes"] = np.array([len(a) for a in rec["rand"]])
+        out[name + "/noise_randn_like"] = cat(rec["randn_like"])
+        out[name + "/noise_rot"] = cat(rec["rot"])
+        print("mh", name, "states", coords.shape[0], "accepted", accepted, "iters", len(rec["rand"]))
+    model.load_state_dict(sd)
+    np.savez_compressed(os.path.join(OUT, "mh_tiny.npz"), **out)
 
 
 def main():
@@ -301,6 +435,9 @@ def main():
     d.update(np_sd(em.state_dict()))
     np.savez_compressed(os.path.join(OUT, "euler_maruyama.npz"), **d)
     print("euler_maruyama ok")
+
+    # ---- (7) the MH loop itself: the reference's sample_with_model driven with a synthetic energy --
+    gen_mh_goldens(tiny)
 
     # ---- (6) alanine-dipeptide topology as data (22 atoms) ---------------------------------------
     np.savez_compressed(os.path.join(OUT, "ad_topology.npz"), coords_nm=ad_x.numpy(), atom_types=ad_t.numpy(),

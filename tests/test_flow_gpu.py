@@ -1,0 +1,180 @@
+"""Parity of the HIP flow (through the C ABI) against the committed reference vectors and the
+oracle.  Bar: 1e-5 relative (north-star) on sampled coordinates, velocities and log-densities."""
+import pytest
+import torch
+
+from oracle import flow_oracle as fo
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+SIMPLE, FUSED = 2, 1
+
+
+def test_library_sees_gpu():
+    from timewarp_amd import _lib
+
+    assert _lib.load().tw_device_count() >= 1
+    assert torch.cuda.is_available()
+
+
+def test_scores_kernel_vs_oracle():
+    import ctypes as C
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    for V in (7, 22, 60):
+        B = 5
+        x = torch.randn(B, V, 3, generator=g) * 0.4
+        mask = torch.zeros(B, V, dtype=torch.bool)
+        mask[1, V - 2:] = True
+        mask[3, V // 2:] = True
+        ls = torch.tensor([0.1, 0.2, 0.5, 0.7, 1.0, 1.2])
+        ref = fo.kernel_scores(x, mask, ls)
+        out = torch.empty(B, 6, V, V, device="cuda")
+        xd, md, ld = x.cuda(), mask.to(torch.uint8).cuda(), ls.cuda()
+        _lib.check(lib.tw_kernel_scores(xd.data_ptr(), md.data_ptr(), ld.data_ptr(), 6, B, V, 1, int(V > 25),
+                                        out.data_ptr(), None), "tw_kernel_scores")
+        assert H.rel_err(out.cpu(), ref) < (2e-5 if V > 25 else 2e-6), V  # V>25: cdist matmul cancellation noise
+
+
+def test_tiny_kernel_simple_path():
+    d, sd = H.load("kernel_tiny")
+    m = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2,
+                          lengthscales=(0.1, 0.5, 1.2), path=SIMPLE)
+    with torch.no_grad():
+        m.coords_prior_log_scale.fill_(-0.3)
+        m.velocs_prior_log_scale.fill_(0.2)
+    m.load_state_dict(sd)
+    H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
+    H.assert_case_close(H.run_model_case(m, d, "b1_"), d, "b1_", tol=TOL)
+
+
+def test_tiny_dense_simple_path():
+    d, sd = H.load("dense_tiny")
+    m = H.tw_dense_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2, n_head=2, rff_dim=4,
+                         path=SIMPLE)
+    H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
+    H.assert_case_close(H.run_model_case(m, d, "b1_"), d, "b1_", tol=TOL)
+
+
+@pytest.mark.parametrize("path", [SIMPLE, FUSED])
+def test_netblock_stages_vs_reference_trace(path):
+    """Every stage of one coupling net (first net of the reverse pass) against the reference's
+    own intermediate activations."""
+    d, _ = H.load("kernel_full_ad")
+    sd = H.full_kernel_sd()
+    m = H.tw_kernel_model(sd, path=path)
+    xc = d["x_coords"] - fo.centre_of_mass(d["x_coords"], d["masked"])
+    S = 2
+    acts, out = m.debug_netblock(7, 0, d["atom_types"].cuda(), xc.cuda(), d["x_velocs"].cuda(), d["masked"].cuda(),
+                                 d["z_coords"][:S, 0].cuda(), path)
+    names = ["tr_in_mlp", "tr_enc0", "tr_enc1", "tr_enc2"]
+    for i, n in enumerate(names):
+        e = H.rel_err(acts[i].cpu(), d[n])
+        assert e < TOL, (n, e)
+    e = H.rel_err(out.cpu(), d["tr_out_mlp"])
+    assert e < TOL, ("out_mlp", e)
+
+
+@pytest.mark.parametrize("path", [SIMPLE, FUSED])
+@pytest.mark.parametrize("name,calibrated", [("kernel_full_ad", False), ("kernel_full_ad_calibrated", True)])
+def test_full_kernel_ad_golden(path, name, calibrated):
+    d, _ = H.load(name)
+    m = H.tw_kernel_model(H.full_kernel_sd(calibrated), path=path)
+    H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
+
+
+@pytest.mark.parametrize("path", [SIMPLE, FUSED])
+def test_full_kernel_v60_golden(path):
+    """60 atoms: 4-tile waves in the fused kernel and torch.cdist's matmul branch for the scores."""
+    d, _ = H.load("kernel_full_v60")
+    m = H.tw_kernel_model(H.full_kernel_sd(), path=path)
+    H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5)
+
+
+def test_full_dense_ad_golden():
+    d, _ = H.load("dense_full_ad")
+    m = H.tw_dense_model(H.full_dense_sd(), path=SIMPLE)
+    H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
+
+
+@pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25])])
+def test_fused_batched_padding_vs_oracle(V, lens):
+    """Ragged batch (different conditioning state per row, padded atoms) on the fused path against
+    the oracle: pins the per-row score fragments and the mask handling
+    (reference property test: tests/test_batching.py:132-177)."""
+    sd = H.full_kernel_sd()
+    g = torch.Generator().manual_seed(100 + V)
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.3
+    x_v = torch.randn(B, V, 3, generator=g) * 0.5
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+    y_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    for path in (FUSED, SIMPLE):
+        m = H.tw_kernel_model(sd, path=path)
+        out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                               y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
+        assert H.rel_err(out, ref) < TOL, (path, H.rel_err(out, ref))
+        # batched == per item (tests/test_batching.py)
+        one = m.log_likelihood(atom_types=at[1:2].cuda(), x_coords=x_c[1:2].cuda(), x_velocs=x_v[1:2].cuda(),
+                               y_coords=y_c[1:2].cuda(), y_velocs=y_v[1:2].cuda(), adj_list=None, edge_batch_idx=None,
+                               masked_elements=mask[1:2].cuda()).cpu()
+        assert abs(float(one[0] - out[1])) < 1e-4 * max(1.0, abs(float(out[1])))
+
+
+def test_roundtrip_full_size_S1000():
+    """BASELINE size (S=1000 proposals, 22 atoms): size-independent property -- pushing the
+    sampled (y, v) back through the density direction recovers log p to fp32 round-off."""
+    m = H.tw_kernel_model(H.full_kernel_sd(calibrated=True), path=FUSED)
+    d, _ = H.load("kernel_full_ad_calibrated")
+    S = 1000
+    g = torch.Generator().manual_seed(5)
+    sd = H.full_kernel_sd(calibrated=True)
+    zc, zv = fo.draw_latents(sd, S, (1, 22, 3), g)
+    at, xc, xv, mk = d["atom_types"].cuda(), d["x_coords"].cuda(), d["x_velocs"].cuda(), d["masked"].cuda()
+    yc, yv, lp = m.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None,
+                                                edge_batch_idx=None, masked_elements=mk, num_samples=S,
+                                                z_coords=zc.cuda(), z_velocs=zv.cuda())
+    ll = m.log_likelihood(atom_types=at.repeat(S, 1), x_coords=xc.repeat(S, 1, 1), x_velocs=xv.repeat(S, 1, 1),
+                          y_coords=yc.squeeze(1), y_velocs=yv.squeeze(1), adj_list=None, edge_batch_idx=None,
+                          masked_elements=mk.repeat(S, 1))
+    assert torch.isfinite(lp).all() and torch.isfinite(ll).all()
+    assert H.rel_err(ll.cpu(), lp.squeeze(1).cpu()) < TOL
+    # first 8 rows against the oracle
+    ryc, ryv, rlp = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, d["atom_types"], d["x_coords"],
+                                                    d["x_velocs"], d["masked"], zc[:8], zv[:8])
+    assert H.rel_err(yc[:8].cpu(), ryc) < TOL and H.rel_err(lp[:8].cpu(), rlp) < TOL
+
+
+def test_fused_equals_simple_large_batch():
+    sd = H.full_kernel_sd()
+    d, _ = H.load("kernel_full_ad")
+    S = 130  # not a multiple of the molecules-per-wave: exercises the partial last block
+    g = torch.Generator().manual_seed(9)
+    zc, zv = fo.draw_latents(sd, S, (1, 22, 3), g)
+    outs = []
+    for path in (FUSED, SIMPLE):
+        m = H.tw_kernel_model(sd, path=path)
+        outs.append(m.conditional_sample_with_logp(
+            atom_types=d["atom_types"].cuda(), x_coords=d["x_coords"].cuda(), x_velocs=d["x_velocs"].cuda(),
+            adj_list=None, edge_batch_idx=None, masked_elements=d["masked"].cuda(), num_samples=S,
+            z_coords=zc.cuda(), z_velocs=zv.cuda()))
+    for a, b in zip(*outs):
+        assert H.rel_err(a.cpu(), b.cpu()) < TOL
+
+
+def test_no_cpu_fallback():
+    m = H.tw_kernel_model(H.full_kernel_sd(), device="cpu")
+    d, _ = H.load("kernel_full_ad")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.log_likelihood(atom_types=d["atom_types"], x_coords=d["x_coords"], x_velocs=d["x_velocs"],
+                         y_coords=d["y_coords"], y_velocs=d["y_velocs"], adj_list=None, edge_batch_idx=None,
+                         masked_elements=d["masked"])

@@ -1,0 +1,270 @@
+// extern "C" entry points of libtimewarp_hip.so (see include/timewarp_hip.h).
+#include "tw_common.h"
+
+namespace tw {
+const char* last_error();
+int launch_prior_logp(const float* zc, const float* zv, const uint8_t* masked, int64_t n_cond, const float* prior,
+                      const float* delta, float sign, float* out, int64_t n_rows, int V, hipStream_t s);
+int launch_uncentre_add(const float* xc, const float* com, const float* resid, int64_t n_cond, float* y, int V,
+                        int displacement, int64_t n_rows, hipStream_t s);
+int launch_sub(const float* a, const float* b, float* o, int64_t total, hipStream_t s);
+int launch_kinetic(const float* v, const float* masses, int random_velocs, float kbT, float* out, int64_t n, int V,
+                   hipStream_t s);
+int launch_mh_accept(const float* energy, const float* p_xy, const float* p_yx, const float* u, const float* yc,
+                     const float* yv, float* xc, float* xv, float* out_exp, float* out_pacc, uint8_t* out_acc,
+                     int32_t* result, int64_t S, int V, hipStream_t s);
+int launch_chirality(const float* coords, const int32_t* centres, const float* ref, int n_centres, uint8_t* changed,
+                     int64_t n_rows, int V, hipStream_t s);
+int amber_energy(const tw_forcefield* ff, const float* coords, double* out, double* terms, int64_t n, hipStream_t s);
+}  // namespace tw
+
+using namespace tw;
+
+static int check_desc(const tw_flow_desc* d) {
+  TW_REQUIRE(d != nullptr, "desc is NULL");
+  TW_REQUIRE(d->variant == 0 || d->variant == 1, "unknown variant %d", d->variant);
+  TW_REQUIRE(d->n_coupling > 0 && d->n_layers > 0 && d->d_model > 0 && d->d_ff > 0 && d->d_hidden > 0 &&
+                 d->d_emb > 0 && d->n_heads > 0 && d->n_elements > 0,
+             "non-positive dimension in tw_flow_desc");
+  TW_REQUIRE(d->variant == 0 || d->d_model % d->n_heads == 0, "d_model %% n_heads != 0");
+  TW_REQUIRE(d->d_rff >= 0 && d->d_rff % 2 == 0, "d_rff must be even");
+  return TW_OK;
+}
+
+static bool fused_supported(const tw_flow_desc& d, int n_atoms) {
+  FusedGeom g;
+  return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb % 4 == 0 &&
+         d.d_emb + 9 <= 48 && fused_geom(n_atoms, &g);
+}
+
+static int resolve_path(const tw_flow_desc& d, int n_atoms, int path, const float* packed, int* out) {
+  if (path == TW_PATH_AUTO) path = (packed && fused_supported(d, n_atoms)) ? TW_PATH_FUSED : TW_PATH_SIMPLE;
+  if (path == TW_PATH_FUSED) {
+    TW_REQUIRE(fused_supported(d, n_atoms), "fused path unsupported for this config (variant=%d d_model=%d n_atoms=%d)",
+               d.variant, d.d_model, n_atoms);
+    TW_REQUIRE(packed != nullptr, "fused path needs the packed weight stream (tw_flow_pack)");
+  } else {
+    TW_REQUIRE(path == TW_PATH_SIMPLE, "unknown path %d", path);
+  }
+  *out = path;
+  return TW_OK;
+}
+
+extern "C" {
+
+const char* tw_last_error(void) { return tw::last_error(); }
+int tw_abi_version(void) { return TW_ABI_VERSION; }
+
+int tw_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int64_t tw_flow_raw_floats(const tw_flow_desc* desc) {
+  if (check_desc(desc)) return -1;
+  return raw_layout(*desc).total;
+}
+
+int64_t tw_flow_packed_floats(const tw_flow_desc* desc) {
+  if (check_desc(desc)) return -1;
+  if (!fused_supported(*desc, 22)) return 0;
+  return packed_layout(*desc).total;
+}
+
+int tw_flow_pack(const tw_flow_desc* desc, const float* raw, float* packed, void* stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  TW_REQUIRE(fused_supported(*desc, 22), "fused path unsupported for this config");
+  TW_REQUIRE(raw && packed, "NULL buffer");
+  return pack_weights(*desc, raw, packed, (hipStream_t)stream);
+}
+
+int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_t n_atoms) {
+  if (check_desc(desc) || n_rows < 0 || n_atoms <= 0) return -1;
+  const int64_t rows = n_rows > 0 ? n_rows : 1;
+  int64_t a = simple_workspace_bytes(*desc, rows, n_atoms);
+  int64_t b = fused_supported(*desc, n_atoms) ? fused_workspace_bytes(*desc, rows, n_atoms) : 0;
+  // the likelihood / sampling entry points carve their own temporaries in front of the flow scratch
+  const int64_t extra = 6 * ((rows * n_atoms * 3 * 4 + 255) / 256 * 256) + 4 * ((rows * 4 + 255) / 256 * 256);
+  return (a > b ? a : b) + extra;
+}
+
+int tw_flow_pass(const tw_flow_desc* desc, const float* raw, const float* packed, const int32_t* atom_types,
+                 const float* x_coords, const float* x_velocs, const uint8_t* masked, int64_t n_cond, float* z_coords,
+                 float* z_velocs, float* delta_logp, int64_t n_rows, int32_t n_atoms, int32_t reverse, int32_t path,
+                 void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  TW_REQUIRE(n_rows >= 0 && n_atoms > 0 && n_cond > 0, "bad sizes");
+  TW_REQUIRE(n_rows % n_cond == 0, "n_rows (%lld) must be a multiple of n_cond (%lld)", (long long)n_rows,
+             (long long)n_cond);
+  if (n_rows == 0) return TW_OK;
+  TW_REQUIRE(raw && atom_types && x_coords && x_velocs && masked && z_coords && z_velocs && delta_logp && workspace,
+             "NULL pointer argument");
+  int p;
+  if ((rc = resolve_path(*desc, n_atoms, path, packed, &p))) return rc;
+  FlowArgs a{desc, raw, packed, atom_types, x_coords, x_velocs, masked, n_cond, z_coords, z_velocs,
+             delta_logp, n_rows, n_atoms, reverse, workspace, workspace_bytes, (hipStream_t)stream};
+  return p == TW_PATH_FUSED ? flow_pass_fused(a) : flow_pass_simple(a);
+}
+
+static char* carve(char*& p, int64_t bytes) {
+  char* r = p;
+  p += (bytes + 255) / 256 * 256;
+  return r;
+}
+
+int tw_flow_log_likelihood(const tw_flow_desc* desc, const float* raw, const float* packed, const int32_t* atom_types,
+                           const float* x_coords, const float* x_velocs, const float* y_coords, const float* y_velocs,
+                           const uint8_t* masked, float* out_logp, int64_t n_rows, int32_t n_atoms, int32_t path,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  TW_REQUIRE(n_rows >= 0 && n_atoms > 0, "bad sizes");
+  if (n_rows == 0) return TW_OK;
+  TW_REQUIRE(raw && atom_types && x_coords && x_velocs && y_coords && y_velocs && masked && out_logp && workspace,
+             "NULL pointer argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t el = n_rows * n_atoms * 3;
+  char* p = (char*)workspace;
+  float* xc = (float*)carve(p, el * 4);
+  float* zc = (float*)carve(p, el * 4);
+  float* zv = (float*)carve(p, el * 4);
+  float* xv0 = (float*)carve(p, el * 4);
+  float* delta = (float*)carve(p, n_rows * 4);
+  const int64_t used = p - (char*)workspace;
+  TW_REQUIRE(used < workspace_bytes, "workspace too small");
+  // flow.py:148-157: residual target, centred conditioning positions
+  if (desc->displacement) {
+    if ((rc = launch_sub(y_coords, x_coords, zc, el, s))) return rc;
+  } else {
+    TW_HIP_CHECK(hipMemcpyAsync(zc, y_coords, el * 4, hipMemcpyDeviceToDevice, s));
+  }
+  TW_HIP_CHECK(hipMemcpyAsync(zv, y_velocs, el * 4, hipMemcpyDeviceToDevice, s));
+  if ((rc = launch_centre(x_coords, masked, xc, nullptr, n_rows, n_atoms, s))) return rc;
+  const float* xv = x_velocs;
+  if (desc->ignore_cond_velocity) {
+    TW_HIP_CHECK(hipMemsetAsync(xv0, 0, el * 4, s));
+    xv = xv0;
+  }
+  TW_HIP_CHECK(hipMemsetAsync(delta, 0, n_rows * 4, s));
+  if ((rc = tw_flow_pass(desc, raw, packed, atom_types, xc, xv, masked, n_rows, zc, zv, delta, n_rows, n_atoms, 0, path,
+                         p, workspace_bytes - used, stream)))
+    return rc;
+  const RawLayout L = raw_layout(*desc);
+  // flow.py:191-203: log p(y) = log N(z) - delta_logp
+  return launch_prior_logp(zc, zv, masked, n_rows, raw + L.prior, delta, -1.f, out_logp, n_rows, n_atoms, s);
+}
+
+int tw_flow_sample_with_logp(const tw_flow_desc* desc, const float* raw, const float* packed, const int32_t* atom_types,
+                             const float* x_coords, const float* x_velocs, const uint8_t* masked, const float* z_coords,
+                             const float* z_velocs, float* y_coords, float* y_velocs, float* out_logp, int64_t n_samples,
+                             int64_t n_cond, int32_t n_atoms, int32_t path, void* workspace, int64_t workspace_bytes,
+                             void* stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  TW_REQUIRE(n_samples >= 0 && n_cond > 0 && n_atoms > 0, "bad sizes");
+  TW_REQUIRE(n_cond == 1 || n_samples == 1,
+             "the reference's mask broadcast (flow.py:326) needs n_cond == 1 or n_samples == 1");
+  const int64_t n_rows = n_samples * n_cond;
+  if (n_rows == 0) return TW_OK;
+  TW_REQUIRE(raw && atom_types && x_coords && x_velocs && masked && z_coords && z_velocs && y_coords && y_velocs &&
+                 out_logp && workspace,
+             "NULL pointer argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t el = n_rows * n_atoms * 3, elc = n_cond * n_atoms * 3;
+  char* p = (char*)workspace;
+  float* xc = (float*)carve(p, elc * 4);
+  float* com = (float*)carve(p, n_cond * 3 * 4);
+  float* rc_ = (float*)carve(p, el * 4);
+  float* xv0 = (float*)carve(p, elc * 4);
+  float* delta = (float*)carve(p, n_rows * 4);
+  const int64_t used = p - (char*)workspace;
+  TW_REQUIRE(used < workspace_bytes, "workspace too small");
+  if ((rc = launch_centre(x_coords, masked, xc, com, n_cond, n_atoms, s))) return rc;
+  const float* xv = x_velocs;
+  if (desc->ignore_cond_velocity) {
+    TW_HIP_CHECK(hipMemsetAsync(xv0, 0, elc * 4, s));
+    xv = xv0;
+  }
+  // the flow updates in place: residual coords go through a scratch copy, velocities straight into y_velocs
+  TW_HIP_CHECK(hipMemcpyAsync(rc_, z_coords, el * 4, hipMemcpyDeviceToDevice, s));
+  TW_HIP_CHECK(hipMemcpyAsync(y_velocs, z_velocs, el * 4, hipMemcpyDeviceToDevice, s));
+  TW_HIP_CHECK(hipMemsetAsync(delta, 0, n_rows * 4, s));
+  if ((rc = tw_flow_pass(desc, raw, packed, atom_types, xc, xv, masked, n_cond, rc_, y_velocs, delta, n_rows, n_atoms, 1,
+                         path, p, workspace_bytes - used, stream)))
+    return rc;
+  const RawLayout L = raw_layout(*desc);
+  // flow.py:322-334: log p(y|x) = log N(z) + delta_logp, with z the INPUT latents
+  if ((rc = launch_prior_logp(z_coords, z_velocs, masked, n_cond, raw + L.prior, delta, +1.f, out_logp, n_rows, n_atoms, s)))
+    return rc;
+  // flow.py:303-310: y = (x_centred + com) + residual
+  return launch_uncentre_add(xc, com, rc_, n_cond, y_coords, n_atoms, desc->displacement, n_rows, s);
+}
+
+int tw_kernel_scores(const float* x_coords, const uint8_t* masked, const float* lengthscales, int32_t n_heads,
+                     int64_t n_cond, int32_t n_atoms, int32_t normalise, int32_t use_mm, float* out, void* stream) {
+  TW_REQUIRE(x_coords && masked && lengthscales && out, "NULL pointer argument");
+  TW_REQUIRE(n_heads > 0 && n_cond >= 0 && n_atoms > 0, "bad sizes");
+  TW_REQUIRE((size_t)(3 * n_atoms + n_atoms * n_atoms) * 4 <= 64 * 1024, "n_atoms too large for the scores kernel");
+  return launch_scores(x_coords, masked, lengthscales, n_heads, n_cond, n_atoms, normalise, use_mm, out,
+                       (hipStream_t)stream);
+}
+
+int tw_centre(const float* x_coords, const uint8_t* masked, float* out_centred, float* out_com, int64_t n_rows,
+              int32_t n_atoms, void* stream) {
+  TW_REQUIRE(x_coords && masked, "NULL pointer argument");
+  return launch_centre(x_coords, masked, out_centred, out_com, n_rows, n_atoms, (hipStream_t)stream);
+}
+
+int tw_kinetic_energy(const float* velocs, const float* masses, int32_t random_velocs, float kbT, float* out,
+                      int64_t n_rows, int32_t n_atoms, void* stream) {
+  TW_REQUIRE(velocs && out && (random_velocs || masses), "NULL pointer argument");
+  TW_REQUIRE(random_velocs || kbT > 0.f, "kbT required unless random_velocs");
+  return launch_kinetic(velocs, masses, random_velocs, kbT, out, n_rows, n_atoms, (hipStream_t)stream);
+}
+
+int tw_amber_energy(const tw_forcefield* ff, const float* coords, double* out_energy, double* out_terms, int64_t n_rows,
+                    void* stream) {
+  TW_REQUIRE(ff && coords && out_energy, "NULL pointer argument");
+  TW_REQUIRE(ff->n_atoms > 0 && ff->n_atoms <= 256, "n_atoms must be in 1..256");
+  return amber_energy(ff, coords, out_energy, out_terms, n_rows, (hipStream_t)stream);
+}
+
+int tw_mh_accept(const float* energy, const float* p_xy, const float* p_yx, const float* u, const float* y_coords,
+                 const float* y_velocs, float* x_coords, float* x_velocs, float* out_exponent, float* out_p_acc,
+                 uint8_t* out_accepted, int32_t* result, int64_t n_proposals, int32_t n_atoms, void* stream) {
+  TW_REQUIRE(energy && p_xy && p_yx && u && y_coords && y_velocs && x_coords && x_velocs && out_exponent && out_p_acc &&
+                 out_accepted && result,
+             "NULL pointer argument");
+  TW_REQUIRE(n_proposals > 0 && n_proposals < (1LL << 30), "bad n_proposals");
+  return launch_mh_accept(energy, p_xy, p_yx, u, y_coords, y_velocs, x_coords, x_velocs, out_exponent, out_p_acc,
+                          out_accepted, result, n_proposals, n_atoms, (hipStream_t)stream);
+}
+
+int tw_chirality_changed(const float* coords, const int32_t* centres, const float* reference_signs, int32_t n_centres,
+                         uint8_t* out_changed, int64_t n_rows, int32_t n_atoms, void* stream) {
+  TW_REQUIRE(coords && out_changed && (n_centres == 0 || (centres && reference_signs)), "NULL pointer argument");
+  return launch_chirality(coords, centres, reference_signs, n_centres, out_changed, n_rows, n_atoms,
+                          (hipStream_t)stream);
+}
+
+int tw_debug_netblock(const tw_flow_desc* desc, const float* raw, const float* packed, int32_t coupling, int32_t net,
+                      const int32_t* atom_types, const float* x_coords, const float* x_velocs, const uint8_t* masked,
+                      int64_t n_cond, const float* z_other, int64_t n_rows, int32_t n_atoms, int32_t path, float* dump,
+                      void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  TW_REQUIRE(raw && atom_types && x_coords && x_velocs && masked && z_other && dump && workspace, "NULL pointer argument");
+  TW_REQUIRE(coupling >= 0 && coupling < desc->n_coupling && (net == 0 || net == 1), "bad coupling/net index");
+  TW_REQUIRE(n_rows > 0 && n_cond > 0 && n_rows % n_cond == 0, "bad sizes");
+  int p;
+  if ((rc = resolve_path(*desc, n_atoms, path, packed, &p))) return rc;
+  FlowArgs a{desc, raw, packed, atom_types, x_coords, x_velocs, masked, n_cond, nullptr, nullptr,
+             nullptr, n_rows, n_atoms, 0, workspace, workspace_bytes, (hipStream_t)stream};
+  return p == TW_PATH_FUSED ? debug_netblock_fused(a, coupling, net, z_other, dump)
+                            : debug_netblock_simple(a, coupling, net, z_other, dump);
+}
+
+}  // extern "C"

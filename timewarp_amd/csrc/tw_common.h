@@ -1,0 +1,123 @@
+// Internal declarations shared by the HIP translation units of libtimewarp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/timewarp_hip.h"
+
+namespace tw {
+
+void set_error(const char* fmt, ...);
+
+#define TW_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      tw::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return TW_ERR_HIP;                                                                \
+    }                                                                                   \
+  } while (0)
+
+#define TW_LAUNCH_CHECK() TW_HIP_CHECK(hipGetLastError())
+
+#define TW_REQUIRE(cond, ...)        \
+  do {                               \
+    if (!(cond)) {                   \
+      tw::set_error(__VA_ARGS__);    \
+      return TW_ERR_INVALID;         \
+    }                                \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// Raw (canonical row-major) weight layout -- mirrored by timewarp_amd/weights.py
+// ------------------------------------------------------------------------------------------
+struct LayerOff {  // offsets relative to the start of one encoder layer
+  int64_t wv, wo;                     // kernel: values_proj.w [H*d,d], out_projection.w [d,H*d]
+  int64_t in_w, in_b, out_w, out_b;   // dense : in_proj [3d,d],[3d]; out_proj [d,d],[d]
+  int64_t w1, b1, w2, b2, n1w, n1b, n2w, n2b;
+  int64_t size;
+};
+
+struct NetOff {  // offsets relative to the start of one net (scale_transformer / shift_transformer)
+  int64_t in0_w, in0_b, in2_w, in2_b;
+  int64_t layers;  // first encoder layer
+  int64_t out0_w, out0_b, out2_w, out2_b;
+  int64_t size;
+};
+
+struct RawLayout {
+  int d_in;
+  int64_t emb, lengthscales, prior;  // prior: [coords_log_scale, velocs_log_scale]
+  int64_t chain;                     // first coupling layer
+  int64_t rff;                       // relative to coupling start (dense; [3, d_rff/2])
+  int64_t nets;                      // relative to coupling start: scale net, then shift net
+  int64_t coupling_size;
+  LayerOff layer;
+  NetOff net;
+  int64_t total;
+};
+
+RawLayout raw_layout(const tw_flow_desc& d);
+
+inline int64_t net_base(const RawLayout& L, int c, int net) {
+  return L.chain + (int64_t)c * L.coupling_size + L.nets + (int64_t)net * L.net.size;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused-path weight stream (tw_netblock.hip)
+// ------------------------------------------------------------------------------------------
+struct PackedLayout {
+  // per net: a stream of 1 KiB tiles in consumption order, then small fp32 side arrays
+  int64_t tiles_per_net;       // number of 256-float tiles
+  int64_t side_per_net;        // floats: biases, LayerNorm weights
+  int64_t net_stride;          // floats (tiles*256 + side, padded to 256)
+  int64_t total;
+};
+PackedLayout packed_layout(const tw_flow_desc& d);
+
+// geometry of the fused kernel for a given atom count
+struct FusedGeom {
+  int nt;        // 16-token tiles per wave (3 or 4)
+  int mpw;       // molecules per wave
+  int tile_mask; // bit (jt*nt+mt) set when score tile (jt,mt) can be non-zero
+};
+bool fused_geom(int n_atoms, FusedGeom* g);
+
+// launchers implemented in the .hip files ----------------------------------------------------
+int launch_scores(const float* x, const uint8_t* masked, const float* ls, int H, int64_t B, int V,
+                  int normalise, int use_mm, float* out, hipStream_t s);
+int launch_centre(const float* x, const uint8_t* masked, float* xc, float* com, int64_t n, int V,
+                  hipStream_t s);
+
+struct FlowArgs {
+  const tw_flow_desc* desc;
+  const float* raw;
+  const float* packed;
+  const int32_t* atom_types;
+  const float* x_coords;  // centred
+  const float* x_velocs;
+  const uint8_t* masked;
+  int64_t n_cond;
+  float* z_coords;
+  float* z_velocs;
+  float* delta_logp;
+  int64_t n_rows;
+  int n_atoms;
+  int reverse;
+  void* ws;
+  int64_t ws_bytes;
+  hipStream_t stream;
+};
+int flow_pass_simple(const FlowArgs& a);
+int flow_pass_fused(const FlowArgs& a);
+int64_t simple_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms);
+int64_t fused_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms);
+int launch_coupling(const float* s_raw, const float* t, const uint8_t* masked, int64_t n_cond,
+                    float* z, float* delta_logp, int64_t n_rows, int V, int reverse, hipStream_t s);
+int pack_weights(const tw_flow_desc& d, const float* raw, float* packed, hipStream_t s);
+int debug_netblock_simple(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
+int debug_netblock_fused(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
+
+}  // namespace tw

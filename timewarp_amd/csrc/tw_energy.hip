@@ -1,0 +1,207 @@
+// AMBER-style potential energy on the GPU: one wave per conformation, fp64 arithmetic.
+//
+// Replaces the OpenMM call chain behind OpenmmPotentialEnergyTorch.forward
+// (utils/openmm/openmm_bridge.py:281-294 -> bgflow -> Context.getState(getEnergy=True)) for Systems
+// built by simulation/md.py:128-187.  OpenMM 7.7 itself is a third-party dependency that is not
+// vendored in the reference; the functional forms below restate its published Reference-platform
+// algorithms (HarmonicBondForce, HarmonicAngleForce, PeriodicTorsionForce, NonbondedForce with
+// CutoffNonPeriodic + reaction field, GBSAOBCForce = OBC-II + ACE surface term).  The same maths is
+// restated in plain C in oracle/energy_oracle.c, which is what the parity tests compare against.
+#include "tw_common.h"
+
+namespace tw {
+
+#define TW_ONE_4PI_EPS0 138.935456  // OpenMM SimTKOpenMMRealType.h (kJ nm / (mol e^2))
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff, const float* __restrict__ coords,
+                                                           double* __restrict__ out, double* __restrict__ terms) {
+  extern __shared__ __attribute__((aligned(16))) double smd[];
+  const int V = ff.n_atoms;
+  double* x = smd;             // [V*3]
+  double* born = x + 3 * V;    // [V]
+  uint8_t* excl = (uint8_t*)(born + V);  // [V*V]
+  const int64_t n = blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 3 * V; i += 64) x[i] = (double)coords[n * 3 * V + i];
+  for (int i = lane; i < V * V; i += 64) excl[i] = 0;
+  __syncthreads();
+  for (int e = lane; e < ff.n_exceptions; e += 64) {
+    const int i = ff.exc_idx[2 * e], j = ff.exc_idx[2 * e + 1];
+    excl[i * V + j] = 1;
+    excl[j * V + i] = 1;
+  }
+  __syncthreads();
+
+  double e_bond = 0, e_angle = 0, e_tors = 0, e_nb = 0, e_gb = 0;
+
+  // HarmonicBondForce: 1/2 k (r - r0)^2
+  for (int b = lane; b < ff.n_bonds; b += 64) {
+    const int i = ff.bond_idx[2 * b], j = ff.bond_idx[2 * b + 1];
+    const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    const double d = r - ff.bond_par[2 * b];
+    e_bond += 0.5 * ff.bond_par[2 * b + 1] * d * d;
+  }
+  // HarmonicAngleForce: 1/2 k (theta - theta0)^2
+  for (int a = lane; a < ff.n_angles; a += 64) {
+    const int i = ff.angle_idx[3 * a], j = ff.angle_idx[3 * a + 1], k = ff.angle_idx[3 * a + 2];
+    double v0[3], v1[3];
+    for (int c = 0; c < 3; ++c) { v0[c] = x[3 * i + c] - x[3 * j + c]; v1[c] = x[3 * k + c] - x[3 * j + c]; }
+    const double d00 = v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2];
+    const double d11 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+    const double d01 = v0[0] * v1[0] + v0[1] * v1[1] + v0[2] * v1[2];
+    double cs = d01 / sqrt(d00 * d11);
+    cs = fmin(1.0, fmax(-1.0, cs));
+    const double d = acos(cs) - ff.angle_par[2 * a];
+    e_angle += 0.5 * ff.angle_par[2 * a + 1] * d * d;
+  }
+  // PeriodicTorsionForce: k (1 + cos(n phi - phase))
+  for (int t = lane; t < ff.n_torsions; t += 64) {
+    const int a = ff.torsion_idx[4 * t], b = ff.torsion_idx[4 * t + 1], c = ff.torsion_idx[4 * t + 2],
+              d = ff.torsion_idx[4 * t + 3];
+    double r0[3], r1[3], r2[3];
+    for (int q = 0; q < 3; ++q) {
+      r0[q] = x[3 * a + q] - x[3 * b + q];
+      r1[q] = x[3 * c + q] - x[3 * b + q];
+      r2[q] = x[3 * c + q] - x[3 * d + q];
+    }
+    double c0[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    double c1[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    const double n0 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2];
+    const double n1 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2];
+    const double dt = c0[0] * c1[0] + c0[1] * c1[1] + c0[2] * c1[2];
+    double cs = dt / sqrt(n0 * n1);
+    cs = fmin(1.0, fmax(-1.0, cs));
+    double phi = acos(cs);
+    // sign convention of OpenMM's reference kernel: sign of r0 . (r1 x r2)
+    const double sgn = r0[0] * c1[0] + r0[1] * c1[1] + r0[2] * c1[2];
+    if (sgn < 0) phi = -phi;
+    e_tors += ff.torsion_par[3 * t + 2] * (1.0 + cos(ff.torsion_par[3 * t] * phi - ff.torsion_par[3 * t + 1]));
+  }
+  // NonbondedForce exceptions (1-4 pairs; 1-2/1-3 carry zeros): no cutoff, no reaction field
+  for (int e = lane; e < ff.n_exceptions; e += 64) {
+    const double qq = ff.exc_par[3 * e], sig = ff.exc_par[3 * e + 1], eps = ff.exc_par[3 * e + 2];
+    if (qq == 0.0 && eps == 0.0) continue;
+    const int i = ff.exc_idx[2 * e], j = ff.exc_idx[2 * e + 1];
+    const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    const double sr2 = (sig / r) * (sig / r), sr6 = sr2 * sr2 * sr2;
+    e_nb += TW_ONE_4PI_EPS0 * qq / r + 4.0 * eps * (sr6 * sr6 - sr6);
+  }
+  // NonbondedForce, all non-excluded pairs inside the cutoff
+  const bool use_cut = ff.cutoff > 0.0;
+  const double rc = ff.cutoff;
+  const double krf = use_cut ? (1.0 / (rc * rc * rc)) * (ff.rf_dielectric - 1.0) / (2.0 * ff.rf_dielectric + 1.0) : 0.0;
+  const double crf = use_cut ? (1.0 / rc) * (3.0 * ff.rf_dielectric) / (2.0 * ff.rf_dielectric + 1.0) : 0.0;
+  const int npairs = V * (V - 1) / 2;
+  for (int p = lane; p < npairs; p += 64) {
+    // decode (i<j) from the linear index
+    int i = (int)((sqrt(8.0 * p + 1.0) + 1.0) * 0.5);
+    while (i * (i - 1) / 2 > p) --i;
+    while ((i + 1) * i / 2 <= p) ++i;
+    const int j = p - i * (i - 1) / 2;  // j < i
+    if (excl[i * V + j]) continue;
+    const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double r = sqrt(r2);
+    if (use_cut && r >= rc) continue;
+    const double* pi = ff.atom_par + 5 * i;
+    const double* pj = ff.atom_par + 5 * j;
+    const double sig = 0.5 * (pi[1] + pj[1]);
+    const double eps = sqrt(pi[2] * pj[2]);
+    const double sr2 = (sig * sig) / r2, sr6 = sr2 * sr2 * sr2;
+    e_nb += 4.0 * eps * (sr6 * sr6 - sr6);
+    e_nb += TW_ONE_4PI_EPS0 * pi[0] * pj[0] * (use_cut ? (1.0 / r + krf * r2 - crf) : 1.0 / r);
+  }
+  // GBSAOBCForce (OBC-II alpha=1 beta=0.8 gamma=4.85, dielectric offset 0.009 nm, probe 0.14 nm)
+  if (ff.has_gbsa) {
+    const double offset = 0.009, alpha = 1.0, beta = 0.8, gamma = 4.85, probe = 0.14;
+    for (int i = lane; i < V; i += 64) {
+      const double rad_i = ff.atom_par[5 * i + 3];
+      const double off_i = rad_i - offset;
+      double sum = 0.0;
+      for (int j = 0; j < V; ++j) {
+        if (j == i) continue;
+        const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        if (use_cut && r > rc) continue;
+        const double off_j = ff.atom_par[5 * j + 3] - offset;
+        const double sr_j = off_j * ff.atom_par[5 * j + 4];
+        const double r_sr = r + sr_j;
+        if (off_i < r_sr) {
+          const double rinv = 1.0 / r;
+          const double ad = fabs(r - sr_j);
+          const double l = 1.0 / (off_i > ad ? off_i : ad);
+          const double u = 1.0 / r_sr;
+          const double l2 = l * l, u2 = u * u;
+          const double ratio = log(u / l);
+          double term = l - u + 0.25 * r * (u2 - l2) + 0.5 * rinv * ratio + 0.25 * sr_j * sr_j * rinv * (l2 - u2);
+          if (off_i < (sr_j - r)) term += 2.0 * (1.0 / off_i - l);
+          sum += term;
+        }
+      }
+      sum *= 0.5 * off_i;
+      const double s2 = sum * sum, s3 = sum * s2;
+      const double th = tanh(alpha * sum - beta * s2 + gamma * s3);
+      born[i] = 1.0 / (1.0 / off_i - th / rad_i);
+    }
+    __syncthreads();
+    const double pre = -TW_ONE_4PI_EPS0 * (1.0 / ff.solute_dielectric - 1.0 / ff.solvent_dielectric);
+    // ACE non-polar term: 4 pi * surface_area_energy * (r+probe)^2 (r/B)^6
+    const double pi4a = 4.0 * 3.14159265358979323846 * ff.surface_area_energy;
+    for (int i = lane; i < V; i += 64) {
+      const double rad = ff.atom_par[5 * i + 3];
+      if (born[i] > 0.0) {
+        const double rr = rad + probe;
+        const double ratio = rad / born[i];
+        const double r3 = ratio * ratio * ratio;
+        e_gb += pi4a * rr * rr * r3 * r3;
+      }
+      // self term
+      const double q = ff.atom_par[5 * i];
+      e_gb += 0.5 * pre * q * q / born[i];
+    }
+    for (int p = lane; p < npairs; p += 64) {
+      int i = (int)((sqrt(8.0 * p + 1.0) + 1.0) * 0.5);
+      while (i * (i - 1) / 2 > p) --i;
+      while ((i + 1) * i / 2 <= p) ++i;
+      const int j = p - i * (i - 1) / 2;
+      const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      if (use_cut && sqrt(r2) > rc) continue;
+      const double a2 = born[i] * born[j];
+      const double dij = r2 / (4.0 * a2);
+      const double den = sqrt(r2 + a2 * exp(-dij));
+      const double qq = pre * ff.atom_par[5 * i] * ff.atom_par[5 * j];
+      double e = qq / den;
+      if (use_cut) e -= qq / rc;
+      e_gb += e;
+    }
+  }
+  e_bond = wsum(e_bond); e_angle = wsum(e_angle); e_tors = wsum(e_tors); e_nb = wsum(e_nb); e_gb = wsum(e_gb);
+  if (lane == 0) {
+    out[n] = e_bond + e_angle + e_tors + e_nb + e_gb;
+    if (terms) {
+      terms[5 * n] = e_bond; terms[5 * n + 1] = e_angle; terms[5 * n + 2] = e_tors; terms[5 * n + 3] = e_nb;
+      terms[5 * n + 4] = e_gb;
+    }
+  }
+}
+
+int amber_energy(const tw_forcefield* ff, const float* coords, double* out, double* terms, int64_t n, hipStream_t s) {
+  if (n == 0) return TW_OK;
+  const int V = ff->n_atoms;
+  size_t shm = (size_t)(4 * V) * sizeof(double) + (size_t)V * V;
+  shm = (shm + 15) / 16 * 16;
+  hipLaunchKernelGGL(amber_energy_kernel, dim3((unsigned)n), dim3(64), shm, s, *ff, coords, out, terms);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+
+}  // namespace tw

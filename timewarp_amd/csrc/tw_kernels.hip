@@ -1,0 +1,706 @@
+// Glue kernels (scores, centring, coupling, prior log-prob, kinetic energy, MH accept, chirality)
+// and the SIMPLE flow path: one plain HIP kernel per reference torch op.  The simple path is the
+// always-available HIP implementation (all variants, any atom count); the fused f32-MFMA path
+// (tw_netblock.hip) is the fast one for the kernel variant.
+#include <stdarg.h>
+
+#include "tw_common.h"
+
+namespace tw {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+RawLayout raw_layout(const tw_flow_desc& d) {
+  RawLayout L;
+  const int64_t dm = d.d_model, ff = d.d_ff, hid = d.d_hidden, H = d.n_heads;
+  L.d_in = d.d_emb + 9 + (d.variant == 1 ? d.d_rff : 0);
+  int64_t o = 0;
+  L.emb = o; o += (int64_t)d.n_elements * d.d_emb;
+  L.lengthscales = o; o += (d.variant == 0 ? H : 0);
+  L.prior = o; o += 2;
+  L.chain = o;
+  // layer
+  LayerOff& y = L.layer;
+  int64_t q = 0;
+  y.wv = y.wo = y.in_w = y.in_b = y.out_w = y.out_b = -1;
+  if (d.variant == 0) {
+    y.wv = q; q += H * dm * dm;
+    y.wo = q; q += dm * H * dm;
+  } else {
+    y.in_w = q; q += 3 * dm * dm;
+    y.in_b = q; q += 3 * dm;
+    y.out_w = q; q += dm * dm;
+    y.out_b = q; q += dm;
+  }
+  y.w1 = q; q += ff * dm;
+  y.b1 = q; q += ff;
+  y.w2 = q; q += dm * ff;
+  y.b2 = q; q += dm;
+  y.n1w = q; q += dm;
+  y.n1b = q; q += dm;
+  y.n2w = q; q += dm;
+  y.n2b = q; q += dm;
+  y.size = q;
+  // net
+  NetOff& n = L.net;
+  q = 0;
+  n.in0_w = q; q += hid * L.d_in;
+  n.in0_b = q; q += hid;
+  n.in2_w = q; q += dm * hid;
+  n.in2_b = q; q += dm;
+  n.layers = q; q += (int64_t)d.n_layers * y.size;
+  n.out0_w = q; q += hid * dm;
+  n.out0_b = q; q += hid;
+  n.out2_w = q; q += 3 * hid;
+  n.out2_b = q; q += 3;
+  n.size = q;
+  // coupling
+  q = 0;
+  L.rff = q; q += (d.variant == 1 ? 3 * (d.d_rff / 2) : 0);
+  L.nets = q; q += 2 * n.size;
+  L.coupling_size = q;
+  L.total = L.chain + (int64_t)d.n_coupling * L.coupling_size;
+  return L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compute_kernel_attention_scores  (kernel_attention.py:69-121)
+// one workgroup per conditioning row; out [B,H,V,V]
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pair_distance(const float* x, int q, int m, int use_mm) {
+  float qx = x[3 * q], qy = x[3 * q + 1], qz = x[3 * q + 2];
+  float mx = x[3 * m], my = x[3 * m + 1], mz = x[3 * m + 2];
+  if (!use_mm) {
+    float dx = qx - mx, dy = qy - my, dz = qz - mz;
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+  }
+  // torch.cdist matmul formulation: [-2x, |x|^2, 1] . [y, 1, |y|^2], clamp_min(0), sqrt
+  float qn = qx * qx + qy * qy + qz * qz;
+  float mn = mx * mx + my * my + mz * mz;
+  float acc = (-2.f * qx) * mx;
+  acc = fmaf(-2.f * qy, my, acc);
+  acc = fmaf(-2.f * qz, mz, acc);
+  acc = acc + qn;
+  acc = acc + mn;
+  return sqrtf(fmaxf(acc, 0.f));
+}
+
+__global__ void scores_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
+                              const float* __restrict__ ls, int H, int V, int normalise, int use_mm,
+                              float* __restrict__ out) {
+  extern __shared__ float sm[];
+  float* xs = sm;            // [V*3]
+  float* dist = sm + 3 * V;  // [V*V]
+  const int64_t b = blockIdx.x;
+  for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) xs[i] = x[b * 3 * V + i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < V * V; i += blockDim.x) dist[i] = pair_distance(xs, i / V, i % V, use_mm);
+  __syncthreads();
+  // one thread per (h, q) row
+  for (int r = threadIdx.x; r < H * V; r += blockDim.x) {
+    const int h = r / V, q = r % V;
+    const float l = ls[h];
+    float sum = 0.f;
+    for (int m = 0; m < V; ++m) {
+      float sc = dist[q * V + m] / l;
+      float e = masked[b * V + m] ? 0.f : expf(-(sc * sc));
+      sum += fabsf(e);
+    }
+    const float denom = sum + 1e-5f;
+    float* o = out + ((b * H + h) * V + q) * (int64_t)V;
+    for (int m = 0; m < V; ++m) {
+      float sc = dist[q * V + m] / l;
+      float e = masked[b * V + m] ? 0.f : expf(-(sc * sc));
+      o[m] = normalise ? e / denom : e;
+    }
+  }
+}
+
+int launch_scores(const float* x, const uint8_t* masked, const float* ls, int H, int64_t B, int V,
+                  int normalise, int use_mm, float* out, hipStream_t s) {
+  if (B == 0) return TW_OK;
+  size_t shm = (size_t)(3 * V + V * V) * sizeof(float);
+  hipLaunchKernelGGL(scores_kernel, dim3((unsigned)B), dim3(256), shm, s, x, masked, ls, H, V, normalise,
+                     use_mm, out);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_centre_of_mass (molecule_utils.py:15-29)
+// ------------------------------------------------------------------------------------------------
+__global__ void centre_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
+                              float* __restrict__ xc, float* __restrict__ com, int V) {
+  const int64_t n = blockIdx.x;
+  const int lane = threadIdx.x;
+  float sx = 0, sy = 0, sz = 0, cnt = 0;
+  for (int a = lane; a < V; a += 64) {
+    float keep = masked[n * V + a] ? 0.f : 1.f;
+    sx += keep * x[(n * V + a) * 3 + 0];
+    sy += keep * x[(n * V + a) * 3 + 1];
+    sz += keep * x[(n * V + a) * 3 + 2];
+    cnt += keep;
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); cnt = wave_sum(cnt);
+  const float cx = sx / cnt, cy = sy / cnt, cz = sz / cnt;
+  if (com && lane == 0) { com[n * 3] = cx; com[n * 3 + 1] = cy; com[n * 3 + 2] = cz; }
+  if (xc)
+    for (int a = lane; a < V; a += 64) {
+      xc[(n * V + a) * 3 + 0] = x[(n * V + a) * 3 + 0] - cx;
+      xc[(n * V + a) * 3 + 1] = x[(n * V + a) * 3 + 1] - cy;
+      xc[(n * V + a) * 3 + 2] = x[(n * V + a) * 3 + 2] - cz;
+    }
+}
+
+int launch_centre(const float* x, const uint8_t* masked, float* xc, float* com, int64_t n, int V,
+                  hipStream_t s) {
+  if (n == 0) return TW_OK;
+  hipLaunchKernelGGL(centre_kernel, dim3((unsigned)n), dim3(64), 0, s, x, masked, xc, com, V);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// affine coupling + log-det (layers/nvp.py:89-183); one wave per row
+//   forward: z' = z*exp(s)+t, logdet = +sum log(exp(s)); reverse: z' = (z-t)/exp(s), logdet = -sum
+//   delta_logp -= logdet (nvp.py:86)
+// ------------------------------------------------------------------------------------------------
+__global__ void coupling_kernel(const float* __restrict__ s_raw, const float* __restrict__ t,
+                                const uint8_t* __restrict__ masked, int64_t n_cond, float* __restrict__ z,
+                                float* __restrict__ delta_logp, int V, int reverse) {
+  const int64_t n = blockIdx.x;
+  const int64_t c = n % n_cond;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < 3 * V; i += 64) {
+    const int64_t idx = n * 3 * V + i;
+    const float scale = expf(s_raw[idx]);
+    const float shift = t[idx];
+    const float keep = masked[c * V + i / 3] ? 0.f : 1.f;
+    acc += logf(scale) * keep;
+    z[idx] = reverse ? (z[idx] - shift) / scale : z[idx] * scale + shift;
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) {
+    const float logdet = reverse ? -acc : acc;
+    delta_logp[n] = delta_logp[n] - logdet;
+  }
+}
+
+int launch_coupling(const float* s_raw, const float* t, const uint8_t* masked, int64_t n_cond, float* z,
+                    float* delta_logp, int64_t n_rows, int V, int reverse, hipStream_t s) {
+  if (n_rows == 0) return TW_OK;
+  hipLaunchKernelGGL(coupling_kernel, dim3((unsigned)n_rows), dim3(64), 0, s, s_raw, t, masked, n_cond, z,
+                     delta_logp, V, reverse);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prior log-density + final assembly (flow.py:191-203, 303-334)
+// Normal(0, e^ls).log_prob(z) = -z^2/(2 var) - log(scale) - log(sqrt(2 pi))
+// ------------------------------------------------------------------------------------------------
+__global__ void prior_logp_kernel(const float* __restrict__ zc, const float* __restrict__ zv,
+                                  const uint8_t* __restrict__ masked, int64_t n_cond,
+                                  const float* __restrict__ prior, const float* __restrict__ delta,
+                                  float sign, float* __restrict__ out, int V) {
+  const int64_t n = blockIdx.x;
+  const int64_t c = n % n_cond;
+  const float sc = expf(prior[0]), sv = expf(prior[1]);
+  const float var_c = sc * sc, var_v = sv * sv;
+  const float lsc = logf(sc), lsv = logf(sv);
+  const float half_log_2pi = 0.91893853320467274178f;
+  float ac = 0.f, av = 0.f;
+  for (int i = threadIdx.x; i < 3 * V; i += 64) {
+    const float keep = masked[c * V + i / 3] ? 0.f : 1.f;
+    const float a = zc[n * 3 * V + i], b = zv[n * 3 * V + i];
+    ac += keep * (-(a * a) / (2.f * var_c) - lsc - half_log_2pi);
+    av += keep * (-(b * b) / (2.f * var_v) - lsv - half_log_2pi);
+  }
+  ac = wave_sum(ac);
+  av = wave_sum(av);
+  if (threadIdx.x == 0) out[n] = (ac + av) + sign * delta[n];
+}
+
+// y = (x_centred + com) + residual  (flow.py:303-310)
+__global__ void uncentre_add_kernel(const float* __restrict__ xc, const float* __restrict__ com,
+                                    const float* __restrict__ resid, int64_t n_cond, float* __restrict__ y,
+                                    int V, int displacement, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t n = i / (3 * V);
+  const int r = (int)(i % (3 * V));
+  const int64_t c = n % n_cond;
+  float base = xc[c * 3 * V + r] + com[c * 3 + r % 3];
+  y[i] = displacement ? base + resid[i] : resid[i];
+}
+
+__global__ void sub_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
+                           int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) o[i] = a[i] - b[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// compute_kinetic_energy (evaluation_utils.py:416-436)
+// ------------------------------------------------------------------------------------------------
+__global__ void kinetic_kernel(const float* __restrict__ v, const float* __restrict__ masses, int random_velocs,
+                               float kbT, float* __restrict__ out, int V) {
+  const int64_t n = blockIdx.x;
+  float acc = 0.f;
+  for (int a = threadIdx.x; a < V; a += 64) {
+    const float* p = v + (n * V + a) * 3;
+    float s = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    acc += random_velocs ? s : masses[a] * s;
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) out[n] = random_velocs ? 0.5f * acc : 0.5f * acc / kbT;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MH accept step (evaluation_utils.py:659-677): single workgroup, first-true scan + state update
+// ------------------------------------------------------------------------------------------------
+__global__ void mh_accept_kernel(const float* __restrict__ energy, const float* __restrict__ p_xy,
+                                 const float* __restrict__ p_yx, const float* __restrict__ u,
+                                 const float* __restrict__ yc, const float* __restrict__ yv,
+                                 float* __restrict__ xc, float* __restrict__ xv, float* __restrict__ out_exp,
+                                 float* __restrict__ out_pacc, uint8_t* __restrict__ out_acc,
+                                 int32_t* __restrict__ result, int64_t S, int V) {
+  __shared__ int first;
+  if (threadIdx.x == 0) first = 0x7fffffff;
+  __syncthreads();
+  int local = 0x7fffffff;
+  for (int64_t s = threadIdx.x; s < S; s += blockDim.x) {
+    const float e = energy[s] + p_xy[s] - p_yx[s];
+    const float p = fminf(1.f, expf(-e));
+    const bool acc = u[s] < p;
+    out_exp[s] = e;
+    out_pacc[s] = p;
+    out_acc[s] = acc ? 1 : 0;
+    if (acc && (int)s < local) local = (int)s;
+  }
+  atomicMin(&first, local);
+  __syncthreads();
+  const int k = first;
+  const bool any = k != 0x7fffffff;
+  if (any)
+    for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) {
+      xc[i] = yc[(int64_t)k * 3 * V + i];
+      xv[i] = yv[(int64_t)k * 3 * V + i];
+    }
+  if (threadIdx.x == 0) {
+    result[0] = any ? k : (int)(S - 1);
+    result[1] = any ? 1 : 0;
+    result[2] = 0;
+    result[3] = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// chirality (utils/chirality.py:40-80): sign of (b-a) . ((c-a) x (d-a)) per centre
+// ------------------------------------------------------------------------------------------------
+__global__ void chirality_kernel(const float* __restrict__ coords, const int32_t* __restrict__ centres,
+                                 const float* __restrict__ ref, int n_centres, uint8_t* __restrict__ changed,
+                                 int64_t n_rows, int V) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_rows) return;
+  const float* x = coords + n * 3 * V;
+  bool ch = false;
+  for (int c = 0; c < n_centres; ++c) {
+    const int i0 = centres[4 * c], i1 = centres[4 * c + 1], i2 = centres[4 * c + 2], i3 = centres[4 * c + 3];
+    // direction vectors from the first listed atom to the other three (chirality.py:52-60)
+    float a[3], b[3], d[3];
+    for (int k = 0; k < 3; ++k) {
+      a[k] = x[3 * i1 + k] - x[3 * i0 + k];
+      b[k] = x[3 * i2 + k] - x[3 * i0 + k];
+      d[k] = x[3 * i3 + k] - x[3 * i0 + k];
+    }
+    // perm_sign = d0 . (d1 x d2)  (chirality.py:57-61)
+    float cx = b[1] * d[2] - b[2] * d[1];
+    float cy = b[2] * d[0] - b[0] * d[2];
+    float cz = b[0] * d[1] - b[1] * d[0];
+    float dot = a[0] * cx + a[1] * cy + a[2] * cz;
+    float sgn = (dot > 0.f) ? 1.f : ((dot < 0.f) ? -1.f : 0.f);
+    if (sgn != ref[c]) ch = true;
+  }
+  changed[n] = ch ? 1 : 0;
+}
+
+// ================================================================================================
+// SIMPLE PATH kernels
+// ================================================================================================
+
+// u[n, a, :] = cat(emb[type], x_coords, x_velocs, z_other [, rff(x_coords)])
+// (custom_transformer_nvp.py:64-71, transformer_nvp.py:76-88)
+__global__ void build_input_kernel(const float* __restrict__ emb, const int32_t* __restrict__ types,
+                                   const float* __restrict__ xc, const float* __restrict__ xv,
+                                   const float* __restrict__ z_other, const float* __restrict__ rff_vec,
+                                   int d_rff, int64_t n_cond, int V, int d_emb, int d_in, float* __restrict__ u,
+                                   int64_t tokens) {
+  const int64_t tok = blockIdx.x;
+  if (tok >= tokens) return;
+  const int64_t n = tok / V;
+  const int a = (int)(tok % V);
+  const int64_t c = n % n_cond;
+  const int ty = types[c * V + a];
+  const float* px = xc + (c * V + a) * 3;
+  for (int f = threadIdx.x; f < d_in; f += blockDim.x) {
+    float val;
+    if (f < d_emb) val = emb[ty * d_emb + f];
+    else if (f < d_emb + 3) val = px[f - d_emb];
+    else if (f < d_emb + 6) val = xv[(c * V + a) * 3 + f - d_emb - 3];
+    else if (f < d_emb + 9) val = z_other[tok * 3 + f - d_emb - 6];
+    else {
+      // rff_position_encoder.py:57-62: sqrt(1/n) * [cos(x G), sin(x G)]
+      const int nvec = d_rff / 2;
+      const int j = f - d_emb - 9;
+      const int col = j % nvec;
+      float ip = px[0] * rff_vec[0 * nvec + col] + px[1] * rff_vec[1 * nvec + col] + px[2] * rff_vec[2 * nvec + col];
+      val = sqrtf(1.0f / nvec) * (j < nvec ? cosf(ip) : sinf(ip));
+    }
+    u[tok * d_in + f] = val;
+  }
+}
+
+// Y[M,N] = act(X[M,K] W[N,K]^T + b): 64x64 tile, 16x16 threads, 4x4 micro-tile, fp32 FMA.
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+template <int ACT>
+__global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, float* __restrict__ Y,
+                                                      int64_t M, int N, int K) {
+  __shared__ float xs[16][65];
+  __shared__ float wsh[16][65];
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+  const int64_t m0 = (int64_t)blockIdx.y * 64;
+  const int n0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+      const int r = i / 16, kk = i % 16;
+      const int64_t m = m0 + r;
+      const int n = n0 + r;
+      xs[kk][r] = (m < M && k0 + kk < K) ? X[m * K + k0 + kk] : 0.f;
+      wsh[kk][r] = (n < N && k0 + kk < K) ? W[(int64_t)n * K + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = xs[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = wsh[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= N) continue;
+      float v = acc[i][j] + (bias ? bias[n] : 0.f);
+      if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+      if (ACT == ACT_SILU) v = v / (1.f + expf(-v));
+      Y[m * N + n] = v;
+    }
+  }
+}
+
+static int launch_linear(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K,
+                         int act, hipStream_t s) {
+  dim3 grid((N + 63) / 64, (unsigned)((M + 63) / 64));
+  if (act == ACT_NONE) hipLaunchKernelGGL(linear_kernel<ACT_NONE>, grid, dim3(256), 0, s, X, W, b, Y, M, N, K);
+  else if (act == ACT_RELU) hipLaunchKernelGGL(linear_kernel<ACT_RELU>, grid, dim3(256), 0, s, X, W, b, Y, M, N, K);
+  else hipLaunchKernelGGL(linear_kernel<ACT_SILU>, grid, dim3(256), 0, s, X, W, b, Y, M, N, K);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+
+// attend + flatten_multihead (kernel_attention.py:124-156):
+// att[n, q, h*D + d] = sum_m scores[n % B, h, q, m] * vals[n, m, h*D + d]; grid (n, h), block D threads
+__global__ void attend_kernel(const float* __restrict__ scores, const float* __restrict__ vals,
+                              float* __restrict__ att, int64_t n_cond, int H, int V, int D) {
+  extern __shared__ float sc[];  // [V*V]
+  const int64_t n = blockIdx.x;
+  const int h = blockIdx.y;
+  const int64_t c = n % n_cond;
+  for (int i = threadIdx.x; i < V * V; i += blockDim.x) sc[i] = scores[((c * H + h) * V) * (int64_t)V + i];
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    for (int q = 0; q < V; ++q) {
+      float acc = 0.f;
+      for (int m = 0; m < V; ++m) acc = fmaf(sc[q * V + m], vals[((n * V + m) * H + h) * (int64_t)D + d], acc);
+      att[((n * V + q) * H + h) * (int64_t)D + d] = acc;
+    }
+  }
+}
+
+// dense softmax attention for one (row, head): qkv [n, V, 3*d]; out [n, V, d]
+// (torch.nn.MultiheadAttention with key padding mask)
+__global__ void sdpa_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ masked, int64_t n_cond,
+                            float* __restrict__ out, int V, int d, int n_head) {
+  extern __shared__ float sm[];
+  const int dh = d / n_head;
+  float* q = sm;               // [V*dh]
+  float* k = q + V * dh;       // [V*dh]
+  float* v = k + V * dh;       // [V*dh]
+  float* p = v + V * dh;       // [V*V]
+  const int64_t n = blockIdx.x;
+  const int h = blockIdx.y;
+  const int64_t c = n % n_cond;
+  for (int i = threadIdx.x; i < V * dh; i += blockDim.x) {
+    const int a = i / dh, j = i % dh;
+    const float* row = qkv + (n * V + a) * 3 * (int64_t)d;
+    q[i] = row[h * dh + j] / sqrtf((float)dh);
+    k[i] = row[d + h * dh + j];
+    v[i] = row[2 * d + h * dh + j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < V * V; i += blockDim.x) {
+    const int a = i / V, m = i % V;
+    float acc = 0.f;
+    for (int j = 0; j < dh; ++j) acc = fmaf(q[a * dh + j], k[m * dh + j], acc);
+    p[i] = masked[c * V + m] ? -INFINITY : acc;
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < V; a += blockDim.x) {
+    float mx = -INFINITY;
+    for (int m = 0; m < V; ++m) mx = fmaxf(mx, p[a * V + m]);
+    float sum = 0.f;
+    for (int m = 0; m < V; ++m) { float e = expf(p[a * V + m] - mx); p[a * V + m] = e; sum += e; }
+    for (int m = 0; m < V; ++m) p[a * V + m] /= sum;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < V * dh; i += blockDim.x) {
+    const int a = i / dh, j = i % dh;
+    float acc = 0.f;
+    for (int m = 0; m < V; ++m) acc = fmaf(p[a * V + m], v[m * dh + j], acc);
+    out[(n * V + a) * (int64_t)d + h * dh + j] = acc;
+  }
+}
+
+// h = LayerNorm(h + delta) (custom_attention_encoder.py:109-114); one wave per token
+__global__ void add_ln_kernel(float* __restrict__ h, const float* __restrict__ delta, const float* __restrict__ w,
+                              const float* __restrict__ b, float eps, int D, int64_t tokens) {
+  const int64_t tok = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  if (tok >= tokens) return;
+  const int lane = threadIdx.x % 64;
+  float* row = h + tok * D;
+  const float* drow = delta + tok * D;
+  float sum = 0.f;
+  for (int i = lane; i < D; i += 64) { float v = row[i] + drow[i]; row[i] = v; sum += v; }
+  sum = wave_sum(sum);
+  const float mean = sum / D;
+  float var = 0.f;
+  for (int i = lane; i < D; i += 64) { float dv = row[i] - mean; var += dv * dv; }
+  var = wave_sum(var) / D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int i = lane; i < D; i += 64) row[i] = (row[i] - mean) * rstd * w[i] + b[i];
+}
+
+struct SimpleWs {
+  float *u, *h0, *h, *vals, *att, *ff, *tmp, *s_out, *t_out, *scores;
+  int64_t bytes;
+};
+
+static SimpleWs simple_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
+  SimpleWs w;
+  const int64_t M = n_rows * V;
+  const int d_in = d.d_emb + 9 + (d.variant == 1 ? d.d_rff : 0);
+  const int64_t wide = d.variant == 0 ? (int64_t)d.n_heads * d.d_model : 3LL * d.d_model;
+  char* p = (char*)base;
+  auto take = [&](int64_t floats) {
+    float* r = (float*)p;
+    p += ((floats * 4 + 255) / 256) * 256;
+    return r;
+  };
+  w.u = take(M * d_in);
+  w.h0 = take(M * d.d_hidden);
+  w.h = take(M * d.d_model);
+  w.vals = take(M * wide);
+  w.att = take(M * wide);
+  w.ff = take(M * d.d_ff);
+  w.tmp = take(M * d.d_model);
+  w.s_out = take(M * 3);
+  w.t_out = take(M * 3);
+  w.scores = take(n_rows * (int64_t)d.n_heads * V * V);
+  w.bytes = p - (char*)base;
+  return w;
+}
+
+int64_t simple_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms) {
+  return simple_ws(d, n_rows, n_atoms, nullptr).bytes;
+}
+
+// one net-block on the simple path; out [M,3].  dump (optional): activations after each stage.
+static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs& w, int c, int net,
+                           const float* z_other, float* out, float* dump) {
+  const tw_flow_desc& d = *a.desc;
+  const int V = a.n_atoms;
+  const int64_t M = a.n_rows * V;
+  const float* nb = a.raw + net_base(L, c, net);
+  hipStream_t s = a.stream;
+  const float* rff = d.variant == 1 ? a.raw + L.chain + (int64_t)c * L.coupling_size + L.rff : nullptr;
+  hipLaunchKernelGGL(build_input_kernel, dim3((unsigned)M), dim3(64), 0, s, a.raw + L.emb, a.atom_types, a.x_coords,
+                     a.x_velocs, z_other, rff, d.d_rff, a.n_cond, V, d.d_emb, L.d_in, w.u, M);
+  TW_LAUNCH_CHECK();
+  int rc;
+  if ((rc = launch_linear(w.u, nb + L.net.in0_w, nb + L.net.in0_b, w.h0, M, d.d_hidden, L.d_in, ACT_SILU, s))) return rc;
+  if ((rc = launch_linear(w.h0, nb + L.net.in2_w, nb + L.net.in2_b, w.h, M, d.d_model, d.d_hidden, ACT_NONE, s))) return rc;
+  const int64_t act_sz = M * d.d_model;
+  if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump, w.h, act_sz * 4, hipMemcpyDeviceToDevice, s));
+  for (int l = 0; l < d.n_layers; ++l) {
+    const float* lb = nb + L.net.layers + (int64_t)l * L.layer.size;
+    if (d.variant == 0) {
+      const int HD = d.n_heads * d.d_model;
+      if ((rc = launch_linear(w.h, lb + L.layer.wv, nullptr, w.vals, M, HD, d.d_model, ACT_NONE, s))) return rc;
+      hipLaunchKernelGGL(attend_kernel, dim3((unsigned)a.n_rows, d.n_heads), dim3(128), (size_t)V * V * 4, s, w.scores,
+                         w.vals, w.att, a.n_cond, d.n_heads, V, d.d_model);
+      TW_LAUNCH_CHECK();
+      if ((rc = launch_linear(w.att, lb + L.layer.wo, nullptr, w.tmp, M, d.d_model, HD, ACT_NONE, s))) return rc;
+    } else {
+      if ((rc = launch_linear(w.h, lb + L.layer.in_w, lb + L.layer.in_b, w.vals, M, 3 * d.d_model, d.d_model, ACT_NONE, s))) return rc;
+      const int dh = d.d_model / d.n_heads;
+      hipLaunchKernelGGL(sdpa_kernel, dim3((unsigned)a.n_rows, d.n_heads), dim3(128),
+                         (size_t)(3 * V * dh + V * V) * 4, s, w.vals, a.masked, a.n_cond, w.att, V, d.d_model,
+                         d.n_heads);
+      TW_LAUNCH_CHECK();
+      if ((rc = launch_linear(w.att, lb + L.layer.out_w, lb + L.layer.out_b, w.tmp, M, d.d_model, d.d_model, ACT_NONE, s))) return rc;
+    }
+    hipLaunchKernelGGL(add_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.h, w.tmp, lb + L.layer.n1w,
+                       lb + L.layer.n1b, d.ln_eps, d.d_model, M);
+    TW_LAUNCH_CHECK();
+    if ((rc = launch_linear(w.h, lb + L.layer.w1, lb + L.layer.b1, w.ff, M, d.d_ff, d.d_model, ACT_RELU, s))) return rc;
+    if ((rc = launch_linear(w.ff, lb + L.layer.w2, lb + L.layer.b2, w.tmp, M, d.d_model, d.d_ff, ACT_NONE, s))) return rc;
+    hipLaunchKernelGGL(add_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.h, w.tmp, lb + L.layer.n2w,
+                       lb + L.layer.n2b, d.ln_eps, d.d_model, M);
+    TW_LAUNCH_CHECK();
+    if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump + (l + 1) * act_sz, w.h, act_sz * 4, hipMemcpyDeviceToDevice, s));
+  }
+  if ((rc = launch_linear(w.h, nb + L.net.out0_w, nb + L.net.out0_b, w.h0, M, d.d_hidden, d.d_model, ACT_SILU, s))) return rc;
+  if ((rc = launch_linear(w.h0, nb + L.net.out2_w, nb + L.net.out2_b, out, M, 3, d.d_hidden, ACT_NONE, s))) return rc;
+  if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump + (d.n_layers + 1) * act_sz, out, M * 3 * 4, hipMemcpyDeviceToDevice, s));
+  return TW_OK;
+}
+
+static int simple_scores(const FlowArgs& a, const RawLayout& L, const SimpleWs& w) {
+  const tw_flow_desc& d = *a.desc;
+  if (d.variant != 0) return TW_OK;
+  // one score matrix per flow call, shared by every encoder layer (model_constructor.py:192-195)
+  return launch_scores(a.x_coords, a.masked, a.raw + L.lengthscales, d.n_heads, a.n_cond, a.n_atoms, d.normalise,
+                       a.n_atoms > 25, w.scores, a.stream);
+}
+
+int flow_pass_simple(const FlowArgs& a) {
+  const tw_flow_desc& d = *a.desc;
+  const RawLayout L = raw_layout(d);
+  const SimpleWs w = simple_ws(d, a.n_rows, a.n_atoms, a.ws);
+  if (w.bytes > a.ws_bytes) {
+    set_error("workspace too small: need %lld bytes, have %lld", (long long)w.bytes, (long long)a.ws_bytes);
+    return TW_ERR_WORKSPACE;
+  }
+  int rc;
+  if ((rc = simple_scores(a, L, w))) return rc;
+  for (int i = 0; i < d.n_coupling; ++i) {
+    const int c = a.reverse ? d.n_coupling - 1 - i : i;
+    const bool positions = (c % 2) == d.pos_mod2;
+    const float* z_other = positions ? a.z_velocs : a.z_coords;
+    float* z_t = positions ? a.z_coords : a.z_velocs;
+    if ((rc = netblock_simple(a, L, w, c, 0, z_other, w.s_out, nullptr))) return rc;
+    if ((rc = netblock_simple(a, L, w, c, 1, z_other, w.t_out, nullptr))) return rc;
+    if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, z_t, a.delta_logp, a.n_rows, a.n_atoms,
+                              a.reverse, a.stream)))
+      return rc;
+  }
+  return TW_OK;
+}
+
+int debug_netblock_simple(const FlowArgs& a, int c, int net, const float* z_other, float* dump) {
+  const tw_flow_desc& d = *a.desc;
+  const RawLayout L = raw_layout(d);
+  const SimpleWs w = simple_ws(d, a.n_rows, a.n_atoms, a.ws);
+  if (w.bytes > a.ws_bytes) {
+    set_error("workspace too small: need %lld bytes, have %lld", (long long)w.bytes, (long long)a.ws_bytes);
+    return TW_ERR_WORKSPACE;
+  }
+  int rc;
+  if ((rc = simple_scores(a, L, w))) return rc;
+  return netblock_simple(a, L, w, c, net, z_other, w.s_out, dump);
+}
+
+// launch helpers used by tw_api.hip -----------------------------------------------------------------
+int launch_prior_logp(const float* zc, const float* zv, const uint8_t* masked, int64_t n_cond, const float* prior,
+                      const float* delta, float sign, float* out, int64_t n_rows, int V, hipStream_t s) {
+  if (n_rows == 0) return TW_OK;
+  hipLaunchKernelGGL(prior_logp_kernel, dim3((unsigned)n_rows), dim3(64), 0, s, zc, zv, masked, n_cond, prior, delta,
+                     sign, out, V);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+int launch_uncentre_add(const float* xc, const float* com, const float* resid, int64_t n_cond, float* y, int V,
+                        int displacement, int64_t n_rows, hipStream_t s) {
+  const int64_t total = n_rows * 3 * V;
+  if (total == 0) return TW_OK;
+  hipLaunchKernelGGL(uncentre_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xc, com, resid, n_cond,
+                     y, V, displacement, total);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+int launch_sub(const float* a, const float* b, float* o, int64_t total, hipStream_t s) {
+  if (total == 0) return TW_OK;
+  hipLaunchKernelGGL(sub_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, b, o, total);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+int launch_kinetic(const float* v, const float* masses, int random_velocs, float kbT, float* out, int64_t n, int V,
+                   hipStream_t s) {
+  if (n == 0) return TW_OK;
+  hipLaunchKernelGGL(kinetic_kernel, dim3((unsigned)n), dim3(64), 0, s, v, masses, random_velocs, kbT, out, V);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+int launch_mh_accept(const float* energy, const float* p_xy, const float* p_yx, const float* u, const float* yc,
+                     const float* yv, float* xc, float* xv, float* out_exp, float* out_pacc, uint8_t* out_acc,
+                     int32_t* result, int64_t S, int V, hipStream_t s) {
+  hipLaunchKernelGGL(mh_accept_kernel, dim3(1), dim3(256), 0, s, energy, p_xy, p_yx, u, yc, yv, xc, xv, out_exp,
+                     out_pacc, out_acc, result, S, V);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+int launch_chirality(const float* coords, const int32_t* centres, const float* ref, int n_centres, uint8_t* changed,
+                     int64_t n_rows, int V, hipStream_t s) {
+  if (n_rows == 0) return TW_OK;
+  hipLaunchKernelGGL(chirality_kernel, dim3((unsigned)((n_rows + 127) / 128)), dim3(128), 0, s, coords, centres, ref,
+                     n_centres, changed, n_rows, V);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+
+}  // namespace tw

@@ -1,0 +1,127 @@
+"""`model_constructor(config) -> nn.Module`: the drop-in seam (reference model_constructor.py:51-76).
+
+`config` may be this package's ModelConfig, the reference's own ModelConfig dataclass or an
+OmegaConf node with the same fields (they are read by attribute).  Supported model types: the two
+NVP flows on the sampling hot path and the Euler-Maruyama plumbing baseline; any other
+`model_type` raises NotImplementedError exactly like the reference's final branch."""
+from __future__ import annotations
+
+import torch.nn as nn
+
+from . import _lib
+from .model_configs import duck_get as g
+from .modules import layers as L
+from .modules.baselines import EulerMaruyamaGaussian
+from .modules.flow import ConditionalFlowDensityModel
+from .weights import DENSE, KERNEL, FlowDims
+
+ELEMENT_VOCAB = ("C", "H", "N", "O", "S")  # dataloader.py:24-25
+
+
+def model_constructor(config) -> nn.Module:
+    model_type = g(config, "model_type")
+    if model_type == "custom_attention_transformer_nvp":
+        sub = g(config, "custom_transformer_nvp_config")
+        assert sub is not None
+        return custom_transformer_nvp_constructor(sub)
+    if model_type == "transformer_nvp":
+        sub = g(config, "transformer_nvp_config")
+        assert sub is not None
+        return transformer_nvp_constructor(sub)
+    if model_type == "euler_maruyama_gaussian":
+        return EulerMaruyamaGaussian()
+    raise NotImplementedError(f"{model_type} is not a recognised model.")
+
+
+def _density_flags(cfg):
+    cfd = g(cfg, "conditional_flow_density")
+    return (
+        bool(g(cfd, "scale_requires_grad", True)),
+        bool(g(cfd, "ignore_conditional_velocity", False)),
+        bool(g(cfd, "use_displacement_as_target", True)),
+    )
+
+
+def _single_hidden(cfg) -> int:
+    hidden = list(g(cfg, "latent_mlp_hidden_dims"))
+    if len(hidden) != 1:
+        raise NotImplementedError("the HIP path supports exactly one hidden layer in in_mlp/out_mlp "
+                                  f"(every reference config uses [256]); got {hidden}")
+    return int(hidden[0])
+
+
+def custom_transformer_nvp_constructor(config, execution_path: int = _lib.TW_PATH_AUTO) -> ConditionalFlowDensityModel:
+    """custom_transformer_nvp_constructor (model_constructor.py:153-197), attention_type 'kernel'."""
+    n_coupling = int(g(config, "num_coupling_layers"))
+    assert n_coupling % 2 == 0, "Real NVP should have an even number of coupling layers"
+    pos_mod = int(g(config, "position_layer_index_mod_2", 0))
+    assert pos_mod in (0, 1), "positions_layer_index can only be 0 or 1"
+    enc = g(config, "encoder_layer_config")
+    attention_type = g(enc, "attention_type")
+    if attention_type != "kernel":
+        raise NotImplementedError(f"attention_type '{attention_type}' is outside the HIP hot path (only 'kernel')")
+    lengthscales = list(g(enc, "lengthscales"))
+    assert len(lengthscales) > 0
+    normalise = g(enc, "normalise_kernel_values")
+    assert normalise is not None
+    d_model, d_ff = int(g(enc, "d_model")), int(g(enc, "dim_feedforward"))
+    if float(g(enc, "dropout", 0.0)) != 0.0:
+        raise NotImplementedError("dropout must be 0 for sampling (stochastic likelihood otherwise)")
+    emb = int(g(config, "atom_embedding_dim"))
+    hidden = _single_hidden(config)
+    n_layers = int(g(config, "num_transformer_layers"))
+    H = len(lengthscales)  # the number of heads is the number of lengthscales (custom_attention_encoder.py:165-168)
+
+    def encoder_layer():
+        att = L.KernelAttention(value_dim=d_model, output_dim=d_model, lengthscales=lengthscales,
+                                normalise_kernel_values=bool(normalise))
+        sa = L.KernelSelfAttention(input_dim=d_model, num_heads=H, value_dim=d_model, attention=att)
+        return L.CustomTransformerEncoderLayer(d_model=d_model, self_attention=sa, dim_feedforward=d_ff)
+
+    def block():
+        return L.CustomAttentionTransformerBlock(emb + 9, 3, [hidden], [encoder_layer() for _ in range(n_layers)])
+
+    chain = [
+        L.CouplingLayer("positions" if i % 2 == pos_mod else "velocities", block(), block())
+        for i in range(n_coupling)
+    ]
+    flow = L.ConditionalSequentialFlow(chain, nn.Embedding(len(ELEMENT_VOCAB), emb))
+    srg, icv, disp = _density_flags(config)
+    dims = FlowDims(KERNEL, n_coupling, n_layers, d_model, d_ff, hidden, emb, H, 0, len(ELEMENT_VOCAB), pos_mod,
+                    disp, icv, bool(normalise), 1e-5)
+    return ConditionalFlowDensityModel(flow, dims, scale_requires_grad=srg, execution_path=execution_path)
+
+
+def transformer_nvp_constructor(config, execution_path: int = _lib.TW_PATH_AUTO) -> ConditionalFlowDensityModel:
+    """transformer_nvp_constructor (model_constructor.py:200-238): dense softmax attention."""
+    n_coupling = int(g(config, "num_coupling_layers"))
+    assert n_coupling % 2 == 0, "Real NVP should have an even number of coupling layers"
+    pos_mod = int(g(config, "position_layer_index_mod_2", 0))
+    assert pos_mod in (0, 1), "positions_layer_index can only be 0 or 1"
+    tc = g(config, "transformer_config")
+    n_head, d_ff = int(g(tc, "n_head", 8)), int(g(tc, "dim_feedforward", 2048))
+    dropout = float(g(tc, "dropout", 0.0))
+    if dropout != 0.0:
+        raise NotImplementedError("dropout must be 0 for sampling (stochastic likelihood otherwise)")
+    rff = g(config, "rff_position_encoder_config")
+    enc_dim = int(g(rff, "encoding_dim", 0)) if rff is not None else 0
+    scale_mean = float(g(rff, "scale_mean", 1.0)) if rff is not None else 1.0
+    scale_std = float(g(rff, "scale_stddev", 1.0)) if rff is not None else 1.0
+    emb = int(g(config, "atom_embedding_dim"))
+    d_model = int(g(config, "transformer_hidden_dim"))
+    hidden = _single_hidden(config)
+    n_layers = int(g(config, "num_transformer_layers"))
+
+    def block():
+        return L.TransformerBlock(emb + 9 + enc_dim, 3, d_model, [hidden], n_layers, n_head, d_ff, dropout)
+
+    chain = [
+        L.CouplingLayer("positions" if i % 2 == pos_mod else "velocities", block(), block(),
+                        position_encoder=L.RFFPositionEncoder(3, enc_dim, scale_mean, scale_std))
+        for i in range(n_coupling)
+    ]
+    flow = L.ConditionalSequentialFlow(chain, nn.Embedding(len(ELEMENT_VOCAB), emb))
+    srg, icv, disp = _density_flags(config)
+    dims = FlowDims(DENSE, n_coupling, n_layers, d_model, d_ff, hidden, emb, n_head, enc_dim, len(ELEMENT_VOCAB),
+                    pos_mod, disp, icv, True, 1e-5)
+    return ConditionalFlowDensityModel(flow, dims, scale_requires_grad=srg, execution_path=execution_path)

@@ -1,0 +1,182 @@
+"""ConditionalFlowDensityModel backed by libtimewarp_hip.so.
+
+Same constructor-visible state, method names, keyword arguments, return shapes and error
+behaviour as the reference class (modules/model_wrappers/flow.py:106-336); the arithmetic runs in
+hand-written HIP kernels through the C ABI in include/timewarp_hip.h.  Inference only: outputs
+carry no autograd graph (training is outside this build's scope)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import _lib
+from ..weights import FlowDims, pack_raw, strip_module_prefix
+from .density_model_base import ConditionalDensityModel
+
+
+class ConditionalFlowDensityModel(ConditionalDensityModel):
+    def __init__(self, flow: nn.Module, dims: FlowDims, scale_requires_grad: bool = True,
+                 execution_path: int = _lib.TW_PATH_AUTO):
+        super().__init__()
+        self.flow = flow
+        self.coords_prior_log_scale = nn.Parameter(torch.tensor(0.0), requires_grad=scale_requires_grad)
+        self.velocs_prior_log_scale = nn.Parameter(torch.tensor(0.0), requires_grad=scale_requires_grad)
+        self.dims = dims
+        self.ignore_conditional_velocity = dims.ignore_cond_velocity
+        self.use_displacement_as_target = dims.displacement
+        self.execution_path = execution_path
+        self._dev_weights = None  # (device, raw, packed)
+        self._workspace = None
+        self._dirty = True
+
+    # ------------------------------------------------------------------ weight cache
+    def _apply(self, fn, *a, **k):
+        self._dirty = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._dirty = True
+        return super().load_state_dict(strip_module_prefix(state_dict), strict=strict, **kw)
+
+    def refresh_weights(self) -> None:
+        """Re-pack the device weight buffers after parameters were modified in place."""
+        self._dirty = True
+
+    def _weights(self, device: torch.device):
+        if self.training:
+            self._dirty = True  # parameters may be changing under us: never serve a stale pack
+        if self._dirty or self._dev_weights is None or self._dev_weights[0] != device:
+            lib = _lib.load()
+            desc = self.dims.to_desc()
+            raw_cpu = pack_raw(self.state_dict(), self.dims)
+            expect = lib.tw_flow_raw_floats(C.byref(desc))
+            if expect != raw_cpu.numel():
+                raise RuntimeError(f"raw weight layout mismatch: host packed {raw_cpu.numel()} floats, library expects {expect}")
+            raw = raw_cpu.to(device)
+            packed = None
+            n_packed = lib.tw_flow_packed_floats(C.byref(desc))
+            if n_packed > 0:
+                packed = torch.empty(n_packed, dtype=torch.float32, device=device)
+                with torch.cuda.device(device):
+                    _lib.check(lib.tw_flow_pack(C.byref(desc), raw.data_ptr(), packed.data_ptr(),
+                                                _lib.stream_ptr(device)), "tw_flow_pack")
+            self._dev_weights = (device, raw, packed)
+            self._dirty = False
+        return self._dev_weights[1], self._dev_weights[2]
+
+    def _ws(self, device: torch.device, n_rows: int, n_atoms: int):
+        lib = _lib.load()
+        desc = self.dims.to_desc()
+        need = lib.tw_flow_workspace_bytes(C.byref(desc), n_rows, n_atoms)
+        if need < 0:
+            raise RuntimeError("tw_flow_workspace_bytes failed: " + lib.tw_last_error().decode())
+        if self._workspace is None or self._workspace.device != device or self._workspace.numel() < need:
+            self._workspace = torch.empty(int(need), dtype=torch.uint8, device=device)
+        return self._workspace
+
+    @staticmethod
+    def _prep(atom_types, masked_elements, *floats):
+        dev = floats[0].device
+        out = [_lib.require_gpu_tensor(atom_types, torch.int32, "atom_types"),
+               _lib.require_gpu_tensor(masked_elements.to(torch.uint8), torch.uint8, "masked_elements")]
+        out += [_lib.require_gpu_tensor(f.to(dev), torch.float32, "coords/velocs") for f in floats]
+        return out
+
+    # ------------------------------------------------------------------ API (flow.py:131-336)
+    @torch.no_grad()
+    def log_likelihood(self, atom_types: Tensor, x_coords: Tensor, x_velocs: Tensor, y_coords: Tensor,
+                       y_velocs: Tensor, adj_list: Optional[Tensor], edge_batch_idx: Optional[Tensor],
+                       masked_elements: Tensor, logger=None) -> Tensor:
+        """log p(y | x) per batch element, [B] (flow.py:131-215).  adj_list / edge_batch_idx are
+        accepted and ignored, as in the reference."""
+        at, mk, xc, xv, yc, yv = self._prep(atom_types, masked_elements, x_coords, x_velocs, y_coords, y_velocs)
+        dev = xc.device
+        B, V = xc.shape[0], xc.shape[1]
+        raw, packed = self._weights(dev)
+        ws = self._ws(dev, B, V)
+        out = torch.empty(B, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        desc = self.dims.to_desc()
+        with torch.cuda.device(dev):
+            _lib.check(lib.tw_flow_log_likelihood(
+                C.byref(desc), raw.data_ptr(), _lib.ptr(packed), at.data_ptr(), xc.data_ptr(), xv.data_ptr(),
+                yc.data_ptr(), yv.data_ptr(), mk.data_ptr(), out.data_ptr(), B, V, self.execution_path,
+                ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "tw_flow_log_likelihood")
+        return out
+
+    def conditional_sample(self, atom_types, x_coords, x_velocs, adj_list, edge_batch_idx, masked_elements,
+                           num_samples: int, logger=None) -> Tuple[Tensor, Tensor]:
+        y_c, y_v, _ = self.conditional_sample_with_logp(
+            atom_types=atom_types, x_coords=x_coords, x_velocs=x_velocs, adj_list=adj_list,
+            edge_batch_idx=edge_batch_idx, masked_elements=masked_elements, num_samples=num_samples, logger=logger)
+        return y_c, y_v
+
+    @torch.no_grad()
+    def conditional_sample_with_logp(self, atom_types: Tensor, x_coords: Tensor, x_velocs: Tensor,
+                                     adj_list: Optional[Tensor], edge_batch_idx: Optional[Tensor],
+                                     masked_elements: Tensor, num_samples: int, logger=None,
+                                     z_coords: Optional[Tensor] = None, z_velocs: Optional[Tensor] = None,
+                                     ) -> Tuple[Tensor, Tensor, Tensor]:
+        """Samples y ~ p(.|x) and their log-density: ([S,B,V,3], [S,B,V,3], [S,B]) (flow.py:242-336).
+
+        Extension over the reference signature: `z_coords` / `z_velocs` [S,B,V,3] may carry the
+        latent noise explicitly (already scaled by exp(prior log-scale)); when omitted it is drawn
+        on the device in the reference's order (coords first, flow.py:274-275)."""
+        at, mk, xc, xv = self._prep(atom_types, masked_elements, x_coords, x_velocs)
+        dev = xc.device
+        B, V = xc.shape[0], xc.shape[1]
+        S = int(num_samples)
+        if not (B == 1 or S == 1):
+            # flow.py:326 multiplies a [B,V,1] mask into [S*B,V,3]: torch raises for B>1 and S>1
+            raise RuntimeError(f"The size of tensor a ({B}) must match the size of tensor b ({S * B}) at non-singleton dimension 0")
+        if z_coords is None:
+            z_coords = torch.randn((S, B, V, 3), device=dev) * torch.exp(self.coords_prior_log_scale.detach()).to(dev)
+        if z_velocs is None:
+            z_velocs = torch.randn((S, B, V, 3), device=dev) * torch.exp(self.velocs_prior_log_scale.detach()).to(dev)
+        zc = _lib.require_gpu_tensor(z_coords.to(dev), torch.float32, "z_coords")
+        zv = _lib.require_gpu_tensor(z_velocs.to(dev), torch.float32, "z_velocs")
+        if tuple(zc.shape) != (S, B, V, 3) or tuple(zv.shape) != (S, B, V, 3):
+            raise ValueError("z_coords / z_velocs must have shape [num_samples, B, V, 3]")
+        raw, packed = self._weights(dev)
+        ws = self._ws(dev, S * B, V)
+        y_c = torch.empty((S, B, V, 3), dtype=torch.float32, device=dev)
+        y_v = torch.empty((S, B, V, 3), dtype=torch.float32, device=dev)
+        logp = torch.empty((S, B), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        desc = self.dims.to_desc()
+        with torch.cuda.device(dev):
+            _lib.check(lib.tw_flow_sample_with_logp(
+                C.byref(desc), raw.data_ptr(), _lib.ptr(packed), at.data_ptr(), xc.data_ptr(), xv.data_ptr(),
+                mk.data_ptr(), zc.data_ptr(), zv.data_ptr(), y_c.data_ptr(), y_v.data_ptr(), logp.data_ptr(),
+                S, B, V, self.execution_path, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
+                "tw_flow_sample_with_logp")
+        return y_c, y_v, logp
+
+    # ------------------------------------------------------------------ inspection (tests)
+    @torch.no_grad()
+    def debug_netblock(self, coupling: int, net: int, atom_types, x_coords_centred, x_velocs, masked_elements,
+                       z_other, path: int):
+        """Run one coupling net and return the activations after in_mlp, every encoder layer and
+        out_mlp: ([n_layers+1, N, V, d_model], [N, V, 3]).  Test hook for the HIP kernels."""
+        at, mk, xc, xv, zo = self._prep(atom_types, masked_elements, x_coords_centred, x_velocs, z_other)
+        dev = xc.device
+        n_cond, V = xc.shape[0], xc.shape[1]
+        N = zo.shape[0]
+        raw, packed = self._weights(dev)
+        ws = self._ws(dev, N, V)
+        L, dm = self.dims.n_layers, self.dims.d_model
+        dump = torch.zeros((L + 1) * N * V * dm + N * V * 3, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        desc = self.dims.to_desc()
+        with torch.cuda.device(dev):
+            _lib.check(lib.tw_debug_netblock(
+                C.byref(desc), raw.data_ptr(), _lib.ptr(packed), coupling, net, at.data_ptr(), xc.data_ptr(),
+                xv.data_ptr(), mk.data_ptr(), n_cond, zo.data_ptr(), N, V, path, dump.data_ptr(), ws.data_ptr(),
+                ws.numel(), _lib.stream_ptr(dev)), "tw_debug_netblock")
+        acts = dump[: (L + 1) * N * V * dm].reshape(L + 1, N, V, dm)
+        out = dump[(L + 1) * N * V * dm:].reshape(N, V, 3)
+        return acts, out
