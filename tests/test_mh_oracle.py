@@ -1,0 +1,73 @@
+"""Pin oracle/mh_oracle.py against traces recorded from the reference's own sample_with_model
+(oracle/gen_golden.py::gen_mh_goldens).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as fo
+from oracle import mh_oracle as mo
+from tests import helpers as H
+
+SCENARIOS = {
+    "s10": dict(accept=True, num_proposal_steps=10, num_samples=25),
+    "s10_randv": dict(accept=True, num_proposal_steps=10, num_samples=25, random_velocs=True, resample_velocs=True),
+    "adaptive": dict(accept=True, num_proposal_steps=10, num_samples=30, adaptive_parallelism=True),
+    "noaccept_s1": dict(accept=False, num_proposal_steps=1, num_samples=6),
+    "chirality": dict(accept=True, num_proposal_steps=10, num_samples=20, chirality=True),
+    "init_random": dict(accept=True, num_proposal_steps=4, num_samples=8, initialize_randomly=True),
+}
+STAT_FIELDS = ("acceptance_indicator", "acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin",
+               "energies_pot_delta", "energies_kin_delta")
+
+
+def load_mh():
+    import os
+    z = np.load(os.path.join(H.GOLDEN, "mh_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    return z, sd
+
+
+def replay(z, name, device="cpu"):
+    return mo.ReplayNoise(z[name + "/noise_normal"], z[name + "/noise_normal_sizes"], z[name + "/noise_rand"],
+                          z[name + "/noise_rand_sizes"], z[name + "/noise_randn_like"], device=device)
+
+
+def check_against_golden(z, name, coords, velocs, accepted, stats, tol=2e-5):
+    assert coords.shape == z[name + "/coords"].shape
+    assert int(accepted) == int(z[name + "/accepted"])
+    assert H.rel_err(coords, z[name + "/coords"]) < tol
+    assert H.rel_err(velocs, z[name + "/velocs"]) < tol
+    for f in STAT_FIELDS:
+        a, b = np.asarray(getattr(stats, f)), z[f"{name}/stats_{f}"]
+        assert a.shape == b.shape, f
+        if f == "acceptance_indicator":
+            assert (a.astype(bool) == b.astype(bool)).all()
+        else:
+            assert H.rel_err(a.astype(np.float64), b.astype(np.float64)) < 1e-4, (f, H.rel_err(a, b))
+    # the reference's own invariant (tests/test_evaluation_utils.py:138)
+    assert len(coords) == len(stats.acceptance) + 1
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_mh_oracle_replays_reference(name):
+    z, sd = load_mh()
+    kw = dict(SCENARIOS[name])
+    extra = {}
+    if kw.pop("chirality", False):
+        extra = dict(chirality_centers=torch.from_numpy(z["centres"]),
+                     reference_signs=torch.from_numpy(z[name + "/reference_signs"]))
+    x0, v0 = torch.from_numpy(z["x0"]), torch.from_numpy(z["v0"])
+    model = mo.OracleModel(sd, H.TINY_KERNEL_SPEC)
+    energy = mo.SyntheticEnergy(x0.clone())
+    coords, velocs, accepted, stats = mo.sample_with_model(
+        torch.from_numpy(z["atom_types"]), x0, v0, torch.zeros(1, x0.shape[1], dtype=torch.bool), model, energy,
+        torch.from_numpy(z["masses"]), noise=replay(z, name), **kw, **extra)
+    check_against_golden(z, name, coords, velocs, accepted, stats)
+
+
+def test_compute_num_proposal_steps():
+    # evaluation_utils.py:32-64: ceil(log(1-target)/log(1-p)) clipped to [1, max]
+    assert mo.compute_num_proposal_steps(1e-3, max_steps=100) == 100
+    assert mo.compute_num_proposal_steps(0.5, max_steps=100) == 4
+    assert mo.compute_num_proposal_steps(1.0, max_steps=100) == 1
+    assert mo.compute_num_proposal_steps(0.0, max_steps=7) == 7
