@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""Benchmark of the Timewarp sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one Metropolis-Hastings iteration of `kernel_transformer_nvp` on alanine dipeptide
+with 1000 parallel proposals (BASELINE.json configs[1]): 1000 proposals + log p(y|x) through the
+8-layer flow (reverse pass), potential and kinetic energies, log p(x|y) (forward pass), accept scan.
+Inputs are synthetic (no checkpoint/trajectory exists offline): the PDB geometry of
+simulation/testdata/alanine-dipeptide.pdb, name-seeded random weights with the SURVEY section 8d
+calibration so the acceptance path is non-degenerate, device-generated noise.  Everything is
+resident in HBM before the timed region.
+
+N > 1: one independent chain per rank/GPU (no data-path collective), one all-gather of the
+trajectories at collection time (inside the timed region), `value` = accepted samples of all
+ranks / max-over-ranks time.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+S_PROPOSALS = 1000
+V_ATOMS = 22
+FLOP_PER_SAMPLE_PASS = 1.612e9  # 16 * V * F_blk(V), V = 22
+N_COUPLING = 8
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+# Synthetic-weight calibration (SURVEY section 8d idea, tuned so acceptance is non-degenerate against
+# the stiff bonded terms): identity flow (last out_mlp layer zeroed), coordinate prior std e^-7 nm,
+# velocity prior std 1 with isotropic resampled velocities (the reference's --random-velocities
+# --resample-velocities mode), for which the velocity terms of the MH exponent cancel exactly.
+CALIBRATION = dict(coords_log_scale=-7.0, velocs_log_scale=0.0)
+MH_MODE = dict(accept=True, random_velocs=True, resample_velocs=True)
+
+
+def build_chain(device, seed, proposals):
+    import timewarp_amd as tw
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.utils.evaluation_utils import MetropolisHastingsChain
+
+    model = tw.model_constructor(synthetic.kernel_transformer_nvp_config())
+    model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), base_seed=0, calibrated=True, **CALIBRATION))
+    model = model.to(device).eval()
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+    energy = AmberPotentialEnergyTorch.alanine_dipeptide()
+    batch = single_state_batch("alanine-dipeptide", types, coords, torch.zeros(V_ATOMS, 3))
+    chain = MetropolisHastingsChain(batch, model, device, energy, masses, num_proposal_steps=proposals, **MH_MODE)
+    return chain, model
+
+
+def cpu_baseline(proposals):
+    """The oracle (oracle/flow_oracle.py + oracle/mh_oracle.py + oracle/energy_oracle.c) on this
+    box's host cores: full 1000-proposal MH iterations, bounded to ~10-30 s of CPU work."""
+    from oracle import flow_oracle as fo
+    from oracle import mh_oracle as mo
+    from timewarp_amd import synthetic
+    from timewarp_amd.forcefield import alanine_dipeptide_amber99sb
+    import numpy as np
+    import subprocess
+
+    so = os.path.join(ROOT, "oracle", "_build", "libenergy_oracle.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+    lib = C.CDLL(so)
+    tables = alanine_dipeptide_amber99sb()
+
+    class FF(C.Structure):
+        _fields_ = [(n, C.c_int32) for n in ("n_atoms", "n_bonds", "n_angles", "n_torsions", "n_exceptions", "has_gbsa")] + \
+                   [(n, C.c_double) for n in ("cutoff", "rf_dielectric", "solute_dielectric", "solvent_dielectric", "surface_area_energy")] + \
+                   [(n, C.c_void_p) for n in ("bond_idx", "bond_par", "angle_idx", "angle_par", "torsion_idx", "torsion_par", "exc_idx", "exc_par", "atom_par")]
+
+    arrs = [np.ascontiguousarray(a) for a in (
+        tables.bond_idx.astype(np.int32), tables.bond_par, tables.angle_idx.astype(np.int32), tables.angle_par,
+        tables.torsion_idx.astype(np.int32), tables.torsion_par, tables.exc_idx.astype(np.int32), tables.exc_par, tables.atom_par)]
+    ff = FF(tables.n_atoms, len(arrs[0]), len(arrs[2]), len(arrs[4]), len(arrs[6]), int(tables.has_gbsa), tables.cutoff,
+            tables.rf_dielectric, tables.solute_dielectric, tables.solvent_dielectric, tables.surface_area_energy,
+            *[a.ctypes.data for a in arrs])
+
+    class CEnergy:
+        kbT = 8.314462618e-3 * 310.0
+
+        def __call__(self, coords):
+            x = np.ascontiguousarray(coords.reshape(-1, V_ATOMS, 3).numpy(), dtype=np.float32)
+            out = np.zeros(x.shape[0])
+            lib.oracle_amber_energy(C.byref(ff), x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), None,
+                                    C.c_int64(x.shape[0]))
+            return torch.from_numpy(out).to(torch.float32)[:, None]
+
+    class Noise:
+        def __init__(self):
+            self.g = torch.Generator().manual_seed(0)
+
+        def randn_like(self, t):
+            return torch.randn(t.shape, generator=self.g)
+
+        def latents(self, S, B, V, sc, sv):
+            return torch.randn((S, B, V, 3), generator=self.g) * sc, torch.randn((S, B, V, 3), generator=self.g) * sv
+
+        def uniform(self, S):
+            return torch.rand(S, generator=self.g)
+
+    threads = torch.get_num_threads()
+    spec = fo.FlowSpec(variant="kernel")
+    sd = fo.synth_state_dict(fo.make_template(spec), 0, calibrated=True, **CALIBRATION)
+    model = mo.OracleModel(sd, spec)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    velocs = torch.zeros(V_ATOMS, 3)
+    mask = torch.zeros(1, V_ATOMS, dtype=torch.bool)
+    kw = dict(num_proposal_steps=proposals, **MH_MODE)
+    # warm-up on a small batch (thread pools, allocator)
+    mo.sample_with_model(types[None], coords[None], velocs[None], mask, model, CEnergy(), masses, 1, Noise(),
+                         num_proposal_steps=16, **MH_MODE)
+    iters, accepted, t0 = 0, 0, time.perf_counter()
+    x_c, x_v = coords[None], velocs[None]
+    while True:
+        c, v, acc, _ = mo.sample_with_model(types[None], x_c, x_v, mask, model, CEnergy(), masses, 1, Noise(), **kw)
+        x_c, x_v = torch.from_numpy(c[-1:]), torch.from_numpy(v[-1:])
+        iters += 1
+        accepted += acc
+        elapsed = time.perf_counter() - t0
+        if elapsed > 10.0 or iters >= 3:
+            break
+    return {
+        "value": accepted / elapsed,
+        "unit": "MH-accepted samples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{iters} full MH iteration(s) of {proposals} proposals (flow reverse+forward via oracle/flow_oracle.py on torch-CPU fp32, "
+                  f"energies via oracle/energy_oracle.c on 1 core, accept scan) in {elapsed:.2f} s",
+        "proposals_per_s": iters * proposals / elapsed,
+        "s_per_iteration": elapsed / iters,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--proposals", type=int, default=S_PROPOSALS)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from timewarp_amd import _lib, distributed
+
+    rank, world, local = distributed.init_from_env("nccl")
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    lib = _lib.load()
+
+    chain, model = build_chain(device, distributed.chain_seed(args.seed, rank), args.proposals)
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            chain.step()
+    torch.cuda.synchronize()
+    acc0, prop0 = chain.accepted, chain.proposals
+    states0 = sum(t.shape[0] for t in chain.chain_c)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    lib.tw_profile_begin()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(args.steps):
+            chain.step()
+        traj, _ = chain.trajectory()
+        gathered, _ = distributed.gather_trajectories(traj)  # the one collective (no-op at N=1)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches = C.c_double(0.0), C.c_int64(0)
+    lib.tw_profile_end(C.byref(k_ms), C.byref(k_launches))
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+    states = sum(x.shape[0] for x in chain.chain_c) - states0
+    accepted, proposals, states = distributed.all_reduce_counters(
+        [chain.accepted - acc0, chain.proposals - prop0, states], device)
+
+    if rank == 0:
+        launches = max(int(k_launches.value), 1)
+        avg_ms = k_ms.value / launches
+        flop_per_launch = FLOP_PER_SAMPLE_PASS * args.proposals / N_COUPLING
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "MH-accepted samples/sec (whole node), alanine-dipeptide kernel_transformer_nvp",
+            "value": accepted / elapsed,
+            "unit": "MH-accepted samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "kernel_transformer_nvp.yaml, alanine-dipeptide (22 atoms), 1000-proposal parallel MH, "
+                            "1 chain per GPU (BASELINE.json configs[1]; configs[2] when n_gpus=8)",
+                "proposals_per_step": args.proposals,
+                "chains_per_gpu": 1,
+                "weights": "name-seeded synthetic, SURVEY 8d calibration",
+                "execution_path": "fused f32-MFMA",
+            },
+            "proposals_per_s": proposals / elapsed,
+            "chain_states_per_s": states / elapsed,
+            "accepted_per_step": accepted / (args.steps * world),
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "tw::netblock_kernel<3> (both coupling nets of one coupling layer, all proposals)",
+                "achieved": achieved,
+                "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "avg_launch_ms": avg_ms,
+                "launches": int(k_launches.value),
+                "algorithmic_flop_per_launch": flop_per_launch,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.proposals)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -177,7 +177,9 @@ int tw_amber_energy(const tw_forcefield* ff, const float* coords, double* out_en
  *   p_acc = min(1, e^-exponent); accepted[s] = u[s] < p_acc; k = first accepted index (or S-1);
  *   if any accepted: x <- y[k].  result (device, int32[4]) = {k_unclipped, any_accepted, 0, 0}.
  * energy = (e_pot_y - e_pot_x) + (e_kin_y - e_kin_x) is formed by the caller.
- * x_coords/x_velocs [n_atoms,3] are the chain state, updated in place. */
+ * x_coords/x_velocs [n_atoms,3] are the chain state, updated in place; pass both NULL to only
+ * score the proposals (the host then applies the reference's `k = min(k, N - i)` clipping,
+ * evaluation_utils.py:680, before it moves the chain). */
 int tw_mh_accept(const float* energy, const float* p_xy, const float* p_yx, const float* u,
                  const float* y_coords, const float* y_velocs, float* x_coords, float* x_velocs,
                  float* out_exponent, float* out_p_acc, uint8_t* out_accepted, int32_t* result,
@@ -188,6 +190,13 @@ int tw_mh_accept(const float* energy, const float* p_xy, const float* p_yx, cons
 int tw_chirality_changed(const float* coords, const int32_t* centres, const float* reference_signs,
                          int32_t n_centres, uint8_t* out_changed, int64_t n_rows, int32_t n_atoms,
                          void* stream);
+
+/* Measurement hooks (bench.py roofline leg): between tw_profile_begin() and tw_profile_end() every
+ * launch of the dominant kernel (the fused net-block kernel) is bracketed by hipEvents recorded on
+ * the launch stream.  tw_profile_end synchronises those events and returns (host pointers) the
+ * summed kernel time in milliseconds and the number of launches.  Not thread-safe. */
+int tw_profile_begin(void);
+int tw_profile_end(double* total_ms, int64_t* launches);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every
  * stage (in_mlp, each encoder layer, out_mlp) as [n_rows,n_atoms,d] row-major floats.

@@ -414,7 +414,8 @@ def synth_tensor(name: str, shape, base_seed: int = 0) -> Tensor:
     return t
 
 
-def synth_state_dict(template: Dict[str, Tensor], base_seed: int = 0, calibrated: bool = False) -> StateDict:
+def synth_state_dict(template: Dict[str, Tensor], base_seed: int = 0, calibrated: bool = False,
+                     coords_log_scale: float = -5.0, velocs_log_scale: float = -5.0) -> StateDict:
     """Fill a state_dict with the name-seeded recipe.  `template` supplies names/shapes (and the
     values of persistent buffers, which are kept).  calibrated=True applies SURVEY section 8d's
     throughput calibration: prior log-scales = -5 and the last out_mlp layer zeroed (s=1, t=0)."""
@@ -426,8 +427,10 @@ def synth_state_dict(template: Dict[str, Tensor], base_seed: int = 0, calibrated
             out[k] = synth_tensor(k, v.shape, base_seed).to(v.dtype)
     if calibrated:
         for k in list(out):
-            if k in ("coords_prior_log_scale", "velocs_prior_log_scale"):
-                out[k] = torch.tensor(-5.0)
+            if k == "coords_prior_log_scale":
+                out[k] = torch.tensor(float(coords_log_scale))
+            if k == "velocs_prior_log_scale":
+                out[k] = torch.tensor(float(velocs_log_scale))
             if ".out_mlp._layers.2." in k:
                 out[k] = torch.zeros_like(out[k])
     return out

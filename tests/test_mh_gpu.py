@@ -1,0 +1,92 @@
+"""The product MH loop (HIP) replayed on the reference's recorded traces, plus the energy kernel
+against the C oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mh_oracle as mo
+from tests import helpers as H
+from tests.test_mh_oracle import SCENARIOS, check_against_golden, load_mh, replay
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_sample_with_model_replays_reference(name):
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.utils.evaluation_utils import sample_with_model
+
+    z, sd = load_mh()
+    kw = dict(SCENARIOS[name])
+    extra = {}
+    if kw.pop("chirality", False):
+        extra = dict(chirality_centers=torch.from_numpy(z["centres"]),
+                     reference_signs=torch.from_numpy(z[name + "/reference_signs"]))
+    model = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2,
+                              lengthscales=(0.1, 0.5, 1.2), path=2)
+    x0, v0 = torch.from_numpy(z["x0"]), torch.from_numpy(z["v0"])
+    batch = single_state_batch("tiny", torch.from_numpy(z["atom_types"]), x0, v0)
+    energy = mo.SyntheticEnergy(x0.clone().cuda())  # a torch callable with .kbT: the loop's only requirement
+    coords, velocs, accepted, stats = sample_with_model(
+        batch, model, torch.device("cuda"), energy, torch.from_numpy(z["masses"]), disable_tqdm=True,
+        noise=replay(z, name, device="cuda"), **kw, **extra)
+    check_against_golden(z, name, coords, velocs, accepted, stats)
+
+
+class _OracleFF(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_atoms", "n_bonds", "n_angles", "n_torsions", "n_exceptions", "has_gbsa")] + \
+               [(n, C.c_double) for n in ("cutoff", "rf_dielectric", "solute_dielectric", "solvent_dielectric", "surface_area_energy")] + \
+               [(n, C.c_void_p) for n in ("bond_idx", "bond_par", "angle_idx", "angle_par", "torsion_idx", "torsion_par", "exc_idx", "exc_par", "atom_par")]
+
+
+def oracle_energy(tables, coords):
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libenergy_oracle.so"))
+    arrs = [np.ascontiguousarray(a) for a in (
+        tables.bond_idx.astype(np.int32), tables.bond_par, tables.angle_idx.astype(np.int32), tables.angle_par,
+        tables.torsion_idx.astype(np.int32), tables.torsion_par, tables.exc_idx.astype(np.int32), tables.exc_par, tables.atom_par)]
+    ff = _OracleFF(tables.n_atoms, len(arrs[0]), len(arrs[2]), len(arrs[4]), len(arrs[6]), int(tables.has_gbsa),
+                   tables.cutoff, tables.rf_dielectric, tables.solute_dielectric, tables.solvent_dielectric,
+                   tables.surface_area_energy, *[a.ctypes.data for a in arrs])
+    x = np.ascontiguousarray(coords, dtype=np.float32)
+    n = x.shape[0]
+    out, terms = np.zeros(n), np.zeros((n, 5))
+    lib.oracle_amber_energy(C.byref(ff), x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                            terms.ctypes.data_as(C.c_void_p), C.c_int64(n))
+    return out, terms
+
+
+def test_amber_energy_kernel_vs_c_oracle():
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+
+    e = AmberPotentialEnergyTorch.alanine_dipeptide()
+    assert abs(e.kbT - 2.57748) < 1e-4  # R * 310 K
+    d, _ = H.load("kernel_full_ad")
+    g = torch.Generator().manual_seed(1)
+    x = d["x_coords"] + torch.randn(64, 22, 3, generator=g) * 0.01
+    x[5] = d["x_coords"][0] * 3.0  # stretched: some pairs beyond the 2 nm cutoff
+    out, terms = e.energy_and_terms(x.cuda(), want_terms=True)
+    ref, ref_terms = oracle_energy(e.tables, x.numpy())
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-10, atol=1e-8)
+    assert np.allclose(terms.cpu().numpy(), ref_terms, rtol=1e-9, atol=1e-8)
+    assert e(x.cuda()).shape == (64, 1) and e(x.cuda()).dtype == torch.float32
+
+
+def test_accept_kernel_first_index_and_clipping():
+    from timewarp_amd.utils.evaluation_utils import _mh_accept
+
+    S = 1000
+    g = torch.Generator().manual_seed(0)
+    energy = torch.randn(S, generator=g) * 3 + 4
+    pxy, pyx, u = torch.randn(S, generator=g), torch.randn(S, generator=g), torch.rand(S, generator=g)
+    ex, p_acc, acc, res = _mh_accept(energy.cuda(), pxy.cuda(), pyx.cuda(), u.cuda())
+    e_ref = energy + pxy - pyx
+    p_ref = torch.clamp(torch.exp(-e_ref), max=1.0)
+    a_ref = u < p_ref
+    assert torch.allclose(ex.cpu(), e_ref) and torch.allclose(p_acc.cpu(), p_ref, rtol=1e-6)
+    assert (acc.cpu().bool() == a_ref).all()
+    assert int(res[0]) == int(a_ref.nonzero()[0]) and int(res[1]) == 1
+    ex, p_acc, acc, res = _mh_accept((energy + 1e4).cuda(), pxy.cuda(), pyx.cuda(), u.cuda())
+    assert int(res[0]) == S - 1 and int(res[1]) == 0

@@ -93,6 +93,8 @@ SIGNATURES = {
     "tw_amber_energy": (C.c_int, [C.POINTER(ForceField), _P, _P, _P, _I64, _P]),
     "tw_mh_accept": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "tw_chirality_changed": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _I32, _P]),
+    "tw_profile_begin": (C.c_int, []),
+    "tw_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tw_debug_netblock": (
         C.c_int,
         [_DESC, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _P, _P, _I64, _P],

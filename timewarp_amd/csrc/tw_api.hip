@@ -235,9 +235,9 @@ int tw_amber_energy(const tw_forcefield* ff, const float* coords, double* out_en
 int tw_mh_accept(const float* energy, const float* p_xy, const float* p_yx, const float* u, const float* y_coords,
                  const float* y_velocs, float* x_coords, float* x_velocs, float* out_exponent, float* out_p_acc,
                  uint8_t* out_accepted, int32_t* result, int64_t n_proposals, int32_t n_atoms, void* stream) {
-  TW_REQUIRE(energy && p_xy && p_yx && u && y_coords && y_velocs && x_coords && x_velocs && out_exponent && out_p_acc &&
-                 out_accepted && result,
-             "NULL pointer argument");
+  TW_REQUIRE(energy && p_xy && p_yx && u && out_exponent && out_p_acc && out_accepted && result, "NULL pointer argument");
+  TW_REQUIRE((x_coords == nullptr) == (x_velocs == nullptr), "x_coords and x_velocs must both be given or both be NULL");
+  TW_REQUIRE(!x_coords || (y_coords && y_velocs), "state update needs y_coords / y_velocs");
   TW_REQUIRE(n_proposals > 0 && n_proposals < (1LL << 30), "bad n_proposals");
   return launch_mh_accept(energy, p_xy, p_yx, u, y_coords, y_velocs, x_coords, x_velocs, out_exponent, out_p_acc,
                           out_accepted, result, n_proposals, n_atoms, (hipStream_t)stream);
@@ -249,6 +249,9 @@ int tw_chirality_changed(const float* coords, const int32_t* centres, const floa
   return launch_chirality(coords, centres, reference_signs, n_centres, out_changed, n_rows, n_atoms,
                           (hipStream_t)stream);
 }
+
+int tw_profile_begin(void) { return profile_begin(); }
+int tw_profile_end(double* total_ms, int64_t* launches) { return profile_end(total_ms, launches); }
 
 int tw_debug_netblock(const tw_flow_desc* desc, const float* raw, const float* packed, int32_t coupling, int32_t net,
                       const int32_t* atom_types, const float* x_coords, const float* x_velocs, const uint8_t* masked,

@@ -119,5 +119,7 @@ int launch_coupling(const float* s_raw, const float* t, const uint8_t* masked, i
 int pack_weights(const tw_flow_desc& d, const float* raw, float* packed, hipStream_t s);
 int debug_netblock_simple(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
 int debug_netblock_fused(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
+int profile_begin();
+int profile_end(double* total_ms, int64_t* launches);
 
 }  // namespace tw

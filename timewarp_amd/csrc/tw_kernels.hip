@@ -303,7 +303,7 @@ __global__ void mh_accept_kernel(const float* __restrict__ energy, const float* 
   __syncthreads();
   const int k = first;
   const bool any = k != 0x7fffffff;
-  if (any)
+  if (any && xc && xv)
     for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) {
       xc[i] = yc[(int64_t)k * 3 * V + i];
       xv[i] = yv[(int64_t)k * 3 * V + i];

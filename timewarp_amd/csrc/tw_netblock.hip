@@ -16,6 +16,9 @@
 //    fp64 at pack time; the per-head mixing A_h X is an MFMA against block-diagonal score
 //    fragments, with X transposed through a wave-private LDS tile.
 //  * blockIdx -> (net, block) is XCD-aware: XCDs 0-3 stream the scale net, 4-7 the shift net.
+#include <utility>
+#include <vector>
+
 #include "tw_common.h"
 
 namespace tw {
@@ -614,6 +617,32 @@ netblock_kernel(const NBParams p) {
 // ================================================================================================
 // host side
 // ================================================================================================
+// optional timing of the net-block launches (bench.py's roofline leg): HIP events on the launch stream
+static bool g_profile = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
+static size_t g_events_used = 0;
+
+int profile_begin() {
+  g_profile = true;
+  g_events_used = 0;
+  return TW_OK;
+}
+
+int profile_end(double* total_ms, int64_t* launches) {
+  g_profile = false;
+  double ms = 0.0;
+  for (size_t i = 0; i < g_events_used; ++i) {
+    TW_HIP_CHECK(hipEventSynchronize(g_events[i].second));
+    float t = 0.f;
+    TW_HIP_CHECK(hipEventElapsedTime(&t, g_events[i].first, g_events[i].second));
+    ms += t;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = (int64_t)g_events_used;
+  g_events_used = 0;
+  return TW_OK;
+}
+
 struct FusedWs {
   float *s_out, *t_out, *sfrag;
   int64_t nblk_scores, bytes;
@@ -698,14 +727,35 @@ static int launch_netblock(const FlowArgs& a, const RawLayout& L, const FusedGeo
   const int wgs_per_net = (p.nblocks + 3) / 4;
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
   const size_t shm = (size_t)4 * 16 * g.nt * XS * sizeof(float);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (g_profile) {
+    if (g_events_used == g_events.size()) {
+      hipEvent_t e0, e1;
+      TW_HIP_CHECK(hipEventCreate(&e0));
+      TW_HIP_CHECK(hipEventCreate(&e1));
+      g_events.emplace_back(e0, e1);
+    }
+    ev0 = g_events[g_events_used].first;
+    ev1 = g_events[g_events_used].second;
+    ++g_events_used;
+    TW_HIP_CHECK(hipEventRecord(ev0, a.stream));
+  }
+  static bool attr3 = false, attr4 = false;
   if (g.nt == 3) {
-    TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    if (!attr3) {
+      TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr3 = true;
+    }
     hipLaunchKernelGGL(netblock_kernel<3>, dim3(grid), dim3(256), shm, a.stream, p);
   } else {
-    TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    if (!attr4) {
+      TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr4 = true;
+    }
     hipLaunchKernelGGL(netblock_kernel<4>, dim3(grid), dim3(256), shm, a.stream, p);
   }
   TW_LAUNCH_CHECK();
+  if (ev1) TW_HIP_CHECK(hipEventRecord(ev1, a.stream));
   return TW_OK;
 }
 

@@ -1,0 +1,70 @@
+"""Potential-energy callable with the contract of `OpenmmPotentialEnergyTorch`
+(utils/openmm/openmm_bridge.py:252-307): `energy(coords[..., V, 3]) -> [N, 1]` in kJ/mol on the
+input's device/dtype, attribute `kbT` (kJ/mol).  The arithmetic is the HIP kernel behind
+`tw_amber_energy`; there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .forcefield import ForceFieldTables, alanine_dipeptide_amber99sb, tables_from_openmm_system
+
+GAS_CONSTANT = 8.314462618e-3  # kJ/(mol K), as openmm.unit.MOLAR_GAS_CONSTANT_R
+
+
+class AmberPotentialEnergyTorch:
+    def __init__(self, tables: ForceFieldTables, temperature: float = 310.0):
+        self.tables = tables
+        self.temperature = float(temperature)
+        self._dev = {}
+
+    @classmethod
+    def alanine_dipeptide(cls, temperature: float = 310.0) -> "AmberPotentialEnergyTorch":
+        """Preset `alanine-dipeptide` of simulation/md.py:31-37,75-82 (310 K, 2 nm cutoff, OBC)."""
+        return cls(alanine_dipeptide_amber99sb(), temperature)
+
+    @classmethod
+    def from_openmm(cls, system, integrator=None, platform_name=None, platform_properties=None, **_):
+        """Same positional arguments as OpenmmPotentialEnergyTorch(system, integrator, platform_name=...)
+        (evaluate.py:296-301); the platform arguments are irrelevant here and ignored."""
+        temperature = 310.0
+        if integrator is not None and hasattr(integrator, "getTemperature"):
+            import openmm.unit as u
+
+            temperature = integrator.getTemperature().value_in_unit(u.kelvin)
+        return cls(tables_from_openmm_system(system), temperature)
+
+    @property
+    def kbT(self) -> float:
+        """openmm_bridge.py:299-307: R * T in kJ/mol."""
+        return GAS_CONSTANT * self.temperature
+
+    def _device_ff(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = self.tables.to_device(device)
+        return self._dev[key]
+
+    @torch.no_grad()
+    def energy_and_terms(self, coords: torch.Tensor, want_terms: bool = False):
+        V = self.tables.n_atoms
+        x = _lib.require_gpu_tensor(coords.reshape(-1, V, 3), torch.float32, "coords")
+        n = x.shape[0]
+        dev = x.device
+        ff = self._device_ff(dev)
+        out = torch.empty(n, dtype=torch.float64, device=dev)
+        terms = torch.empty((n, 5), dtype=torch.float64, device=dev) if want_terms else None
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.tw_amber_energy(C.byref(ff.struct), x.data_ptr(), out.data_ptr(), _lib.ptr(terms), n,
+                                           _lib.stream_ptr(dev)), "tw_amber_energy")
+        return out, terms
+
+    def __call__(self, coords: torch.Tensor) -> torch.Tensor:
+        e, _ = self.energy_and_terms(coords)
+        return e.to(coords.dtype)[:, None]
+
+    forward = __call__
+    energy = __call__

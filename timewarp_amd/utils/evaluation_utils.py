@@ -1,0 +1,323 @@
+"""Batched Metropolis-Hastings sampling with the flow as proposal: the sampling half of the
+reference's utils/evaluation_utils.py (`sample_with_model` :468-745, `compute_kinetic_energy`
+:416-436, `compute_num_proposal_steps` :32-64, `ChainStats` :67-114), same names, arguments and
+return values.  Every numeric step of an iteration runs on the GPU through libtimewarp_hip.so:
+
+    proposals + log p(y|x)      tw_flow_sample_with_logp      (model.conditional_sample_with_logp)
+    potential energies          tw_amber_energy               (the energy callable)
+    kinetic energies            tw_kinetic_energy
+    chirality guard             tw_chirality_changed
+    log p(x|y) of the reverse   tw_flow_log_likelihood        (model.log_likelihood)
+    exponent, p_acc, u < p_acc, first accepted index          tw_mh_accept
+
+The host reads back 8 bytes per iteration (first accepted index, any-accepted flag); chain states
+and ChainStats stay on the device until the loop ends (the reference does >= 10 D2H copies per
+iteration).  Two redundancies of the reference are not reproduced because they cannot change the
+result: E_pot and E_kin of the current state are evaluated once instead of on S identical copies
+(evaluation_utils.py:620-629)."""
+from __future__ import annotations
+
+import pickle
+from dataclasses import astuple, dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+from tqdm.auto import tqdm
+
+from .. import _lib
+
+
+def compute_num_proposal_steps(current_acceptance_probability: float, target_acceptance_per_step: float = 0.9,
+                               max_num_proposal_steps: int = 100) -> int:
+    """Number of parallel proposals so that at least one is accepted with the target probability:
+    ceil(log(1-target) / log(1-p)), p clipped to [1e-3, 1-1e-3], result in [1, max]."""
+    p_rej = min(max(1 - current_acceptance_probability, 1e-3), 1 - 1e-3)
+    with np.errstate(all="ignore"):
+        wanted = np.nan_to_num(np.log(1 - target_acceptance_per_step) / np.log(p_rej), nan=np.inf)
+    return max(int(np.ceil(min(wanted, max_num_proposal_steps))), 1)
+
+
+@dataclass
+class ChainStats:
+    """Per-emitted-state statistics of one chain (same nine fields as the reference)."""
+
+    acceptance_indicator: np.ndarray
+    acceptance: np.ndarray
+    p_xy: np.ndarray
+    p_yx: np.ndarray
+    exponent: np.ndarray
+    energies_pot: np.ndarray
+    energies_kin: np.ndarray
+    energies_pot_delta: np.ndarray
+    energies_kin_delta: np.ndarray
+
+    def __len__(self):
+        return len(self.acceptance)
+
+    def __getitem__(self, key):
+        return ChainStats(*map(lambda x: x[key], astuple(self)))
+
+    def thin(self, step):
+        return ChainStats(*map(lambda x: x[0: x.shape[0]: step], astuple(self)))
+
+    def save(self, path):
+        with open(path, "wb") as f:
+            pickle.dump(self, f)
+
+    @staticmethod
+    def load(path):
+        with open(path, "rb") as f:
+            return pickle.load(f)
+
+
+def compute_kinetic_energy(velocs: torch.Tensor, masses: torch.Tensor, random_velocs: bool = False,
+                           kbT: Optional[float] = None) -> torch.Tensor:
+    """0.5 * sum v^2 (isotropic-Gaussian velocities) or 0.5 * sum m v^2 / kbT; [batch]."""
+    if not random_velocs:
+        assert kbT, "Requires kbT to compute energy"
+    v = _lib.require_gpu_tensor(velocs, torch.float32, "velocs")
+    n, V = v.shape[0], v.shape[1]
+    m = _lib.require_gpu_tensor(masses.to(v.device).reshape(-1), torch.float32, "masses")
+    out = torch.empty(n, dtype=torch.float32, device=v.device)
+    lib = _lib.load()
+    with torch.cuda.device(v.device):
+        _lib.check(lib.tw_kinetic_energy(v.data_ptr(), m.data_ptr(), int(random_velocs), float(kbT or 0.0),
+                                         out.data_ptr(), n, V, _lib.stream_ptr(v.device)), "tw_kinetic_energy")
+    return out
+
+
+def check_symmetry_change(coords: torch.Tensor, chirality_centers: torch.Tensor, reference_signs: torch.Tensor) -> torch.Tensor:
+    """True where the sign of the triple product at any chirality centre differs from the
+    reference (utils/chirality.py:40-80); [batch] bool."""
+    x = _lib.require_gpu_tensor(coords, torch.float32, "coords")
+    n, V = x.shape[0], x.shape[1]
+    cen = _lib.require_gpu_tensor(chirality_centers.to(x.device), torch.int32, "chirality_centers")
+    ref = _lib.require_gpu_tensor(reference_signs.to(x.device).reshape(-1), torch.float32, "reference_signs")
+    out = torch.empty(n, dtype=torch.uint8, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.tw_chirality_changed(x.data_ptr(), cen.data_ptr(), ref.data_ptr(), cen.shape[0], out.data_ptr(),
+                                            n, V, _lib.stream_ptr(x.device)), "tw_chirality_changed")
+    return out.bool()
+
+
+class DeviceNoise:
+    """Random draws from the device generator, in the reference's order and shapes."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def randn_like(self, t):
+        return torch.randn_like(t)
+
+    def latents(self, S, B, V, scale_c, scale_v):
+        zc = torch.randn((S, B, V, 3), device=self.device) * scale_c
+        zv = torch.randn((S, B, V, 3), device=self.device) * scale_v
+        return zc, zv
+
+    def uniform(self, S):
+        return torch.rand(S, device=self.device)
+
+    def rotation(self):
+        # uniform SO(3) via QR of a Gaussian matrix (the reference uses scipy's Rotation.random())
+        q, r = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))
+        q = q * torch.sign(torch.diagonal(r))
+        if torch.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        return q.to(torch.float32).to(self.device)
+
+
+def _mh_accept(energy, p_xy, p_yx, u):
+    S = energy.shape[0]
+    dev = energy.device
+    ex = torch.empty(S, dtype=torch.float32, device=dev)
+    p_acc = torch.empty(S, dtype=torch.float32, device=dev)
+    acc = torch.empty(S, dtype=torch.uint8, device=dev)
+    res = torch.empty(4, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.tw_mh_accept(energy.data_ptr(), p_xy.data_ptr(), p_yx.data_ptr(), u.data_ptr(), None, None, None,
+                                    None, ex.data_ptr(), p_acc.data_ptr(), acc.data_ptr(), res.data_ptr(), S, 0,
+                                    _lib.stream_ptr(dev)), "tw_mh_accept")
+    return ex, p_acc, acc, res
+
+
+class MetropolisHastingsChain:
+    """State and one-iteration `step()` of the loop in `sample_with_model` (reference
+    evaluation_utils.py:517-745).  `sample_with_model` drives it until enough states are emitted;
+    bench.py drives it for an exact number of iterations."""
+
+    KEYS = ("ind", "acc", "pxy", "pyx", "exp", "epot", "ekin", "dpot", "dkin")
+
+    def __init__(self, batch, model, device, energy_fn, masses, accept=False, random_velocs=False,
+                 resample_velocs=False, initialize_randomly=False, num_proposal_steps=1, adaptive_parallelism=False,
+                 acceptance_rate_smoothing_factor=0.01, rotate=False, reference_signs=None, chirality_centers=None,
+                 noise=None):
+        assert batch.atom_coords.size(0) == 1, "only batch-size of 1 is supported"
+        self.device = device = torch.device(device)
+        self.model, self.energy_fn = model, energy_fn
+        self.noise = noise or DeviceNoise(device)
+        f32 = torch.float32
+        self.accept, self.random_velocs, self.resample_velocs, self.rotate = accept, random_velocs, resample_velocs, rotate
+        self.adaptive, self.smoothing = adaptive_parallelism, acceptance_rate_smoothing_factor
+        self.x_coords = batch.atom_coords.to(device, f32).contiguous()
+        self.x_velocs = (self.noise.randn_like(self.x_coords) if random_velocs
+                         else batch.atom_velocs.to(device, f32).contiguous())
+        self.masked = batch.masked_elements.to(device)
+        self.adj_list = batch.adj_list.to(device) if batch.adj_list is not None else None
+        self.ebi = batch.edge_batch_idx.to(device) if batch.edge_batch_idx is not None else None
+        self.atom_types = batch.atom_types.to(device)
+        self.masses = masses.to(device, f32)
+        self.V = self.x_coords.shape[1]
+        self.use_chirality = chirality_centers is not None and reference_signs is not None
+        self.chirality_centers, self.reference_signs = chirality_centers, reference_signs
+        if initialize_randomly:
+            print("Initializaing chain at a random point rather than a data sample.")
+            yc, yv, _ = self._propose(self.noise.randn_like(self.x_coords), self.noise.randn_like(self.x_velocs), 1)
+            self.x_coords, self.x_velocs = yc.squeeze(0).contiguous(), yv.squeeze(0).contiguous()
+        self.kbT = energy_fn.kbT
+        self.chain_c, self.chain_v = [self.x_coords.clone()], [self.x_velocs.clone()]
+        self.rec = {k: [] for k in self.KEYS}
+        self.accepted = 0
+        self.proposals = 0
+        self.p_bar = 1e-3  # start by proposing as many as possible
+        self.s_max = num_proposal_steps
+        self.S = self.s_max if not adaptive_parallelism else compute_num_proposal_steps(self.p_bar, max_num_proposal_steps=self.s_max)
+        self.sgn = 1.0 if random_velocs else -1.0
+
+    def _propose(self, xc, xv, S):
+        sc = torch.exp(self.model.coords_prior_log_scale.detach()).to(self.device)
+        sv = torch.exp(self.model.velocs_prior_log_scale.detach()).to(self.device)
+        zc, zv = self.noise.latents(S, 1, self.V, sc, sv)
+        return self.model.conditional_sample_with_logp(
+            atom_types=self.atom_types, x_coords=xc, x_velocs=xv, adj_list=self.adj_list, edge_batch_idx=self.ebi,
+            masked_elements=self.masked, num_samples=S, z_coords=zc, z_velocs=zv)
+
+    def step(self, remaining: Optional[int] = None) -> int:
+        """One MH iteration; returns the number of chain states emitted (k + 1).  `remaining`
+        = num_samples - i applies the reference's clip `k = min(k, N - i)` (:680)."""
+        S, V, device = self.S, self.V, self.device
+        model, noise, kbT = self.model, self.noise, self.kbT
+        x_coords, x_velocs = self.x_coords, self.x_velocs
+        if self.random_velocs and self.resample_velocs:
+            x_velocs = noise.randn_like(x_velocs)
+        if self.rotate:
+            # the reference's (Q @ x.T).T raises for a [1,V,3] tensor; this applies the intended rotation
+            Q = noise.rotation().to(x_coords)
+            x_coords = (x_coords @ Q.T).contiguous()
+            x_velocs = (x_velocs @ Q.T).contiguous()
+
+        y_c, y_v, p_xy = self._propose(x_coords, x_velocs, S)
+        y_c, y_v = y_c.squeeze(1), y_v.squeeze(1)
+        # current state: one evaluation broadcast over the S proposals
+        e_pot_x = (self.energy_fn(x_coords) / kbT).squeeze(-1)
+        e_kin_x = compute_kinetic_energy(x_velocs, self.masses, random_velocs=self.random_velocs, kbT=kbT)
+        e_kin_y = compute_kinetic_energy(y_v, self.masses, random_velocs=self.random_velocs, kbT=kbT)
+        e_pot_y = (self.energy_fn(y_c) / kbT).squeeze(-1)
+        if self.use_chirality:
+            changed = check_symmetry_change(y_c, self.chirality_centers, self.reference_signs)
+            e_pot_y = torch.where(changed, e_pot_y + 2000, e_pot_y)
+        e_kin = e_kin_y - e_kin_x
+        e_pot = e_pot_y - e_pot_x
+        energy = (e_pot + e_kin).contiguous()
+
+        sgn = self.sgn
+        p_yx = model.log_likelihood(
+            atom_types=self.atom_types.expand(S, V), y_coords=x_coords.expand(S, V, 3),
+            y_velocs=(sgn * x_velocs).expand(S, V, 3), x_coords=y_c, x_velocs=sgn * y_v, adj_list=self.adj_list,
+            edge_batch_idx=self.ebi, masked_elements=self.masked.expand(S, V))
+        p_xy = p_xy.reshape(S).contiguous()
+        self.proposals += S
+
+        if self.accept:
+            u = noise.uniform(S).to(device, torch.float32).contiguous()
+            ex, p_acc, acc, res = _mh_accept(energy, p_xy, p_yx, u)
+            k_true, any_acc = (int(v) for v in res[:2].tolist())  # the one host sync of the iteration
+            if any_acc:
+                self.accepted += 1
+            k = k_true if remaining is None else min(k_true, remaining)  # NB: N - i, not N - i - 1
+            moved = bool(any_acc) and k == k_true
+            self.rec["ind"].append(acc[: k + 1].bool())
+            self.p_bar = self.smoothing * (1 - (not any_acc)) + (1 - self.smoothing) ** k * self.p_bar
+            if self.adaptive:
+                self.S = compute_num_proposal_steps(self.p_bar, max_num_proposal_steps=self.s_max)
+        elif S == 1:
+            ex = energy + p_xy - p_yx
+            p_acc = torch.clamp(torch.exp(-ex), max=1.0)
+            k, moved = 0, True
+            self.accepted += 1
+            self.rec["ind"].append(torch.ones(1, dtype=torch.bool, device=device))
+        else:
+            raise ValueError("Number of proposals has to be one if everything is accepted!")
+
+        # emitted rows: k copies of the old state, then row k (the accepted proposal, if the chain moved)
+        new_c = y_c[k: k + 1] if moved else x_coords
+        new_v = y_v[k: k + 1] if moved else x_velocs
+        if k > 0:
+            self.chain_c.append(x_coords.expand(k, V, 3))
+            self.chain_v.append(x_velocs.expand(k, V, 3))
+        self.chain_c.append(new_c.clone())
+        self.chain_v.append(new_v.clone())
+        self.x_coords, self.x_velocs = new_c.contiguous(), new_v.contiguous()
+        for name, t in (("acc", p_acc), ("pxy", p_xy), ("pyx", p_yx), ("exp", ex), ("epot", e_pot_y), ("ekin", e_kin_y),
+                        ("dpot", e_pot), ("dkin", e_kin)):
+            self.rec[name].append(t[: k + 1])
+        return k + 1
+
+    def trajectory(self):
+        """Device tensors: coords [1+n,V,3], velocs [1+n,V,3]."""
+        return torch.cat(self.chain_c, dim=0), torch.cat(self.chain_v, dim=0)
+
+    def result(self):
+        c, v = self.trajectory()
+        stats = ChainStats(*[torch.cat(self.rec[k], dim=0).cpu().numpy() for k in self.KEYS])
+        return c.cpu().numpy(), v.cpu().numpy(), self.accepted, stats
+
+
+def sample_with_model(
+    batch,
+    model,
+    device: torch.device,
+    openmm_potential_energy_torch,
+    masses: torch.Tensor,
+    num_samples: int,
+    accept: bool = False,
+    random_velocs: bool = False,
+    resample_velocs: bool = False,
+    initialize_randomly: bool = False,
+    num_openmm_steps: int = 0,
+    sim=None,
+    openmm_on_proposal: bool = False,
+    openmm_on_current: bool = False,
+    num_proposal_steps: int = 1,
+    adaptive_parallelism: bool = False,
+    acceptance_rate_smoothing_factor: float = 0.01,
+    rotate: bool = False,
+    reference_signs: Optional[torch.Tensor] = None,
+    chirality_centers: Optional[torch.Tensor] = None,
+    disable_tqdm: Optional[bool] = False,
+    noise=None,
+):
+    """Run one Markov chain of (at least) `num_samples` states.
+
+    Arguments, semantics and returns follow the reference function; `noise` (extension) supplies
+    the random draws (default: the device generator).  Returns
+    (sampled_coords [1+n,V,3] float32 numpy, sampled_velocs, accepted:int, ChainStats)."""
+    if sim is not None and num_openmm_steps > 0 and (openmm_on_proposal or openmm_on_current):
+        raise NotImplementedError("OpenMM integration steps inside the chain need OpenMM; outside this build's scope")
+    chain = MetropolisHastingsChain(
+        batch, model, device, openmm_potential_energy_torch, masses, accept=accept, random_velocs=random_velocs,
+        resample_velocs=resample_velocs, initialize_randomly=initialize_randomly, num_proposal_steps=num_proposal_steps,
+        adaptive_parallelism=adaptive_parallelism, acceptance_rate_smoothing_factor=acceptance_rate_smoothing_factor,
+        rotate=rotate, reference_signs=reference_signs, chirality_centers=chirality_centers, noise=noise)
+    print("Sample with the model using Metropolis Hastings" if accept else "Sample with the model by accepting every setp")
+    i = 0
+    pbar = tqdm(total=num_samples, disable=disable_tqdm)
+    with torch.no_grad():
+        while i < num_samples:
+            n = chain.step(num_samples - i)
+            i += n
+            pbar.update(n)
+    pbar.close()
+    return chain.result()
