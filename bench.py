@@ -201,6 +201,14 @@ def main():
         launches = max(int(k_launches.value), 1)
         avg_ms = k_ms.value / launches
         flop_per_launch = FLOP_PER_SAMPLE_PASS * args.proposals / N_COUPLING
+        # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied), summarised in profiles/
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if args.proposals == S_PROPOSALS and os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f)["netblock_kernel"]["traffic_bytes_per_launch_corrected"]
+            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "MH-accepted samples/sec (whole node), alanine-dipeptide kernel_transformer_nvp",
@@ -233,7 +241,8 @@ def main():
                 "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms,
                 "launches": int(k_launches.value),
                 "algorithmic_flop_per_launch": flop_per_launch,
