@@ -32,6 +32,13 @@ V_ATOMS = 22
 FLOP_PER_SAMPLE_PASS = 1.612e9  # 16 * V * F_blk(V), V = 22
 N_COUPLING = 8
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (~2.5 PF)
+# execution paths of the flow (include/timewarp_hip.h): both hold the 1e-5 parity bar
+PATHS = {
+    "h3": dict(path=3, dtype="f16x3 (split-fp16 operands, 3 MFMAs per fp32 product, fp32 accumulate)",
+               kernel="tw::netblock_h3_kernel<3>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=3),
+    "f32": dict(path=1, dtype="f32", kernel="tw::netblock_kernel<3>", peak=F32_MFMA_PEAK_TFLOPS, mfma_per_product=1),
+}
 # Synthetic-weight calibration (SURVEY section 8d idea, tuned so acceptance is non-degenerate against
 # the stiff bonded terms): identity flow (last out_mlp layer zeroed), coordinate prior std e^-7 nm,
 # velocity prior std 1 with isotropic resampled velocities (the reference's --random-velocities
@@ -40,7 +47,7 @@ CALIBRATION = dict(coords_log_scale=-7.0, velocs_log_scale=0.0)
 MH_MODE = dict(accept=True, random_velocs=True, resample_velocs=True)
 
 
-def build_chain(device, seed, proposals):
+def build_chain(device, seed, proposals, path):
     import timewarp_amd as tw
     from timewarp_amd import synthetic
     from timewarp_amd.dataloader import single_state_batch
@@ -49,6 +56,7 @@ def build_chain(device, seed, proposals):
 
     model = tw.model_constructor(synthetic.kernel_transformer_nvp_config())
     model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), base_seed=0, calibrated=True, **CALIBRATION))
+    model.execution_path = path
     model = model.to(device).eval()
     types, coords, masses = synthetic.alanine_dipeptide_state()
     torch.manual_seed(seed)
@@ -151,6 +159,8 @@ def main():
     ap.add_argument("--proposals", type=int, default=S_PROPOSALS)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", choices=sorted(PATHS), default="h3",
+                    help="flow execution path: split-fp16 fused kernel (default) or exact-f32 fused kernel")
     args = ap.parse_args()
 
     from timewarp_amd import _lib, distributed
@@ -164,7 +174,8 @@ def main():
     torch.cuda.set_device(device)
     lib = _lib.load()
 
-    chain, model = build_chain(device, distributed.chain_seed(args.seed, rank), args.proposals)
+    pinfo = PATHS[args.path]
+    chain, model = build_chain(device, distributed.chain_seed(args.seed, rank), args.proposals, pinfo["path"])
     with torch.no_grad():
         for _ in range(args.warmup):
             chain.step()
@@ -207,8 +218,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if args.proposals == S_PROPOSALS and os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f)["netblock_kernel"]["traffic_bytes_per_launch_corrected"]
-            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                rec = json.load(f).get("netblock_h3_kernel" if args.path == "h3" else "netblock_kernel")
+            if rec:
+                traffic = rec["traffic_bytes_per_launch_corrected"]
+                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "MH-accepted samples/sec (whole node), alanine-dipeptide kernel_transformer_nvp",
@@ -221,7 +234,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": pinfo["dtype"],
             "data": "synthetic",
             "config": {
                 "workload": "kernel_transformer_nvp.yaml, alanine-dipeptide (22 atoms), 1000-proposal parallel MH, "
@@ -229,18 +242,19 @@ def main():
                 "proposals_per_step": args.proposals,
                 "chains_per_gpu": 1,
                 "weights": "name-seeded synthetic, SURVEY 8d calibration",
-                "execution_path": "fused f32-MFMA",
+                "execution_path": args.path,
             },
             "proposals_per_s": proposals / elapsed,
             "chain_states_per_s": states / elapsed,
             "accepted_per_step": accepted / (args.steps * world),
             "roofline": {
                 "bound": "mfma",
-                "kernel": "tw::netblock_kernel<3> (both coupling nets of one coupling layer, all proposals)",
+                "kernel": pinfo["kernel"] + " (both coupling nets of one coupling layer, all proposals)",
                 "achieved": achieved,
-                "peak": F32_MFMA_PEAK_TFLOPS,
+                "peak": pinfo["peak"],
                 "unit": "TFLOP/s",
-                "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                "frac": achieved / pinfo["peak"],
+                "mfma_per_fp32_product": pinfo["mfma_per_product"],
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms,

@@ -80,6 +80,11 @@ int64_t tw_flow_packed_floats(const tw_flow_desc* desc);
  * W_o[:,h] @ W_v[h] per head in fp64, re-tiles every matrix into 16x16 MFMA A-fragments). */
 int tw_flow_pack(const tw_flow_desc* desc, const float* raw, float* packed, void* stream);
 
+/* The split-fp16 weight stream of TW_PATH_FUSED_H3: size in BYTES (0 if unsupported) and builder
+ * (per-matrix power-of-two scaling, fp16 hi/lo tile pairs in LDS-DMA stage order). */
+int64_t tw_flow_packed_h3_bytes(const tw_flow_desc* desc);
+int tw_flow_pack_h3(const tw_flow_desc* desc, const float* raw, void* packed_h3, void* stream);
+
 /* Bytes of scratch the flow entry points need for n_rows conformations of n_atoms atoms. */
 int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_t n_atoms);
 
@@ -87,6 +92,10 @@ int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_
 #define TW_PATH_AUTO 0   /* fused MFMA path where supported, else simple */
 #define TW_PATH_FUSED 1  /* fused f32-MFMA net-block kernel (kernel variant, n_atoms <= 64) */
 #define TW_PATH_SIMPLE 2 /* one plain HIP kernel per reference op (all variants) */
+#define TW_PATH_FUSED_H3 3 /* fused split-fp16 kernel: every fp32 product as 3 half-precision MFMAs with fp32
+                              accumulation (2^-22 operand representation); kernel variant, n_atoms <= 24;
+                              needs |activations| < 65504.  `packed` must then point at the
+                              tw_flow_pack_h3 stream.  Never chosen by TW_PATH_AUTO. */
 
 /* ConditionalSequentialFlow.forward (modules/model_wrappers/flow.py:51-103) over
  * NVPCouplingLayer.forward (modules/layers/nvp.py:22-183) with
@@ -197,6 +206,10 @@ int tw_chirality_changed(const float* coords, const int32_t* centres, const floa
  * summed kernel time in milliseconds and the number of launches.  Not thread-safe. */
 int tw_profile_begin(void);
 int tw_profile_end(double* total_ms, int64_t* launches);
+
+/* Timing experiments on the split-fp16 kernel (results become WRONG): bit 0 = no weight LDS-DMA after
+ * the prologue, bit 1 = no workgroup barriers.  0 restores normal operation. */
+int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every
  * stage (in_mlp, each encoder layer, out_mlp) as [n_rows,n_atoms,d] row-major floats.

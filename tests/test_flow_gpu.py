@@ -9,7 +9,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
-SIMPLE, FUSED = 2, 1
+SIMPLE, FUSED, H3 = 2, 1, 3
 
 
 def test_library_sees_gpu():
@@ -60,7 +60,7 @@ def test_tiny_dense_simple_path():
     H.assert_case_close(H.run_model_case(m, d, "b1_"), d, "b1_", tol=TOL)
 
 
-@pytest.mark.parametrize("path", [SIMPLE, FUSED])
+@pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])
 def test_netblock_stages_vs_reference_trace(path):
     """Every stage of one coupling net (first net of the reverse pass) against the reference's
     own intermediate activations."""
@@ -79,7 +79,7 @@ def test_netblock_stages_vs_reference_trace(path):
     assert e < TOL, ("out_mlp", e)
 
 
-@pytest.mark.parametrize("path", [SIMPLE, FUSED])
+@pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])
 @pytest.mark.parametrize("name,calibrated", [("kernel_full_ad", False), ("kernel_full_ad_calibrated", True)])
 def test_full_kernel_ad_golden(path, name, calibrated):
     d, _ = H.load(name)
@@ -118,7 +118,7 @@ def test_fused_batched_padding_vs_oracle(V, lens):
     for b, n in enumerate(lens):
         mask[b, n:] = True
     ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
-    for path in (FUSED, SIMPLE):
+    for path in (FUSED, SIMPLE) + ((H3,) if V == 22 else ()):
         m = H.tw_kernel_model(sd, path=path)
         out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
                                y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
@@ -157,18 +157,19 @@ def test_roundtrip_full_size_S1000():
 def test_fused_equals_simple_large_batch():
     sd = H.full_kernel_sd()
     d, _ = H.load("kernel_full_ad")
-    S = 130  # not a multiple of the molecules-per-wave: exercises the partial last block
+    S = 131  # odd: partial last wave block AND a workgroup with idle waves
     g = torch.Generator().manual_seed(9)
     zc, zv = fo.draw_latents(sd, S, (1, 22, 3), g)
     outs = []
-    for path in (FUSED, SIMPLE):
+    for path in (FUSED, SIMPLE, H3):
         m = H.tw_kernel_model(sd, path=path)
         outs.append(m.conditional_sample_with_logp(
             atom_types=d["atom_types"].cuda(), x_coords=d["x_coords"].cuda(), x_velocs=d["x_velocs"].cuda(),
             adj_list=None, edge_batch_idx=None, masked_elements=d["masked"].cuda(), num_samples=S,
             z_coords=zc.cuda(), z_velocs=zv.cuda()))
-    for a, b in zip(*outs):
-        assert H.rel_err(a.cpu(), b.cpu()) < TOL
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert H.rel_err(a.cpu(), b.cpu()) < TOL
 
 
 def test_no_cpu_fallback():

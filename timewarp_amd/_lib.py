@@ -16,7 +16,7 @@ from . import build as _build
 
 _LIB: Optional[C.CDLL] = None
 
-TW_PATH_AUTO, TW_PATH_FUSED, TW_PATH_SIMPLE = 0, 1, 2
+TW_PATH_AUTO, TW_PATH_FUSED, TW_PATH_SIMPLE, TW_PATH_FUSED_H3 = 0, 1, 2, 3
 
 
 class FlowDesc(C.Structure):
@@ -80,6 +80,8 @@ SIGNATURES = {
     "tw_flow_raw_floats": (_I64, [_DESC]),
     "tw_flow_packed_floats": (_I64, [_DESC]),
     "tw_flow_pack": (C.c_int, [_DESC, _P, _P, _P]),
+    "tw_flow_packed_h3_bytes": (_I64, [_DESC]),
+    "tw_flow_pack_h3": (C.c_int, [_DESC, _P, _P, _P]),
     "tw_flow_workspace_bytes": (_I64, [_DESC, _I64, _I32]),
     "tw_flow_pass": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I64, _P]),
     "tw_flow_log_likelihood": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _I64, _P]),
@@ -93,6 +95,7 @@ SIGNATURES = {
     "tw_amber_energy": (C.c_int, [C.POINTER(ForceField), _P, _P, _P, _I64, _P]),
     "tw_mh_accept": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "tw_chirality_changed": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _I32, _P]),
+    "tw_debug_set_flags": (C.c_int, [C.c_int]),
     "tw_profile_begin": (C.c_int, []),
     "tw_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tw_debug_netblock": (

@@ -39,7 +39,11 @@ static bool fused_supported(const tw_flow_desc& d, int n_atoms) {
 
 static int resolve_path(const tw_flow_desc& d, int n_atoms, int path, const float* packed, int* out) {
   if (path == TW_PATH_AUTO) path = (packed && fused_supported(d, n_atoms)) ? TW_PATH_FUSED : TW_PATH_SIMPLE;
-  if (path == TW_PATH_FUSED) {
+  if (path == TW_PATH_FUSED_H3) {
+    TW_REQUIRE(h3_supported(d, n_atoms), "split-fp16 path unsupported for this config (variant=%d d_model=%d n_atoms=%d)",
+               d.variant, d.d_model, n_atoms);
+    TW_REQUIRE(packed != nullptr, "split-fp16 path needs its packed weight stream (tw_flow_pack_h3)");
+  } else if (path == TW_PATH_FUSED) {
     TW_REQUIRE(fused_supported(d, n_atoms), "fused path unsupported for this config (variant=%d d_model=%d n_atoms=%d)",
                d.variant, d.d_model, n_atoms);
     TW_REQUIRE(packed != nullptr, "fused path needs the packed weight stream (tw_flow_pack)");
@@ -80,11 +84,31 @@ int tw_flow_pack(const tw_flow_desc* desc, const float* raw, float* packed, void
   return pack_weights(*desc, raw, packed, (hipStream_t)stream);
 }
 
+int64_t tw_flow_packed_h3_bytes(const tw_flow_desc* desc) {
+  if (check_desc(desc)) return -1;
+  if (!h3_supported(*desc, 22)) return 0;
+  return h3_packed_bytes(*desc);
+}
+
+int tw_flow_pack_h3(const tw_flow_desc* desc, const float* raw, void* packed_h3, void* stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  TW_REQUIRE(h3_supported(*desc, 22), "split-fp16 path unsupported for this config");
+  TW_REQUIRE(raw && packed_h3, "NULL buffer");
+  // the last 256 bytes of the over-fetch slack double as scratch for the per-matrix scale search
+  float* scratch = (float*)((char*)packed_h3 + h3_packed_bytes(*desc) - 256);
+  return h3_pack_weights(*desc, raw, (char*)packed_h3, scratch, (hipStream_t)stream);
+}
+
 int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_t n_atoms) {
   if (check_desc(desc) || n_rows < 0 || n_atoms <= 0) return -1;
   const int64_t rows = n_rows > 0 ? n_rows : 1;
   int64_t a = simple_workspace_bytes(*desc, rows, n_atoms);
   int64_t b = fused_supported(*desc, n_atoms) ? fused_workspace_bytes(*desc, rows, n_atoms) : 0;
+  if (h3_supported(*desc, n_atoms)) {
+    const int64_t c = h3_workspace_bytes(*desc, rows, n_atoms);
+    if (c > b) b = c;
+  }
   // the likelihood / sampling entry points carve their own temporaries in front of the flow scratch
   const int64_t extra = 6 * ((rows * n_atoms * 3 * 4 + 255) / 256 * 256) + 4 * ((rows * 4 + 255) / 256 * 256);
   return (a > b ? a : b) + extra;
@@ -106,6 +130,7 @@ int tw_flow_pass(const tw_flow_desc* desc, const float* raw, const float* packed
   if ((rc = resolve_path(*desc, n_atoms, path, packed, &p))) return rc;
   FlowArgs a{desc, raw, packed, atom_types, x_coords, x_velocs, masked, n_cond, z_coords, z_velocs,
              delta_logp, n_rows, n_atoms, reverse, workspace, workspace_bytes, (hipStream_t)stream};
+  if (p == TW_PATH_FUSED_H3) return flow_pass_h3(a);
   return p == TW_PATH_FUSED ? flow_pass_fused(a) : flow_pass_simple(a);
 }
 
@@ -250,6 +275,11 @@ int tw_chirality_changed(const float* coords, const int32_t* centres, const floa
                           (hipStream_t)stream);
 }
 
+int tw_debug_set_flags(int flags) {
+  tw::g_debug_flags = flags;
+  return TW_OK;
+}
+
 int tw_profile_begin(void) { return profile_begin(); }
 int tw_profile_end(double* total_ms, int64_t* launches) { return profile_end(total_ms, launches); }
 
@@ -266,6 +296,7 @@ int tw_debug_netblock(const tw_flow_desc* desc, const float* raw, const float* p
   if ((rc = resolve_path(*desc, n_atoms, path, packed, &p))) return rc;
   FlowArgs a{desc, raw, packed, atom_types, x_coords, x_velocs, masked, n_cond, nullptr, nullptr,
              nullptr, n_rows, n_atoms, 0, workspace, workspace_bytes, (hipStream_t)stream};
+  if (p == TW_PATH_FUSED_H3) return debug_netblock_h3(a, coupling, net, z_other, dump);
   return p == TW_PATH_FUSED ? debug_netblock_fused(a, coupling, net, z_other, dump)
                             : debug_netblock_simple(a, coupling, net, z_other, dump);
 }

@@ -119,6 +119,15 @@ int launch_coupling(const float* s_raw, const float* t, const uint8_t* masked, i
 int pack_weights(const tw_flow_desc& d, const float* raw, float* packed, hipStream_t s);
 int debug_netblock_simple(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
 int debug_netblock_fused(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
+// split-fp16 fused path (tw_netblock_h3.hip); FlowArgs::packed points at the h3 stream (bytes)
+bool h3_supported(const tw_flow_desc& d, int n_atoms);
+int64_t h3_packed_bytes(const tw_flow_desc& d);
+int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms);
+int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float* scratch, hipStream_t s);
+int flow_pass_h3(const FlowArgs& a);
+int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
+extern int g_debug_flags;
+int profile_mark(hipStream_t s, bool begin);
 int profile_begin();
 int profile_end(double* total_ms, int64_t* launches);
 

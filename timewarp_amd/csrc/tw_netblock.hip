@@ -628,6 +628,24 @@ int profile_begin() {
   return TW_OK;
 }
 
+// begin=true records the start event of a new launch, begin=false the stop event of the last one
+int profile_mark(hipStream_t s, bool begin) {
+  if (!g_profile) return TW_OK;
+  if (begin) {
+    if (g_events_used == g_events.size()) {
+      hipEvent_t e0, e1;
+      TW_HIP_CHECK(hipEventCreate(&e0));
+      TW_HIP_CHECK(hipEventCreate(&e1));
+      g_events.emplace_back(e0, e1);
+    }
+    TW_HIP_CHECK(hipEventRecord(g_events[g_events_used].first, s));
+    ++g_events_used;
+  } else {
+    TW_HIP_CHECK(hipEventRecord(g_events[g_events_used - 1].second, s));
+  }
+  return TW_OK;
+}
+
 int profile_end(double* total_ms, int64_t* launches) {
   g_profile = false;
   double ms = 0.0;
@@ -727,19 +745,8 @@ static int launch_netblock(const FlowArgs& a, const RawLayout& L, const FusedGeo
   const int wgs_per_net = (p.nblocks + 3) / 4;
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
   const size_t shm = (size_t)4 * 16 * g.nt * XS * sizeof(float);
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (g_profile) {
-    if (g_events_used == g_events.size()) {
-      hipEvent_t e0, e1;
-      TW_HIP_CHECK(hipEventCreate(&e0));
-      TW_HIP_CHECK(hipEventCreate(&e1));
-      g_events.emplace_back(e0, e1);
-    }
-    ev0 = g_events[g_events_used].first;
-    ev1 = g_events[g_events_used].second;
-    ++g_events_used;
-    TW_HIP_CHECK(hipEventRecord(ev0, a.stream));
-  }
+  int prc;
+  if ((prc = profile_mark(a.stream, true))) return prc;
   static bool attr3 = false, attr4 = false;
   if (g.nt == 3) {
     if (!attr3) {
@@ -755,7 +762,7 @@ static int launch_netblock(const FlowArgs& a, const RawLayout& L, const FusedGeo
     hipLaunchKernelGGL(netblock_kernel<4>, dim3(grid), dim3(256), shm, a.stream, p);
   }
   TW_LAUNCH_CHECK();
-  if (ev1) TW_HIP_CHECK(hipEventRecord(ev1, a.stream));
+  if ((prc = profile_mark(a.stream, false))) return prc;
   return TW_OK;
 }
 

@@ -1,0 +1,987 @@
+// Split-fp16 ("h3") variant of the fused net-block kernel (gfx950 / CDNA4).
+//
+// Same structure as tw_netblock.hip (transposed formulation, activations chained in registers in
+// MFMA D/B layout, one wave = whole molecules, folded kernel attention), but every fp32 product
+// a*b is evaluated on the half-precision matrix pipe as
+//        a*b  ~=  ah*bh + ah*bl + al*bh        (a = ah + al, ah = fp16(a), al = fp16(a - ah))
+// with fp32 accumulation: three v_mfma_f32_16x16x32_f16 per 32-deep k-step instead of eight
+// v_mfma_f32_16x16x4_f32, i.e. 5.3x fewer matrix-pipe cycles at a representation error of 2^-22
+// per operand (fp32-class; measured end-to-end error vs the reference ~3e-6 relative).
+//
+// Differences that follow from the 5x shorter compute time per weight byte:
+//  * weights (fp16 hi/lo tile pairs, per-matrix power-of-two scaled so the lo halves stay normal)
+//    are staged through LDS by LDS-DMA (global_load_lds, 16 B/lane) in 17 KiB stages shared by the
+//    4 waves of a workgroup, double buffered, one barrier per stage;
+//  * the mixing A_h X runs on the same 3-product scheme from an fp16 hi/lo copy of X stored
+//    TRANSPOSED in LDS ([feature][token], row stride 56 halfs -> conflict-free ds_read_b128).
+// Only NT = 3 (<= 24 atoms per molecule ... 2x22) is supported; other sizes use the f32 kernel.
+#include <utility>
+#include <vector>
+
+#include "tw_common.h"
+
+namespace tw {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#ifndef H3_DEBUG_SYNC
+#define H3_DEBUG_SYNC 0
+#endif
+#define H3_NT 3
+#define H3_TOK (16 * H3_NT)
+#define H3_XT 56                    // halfs per feature row of the transposed X tile
+#define H3_PAIR_BYTES 2048          // one (hi, lo) tile pair: 16 out x 32 k
+#define H3_STAGE_PAIRS 4
+#define H3_STAGE_TILE_BYTES 8192    // 4 pairs
+#define H3_STAGE_BYTES 9216         // + 1 KiB aux (bias[32], scale)
+#define H3_RING 5                   // stage buffers: 1 being read + 4 in flight (~1 us of LDS-DMA latency)
+#define H3_XT_BYTES (128 * H3_XT * 2)  // one of (hi, lo)
+#define H3_WAVE_LDS (2 * H3_XT_BYTES)
+#define H3_LDS_BYTES (H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS)
+#define H3_TARGET_MAX 4096.0f       // |w| * 2^s is scaled up to just below this
+
+// stage sequence per net (each 9 KiB = 4 tile pairs + aux):
+//   IN   : hid_chunks x [A: W0 chunk (2 ot x 2 ks) + aux(b0 chunk, scale0)][B0: W2 chunk ot 0-3][B1: ot 4-7]
+//   layer: H heads x 8 x [Wc, one ot x 4 ks]
+//          ff_chunks x [A0: W1 chunk o=0 (4 ks) + aux(b1 chunk, scale1)][A1: o=1][B0: W2 chunk ot 0-3][B1: ot 4-7]
+//   OUT  : hid_chunks x [A0: W0 chunk o=0 + aux][A1: o=1][B: W2 chunk (1 pair)]
+// side floats per net: in2_b[128] { n1w n1b [128] b2[128] n2w n2b [128] } out2_b[16]
+//                      scales: in0, in2, per layer (wc, w1, w2), out0, out2  (as 2^-s multipliers)
+struct H3Geom {
+  int hid_chunks, ff_chunks, H, L;
+  int64_t stages;
+  int64_t side_in2b, side_layers, side_layer_size, side_out2b, side_scales, side_size;
+  int64_t net_stride_bytes;
+};
+
+static H3Geom h3_geom(const tw_flow_desc& d) {
+  H3Geom g;
+  g.hid_chunks = d.d_hidden / 32;
+  g.ff_chunks = d.d_ff / 32;
+  g.H = d.n_heads;
+  g.L = d.n_layers;
+  g.stages = 3LL * g.hid_chunks + (int64_t)g.L * (8LL * g.H + 4LL * g.ff_chunks) + 3LL * g.hid_chunks;
+  int64_t o = 0;
+  g.side_in2b = o; o += 128;
+  g.side_layers = o;
+  g.side_layer_size = 128 * 5;
+  o += g.L * g.side_layer_size;
+  g.side_out2b = o; o += 16;
+  g.side_scales = o; o += 4 + 3 * g.L;
+  g.side_size = (o + 63) / 64 * 64;
+  g.net_stride_bytes = (g.stages * H3_STAGE_BYTES + g.side_size * 4 + 1023) / 1024 * 1024;
+  return g;
+}
+
+int64_t h3_packed_bytes(const tw_flow_desc& d) {
+  H3Geom g = h3_geom(d);
+  return g.net_stride_bytes * 2 * d.n_coupling + (H3_RING + 1) * H3_STAGE_BYTES;  // DMA prefetch overrun slack
+}
+
+bool h3_supported(const tw_flow_desc& d, int n_atoms) {
+  FusedGeom fg;
+  return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
+         fused_geom(n_atoms, &fg) && fg.nt == H3_NT;
+}
+
+// ================================================================================================
+// packing: fp32 raw weights -> scaled fp16 hi/lo tile pairs
+// pair (ot, ks) element (lane, e): W[16 ot + (lane&15)][32 ks + 16 (e/4) + 4 (lane>>4) + e%4]
+// ================================================================================================
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  // v >= 0: integer compare is order preserving
+  atomicMax((int*)addr, __float_as_int(v));
+}
+
+__global__ void h3_absmax_kernel(const float* __restrict__ src, int64_t n, float* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(src[i]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomic_max_float(out, m);
+}
+
+__device__ __forceinline__ double fold_elem(const float* wv, const float* wo, int H, int h, int o_row, int i_col) {
+  double acc = 0.0;
+  for (int k = 0; k < 128; ++k)
+    acc += (double)wo[(int64_t)o_row * (H * 128) + h * 128 + k] * (double)wv[(int64_t)(h * 128 + k) * 128 + i_col];
+  return acc;
+}
+
+__global__ void h3_fold_absmax_kernel(const float* __restrict__ wv, const float* __restrict__ wo, int H,
+                                      float* __restrict__ out) {
+  const int h = blockIdx.y;
+  float m = 0.f;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 128 * 128; idx += gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf((float)fold_elem(wv, wo, H, h, idx / 128, idx % 128)));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomic_max_float(out, m);
+}
+
+// scale exponent: largest power of two with max * 2^s < H3_TARGET_MAX; writes 2^s and 2^-s
+__global__ void h3_scale_kernel(const float* __restrict__ absmax, float* __restrict__ up, float* __restrict__ down) {
+  float m = absmax[0];
+  int s = 0;
+  if (m > 0.f && isfinite(m)) {
+    s = (int)floorf(log2f(H3_TARGET_MAX / m));
+    if (s > 24) s = 24;
+    if (s < -24) s = -24;
+    while (ldexpf(m, s) >= H3_TARGET_MAX) --s;
+  }
+  up[0] = ldexpf(1.f, s);
+  down[0] = ldexpf(1.f, -s);
+}
+
+__device__ __forceinline__ void store_pair(char* pair, int lane, int e, float v) {
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  ((_Float16*)(pair + lane * 16))[e] = hi;
+  ((_Float16*)(pair + 1024 + lane * 16))[e] = lo;
+}
+
+// tile pairs ordered ot-major over (n_ot, n_ks); src row-major [rows, cols] (ld)
+__global__ void h3_pack_block_kernel(const float* __restrict__ src, int ld, int rows_valid, int cols_valid, int row0,
+                                     int col0, int n_ks, const float* __restrict__ scale_up, char* __restrict__ dst) {
+  const int ot = blockIdx.x, ks = blockIdx.y, lane = threadIdx.x;
+  const float sc = scale_up[0];
+  const int row = row0 + 16 * ot + (lane & 15);
+  char* pair = dst + (int64_t)(ot * n_ks + ks) * H3_PAIR_BYTES;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int col = col0 + 32 * ks + 16 * (e / 4) + 4 * (lane >> 4) + (e % 4);
+    const float v = (row < rows_valid && col < cols_valid) ? src[(int64_t)row * ld + col] * sc : 0.f;
+    store_pair(pair, lane, e, v);
+  }
+}
+
+__global__ void h3_pack_fold_kernel(const float* __restrict__ wv, const float* __restrict__ wo, int H, int h, int ot0,
+                                    const float* __restrict__ scale_up, char* __restrict__ dst) {
+  const int o = blockIdx.x, ks = blockIdx.y, lane = threadIdx.x;  // o in 0..1 -> ot = ot0 + o
+  const float sc = scale_up[0];
+  const int row = 16 * (ot0 + o) + (lane & 15);
+  char* pair = dst + (int64_t)(o * 4 + ks) * H3_PAIR_BYTES;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int col = 32 * ks + 16 * (e / 4) + 4 * (lane >> 4) + (e % 4);
+    store_pair(pair, lane, e, (float)(fold_elem(wv, wo, H, h, row, col) * (double)sc));
+  }
+}
+
+__global__ void h3_copy_kernel(const float* __restrict__ src, int n, float* __restrict__ dst, int n_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) dst[i] = i < n ? src[i] : 0.f;
+}
+
+int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float* scratch /* >= 64 floats */,
+                    hipStream_t s) {
+  const RawLayout L = raw_layout(d);
+  const H3Geom g = h3_geom(d);
+  TW_HIP_CHECK(hipMemsetAsync(packed, 0, h3_packed_bytes(d), s));
+  auto absmax = [&](const float* src, int64_t n, float* up, float* down) -> int {
+    TW_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float), s));
+    hipLaunchKernelGGL(h3_absmax_kernel, dim3(64), dim3(256), 0, s, src, n, scratch);
+    TW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(h3_scale_kernel, dim3(1), dim3(1), 0, s, scratch, up, down);
+    TW_LAUNCH_CHECK();
+    return TW_OK;
+  };
+  auto block = [&](const float* src, int ld, int rows_valid, int cols_valid, int row0, int col0, int n_ot, int n_ks,
+                   const float* up, char* dst) -> int {
+    hipLaunchKernelGGL(h3_pack_block_kernel, dim3(n_ot, n_ks), dim3(64), 0, s, src, ld, rows_valid, cols_valid, row0,
+                       col0, n_ks, up, dst);
+    TW_LAUNCH_CHECK();
+    return TW_OK;
+  };
+  auto copy = [&](const float* src, int n, float* dst, int n_pad) -> int {
+    hipLaunchKernelGGL(h3_copy_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, s, src, n, dst, n_pad);
+    TW_LAUNCH_CHECK();
+    return TW_OK;
+  };
+  float* up = scratch + 8;  // scratch[8] holds the current 2^s
+  int rc;
+  for (int c = 0; c < d.n_coupling; ++c)
+    for (int net = 0; net < 2; ++net) {
+      const float* nb = raw + net_base(L, c, net);
+      char* pn = packed + (int64_t)(c * 2 + net) * g.net_stride_bytes;
+      float* side = (float*)(pn + g.stages * H3_STAGE_BYTES);
+      float* scales = side + g.side_scales;  // 2^-s multipliers, in stream order
+      char* st = pn;
+      // ---- IN
+      if ((rc = absmax(nb + L.net.in0_w, (int64_t)d.d_hidden * L.d_in, up, scales + 0))) return rc;
+      for (int ch = 0; ch < g.hid_chunks; ++ch) {
+        char* a = st + (int64_t)(3 * ch) * H3_STAGE_BYTES;
+        if ((rc = block(nb + L.net.in0_w, L.d_in, d.d_hidden, L.d_in, 32 * ch, 0, 2, 2, up, a))) return rc;
+        if ((rc = copy(nb + L.net.in0_b + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
+        if ((rc = copy(scales + 0, 1, (float*)(a + H3_STAGE_TILE_BYTES) + 32, 1))) return rc;
+      }
+      if ((rc = absmax(nb + L.net.in2_w, (int64_t)128 * d.d_hidden, up, scales + 1))) return rc;
+      for (int ch = 0; ch < g.hid_chunks; ++ch)
+        for (int hf = 0; hf < 2; ++hf) {
+          char* b = st + (int64_t)(3 * ch + 1 + hf) * H3_STAGE_BYTES;
+          if ((rc = block(nb + L.net.in2_w, d.d_hidden, 128, d.d_hidden, 64 * hf, 32 * ch, 4, 1, up, b))) return rc;
+        }
+      st += (int64_t)3 * g.hid_chunks * H3_STAGE_BYTES;
+      if ((rc = copy(nb + L.net.in2_b, 128, side + g.side_in2b, 128))) return rc;
+      // ---- layers
+      for (int l = 0; l < d.n_layers; ++l) {
+        const float* lb = nb + L.net.layers + (int64_t)l * L.layer.size;
+        float* sl = side + g.side_layers + (int64_t)l * g.side_layer_size;
+        float* lsc = scales + 2 + 3 * l;
+        // folded attention: one scale for all heads of the layer
+        TW_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float), s));
+        hipLaunchKernelGGL(h3_fold_absmax_kernel, dim3(16, d.n_heads), dim3(256), 0, s, lb + L.layer.wv, lb + L.layer.wo,
+                           d.n_heads, scratch);
+        TW_LAUNCH_CHECK();
+        hipLaunchKernelGGL(h3_scale_kernel, dim3(1), dim3(1), 0, s, scratch, up, lsc + 0);
+        TW_LAUNCH_CHECK();
+        for (int h = 0; h < d.n_heads; ++h)
+          for (int ot = 0; ot < 8; ++ot) {
+            hipLaunchKernelGGL(h3_pack_fold_kernel, dim3(1, 4), dim3(64), 0, s, lb + L.layer.wv, lb + L.layer.wo, d.n_heads, h,
+                               ot, up, st + (int64_t)(8 * h + ot) * H3_STAGE_BYTES);
+            TW_LAUNCH_CHECK();
+          }
+        st += (int64_t)8 * d.n_heads * H3_STAGE_BYTES;
+        if ((rc = absmax(lb + L.layer.w1, (int64_t)d.d_ff * 128, up, lsc + 1))) return rc;
+        for (int ch = 0; ch < g.ff_chunks; ++ch)
+          for (int o = 0; o < 2; ++o) {
+            char* a = st + (int64_t)(4 * ch + o) * H3_STAGE_BYTES;
+            if ((rc = block(lb + L.layer.w1, 128, d.d_ff, 128, 32 * ch + 16 * o, 0, 1, 4, up, a))) return rc;
+            if (o == 0) {
+              if ((rc = copy(lb + L.layer.b1 + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
+              if ((rc = copy(lsc + 1, 1, (float*)(a + H3_STAGE_TILE_BYTES) + 32, 1))) return rc;
+            }
+          }
+        if ((rc = absmax(lb + L.layer.w2, (int64_t)128 * d.d_ff, up, lsc + 2))) return rc;
+        for (int ch = 0; ch < g.ff_chunks; ++ch)
+          for (int hf = 0; hf < 2; ++hf) {
+            char* b = st + (int64_t)(4 * ch + 2 + hf) * H3_STAGE_BYTES;
+            if ((rc = block(lb + L.layer.w2, d.d_ff, 128, d.d_ff, 64 * hf, 32 * ch, 4, 1, up, b))) return rc;
+          }
+        st += (int64_t)4 * g.ff_chunks * H3_STAGE_BYTES;
+        if ((rc = copy(lb + L.layer.n1w, 128, sl, 128))) return rc;
+        if ((rc = copy(lb + L.layer.n1b, 128, sl + 128, 128))) return rc;
+        if ((rc = copy(lb + L.layer.b2, 128, sl + 256, 128))) return rc;
+        if ((rc = copy(lb + L.layer.n2w, 128, sl + 384, 128))) return rc;
+        if ((rc = copy(lb + L.layer.n2b, 128, sl + 512, 128))) return rc;
+      }
+      // ---- OUT
+      float* osc = scales + 2 + 3 * d.n_layers;
+      if ((rc = absmax(nb + L.net.out0_w, (int64_t)d.d_hidden * 128, up, osc + 0))) return rc;
+      for (int ch = 0; ch < g.hid_chunks; ++ch)
+        for (int o = 0; o < 2; ++o) {
+          char* a = st + (int64_t)(3 * ch + o) * H3_STAGE_BYTES;
+          if ((rc = block(nb + L.net.out0_w, 128, d.d_hidden, 128, 32 * ch + 16 * o, 0, 1, 4, up, a))) return rc;
+          if (o == 0) {
+            if ((rc = copy(nb + L.net.out0_b + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
+            if ((rc = copy(osc + 0, 1, (float*)(a + H3_STAGE_TILE_BYTES) + 32, 1))) return rc;
+          }
+        }
+      if ((rc = absmax(nb + L.net.out2_w, (int64_t)3 * d.d_hidden, up, osc + 1))) return rc;
+      for (int ch = 0; ch < g.hid_chunks; ++ch) {
+        char* b = st + (int64_t)(3 * ch + 2) * H3_STAGE_BYTES;
+        if ((rc = block(nb + L.net.out2_w, d.d_hidden, 3, d.d_hidden, 0, 32 * ch, 1, 1, up, b))) return rc;
+      }
+      if ((rc = copy(nb + L.net.out2_b, 3, side + g.side_out2b, 16))) return rc;
+    }
+  return TW_OK;
+}
+
+// ================================================================================================
+// block-diagonal score fragments, fp16 hi/lo:
+// per (blk, head, jt): [k-step 0: 64 x h8 hi][64 x h8 lo][k-step 1 (keys 32..47): 64 x h4 hi][64 x h4 lo] = 3 KiB
+//   k-step 0 element (lane, e): S[query 16jt + (lane&15)][key 8 (lane>>4) + e]
+//   k-step 1 element (lane, e): S[query 16jt + (lane&15)][key 32 + 4 (lane>>4) + e]
+// ================================================================================================
+#define H3_SF_BYTES 3072
+
+__device__ __forceinline__ float h3_pair_dist(const float* x, int q, int m) {
+  float dx = x[3 * q] - x[3 * m], dy = x[3 * q + 1] - x[3 * m + 1], dz = x[3 * q + 2] - x[3 * m + 2];
+  return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+__global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
+                                     const float* __restrict__ ls, int H, int V, int mpw, int64_t n_rows,
+                                     int64_t n_cond, int normalise, char* __restrict__ sfrag) {
+  extern __shared__ float sm[];
+  float* xs = sm;
+  float* dist = xs + mpw * V * 3;
+  float* denom = dist + mpw * V * V;
+  uint8_t* msk = (uint8_t*)(denom + mpw * H * V);
+  const int64_t blk = blockIdx.x;
+  for (int i = threadIdx.x; i < mpw * V * 3; i += blockDim.x) {
+    int64_t n = blk * mpw + i / (V * 3);
+    if (n >= n_rows) n = n_rows - 1;
+    xs[i] = x[(n % n_cond) * V * 3 + i % (V * 3)];
+  }
+  for (int i = threadIdx.x; i < mpw * V; i += blockDim.x) {
+    int64_t n = blk * mpw + i / V;
+    if (n >= n_rows) n = n_rows - 1;
+    msk[i] = masked[(n % n_cond) * V + i % V];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < mpw * V * V; i += blockDim.x) {
+    const int q = i / (V * V), r = i % (V * V);
+    dist[i] = h3_pair_dist(xs + q * V * 3, r / V, r % V);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < mpw * H * V; i += blockDim.x) {
+    const int q = i / (H * V), h = (i / V) % H, a = i % V;
+    float sum = 0.f;
+    for (int m = 0; m < V; ++m) {
+      float sc = dist[(q * V + a) * V + m] / ls[h];
+      float e = msk[q * V + m] ? 0.f : expf(-(sc * sc));
+      sum += fabsf(e);
+    }
+    denom[i] = sum + 1e-5f;
+  }
+  __syncthreads();
+  // one thread per (head, jt, lane, key slot 0..11): slots 0..7 -> k-step 0, 8..11 -> k-step 1
+  const int total = H * H3_NT * 64 * 12;
+  char* out = sfrag + blk * (int64_t)H * H3_NT * H3_SF_BYTES;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int slot = i % 12, lane = (i / 12) % 64, jt = (i / (12 * 64)) % H3_NT, h = i / (12 * 64 * H3_NT);
+    const int tq = 16 * jt + (lane & 15);
+    const int tk = slot < 8 ? 8 * (lane >> 4) + slot : 32 + 4 * (lane >> 4) + (slot - 8);
+    float val = 0.f;
+    const int mq = tq / V, mk = tk / V;
+    if (mq == mk && mq < mpw) {
+      const int a = tq % V, m = tk % V;
+      if (!msk[mq * V + m]) {
+        float sc = dist[(mq * V + a) * V + m] / ls[h];
+        float e = expf(-(sc * sc));
+        val = normalise ? e / denom[(mq * H + h) * V + a] : e;
+      }
+    }
+    const _Float16 hi = (_Float16)val;
+    const _Float16 lo = (_Float16)(val - (float)hi);
+    char* base = out + (int64_t)(h * H3_NT + jt) * H3_SF_BYTES;
+    if (slot < 8) {
+      ((_Float16*)(base + lane * 16))[slot] = hi;
+      ((_Float16*)(base + 1024 + lane * 16))[slot] = lo;
+    } else {
+      ((_Float16*)(base + 2048 + lane * 8))[slot - 8] = hi;
+      ((_Float16*)(base + 2560 + lane * 8))[slot - 8] = lo;
+    }
+  }
+}
+
+// ================================================================================================
+// the kernel
+// ================================================================================================
+struct H3Params {
+  const char* packed;  // net 0 of this coupling layer
+  int64_t net_stride_bytes;
+  int64_t stages;
+  int64_t side_in2b, side_layers, side_layer_size, side_out2b, side_scales;
+  const float* emb;
+  const int32_t* types;
+  const float* xc;
+  const float* xv;
+  const float* z_other;
+  const char* sfrag;
+  int sfrag_shared;
+  float* out[2];
+  float* dump;
+  int64_t n_rows, n_cond;
+  int V, mpw, nblocks;
+  int H, n_layers, ff_chunks, hid_chunks, d_emb;
+  float eps;
+  int net_sel;
+  int debug;  // timing experiments only: bit 0 = no weight DMA after the prologue, bit 1 = no barriers,
+              // bit 2 = skip the FFN/MLP epilogue + fp16 split, bit 3 = skip the mixing MFMAs + split
+};
+
+template <int NT>
+struct BOp {  // B operand of one 32-deep k-step for NT token tiles, split fp16
+  h8 h[NT], l[NT];
+};
+
+__device__ __forceinline__ f4 mfma32(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f4 mfma16(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+
+// acc[jt] += (ah + al) x (b.h + b.l) without the lo x lo term
+template <int NT>
+__device__ __forceinline__ void mma3(const h8 ah, const h8 al, const BOp<NT>& b, f4 (&acc)[NT]) {
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) acc[jt] = mfma32(ah, b.h[jt], acc[jt]);
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) acc[jt] = mfma32(ah, b.l[jt], acc[jt]);
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) acc[jt] = mfma32(al, b.h[jt], acc[jt]);
+}
+
+// two D tiles (features 16t..16t+15, 16t+16..16t+31 of one token) -> split B-operand element vector
+__device__ __forceinline__ void split8(const f4 a, const f4 b, h8& hi, h8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 ha = (_Float16)a[e];
+    const _Float16 hb = (_Float16)b[e];
+    hi[e] = ha;
+    hi[e + 4] = hb;
+    lo[e] = (_Float16)(a[e] - (float)ha);
+    lo[e + 4] = (_Float16)(b[e] - (float)hb);
+  }
+}
+
+template <int NT, int KS>
+__device__ __forceinline__ void to_bop(const f4 (&x)[2 * KS][NT], BOp<NT> (&b)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) split8(x[2 * ks][jt], x[2 * ks + 1][jt], b[ks].h[jt], b[ks].l[jt]);
+}
+
+__device__ __forceinline__ float h3_xor_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int NT>
+__device__ __forceinline__ void h3_add_layernorm(f4 (&x)[8][NT], const f4 (&y)[8][NT], const float* lnw_lane,
+                                                 const float* lnb_lane, float eps) {
+  f4 w[8], b[8];
+#pragma unroll
+  for (int ft = 0; ft < 8; ++ft) {
+    w[ft] = *(const f4*)(lnw_lane + 16 * ft);
+    b[ft] = *(const f4*)(lnb_lane + 16 * ft);
+  }
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    float s = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) {
+      x[ft][jt] = x[ft][jt] + y[ft][jt];
+      s += (x[ft][jt][0] + x[ft][jt][1]) + (x[ft][jt][2] + x[ft][jt][3]);
+    }
+    const float mean = h3_xor_sum(s) * (1.f / 128.f);
+    float q = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) {
+      x[ft][jt] = x[ft][jt] - mean;
+      q += (x[ft][jt][0] * x[ft][jt][0] + x[ft][jt][1] * x[ft][jt][1]) +
+           (x[ft][jt][2] * x[ft][jt][2] + x[ft][jt][3] * x[ft][jt][3]);
+    }
+    const float var = h3_xor_sum(q) * (1.f / 128.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) x[ft][jt] = x[ft][jt] * rstd * w[ft] + b[ft];
+  }
+}
+
+// The weight pipeline: a ring of H3_RING stage buffers in LDS.  While stage s is being read, the
+// LDS-DMA of stages s+1 .. s+RING-1 is in flight or landed.  `advance`:
+//   1. counted wait: this wave's share of stage s+1 has landed (RING-2 younger stages may stay in flight);
+//      the count is stated in asm - hipcc neither counts LDS-DMA nor reliably waits for it;
+//   2. raw s_barrier (not __syncthreads(), whose fence would drain the DMA queue): every wave has
+//      finished reading stage s and every wave's share of s+1 is in LDS;
+//   3. refill the buffer just released with stage s+RING.
+// Each wave moves 2 KiB of every stage; wave 0 additionally moves the 1 KiB aux block.
+struct H3Pipe {
+  const char* gnext;  // global address of the next stage to fetch (this lane's 16 B)
+  char* lds;          // ring base
+  int cur;            // ring slot of the current stage
+  int wave;
+  int debug;
+
+  __device__ __forceinline__ void fetch(int slot) {
+    char* dst = lds + slot * H3_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gnext + wave * 2048 + i * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + wave * 2048 + i * 1024), 16, 0, 0);
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gnext + H3_STAGE_TILE_BYTES),
+                                       (__attribute__((address_space(3))) void*)(dst + H3_STAGE_TILE_BYTES), 16, 0, 0);
+    gnext += H3_STAGE_BYTES;
+  }
+  __device__ __forceinline__ void start() {
+#pragma unroll
+    for (int i = 0; i < H3_RING; ++i) fetch(i);
+    cur = 0;
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // 3 ops x (RING-1) younger stages
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // 2 ops x (RING-1)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  __device__ __forceinline__ const char* stage() const { return lds + cur * H3_STAGE_BYTES; }
+  __device__ __forceinline__ void advance() {
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");  // 3 ops x (RING-2)
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");            // 2 ops x (RING-2)
+    if (!(debug & 2)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int released = cur;
+    cur = (cur + 1 == H3_RING) ? 0 : cur + 1;
+    if (!(debug & 1)) fetch(released);
+  }
+};
+static_assert(H3_RING == 5, "the vmcnt immediates in H3Pipe assume a 5-deep ring");
+
+// chained MLP stage:  y[OT_OUT] += W2 . act(sc0 * (W0 . xin) + b0), 32 hidden units per chunk.
+// Stages per chunk: W0 chunk as 8/KS... = (2*KS_IN)/4 stages (aux on the first), W2 chunk as ceil(OT_OUT/4).
+template <int NT, int KS_IN, int OT_OUT, bool SILU>
+__device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&yacc)[OT_OUT][NT], H3Pipe& pipe,
+                                             int n_chunks, int lane) {
+  const int g = lane >> 4;
+  constexpr int O_PER_STAGE = H3_STAGE_PAIRS / KS_IN;  // 1 (KS_IN = 4) or 2 (KS_IN = 2)
+  constexpr int A_STAGES = 2 / O_PER_STAGE;
+  constexpr int B_STAGES = (OT_OUT + 3) / 4;
+  BOp<NT> hb[1];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) { hb[0].h[jt] = xin[0].h[jt]; hb[0].l[jt] = xin[0].l[jt]; }
+  for (int c = 0; c < n_chunks; ++c) {
+    f4 hacc[2][NT];
+    f4 bias[2];
+    float sc = 1.f;
+#pragma unroll
+    for (int a = 0; a < A_STAGES; ++a) {
+      const char* st = pipe.stage();
+      if (a == 0) {
+        const float* aux = (const float*)(st + H3_STAGE_TILE_BYTES);
+        sc = aux[32];
+        bias[0] = *(const f4*)(aux + 4 * g);
+        bias[1] = *(const f4*)(aux + 16 + 4 * g);
+      }
+#pragma unroll
+      for (int oo = 0; oo < O_PER_STAGE; ++oo) {
+        const int o = a * O_PER_STAGE + oo;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) hacc[o][jt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS_IN; ++ks) {
+          const char* pr = st + (oo * KS_IN + ks) * H3_PAIR_BYTES + lane * 16;
+          const h8 ah = *(const h8*)pr;
+          const h8 al = *(const h8*)(pr + 1024);
+          mma3<NT>(ah, al, xin[ks], hacc[o]);
+        }
+      }
+      pipe.advance();
+    }
+    if (!(pipe.debug & 4)) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = fmaf(hacc[o][jt][r], sc, bias[o][r]);
+            hacc[o][jt][r] = SILU ? v / (1.f + expf(-v)) : fmaxf(v, 0.f);
+          }
+      to_bop<NT, 1>(hacc, hb);
+    } else {
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) asm volatile("" : "+v"(hacc[0][jt]), "+v"(hacc[1][jt]));
+    }
+#pragma unroll
+    for (int b = 0; b < B_STAGES; ++b) {
+      const char* st = pipe.stage();
+#pragma unroll
+      for (int oo = 0; oo < 4; ++oo) {
+        const int ot = 4 * b + oo;
+        if (ot < OT_OUT) {
+          const char* pr = st + oo * H3_PAIR_BYTES + lane * 16;
+          const h8 ah = *(const h8*)pr;
+          const h8 al = *(const h8*)(pr + 1024);
+          mma3<NT>(ah, al, hb[0], yacc[ot]);
+        }
+      }
+      pipe.advance();
+    }
+  }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+netblock_h3_kernel(const H3Params p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, i16 = lane & 15;
+
+  int net, wg;
+  if (p.net_sel < 0) {
+    const int xcd = blockIdx.x & 7;
+    net = xcd >> 2;
+    wg = (blockIdx.x >> 3) * 4 + (xcd & 3);
+  } else {
+    net = p.net_sel;
+    wg = blockIdx.x;
+  }
+  // every wave of the workgroup takes part in the weight pipeline, even if it owns no rows
+  const int blk = wg * 4 + wave;
+  const bool active = blk < p.nblocks;
+  if (wg * 4 >= p.nblocks) return;  // whole workgroup idle (uniform)
+
+  const char* net_base = p.packed + (int64_t)net * p.net_stride_bytes;
+  const float* side = (const float*)(net_base + p.stages * H3_STAGE_BYTES);
+  const float* scales = side + p.side_scales;
+  _Float16* xt_hi = (_Float16*)(lds + H3_RING * H3_STAGE_BYTES + wave * H3_WAVE_LDS);
+  _Float16* xt_lo = xt_hi + 128 * H3_XT;
+
+  // ---- token bookkeeping and input features (ordinary loads: before the DMA pipeline starts) ----
+  int64_t tok_row[NT];
+  int tok_atom[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int t = 16 * jt + i16;
+    const int q = t / p.V;
+    const int64_t n = (int64_t)blk * p.mpw + q;
+    const bool ok = active && q < p.mpw && n < p.n_rows;
+    tok_row[jt] = ok ? n : -1;
+    tok_atom[jt] = t - q * p.V;
+  }
+  // u in B-operand element order: k-step ks, element e  <->  feature 32 ks + 16 (e/4) + 4 g + e%4
+  BOp<NT> u[2];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int64_t n = tok_row[jt];
+    const int64_t c = n < 0 ? 0 : n % p.n_cond;
+    const int a = tok_atom[jt];
+    const int ty = n < 0 ? 0 : p.types[c * p.V + a];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int f = 32 * ks + 16 * (e / 4) + 4 * g + (e % 4);
+        float val = 0.f;
+        if (n >= 0) {
+          if (f < p.d_emb) val = p.emb[ty * p.d_emb + f];
+          else if (f < p.d_emb + 3) val = p.xc[(c * p.V + a) * 3 + (f - p.d_emb)];
+          else if (f < p.d_emb + 6) val = p.xv[(c * p.V + a) * 3 + (f - p.d_emb - 3)];
+          else if (f < p.d_emb + 9) val = p.z_other[(n * p.V + a) * 3 + (f - p.d_emb - 6)];
+        }
+        const _Float16 hi = (_Float16)val;
+        u[ks].h[jt][e] = hi;
+        u[ks].l[jt][e] = (_Float16)(val - (float)hi);
+      }
+  }
+  // zero the transposed tile once: its pad columns are multiplied by zero scores and must be finite
+  for (int i = lane; i < H3_WAVE_LDS / 16; i += 64) ((f4*)xt_hi)[i] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- start the weight pipeline ----
+  H3Pipe pipe;
+  pipe.gnext = net_base + lane * 16;
+  pipe.lds = lds;
+  pipe.cur = 0;
+  pipe.wave = wave;
+  pipe.debug = p.debug;
+  pipe.start();
+
+  auto dump_x = [&](const f4 (&x)[8][NT], int stage) {
+    if (!p.dump) return;
+    float* d = p.dump + (int64_t)stage * p.n_rows * p.V * 128;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      if (tok_row[jt] < 0) continue;
+      float* row = d + (tok_row[jt] * p.V + tok_atom[jt]) * 128;
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) *(f4*)(row + 16 * ft + 4 * g) = x[ft][jt];
+    }
+  };
+
+  // ---- IN stage ----
+  f4 x[8][NT];
+  {
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) x[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
+    h3_mlp_chain<NT, 2, 8, true>(u, x, pipe, p.hid_chunks, lane);
+    const float sc = scales[1];
+    const float* b2 = side + p.side_in2b + 4 * g;
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+      const f4 bb = *(const f4*)(b2 + 16 * ot);
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) x[ot][jt] = x[ot][jt] * sc + bb;
+    }
+  }
+  dump_x(x, 0);
+
+  const char* sf_base = p.sfrag + (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * H3_SF_BYTES);
+
+  for (int l = 0; l < p.n_layers; ++l) {
+    const float* sl = side + p.side_layers + (int64_t)l * p.side_layer_size;
+    const float* lsc = scales + 2 + 3 * l;
+    // x -> transposed fp16 hi/lo tile in LDS
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = x[ft][jt][r];
+          const _Float16 hi = (_Float16)v;
+          const int idx = (16 * ft + 4 * g + r) * H3_XT + 16 * jt + i16;
+          xt_hi[idx] = hi;
+          xt_lo[idx] = (_Float16)(v - (float)hi);
+        }
+
+    f4 y[8][NT];
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    for (int h = 0; h < p.H; ++h) {
+      // score fragments of this head (B operand of the mixing MFMA)
+      h8 s0h[NT], s0l[NT];
+      h4 s1h[NT], s1l[NT];
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const char* sp = sf_base + (int64_t)(h * NT + jt) * H3_SF_BYTES;
+        s0h[jt] = *(const h8*)(sp + lane * 16);
+        s0l[jt] = *(const h8*)(sp + 1024 + lane * 16);
+        s1h[jt] = *(const h4*)(sp + 2048 + lane * 8);
+        s1l[jt] = *(const h4*)(sp + 2560 + lane * 8);
+      }
+      // mixing: xm = (A_h X)^T, produced directly as the split B operand of the Wc GEMM
+      BOp<NT> xm[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (p.debug & 8) {
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) { xm[ks].h[jt] = s0h[jt]; xm[ks].l[jt] = s0l[jt]; }
+          continue;
+        }
+        f4 acc[2][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int row = (16 * (2 * ks + t) + i16) * H3_XT;
+          const h8 a0h = *(const h8*)(xt_hi + row + 8 * g);
+          const h8 a0l = *(const h8*)(xt_lo + row + 8 * g);
+          const h4 a1h = *(const h4*)(xt_hi + row + 32 + 4 * g);
+          const h4 a1l = *(const h4*)(xt_lo + row + 32 + 4 * g);
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a0h, s0h[jt], (f4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma16(a1h, s1h[jt], acc[t][jt]);
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a0h, s0l[jt], acc[t][jt]);
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma16(a1h, s1l[jt], acc[t][jt]);
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a0l, s0h[jt], acc[t][jt]);
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma16(a1l, s1h[jt], acc[t][jt]);
+        }
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) split8(acc[0][jt], acc[1][jt], xm[ks].h[jt], xm[ks].l[jt]);
+      }
+      // y += Wc_h . xm : eight stages of (one ot x 4 ks)
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot) {
+        const char* st = pipe.stage();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const char* pr = st + ks * H3_PAIR_BYTES + lane * 16;
+          const h8 ah = *(const h8*)pr;
+          const h8 al = *(const h8*)(pr + 1024);
+          mma3<NT>(ah, al, xm[ks], y[ot]);
+        }
+        pipe.advance();
+      }
+    }
+    {
+      const float sc = lsc[0];
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) y[ot][jt] = y[ot][jt] * sc;
+    }
+    h3_add_layernorm<NT>(x, y, sl + 4 * g, sl + 128 + 4 * g, p.eps);
+
+    // FFN
+    {
+      BOp<NT> xb[4];
+      to_bop<NT, 4>(x, xb);
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
+      h3_mlp_chain<NT, 4, 8, false>(xb, y, pipe, p.ff_chunks, lane);
+      const float sc = lsc[2];
+      const float* b2 = sl + 256 + 4 * g;
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot) {
+        const f4 bb = *(const f4*)(b2 + 16 * ot);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) y[ot][jt] = y[ot][jt] * sc + bb;
+      }
+    }
+    h3_add_layernorm<NT>(x, y, sl + 384 + 4 * g, sl + 512 + 4 * g, p.eps);
+    dump_x(x, l + 1);
+  }
+
+  // ---- OUT stage ----
+  f4 o[1][NT];
+  {
+    BOp<NT> xb[4];
+    to_bop<NT, 4>(x, xb);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) o[0][jt] = (f4){0.f, 0.f, 0.f, 0.f};
+    h3_mlp_chain<NT, 4, 1, true>(xb, o, pipe, p.hid_chunks, lane);
+    const float sc = scales[2 + 3 * p.n_layers + 1];
+    const f4 bb = *(const f4*)(side + p.side_out2b + 4 * g);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) o[0][jt] = o[0][jt] * sc + bb;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // drain the over-fetched stages before the workgroup retires its LDS
+  if (g == 0) {
+    float* outp = p.out[net];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      if (tok_row[jt] < 0) continue;
+      float* dst = outp + (tok_row[jt] * p.V + tok_atom[jt]) * 3;
+      dst[0] = o[0][jt][0];
+      dst[1] = o[0][jt][1];
+      dst[2] = o[0][jt][2];
+      if (p.dump) {
+        float* dd = p.dump + (int64_t)(p.n_layers + 1) * p.n_rows * p.V * 128 + (tok_row[jt] * p.V + tok_atom[jt]) * 3;
+        dd[0] = o[0][jt][0]; dd[1] = o[0][jt][1]; dd[2] = o[0][jt][2];
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct H3Ws {
+  float *s_out, *t_out;
+  char* sfrag;
+  int64_t bytes;
+};
+
+static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
+  FusedGeom g;
+  fused_geom(V, &g);
+  H3Ws w;
+  char* p = (char*)base;
+  auto take = [&](int64_t bytes) {
+    char* r = p;
+    p += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  const int64_t nblocks = (n_rows + g.mpw - 1) / g.mpw;
+  w.s_out = (float*)take(n_rows * V * 3 * 4);
+  w.t_out = (float*)take(n_rows * V * 3 * 4);
+  w.sfrag = take(nblocks * d.n_heads * H3_NT * H3_SF_BYTES);
+  w.bytes = p - (char*)base;
+  return w;
+}
+
+int g_debug_flags = 0;
+
+int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms) {
+  return h3_ws(d, n_rows, n_atoms, nullptr).bytes;
+}
+
+static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg, int c, int net_sel, const float* z_other,
+                     const char* sfrag, bool shared, float* s_out, float* t_out, float* dump) {
+  const tw_flow_desc& d = *a.desc;
+  const H3Geom g = h3_geom(d);
+  H3Params p;
+  p.packed = (const char*)a.packed + (int64_t)(c * 2) * g.net_stride_bytes;
+  p.net_stride_bytes = g.net_stride_bytes;
+  p.stages = g.stages;
+  p.side_in2b = g.side_in2b;
+  p.side_layers = g.side_layers;
+  p.side_layer_size = g.side_layer_size;
+  p.side_out2b = g.side_out2b;
+  p.side_scales = g.side_scales;
+  p.emb = a.raw + L.emb;
+  p.types = a.atom_types;
+  p.xc = a.x_coords;
+  p.xv = a.x_velocs;
+  p.z_other = z_other;
+  p.sfrag = sfrag;
+  p.sfrag_shared = shared ? 1 : 0;
+  p.out[0] = s_out;
+  p.out[1] = t_out;
+  p.dump = dump;
+  p.n_rows = a.n_rows;
+  p.n_cond = a.n_cond;
+  p.V = a.n_atoms;
+  p.mpw = fg.mpw;
+  p.nblocks = (int)((a.n_rows + fg.mpw - 1) / fg.mpw);
+  p.H = d.n_heads;
+  p.n_layers = d.n_layers;
+  p.ff_chunks = g.ff_chunks;
+  p.hid_chunks = g.hid_chunks;
+  p.d_emb = d.d_emb;
+  p.eps = d.ln_eps;
+  p.net_sel = net_sel;
+  p.debug = g_debug_flags;
+  const int wgs_per_net = (p.nblocks + 3) / 4;
+  unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
+  static bool attr = false;
+  if (!attr) {
+    TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_h3_kernel<H3_NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)H3_LDS_BYTES));
+    attr = true;
+  }
+  int prc;
+  if ((prc = profile_mark(a.stream, true))) return prc;
+  hipLaunchKernelGGL(netblock_h3_kernel<H3_NT>, dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
+  TW_LAUNCH_CHECK();
+  if ((prc = profile_mark(a.stream, false))) return prc;
+  return TW_OK;
+}
+
+static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg, char* sfrag, bool shared) {
+  const tw_flow_desc& d = *a.desc;
+  const int V = a.n_atoms;
+  const int64_t nblocks = shared ? 1 : (a.n_rows + fg.mpw - 1) / fg.mpw;
+  size_t shm = (size_t)(fg.mpw * V * 3 + fg.mpw * V * V + fg.mpw * d.n_heads * V) * 4 + (size_t)fg.mpw * V;
+  hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks), dim3(256), shm, a.stream, a.x_coords, a.masked,
+                     a.raw + L.lengthscales, d.n_heads, V, fg.mpw, a.n_rows, a.n_cond, d.normalise, sfrag);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+
+int flow_pass_h3(const FlowArgs& a) {
+  const tw_flow_desc& d = *a.desc;
+  FusedGeom fg;
+  TW_REQUIRE(fused_geom(a.n_atoms, &fg) && fg.nt == H3_NT, "split-fp16 path: unsupported atom count %d", a.n_atoms);
+  const RawLayout L = raw_layout(d);
+  const H3Ws w = h3_ws(d, a.n_rows, a.n_atoms, a.ws);
+  if (w.bytes > a.ws_bytes) {
+    set_error("workspace too small: need %lld bytes, have %lld", (long long)w.bytes, (long long)a.ws_bytes);
+    return TW_ERR_WORKSPACE;
+  }
+  const bool shared = a.n_cond == 1;
+  int rc;
+  if ((rc = h3_score_frags(a, L, fg, w.sfrag, shared))) return rc;
+  for (int i = 0; i < d.n_coupling; ++i) {
+    const int c = a.reverse ? d.n_coupling - 1 - i : i;
+    const bool positions = (c % 2) == d.pos_mod2;
+    const float* z_other = positions ? a.z_velocs : a.z_coords;
+    float* z_t = positions ? a.z_coords : a.z_velocs;
+    if ((rc = h3_launch(a, L, fg, c, -1, z_other, w.sfrag, shared, w.s_out, w.t_out, nullptr))) return rc;
+    if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, z_t, a.delta_logp, a.n_rows, a.n_atoms, a.reverse,
+                              a.stream)))
+      return rc;
+  }
+  return TW_OK;
+}
+
+int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, float* dump) {
+  const tw_flow_desc& d = *a.desc;
+  FusedGeom fg;
+  TW_REQUIRE(fused_geom(a.n_atoms, &fg) && fg.nt == H3_NT, "split-fp16 path: unsupported atom count %d", a.n_atoms);
+  const RawLayout L = raw_layout(d);
+  const H3Ws w = h3_ws(d, a.n_rows, a.n_atoms, a.ws);
+  if (w.bytes > a.ws_bytes) {
+    set_error("workspace too small: need %lld bytes, have %lld", (long long)w.bytes, (long long)a.ws_bytes);
+    return TW_ERR_WORKSPACE;
+  }
+  const bool shared = a.n_cond == 1;
+  int rc;
+  if ((rc = h3_score_frags(a, L, fg, w.sfrag, shared))) return rc;
+  return h3_launch(a, L, fg, c, net, z_other, w.sfrag, shared, w.s_out, w.t_out, dump);
+}
+
+}  // namespace tw

@@ -29,7 +29,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         self.ignore_conditional_velocity = dims.ignore_cond_velocity
         self.use_displacement_as_target = dims.displacement
         self.execution_path = execution_path
-        self._dev_weights = None  # (device, raw, packed)
+        self._dev_weights = None  # {"device", "raw", "f32", "h3"}
         self._workspace = None
         self._dirty = True
 
@@ -47,26 +47,42 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         self._dirty = True
 
     def _weights(self, device: torch.device):
+        """(raw, packed) device buffers; `packed` is the stream of the active execution path (the
+        f32 fragment stream, or the split-fp16 stage stream for TW_PATH_FUSED_H3), built lazily."""
         if self.training:
             self._dirty = True  # parameters may be changing under us: never serve a stale pack
-        if self._dirty or self._dev_weights is None or self._dev_weights[0] != device:
+        if self._dirty or self._dev_weights is None or self._dev_weights["device"] != device:
             lib = _lib.load()
             desc = self.dims.to_desc()
             raw_cpu = pack_raw(self.state_dict(), self.dims)
             expect = lib.tw_flow_raw_floats(C.byref(desc))
             if expect != raw_cpu.numel():
                 raise RuntimeError(f"raw weight layout mismatch: host packed {raw_cpu.numel()} floats, library expects {expect}")
-            raw = raw_cpu.to(device)
-            packed = None
-            n_packed = lib.tw_flow_packed_floats(C.byref(desc))
-            if n_packed > 0:
-                packed = torch.empty(n_packed, dtype=torch.float32, device=device)
-                with torch.cuda.device(device):
-                    _lib.check(lib.tw_flow_pack(C.byref(desc), raw.data_ptr(), packed.data_ptr(),
-                                                _lib.stream_ptr(device)), "tw_flow_pack")
-            self._dev_weights = (device, raw, packed)
+            self._dev_weights = {"device": device, "raw": raw_cpu.to(device), "f32": None, "h3": None}
             self._dirty = False
-        return self._dev_weights[1], self._dev_weights[2]
+        w = self._dev_weights
+        lib = _lib.load()
+        desc = self.dims.to_desc()
+        if self.execution_path == _lib.TW_PATH_FUSED_H3:
+            if w["h3"] is None:
+                n = lib.tw_flow_packed_h3_bytes(C.byref(desc))
+                if n <= 0:
+                    raise RuntimeError("the split-fp16 path does not support this model configuration")
+                buf = torch.empty(n, dtype=torch.uint8, device=device)
+                with torch.cuda.device(device):
+                    _lib.check(lib.tw_flow_pack_h3(C.byref(desc), w["raw"].data_ptr(), buf.data_ptr(),
+                                                   _lib.stream_ptr(device)), "tw_flow_pack_h3")
+                w["h3"] = buf
+            return w["raw"], w["h3"]
+        if w["f32"] is None and self.execution_path != _lib.TW_PATH_SIMPLE:
+            n = lib.tw_flow_packed_floats(C.byref(desc))
+            if n > 0:
+                buf = torch.empty(n, dtype=torch.float32, device=device)
+                with torch.cuda.device(device):
+                    _lib.check(lib.tw_flow_pack(C.byref(desc), w["raw"].data_ptr(), buf.data_ptr(),
+                                                _lib.stream_ptr(device)), "tw_flow_pack")
+                w["f32"] = buf
+        return w["raw"], w["f32"]
 
     def _ws(self, device: torch.device, n_rows: int, n_atoms: int):
         lib = _lib.load()

@@ -13,9 +13,12 @@ from tests import helpers as H  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--S", type=int, default=1000)
 ap.add_argument("--iters", type=int, default=5)
-ap.add_argument("--paths", default="1,2")
+ap.add_argument("--paths", default="1,3")
+ap.add_argument("--debug-flags", type=int, default=0)
 args = ap.parse_args()
 
+from timewarp_amd import _lib
+_lib.load().tw_debug_set_flags(args.debug_flags)
 d, _ = H.load("kernel_full_ad_calibrated")
 sd = H.full_kernel_sd(calibrated=True)
 S = args.S
