@@ -25,6 +25,8 @@ namespace tw {
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));  // raw 128-bit register tuple
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 #ifndef H3_DEBUG_SYNC
 #define H3_DEBUG_SYNC 0
@@ -389,8 +391,7 @@ struct H3Params {
   int H, n_layers, ff_chunks, hid_chunks, d_emb;
   float eps;
   int net_sel;
-  int debug;  // timing experiments only: bit 0 = no weight DMA after the prologue, bit 1 = no barriers,
-              // bit 2 = skip the FFN/MLP epilogue + fp16 split, bit 3 = skip the mixing MFMAs + split
+  int debug;  // timing experiments only: bit 0 = no weight DMA after the prologue, bit 1 = no barriers
 };
 
 template <int NT>
@@ -433,6 +434,16 @@ __device__ __forceinline__ void to_bop(const f4 (&x)[2 * KS][NT], BOp<NT> (&b)[K
     for (int jt = 0; jt < NT; ++jt) split8(x[2 * ks][jt], x[2 * ks + 1][jt], b[ks].h[jt], b[ks].l[jt]);
 }
 
+// hipcc's s_waitcnt insertion cannot be trusted for ordinary global loads while LDS-DMA is in flight
+// (a missing wait was observed once control flow was added around the score-fragment loads), so every
+// such load group is followed by an explicit full drain, and each loaded value is passed through an
+// empty asm so that no consumer can be scheduled above the drain.
+#define H3_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+__device__ __forceinline__ void h3_settle(f4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void h3_settle(h8& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void h3_settle(h4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void h3_settle(float& v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ float h3_xor_sum(float v) {
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
@@ -448,6 +459,9 @@ __device__ __forceinline__ void h3_add_layernorm(f4 (&x)[8][NT], const f4 (&y)[8
     w[ft] = *(const f4*)(lnw_lane + 16 * ft);
     b[ft] = *(const f4*)(lnb_lane + 16 * ft);
   }
+  H3_DRAIN();
+#pragma unroll
+  for (int ft = 0; ft < 8; ++ft) { h3_settle(w[ft]); h3_settle(b[ft]); }
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     float s = 0.f;
@@ -471,12 +485,14 @@ __device__ __forceinline__ void h3_add_layernorm(f4 (&x)[8][NT], const f4 (&y)[8
   }
 }
 
-// The weight pipeline: a ring of H3_RING stage buffers in LDS.  While stage s is being read, the
-// LDS-DMA of stages s+1 .. s+RING-1 is in flight or landed.  `advance`:
-//   1. counted wait: this wave's share of stage s+1 has landed (RING-2 younger stages may stay in flight);
-//      the count is stated in asm - hipcc neither counts LDS-DMA nor reliably waits for it;
-//   2. raw s_barrier (not __syncthreads(), whose fence would drain the DMA queue): every wave has
-//      finished reading stage s and every wave's share of s+1 is in LDS;
+// The weight pipeline: a ring of H3_RING stage buffers in LDS, refilled by LDS-DMA.  `advance`:
+//   1. s_waitcnt vmcnt(0): every LDS-DMA this wave has issued has landed (stated in asm: hipcc neither
+//      counts LDS-DMA nor reliably waits for it).  Counted waits (leaving younger stages in flight
+//      across the barrier) were tried and produced stale tiles - completion order between LDS-DMA and
+//      the kernel's ordinary loads is evidently not the issue order - so the DMA queue is drained here;
+//      the ring still keeps RING-1 stages of prefetch distance because the drain happens one full
+//      stage of compute after the youngest fetch was issued;
+//   2. raw s_barrier: every wave has finished reading the current stage and all shares have landed;
 //   3. refill the buffer just released with stage s+RING.
 // Each wave moves 2 KiB of every stage; wave 0 additionally moves the 1 KiB aux block.
 struct H3Pipe {
@@ -501,15 +517,13 @@ struct H3Pipe {
 #pragma unroll
     for (int i = 0; i < H3_RING; ++i) fetch(i);
     cur = 0;
-    if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // 3 ops x (RING-1) younger stages
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // 2 ops x (RING-1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
   __device__ __forceinline__ const char* stage() const { return lds + cur * H3_STAGE_BYTES; }
   __device__ __forceinline__ void advance() {
-    if (wave == 0) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");  // 3 ops x (RING-2)
-    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");            // 2 ops x (RING-2)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (!(debug & 2)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const int released = cur;
@@ -517,7 +531,21 @@ struct H3Pipe {
     if (!(debug & 1)) fetch(released);
   }
 };
-static_assert(H3_RING == 5, "the vmcnt immediates in H3Pipe assume a 5-deep ring");
+
+// All tile pairs of the current stage, read up front into distinct registers (hipcc otherwise reuses
+// one register quad for every read and exposes the LDS latency eight times per stage); the
+// sched_barrier keeps the reads ahead of the MFMAs that consume them.
+struct H3Tiles {
+  // Tile pairs are read from LDS right where they are used.  Reading all eight up front would hide
+  // the LDS latency (hipcc reuses one register quad for every read and exposes it per pair), but every
+  // attempt to force that order (sched_barrier, asm register fences) produced wrong results in this
+  // ~500-register kernel; left as measured future work.
+  const char* base;
+  __device__ __forceinline__ void load(const char* st, int lane) { base = st + lane * 16; }
+  __device__ __forceinline__ void ready(int) {}
+  __device__ __forceinline__ h8 hi(int p) const { return *(const h8*)(base + p * H3_PAIR_BYTES); }
+  __device__ __forceinline__ h8 lo(int p) const { return *(const h8*)(base + p * H3_PAIR_BYTES + 1024); }
+};
 
 // chained MLP stage:  y[OT_OUT] += W2 . act(sc0 * (W0 . xin) + b0), 32 hidden units per chunk.
 // Stages per chunk: W0 chunk as 8/KS... = (2*KS_IN)/4 stages (aux on the first), W2 chunk as ceil(OT_OUT/4).
@@ -528,9 +556,6 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
   constexpr int O_PER_STAGE = H3_STAGE_PAIRS / KS_IN;  // 1 (KS_IN = 4) or 2 (KS_IN = 2)
   constexpr int A_STAGES = 2 / O_PER_STAGE;
   constexpr int B_STAGES = (OT_OUT + 3) / 4;
-  BOp<NT> hb[1];
-#pragma unroll
-  for (int jt = 0; jt < NT; ++jt) { hb[0].h[jt] = xin[0].h[jt]; hb[0].l[jt] = xin[0].l[jt]; }
   for (int c = 0; c < n_chunks; ++c) {
     f4 hacc[2][NT];
     f4 bias[2];
@@ -544,6 +569,8 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
         bias[0] = *(const f4*)(aux + 4 * g);
         bias[1] = *(const f4*)(aux + 16 + 4 * g);
       }
+      H3Tiles w;
+      w.load(st, lane);
 #pragma unroll
       for (int oo = 0; oo < O_PER_STAGE; ++oo) {
         const int o = a * O_PER_STAGE + oo;
@@ -551,41 +578,34 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
         for (int jt = 0; jt < NT; ++jt) hacc[o][jt] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS_IN; ++ks) {
-          const char* pr = st + (oo * KS_IN + ks) * H3_PAIR_BYTES + lane * 16;
-          const h8 ah = *(const h8*)pr;
-          const h8 al = *(const h8*)(pr + 1024);
-          mma3<NT>(ah, al, xin[ks], hacc[o]);
+          const int pr = oo * KS_IN + ks;
+          if (pr % 2 == 0) w.ready(pr);
+          mma3<NT>(w.hi(pr), w.lo(pr), xin[ks], hacc[o]);
         }
       }
       pipe.advance();
     }
-    if (!(pipe.debug & 4)) {
 #pragma unroll
-      for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
+      for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = fmaf(hacc[o][jt][r], sc, bias[o][r]);
-            hacc[o][jt][r] = SILU ? v / (1.f + expf(-v)) : fmaxf(v, 0.f);
-          }
-      to_bop<NT, 1>(hacc, hb);
-    } else {
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) asm volatile("" : "+v"(hacc[0][jt]), "+v"(hacc[1][jt]));
-    }
+        for (int r = 0; r < 4; ++r) {
+          const float v = fmaf(hacc[o][jt][r], sc, bias[o][r]);
+          hacc[o][jt][r] = SILU ? v / (1.f + expf(-v)) : fmaxf(v, 0.f);
+        }
+    BOp<NT> hb[1];
+    to_bop<NT, 1>(hacc, hb);
 #pragma unroll
     for (int b = 0; b < B_STAGES; ++b) {
       const char* st = pipe.stage();
+      H3Tiles w;
+      w.load(st, lane);
 #pragma unroll
       for (int oo = 0; oo < 4; ++oo) {
         const int ot = 4 * b + oo;
-        if (ot < OT_OUT) {
-          const char* pr = st + oo * H3_PAIR_BYTES + lane * 16;
-          const h8 ah = *(const h8*)pr;
-          const h8 al = *(const h8*)(pr + 1024);
-          mma3<NT>(ah, al, hb[0], yacc[ot]);
-        }
+        if (oo % 2 == 0) w.ready(oo);
+        if (ot < OT_OUT) mma3<NT>(w.hi(oo), w.lo(oo), hb[0], yacc[ot]);
       }
       pipe.advance();
     }
@@ -689,13 +709,18 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) x[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
     h3_mlp_chain<NT, 2, 8, true>(u, x, pipe, p.hid_chunks, lane);
-    const float sc = scales[1];
+    float sc = scales[1];
     const float* b2 = side + p.side_in2b + 4 * g;
+    f4 bb[8];
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) bb[ot] = *(const f4*)(b2 + 16 * ot);
+    H3_DRAIN();
+    h3_settle(sc);
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) {
-      const f4 bb = *(const f4*)(b2 + 16 * ot);
+      h3_settle(bb[ot]);
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) x[ot][jt] = x[ot][jt] * sc + bb;
+      for (int jt = 0; jt < NT; ++jt) x[ot][jt] = x[ot][jt] * sc + bb[ot];
     }
   }
   dump_x(x, 0);
@@ -737,15 +762,13 @@ netblock_h3_kernel(const H3Params p) {
         s1h[jt] = *(const h4*)(sp + 2048 + lane * 8);
         s1l[jt] = *(const h4*)(sp + 2560 + lane * 8);
       }
+      H3_DRAIN();
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) { h3_settle(s0h[jt]); h3_settle(s0l[jt]); h3_settle(s1h[jt]); h3_settle(s1l[jt]); }
       // mixing: xm = (A_h X)^T, produced directly as the split B operand of the Wc GEMM
       BOp<NT> xm[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        if (p.debug & 8) {
-#pragma unroll
-          for (int jt = 0; jt < NT; ++jt) { xm[ks].h[jt] = s0h[jt]; xm[ks].l[jt] = s0l[jt]; }
-          continue;
-        }
         f4 acc[2][NT];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -774,18 +797,20 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot) {
         const char* st = pipe.stage();
+        H3Tiles w;
+        w.load(st, lane);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const char* pr = st + ks * H3_PAIR_BYTES + lane * 16;
-          const h8 ah = *(const h8*)pr;
-          const h8 al = *(const h8*)(pr + 1024);
-          mma3<NT>(ah, al, xm[ks], y[ot]);
+          if (ks % 2 == 0) w.ready(ks);
+          mma3<NT>(w.hi(ks), w.lo(ks), xm[ks], y[ot]);
         }
         pipe.advance();
       }
     }
     {
-      const float sc = lsc[0];
+      float sc = lsc[0];
+      H3_DRAIN();
+      h3_settle(sc);
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
@@ -802,13 +827,18 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
       h3_mlp_chain<NT, 4, 8, false>(xb, y, pipe, p.ff_chunks, lane);
-      const float sc = lsc[2];
+      float sc = lsc[2];
       const float* b2 = sl + 256 + 4 * g;
+      f4 bb[8];
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot) bb[ot] = *(const f4*)(b2 + 16 * ot);
+      H3_DRAIN();
+      h3_settle(sc);
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot) {
-        const f4 bb = *(const f4*)(b2 + 16 * ot);
+        h3_settle(bb[ot]);
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) y[ot][jt] = y[ot][jt] * sc + bb;
+        for (int jt = 0; jt < NT; ++jt) y[ot][jt] = y[ot][jt] * sc + bb[ot];
       }
     }
     h3_add_layernorm<NT>(x, y, sl + 384 + 4 * g, sl + 512 + 4 * g, p.eps);
@@ -823,8 +853,11 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) o[0][jt] = (f4){0.f, 0.f, 0.f, 0.f};
     h3_mlp_chain<NT, 4, 1, true>(xb, o, pipe, p.hid_chunks, lane);
-    const float sc = scales[2 + 3 * p.n_layers + 1];
-    const f4 bb = *(const f4*)(side + p.side_out2b + 4 * g);
+    float sc = scales[2 + 3 * p.n_layers + 1];
+    f4 bb = *(const f4*)(side + p.side_out2b + 4 * g);
+    H3_DRAIN();
+    h3_settle(sc);
+    h3_settle(bb);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) o[0][jt] = o[0][jt] * sc + bb;
   }
