@@ -27,6 +27,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));  // raw 128-bit register tuple
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));  // raw 128-bit register tuple
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 #ifndef H3_DEBUG_SYNC
 #define H3_DEBUG_SYNC 0
@@ -435,14 +437,57 @@ __device__ __forceinline__ void to_bop(const f4 (&x)[2 * KS][NT], BOp<NT> (&b)[K
 }
 
 // hipcc's s_waitcnt insertion cannot be trusted for ordinary global loads while LDS-DMA is in flight
-// (a missing wait was observed once control flow was added around the score-fragment loads), so every
-// such load group is followed by an explicit full drain, and each loaded value is passed through an
-// empty asm so that no consumer can be scheduled above the drain.
-#define H3_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-__device__ __forceinline__ void h3_settle(f4& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void h3_settle(h8& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void h3_settle(h4& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void h3_settle(float& v) { asm volatile("" : "+v"(v)); }
+// (a missing wait was observed once control flow was added around the score-fragment loads).  Every
+// global load inside the pipelined part of the kernel is therefore issued from inline asm together
+// with its own s_waitcnt vmcnt(0) in ONE statement (early-clobber outputs): the compiler neither
+// counts nor schedules around these loads, and the wait also drains the LDS-DMA queue.
+__device__ __forceinline__ void h3_load8_f4(const float* p, f4 (&v)[8]) {  // v[i] = *(f4*)(p + 16 i)
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off\n\t"
+      "global_load_dwordx4 %1, %8, off offset:64\n\t"
+      "global_load_dwordx4 %2, %8, off offset:128\n\t"
+      "global_load_dwordx4 %3, %8, off offset:192\n\t"
+      "global_load_dwordx4 %4, %8, off offset:256\n\t"
+      "global_load_dwordx4 %5, %8, off offset:320\n\t"
+      "global_load_dwordx4 %6, %8, off offset:384\n\t"
+      "global_load_dwordx4 %7, %8, off offset:448\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p)
+      : "memory");
+}
+__device__ __forceinline__ f4 h3_load_f4(const float* p) {
+  f4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ float h3_load_f1(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+// score fragments of one head for three token tiles (H3_SF_BYTES apart): 16-B and 8-B parts
+__device__ __forceinline__ void h3_load_sf3(const char* p16, const char* p8, u4 (&a)[3], u4 (&b)[3], u2 (&c)[3], u2 (&d)[3]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %12, off\n\t"
+      "global_load_dwordx4 %1, %12, off offset:1024\n\t"
+      "global_load_dwordx2 %2, %13, off offset:2048\n\t"
+      "global_load_dwordx2 %3, %13, off offset:2560\n\t"
+      "global_load_dwordx4 %4, %14, off\n\t"
+      "global_load_dwordx4 %5, %14, off offset:1024\n\t"
+      "global_load_dwordx2 %6, %15, off offset:2048\n\t"
+      "global_load_dwordx2 %7, %15, off offset:2560\n\t"
+      "global_load_dwordx4 %8, %16, off\n\t"
+      "global_load_dwordx4 %9, %16, off offset:1024\n\t"
+      "global_load_dwordx2 %10, %17, off offset:2048\n\t"
+      "global_load_dwordx2 %11, %17, off offset:2560\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a[0]), "=&v"(b[0]), "=&v"(c[0]), "=&v"(d[0]), "=&v"(a[1]), "=&v"(b[1]), "=&v"(c[1]), "=&v"(d[1]),
+        "=&v"(a[2]), "=&v"(b[2]), "=&v"(c[2]), "=&v"(d[2])
+      : "v"(p16), "v"(p8), "v"(p16 + H3_SF_BYTES), "v"(p8 + H3_SF_BYTES), "v"(p16 + 2 * H3_SF_BYTES),
+        "v"(p8 + 2 * H3_SF_BYTES)
+      : "memory");
+}
 
 __device__ __forceinline__ float h3_xor_sum(float v) {
   v += __shfl_xor(v, 16);
@@ -454,14 +499,8 @@ template <int NT>
 __device__ __forceinline__ void h3_add_layernorm(f4 (&x)[8][NT], const f4 (&y)[8][NT], const float* lnw_lane,
                                                  const float* lnb_lane, float eps) {
   f4 w[8], b[8];
-#pragma unroll
-  for (int ft = 0; ft < 8; ++ft) {
-    w[ft] = *(const f4*)(lnw_lane + 16 * ft);
-    b[ft] = *(const f4*)(lnb_lane + 16 * ft);
-  }
-  H3_DRAIN();
-#pragma unroll
-  for (int ft = 0; ft < 8; ++ft) { h3_settle(w[ft]); h3_settle(b[ft]); }
+  h3_load8_f4(lnw_lane, w);
+  h3_load8_f4(lnb_lane, b);
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     float s = 0.f;
@@ -709,16 +748,11 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) x[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
     h3_mlp_chain<NT, 2, 8, true>(u, x, pipe, p.hid_chunks, lane);
-    float sc = scales[1];
-    const float* b2 = side + p.side_in2b + 4 * g;
+    const float sc = h3_load_f1(scales + 1);
     f4 bb[8];
-#pragma unroll
-    for (int ot = 0; ot < 8; ++ot) bb[ot] = *(const f4*)(b2 + 16 * ot);
-    H3_DRAIN();
-    h3_settle(sc);
+    h3_load8_f4(side + p.side_in2b + 4 * g, bb);
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) {
-      h3_settle(bb[ot]);
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) x[ot][jt] = x[ot][jt] * sc + bb[ot];
     }
@@ -752,19 +786,22 @@ netblock_h3_kernel(const H3Params p) {
 
     for (int h = 0; h < p.H; ++h) {
       // score fragments of this head (B operand of the mixing MFMA)
+      static_assert(NT == 3, "h3_load_sf3 loads three token tiles");
+      u4 r0h[3], r0l[3];
+      u2 r1h[3], r1l[3];
+      {
+        const char* sp = sf_base + (int64_t)(h * NT) * H3_SF_BYTES;
+        h3_load_sf3(sp + lane * 16, sp + lane * 8, r0h, r0l, r1h, r1l);
+      }
       h8 s0h[NT], s0l[NT];
       h4 s1h[NT], s1l[NT];
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
-        const char* sp = sf_base + (int64_t)(h * NT + jt) * H3_SF_BYTES;
-        s0h[jt] = *(const h8*)(sp + lane * 16);
-        s0l[jt] = *(const h8*)(sp + 1024 + lane * 16);
-        s1h[jt] = *(const h4*)(sp + 2048 + lane * 8);
-        s1l[jt] = *(const h4*)(sp + 2560 + lane * 8);
+        s0h[jt] = __builtin_bit_cast(h8, r0h[jt]);
+        s0l[jt] = __builtin_bit_cast(h8, r0l[jt]);
+        s1h[jt] = __builtin_bit_cast(h4, r1h[jt]);
+        s1l[jt] = __builtin_bit_cast(h4, r1l[jt]);
       }
-      H3_DRAIN();
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) { h3_settle(s0h[jt]); h3_settle(s0l[jt]); h3_settle(s1h[jt]); h3_settle(s1l[jt]); }
       // mixing: xm = (A_h X)^T, produced directly as the split B operand of the Wc GEMM
       BOp<NT> xm[4];
 #pragma unroll
@@ -808,9 +845,7 @@ netblock_h3_kernel(const H3Params p) {
       }
     }
     {
-      float sc = lsc[0];
-      H3_DRAIN();
-      h3_settle(sc);
+      const float sc = h3_load_f1(lsc);
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
@@ -827,16 +862,11 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
       h3_mlp_chain<NT, 4, 8, false>(xb, y, pipe, p.ff_chunks, lane);
-      float sc = lsc[2];
-      const float* b2 = sl + 256 + 4 * g;
+      const float sc = h3_load_f1(lsc + 2);
       f4 bb[8];
-#pragma unroll
-      for (int ot = 0; ot < 8; ++ot) bb[ot] = *(const f4*)(b2 + 16 * ot);
-      H3_DRAIN();
-      h3_settle(sc);
+      h3_load8_f4(sl + 256 + 4 * g, bb);
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot) {
-        h3_settle(bb[ot]);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) y[ot][jt] = y[ot][jt] * sc + bb[ot];
       }
@@ -853,11 +883,8 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) o[0][jt] = (f4){0.f, 0.f, 0.f, 0.f};
     h3_mlp_chain<NT, 4, 1, true>(xb, o, pipe, p.hid_chunks, lane);
-    float sc = scales[2 + 3 * p.n_layers + 1];
-    f4 bb = *(const f4*)(side + p.side_out2b + 4 * g);
-    H3_DRAIN();
-    h3_settle(sc);
-    h3_settle(bb);
+    const float sc = h3_load_f1(scales + 2 + 3 * p.n_layers + 1);
+    const f4 bb = h3_load_f4(side + p.side_out2b + 4 * g);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) o[0][jt] = o[0][jt] * sc + bb;
   }
