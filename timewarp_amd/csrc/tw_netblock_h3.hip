@@ -38,6 +38,9 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3_XT 56                    // halfs per feature row of the transposed X tile
 #define H3_PAIR_BYTES 2048          // one (hi, lo) tile pair: 16 out x 32 k
 #define H3_STAGE_PAIRS 4
+#ifndef H3_SCHED
+#define H3_SCHED 1
+#endif
 #define H3_STAGE_TILE_BYTES 8192    // 4 pairs
 #define H3_STAGE_BYTES 9216         // + 1 KiB aux (bias[32], scale)
 #define H3_RING 5                   // stage buffers: 1 being read + 4 in flight (~1 us of LDS-DMA latency)
@@ -575,16 +578,49 @@ struct H3Pipe {
 // one register quad for every read and exposes the LDS latency eight times per stage); the
 // sched_barrier keeps the reads ahead of the MFMAs that consume them.
 struct H3Tiles {
-  // Tile pairs are read from LDS right where they are used.  Reading all eight up front would hide
-  // the LDS latency (hipcc reuses one register quad for every read and exposes it per pair), but every
-  // attempt to force that order (sched_barrier, asm register fences) produced wrong results in this
-  // ~500-register kernel; left as measured future work.
+  // Rolling prefetch of the stage's four tile pairs: pair p+2 is read while pair p is consumed.
+  // hipcc's default is read -> wait -> use per pair, which exposes the LDS latency eight times per
+  // stage; reading all eight at once is slower still (four waves burst-read the same 8 KiB and queue
+  // on the 128 B/clk LDS port).  sched_barrier(0) pins the source order: pair p's MFMAs may not sink
+  // below, nor pair p+2's reads rise above, the fence between them.
+  h8 t[2 * H3_STAGE_PAIRS];
+  const char* base;
+  __device__ __forceinline__ void rd(int p) {
+    t[2 * p] = *(const h8*)(base + p * H3_PAIR_BYTES);
+    t[2 * p + 1] = *(const h8*)(base + p * H3_PAIR_BYTES + 1024);
+  }
+  __device__ __forceinline__ void load(const char* st, int lane) {
+    base = st + lane * 16;
+    rd(0);
+    rd(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // call before consuming pair p
+  __device__ __forceinline__ void ready(int p) {
+    if (p + 2 < H3_STAGE_PAIRS) rd(p + 2);
+  }
+  // call after consuming pair p
+  __device__ __forceinline__ void done(int) { __builtin_amdgcn_sched_barrier(0); }
+  __device__ __forceinline__ h8 hi(int p) const { return t[2 * p]; }
+  __device__ __forceinline__ h8 lo(int p) const { return t[2 * p + 1]; }
+};
+__device__ __forceinline__ void h3_stage_sched() {}
+struct H3TilesPlain {  // read at use
   const char* base;
   __device__ __forceinline__ void load(const char* st, int lane) { base = st + lane * 16; }
   __device__ __forceinline__ void ready(int) {}
+  __device__ __forceinline__ void done(int) {}
   __device__ __forceinline__ h8 hi(int p) const { return *(const h8*)(base + p * H3_PAIR_BYTES); }
   __device__ __forceinline__ h8 lo(int p) const { return *(const h8*)(base + p * H3_PAIR_BYTES + 1024); }
 };
+#ifndef H3_WC_PREFETCH
+#define H3_WC_PREFETCH 0
+#endif
+#if H3_WC_PREFETCH
+typedef H3Tiles H3TilesWc;
+#else
+typedef H3TilesPlain H3TilesWc;
+#endif
 
 // chained MLP stage:  y[OT_OUT] += W2 . act(sc0 * (W0 . xin) + b0), 32 hidden units per chunk.
 // Stages per chunk: W0 chunk as 8/KS... = (2*KS_IN)/4 stages (aux on the first), W2 chunk as ceil(OT_OUT/4).
@@ -618,10 +654,12 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
 #pragma unroll
         for (int ks = 0; ks < KS_IN; ++ks) {
           const int pr = oo * KS_IN + ks;
-          if (pr % 2 == 0) w.ready(pr);
+          w.ready(pr);
           mma3<NT>(w.hi(pr), w.lo(pr), xin[ks], hacc[o]);
+          w.done(pr);
         }
       }
+      h3_stage_sched();
       pipe.advance();
     }
 #pragma unroll
@@ -643,9 +681,11 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
 #pragma unroll
       for (int oo = 0; oo < 4; ++oo) {
         const int ot = 4 * b + oo;
-        if (oo % 2 == 0) w.ready(oo);
+        w.ready(oo);
         if (ot < OT_OUT) mma3<NT>(w.hi(oo), w.lo(oo), hb[0], yacc[ot]);
+        w.done(oo);
       }
+      h3_stage_sched();
       pipe.advance();
     }
   }
@@ -834,13 +874,15 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot) {
         const char* st = pipe.stage();
-        H3Tiles w;
+        H3TilesWc w;
         w.load(st, lane);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          if (ks % 2 == 0) w.ready(ks);
+          w.ready(ks);
           mma3<NT>(w.hi(ks), w.lo(ks), xm[ks], y[ot]);
+          w.done(ks);
         }
+        h3_stage_sched();
         pipe.advance();
       }
     }
