@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libtimewarp_hip.so")
+LIB_PATH = os.environ.get("TW_HIP_LIB") or os.path.join(LIB_DIR, "libtimewarp_hip.so")  # TW_HIP_LIB: use a prebuilt library
 SOURCES = ["tw_kernels.hip", "tw_netblock.hip", "tw_netblock_h3.hip", "tw_energy.hip", "tw_api.hip"]
 HEADERS = [os.path.join(CSRC, "tw_common.h"), os.path.join(HERE, "..", "include", "timewarp_hip.h")]
 

@@ -10,11 +10,18 @@
 //
 // Differences that follow from the 5x shorter compute time per weight byte:
 //  * weights (fp16 hi/lo tile pairs, per-matrix power-of-two scaled so the lo halves stay normal)
-//    are staged through LDS by LDS-DMA (global_load_lds, 16 B/lane) in 17 KiB stages shared by the
-//    4 waves of a workgroup, double buffered, one barrier per stage;
+//    are staged through LDS by LDS-DMA (global_load_lds, 16 B/lane) in 9 KiB stages (4 tile pairs +
+//    1 KiB of bias/scale) shared by the 4 waves of a workgroup, in a 5-deep ring, one barrier per stage;
 //  * the mixing A_h X runs on the same 3-product scheme from an fp16 hi/lo copy of X stored
 //    TRANSPOSED in LDS ([feature][token], row stride 56 halfs -> conflict-free ds_read_b128).
 // Only NT = 3 (<= 24 atoms per molecule ... 2x22) is supported; other sizes use the f32 kernel.
+//
+// Toolchain note (ROCm 7.2 hipcc, gfx950): a dependent accumulation chain that alternates
+// v_mfma_f32_16x16x32_f16 (K=32) and v_mfma_f32_16x16x16_f16 (K=16) on ONE accumulator is emitted back
+// to back, but the hardware needs >= 5 wait states between the two shapes; terms are silently dropped
+// (tools/probe/).  The mixing below therefore keeps the K=32 body and the K=16 tail in separate
+// accumulators.  Before this was understood it showed up as results that changed with any scheduling
+// perturbation of the kernel.
 #include <utility>
 #include <vector>
 
@@ -27,8 +34,6 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));  // raw 128-bit register tuple
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
-typedef unsigned u4 __attribute__((ext_vector_type(4)));  // raw 128-bit register tuple
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 #ifndef H3_DEBUG_SYNC
 #define H3_DEBUG_SYNC 0
@@ -38,9 +43,6 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3_XT 56                    // halfs per feature row of the transposed X tile
 #define H3_PAIR_BYTES 2048          // one (hi, lo) tile pair: 16 out x 32 k
 #define H3_STAGE_PAIRS 4
-#ifndef H3_SCHED
-#define H3_SCHED 1
-#endif
 #define H3_STAGE_TILE_BYTES 8192    // 4 pairs
 #define H3_STAGE_BYTES 9216         // + 1 KiB aux (bias[32], scale)
 #define H3_RING 5                   // stage buffers: 1 being read + 4 in flight (~1 us of LDS-DMA latency)
@@ -604,24 +606,6 @@ struct H3Tiles {
   __device__ __forceinline__ h8 hi(int p) const { return t[2 * p]; }
   __device__ __forceinline__ h8 lo(int p) const { return t[2 * p + 1]; }
 };
-__device__ __forceinline__ void h3_stage_sched() {}
-struct H3TilesPlain {  // read at use
-  const char* base;
-  __device__ __forceinline__ void load(const char* st, int lane) { base = st + lane * 16; }
-  __device__ __forceinline__ void ready(int) {}
-  __device__ __forceinline__ void done(int) {}
-  __device__ __forceinline__ h8 hi(int p) const { return *(const h8*)(base + p * H3_PAIR_BYTES); }
-  __device__ __forceinline__ h8 lo(int p) const { return *(const h8*)(base + p * H3_PAIR_BYTES + 1024); }
-};
-#ifndef H3_WC_PREFETCH
-#define H3_WC_PREFETCH 0
-#endif
-#if H3_WC_PREFETCH
-typedef H3Tiles H3TilesWc;
-#else
-typedef H3TilesPlain H3TilesWc;
-#endif
-
 // chained MLP stage:  y[OT_OUT] += W2 . act(sc0 * (W0 . xin) + b0), 32 hidden units per chunk.
 // Stages per chunk: W0 chunk as 8/KS... = (2*KS_IN)/4 stages (aux on the first), W2 chunk as ceil(OT_OUT/4).
 template <int NT, int KS_IN, int OT_OUT, bool SILU>
@@ -659,7 +643,6 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
           w.done(pr);
         }
       }
-      h3_stage_sched();
       pipe.advance();
     }
 #pragma unroll
@@ -685,7 +668,6 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
         if (ot < OT_OUT) mma3<NT>(w.hi(oo), w.lo(oo), hb[0], yacc[ot]);
         w.done(oo);
       }
-      h3_stage_sched();
       pipe.advance();
     }
   }
@@ -846,7 +828,12 @@ netblock_h3_kernel(const H3Params p) {
       BOp<NT> xm[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        f4 acc[2][NT];
+        // The K=32 body and the K=16 tail accumulate in SEPARATE registers and are summed on the VALU.
+        // A dependent chain that alternates v_mfma_f32_16x16x32_f16 and v_mfma_f32_16x16x16_f16 on one
+        // accumulator needs >= 5 wait states between the two opcodes on gfx950 (SrcC forwarding only
+        // works between MFMAs of the same shape); hipcc (ROCm 7.2) does not insert them and the chain
+        // silently drops terms (tools/probe/mfma_chain_builtin.hip reproduces it: 192 instead of 384).
+        f4 acc[2][NT], tail[2][NT];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int row = (16 * (2 * ks + t) + i16) * H3_XT;
@@ -857,16 +844,20 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a0h, s0h[jt], (f4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-          for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma16(a1h, s1h[jt], acc[t][jt]);
+          for (int jt = 0; jt < NT; ++jt) tail[t][jt] = mfma16(a1h, s1h[jt], (f4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a0h, s0l[jt], acc[t][jt]);
 #pragma unroll
-          for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma16(a1h, s1l[jt], acc[t][jt]);
+          for (int jt = 0; jt < NT; ++jt) tail[t][jt] = mfma16(a1h, s1l[jt], tail[t][jt]);
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a0l, s0h[jt], acc[t][jt]);
 #pragma unroll
-          for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma16(a1l, s1h[jt], acc[t][jt]);
+          for (int jt = 0; jt < NT; ++jt) tail[t][jt] = mfma16(a1l, s1h[jt], tail[t][jt]);
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[t][jt] = acc[t][jt] + tail[t][jt];
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) split8(acc[0][jt], acc[1][jt], xm[ks].h[jt], xm[ks].l[jt]);
       }
@@ -874,7 +865,7 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot) {
         const char* st = pipe.stage();
-        H3TilesWc w;
+        H3Tiles w;
         w.load(st, lane);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -882,8 +873,7 @@ netblock_h3_kernel(const H3Params p) {
           mma3<NT>(w.hi(ks), w.lo(ks), xm[ks], y[ot]);
           w.done(ks);
         }
-        h3_stage_sched();
-        pipe.advance();
+          pipe.advance();
       }
     }
     {
@@ -893,6 +883,7 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) y[ot][jt] = y[ot][jt] * sc;
     }
+    if (p.debug & 4) dump_x(y, l + 1);
     h3_add_layernorm<NT>(x, y, sl + 4 * g, sl + 128 + 4 * g, p.eps);
 
     // FFN
@@ -914,7 +905,7 @@ netblock_h3_kernel(const H3Params p) {
       }
     }
     h3_add_layernorm<NT>(x, y, sl + 384 + 4 * g, sl + 512 + 4 * g, p.eps);
-    dump_x(x, l + 1);
+    if (!(p.debug & 4)) dump_x(x, l + 1);
   }
 
   // ---- OUT stage ----
