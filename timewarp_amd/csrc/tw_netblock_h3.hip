@@ -51,11 +51,12 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3_LDS_BYTES (H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS)
 #define H3_TARGET_MAX 4096.0f       // |w| * 2^s is scaled up to just below this
 
-// stage sequence per net (each 9 KiB = 4 tile pairs + aux):
-//   IN   : hid_chunks x [A: W0 chunk (2 ot x 2 ks) + aux(b0 chunk, scale0)][B0: W2 chunk ot 0-3][B1: ot 4-7]
+// stage sequence per net (each 9 KiB = 4 tile pairs + aux); the A and B stages of the chunked MLPs are
+// emitted software pipelined,  A(0) | A(1) B(0) | A(2) B(1) | ... | B(n-1)  (h3_mlp_chain):
+//   IN   : hid_chunks x { A: [W0 chunk (2 ot x 2 ks) + aux(b0 chunk, scale0)]  B: [W2 chunk ot 0-3][ot 4-7] }
 //   layer: H heads x 8 x [Wc, one ot x 4 ks]
-//          ff_chunks x [A0: W1 chunk o=0 (4 ks) + aux(b1 chunk, scale1)][A1: o=1][B0: W2 chunk ot 0-3][B1: ot 4-7]
-//   OUT  : hid_chunks x [A0: W0 chunk o=0 + aux][A1: o=1][B: W2 chunk (1 pair)]
+//          ff_chunks x { A: [W1 chunk o=0 (4 ks) + aux(b1 chunk, scale1)][o=1]  B: [W2 chunk ot 0-3][ot 4-7] }
+//   OUT  : hid_chunks x { A: [W0 chunk o=0 + aux][o=1]  B: [W2 chunk (1 pair)] }
 // side floats per net: in2_b[128] { n1w n1b [128] b2[128] n2w n2b [128] } out2_b[16]
 //                      scales: in0, in2, per layer (wc, w1, w2), out0, out2  (as 2^-s multipliers)
 struct H3Geom {
@@ -210,6 +211,9 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
   };
   float* up = scratch + 8;  // scratch[8] holds the current 2^s
   int rc;
+  // stage index of the A / B stages of chunk `ch` in the pipelined order  A(0) | A(1) B(0) | ... | B(n-1)
+  auto a_off = [](int ch, int n, int A, int B) -> int64_t { return ch == 0 ? 0 : A + (int64_t)(ch - 1) * (A + B); };
+  auto b_off = [](int ch, int n, int A, int B) -> int64_t { return A + (int64_t)ch * (A + B) + (ch < n - 1 ? A : 0); };
   for (int c = 0; c < d.n_coupling; ++c)
     for (int net = 0; net < 2; ++net) {
       const float* nb = raw + net_base(L, c, net);
@@ -220,7 +224,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
       // ---- IN
       if ((rc = absmax(nb + L.net.in0_w, (int64_t)d.d_hidden * L.d_in, up, scales + 0))) return rc;
       for (int ch = 0; ch < g.hid_chunks; ++ch) {
-        char* a = st + (int64_t)(3 * ch) * H3_STAGE_BYTES;
+        char* a = st + a_off(ch, g.hid_chunks, 1, 2) * H3_STAGE_BYTES;
         if ((rc = block(nb + L.net.in0_w, L.d_in, d.d_hidden, L.d_in, 32 * ch, 0, 2, 2, up, a))) return rc;
         if ((rc = copy(nb + L.net.in0_b + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
         if ((rc = copy(scales + 0, 1, (float*)(a + H3_STAGE_TILE_BYTES) + 32, 1))) return rc;
@@ -228,7 +232,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
       if ((rc = absmax(nb + L.net.in2_w, (int64_t)128 * d.d_hidden, up, scales + 1))) return rc;
       for (int ch = 0; ch < g.hid_chunks; ++ch)
         for (int hf = 0; hf < 2; ++hf) {
-          char* b = st + (int64_t)(3 * ch + 1 + hf) * H3_STAGE_BYTES;
+          char* b = st + (b_off(ch, g.hid_chunks, 1, 2) + hf) * H3_STAGE_BYTES;
           if ((rc = block(nb + L.net.in2_w, d.d_hidden, 128, d.d_hidden, 64 * hf, 32 * ch, 4, 1, up, b))) return rc;
         }
       st += (int64_t)3 * g.hid_chunks * H3_STAGE_BYTES;
@@ -255,7 +259,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         if ((rc = absmax(lb + L.layer.w1, (int64_t)d.d_ff * 128, up, lsc + 1))) return rc;
         for (int ch = 0; ch < g.ff_chunks; ++ch)
           for (int o = 0; o < 2; ++o) {
-            char* a = st + (int64_t)(4 * ch + o) * H3_STAGE_BYTES;
+            char* a = st + (a_off(ch, g.ff_chunks, 2, 2) + o) * H3_STAGE_BYTES;
             if ((rc = block(lb + L.layer.w1, 128, d.d_ff, 128, 32 * ch + 16 * o, 0, 1, 4, up, a))) return rc;
             if (o == 0) {
               if ((rc = copy(lb + L.layer.b1 + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
@@ -265,7 +269,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         if ((rc = absmax(lb + L.layer.w2, (int64_t)128 * d.d_ff, up, lsc + 2))) return rc;
         for (int ch = 0; ch < g.ff_chunks; ++ch)
           for (int hf = 0; hf < 2; ++hf) {
-            char* b = st + (int64_t)(4 * ch + 2 + hf) * H3_STAGE_BYTES;
+            char* b = st + (b_off(ch, g.ff_chunks, 2, 2) + hf) * H3_STAGE_BYTES;
             if ((rc = block(lb + L.layer.w2, d.d_ff, 128, d.d_ff, 64 * hf, 32 * ch, 4, 1, up, b))) return rc;
           }
         st += (int64_t)4 * g.ff_chunks * H3_STAGE_BYTES;
@@ -280,7 +284,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
       if ((rc = absmax(nb + L.net.out0_w, (int64_t)d.d_hidden * 128, up, osc + 0))) return rc;
       for (int ch = 0; ch < g.hid_chunks; ++ch)
         for (int o = 0; o < 2; ++o) {
-          char* a = st + (int64_t)(3 * ch + o) * H3_STAGE_BYTES;
+          char* a = st + (a_off(ch, g.hid_chunks, 2, 1) + o) * H3_STAGE_BYTES;
           if ((rc = block(nb + L.net.out0_w, 128, d.d_hidden, 128, 32 * ch + 16 * o, 0, 1, 4, up, a))) return rc;
           if (o == 0) {
             if ((rc = copy(nb + L.net.out0_b + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
@@ -289,7 +293,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         }
       if ((rc = absmax(nb + L.net.out2_w, (int64_t)3 * d.d_hidden, up, osc + 1))) return rc;
       for (int ch = 0; ch < g.hid_chunks; ++ch) {
-        char* b = st + (int64_t)(3 * ch + 2) * H3_STAGE_BYTES;
+        char* b = st + b_off(ch, g.hid_chunks, 2, 1) * H3_STAGE_BYTES;
         if ((rc = block(nb + L.net.out2_w, d.d_hidden, 3, d.d_hidden, 0, 32 * ch, 1, 1, up, b))) return rc;
       }
       if ((rc = copy(nb + L.net.out2_b, 3, side + g.side_out2b, 16))) return rc;
@@ -607,7 +611,12 @@ struct H3Tiles {
   __device__ __forceinline__ h8 lo(int p) const { return t[2 * p + 1]; }
 };
 // chained MLP stage:  y[OT_OUT] += W2 . act(sc0 * (W0 . xin) + b0), 32 hidden units per chunk.
-// Stages per chunk: W0 chunk as 8/KS... = (2*KS_IN)/4 stages (aux on the first), W2 chunk as ceil(OT_OUT/4).
+// A stages (W0 chunk -> hidden pre-activations, aux block on the first) and B stages (W2 chunk) of
+// consecutive chunks are software pipelined:  A(0) | A(1) B(0) | A(2) B(1) | ... | B(n-1).  The
+// epilogue of chunk c+1 (scale, bias, activation, fp16 hi/lo split: ~27 VALU per 4 values) has no
+// dependence on the B(c) MFMAs, so it is placed inside B(c)'s stages, one 4-value unit per tile pair,
+// where it issues in the shadow of the MFMAs instead of between two MFMA bursts (PMC: 22% of the wave's
+// cycles were VALU issue with the matrix pipe idle).  h3_pack_weights emits the stages in this order.
 template <int NT, int KS_IN, int OT_OUT, bool SILU>
 __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&yacc)[OT_OUT][NT], H3Pipe& pipe,
                                              int n_chunks, int lane) {
@@ -615,10 +624,12 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
   constexpr int O_PER_STAGE = H3_STAGE_PAIRS / KS_IN;  // 1 (KS_IN = 4) or 2 (KS_IN = 2)
   constexpr int A_STAGES = 2 / O_PER_STAGE;
   constexpr int B_STAGES = (OT_OUT + 3) / 4;
-  for (int c = 0; c < n_chunks; ++c) {
-    f4 hacc[2][NT];
-    f4 bias[2];
-    float sc = 1.f;
+  constexpr int UNITS = 2 * NT;  // epilogue units: (o, jt), four hidden values of one token column each
+  f4 hacc[2][NT];
+  f4 bias[2];
+  float sc = 1.f;
+
+  auto a_stages = [&]() {
 #pragma unroll
     for (int a = 0; a < A_STAGES; ++a) {
       const char* st = pipe.stage();
@@ -645,17 +656,31 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
       }
       pipe.advance();
     }
+  };
+  // unit u = (o, jt): activation of hacc[o][jt] -> elements 4o..4o+3 of the split B operand.  The two empty
+  // asm statements pin the unit between the scheduling fences of the tile pair it is issued with (pure
+  // arithmetic is otherwise free to be linearised anywhere in the block, i.e. in front of all MFMAs).
+  auto epi_unit = [&](int u, BOp<NT>& dst, bool pin) {
+    const int o = u / NT, jt = u % NT;
+    f4 in = hacc[o][jt];
+    if (pin) asm volatile("" : "+v"(in));
+    h4 hi4, lo4;
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int r = 0; r < 4; ++r) {
+      const float pre = fmaf(in[r], sc, bias[o][r]);
+      const float v = SILU ? pre / (1.f + expf(-pre)) : fmaxf(pre, 0.f);
+      const _Float16 hi = (_Float16)v;
+      hi4[r] = hi;
+      lo4[r] = (_Float16)(v - (float)hi);
+    }
+    if (pin) asm volatile("" : "+v"(hi4), "+v"(lo4));
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = fmaf(hacc[o][jt][r], sc, bias[o][r]);
-          hacc[o][jt][r] = SILU ? v / (1.f + expf(-v)) : fmaxf(v, 0.f);
-        }
-    BOp<NT> hb[1];
-    to_bop<NT, 1>(hacc, hb);
+    for (int r = 0; r < 4; ++r) {
+      dst.h[jt][4 * o + r] = hi4[r];
+      dst.l[jt][4 * o + r] = lo4[r];
+    }
+  };
+  auto b_stages = [&](const BOp<NT>& cur, bool with_epi, BOp<NT>& nxt) {
 #pragma unroll
     for (int b = 0; b < B_STAGES; ++b) {
       const char* st = pipe.stage();
@@ -665,12 +690,44 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
       for (int oo = 0; oo < 4; ++oo) {
         const int ot = 4 * b + oo;
         w.ready(oo);
-        if (ot < OT_OUT) mma3<NT>(w.hi(oo), w.lo(oo), hb[0], yacc[ot]);
+        if (with_epi) {
+          if (B_STAGES == 1) {
+            if (oo == 0)
+#pragma unroll
+              for (int u = 0; u < UNITS; ++u) epi_unit(u, nxt, false);
+          } else {
+            const int u = 4 * b + oo;
+            if (u < UNITS) epi_unit(u, nxt, true);
+          }
+        }
+        if (ot < OT_OUT) mma3<NT>(w.hi(oo), w.lo(oo), cur, yacc[ot]);
+        if (with_epi && B_STAGES > 1 && 4 * b + oo < UNITS) {
+          // issue order inside this pair's region: one MFMA, then two of the unit's VALU ops in its shadow
+          // (tools/probe/mfma_valu_overlap.hip: two VALU ops per K=32 MFMA issue for free, the third costs)
+#pragma unroll
+          for (int i = 0; i < 3 * NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+        }
         w.done(oo);
       }
       pipe.advance();
     }
+  };
+
+  BOp<NT> hb;
+  a_stages();
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) epi_unit(u, hb, false);
+  for (int c = 0; c + 1 < n_chunks; ++c) {
+    a_stages();  // chunk c+1
+    BOp<NT> nxt;
+    b_stages(hb, true, nxt);  // chunk c, with the epilogue of chunk c+1 in its shadow
+    hb = nxt;
   }
+  BOp<NT> unused;
+  b_stages(hb, false, unused);
 }
 
 template <int NT>
