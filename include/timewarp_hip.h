@@ -63,7 +63,8 @@ int tw_device_count(void);
 /* ---------------------------------------------------------------------------------------------
  * Weights.  The host packs the reference state_dict (SURVEY.md section 8b names) into ONE flat fp32
  * device buffer in the canonical order documented in DESIGN.md ("raw layout"):
- *   embedding[n_elements,d_emb], lengthscales[n_heads] (kernel) , prior log-scales[2],
+ *   embedding[n_elements,d_emb], lengthscales[2,n_heads] (kernel; row 0 is used by forward passes, row 1 by
+ *   reverse passes - equal unless the lengthscales are learnable, see timewarp_amd/weights.py), prior log-scales[2],
  *   then for c in coupling layers, net in (scale, shift):  [dense: rff vectors[3,d_rff/2] once per c]
  *     in_mlp.0.{w[d_hidden,d_in],b}, in_mlp.2.{w[d_model,d_hidden],b},
  *     per layer: kernel: values_proj.w[H*d_model,d_model], out_projection.w[d_model,H*d_model]

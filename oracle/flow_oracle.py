@@ -42,6 +42,7 @@ class FlowSpec:
     use_displacement_as_target: bool = True
     ignore_conditional_velocity: bool = False
     normalise_kernel_values: bool = True
+    attention_type: str = "kernel"  # "kernel" | "learnable_kernel" (kernel_attention.py:159-252)
 
 
 # --------------------------------------------------------------------------------------
@@ -248,7 +249,15 @@ def flow_pass(
     if spec.variant == "kernel":
         # one score matrix per flow call: the reference's Cache makes all 48 encoder layers
         # share it (model_constructor.py:192-195, flow.py:188,299).
-        ls = sd["flow.chain.0.scale_transformer.encoder_layers.0.self_attn.attention.lengthscales"]
+        # The cache key ignores the lengthscales (keyword transform Returns(0)), so the scores are those of
+        # the attention layer evaluated FIRST in this call: chain[0]'s scale net going forward, chain[n-1]'s
+        # going in reverse (custom_transformer_nvp.py:44-93 evaluates the scale net before the shift net).
+        first = spec.num_coupling_layers - 1 if reverse else 0
+        att = f"flow.chain.{first}.scale_transformer.encoder_layers.0.self_attn.attention."
+        if spec.attention_type == "learnable_kernel":
+            ls = torch.exp(sd[att + "log_lengthscales"])  # kernel_attention.py:251-252
+        else:
+            ls = sd[att + "lengthscales"]
         scores = kernel_scores(x_coords, masked, ls, spec.normalise_kernel_values)
     order = range(spec.num_coupling_layers)
     if reverse:

@@ -93,10 +93,10 @@ def ad_topology():
     return torch.tensor(coords, dtype=torch.float32) * 0.1, torch.tensor(types, dtype=torch.int64)
 
 
-def kernel_model(emb, d_model, ff, mlp_hidden, n_coupling, n_layers, lengthscales):
+def kernel_model(emb, d_model, ff, mlp_hidden, n_coupling, n_layers, lengthscales, attention_type="kernel"):
     enc = CustomAttentionEncoderLayerConfig(
         d_model=d_model, dim_feedforward=ff, dropout=0.0, num_heads=len(lengthscales),
-        attention_type="kernel", lengthscales=list(lengthscales), normalise_kernel_values=True,
+        attention_type=attention_type, lengthscales=list(lengthscales), normalise_kernel_values=True,
     )
     cfg = CustomAttentionTransformerNVPConfig(
         atom_embedding_dim=emb, latent_mlp_hidden_dims=list(mlp_hidden), num_coupling_layers=n_coupling,
@@ -296,18 +296,131 @@ def gen_mh_goldens(model):
     np.savez_compressed(os.path.join(OUT, "mh_tiny.npz"), **out)
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
-    torch.set_num_threads(8)
-    ad_x, ad_t = ad_topology()
+def gen_sob_golden(model):
+    """Run the REAL sample_on_batches (utils/evaluation_utils.py:190-333) on CPU with the tiny kernel
+    model, a synthetic energy and recorded noise over three single-molecule batches."""
+    from timewarp.utils import evaluation_utils as eu
+    from timewarp.dataloader import DenseMolDynBatch
 
-    # ---- (1) tiny kernel model, reference-initialised weights stored in full ------------------
+    V = 7
+    g = torch.Generator().manual_seed(91)
+    masses = torch.tensor([12.01, 1.008, 14.01, 16.0, 12.01, 1.008, 1.008])
+    x_ref = torch.randn(1, V, 3, generator=g) * 0.3
+    energy = SyntheticEnergy(x_ref.clone())
+    batches = []
+    for b in range(3):
+        at = torch.randint(0, 5, (1, V), generator=g)
+        x0 = x_ref + torch.randn(1, V, 3, generator=g) * 0.05
+        v0 = torch.randn(1, V, 3, generator=g)
+        y0 = x0 + torch.randn(1, V, 3, generator=g) * 0.05
+        w0 = torch.randn(1, V, 3, generator=g)
+        batches.append(DenseMolDynBatch(
+            names=[f"tiny{b}"], atom_types=at, adj_list=torch.zeros((0, 2), dtype=torch.int64),
+            edge_batch_idx=torch.zeros((0,), dtype=torch.int64), atom_coords=x0, atom_velocs=v0,
+            atom_forces=torch.zeros_like(x0), atom_coord_targets=y0, atom_veloc_targets=w0,
+            atom_force_targets=torch.zeros_like(x0), masked_elements=torch.zeros(1, V, dtype=torch.bool)))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        model.coords_prior_log_scale.fill_(-3.0)
+        model.velocs_prior_log_scale.fill_(0.0)
+        for k, v in model.state_dict().items():
+            if ".out_mlp._layers.2." in k:
+                v.mul_(0.002)
+    out = dict(masses=masses.numpy(), x_ref=x_ref.numpy())
+    for b, bt in enumerate(batches):
+        out[f"batch{b}/atom_types"] = bt.atom_types.numpy()
+        out[f"batch{b}/x"] = bt.atom_coords.numpy()
+        out[f"batch{b}/v"] = bt.atom_velocs.numpy()
+        out[f"batch{b}/y"] = bt.atom_coord_targets.numpy()
+        out[f"batch{b}/w"] = bt.atom_veloc_targets.numpy()
+    out.update(np_sd(model.state_dict()))
+    names = ("y_coords_model", "y_velocs_model", "traj_coords", "traj_velocs", "traj_coords_conditioning",
+             "traj_velocs_conditioning", "ll_reverse", "ll_forward", "ll_reverse_training", "ll_forward_training",
+             "acceptance")
+    for tag, rv in (("fixedv", False), ("randv", True)):
+        rec = {"normal": [], "randn_like": []}
+        orig_rsample = torch.distributions.Normal.rsample
+        orig_randn_like = torch.randn_like
+
+        def rsample(self, shape=torch.Size()):
+            r = orig_rsample(self, shape)
+            rec["normal"].append(r.detach().numpy().copy().reshape(-1))
+            return r
+
+        def randn_like(t, **k):
+            r = orig_randn_like(t, **k)
+            rec["randn_like"].append(r.numpy().copy().reshape(-1))
+            return r
+
+        torch.distributions.Normal.rsample = rsample
+        torch.randn_like = randn_like
+        try:
+            torch.manual_seed(777)
+            res = eu.sample_on_batches(batches, model, torch.device("cpu"), energy, False, masses, random_velocs=rv)
+        finally:
+            torch.distributions.Normal.rsample = orig_rsample
+            torch.randn_like = orig_randn_like
+        for n, a in zip(names, res):
+            out[f"{tag}/{n}"] = np.asarray(a)
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros((0,), np.float32)
+        out[f"{tag}/noise_normal"] = cat(rec["normal"])
+        out[f"{tag}/noise_normal_sizes"] = np.array([len(a) for a in rec["normal"]])
+        out[f"{tag}/noise_randn_like"] = cat(rec["randn_like"])
+        print("sob", tag, {n: np.asarray(a).shape for n, a in zip(names, res)}, "mean p_acc", float(np.mean(res[-1])))
+    model.load_state_dict(sd)
+    np.savez_compressed(os.path.join(OUT, "sob_tiny.npz"), **out)
+
+
+def gen_learnable_golden():
+    """Tiny learnable-lengthscale model (attention_type "learnable_kernel") with DIFFERENT
+    log_lengthscales in every attention layer: pins which layer's lengthscales a flow call uses."""
+    torch.manual_seed(4711)
+    m = kernel_model(emb=4, d_model=8, ff=16, mlp_hidden=[8], n_coupling=2, n_layers=2, lengthscales=[0.1, 0.5, 1.2],
+                     attention_type="learnable_kernel")
+    g = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        m.coords_prior_log_scale.fill_(-0.3)
+        m.velocs_prior_log_scale.fill_(0.2)
+        for k, v in m.state_dict().items():
+            if k.endswith("log_lengthscales"):
+                v.add_(torch.randn(v.shape, generator=g) * 0.4)
+    at, x_c, x_v, mask, y_c, y_v = padded_batch(g, 3, 7, [7, 5, 6])
+    d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
+    d.update(run_case(m, at, x_c, x_v, mask, y_c, y_v, 0, 0))
+    d.update(np_sd(m.state_dict()))
+    at1, x1, v1, m1, yc1, yv1 = padded_batch(g, 1, 7, [5])
+    r = run_case(m, at1, x1, v1, m1, yc1, yv1, 4, 97)
+    d.update({"b1_" + k: v for k, v in base_inputs(at1, x1, v1, m1, yc1, yv1).items()})
+    d.update({"b1_" + k: v for k, v in r.items()})
+    np.savez_compressed(os.path.join(OUT, "kernel_learnable_tiny.npz"), **d)
+    print("kernel_learnable_tiny", {k: v.shape for k, v in d.items() if not k.startswith("sd::")})
+
+
+def tiny_kernel_model():
     torch.manual_seed(1234)
     tiny = kernel_model(emb=4, d_model=8, ff=16, mlp_hidden=[8], n_coupling=2, n_layers=2,
                         lengthscales=[0.1, 0.5, 1.2])
     with torch.no_grad():
         tiny.coords_prior_log_scale.fill_(-0.3)
         tiny.velocs_prior_log_scale.fill_(0.2)
+    return tiny
+
+
+def main():
+    if "--only-sob" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        gen_sob_golden(tiny_kernel_model())
+        return
+    if "--only-learnable" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        gen_learnable_golden()
+        return
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ad_x, ad_t = ad_topology()
+
+    # ---- (1) tiny kernel model, reference-initialised weights stored in full ------------------
+    tiny = tiny_kernel_model()
     g = torch.Generator().manual_seed(7)
     at, x_c, x_v, mask, y_c, y_v = padded_batch(g, 3, 7, [7, 5, 6])
     d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
@@ -441,6 +554,8 @@ def main():
 
     # ---- (7) the MH loop itself: the reference's sample_with_model driven with a synthetic energy --
     gen_mh_goldens(tiny)
+    gen_sob_golden(tiny)
+    gen_learnable_golden()
 
     # ---- (6) alanine-dipeptide topology as data (22 atoms) ---------------------------------------
     np.savez_compressed(os.path.join(OUT, "ad_topology.npz"), coords_nm=ad_x.numpy(), atom_types=ad_t.numpy(),

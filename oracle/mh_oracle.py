@@ -203,3 +203,38 @@ def sample_with_model(atom_types, x_coords, x_velocs, masked, model: OracleModel
         S = S_next
     stats = ChainStats(*[np.concatenate(rec[n], axis=0) for n in names])
     return np.concatenate(coords_out, axis=0), np.concatenate(velocs_out, axis=0), accepted, stats
+
+
+def sample_on_batches(batches, model: OracleModel, energy, masses, noise, random_velocs=False):
+    """Restatement of utils/evaluation_utils.py:190-333 (data_augmentation=False).  `batches` is a list
+    of dicts with atom_types [1,V], x, v, y, w [1,V,3]; returns the reference's eleven arrays."""
+    kbT = energy.kbT
+    sgn = 1.0 if random_velocs else -1.0
+    cols = {k: [] for k in ("y_c", "y_v", "t_c", "t_v", "c_c", "c_v", "p_xy", "p_yx", "p_xy_tr", "p_yx_tr", "acc")}
+    for b in batches:
+        at, x_c, y_t = b["atom_types"], b["x"], b["y"]
+        mk = torch.zeros(at.shape, dtype=torch.bool)
+        if random_velocs:
+            x_v = noise.randn_like(x_c)          # :236
+            w_t = noise.randn_like(y_t)          # :237
+        else:
+            x_v, w_t = b["v"], b["w"]
+        sc, sv = model.scales()
+        z_c, z_v = noise.latents(1, x_c.shape[0], x_c.shape[1], sc, sv)
+        y_c, y_v, _ = model.conditional_sample_with_logp(at, x_c, x_v, mk, z_c, z_v)   # :242-250 (num_samples=1)
+        y_c, y_v = y_c.squeeze(0), y_v.squeeze(0)
+        p_xy = model.log_likelihood(at, x_c, x_v, y_c, y_v, mk)                        # :253-262
+        e_kin = compute_kinetic_energy(y_v, masses, random_velocs, kbT) - compute_kinetic_energy(x_v, masses, random_velocs, kbT)
+        e_pot = ((energy(y_c) - energy(x_c)) / kbT).view(-1)                           # :268-271
+        p_yx = model.log_likelihood(at, y_c, sgn * y_v, x_c, sgn * x_v, mk)            # :275-284
+        ex = e_pot + e_kin + p_xy - p_yx                                               # :288
+        p_acc = torch.min(torch.tensor(1.0), torch.exp(-ex))                           # :289
+        p_xy_tr = model.log_likelihood(at, x_c, x_v, y_t, w_t, mk)                     # :292-301
+        p_yx_tr = model.log_likelihood(at, y_t, sgn * w_t, x_c, sgn * x_v, mk)         # :303-312
+        for k, t in (("acc", p_acc), ("p_xy", p_xy), ("p_yx", p_yx), ("p_xy_tr", p_xy_tr), ("p_yx_tr", p_yx_tr),
+                     ("y_c", y_c), ("y_v", y_v), ("c_c", x_c), ("c_v", x_v), ("t_c", y_t), ("t_v", b["w"])):
+            cols[k].append(t.detach().numpy())
+    arr = {k: np.array(v) for k, v in cols.items()}
+    sq = lambda a: a.squeeze(1)
+    return (sq(arr["y_c"]), sq(arr["y_v"]), sq(arr["t_c"]), sq(arr["t_v"]), sq(arr["c_c"]), sq(arr["c_v"]),
+            arr["p_yx"], arr["p_xy"], arr["p_yx_tr"], arr["p_xy_tr"], arr["acc"])

@@ -52,6 +52,44 @@ def test_tiny_kernel_simple_path():
     H.assert_case_close(H.run_model_case(m, d, "b1_"), d, "b1_", tol=TOL)
 
 
+def test_tiny_learnable_lengthscales():
+    """attention_type "learnable_kernel", per-layer log_lengthscales all different: forward and reverse
+    passes use the lengthscales of the layer the reference evaluates first (weights.py LENGTHSCALES)."""
+    d, sd = H.load("kernel_learnable_tiny")
+    m = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2,
+                          lengthscales=(0.1, 0.5, 1.2), path=SIMPLE, attention_type="learnable_kernel")
+    H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
+    H.assert_case_close(H.run_model_case(m, d, "b1_"), d, "b1_", tol=TOL)
+
+
+@pytest.mark.parametrize("path", [FUSED, H3])
+def test_full_learnable_lengthscales_fused(path):
+    """Full-size model with distinct forward / reverse lengthscales on the fused kernels vs the oracle."""
+    spec = fo.FlowSpec(variant="kernel", attention_type="learnable_kernel")
+    sd = dict(H.full_kernel_sd())
+    g = torch.Generator().manual_seed(5)
+    base = torch.log(torch.tensor([0.1, 0.2, 0.5, 0.7, 1.0, 1.2]))
+    for c in range(8):
+        for net in ("scale_transformer", "shift_transformer"):
+            for l in range(3):
+                sd[f"flow.chain.{c}.{net}.encoder_layers.{l}.self_attn.attention.log_lengthscales"] = \
+                    base + torch.randn(6, generator=g) * 0.3
+    m = H.tw_kernel_model(sd, path=path, attention_type="learnable_kernel")
+    d, _ = H.load("kernel_full_ad")
+    at, xc, xv, mk = d["atom_types"], d["x_coords"], d["x_velocs"], d["masked"]
+    zc, zv = d["z_coords"], d["z_velocs"]
+    ref = fo.conditional_sample_with_logp(sd, spec, at, xc, xv, mk, zc, zv)
+    got = m.conditional_sample_with_logp(atom_types=at.cuda(), x_coords=xc.cuda(), x_velocs=xv.cuda(), adj_list=None,
+                                         edge_batch_idx=None, masked_elements=mk.cuda(), num_samples=zc.shape[0],
+                                         z_coords=zc.cuda(), z_velocs=zv.cuda())
+    for a, b in zip(got, ref):
+        assert H.rel_err(a.cpu(), b) < 1e-5
+    ll_ref = fo.log_likelihood(sd, spec, at, xc, xv, d["y_coords"], d["y_velocs"], mk)
+    ll = m.log_likelihood(atom_types=at.cuda(), x_coords=xc.cuda(), x_velocs=xv.cuda(), y_coords=d["y_coords"].cuda(),
+                          y_velocs=d["y_velocs"].cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda())
+    assert H.rel_err(ll.cpu(), ll_ref) < 1e-5
+
+
 def test_tiny_dense_simple_path():
     d, sd = H.load("dense_tiny")
     m = H.tw_dense_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2, n_head=2, rff_dim=4,

@@ -48,14 +48,27 @@ def test_raw_layout_matches_library_and_oracle_template():
     sd = synthetic.synth_state_dict(sd, 0)
     raw = pack_raw(sd, m.dims)
     assert torch.equal(raw[:160], sd["flow.atom_embedder.weight"].reshape(-1))
-    assert torch.equal(raw[160:166], torch.tensor([0.1, 0.2, 0.5, 0.7, 1.0, 1.2]))
-    assert raw[166] == sd["coords_prior_log_scale"] and raw[167] == sd["velocs_prior_log_scale"]
-    assert torch.equal(raw[168:168 + 256 * 41], sd["flow.chain.0.scale_transformer.in_mlp._layers.0.weight"].reshape(-1))
+    ls = torch.tensor([0.1, 0.2, 0.5, 0.7, 1.0, 1.2])
+    assert torch.equal(raw[160:172], torch.cat([ls, ls]))  # forward-pass row, reverse-pass row
+    assert raw[172] == sd["coords_prior_log_scale"] and raw[173] == sd["velocs_prior_log_scale"]
+    assert torch.equal(raw[174:174 + 256 * 41], sd["flow.chain.0.scale_transformer.in_mlp._layers.0.weight"].reshape(-1))
     assert raw_entries(m.dims)[-1][0] == "flow.chain.7.shift_transformer.out_mlp._layers.2.bias"
     with pytest.raises(ValueError):
         bad = dict(sd)
         bad["flow.atom_embedder.weight"] = torch.zeros(5, 31)
         pack_raw(bad, m.dims)
+    # learnable lengthscales: row 0 from chain 0, row 1 from the last coupling layer (first layer evaluated
+    # by a forward / reverse pass), and the extra parameter is part of the state_dict
+    cfg = synthetic.kernel_transformer_nvp_config()
+    cfg.custom_transformer_nvp_config.encoder_layer_config.attention_type = "learnable_kernel"
+    ml = tw.model_constructor(cfg)
+    key = "flow.chain.{}.scale_transformer.encoder_layers.0.self_attn.attention.log_lengthscales"
+    sdl = ml.state_dict()
+    assert key.format(3) in sdl and lib.tw_flow_raw_floats(C.byref(ml.dims.to_desc())) == raw_numel(ml.dims)
+    sdl[key.format(0)] = torch.log(ls * 2.0)
+    sdl[key.format(7)] = torch.log(ls * 3.0)
+    rawl = pack_raw(sdl, ml.dims)
+    assert torch.allclose(rawl[160:166], ls * 2.0) and torch.allclose(rawl[166:172], ls * 3.0)
 
 
 def test_dense_constructor_keys_and_module_prefix():
@@ -153,3 +166,70 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_transform_batch_is_rigid():
+    """transform_batch: coordinates translate+rotate, velocities rotate; the flow is equivariant only up
+    to the model, so just check the geometry (distances preserved, velocity norms preserved)."""
+    from timewarp_amd.dataloader import single_state_batch, transform_batch
+
+    g = torch.Generator().manual_seed(3)
+    x, v = torch.randn(1, 9, 3, generator=g), torch.randn(1, 9, 3, generator=g)
+    b = single_state_batch("m", torch.zeros(9, dtype=torch.int64), x, v)
+    t = transform_batch(b)
+    assert torch.allclose(torch.cdist(t.atom_coords, t.atom_coords), torch.cdist(x, x), atol=1e-5)
+    assert torch.allclose(t.atom_velocs.norm(dim=-1), v.norm(dim=-1), atol=1e-5)
+    assert not torch.allclose(t.atom_coords, x)
+
+
+def test_find_chirality_centers_alanine_dipeptide_like():
+    """A carbon with four bonds, three of them to heavy atoms, is a centre; a methyl carbon is not
+    (reference utils/chirality.py:14-38)."""
+    from timewarp_amd.utils.chirality import compute_chirality_sign, find_chirality_centers
+
+    # atoms: 0 C(alpha) 1 N 2 C' 3 C(beta) 4 H | methyl 3: 5 H 6 H 7 H | 8 H on N, 9 O on C'
+    types = torch.tensor([[0, 2, 0, 0, 1, 1, 1, 1, 1, 3]])
+    adj = torch.tensor([[0, 1], [0, 2], [0, 3], [0, 4], [3, 5], [3, 6], [3, 7], [1, 8], [2, 9]])
+    cen = find_chirality_centers(adj, types)
+    assert cen.tolist() == [[0, 1, 2, 3]]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 10, 3, generator=g)
+    s = compute_chirality_sign(x, cen)
+    mirrored = x * torch.tensor([1.0, 1.0, -1.0])
+    assert s.shape == (2, 1) and torch.equal(compute_chirality_sign(mirrored, cen), -s)
+    assert torch.equal(mo.compute_chirality_sign(x, cen), s)
+
+
+def test_sample_trajectory_segments_and_resume(tmp_path):
+    """Segment files, thinning by 10, time field, and resume from the last saved row
+    (reference sample_trajectory.py:234-279), with the sampler injected so no GPU is needed."""
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.sample_trajectory import resume_point, sample_trajectory, segment_path
+
+    V = 4
+    calls = []
+
+    def fake_sampler(batch, model, device, energy, masses, num_samples, accept, **kw):
+        start = batch.atom_coords.numpy().astype(np.float32)
+        calls.append(start.copy())
+        steps = np.arange(num_samples + 1, dtype=np.float32)[:, None, None]
+        coords = start + steps * 0.001  # state j = start + j*0.001
+        return coords, coords, 0, None
+
+    out = str(tmp_path / "chain")
+    b = single_state_batch("pep", torch.zeros(V, dtype=torch.int64), torch.zeros(1, V, 3))
+    n = sample_trajectory(b, None, "cpu", None, None, out, "pep", num_samples=40, saving_interval=20,
+                          sampler=fake_sampler, verbose=False)
+    assert n == 2 and sorted(os.listdir(out)) == ["pep_trajectory_model_0.npz", "pep_trajectory_model_1.npz"]
+    z0 = np.load(segment_path(out, "pep", 0))
+    assert z0["positions"].shape == (3, V, 3) and float(z0["time"]) >= 0.0       # rows 0, 10, 20 of 21 states
+    assert np.allclose(z0["positions"][:, 0, 0], [0.0, 0.010, 0.020], atol=1e-6)
+    assert np.allclose(calls[1][0, 0, 0], 0.020, atol=1e-6)                     # segment 1 starts at the last state
+    # resume: nothing left to do for the same length, two more segments for a longer chain
+    assert sample_trajectory(b, None, "cpu", None, None, out, "pep", 40, 20, sampler=fake_sampler, verbose=False) == 0
+    done, last = resume_point(out, "pep")
+    assert done == 2 and np.allclose(last[0, 0, 0], 0.040, atol=1e-6)
+    b2 = single_state_batch("pep", torch.zeros(V, dtype=torch.int64), torch.zeros(1, V, 3))
+    assert sample_trajectory(b2, None, "cpu", None, None, out, "pep", 80, 20, sampler=fake_sampler, verbose=False) == 2
+    assert np.allclose(calls[-2][0, 0, 0], 0.040, atol=1e-6)                    # resumed from the saved row
+    assert len(os.listdir(out)) == 4

@@ -71,3 +71,39 @@ def test_compute_num_proposal_steps():
     assert mo.compute_num_proposal_steps(0.5, max_steps=100) == 4
     assert mo.compute_num_proposal_steps(1.0, max_steps=100) == 1
     assert mo.compute_num_proposal_steps(0.0, max_steps=7) == 7
+
+
+# ------------------------------------------------------------------ sample_on_batches (evaluation_utils.py:190-333)
+SOB_NAMES = ("y_coords_model", "y_velocs_model", "traj_coords", "traj_velocs", "traj_coords_conditioning",
+             "traj_velocs_conditioning", "ll_reverse", "ll_forward", "ll_reverse_training", "ll_forward_training",
+             "acceptance")
+
+
+def load_sob():
+    import os
+    z = np.load(os.path.join(H.GOLDEN, "sob_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    batches = [dict(atom_types=torch.from_numpy(z[f"batch{b}/atom_types"]), **{k: torch.from_numpy(z[f"batch{b}/{k}"]) for k in "xvyw"})
+               for b in range(3)]
+    return z, sd, batches
+
+
+def sob_replay(z, tag, device="cpu"):
+    return mo.ReplayNoise(z[tag + "/noise_normal"], z[tag + "/noise_normal_sizes"], np.zeros(0, np.float32), [],
+                          z[tag + "/noise_randn_like"], device=device)
+
+
+def check_sob(z, tag, res, tol=2e-5):
+    for n, a in zip(SOB_NAMES, res):
+        b = z[f"{tag}/{n}"]
+        assert np.asarray(a).shape == b.shape, n
+        assert H.rel_err(np.asarray(a, np.float64), b.astype(np.float64)) < (1e-4 if n.startswith("ll_") or n == "acceptance" else tol), n
+
+
+@pytest.mark.parametrize("tag,random_velocs", [("fixedv", False), ("randv", True)])
+def test_sample_on_batches_oracle_replays_reference(tag, random_velocs):
+    z, sd, batches = load_sob()
+    model = mo.OracleModel(sd, H.TINY_KERNEL_SPEC)
+    energy = mo.SyntheticEnergy(torch.from_numpy(z["x_ref"]).clone())
+    res = mo.sample_on_batches(batches, model, energy, torch.from_numpy(z["masses"]), sob_replay(z, tag), random_velocs)
+    check_sob(z, tag, res)

@@ -35,6 +35,23 @@ def test_kernel_tiny_batch_and_sampling():
     _check_case(d, sd, H.TINY_KERNEL_SPEC, "b1_")
 
 
+def test_kernel_learnable_lengthscales():
+    """attention_type "learnable_kernel" with different log_lengthscales per layer: a flow call uses the
+    lengthscales of the first attention layer it evaluates (the reference's score cache ignores them)."""
+    d, sd = H.load("kernel_learnable_tiny")
+    _check_case(d, sd, H.TINY_LEARNABLE_SPEC)
+    _check_case(d, sd, H.TINY_LEARNABLE_SPEC, "b1_")
+    # and the quirk is real: using chain[0]'s lengthscales for the reverse pass does not reproduce the reference
+    wrong = dict(sd)
+    k = "flow.chain.{}.scale_transformer.encoder_layers.0.self_attn.attention.log_lengthscales"
+    wrong[k.format(1)] = sd[k.format(0)]
+    g = lambda n: d["b1_" + n]
+    yc, _, _ = fo.conditional_sample_with_logp(wrong, H.TINY_LEARNABLE_SPEC, g("atom_types"), g("x_coords"), g("x_velocs"),
+                                               g("masked"), g("z_coords"), g("z_velocs"))
+    keep = ~g("masked")[0]
+    assert H.rel_err(yc[:, :, keep], g("s_y_coords")[:, :, keep]) > 1e-4
+
+
 def test_template_matches_reference_names():
     _, sd = H.load("kernel_tiny")
     t = fo.make_template(H.TINY_KERNEL_SPEC, atom_embedding_dim=4, d_model=8, dim_feedforward=16,

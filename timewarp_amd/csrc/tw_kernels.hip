@@ -23,7 +23,7 @@ RawLayout raw_layout(const tw_flow_desc& d) {
   L.d_in = d.d_emb + 9 + (d.variant == 1 ? d.d_rff : 0);
   int64_t o = 0;
   L.emb = o; o += (int64_t)d.n_elements * d.d_emb;
-  L.lengthscales = o; o += (d.variant == 0 ? H : 0);
+  L.lengthscales = o; o += (d.variant == 0 ? 2 * H : 0);  // [0]: used by the forward pass, [1]: by the reverse pass
   L.prior = o; o += 2;
   L.chain = o;
   // layer
@@ -614,7 +614,7 @@ static int simple_scores(const FlowArgs& a, const RawLayout& L, const SimpleWs& 
   const tw_flow_desc& d = *a.desc;
   if (d.variant != 0) return TW_OK;
   // one score matrix per flow call, shared by every encoder layer (model_constructor.py:192-195)
-  return launch_scores(a.x_coords, a.masked, a.raw + L.lengthscales, d.n_heads, a.n_cond, a.n_atoms, d.normalise,
+  return launch_scores(a.x_coords, a.masked, a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, a.n_cond, a.n_atoms, d.normalise,
                        a.n_atoms > 25, w.scores, a.stream);
 }
 

@@ -696,7 +696,7 @@ static int launch_score_frags(const FlowArgs& a, const RawLayout& L, const Fused
   const int64_t nblocks = shared ? 1 : (a.n_rows + g.mpw - 1) / g.mpw;
   size_t shm = (size_t)(g.mpw * V * 3 + g.mpw * V * V + g.mpw * d.n_heads * V) * 4 + (size_t)g.mpw * V;
   hipLaunchKernelGGL(score_frag_kernel, dim3((unsigned)nblocks), dim3(256), shm, a.stream, a.x_coords, a.masked,
-                     a.raw + L.lengthscales, d.n_heads, V, g.mpw, g.nt, a.n_rows, a.n_cond, d.normalise, V > 25,
+                     a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, V, g.mpw, g.nt, a.n_rows, a.n_cond, d.normalise, V > 25,
                      sfrag);
   TW_LAUNCH_CHECK();
   return TW_OK;

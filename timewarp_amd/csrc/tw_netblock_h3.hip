@@ -1087,7 +1087,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
   const int64_t nblocks = shared ? 1 : (a.n_rows + fg.mpw - 1) / fg.mpw;
   size_t shm = (size_t)(fg.mpw * V * 3 + fg.mpw * V * V + fg.mpw * d.n_heads * V) * 4 + (size_t)fg.mpw * V;
   hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks), dim3(256), shm, a.stream, a.x_coords, a.masked,
-                     a.raw + L.lengthscales, d.n_heads, V, fg.mpw, a.n_rows, a.n_cond, d.normalise, sfrag);
+                     a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, V, fg.mpw, a.n_rows, a.n_cond, d.normalise, sfrag);
   TW_LAUNCH_CHECK();
   return TW_OK;
 }

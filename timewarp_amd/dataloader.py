@@ -49,3 +49,34 @@ def single_state_batch(name: str, atom_types: torch.Tensor, coords: torch.Tensor
 def elements_from_atom_names(names: Sequence[str]) -> torch.Tensor:
     """Element id from a PDB atom name = its first alphabetic character (1HH3 -> H, CA -> C)."""
     return torch.tensor([ELEMENT_VOCAB[next(ch for ch in n if ch.isalpha())] for n in names], dtype=torch.int64)
+
+
+def random_rotation_matrix(dtype=torch.float32) -> torch.Tensor:
+    """Uniform SO(3) rotation (QR of a Gaussian matrix, sign-fixed; the reference draws its matrix with
+    scipy, equivariance/equivariance_utils.py)."""
+    q, r = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))
+    q = q * torch.sign(torch.diagonal(r))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q.to(dtype)
+
+
+def transform_batch(batch: DenseMolDynBatch, rotation: Optional[torch.Tensor] = None,
+                    translation: Optional[torch.Tensor] = None, dtype=torch.float32) -> DenseMolDynBatch:
+    """Data augmentation used by `sample_on_batches`: translate, then rotate (coordinates get both,
+    velocities and forces only the rotation), equivariance/equivariance_transforms.py:153-177.  With no
+    arguments a random translation ~ N(0, 1)^3 and a random rotation are drawn."""
+    t = torch.randn(3, dtype=dtype) if translation is None else translation.to(dtype)
+    R = random_rotation_matrix(dtype) if rotation is None else rotation.to(dtype)
+
+    def coord(x):
+        return ((R.to(x.device) @ (x + t.to(x.device)).transpose(-1, -2)).transpose(-1, -2)).contiguous()
+
+    def veloc(v):
+        return ((R.to(v.device) @ v.transpose(-1, -2)).transpose(-1, -2)).contiguous()
+
+    return DenseMolDynBatch(
+        names=batch.names, atom_types=batch.atom_types, adj_list=batch.adj_list, edge_batch_idx=batch.edge_batch_idx,
+        atom_coords=coord(batch.atom_coords), atom_velocs=veloc(batch.atom_velocs), atom_forces=veloc(batch.atom_forces),
+        atom_coord_targets=coord(batch.atom_coord_targets), atom_veloc_targets=veloc(batch.atom_veloc_targets),
+        atom_force_targets=veloc(batch.atom_force_targets), masked_elements=batch.masked_elements)

@@ -12,7 +12,7 @@ After `install()` the reference's scripts run unchanged:
   * our model classes are registered as virtual subclasses of the reference's ABCs, so
     `isinstance(model, ConditionalDensityModel)` and the `functools.singledispatch` in
     utils/sampling_utils.py:17-68 and utils/loss_utils.py:91-141 resolve them;
-  * `sample_with_model` and `OpenmmPotentialEnergyTorch` are replaced by the HIP-backed versions
+  * `sample_with_model`, `sample_on_batches` and `OpenmmPotentialEnergyTorch` are replaced by the HIP-backed versions
     (the energy one reads its tables out of the `openmm.System` it is given).
 """
 from __future__ import annotations
@@ -46,8 +46,8 @@ def install(replace_energy: bool = True, replace_mh_loop: bool = True) -> dict:
         if getattr(config, "model_type", None) in _SUPPORTED:
             if config.model_type == "custom_attention_transformer_nvp":
                 enc = config.custom_transformer_nvp_config.encoder_layer_config
-                if getattr(enc, "attention_type", None) != "kernel":
-                    return original(config)
+                if getattr(enc, "attention_type", None) not in ("kernel", "learnable_kernel"):
+                    return original(config)  # chebyshev_kernel / local attention stay on the reference
             return _tw_model_constructor(config)
         return original(config)
 
@@ -68,7 +68,9 @@ def install(replace_energy: bool = True, replace_mh_loop: bool = True) -> dict:
         eu = _try_import("timewarp.utils.evaluation_utils")
         if eu is not None:
             eu.sample_with_model = _eu.sample_with_model
+            eu.sample_on_batches = _eu.sample_on_batches
             patched["timewarp.utils.evaluation_utils.sample_with_model"] = True
+            patched["timewarp.utils.evaluation_utils.sample_on_batches"] = True
     if replace_energy:
         for name in ("timewarp.utils.openmm.openmm_bridge", "timewarp.utils.evaluation_utils"):
             mod = _try_import(name)

@@ -45,6 +45,15 @@ class KernelAttention(_WeightsOnly):
         self._out_projection = nn.Linear(value_dim * len(lengthscales), output_dim, bias=False)
 
 
+class LearnableLengthscaleKernelAttention(KernelAttention):
+    """KernelAttention + `log_lengthscales` parameter, initialised to log(lengthscales)
+    (layers/kernel_attention.py:217-252).  The `lengthscales` buffer stays in the state_dict, unused."""
+
+    def __init__(self, value_dim: int, output_dim: int, lengthscales: Sequence[float], normalise_kernel_values: bool):
+        super().__init__(value_dim, output_dim, lengthscales, normalise_kernel_values)
+        self.log_lengthscales = nn.Parameter(torch.log(torch.tensor(list(lengthscales), dtype=torch.float32)))
+
+
 class KernelSelfAttention(_WeightsOnly):
     """Bias-free `values_proj` + `attention` (layers/kernel_self_attention.py:12-27)."""
 

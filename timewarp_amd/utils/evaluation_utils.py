@@ -321,3 +321,69 @@ def sample_with_model(
             pbar.update(n)
     pbar.close()
     return chain.result()
+
+
+def sample_on_batches(batches, model, device, openmm_potential_energy_torch, data_augmentation, masses,
+                      random_velocs: bool = False, noise=None):
+    """One-step acceptance statistics over dataset batches (reference utils/evaluation_utils.py:190-333):
+    for every batch (one conditioning state each) draw one proposal y ~ p(.|x), evaluate log p(y|x),
+    log p(x~|y~) (velocities negated unless `random_velocs`), the energy change, the MH acceptance
+    probability, and the forward / reverse likelihood of the dataset's own target pair.  Same argument
+    order and the same eleven return arrays as the reference; `noise` (extension) injects the random
+    draws, as in `sample_with_model`."""
+    from ..dataloader import DenseMolDynBatch, transform_batch
+
+    device = torch.device(device)
+    noise = noise or DeviceNoise(device)
+    f32 = torch.float32
+    masses = masses.to(device, f32)
+    kbT = openmm_potential_energy_torch.kbT
+    cols = {k: [] for k in ("y_c", "y_v", "t_c", "t_v", "c_c", "c_v", "p_xy", "p_yx", "p_xy_tr", "p_yx_tr", "acc")}
+    sgn = 1.0 if random_velocs else -1.0
+    with torch.no_grad():
+        for batch in tqdm(batches):
+            if data_augmentation:
+                assert isinstance(batch, DenseMolDynBatch)
+                batch = transform_batch(batch)
+            x_c = batch.atom_coords.to(device, f32).contiguous()
+            y_t = batch.atom_coord_targets.to(device, f32).contiguous()
+            if random_velocs:
+                x_v = noise.randn_like(x_c)
+                w_t = noise.randn_like(y_t)
+            else:
+                x_v = batch.atom_velocs.to(device, f32).contiguous()
+                w_t = batch.atom_veloc_targets.to(device, f32).contiguous()
+            at = batch.atom_types.to(device)
+            mk = batch.masked_elements.to(device)
+            adj = batch.adj_list.to(device) if batch.adj_list is not None else None
+            ebi = batch.edge_batch_idx.to(device) if batch.edge_batch_idx is not None else None
+            B, V = x_c.shape[0], x_c.shape[1]
+            sc = torch.exp(model.coords_prior_log_scale.detach()).to(device)
+            sv = torch.exp(model.velocs_prior_log_scale.detach()).to(device)
+            z_c, z_v = noise.latents(1, B, V, sc, sv)
+            kw = dict(atom_types=at, adj_list=adj, edge_batch_idx=ebi, masked_elements=mk)
+            y_c, y_v, _ = model.conditional_sample_with_logp(x_coords=x_c, x_velocs=x_v, num_samples=1, z_coords=z_c,
+                                                             z_velocs=z_v, **kw)
+            y_c, y_v = y_c.squeeze(0).contiguous(), y_v.squeeze(0).contiguous()
+            p_xy = model.log_likelihood(x_coords=x_c, x_velocs=x_v, y_coords=y_c, y_velocs=y_v, **kw)
+            e_kin = (compute_kinetic_energy(y_v, masses, random_velocs=random_velocs, kbT=kbT)
+                     - compute_kinetic_energy(x_v, masses, random_velocs=random_velocs, kbT=kbT))
+            e_pot = ((openmm_potential_energy_torch(y_c) - openmm_potential_energy_torch(x_c)) / kbT).view(-1)
+            assert e_kin.shape == e_pot.shape
+            energy = e_pot + e_kin
+            p_yx = model.log_likelihood(x_coords=y_c, x_velocs=(sgn * y_v).contiguous(), y_coords=x_c,
+                                        y_velocs=(sgn * x_v).contiguous(), **kw)
+            assert energy.shape == p_xy.shape and p_yx.shape == p_xy.shape
+            p_acc = torch.clamp(torch.exp(-(energy + p_xy - p_yx)), max=1.0)
+            p_xy_tr = model.log_likelihood(x_coords=x_c, x_velocs=x_v, y_coords=y_t, y_velocs=w_t, **kw)
+            p_yx_tr = model.log_likelihood(x_coords=y_t, x_velocs=(sgn * w_t).contiguous(), y_coords=x_c,
+                                           y_velocs=(sgn * x_v).contiguous(), **kw)
+            for k, t in (("acc", p_acc), ("p_xy", p_xy), ("p_yx", p_yx), ("p_xy_tr", p_xy_tr), ("p_yx_tr", p_yx_tr),
+                         ("y_c", y_c), ("y_v", y_v), ("c_c", x_c), ("c_v", x_v)):
+                cols[k].append(t.cpu().numpy())
+            cols["t_c"].append(batch.atom_coord_targets.cpu().numpy())
+            cols["t_v"].append(batch.atom_veloc_targets.cpu().numpy())
+    arr = {k: np.array(v) for k, v in cols.items()}
+    sq = lambda a: a.squeeze(1)  # the reference assumes one conditioning state per batch here (:315-320)
+    return (sq(arr["y_c"]), sq(arr["y_v"]), sq(arr["t_c"]), sq(arr["t_v"]), sq(arr["c_c"]), sq(arr["c_v"]),
+            arr["p_yx"], arr["p_xy"], arr["p_yx_tr"], arr["p_xy_tr"], arr["acc"])

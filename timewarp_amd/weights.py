@@ -11,6 +11,14 @@ import torch
 from ._lib import FlowDesc
 
 KERNEL, DENSE = 0, 1
+# Pseudo-key of the raw layout's lengthscale block [2, H]: row 0 is used by the forward pass
+# (log_likelihood), row 1 by the reverse pass (sampling).  The reference computes the attention scores
+# once per flow call and reuses them in all 48 attention layers - its cache key ignores the lengthscales
+# (model_constructor.py:192-195) - so a flow call uses the lengthscales of the attention layer it
+# evaluates FIRST: chain[0].scale_transformer.encoder_layers[0] going forward, chain[n-1]'s going in
+# reverse.  For attention_type "kernel" every layer holds the same buffer and the two rows are equal;
+# for "learnable_kernel" they are exp(log_lengthscales) of those two layers.
+LENGTHSCALES = "@lengthscales"
 
 
 @dataclass(frozen=True)
@@ -32,6 +40,7 @@ class FlowDims:
     ignore_cond_velocity: bool = False
     normalise: bool = True
     ln_eps: float = 1e-5
+    learnable_lengthscales: bool = False  # attention_type "learnable_kernel" (host-side only, see LENGTHSCALES)
 
     @property
     def d_in(self) -> int:
@@ -50,7 +59,7 @@ def raw_entries(d: FlowDims) -> List[Tuple[str, Tuple[int, ...]]]:
     dm, ff, hid, H = d.d_model, d.d_ff, d.d_hidden, d.n_heads
     out: List[Tuple[str, Tuple[int, ...]]] = [("flow.atom_embedder.weight", (d.n_elements, d.d_emb))]
     if d.variant == KERNEL:
-        out.append(("flow.chain.0.scale_transformer.encoder_layers.0.self_attn.attention.lengthscales", (H,)))
+        out.append((LENGTHSCALES, (2, H)))
     out.append(("coords_prior_log_scale", ()))
     out.append(("velocs_prior_log_scale", ()))
     for c in range(d.n_coupling):
@@ -113,7 +122,15 @@ def pack_raw(state_dict: Dict[str, torch.Tensor], d: FlowDims) -> torch.Tensor:
     a missing key or a shape mismatch, so a wrong checkpoint fails loudly."""
     parts = []
     for key, shape in raw_entries(d):
-        t = state_dict[key]
+        if key == LENGTHSCALES:
+            att = "flow.chain.{}.scale_transformer.encoder_layers.0.self_attn.attention."
+            if d.learnable_lengthscales:
+                rows = [torch.exp(state_dict[att.format(c) + "log_lengthscales"].detach().float()) for c in (0, d.n_coupling - 1)]
+            else:
+                rows = [state_dict[att.format(0) + "lengthscales"].detach().float()] * 2
+            t = torch.stack([r.cpu() for r in rows])
+        else:
+            t = state_dict[key]
         if tuple(t.shape) != tuple(shape):
             raise ValueError(f"{key}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
         parts.append(t.detach().to(device="cpu", dtype=torch.float32).reshape(-1))
