@@ -38,6 +38,9 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #ifndef H3_DEBUG_SYNC
 #define H3_DEBUG_SYNC 0
 #endif
+#ifndef H3_FFN_ASM
+#define H3_FFN_ASM 1
+#endif
 #define H3_NT 3
 #define H3_TOK (16 * H3_NT)
 #define H3_XT 56                    // halfs per feature row of the transposed X tile
@@ -951,7 +954,40 @@ netblock_h3_kernel(const H3Params p) {
       for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
-      h3_mlp_chain<NT, 4, 8, false>(xb, y, pipe, p.ff_chunks, lane);
+#if H3_FFN_ASM
+      if (!(p.debug & 8)) {
+        // Hand-scheduled chunk loop (tools/gen_h3_ffn_asm.py).  Operands travel through the wave-private LDS
+        // block (free between the mixing of this layer and the transposed copy of the next): xb in as 24
+        // x 1 KiB register images, y out the same way; the asm statement owns v0-v203 / a0-a119.
+        char* priv = (char*)xt_hi;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) {
+            *(h8*)(priv + ((ks * NT + jt) * 2) * 1024 + lane * 16) = xb[ks].h[jt];
+            *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = xb[ks].l[jt];
+          }
+        int cur = __builtin_amdgcn_readfirstlane(pipe.cur);
+        const char* gn = pipe.gnext;
+        const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+        const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
+        const int chunks = __builtin_amdgcn_readfirstlane(p.ff_chunks);
+        asm volatile(
+#include "tw_h3_ffn_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+            :
+#include "tw_h3_ffn_clobbers.inc"
+        );
+        pipe.cur = cur;
+        pipe.gnext = gn;
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) y[ot][jt] = *(const f4*)(priv + (ot * NT + jt) * 1024 + lane * 16);
+      } else
+#endif
+        h3_mlp_chain<NT, 4, 8, false>(xb, y, pipe, p.ff_chunks, lane);
       const float sc = h3_load_f1(lsc + 2);
       f4 bb[8];
       h3_load8_f4(sl + 256 + 4 * g, bb);

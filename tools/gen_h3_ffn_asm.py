@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Generate timewarp_amd/csrc/tw_h3_ffn_asm.inc: the hand-scheduled FFN chunk loop of the split-fp16
+net-block kernel (gfx950), as the body of one `asm volatile` statement.
+
+Why asm: PMC counters showed the hipcc build of this loop with the matrix pipe 48 % busy - 2 VALU ops
+per MFMA issued mostly outside the MFMA bursts, LDS latency and the stage barrier exposed 4x per chunk.
+Here every non-MFMA instruction is placed in the shadow of an MFMA (measured capacity per K=32 MFMA:
+2 VALU or 3 SALU ops, tools/probe/mfma_valu_overlap.hip), weight tiles are read two tile pairs ahead and
+the stage barrier sits in the middle of a stage, so the next stage's first tiles are in flight for 18
+MFMAs before they are needed.
+
+Register map (all private to the asm statement, listed as clobbers):
+  v0..v95     xb[ks][jt] = {h: v[8(3ks+jt)..+3], l: +4..+7}   B operand of W1 (split x), loaded from LDS
+  v96..v127   weight tile slots p=0..3: hi v[96+8p..+3], lo v[100+8p..+3]
+  v128..v175  hb[buf][jt] = {h: v[128+24buf+8jt..+3], l: +4..+7}  split hidden activations (double buffer)
+  v176..v183  bias[o][r];  v184 scale;  v186..v193 epilogue temporaries
+  v194 tile LDS address, v195 aux address, v196 scale address, v198:199 DMA source, v200:201 temp,
+  v202 lane*16, v203 (lane>>4)*16
+  a0..a95     yacc[ot][jt] (4 each);  a96..a119 hacc[o][jt]
+Stage order (must match h3_pack_weights):  A0(0) A1(0) | A0(c+1) A1(c+1) B0(c) B1(c) ... | B0(n-1) B1(n-1)."""
+import sys
+
+NT = 3
+XB = lambda ks, jt, part: 8 * (3 * ks + jt) + (0 if part == "h" else 4)
+SLOT = lambda p, part: 96 + 8 * p + (0 if part == "h" else 4)
+HB = lambda buf, jt, part: 128 + 24 * buf + 8 * jt + (0 if part == "h" else 4)
+BIAS = lambda o: 176 + 4 * o
+V_SC, V_T, V_TILE, V_AUX, V_SCADDR, V_GN, V_TMP, V_LANE16, V_G16 = 184, 186, 194, 195, 196, 198, 200, 202, 203  # tuples even-aligned
+YACC = lambda ot, jt: 4 * (3 * ot + jt)
+HACC = lambda o, jt: 96 + 4 * (3 * o + jt)
+# scratch SGPRs (clobbered)
+S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_K1024, S_CNT = 84, 85, 86, 88, 90, 92, 94  # pairs are even-aligned
+STAGE, TILES = 9216, 8192
+
+
+def vr(base, n=4):
+    return f"v[{base}:{base + n - 1}]"
+
+
+def ar(base, n=4):
+    return f"a[{base}:{base + n - 1}]"
+
+
+def mfma(d, a, b, zero=False):
+    return f"v_mfma_f32_16x16x32_f16 {ar(d)}, {vr(a)}, {vr(b)}, {'0' if zero else ar(d)}"
+
+
+def pair_mfmas(acc_of_jt, slot, bop_of_jt, first=False):
+    """9 MFMAs of one tile pair: hi x B.h, hi x B.l, lo x B.h for the three token tiles."""
+    out = []
+    for a_part, b_part, z in (("h", "h", first), ("h", "l", False), ("l", "h", False)):
+        for jt in range(NT):
+            out.append(mfma(acc_of_jt(jt), SLOT(slot, a_part), bop_of_jt(jt, b_part), zero=z))
+    return out
+
+
+def epi_unit(o, jt, buf, relu=True):
+    """hacc[o][jt] -> dwords 2o, 2o+1 of hb[buf].h[jt] / .l[jt]: 20 VALU ops."""
+    t = [V_T + i for i in range(4)] if (o * NT + jt) % 2 == 0 else [V_T + 4 + i for i in range(4)]
+    ops = [f"v_accvgpr_read_b32 v{t[r]}, a{HACC(o, jt) + r}" for r in range(4)]
+    ops += [f"v_fma_f32 v{t[r]}, v{t[r]}, v{V_SC}, v{BIAS(o) + r}" for r in range(4)]
+    ops += [f"v_max_f32 v{t[r]}, v{t[r]}, 0" for r in range(4)]
+    hh = HB(buf, jt, "h") + 2 * o
+    ll = HB(buf, jt, "l") + 2 * o
+    ops += [f"v_cvt_pk_f16_f32 v{hh}, v{t[0]}, v{t[1]}", f"v_cvt_pk_f16_f32 v{hh + 1}, v{t[2]}, v{t[3]}"]
+    for r in range(4):
+        sel = "op_sel:[1,0,0] " if r % 2 else ""
+        ops.append(f"v_fma_mix_f32 v{t[r]}, v{hh + r // 2}, -1.0, v{t[r]} {sel}op_sel_hi:[1,0,0]")
+    ops += [f"v_cvt_pk_f16_f32 v{ll}, v{t[0]}, v{t[1]}", f"v_cvt_pk_f16_f32 v{ll + 1}, v{t[2]}, v{t[3]}"]
+    return ops
+
+
+def tile_reads(pair):
+    return [f"ds_read_b128 {vr(SLOT(pair, 'h'))}, v{V_TILE} offset:{2048 * pair}",
+            f"ds_read_b128 {vr(SLOT(pair, 'l'))}, v{V_TILE} offset:{2048 * pair + 1024}"]
+
+
+def aux_reads():
+    return [f"ds_read_b128 {vr(BIAS(0))}, v{V_AUX} offset:{TILES}",
+            f"ds_read_b128 {vr(BIAS(1))}, v{V_AUX} offset:{TILES + 64}",
+            f"ds_read_b32 v{V_SC}, v{V_SCADDR} offset:{TILES + 128}"]
+
+
+def handoff(next_reads, next_is_a0, label):
+    """Everything after the stage barrier: advance the ring, start reading the next stage, refill the
+    released slot by LDS-DMA.  A list of items to be woven between MFMAs in order; an item that is itself
+    a list is atomic (m0 write + DMA, the wave-0-only branch)."""
+    h = [
+        f"s_mov_b32 s{S_REL}, s{S_OFF}",                       # released slot (ring base + cur*STAGE)
+        "s_add_u32 %[cur], %[cur], 1",
+        ["s_cmp_eq_u32 %[cur], 5", "s_cselect_b32 %[cur], 0, %[cur]"],
+        f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}",
+        f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]",
+    ]
+    if next_reads:
+        h += [f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}"]
+        h += tile_reads(0) + tile_reads(1)
+    h += [
+        [f"s_add_u32 m0, s{S_REL}, s{S_W2048}", "s_nop 0", f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off"],
+        # second KiB: bump BOTH the global address and m0 (an instruction offset would be applied to the LDS
+        # address as well)
+        [f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_K1024}:{S_K1024 + 1}]", "s_add_u32 m0, m0, 1024", "s_nop 0",
+         f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off"],
+        ["s_cmp_lg_u32 %[wave], 0",
+         f"s_cbranch_scc1 .Lh3ffn_noaux_{label}_%=",
+         f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
+         f"s_add_u32 m0, s{S_REL}, {TILES}",
+         "s_nop 0",
+         f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off",
+         f".Lh3ffn_noaux_{label}_%=:"],
+        f"v_lshl_add_u64 {vr(V_GN, 2)}, {vr(V_GN, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]",
+    ]
+    return h
+
+
+def weave(mfmas, valu, misc, valu_per=2, misc_per=2):
+    """Each MFMA is followed by up to `valu_per` VALU ops and `misc_per` other items, spread so the queues
+    empty by the last MFMA (leftovers are appended)."""
+    out = []
+    valu, misc = list(valu), list(misc)
+    n = len(mfmas)
+
+    def emit(item):
+        out.extend(item if isinstance(item, list) else [item])
+
+    for i, m in enumerate(mfmas):
+        out.append(m)
+        left = n - i
+        for _ in range(min(valu_per, -(-len(valu) // left)) if valu else 0):
+            emit(valu.pop(0))
+        for _ in range(min(misc_per, -(-len(misc) // left)) if misc else 0):
+            emit(misc.pop(0))
+    for item in valu + misc:
+        emit(item)
+    return out
+
+
+def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, next_is_a0, label, is_a0):
+    """One 4-pair stage.  kind 'A': hacc[o] += W1tile(ks) . xb[ks];  kind 'B': yacc[4b+oo] += W2tile . hb."""
+    groups = []
+    for p in range(4):
+        if kind == "A":
+            o = o_or_b
+            groups.append(pair_mfmas(lambda jt: HACC(o, jt), p, lambda jt, part: XB(p, jt, part), first=(p == 0)))
+        else:
+            b = o_or_b
+            groups.append(pair_mfmas(lambda jt: YACC(4 * b + p, jt), p, lambda jt, part: HB(hb_cur, jt, part)))
+    aux = 3 if is_a0 else 0
+    epi = list(epi_ops)
+    share = -(-len(epi) // 4)
+    parts = [epi[i * share:(i + 1) * share] for i in range(4)]
+    out = []
+    # outstanding LDS reads at entry: p0.hi p0.lo p1.hi p1.lo (+3 aux)
+    out.append("s_waitcnt lgkmcnt(2)")
+    first_misc = tile_reads(2)
+    if is_a0:
+        # bias / scale of this chunk: read here (not at the previous hand-off) so the previous chunk's epilogue,
+        # still running in the stage before, keeps its values
+        first_misc = [f"v_add_u32 v{V_AUX}, s{S_OFF}, v{V_G16}", f"v_mov_b32 v{V_SCADDR}, s{S_OFF}"] + aux_reads() + first_misc
+    out += weave(groups[0], parts[0], first_misc, misc_per=3)
+    out.append(f"s_waitcnt lgkmcnt({2 + aux})" if aux else "s_waitcnt lgkmcnt(2)")
+    out += weave(groups[1], parts[1], tile_reads(3))
+    out.append("s_waitcnt vmcnt(6) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
+    out.append("s_barrier")
+    out += weave(groups[2], parts[2], handoff(next_reads, next_is_a0, label), misc_per=3)
+    out += weave(groups[3], parts[3], [])
+    return out
+
+
+def generate():
+    L = []
+    A = L.append
+    # ---- setup
+    A(f"v_mbcnt_lo_u32_b32 v{V_LANE16}, -1, 0")
+    A(f"v_mbcnt_hi_u32_b32 v{V_LANE16}, -1, v{V_LANE16}")
+    A(f"v_lshrrev_b32 v{V_G16}, 4, v{V_LANE16}")
+    A(f"v_lshlrev_b32 v{V_G16}, 4, v{V_G16}")
+    A(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_LANE16}")
+    A(f"s_lshl_b32 s{S_W2048}, %[wave], 11")
+    A(f"s_mov_b32 s{S_W2048 + 1}, 0")
+    A(f"s_mov_b32 s{S_STRIDE}, {STAGE}")
+    A(f"s_mov_b32 s{S_STRIDE + 1}, 0")
+    A(f"s_mov_b32 s{S_AUXOFF}, {TILES}")
+    A(f"s_mov_b32 s{S_AUXOFF + 1}, 0")
+    A(f"s_mov_b32 s{S_K1024}, 1024")
+    A(f"s_mov_b32 s{S_K1024 + 1}, 0")
+    # DMA source of this wave = gnext + wave*2048
+    A(f"v_lshl_add_u64 {vr(V_GN, 2)}, %[gn], 0, s[{S_W2048}:{S_W2048 + 1}]")
+    A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
+    A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
+    A(f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}")
+    # xb from the wave-private LDS block
+    A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
+    for i in range(24):
+        A(f"ds_read_b128 {vr(4 * i)}, v{V_TMP} offset:{1024 * i}")
+    for i in range(96):
+        A(f"v_accvgpr_write_b32 a{i}, 0")
+    A("s_waitcnt lgkmcnt(0)")
+    # first stage's reads
+    for r in tile_reads(0) + tile_reads(1):
+        A(r)
+    # ---- prologue: A0(0) A1(0), epilogue of chunk 0 (not hidden)
+    L += stage("A", 0, 0, [], True, False, "p0", True)
+    L += stage("A", 1, 0, [], True, True, "p1", False)
+    A("s_nop 7")
+    for o in range(2):
+        for jt in range(NT):
+            L += epi_unit(o, jt, 0)
+    A(f"s_sub_u32 s{S_CNT}, %[chunks], 1")
+    A(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    A("s_cbranch_scc1 .Lh3ffn_tail_%=")
+    # ---- steady state, two chunks per loop trip so the hb double buffer alternates statically
+    #      trip: A(c+1) B(c)[epi c+1 -> buf1]  A(c+2) B(c+1)[epi c+2 -> buf0]; needs (chunks-1) even -> handled below
+    A(".Lh3ffn_loop_%=:")
+    for half, (cur_buf, nxt_buf) in enumerate(((0, 1), (1, 0))):
+        epi = []
+        for o in range(2):
+            for jt in range(NT):
+                epi += epi_unit(o, jt, nxt_buf)
+        L += stage("A", 0, cur_buf, [], True, False, f"l{half}a0", True)
+        L += stage("A", 1, cur_buf, [], True, False, f"l{half}a1", False)
+        L += stage("B", 0, cur_buf, epi[:60], True, False, f"l{half}b0", False)
+        L += stage("B", 1, cur_buf, epi[60:], True, True, f"l{half}b1", False)
+        A(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+        A(f"s_cmp_eq_u32 s{S_CNT}, 0")
+        if half == 0:
+            A("s_cbranch_scc1 .Lh3ffn_tail1_%=")
+        else:
+            A("s_cbranch_scc0 .Lh3ffn_loop_%=")
+    # ---- tails: last chunk's B stages (hb in buf0 after an even number of loop halves, buf1 after odd)
+    A(".Lh3ffn_tail_%=:")
+    L += stage("B", 0, 0, [], True, False, "t0b0", False)
+    L += stage("B", 1, 0, [], False, False, "t0b1", False)
+    A("s_branch .Lh3ffn_done_%=")
+    A(".Lh3ffn_tail1_%=:")
+    L += stage("B", 0, 1, [], True, False, "t1b0", False)
+    L += stage("B", 1, 1, [], False, False, "t1b1", False)
+    A(".Lh3ffn_done_%=:")
+    # ---- y out through the wave-private LDS block
+    A("s_nop 15")
+    A("s_nop 15")
+    A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
+    for i in range(24):
+        for r in range(4):
+            A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
+        A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
+    A("s_waitcnt lgkmcnt(0)")
+    # gnext back (without the wave term)
+    A(f"s_sub_u32 s{S_AUXOFF}, 0, s{S_W2048}")
+    A(f"s_subb_u32 s{S_AUXOFF + 1}, 0, 0")
+    A(f"v_lshl_add_u64 %[gn], {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]")
+    return L
+
+
+def main():
+    lines = generate()
+    out = ["// GENERATED by tools/gen_h3_ffn_asm.py - do not edit.  Body of the FFN asm statement (see the generator",
+           "// for the register map and the schedule)."]
+    for l in lines:
+        out.append('"' + l + '\\n\\t"')
+    open(sys.argv[1] if len(sys.argv) > 1 else "timewarp_amd/csrc/tw_h3_ffn_asm.inc", "w").write("\n".join(out) + "\n")
+    clob = [f'"v{i}"' for i in range(204)] + [f'"a{i}"' for i in range(120)] + [f'"s{i}"' for i in range(84, 96)] + \
+           ['"vcc"', '"scc"', '"memory"']
+    cl = ["// GENERATED by tools/gen_h3_ffn_asm.py - clobber list of the FFN asm statement."]
+    for i in range(0, len(clob), 12):
+        cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
+    open((sys.argv[1] if len(sys.argv) > 1 else "timewarp_amd/csrc/tw_h3_ffn_asm.inc").replace("_asm.inc", "_clobbers.inc"), "w").write("\n".join(cl) + "\n")
+    n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
+    print(f"{len(lines)} instructions, {n_mfma} MFMAs")
+
+
+main()
