@@ -29,7 +29,7 @@ V_SC, V_T, V_TILE, V_AUX, V_SCADDR, V_GN, V_TMP, V_LANE16, V_G16 = 184, 186, 194
 YACC = lambda ot, jt: 4 * (3 * ot + jt)
 HACC = lambda o, jt: 96 + 4 * (3 * o + jt)
 # scratch SGPRs (clobbered)
-S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_K1024, S_CNT = 84, 85, 86, 88, 90, 92, 94  # pairs are even-aligned
+S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT = 84, 85, 86, 88, 90, 92, 94  # pairs are even-aligned
 STAGE, TILES = 9216, 8192
 
 
@@ -81,35 +81,36 @@ def aux_reads():
             f"ds_read_b32 v{V_SC}, v{V_SCADDR} offset:{TILES + 128}"]
 
 
-def handoff(next_reads, next_is_a0, label):
+def handoff(next_reads, with_aux, label):
     """Everything after the stage barrier: advance the ring, start reading the next stage, refill the
     released slot by LDS-DMA.  A list of items to be woven between MFMAs in order; an item that is itself
-    a list is atomic (m0 write + DMA, the wave-0-only branch)."""
+    a list is atomic (the wave-0-only branch).  `with_aux`: the stage being fetched (5 ahead) may carry a
+    bias/scale block (only A0 stages do), which wave 0 moves with a third DMA.
+    The second KiB of a wave's share uses the instruction offset, which LDS-DMA applies to the global
+    address AND to the LDS address (M0 + offset + 16*lane)."""
     h = [
-        f"s_mov_b32 s{S_REL}, s{S_OFF}",                       # released slot (ring base + cur*STAGE)
-        "s_add_u32 %[cur], %[cur], 1",
-        ["s_cmp_eq_u32 %[cur], 5", "s_cselect_b32 %[cur], 0, %[cur]"],
-        f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}",
-        f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]",
+        f"s_mov_b32 s{S_REL}, s{S_OFF}",                       # slot being released = ring base + cur*STAGE
+        f"s_add_u32 s{S_OFF}, s{S_OFF}, {STAGE}",
+        [f"s_cmp_eq_u32 s{S_OFF}, s{S_END}", f"s_cselect_b32 s{S_OFF}, %[ring], s{S_OFF}"],
     ]
     if next_reads:
         h += [f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}"]
         h += tile_reads(0) + tile_reads(1)
     h += [
-        [f"s_add_u32 m0, s{S_REL}, s{S_W2048}", "s_nop 0", f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off"],
-        # second KiB: bump BOTH the global address and m0 (an instruction offset would be applied to the LDS
-        # address as well)
-        [f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_K1024}:{S_K1024 + 1}]", "s_add_u32 m0, m0, 1024", "s_nop 0",
-         f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off"],
-        ["s_cmp_lg_u32 %[wave], 0",
-         f"s_cbranch_scc1 .Lh3ffn_noaux_{label}_%=",
-         f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
-         f"s_add_u32 m0, s{S_REL}, {TILES}",
-         "s_nop 0",
-         f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off",
-         f".Lh3ffn_noaux_{label}_%=:"],
-        f"v_lshl_add_u64 {vr(V_GN, 2)}, {vr(V_GN, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]",
+        f"s_add_u32 m0, s{S_REL}, s{S_W2048}",
+        f"s_nop 0",
+        f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off",
+        f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off offset:1024",
     ]
+    if with_aux:
+        h += [["s_cmp_lg_u32 %[wave], 0",
+               f"s_cbranch_scc1 .Lh3ffn_noaux_{label}_%=",
+               f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
+               f"s_add_u32 m0, s{S_REL}, {TILES}",
+               "s_nop 0",
+               f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off",
+               f".Lh3ffn_noaux_{label}_%=:"]]
+    h += [f"v_lshl_add_u64 {vr(V_GN, 2)}, {vr(V_GN, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]"]
     return h
 
 
@@ -135,7 +136,7 @@ def weave(mfmas, valu, misc, valu_per=2, misc_per=2):
     return out
 
 
-def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, next_is_a0, label, is_a0):
+def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     """One 4-pair stage.  kind 'A': hacc[o] += W1tile(ks) . xb[ks];  kind 'B': yacc[4b+oo] += W2tile . hb."""
     groups = []
     for p in range(4):
@@ -162,7 +163,7 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, next_is_a0, label, is_a0):
     out += weave(groups[1], parts[1], tile_reads(3))
     out.append("s_waitcnt vmcnt(6) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
     out.append("s_barrier")
-    out += weave(groups[2], parts[2], handoff(next_reads, next_is_a0, label), misc_per=3)
+    out += weave(groups[2], parts[2], handoff(next_reads, with_aux, label), misc_per=3)
     out += weave(groups[3], parts[3], [])
     return out
 
@@ -182,8 +183,7 @@ def generate():
     A(f"s_mov_b32 s{S_STRIDE + 1}, 0")
     A(f"s_mov_b32 s{S_AUXOFF}, {TILES}")
     A(f"s_mov_b32 s{S_AUXOFF + 1}, 0")
-    A(f"s_mov_b32 s{S_K1024}, 1024")
-    A(f"s_mov_b32 s{S_K1024 + 1}, 0")
+    A(f"s_add_u32 s{S_END}, %[ring], {5 * STAGE}")
     # DMA source of this wave = gnext + wave*2048
     A(f"v_lshl_add_u64 {vr(V_GN, 2)}, %[gn], 0, s[{S_W2048}:{S_W2048 + 1}]")
     A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
@@ -200,7 +200,7 @@ def generate():
     for r in tile_reads(0) + tile_reads(1):
         A(r)
     # ---- prologue: A0(0) A1(0), epilogue of chunk 0 (not hidden)
-    L += stage("A", 0, 0, [], True, False, "p0", True)
+    L += stage("A", 0, 0, [], True, True, "p0", True)
     L += stage("A", 1, 0, [], True, True, "p1", False)
     A("s_nop 7")
     for o in range(2):
@@ -217,8 +217,11 @@ def generate():
         for o in range(2):
             for jt in range(NT):
                 epi += epi_unit(o, jt, nxt_buf)
+        # in the steady state the stage fetched by a hand-off is 5 ahead = the kind after this one; only A0 stages
+        # carry a bias/scale block, so B1 fetches one.  A1 keeps the aux DMA as well: in the last trips its
+        # hand-off fetches the first stage AFTER the FFN (an A0 of out_mlp in the last layer).
         L += stage("A", 0, cur_buf, [], True, False, f"l{half}a0", True)
-        L += stage("A", 1, cur_buf, [], True, False, f"l{half}a1", False)
+        L += stage("A", 1, cur_buf, [], True, True, f"l{half}a1", False)
         L += stage("B", 0, cur_buf, epi[:60], True, False, f"l{half}b0", False)
         L += stage("B", 1, cur_buf, epi[60:], True, True, f"l{half}b1", False)
         A(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
@@ -229,13 +232,19 @@ def generate():
             A("s_cbranch_scc0 .Lh3ffn_loop_%=")
     # ---- tails: last chunk's B stages (hb in buf0 after an even number of loop halves, buf1 after odd)
     A(".Lh3ffn_tail_%=:")
-    L += stage("B", 0, 0, [], True, False, "t0b0", False)
-    L += stage("B", 1, 0, [], False, False, "t0b1", False)
+    L += stage("B", 0, 0, [], True, True, "t0b0", False)
+    L += stage("B", 1, 0, [], False, True, "t0b1", False)
     A("s_branch .Lh3ffn_done_%=")
     A(".Lh3ffn_tail1_%=:")
-    L += stage("B", 0, 1, [], True, False, "t1b0", False)
-    L += stage("B", 1, 1, [], False, False, "t1b1", False)
+    L += stage("B", 0, 1, [], True, True, "t1b0", False)
+    L += stage("B", 1, 1, [], False, True, "t1b1", False)
     A(".Lh3ffn_done_%=:")
+    # ring slot index back to the caller: cur = (S_OFF - ring) / STAGE, 0..4
+    A(f"s_sub_u32 s{S_REL}, s{S_OFF}, %[ring]")
+    A("s_mov_b32 %[cur], 0")
+    for k in range(1, 5):
+        A(f"s_cmp_eq_u32 s{S_REL}, {k * STAGE}")
+        A(f"s_cselect_b32 %[cur], {k}, %[cur]")
     # ---- y out through the wave-private LDS block
     A("s_nop 15")
     A("s_nop 15")

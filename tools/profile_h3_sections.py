@@ -1,0 +1,39 @@
+"""Section timing of the split-fp16 net-block kernel from s_memtime stamps (tw_debug_set_flags bit 4 = 16):
+wave 0 of workgroup 0 stamps the shader clock at the section boundaries of one coupling net."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import flow_oracle as fo
+from tests import helpers as H
+from timewarp_amd import _lib
+
+extra = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+sd = H.full_kernel_sd()
+N, V = 1000, 22
+g = torch.Generator().manual_seed(2)
+at = torch.randint(0, 5, (1, V), generator=g)
+x_c = torch.randn(1, V, 3, generator=g) * 0.3
+x_v = torch.randn(1, V, 3, generator=g) * 0.5
+zo = torch.randn(N, V, 3, generator=g) * 0.5
+mask = torch.zeros(1, V, dtype=torch.bool)
+xc = x_c - fo.centre_of_mass(x_c, mask)
+m = H.tw_kernel_model(sd, path=3)
+_lib.load().tw_debug_set_flags(16 | extra)
+for rep in range(3):
+    acts, out = m.debug_netblock(0, 0, at.cuda(), xc.cuda(), x_v.cuda(), mask.cuda(), zo.cuda(), 3)
+torch.cuda.synchronize()
+ts = acts.reshape(-1)[:64].contiguous().view(torch.int64).cpu().tolist()
+L = 3
+names = ["start", "in_mlp"]
+for l in range(L):
+    names += [f"L{l} attention", f"L{l} add+LN1", f"L{l} FFN", f"L{l} add+LN2"]
+names += ["out_mlp"]
+t = ts[: len(names)]
+total = t[-1] - t[0]
+print(f"total {total} cycles")
+agg = {}
+for i in range(1, len(names)):
+    d = t[i] - t[i - 1]
+    key = names[i].split(" ", 1)[-1] if names[i].startswith("L") else names[i]
+    agg[key] = agg.get(key, 0) + d
+    print(f"  {names[i]:16s} {d:9d}  {100.0 * d / total:5.1f} %")
+print({k: f"{100.0 * v / total:.1f}%" for k, v in agg.items()})
