@@ -38,9 +38,6 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #ifndef H3_DEBUG_SYNC
 #define H3_DEBUG_SYNC 0
 #endif
-#ifndef H3_FFN_ASM
-#define H3_FFN_ASM 1
-#endif
 #define H3_NT 3
 #define H3_TOK (16 * H3_NT)
 #define H3_XT 56                    // halfs per feature row of the transposed X tile
@@ -57,7 +54,8 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 // stage sequence per net (each 9 KiB = 4 tile pairs + aux); the A and B stages of the chunked MLPs are
 // emitted software pipelined,  A(0) | A(1) B(0) | A(2) B(1) | ... | B(n-1)  (h3_mlp_chain):
 //   IN   : hid_chunks x { A: [W0 chunk (2 ot x 2 ks) + aux(b0 chunk, scale0)]  B: [W2 chunk ot 0-3][ot 4-7] }
-//   layer: H heads x 8 x [Wc, one ot x 4 ks]
+//   layer: H heads x 4 ks x 2 x [Wc_h: four ot (4 half + oo) of k-step ks]  (ks-major: the GEMM for k-step ks
+//          can start as soon as the mixing has produced xm[ks])
 //          ff_chunks x { A: [W1 chunk o=0 (4 ks) + aux(b1 chunk, scale1)][o=1]  B: [W2 chunk ot 0-3][ot 4-7] }
 //   OUT  : hid_chunks x { A: [W0 chunk o=0 + aux][o=1]  B: [W2 chunk (1 pair)] }
 // side floats per net: in2_b[128] { n1w n1b [128] b2[128] n2w n2b [128] } out2_b[16]
@@ -169,12 +167,13 @@ __global__ void h3_pack_block_kernel(const float* __restrict__ src, int ld, int 
   }
 }
 
-__global__ void h3_pack_fold_kernel(const float* __restrict__ wv, const float* __restrict__ wo, int H, int h, int ot0,
-                                    const float* __restrict__ scale_up, char* __restrict__ dst) {
-  const int o = blockIdx.x, ks = blockIdx.y, lane = threadIdx.x;  // o in 0..1 -> ot = ot0 + o
+// one Wc stage = k-step ks of four output tiles (ot = 4 half + oo): tile pair oo
+__global__ void h3_pack_fold_kernel(const float* __restrict__ wv, const float* __restrict__ wo, int H, int h, int ks,
+                                    int half, const float* __restrict__ scale_up, char* __restrict__ dst) {
+  const int oo = blockIdx.x, lane = threadIdx.x;
   const float sc = scale_up[0];
-  const int row = 16 * (ot0 + o) + (lane & 15);
-  char* pair = dst + (int64_t)(o * 4 + ks) * H3_PAIR_BYTES;
+  const int row = 16 * (4 * half + oo) + (lane & 15);
+  char* pair = dst + (int64_t)oo * H3_PAIR_BYTES;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int col = 32 * ks + 16 * (e / 4) + 4 * (lane >> 4) + (e % 4);
@@ -253,11 +252,12 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         hipLaunchKernelGGL(h3_scale_kernel, dim3(1), dim3(1), 0, s, scratch, up, lsc + 0);
         TW_LAUNCH_CHECK();
         for (int h = 0; h < d.n_heads; ++h)
-          for (int ot = 0; ot < 8; ++ot) {
-            hipLaunchKernelGGL(h3_pack_fold_kernel, dim3(1, 4), dim3(64), 0, s, lb + L.layer.wv, lb + L.layer.wo, d.n_heads, h,
-                               ot, up, st + (int64_t)(8 * h + ot) * H3_STAGE_BYTES);
-            TW_LAUNCH_CHECK();
-          }
+          for (int ks = 0; ks < 4; ++ks)
+            for (int half = 0; half < 2; ++half) {
+              hipLaunchKernelGGL(h3_pack_fold_kernel, dim3(4), dim3(64), 0, s, lb + L.layer.wv, lb + L.layer.wo, d.n_heads, h,
+                                 ks, half, up, st + (int64_t)(8 * h + 2 * ks + half) * H3_STAGE_BYTES);
+              TW_LAUNCH_CHECK();
+            }
         st += (int64_t)8 * d.n_heads * H3_STAGE_BYTES;
         if ((rc = absmax(lb + L.layer.w1, (int64_t)d.d_ff * 128, up, lsc + 1))) return rc;
         for (int ch = 0; ch < g.ff_chunks; ++ch)
@@ -736,7 +736,11 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
   b_stages(hb, false, unused);
 }
 
-template <int NT>
+// ASM = true: attention and FFN run in the generated asm blocks (the product path).  ASM = false: the same two
+// sections as compiled C++ (tw_debug_set_flags bit 3; kept as the readable statement of what the asm computes and
+// for A/B checks).  Two instantiations rather than a runtime branch: with both variants in one function the
+// register allocator spilled 88 VGPRs to scratch.
+template <int NT, bool ASM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_h3_kernel(const H3Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -878,6 +882,30 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (ASM) {
+      // Hand-scheduled attention block (tools/gen_h3_attn_asm.py): all heads, mixing + Wc GEMM; reads the
+      // transposed copy of x written above, returns y through the same wave-private LDS block.
+      char* priv = (char*)xt_hi;
+      int cur = __builtin_amdgcn_readfirstlane(pipe.cur);
+      const char* gn = pipe.gnext;
+      const char* sfp = sf_base;
+      const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+      const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
+      const int heads = __builtin_amdgcn_readfirstlane(p.H);
+      asm volatile(
+#include "tw_h3_attn_asm.inc"
+          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp)
+          :
+#include "tw_h3_attn_clobbers.inc"
+      );
+      pipe.cur = cur;
+      pipe.gnext = gn;
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) y[ot][jt] = *(const f4*)(priv + (ot * NT + jt) * 1024 + lane * 16);
+    } else
     for (int h = 0; h < p.H; ++h) {
       // score fragments of this head (B operand of the mixing MFMA)
       static_assert(NT == 3, "h3_load_sf3 loads three token tiles");
@@ -933,20 +961,22 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) split8(acc[0][jt], acc[1][jt], xm[ks].h[jt], xm[ks].l[jt]);
       }
-      // y += Wc_h . xm : eight stages of (one ot x 4 ks)
+      // y += Wc_h . xm : eight stages, ks-major (k-step ks, output tiles 4 half .. 4 half + 3)
 #pragma unroll
-      for (int ot = 0; ot < 8; ++ot) {
-        const char* st = pipe.stage();
-        H3Tiles w;
-        w.load(st, lane);
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          w.ready(ks);
-          mma3<NT>(w.hi(ks), w.lo(ks), xm[ks], y[ot]);
-          w.done(ks);
-        }
+        for (int half = 0; half < 2; ++half) {
+          const char* st = pipe.stage();
+          H3Tiles w;
+          w.load(st, lane);
+#pragma unroll
+          for (int oo = 0; oo < 4; ++oo) {
+            w.ready(oo);
+            mma3<NT>(w.hi(oo), w.lo(oo), xm[ks], y[4 * half + oo]);
+            w.done(oo);
+          }
           pipe.advance();
-      }
+        }
     }
     {
       const float sc = h3_load_f1(lsc);
@@ -968,8 +998,7 @@ netblock_h3_kernel(const H3Params p) {
       for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
-#if H3_FFN_ASM
-      if (!(p.debug & 8)) {
+      if constexpr (ASM) {
         // Hand-scheduled chunk loop (tools/gen_h3_ffn_asm.py).  Operands travel through the wave-private LDS
         // block (free between the mixing of this layer and the transposed copy of the next): xb in as 24
         // x 1 KiB register images, y out the same way; the asm statement owns v0-v203 / a0-a119.
@@ -999,9 +1028,9 @@ netblock_h3_kernel(const H3Params p) {
         for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt) y[ot][jt] = *(const f4*)(priv + (ot * NT + jt) * 1024 + lane * 16);
-      } else
-#endif
+      } else {
         h3_mlp_chain<NT, 4, 8, false>(xb, y, pipe, p.ff_chunks, lane);
+      }
       const float sc = h3_load_f1(lsc + 2);
       f4 bb[8];
       h3_load8_f4(sl + 256 + 4 * g, bb);
@@ -1071,7 +1100,8 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
   const int64_t nblocks = (n_rows + g.mpw - 1) / g.mpw;
   w.s_out = (float*)take(n_rows * V * 3 * 4);
   w.t_out = (float*)take(n_rows * V * 3 * 4);
-  w.sfrag = take(nblocks * d.n_heads * H3_NT * H3_SF_BYTES);
+  // + one head of slack: the attention asm block prefetches the "next head" also after the last one
+  w.sfrag = take((nblocks * d.n_heads + 1) * H3_NT * H3_SF_BYTES);
   w.bytes = p - (char*)base;
   return w;
 }
@@ -1122,13 +1152,18 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
   static bool attr = false;
   if (!attr) {
-    TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_h3_kernel<H3_NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_h3_kernel<H3_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)H3_LDS_BYTES));
+    TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_h3_kernel<H3_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)H3_LDS_BYTES));
     attr = true;
   }
   int prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
-  hipLaunchKernelGGL(netblock_h3_kernel<H3_NT>, dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
+  if (g_debug_flags & 8)
+    hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
+  else
+    hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
   TW_LAUNCH_CHECK();
   if ((prc = profile_mark(a.stream, false))) return prc;
   return TW_OK;

@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generate timewarp_amd/csrc/tw_h3_attn_asm.inc: the hand-scheduled kernel-attention block of one encoder
+layer of the split-fp16 net-block kernel (gfx950):   y = sum_h Wc_h . (A_h X)^T   for 48 tokens per wave.
+
+Per head h and k-step ks (32 features):
+  mixing   xm[ks] = split( X^T[32 ks .. +31][tokens] . A_h[tokens][queries] )      36 MFMAs (18 K=32 + 18 K=16,
+           separate accumulators - mixed-shape chains need wait states hipcc does not know about), operands:
+           A = rows of the transposed fp16 hi/lo copy of X in the wave-private LDS block, B = score fragments
+  GEMM     y[ot] += Wc_h[ot][ks] . xm[ks]       two weight stages (ot 0-3, 4-7) of 36 MFMAs each
+Software pipeline (one step = one ks):  the mixing MFMAs of the NEXT k-step run first, then the two GEMM stages
+of the current k-step with the fp32 -> fp16 hi/lo split of the new mixing result (72 VALU ops) issued in the
+shadow of their MFMAs.  The score fragments of head h+1 are loaded (12 global loads) right after the last mixing of
+head h and waited for one k-step later.  Stage hand-off as in the FFN block (gen_h3_ffn_asm.py).
+
+Register map (private to the asm statement):
+  v0..v35     score fragments  SF[jt] = {s0h 4, s0l 4, s1h 2, s1l 2}
+  v36..v59    X^T operands, two buffers (t = 0, 1) of {a0h 4, a0l 4, a1h 2, a1l 2}
+  v60..v83    acc[t][jt] (one chain per accumulator, K=32 and K=16 MFMAs alternating five MFMAs apart)
+  v108..v155  xm[buf][jt] = {h 4, l 4}
+  v156..v187  weight tile slots p=0..3: hi v[156+8p..], lo v[160+8p..]
+  v188..v195  temporaries;  v196 tile address; v197/v198 X^T row addresses (8g / 4g column groups)
+  v200:201 DMA source; v202:203 temp; v204 lane*16; v206:207 / v208:209 score-fragment addresses (16 B / 8 B lanes)
+  v210:211 temp
+  a0..a95     y[ot][jt]"""
+import os
+import sys
+
+NT = 3
+STAGE, TILES = 9216, 8192
+XT_ROW = 56 * 2            # bytes per feature row of the transposed tile
+XT_LO = 128 * 56 * 2       # offset of the lo half
+SF_BYTES = 3072
+SF = lambda jt, name: 12 * jt + {"s0h": 0, "s0l": 4, "s1h": 8, "s1l": 10}[name]
+XA = lambda buf, name: 36 + 12 * buf + {"a0h": 0, "a0l": 4, "a1h": 8, "a1l": 10}[name]
+ACC = lambda t, jt: 60 + 4 * (3 * t + jt)
+TAIL = lambda t, jt: 84 + 4 * (3 * t + jt)
+XM = lambda buf, jt, part: 108 + 24 * buf + 8 * jt + (0 if part == "h" else 4)
+SLOT = lambda p, part: 156 + 8 * p + (0 if part == "h" else 4)
+V_T, V_TILE, V_XT0, V_XT1, V_GN, V_TMP, V_LANE16, V_SF16, V_SF8, V_TMP2 = 188, 196, 197, 198, 200, 202, 204, 206, 208, 210
+YACC = lambda ot, jt: 4 * (3 * ot + jt)
+S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT, S_K3072, S_K6144 = 84, 85, 86, 88, 90, 92, 93, 94, 96
+N_V, N_A = 212, 96
+EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(",")))
+
+
+def vr(base, n=4):
+    return f"v[{base}:{base + n - 1}]"
+
+
+def ar(base, n=4):
+    return f"a[{base}:{base + n - 1}]"
+
+
+def mfma32(d, a, b, zero=False, dreg="v"):
+    dd = vr(d) if dreg == "v" else ar(d)
+    return f"v_mfma_f32_16x16x32_f16 {dd}, {vr(a)}, {vr(b)}, {'0' if zero else dd}"
+
+
+def mfma16(d, a, b, zero=False):
+    return f"v_mfma_f32_16x16x16_f16 {vr(d)}, {vr(a, 2)}, {vr(b, 2)}, {'0' if zero else vr(d)}"
+
+
+def xt_reads(ks, t, buf):
+    off = XT_ROW * 16 * (2 * ks + t)
+    return [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
+            f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_LO}",
+            f"ds_read_b64 {vr(XA(buf, 'a1h'), 2)}, v{V_XT1} offset:{off}",
+            f"ds_read_b64 {vr(XA(buf, 'a1l'), 2)}, v{V_XT1} offset:{off + XT_LO}"]
+
+
+def mixing_mfmas():
+    """36 MFMAs of one k-step: six accumulators acc[t][jt], each a chain  K32 hh -> K16 hh -> K32 hl -> K16 hl ->
+    K32 lh -> K16 lh.  Alternating the two MFMA shapes on ONE accumulator needs >= 5 wait states between them
+    (tools/probe/mfma_chain_probe.hip); the six chains are issued round-robin, so two MFMAs of one chain are always
+    five MFMAs (>= 40 cycles) apart."""
+    out = []
+    first = True
+    for a32, b32, a16, b16 in (("a0h", "s0h", "a1h", "s1h"), ("a0h", "s0l", "a1h", "s1l"), ("a0l", "s0h", "a1l", "s1h")):
+        for t in range(2):
+            for jt in range(NT):
+                out.append(mfma32(ACC(t, jt), XA(t, a32), SF(jt, b32), zero=first))
+        for t in range(2):
+            for jt in range(NT):
+                out.append(mfma16(ACC(t, jt), XA(t, a16), SF(jt, b16)))
+        first = False
+    return out
+
+
+def xt_reads_step(ks):
+    return [] if "noxt" in EXPERIMENT else xt_reads(ks, 0, 0) + xt_reads(ks, 1, 1)
+
+
+def mixing_part(ks, reads_issued):
+    """The 36 mixing MFMAs of k-step ks; the eight X^T operand reads are either issued here or were woven into
+    the previous GEMM stage."""
+    out = [] if reads_issued else xt_reads_step(ks)
+    out.append("s_waitcnt lgkmcnt(0)")
+    if "nomix" not in EXPERIMENT:
+        out += mixing_mfmas()
+    return out
+
+
+def split_ops(buf):
+    """acc -> xm[buf]: per (jt, t) 8 VALU ops (2+2 packs, 4 mixed-precision subtractions)."""
+    ops = []
+    k = 0
+    for jt in range(NT):
+        for t in range(2):
+            tt = [V_T + 4 * (k % 2) + r for r in range(4)]
+            k += 1
+            a = ACC(t, jt)
+            hh = XM(buf, jt, "h") + 2 * t
+            ll = XM(buf, jt, "l") + 2 * t
+            ops += [f"v_cvt_pk_f16_f32 v{hh}, v{a}, v{a + 1}", f"v_cvt_pk_f16_f32 v{hh + 1}, v{a + 2}, v{a + 3}"]
+            for r in range(4):
+                sel = "op_sel:[1,0,0] " if r % 2 else ""
+                ops.append(f"v_fma_mix_f32 v{tt[r]}, v{hh + r // 2}, -1.0, v{a + r} {sel}op_sel_hi:[1,0,0]")
+            ops += [f"v_cvt_pk_f16_f32 v{ll}, v{tt[0]}, v{tt[1]}", f"v_cvt_pk_f16_f32 v{ll + 1}, v{tt[2]}, v{tt[3]}"]
+    return ops
+
+
+def tile_reads(pair):
+    return [f"ds_read_b128 {vr(SLOT(pair, 'h'))}, v{V_TILE} offset:{2048 * pair}",
+            f"ds_read_b128 {vr(SLOT(pair, 'l'))}, v{V_TILE} offset:{2048 * pair + 1024}"]
+
+
+def handoff(next_reads, label):
+    h = [
+        f"s_mov_b32 s{S_REL}, s{S_OFF}",
+        f"s_add_u32 s{S_OFF}, s{S_OFF}, {STAGE}",
+        [f"s_cmp_eq_u32 s{S_OFF}, s{S_END}", f"s_cselect_b32 s{S_OFF}, %[ring], s{S_OFF}"],
+    ]
+    if next_reads:
+        h += [f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}"] + tile_reads(0) + tile_reads(1)
+    h += [
+        f"s_add_u32 m0, s{S_REL}, s{S_W2048}",
+        "s_nop 0",
+        f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off",
+        f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off offset:1024",
+        # the stages fetched from here (five ahead) include the FFN's first A stage, which carries a bias/scale block
+        ["s_cmp_lg_u32 %[wave], 0",
+         f"s_cbranch_scc1 .Lh3att_noaux_{label}_%=",
+         f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
+         f"s_add_u32 m0, s{S_REL}, {TILES}",
+         "s_nop 0",
+         f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off",
+         f".Lh3att_noaux_{label}_%=:"],
+        f"v_lshl_add_u64 {vr(V_GN, 2)}, {vr(V_GN, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]",
+    ]
+    return h
+
+
+def weave(mfmas, valu, misc, valu_per=1, misc_per=3, skip=0):
+    out = []
+    valu, misc = list(valu), list(misc)
+    n = len(mfmas)
+
+    def emit(item):
+        out.extend(item if isinstance(item, list) else [item])
+
+    for i, m in enumerate(mfmas):
+        out.append(m)
+        if i < skip:
+            continue
+        left = n - i
+        for _ in range(min(valu_per, -(-len(valu) // left)) if valu else 0):
+            emit(valu.pop(0))
+        for _ in range(min(misc_per, -(-len(misc) // left)) if misc else 0):
+            emit(misc.pop(0))
+    for item in valu + misc:
+        emit(item)
+    return out
+
+
+def gemm_stage(half, xm_buf, valu, next_reads, label, vm_allow=6, skip=0, tail_misc=()):
+    """One Wc stage: y[4 half + p] += tile pair p . xm[xm_buf], with `valu` woven under the MFMAs."""
+    groups = []
+    for p in range(4):
+        g = []
+        for a_part, b_part in (("h", "h"), ("h", "l"), ("l", "h")):
+            for jt in range(NT):
+                g.append(mfma32(YACC(4 * half + p, jt), SLOT(p, a_part), XM(xm_buf, jt, b_part), dreg="a"))
+        groups.append(g)
+    valu = [] if "novalu" in EXPERIMENT else list(valu)
+    share = -(-len(valu) // 4)
+    parts = [valu[i * share:(i + 1) * share] for i in range(4)]
+    out = ["s_waitcnt lgkmcnt(2)"]
+    out += weave(groups[0], parts[0], tile_reads(2), skip=skip)
+    out.append("s_waitcnt lgkmcnt(2)")
+    out += weave(groups[1], parts[1], tile_reads(3))
+    out.append(f"s_waitcnt vmcnt({vm_allow}) lgkmcnt(0)")
+    if "nobarrier" not in EXPERIMENT:
+        out.append("s_barrier")
+    out += weave(groups[2], parts[2], handoff(next_reads, label))
+    out += weave(groups[3], parts[3], list(tail_misc))
+    return out
+
+
+def sf_loads():
+    """Score fragments of the head at V_SF16 / V_SF8 (12 loads), then both addresses advance to the next head."""
+    out = []
+    if "nosf" in EXPERIMENT:
+        return ["s_nop 0"]
+    for jt in range(NT):
+        if jt == 0:
+            a16, a8 = V_SF16, V_SF8
+        else:
+            k = S_K3072 if jt == 1 else S_K6144
+            out += [f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_SF16, 2)}, 0, s[{k}:{k + 1}]",
+                    f"v_lshl_add_u64 {vr(V_TMP2, 2)}, {vr(V_SF8, 2)}, 0, s[{k}:{k + 1}]"]
+            a16, a8 = V_TMP, V_TMP2
+        out += [f"global_load_dwordx4 {vr(SF(jt, 's0h'))}, {vr(a16, 2)}, off",
+                f"global_load_dwordx4 {vr(SF(jt, 's0l'))}, {vr(a16, 2)}, off offset:1024",
+                f"global_load_dwordx2 {vr(SF(jt, 's1h'), 2)}, {vr(a8, 2)}, off offset:2048",
+                f"global_load_dwordx2 {vr(SF(jt, 's1l'), 2)}, {vr(a8, 2)}, off offset:2560"]
+    out += [f"v_lshl_add_u64 {vr(V_SF16, 2)}, {vr(V_SF16, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]",   # NT * SF_BYTES == STAGE
+            f"v_lshl_add_u64 {vr(V_SF8, 2)}, {vr(V_SF8, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]"]
+    return out
+
+
+def generate():
+    assert NT * SF_BYTES == STAGE
+    L = []
+    A = L.append
+    A(f"v_mbcnt_lo_u32_b32 v{V_LANE16}, -1, 0")
+    A(f"v_mbcnt_hi_u32_b32 v{V_LANE16}, -1, v{V_LANE16}")
+    # X^T row addresses: row (lane & 15), column group 8 g (16 B) / 32 + 4 g (8 B)
+    A(f"v_and_b32 v{V_T}, 15, v{V_LANE16}")
+    A(f"v_mul_u32_u24 v{V_T}, {XT_ROW}, v{V_T}")
+    A(f"v_lshrrev_b32 v{V_T + 1}, 4, v{V_LANE16}")
+    A(f"v_lshlrev_b32 v{V_T + 2}, 4, v{V_T + 1}")          # 16 g bytes
+    A(f"v_lshlrev_b32 v{V_T + 3}, 3, v{V_T + 1}")          # 8 g bytes
+    A(f"v_add3_u32 v{V_XT0}, v{V_T}, v{V_T + 2}, %[priv]")
+    A(f"v_add3_u32 v{V_XT1}, v{V_T}, v{V_T + 3}, %[priv]")
+    A(f"v_add_u32 v{V_XT1}, 64, v{V_XT1}")
+    # score-fragment lane addresses: sf + 16 lane (128-bit loads), sf + 8 lane (64-bit loads)
+    A(f"v_lshlrev_b32 v{V_TMP2}, 3, v{V_LANE16}")
+    A(f"v_mov_b32 v{V_TMP2 + 1}, 0")
+    A(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_LANE16}")
+    A(f"v_mov_b32 v{V_LANE16 + 1}, 0")
+    A(f"v_lshl_add_u64 {vr(V_SF16, 2)}, %[sf], 0, {vr(V_LANE16, 2)}")
+    A(f"v_lshl_add_u64 {vr(V_SF8, 2)}, %[sf], 0, {vr(V_TMP2, 2)}")
+    A(f"s_lshl_b32 s{S_W2048}, %[wave], 11")
+    A(f"s_mov_b32 s{S_W2048 + 1}, 0")
+    A(f"s_mov_b32 s{S_STRIDE}, {STAGE}")
+    A(f"s_mov_b32 s{S_STRIDE + 1}, 0")
+    A(f"s_mov_b32 s{S_AUXOFF}, {TILES}")
+    A(f"s_mov_b32 s{S_AUXOFF + 1}, 0")
+    A(f"s_mov_b32 s{S_K3072}, {SF_BYTES}")
+    A(f"s_mov_b32 s{S_K3072 + 1}, 0")
+    A(f"s_mov_b32 s{S_K6144}, {2 * SF_BYTES}")
+    A(f"s_mov_b32 s{S_K6144 + 1}, 0")
+    A(f"s_add_u32 s{S_END}, %[ring], {5 * STAGE}")
+    A(f"v_lshl_add_u64 {vr(V_GN, 2)}, %[gn], 0, s[{S_W2048}:{S_W2048 + 1}]")
+    A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
+    A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
+    A(f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}")
+    for i in range(N_A):
+        A(f"v_accvgpr_write_b32 a{i}, 0")
+    # ---- prologue: score fragments of head 0, mixing of (0, 0) and its split in the open
+    L += sf_loads()
+    A("s_waitcnt vmcnt(0)")
+    for r in tile_reads(0) + tile_reads(1):
+        A(r)
+    L += mixing_part(0, False)
+    A("s_nop 7")
+    L += split_ops(0)
+    A("s_nop 1")
+    A(f"s_mov_b32 s{S_CNT}, %[heads]")
+    # ---- one loop trip = one head: steps ks = 0..3; step ks runs the mixing of the next k-step, then GEMM(ks)
+    A(".Lh3att_head_%=:")
+    # the X^T operand reads of a step's mixing are woven into the last MFMAs of the previous step (first step of the
+    # first head: issued before the loop)
+    L += xt_reads_step(1)
+    for ks in range(4):
+        buf, nbuf = ks % 2, 1 - ks % 2
+        if ks < 3:
+            L += mixing_part(ks + 1, True)
+            if ks == 2:
+                # last use of this head's score fragments is issued: fetch the next head's.  Also after the last
+                # head (the buffer has one head of slack): the s_waitcnt vmcnt counts below assume the 12 loads.
+                L += sf_loads()
+            vm = 18 if ks == 2 else 6   # the 12 fragment loads sit in the same queue behind the stage DMAs
+        else:
+            # mixing of (h + 1, 0): needs the new score fragments; skipped after the last head.  Newer than the 12
+            # fragment loads are the DMAs of two hand-offs: 4 for waves 1-3, up to 6 for wave 0 (aux blocks).
+            A(f"s_cmp_eq_u32 s{S_CNT}, 1")
+            A("s_cbranch_scc1 .Lh3att_nomix_%=")
+            A("s_cmp_eq_u32 %[wave], 0")
+            A("s_cbranch_scc1 .Lh3att_w0_%=")
+            A("s_waitcnt vmcnt(4)")
+            A("s_branch .Lh3att_w1_%=")
+            A(".Lh3att_w0_%=:")
+            A("s_waitcnt vmcnt(6)")
+            A(".Lh3att_w1_%=:")
+            L += mixing_part(0, True)
+            A(".Lh3att_nomix_%=:")
+            vm = 6
+        split = split_ops(nbuf)
+        nxt = (ks + 2) % 4   # k-step whose mixing runs at the start of the next step
+        L += gemm_stage(0, buf, split[:24], True, f"k{ks}a", vm_allow=vm, skip=3)
+        L += gemm_stage(1, buf, split[24:], True, f"k{ks}b", vm_allow=vm, tail_misc=xt_reads_step(nxt))
+        A("s_nop 1")
+    A(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    A(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    A("s_cbranch_scc0 .Lh3att_head_%=")
+    # ---- out: ring slot index, y through the wave-private block (X^T is dead now), DMA pointer
+    A(f"s_sub_u32 s{S_REL}, s{S_OFF}, %[ring]")
+    A("s_mov_b32 %[cur], 0")
+    for k in range(1, 5):
+        A(f"s_cmp_eq_u32 s{S_REL}, {k * STAGE}")
+        A(f"s_cselect_b32 %[cur], {k}, %[cur]")
+    A("s_waitcnt lgkmcnt(0)")
+    A("s_nop 15")
+    A("s_nop 15")
+    A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
+    for i in range(24):
+        for r in range(4):
+            A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
+        A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
+    A("s_waitcnt lgkmcnt(0)")
+    A(f"s_sub_u32 s{S_AUXOFF}, 0, s{S_W2048}")
+    A(f"s_subb_u32 s{S_AUXOFF + 1}, 0, 0")
+    A(f"v_lshl_add_u64 %[gn], {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]")
+    return L
+
+
+def main():
+    lines = generate()
+    base = sys.argv[1] if len(sys.argv) > 1 else "timewarp_amd/csrc/tw_h3_attn_asm.inc"
+    out = ["// GENERATED by tools/gen_h3_attn_asm.py - do not edit.  Body of the attention asm statement."]
+    out += ['"' + l + '\\n\\t"' for l in lines]
+    open(base, "w").write("\n".join(out) + "\n")
+    clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A)] + [f'"s{i}"' for i in range(84, 98)] + \
+           ['"vcc"', '"scc"', '"memory"']
+    cl = ["// GENERATED by tools/gen_h3_attn_asm.py - clobber list of the attention asm statement."]
+    for i in range(0, len(clob), 12):
+        cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
+    open(base.replace("_asm.inc", "_clobbers.inc"), "w").write("\n".join(cl) + "\n")
+    print(f"{len(lines)} instructions, {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs")
+
+
+main()
