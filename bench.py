@@ -36,7 +36,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (
 # execution paths of the flow (include/timewarp_hip.h): both hold the 1e-5 parity bar
 PATHS = {
     "h3": dict(path=3, dtype="f16x3 (split-fp16 operands, 3 MFMAs per fp32 product, fp32 accumulate)",
-               kernel="tw::netblock_h3_kernel<3>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=3),
+               kernel="tw::netblock_h3_kernel<3, true>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=3),
     "f32": dict(path=1, dtype="f32", kernel="tw::netblock_kernel<3>", peak=F32_MFMA_PEAK_TFLOPS, mfma_per_product=1),
 }
 # Synthetic-weight calibration (SURVEY section 8d idea, tuned so acceptance is non-degenerate against
