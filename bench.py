@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--proposals", type=int, default=S_PROPOSALS)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--sync-every", type=int, default=8,
+                    help="MH iterations queued per host read-back of the accept results (sample_with_model's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", choices=sorted(PATHS), default="h3",
                     help="flow execution path: split-fp16 fused kernel (default) or exact-f32 fused kernel")
@@ -178,7 +180,8 @@ def main():
     chain, model = build_chain(device, distributed.chain_seed(args.seed, rank), args.proposals, pinfo["path"])
     with torch.no_grad():
         for _ in range(args.warmup):
-            chain.step()
+            chain.step_deferred()
+        chain.flush()
     torch.cuda.synchronize()
     acc0, prop0 = chain.accepted, chain.proposals
     states0 = sum(t.shape[0] for t in chain.chain_c)
@@ -188,8 +191,12 @@ def main():
     lib.tw_profile_begin()
     t0 = time.perf_counter()
     with torch.no_grad():
-        for _ in range(args.steps):
-            chain.step()
+        # deferred iterations: tw_mh_accept moves the chain state on the device, the host reads the accept results
+        # of `sync_every` iterations with one copy (what sample_with_model does for the bulk of a chain)
+        for it in range(args.steps):
+            chain.step_deferred()
+            if (it + 1) % args.sync_every == 0:
+                chain.flush()
         traj, _ = chain.trajectory()
         gathered, _ = distributed.gather_trajectories(traj)  # the one collective (no-op at N=1)
     torch.cuda.synchronize()

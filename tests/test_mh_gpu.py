@@ -138,3 +138,30 @@ def test_sample_trajectory_writes_and_resumes(tmp_path):
                              num_proposal_steps=10, verbose=False) == 1
     p2 = np.load(segment_path(out, "tiny", 2))["positions"]
     assert np.allclose(p2[0], p1[-1])  # resumed from the last saved row
+
+
+def test_deferred_iterations_equal_synchronous_ones():
+    """sample_with_model with the accept results read back every 4 iterations (the chain state moved on the
+    device by tw_mh_accept) gives bit-identical chains and statistics to one read-back per iteration."""
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.utils.evaluation_utils import sample_with_model
+
+    z, sd = load_mh()
+    model = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2,
+                              lengthscales=(0.1, 0.5, 1.2), path=2)
+    x0, v0 = torch.from_numpy(z["x0"]), torch.from_numpy(z["v0"])
+    energy = mo.SyntheticEnergy(x0.clone().cuda())
+    masses = torch.from_numpy(z["masses"])
+    outs = []
+    for sync_every in (1, 4):
+        for kw in (dict(), dict(random_velocs=True, resample_velocs=True)):
+            batch = single_state_batch("tiny", torch.from_numpy(z["atom_types"]), x0, v0)
+            torch.manual_seed(99)
+            outs.append(sample_with_model(batch, model, torch.device("cuda"), energy, masses, 120, accept=True,
+                                          num_proposal_steps=10, disable_tqdm=True, sync_every=sync_every, **kw))
+    for a, b in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert a[0].shape == b[0].shape and a[2] == b[2] and a[2] > 0
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        for f in ("acceptance_indicator", "acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin",
+                  "energies_pot_delta", "energies_kin_delta"):
+            assert np.array_equal(getattr(a[3], f), getattr(b[3], f)), f

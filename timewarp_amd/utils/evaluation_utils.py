@@ -10,7 +10,8 @@ return values.  Every numeric step of an iteration runs on the GPU through libti
     log p(x|y) of the reverse   tw_flow_log_likelihood        (model.log_likelihood)
     exponent, p_acc, u < p_acc, first accepted index          tw_mh_accept
 
-The host reads back 8 bytes per iteration (first accepted index, any-accepted flag); chain states
+The host reads back 8 bytes per iteration (first accepted index, any-accepted flag) - batched over
+`sync_every` iterations, the accept kernel moving the chain state on the device meanwhile; chain states
 and ChainStats stay on the device until the loop ends (the reference does >= 10 D2H copies per
 iteration).  Two redundancies of the reference are not reproduced because they cannot change the
 result: E_pot and E_kin of the current state are evaluated once instead of on S identical copies
@@ -128,7 +129,10 @@ class DeviceNoise:
         return q.to(torch.float32).to(self.device)
 
 
-def _mh_accept(energy, p_xy, p_yx, u):
+def _mh_accept(energy, p_xy, p_yx, u, y_c=None, y_v=None, x_c=None, x_v=None):
+    """tw_mh_accept.  With y_c/y_v [S,V,3] and x_c/x_v [1,V,3] the kernel also moves the chain state on the device
+    (x <- y[k] if any proposal was accepted), so the host does not have to look at the result before it queues the
+    next iteration."""
     S = energy.shape[0]
     dev = energy.device
     ex = torch.empty(S, dtype=torch.float32, device=dev)
@@ -136,9 +140,11 @@ def _mh_accept(energy, p_xy, p_yx, u):
     acc = torch.empty(S, dtype=torch.uint8, device=dev)
     res = torch.empty(4, dtype=torch.int32, device=dev)
     lib = _lib.load()
+    ptr = lambda t: None if t is None else t.data_ptr()
+    V = 0 if x_c is None else x_c.shape[-2]
     with torch.cuda.device(dev):
-        _lib.check(lib.tw_mh_accept(energy.data_ptr(), p_xy.data_ptr(), p_yx.data_ptr(), u.data_ptr(), None, None, None,
-                                    None, ex.data_ptr(), p_acc.data_ptr(), acc.data_ptr(), res.data_ptr(), S, 0,
+        _lib.check(lib.tw_mh_accept(energy.data_ptr(), p_xy.data_ptr(), p_yx.data_ptr(), u.data_ptr(), ptr(y_c), ptr(y_v),
+                                    ptr(x_c), ptr(x_v), ex.data_ptr(), p_acc.data_ptr(), acc.data_ptr(), res.data_ptr(), S, V,
                                     _lib.stream_ptr(dev)), "tw_mh_accept")
     return ex, p_acc, acc, res
 
@@ -179,6 +185,7 @@ class MetropolisHastingsChain:
         self.kbT = energy_fn.kbT
         self.chain_c, self.chain_v = [self.x_coords.clone()], [self.x_velocs.clone()]
         self.rec = {k: [] for k in self.KEYS}
+        self._pending = []
         self.accepted = 0
         self.proposals = 0
         self.p_bar = 1e-3  # start by proposing as many as possible
@@ -194,10 +201,10 @@ class MetropolisHastingsChain:
             atom_types=self.atom_types, x_coords=xc, x_velocs=xv, adj_list=self.adj_list, edge_batch_idx=self.ebi,
             masked_elements=self.masked, num_samples=S, z_coords=zc, z_velocs=zv)
 
-    def step(self, remaining: Optional[int] = None) -> int:
-        """One MH iteration; returns the number of chain states emitted (k + 1).  `remaining`
-        = num_samples - i applies the reference's clip `k = min(k, N - i)` (:680)."""
-        S, V, device = self.S, self.V, self.device
+    def _evaluate(self):
+        """Everything of one iteration up to the accept test: proposals, energies, both log-likelihoods.
+        Returns the (possibly resampled / rotated) current state and the per-proposal quantities."""
+        S, V = self.S, self.V
         model, noise, kbT = self.model, self.noise, self.kbT
         x_coords, x_velocs = self.x_coords, self.x_velocs
         if self.random_velocs and self.resample_velocs:
@@ -229,16 +236,35 @@ class MetropolisHastingsChain:
             edge_batch_idx=self.ebi, masked_elements=self.masked.expand(S, V))
         p_xy = p_xy.reshape(S).contiguous()
         self.proposals += S
+        return x_coords, x_velocs, y_c, y_v, energy, p_xy, p_yx, e_pot_y, e_kin_y, e_pot, e_kin
+
+    def _emit(self, k, old_c, old_v, new_c, new_v, ind, per_proposal):
+        """Chain rows of one iteration: k copies of the old state, then the new one; statistics rows 0..k."""
+        V = self.V
+        if k > 0:
+            self.chain_c.append(old_c.expand(k, V, 3))
+            self.chain_v.append(old_v.expand(k, V, 3))
+        self.chain_c.append(new_c)
+        self.chain_v.append(new_v)
+        self.rec["ind"].append(ind[: k + 1].bool())
+        for name, t in per_proposal:
+            self.rec[name].append(t[: k + 1])
+
+    def step(self, remaining: Optional[int] = None) -> int:
+        """One MH iteration; returns the number of chain states emitted (k + 1).  `remaining`
+        = num_samples - i applies the reference's clip `k = min(k, N - i)` (:680)."""
+        self.flush()
+        S, device = self.S, self.device
+        x_coords, x_velocs, y_c, y_v, energy, p_xy, p_yx, e_pot_y, e_kin_y, e_pot, e_kin = self._evaluate()
 
         if self.accept:
-            u = noise.uniform(S).to(device, torch.float32).contiguous()
+            u = self.noise.uniform(S).to(device, torch.float32).contiguous()
             ex, p_acc, acc, res = _mh_accept(energy, p_xy, p_yx, u)
             k_true, any_acc = (int(v) for v in res[:2].tolist())  # the one host sync of the iteration
             if any_acc:
                 self.accepted += 1
             k = k_true if remaining is None else min(k_true, remaining)  # NB: N - i, not N - i - 1
             moved = bool(any_acc) and k == k_true
-            self.rec["ind"].append(acc[: k + 1].bool())
             self.p_bar = self.smoothing * (1 - (not any_acc)) + (1 - self.smoothing) ** k * self.p_bar
             if self.adaptive:
                 self.S = compute_num_proposal_steps(self.p_bar, max_num_proposal_steps=self.s_max)
@@ -247,29 +273,61 @@ class MetropolisHastingsChain:
             p_acc = torch.clamp(torch.exp(-ex), max=1.0)
             k, moved = 0, True
             self.accepted += 1
-            self.rec["ind"].append(torch.ones(1, dtype=torch.bool, device=device))
+            acc = torch.ones(1, dtype=torch.bool, device=device)
         else:
             raise ValueError("Number of proposals has to be one if everything is accepted!")
 
         # emitted rows: k copies of the old state, then row k (the accepted proposal, if the chain moved)
-        new_c = y_c[k: k + 1] if moved else x_coords
-        new_v = y_v[k: k + 1] if moved else x_velocs
-        if k > 0:
-            self.chain_c.append(x_coords.expand(k, V, 3))
-            self.chain_v.append(x_velocs.expand(k, V, 3))
-        self.chain_c.append(new_c.clone())
-        self.chain_v.append(new_v.clone())
+        new_c = (y_c[k: k + 1] if moved else x_coords).clone()
+        new_v = (y_v[k: k + 1] if moved else x_velocs).clone()
+        self._emit(k, x_coords, x_velocs, new_c, new_v, acc,
+                   (("acc", p_acc), ("pxy", p_xy), ("pyx", p_yx), ("exp", ex), ("epot", e_pot_y), ("ekin", e_kin_y),
+                    ("dpot", e_pot), ("dkin", e_kin)))
         self.x_coords, self.x_velocs = new_c.contiguous(), new_v.contiguous()
-        for name, t in (("acc", p_acc), ("pxy", p_xy), ("pyx", p_yx), ("exp", ex), ("epot", e_pot_y), ("ekin", e_kin_y),
-                        ("dpot", e_pot), ("dkin", e_kin)):
-            self.rec[name].append(t[: k + 1])
         return k + 1
+
+    # ---- deferred bookkeeping: the accept kernel moves the state on the device, the host reads the results later
+    def can_defer(self) -> bool:
+        """Deferred iterations need the accept test, a fixed proposal count and no per-iteration host decision."""
+        return self.accept and not self.adaptive and not self.rotate
+
+    def step_deferred(self) -> None:
+        """One MH iteration without a host synchronisation: `tw_mh_accept` writes x <- y[k] itself and the
+        iteration's device tensors are parked until `flush()`.  Identical results to `step()` as long as the
+        clip `k = min(k, N - i)` cannot bind (the caller keeps N - i > S)."""
+        assert self.can_defer()
+        S, device = self.S, self.device
+        x_coords, x_velocs, y_c, y_v, energy, p_xy, p_yx, e_pot_y, e_kin_y, e_pot, e_kin = self._evaluate()
+        u = self.noise.uniform(S).to(device, torch.float32).contiguous()
+        new_c, new_v = x_coords.clone(), x_velocs.clone()  # becomes y[k] inside the kernel if a proposal is accepted
+        ex, p_acc, acc, res = _mh_accept(energy, p_xy, p_yx, u, y_c.contiguous(), y_v.contiguous(), new_c, new_v)
+        self._pending.append((res, x_coords, x_velocs, new_c, new_v, acc,
+                              (("acc", p_acc), ("pxy", p_xy), ("pyx", p_yx), ("exp", ex), ("epot", e_pot_y),
+                               ("ekin", e_kin_y), ("dpot", e_pot), ("dkin", e_kin))))
+        self.x_coords, self.x_velocs = new_c, new_v
+
+    def flush(self) -> int:
+        """Read back the parked iterations (one D2H copy for all of them) and do their bookkeeping; returns the
+        number of chain states they emitted."""
+        if not self._pending:
+            return 0
+        results = torch.stack([p[0] for p in self._pending]).cpu().tolist()
+        emitted = 0
+        for (k_true, any_acc, _, _), (_, old_c, old_v, new_c, new_v, acc, per_proposal) in zip(results, self._pending):
+            self.accepted += int(any_acc)
+            self.p_bar = self.smoothing * (1 - (not any_acc)) + (1 - self.smoothing) ** k_true * self.p_bar
+            self._emit(k_true, old_c, old_v, new_c, new_v, acc, per_proposal)
+            emitted += k_true + 1
+        self._pending = []
+        return emitted
 
     def trajectory(self):
         """Device tensors: coords [1+n,V,3], velocs [1+n,V,3]."""
+        self.flush()
         return torch.cat(self.chain_c, dim=0), torch.cat(self.chain_v, dim=0)
 
     def result(self):
+        self.flush()
         c, v = self.trajectory()
         stats = ChainStats(*[torch.cat(self.rec[k], dim=0).cpu().numpy() for k in self.KEYS])
         return c.cpu().numpy(), v.cpu().numpy(), self.accepted, stats
@@ -298,11 +356,13 @@ def sample_with_model(
     chirality_centers: Optional[torch.Tensor] = None,
     disable_tqdm: Optional[bool] = False,
     noise=None,
+    sync_every: int = 8,
 ):
     """Run one Markov chain of (at least) `num_samples` states.
 
     Arguments, semantics and returns follow the reference function; `noise` (extension) supplies
-    the random draws (default: the device generator).  Returns
+    the random draws (default: the device generator); `sync_every` (extension) is the number of iterations
+    queued per host synchronisation (1 = read the accept result every iteration).  Returns
     (sampled_coords [1+n,V,3] float32 numpy, sampled_velocs, accepted:int, ChainStats)."""
     if sim is not None and num_openmm_steps > 0 and (openmm_on_proposal or openmm_on_current):
         raise NotImplementedError("OpenMM integration steps inside the chain need OpenMM; outside this build's scope")
@@ -314,9 +374,18 @@ def sample_with_model(
     print("Sample with the model using Metropolis Hastings" if accept else "Sample with the model by accepting every setp")
     i = 0
     pbar = tqdm(total=num_samples, disable=disable_tqdm)
+    # Iterations are queued `sync_every` at a time without a host synchronisation while the clip k = min(k, N - i)
+    # cannot bind (every iteration emits at most S states); the tail runs one synchronous iteration at a time.
+    # Replayed noise (tests) is consumed exactly as recorded, so it always takes the synchronous path.
+    defer = sync_every > 1 and noise is None and chain.can_defer()
     with torch.no_grad():
         while i < num_samples:
-            n = chain.step(num_samples - i)
+            if defer and num_samples - i > sync_every * chain.S:
+                for _ in range(sync_every):
+                    chain.step_deferred()
+                n = chain.flush()
+            else:
+                n = chain.step(num_samples - i)
             i += n
             pbar.update(n)
     pbar.close()
