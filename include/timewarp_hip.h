@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 1
+#define TW_ABI_VERSION 2
 
 typedef enum {
   TW_OK = 0,
@@ -53,6 +53,10 @@ typedef struct {
   int32_t ignore_cond_velocity;
   int32_t normalise;    /* normalise_kernel_values */
   float ln_eps;         /* 1e-5 */
+  int32_t cheb_order;   /* kernel variant: 0 = Gaussian basis exp(-s^2) (attention_type "kernel"/"learnable_kernel");
+                           > 0 = attention_type "chebyshev_kernel": rational Chebyshev expansion of that order of s^2
+                           with per-layer coefficients (kernel_attention.py:12-66, 255-339); simple path only */
+  int32_t cheb_force_zero; /* force_asymptotic_zero: subtract each head's mean coefficient */
 } tw_flow_desc;
 
 const char* tw_last_error(void);
@@ -67,7 +71,8 @@ int tw_device_count(void);
  *   reverse passes - equal unless the lengthscales are learnable, see timewarp_amd/weights.py), prior log-scales[2],
  *   then for c in coupling layers, net in (scale, shift):  [dense: rff vectors[3,d_rff/2] once per c]
  *     in_mlp.0.{w[d_hidden,d_in],b}, in_mlp.2.{w[d_model,d_hidden],b},
- *     per layer: kernel: values_proj.w[H*d_model,d_model], out_projection.w[d_model,H*d_model]
+ *     per layer: kernel: values_proj.w[H*d_model,d_model], out_projection.w[d_model,H*d_model],
+ *                        [cheb_coeffs[H,cheb_order] when cheb_order > 0]
  *                dense : in_proj.{w[3d,d],b[3d]}, out_proj.{w[d,d],b[d]}
  *                linear1.{w,b}, linear2.{w,b}, norm1.{w,b}, norm2.{w,b}
  *     out_mlp.0.{w[d_hidden,d_model],b}, out_mlp.2.{w[3,d_hidden],b}
@@ -139,6 +144,15 @@ int tw_flow_sample_with_logp(const tw_flow_desc* desc, const float* raw, const f
 int tw_kernel_scores(const float* x_coords, const uint8_t* masked, const float* lengthscales,
                      int32_t n_heads, int64_t n_cond, int32_t n_atoms, int32_t normalise,
                      int32_t use_mm, float* out, void* stream);
+
+/* Same with the learnable rational-Chebyshev basis (chebyshev_basis_function / chebyshev_expansion,
+ * kernel_attention.py:12-66):  score = sum_c coeff[h,c] R_c(s^2),  R_0 = 1, R_1 = (x-1)/(x+1),
+ * R_{n+1} = 2 R_1 R_n - R_{n-1};  cheb_coeffs [n_heads, cheb_order];  force_zero subtracts each head's mean
+ * coefficient (force_asymptotic_zero). */
+int tw_kernel_scores_cheb(const float* x_coords, const uint8_t* masked, const float* lengthscales,
+                          const float* cheb_coeffs, int32_t cheb_order, int32_t force_zero, int32_t n_heads,
+                          int64_t n_cond, int32_t n_atoms, int32_t normalise, int32_t use_mm, float* out,
+                          void* stream);
 
 /* get_centre_of_mass (utils/molecule_utils.py:15-29): out_centred = x - masked mean,
  * out_com [n_rows,3] (either output may be NULL). */

@@ -42,7 +42,8 @@ class FlowSpec:
     use_displacement_as_target: bool = True
     ignore_conditional_velocity: bool = False
     normalise_kernel_values: bool = True
-    attention_type: str = "kernel"  # "kernel" | "learnable_kernel" (kernel_attention.py:159-252)
+    attention_type: str = "kernel"  # "kernel" | "learnable_kernel" | "chebyshev_kernel" (kernel_attention.py:159-339)
+    force_asymptotic_zero: bool = False  # chebyshev_kernel only
 
 
 # --------------------------------------------------------------------------------------
@@ -88,14 +89,31 @@ def cdist_mm(a: Tensor, b: Tensor) -> Tensor:
     return a_.matmul(b_.transpose(-1, -2)).clamp_min(0).sqrt()
 
 
-def kernel_scores(x_coords: Tensor, masked: Tensor, lengthscales: Tensor, normalise: bool = True) -> Tensor:
+def chebyshev_basis(scaled: Tensor, coeffs: Tensor, force_asymptotic_zero: bool) -> Tensor:
+    """kernel_attention.py:12-66: sum_c coeffs[h,c] R_c(scaled^2) with the rational Chebyshev functions
+    R_0 = 1, R_1 = (x-1)/(x+1), R_{n+1} = 2 R_1 R_n - R_{n-1};  coeffs [H, order], scaled [B,H,V,V]."""
+    if force_asymptotic_zero:
+        coeffs = coeffs - coeffs.mean(dim=1, keepdim=True)
+    x = scaled**2
+    order = coeffs.shape[1]
+    rf = (x - 1.0) / (x + 1.0)
+    terms = [torch.ones_like(x)]
+    if order >= 2:
+        terms.append(rf)
+    for _ in range(2, order):
+        terms.append(2.0 * rf * terms[-1] - terms[-2])
+    return torch.einsum("bhcqm,hc->bhqm", torch.stack(terms, dim=2), coeffs)
+
+
+def kernel_scores(x_coords: Tensor, masked: Tensor, lengthscales: Tensor, normalise: bool = True,
+                  cheb_coeffs: Optional[Tensor] = None, force_asymptotic_zero: bool = False) -> Tensor:
     """modules/layers/kernel_attention.py:69-121.
 
-    A[b,h,q,m] = exp(-(|x_q-x_m|/l_h)^2); masked keys -> 0; A /= sum_m |A| + 1e-5.
-    Returns [B,H,V,V]."""
+    A[b,h,q,m] = basis(|x_q-x_m|/l_h), basis(s) = exp(-s^2) or the Chebyshev expansion; masked keys -> 0;
+    A /= sum_m |A| + 1e-5.  Returns [B,H,V,V]."""
     dist = torch.cdist(x_coords, x_coords, compute_mode="use_mm_for_euclid_dist_if_necessary")
     scaled = dist.unsqueeze(-3).expand(-1, len(lengthscales), -1, -1) / lengthscales[None, :, None, None]
-    a = torch.exp(-(scaled**2))
+    a = torch.exp(-(scaled**2)) if cheb_coeffs is None else chebyshev_basis(scaled, cheb_coeffs, force_asymptotic_zero)
     a = a.masked_fill(masked[:, None, None, :], 0.0)
     if normalise:
         a = a / (torch.abs(a).sum(dim=-1, keepdim=True) + 1e-5)
@@ -137,15 +155,24 @@ def encoder_layer_tail(sd: StateDict, prefix: str, h: Tensor, attn_out: Tensor, 
 
 
 def kernel_netblock(
-    sd: StateDict, prefix: str, u: Tensor, scores: Tensor, spec: FlowSpec, trace: Optional[list] = None
+    sd: StateDict, prefix: str, u: Tensor, scores: Optional[Tensor], spec: FlowSpec, trace: Optional[list] = None,
+    positions: Optional[Tensor] = None, masked: Optional[Tensor] = None,
 ) -> Tensor:
-    """custom_transformer_block.py:46-82: in_mlp -> L encoder layers -> out_mlp."""
+    """custom_transformer_block.py:46-82: in_mlp -> L encoder layers -> out_mlp.  `scores` is the per-call matrix
+    (Gaussian bases); for chebyshev_kernel it is None and every layer computes its own from `positions`: there the
+    reference's cache key contains the per-layer basis-function closure (kernel_attention.py:329-333), so nothing
+    is shared between layers."""
     h = mlp(sd, f"{prefix}.in_mlp", u)
     if trace is not None:
         trace.append(("in_mlp", h))
     for l in range(spec.num_transformer_layers):
         p = f"{prefix}.encoder_layers.{l}"
-        a = kernel_self_attention(sd, f"{p}.self_attn", h, scores)
+        layer_scores = scores
+        if layer_scores is None:
+            att = f"{p}.self_attn.attention."
+            layer_scores = kernel_scores(positions, masked, sd[att + "lengthscales"], spec.normalise_kernel_values,
+                                         sd[att + "cheb_coeffs"], spec.force_asymptotic_zero)
+        a = kernel_self_attention(sd, f"{p}.self_attn", h, layer_scores)
         h = encoder_layer_tail(sd, p, h, a, spec.layer_norm_eps)
         if trace is not None:
             trace.append((f"enc{l}", h))
@@ -224,8 +251,8 @@ def scale_and_shift(
         parts.append(rff_encode(x_coords, sd[f"{pre}.position_encoder.gaussian_vectors"]))
     u = torch.cat(parts, dim=-1)
     if spec.variant == "kernel":
-        s = kernel_netblock(sd, f"{pre}.scale_transformer", u, scores, spec)
-        t = kernel_netblock(sd, f"{pre}.shift_transformer", u, scores, spec)
+        s = kernel_netblock(sd, f"{pre}.scale_transformer", u, scores, spec, positions=x_coords, masked=masked)
+        t = kernel_netblock(sd, f"{pre}.shift_transformer", u, scores, spec, positions=x_coords, masked=masked)
     else:
         s = dense_netblock(sd, f"{pre}.scale_transformer", u, masked, spec)
         t = dense_netblock(sd, f"{pre}.shift_transformer", u, masked, spec)
@@ -246,7 +273,7 @@ def flow_pass(
 ) -> Tuple[Tensor, Tensor, Tensor]:
     """flow.py:51-103 (layer order) + layers/nvp.py:22-183 (affine coupling + log-det)."""
     scores = None
-    if spec.variant == "kernel":
+    if spec.variant == "kernel" and spec.attention_type != "chebyshev_kernel":
         # one score matrix per flow call: the reference's Cache makes all 48 encoder layers
         # share it (model_constructor.py:192-195, flow.py:188,299).
         # The cache key ignores the lengthscales (keyword transform Returns(0)), so the scores are those of

@@ -93,10 +93,12 @@ def ad_topology():
     return torch.tensor(coords, dtype=torch.float32) * 0.1, torch.tensor(types, dtype=torch.int64)
 
 
-def kernel_model(emb, d_model, ff, mlp_hidden, n_coupling, n_layers, lengthscales, attention_type="kernel"):
+def kernel_model(emb, d_model, ff, mlp_hidden, n_coupling, n_layers, lengthscales, attention_type="kernel",
+                 cheb_order=None, force_asymptotic_zero=None):
     enc = CustomAttentionEncoderLayerConfig(
         d_model=d_model, dim_feedforward=ff, dropout=0.0, num_heads=len(lengthscales),
         attention_type=attention_type, lengthscales=list(lengthscales), normalise_kernel_values=True,
+        cheb_order=cheb_order, force_asymptotic_zero=force_asymptotic_zero,
     )
     cfg = CustomAttentionTransformerNVPConfig(
         atom_embedding_dim=emb, latent_mlp_hidden_dims=list(mlp_hidden), num_coupling_layers=n_coupling,
@@ -396,6 +398,34 @@ def gen_learnable_golden():
     print("kernel_learnable_tiny", {k: v.shape for k, v in d.items() if not k.startswith("sd::")})
 
 
+def gen_chebyshev_golden():
+    """Tiny chebyshev_kernel models (order 6, with and without force_asymptotic_zero), coefficients perturbed
+    differently in every attention layer: pins the basis, the per-layer scores and the coefficient centring."""
+    for tag, fz in (("kernel_cheb_tiny", False), ("kernel_cheb_zero_tiny", True)):
+        torch.manual_seed(815)
+        m = kernel_model(emb=4, d_model=8, ff=16, mlp_hidden=[8], n_coupling=2, n_layers=2, lengthscales=[0.1, 0.5, 1.2],
+                         attention_type="chebyshev_kernel", cheb_order=6, force_asymptotic_zero=fz)
+        g = torch.Generator().manual_seed(23)
+        with torch.no_grad():
+            m.coords_prior_log_scale.fill_(-0.3)
+            m.velocs_prior_log_scale.fill_(0.2)
+            # the reference builds cheb_coeffs from an expand()ed (stride-0) tensor, which cannot be written in place:
+            # give every attention module its own dense, perturbed coefficient matrix
+            for name, p_ in list(m.named_parameters()):
+                if name.endswith("cheb_coeffs"):
+                    p_.data = p_.detach().clone() + torch.randn(p_.shape, generator=g) * 0.05
+        at, x_c, x_v, mask, y_c, y_v = padded_batch(g, 3, 7, [7, 5, 6])
+        d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
+        d.update(run_case(m, at, x_c, x_v, mask, y_c, y_v, 0, 0))
+        d.update(np_sd(m.state_dict()))
+        at1, x1, v1, m1, yc1, yv1 = padded_batch(g, 1, 7, [5])
+        r = run_case(m, at1, x1, v1, m1, yc1, yv1, 4, 96)
+        d.update({"b1_" + k: v for k, v in base_inputs(at1, x1, v1, m1, yc1, yv1).items()})
+        d.update({"b1_" + k: v for k, v in r.items()})
+        np.savez_compressed(os.path.join(OUT, tag + ".npz"), **d)
+        print(tag, "ok")
+
+
 def tiny_kernel_model():
     torch.manual_seed(1234)
     tiny = kernel_model(emb=4, d_model=8, ff=16, mlp_hidden=[8], n_coupling=2, n_layers=2,
@@ -410,6 +440,10 @@ def main():
     if "--only-sob" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         gen_sob_golden(tiny_kernel_model())
+        return
+    if "--only-cheb" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        gen_chebyshev_golden()
         return
     if "--only-learnable" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
@@ -556,6 +590,7 @@ def main():
     gen_mh_goldens(tiny)
     gen_sob_golden(tiny)
     gen_learnable_golden()
+    gen_chebyshev_golden()
 
     # ---- (6) alanine-dipeptide topology as data (22 atoms) ---------------------------------------
     np.savez_compressed(os.path.join(OUT, "ad_topology.npz"), coords_nm=ad_x.numpy(), atom_types=ad_t.numpy(),

@@ -13,6 +13,10 @@ FULL_DENSE_SPEC = fo.FlowSpec(variant="dense", n_head=8)
 TINY_KERNEL_SPEC = fo.FlowSpec(variant="kernel", num_coupling_layers=2, num_transformer_layers=2)
 TINY_LEARNABLE_SPEC = fo.FlowSpec(variant="kernel", num_coupling_layers=2, num_transformer_layers=2,
                                   attention_type="learnable_kernel")
+TINY_CHEB_SPEC = fo.FlowSpec(variant="kernel", num_coupling_layers=2, num_transformer_layers=2,
+                             attention_type="chebyshev_kernel", force_asymptotic_zero=False)
+TINY_CHEB_ZERO_SPEC = fo.FlowSpec(variant="kernel", num_coupling_layers=2, num_transformer_layers=2,
+                                  attention_type="chebyshev_kernel", force_asymptotic_zero=True)
 TINY_DENSE_SPEC = fo.FlowSpec(variant="dense", num_coupling_layers=2, num_transformer_layers=2, n_head=2)
 
 
@@ -49,12 +53,14 @@ def rel_err(a, b):
 # product-side helpers (GPU tests)
 # ---------------------------------------------------------------------------------------------
 def tw_kernel_model(sd, emb=32, d_model=128, ff=2048, hidden=256, n_coupling=8, n_layers=3,
-                    lengthscales=(0.1, 0.2, 0.5, 0.7, 1.0, 1.2), path=0, device="cuda", attention_type="kernel"):
+                    lengthscales=(0.1, 0.2, 0.5, 0.7, 1.0, 1.2), path=0, device="cuda", attention_type="kernel",
+                    cheb_order=None, force_asymptotic_zero=None):
     import timewarp_amd as tw
 
     enc = tw.CustomAttentionEncoderLayerConfig(d_model=d_model, dim_feedforward=ff, dropout=0.0,
                                                num_heads=len(lengthscales), attention_type=attention_type,
-                                               lengthscales=list(lengthscales), normalise_kernel_values=True)
+                                               lengthscales=list(lengthscales), normalise_kernel_values=True,
+                                               cheb_order=cheb_order, force_asymptotic_zero=force_asymptotic_zero)
     cfg = tw.ModelConfig("custom_attention_transformer_nvp",
                          custom_transformer_nvp_config=tw.CustomAttentionTransformerNVPConfig(
                              emb, [hidden], n_coupling, n_layers, enc))

@@ -90,6 +90,37 @@ def test_full_learnable_lengthscales_fused(path):
     assert H.rel_err(ll.cpu(), ll_ref) < 1e-5
 
 
+@pytest.mark.parametrize("name,fz", [("kernel_cheb_tiny", False), ("kernel_cheb_zero_tiny", True)])
+def test_tiny_chebyshev_attention(name, fz):
+    """attention_type "chebyshev_kernel" (per-op path; the fused kernels decline it) against reference vectors."""
+    d, sd = H.load(name)
+    m = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2, lengthscales=(0.1, 0.5, 1.2),
+                          path=0, attention_type="chebyshev_kernel", cheb_order=6, force_asymptotic_zero=fz)
+    H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
+    H.assert_case_close(H.run_model_case(m, d, "b1_"), d, "b1_", tol=TOL)
+
+
+def test_chebyshev_scores_kernel_vs_oracle():
+    import ctypes as C
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    B, V, H_, order = 3, 22, 6, 9
+    x = torch.randn(B, V, 3, generator=g) * 0.4
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    mask[1, V - 3:] = True
+    ls = torch.tensor([0.1, 0.2, 0.5, 0.7, 1.0, 1.2])
+    coeffs = torch.randn(H_, order, generator=g) * 0.3
+    for fz in (False, True):
+        ref = fo.kernel_scores(x, mask, ls, True, coeffs, fz)
+        out = torch.empty(B, H_, V, V, device="cuda")
+        xd, md, ld, cd = x.cuda(), mask.to(torch.uint8).cuda(), ls.cuda(), coeffs.cuda()
+        _lib.check(lib.tw_kernel_scores_cheb(xd.data_ptr(), md.data_ptr(), ld.data_ptr(), cd.data_ptr(), order, int(fz), H_, B, V,
+                                             1, 0, out.data_ptr(), None), "tw_kernel_scores_cheb")
+        assert H.rel_err(out.cpu(), ref) < 1e-5
+
+
 def test_tiny_dense_simple_path():
     d, sd = H.load("dense_tiny")
     m = H.tw_dense_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2, n_head=2, rff_dim=4,

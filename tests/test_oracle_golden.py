@@ -52,6 +52,15 @@ def test_kernel_learnable_lengthscales():
     assert H.rel_err(yc[:, :, keep], g("s_y_coords")[:, :, keep]) > 1e-4
 
 
+@pytest.mark.parametrize("name,spec", [("kernel_cheb_tiny", H.TINY_CHEB_SPEC), ("kernel_cheb_zero_tiny", H.TINY_CHEB_ZERO_SPEC)])
+def test_kernel_chebyshev_attention(name, spec):
+    """attention_type "chebyshev_kernel": rational-Chebyshev basis with per-layer coefficients, scores recomputed
+    in every attention layer, optional coefficient centring (kernel_attention.py:12-66, 255-339)."""
+    d, sd = H.load(name)
+    _check_case(d, sd, spec)
+    _check_case(d, sd, spec, "b1_")
+
+
 def test_template_matches_reference_names():
     _, sd = H.load("kernel_tiny")
     t = fo.make_template(H.TINY_KERNEL_SPEC, atom_embedding_dim=4, d_model=8, dim_feedforward=16,

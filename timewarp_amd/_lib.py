@@ -38,6 +38,8 @@ class FlowDesc(C.Structure):
         ("ignore_cond_velocity", C.c_int32),
         ("normalise", C.c_int32),
         ("ln_eps", C.c_float),
+        ("cheb_order", C.c_int32),
+        ("cheb_force_zero", C.c_int32),
     ]
 
 
@@ -90,6 +92,7 @@ SIGNATURES = {
         [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I64, _P],
     ),
     "tw_kernel_scores": (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P]),
+    "tw_kernel_scores_cheb": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "tw_centre": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
     "tw_kinetic_energy": (C.c_int, [_P, _P, _I32, _F, _P, _I64, _I32, _P]),
     "tw_amber_energy": (C.c_int, [C.POINTER(ForceField), _P, _P, _P, _I64, _P]),
@@ -127,7 +130,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tw_abi_version() != 1:
+    if lib.tw_abi_version() != 2:
         raise RuntimeError("timewarp_amd: ABI version mismatch between _lib.py and libtimewarp_hip.so")
     _LIB = lib
     return lib

@@ -28,12 +28,13 @@ static int check_desc(const tw_flow_desc* d) {
              "non-positive dimension in tw_flow_desc");
   TW_REQUIRE(d->variant == 0 || d->d_model % d->n_heads == 0, "d_model %% n_heads != 0");
   TW_REQUIRE(d->d_rff >= 0 && d->d_rff % 2 == 0, "d_rff must be even");
+  TW_REQUIRE(d->cheb_order >= 0 && d->cheb_order <= 64 && (d->cheb_order == 0 || d->variant == 0), "bad cheb_order");
   return TW_OK;
 }
 
 static bool fused_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom g;
-  return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb % 4 == 0 &&
+  return d.variant == 0 && d.cheb_order == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb % 4 == 0 &&
          d.d_emb + 9 <= 48 && fused_geom(n_atoms, &g);
 }
 
@@ -235,6 +236,16 @@ int tw_kernel_scores(const float* x_coords, const uint8_t* masked, const float* 
   TW_REQUIRE((size_t)(3 * n_atoms + n_atoms * n_atoms) * 4 <= 64 * 1024, "n_atoms too large for the scores kernel");
   return launch_scores(x_coords, masked, lengthscales, n_heads, n_cond, n_atoms, normalise, use_mm, out,
                        (hipStream_t)stream);
+}
+
+int tw_kernel_scores_cheb(const float* x_coords, const uint8_t* masked, const float* lengthscales, const float* cheb_coeffs,
+                          int32_t cheb_order, int32_t force_zero, int32_t n_heads, int64_t n_cond, int32_t n_atoms,
+                          int32_t normalise, int32_t use_mm, float* out, void* stream) {
+  TW_REQUIRE(x_coords && masked && lengthscales && cheb_coeffs && out, "NULL pointer argument");
+  TW_REQUIRE(n_heads > 0 && n_cond >= 0 && n_atoms > 0 && cheb_order >= 1, "bad sizes");
+  TW_REQUIRE((size_t)(3 * n_atoms + n_atoms * n_atoms) * 4 <= 64 * 1024, "n_atoms too large for the scores kernel");
+  return launch_scores(x_coords, masked, lengthscales, n_heads, n_cond, n_atoms, normalise, use_mm, out,
+                       (hipStream_t)stream, cheb_coeffs, cheb_order, force_zero);
 }
 
 int tw_centre(const float* x_coords, const uint8_t* masked, float* out_centred, float* out_com, int64_t n_rows,

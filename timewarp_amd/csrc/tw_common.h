@@ -35,6 +35,7 @@ void set_error(const char* fmt, ...);
 // ------------------------------------------------------------------------------------------
 struct LayerOff {  // offsets relative to the start of one encoder layer
   int64_t wv, wo;                     // kernel: values_proj.w [H*d,d], out_projection.w [d,H*d]
+  int64_t cheb;                       // kernel with cheb_order > 0: cheb_coeffs [H, order] (else -1)
   int64_t in_w, in_b, out_w, out_b;   // dense : in_proj [3d,d],[3d]; out_proj [d,d],[d]
   int64_t w1, b1, w2, b2, n1w, n1b, n2w, n2b;
   int64_t size;
@@ -86,8 +87,10 @@ struct FusedGeom {
 bool fused_geom(int n_atoms, FusedGeom* g);
 
 // launchers implemented in the .hip files ----------------------------------------------------
+// coeffs == nullptr / order == 0: Gaussian basis; else rational-Chebyshev basis with coeffs [H, order]
 int launch_scores(const float* x, const uint8_t* masked, const float* ls, int H, int64_t B, int V,
-                  int normalise, int use_mm, float* out, hipStream_t s);
+                  int normalise, int use_mm, float* out, hipStream_t s, const float* coeffs = nullptr, int order = 0,
+                  int force_zero = 0);
 int launch_centre(const float* x, const uint8_t* masked, float* xc, float* com, int64_t n, int V,
                   hipStream_t s);
 

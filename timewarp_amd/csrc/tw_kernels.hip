@@ -30,9 +30,11 @@ RawLayout raw_layout(const tw_flow_desc& d) {
   LayerOff& y = L.layer;
   int64_t q = 0;
   y.wv = y.wo = y.in_w = y.in_b = y.out_w = y.out_b = -1;
+  y.cheb = -1;
   if (d.variant == 0) {
     y.wv = q; q += H * dm * dm;
     y.wo = q; q += dm * H * dm;
+    if (d.cheb_order > 0) { y.cheb = q; q += H * d.cheb_order; }
   } else {
     y.in_w = q; q += 3 * dm * dm;
     y.in_b = q; q += 3 * dm;
@@ -106,9 +108,27 @@ __device__ __forceinline__ float pair_distance(const float* x, int q, int m, int
   return sqrtf(fmaxf(acc, 0.f));
 }
 
+// basis value for scaled distance sc: Gaussian exp(-sc^2), or sum_c coeff[c] R_c(sc^2) with the three-term recursion
+// of chebyshev_expansion (kernel_attention.py:37-66), evaluated in the same order as the reference's stacked terms
+__device__ __forceinline__ float basis_value(float sc, const float* __restrict__ coeff, int order, float coeff_mean) {
+  if (order <= 0) return expf(-(sc * sc));
+  const float x = sc * sc;
+  const float rf = (x - 1.0f) / (x + 1.0f);
+  float rprev = 1.0f, rcur = rf;
+  float acc = (coeff[0] - coeff_mean) * rprev;
+  if (order >= 2) acc += (coeff[1] - coeff_mean) * rcur;
+  for (int c = 2; c < order; ++c) {
+    const float rnext = 2.0f * rf * rcur - rprev;
+    acc += (coeff[c] - coeff_mean) * rnext;
+    rprev = rcur;
+    rcur = rnext;
+  }
+  return acc;
+}
+
 __global__ void scores_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
                               const float* __restrict__ ls, int H, int V, int normalise, int use_mm,
-                              float* __restrict__ out) {
+                              float* __restrict__ out, const float* __restrict__ coeffs, int order, int force_zero) {
   extern __shared__ float sm[];
   float* xs = sm;            // [V*3]
   float* dist = sm + 3 * V;  // [V*V]
@@ -121,28 +141,34 @@ __global__ void scores_kernel(const float* __restrict__ x, const uint8_t* __rest
   for (int r = threadIdx.x; r < H * V; r += blockDim.x) {
     const int h = r / V, q = r % V;
     const float l = ls[h];
+    const float* cf = order > 0 ? coeffs + (int64_t)h * order : nullptr;
+    float cmean = 0.f;
+    if (order > 0 && force_zero) {
+      for (int c = 0; c < order; ++c) cmean += cf[c];
+      cmean /= (float)order;
+    }
     float sum = 0.f;
     for (int m = 0; m < V; ++m) {
       float sc = dist[q * V + m] / l;
-      float e = masked[b * V + m] ? 0.f : expf(-(sc * sc));
+      float e = masked[b * V + m] ? 0.f : basis_value(sc, cf, order, cmean);
       sum += fabsf(e);
     }
     const float denom = sum + 1e-5f;
     float* o = out + ((b * H + h) * V + q) * (int64_t)V;
     for (int m = 0; m < V; ++m) {
       float sc = dist[q * V + m] / l;
-      float e = masked[b * V + m] ? 0.f : expf(-(sc * sc));
+      float e = masked[b * V + m] ? 0.f : basis_value(sc, cf, order, cmean);
       o[m] = normalise ? e / denom : e;
     }
   }
 }
 
 int launch_scores(const float* x, const uint8_t* masked, const float* ls, int H, int64_t B, int V,
-                  int normalise, int use_mm, float* out, hipStream_t s) {
+                  int normalise, int use_mm, float* out, hipStream_t s, const float* coeffs, int order, int force_zero) {
   if (B == 0) return TW_OK;
   size_t shm = (size_t)(3 * V + V * V) * sizeof(float);
   hipLaunchKernelGGL(scores_kernel, dim3((unsigned)B), dim3(256), shm, s, x, masked, ls, H, V, normalise,
-                     use_mm, out);
+                     use_mm, out, coeffs, order, force_zero);
   TW_LAUNCH_CHECK();
   return TW_OK;
 }
@@ -580,6 +606,14 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
     const float* lb = nb + L.net.layers + (int64_t)l * L.layer.size;
     if (d.variant == 0) {
       const int HD = d.n_heads * d.d_model;
+      if (d.cheb_order > 0) {
+        // chebyshev_kernel: every attention layer owns its coefficients and the reference's score cache is keyed
+        // by the (per-layer) basis function, so the scores are recomputed for each layer (kernel_attention.py:329-333)
+        if ((rc = launch_scores(a.x_coords, a.masked, a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads,
+                                a.n_cond, a.n_atoms, d.normalise, a.n_atoms > 25, w.scores, s, lb + L.layer.cheb,
+                                d.cheb_order, d.cheb_force_zero)))
+          return rc;
+      }
       if ((rc = launch_linear(w.h, lb + L.layer.wv, nullptr, w.vals, M, HD, d.d_model, ACT_NONE, s))) return rc;
       hipLaunchKernelGGL(attend_kernel, dim3((unsigned)a.n_rows, d.n_heads), dim3(128), (size_t)V * V * 4, s, w.scores,
                          w.vals, w.att, a.n_cond, d.n_heads, V, d.d_model);
@@ -612,7 +646,7 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
 
 static int simple_scores(const FlowArgs& a, const RawLayout& L, const SimpleWs& w) {
   const tw_flow_desc& d = *a.desc;
-  if (d.variant != 0) return TW_OK;
+  if (d.variant != 0 || d.cheb_order > 0) return TW_OK;  // chebyshev_kernel: per layer, in netblock_simple
   // one score matrix per flow call, shared by every encoder layer (model_constructor.py:192-195)
   return launch_scores(a.x_coords, a.masked, a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, a.n_cond, a.n_atoms, d.normalise,
                        a.n_atoms > 25, w.scores, a.stream);

@@ -93,7 +93,7 @@ int64_t h3_packed_bytes(const tw_flow_desc& d) {
 
 bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom fg;
-  return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
+  return d.variant == 0 && d.cheb_order == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
          fused_geom(n_atoms, &fg) && fg.nt == H3_NT;
 }
 

@@ -46,8 +46,8 @@ def install(replace_energy: bool = True, replace_mh_loop: bool = True) -> dict:
         if getattr(config, "model_type", None) in _SUPPORTED:
             if config.model_type == "custom_attention_transformer_nvp":
                 enc = config.custom_transformer_nvp_config.encoder_layer_config
-                if getattr(enc, "attention_type", None) not in ("kernel", "learnable_kernel"):
-                    return original(config)  # chebyshev_kernel / local attention stay on the reference
+                if getattr(enc, "attention_type", None) not in ("kernel", "learnable_kernel", "chebyshev_kernel"):
+                    return original(config)  # local attention stays on the reference
             return _tw_model_constructor(config)
         return original(config)
 

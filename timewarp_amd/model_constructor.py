@@ -58,10 +58,16 @@ def custom_transformer_nvp_constructor(config, execution_path: int = _lib.TW_PAT
     assert pos_mod in (0, 1), "positions_layer_index can only be 0 or 1"
     enc = g(config, "encoder_layer_config")
     attention_type = g(enc, "attention_type")
-    if attention_type not in ("kernel", "learnable_kernel"):
+    if attention_type not in ("kernel", "learnable_kernel", "chebyshev_kernel"):
         raise NotImplementedError(
-            f"attention_type '{attention_type}' is outside the HIP hot path ('kernel', 'learnable_kernel')")
-    att_cls = L.KernelAttention if attention_type == "kernel" else L.LearnableLengthscaleKernelAttention
+            f"attention_type '{attention_type}' is outside the HIP hot path ('kernel', 'learnable_kernel', 'chebyshev_kernel')")
+    cheb_order, cheb_zero = 0, False
+    if attention_type == "chebyshev_kernel":
+        cheb_order = int(g(enc, "cheb_order"))
+        assert cheb_order >= 1
+        assert g(enc, "force_asymptotic_zero") is not None
+        cheb_zero = bool(g(enc, "force_asymptotic_zero"))
+    att_cls = {"kernel": L.KernelAttention, "learnable_kernel": L.LearnableLengthscaleKernelAttention}.get(attention_type)
     lengthscales = list(g(enc, "lengthscales"))
     assert len(lengthscales) > 0
     normalise = g(enc, "normalise_kernel_values")
@@ -75,8 +81,13 @@ def custom_transformer_nvp_constructor(config, execution_path: int = _lib.TW_PAT
     H = len(lengthscales)  # the number of heads is the number of lengthscales (custom_attention_encoder.py:165-168)
 
     def encoder_layer():
-        att = att_cls(value_dim=d_model, output_dim=d_model, lengthscales=lengthscales,
-                      normalise_kernel_values=bool(normalise))
+        if attention_type == "chebyshev_kernel":
+            att = L.LearnableChebyshevKernelAttention(
+                value_dim=d_model, output_dim=d_model, lengthscales=lengthscales, cheb_order=cheb_order,
+                normalise_kernel_values=bool(normalise), force_asymptotic_zero=cheb_zero)
+        else:
+            att = att_cls(value_dim=d_model, output_dim=d_model, lengthscales=lengthscales,
+                          normalise_kernel_values=bool(normalise))
         sa = L.KernelSelfAttention(input_dim=d_model, num_heads=H, value_dim=d_model, attention=att)
         return L.CustomTransformerEncoderLayer(d_model=d_model, self_attention=sa, dim_feedforward=d_ff)
 
@@ -90,7 +101,7 @@ def custom_transformer_nvp_constructor(config, execution_path: int = _lib.TW_PAT
     flow = L.ConditionalSequentialFlow(chain, nn.Embedding(len(ELEMENT_VOCAB), emb))
     srg, icv, disp = _density_flags(config)
     dims = FlowDims(KERNEL, n_coupling, n_layers, d_model, d_ff, hidden, emb, H, 0, len(ELEMENT_VOCAB), pos_mod,
-                    disp, icv, bool(normalise), 1e-5, learnable_lengthscales=attention_type == "learnable_kernel")
+                    disp, icv, bool(normalise), 1e-5, learnable_lengthscales=attention_type == "learnable_kernel", cheb_order=cheb_order, cheb_force_zero=cheb_zero)
     return ConditionalFlowDensityModel(flow, dims, scale_requires_grad=srg, execution_path=execution_path)
 
 

@@ -41,6 +41,8 @@ class FlowDims:
     normalise: bool = True
     ln_eps: float = 1e-5
     learnable_lengthscales: bool = False  # attention_type "learnable_kernel" (host-side only, see LENGTHSCALES)
+    cheb_order: int = 0                   # attention_type "chebyshev_kernel": order of the rational Chebyshev basis
+    cheb_force_zero: bool = False         # force_asymptotic_zero
 
     @property
     def d_in(self) -> int:
@@ -50,7 +52,7 @@ class FlowDims:
         return FlowDesc(
             self.variant, self.n_coupling, self.n_layers, self.d_model, self.d_ff, self.d_hidden, self.d_emb,
             self.n_heads, self.d_rff, self.n_elements, self.pos_mod2, int(self.displacement),
-            int(self.ignore_cond_velocity), int(self.normalise), self.ln_eps,
+            int(self.ignore_cond_velocity), int(self.normalise), self.ln_eps, self.cheb_order, int(self.cheb_force_zero),
         )
 
 
@@ -80,6 +82,8 @@ def raw_entries(d: FlowDims) -> List[Tuple[str, Tuple[int, ...]]]:
                         (f"{q}.self_attn.values_proj.weight", (H * dm, dm)),
                         (f"{q}.self_attn.attention._out_projection.weight", (dm, H * dm)),
                     ]
+                    if d.cheb_order > 0:
+                        out.append((f"{q}.self_attn.attention.cheb_coeffs", (H, d.cheb_order)))
                 else:
                     q = f"{p}.transformer.layers.{l}"
                     out += [
