@@ -882,6 +882,7 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    stamp(40 + 4 * l + 0);
     if constexpr (ASM) {
       // Hand-scheduled attention block (tools/gen_h3_attn_asm.py): all heads, mixing + Wc GEMM; reads the
       // transposed copy of x written above, returns y through the same wave-private LDS block.
@@ -901,6 +902,7 @@ netblock_h3_kernel(const H3Params p) {
       );
       pipe.cur = cur;
       pipe.gnext = gn;
+      stamp(40 + 4 * l + 1);
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
@@ -1010,6 +1012,7 @@ netblock_h3_kernel(const H3Params p) {
             *(h8*)(priv + ((ks * NT + jt) * 2) * 1024 + lane * 16) = xb[ks].h[jt];
             *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = xb[ks].l[jt];
           }
+        stamp(40 + 4 * l + 2);
         int cur = __builtin_amdgcn_readfirstlane(pipe.cur);
         const char* gn = pipe.gnext;
         const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
@@ -1024,6 +1027,7 @@ netblock_h3_kernel(const H3Params p) {
         );
         pipe.cur = cur;
         pipe.gnext = gn;
+        stamp(40 + 4 * l + 3);
 #pragma unroll
         for (int ot = 0; ot < 8; ++ot)
 #pragma unroll

@@ -10,24 +10,28 @@ the stage barrier sits in the middle of a stage, so the next stage's first tiles
 MFMAs before they are needed.
 
 Register map (all private to the asm statement, listed as clobbers):
-  v0..v95     xb[ks][jt] = {h: v[8(3ks+jt)..+3], l: +4..+7}   B operand of W1 (split x), loaded from LDS
+  v0..v71     xb[ks][jt] = {h, l} for k-steps 0..2, a96..a119 for k-step 3: B operand of W1 (split x) from LDS
   v96..v127   weight tile slots p=0..3: hi v[96+8p..+3], lo v[100+8p..+3]
   v128..v175  hb[buf][jt] = {h: v[128+24buf+8jt..+3], l: +4..+7}  split hidden activations (double buffer)
   v176..v183  bias[o][r];  v184 scale;  v186..v193 epilogue temporaries
   v194 tile LDS address, v195 aux address, v196 scale address, v198:199 DMA source, v200:201 temp,
   v202 lane*16, v203 (lane>>4)*16
-  a0..a95     yacc[ot][jt] (4 each);  a96..a119 hacc[o][jt]
+  a0..a95     yacc[ot][jt] (4 each);  v72..v95 hacc[o][jt] (VGPRs: read by the epilogue directly);  s95 scale
 Stage order (must match h3_pack_weights):  A0(0) A1(0) | A0(c+1) A1(c+1) B0(c) B1(c) ... | B0(n-1) B1(n-1)."""
 import sys
 
 NT = 3
-XB = lambda ks, jt, part: 8 * (3 * ks + jt) + (0 if part == "h" else 4)
+# xb[ks][jt]: k-steps 0..2 in VGPRs v0..v71, k-step 3 in AGPRs a96..a119 (MFMA B operands may be AGPRs; this makes
+# room for the hidden accumulators in v72..v95 without asking the compiler for more registers)
+XB = lambda ks, jt, part: (8 * (3 * ks + jt) if ks < 3 else 96 + 8 * jt) + (0 if part == "h" else 4)
+XB_SRC = lambda ks: "v" if ks < 3 else "a"
 SLOT = lambda p, part: 96 + 8 * p + (0 if part == "h" else 4)
 HB = lambda buf, jt, part: 128 + 24 * buf + 8 * jt + (0 if part == "h" else 4)
 BIAS = lambda o: 176 + 4 * o
 V_SC, V_T, V_TILE, V_AUX, V_SCADDR, V_GN, V_TMP, V_LANE16, V_G16 = 184, 186, 194, 195, 196, 198, 200, 202, 203  # tuples even-aligned
 YACC = lambda ot, jt: 4 * (3 * ot + jt)
-HACC = lambda o, jt: 96 + 4 * (3 * o + jt)
+HACC = lambda o, jt: 72 + 4 * (3 * o + jt)   # VGPRs: the epilogue reads them without a v_accvgpr_read
+S_SC = 95
 # scratch SGPRs (clobbered)
 S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT = 84, 85, 86, 88, 90, 92, 94  # pairs are even-aligned
 STAGE, TILES = 9216, 8192
@@ -41,24 +45,26 @@ def ar(base, n=4):
     return f"a[{base}:{base + n - 1}]"
 
 
-def mfma(d, a, b, zero=False):
-    return f"v_mfma_f32_16x16x32_f16 {ar(d)}, {vr(a)}, {vr(b)}, {'0' if zero else ar(d)}"
+def mfma(d, a, b, zero=False, dst="a", bsrc="v"):
+    dd = ar(d) if dst == "a" else vr(d)
+    bb = ar(b) if bsrc == "a" else vr(b)
+    return f"v_mfma_f32_16x16x32_f16 {dd}, {vr(a)}, {bb}, {'0' if zero else dd}"
 
 
-def pair_mfmas(acc_of_jt, slot, bop_of_jt, first=False):
+def pair_mfmas(acc_of_jt, slot, bop_of_jt, first=False, dst="a", bsrc="v"):
     """9 MFMAs of one tile pair: hi x B.h, hi x B.l, lo x B.h for the three token tiles."""
     out = []
     for a_part, b_part, z in (("h", "h", first), ("h", "l", False), ("l", "h", False)):
         for jt in range(NT):
-            out.append(mfma(acc_of_jt(jt), SLOT(slot, a_part), bop_of_jt(jt, b_part), zero=z))
+            out.append(mfma(acc_of_jt(jt), SLOT(slot, a_part), bop_of_jt(jt, b_part), zero=z, dst=dst, bsrc=bsrc))
     return out
 
 
 def epi_unit(o, jt, buf, relu=True):
-    """hacc[o][jt] -> dwords 2o, 2o+1 of hb[buf].h[jt] / .l[jt]: 20 VALU ops."""
+    """hacc[o][jt] -> dwords 2o, 2o+1 of hb[buf].h[jt] / .l[jt]: 16 VALU ops (the hidden pre-activations
+    accumulate in VGPRs and the scale sits in an SGPR: every VALU op costs register-file cycles the MFMAs need)."""
     t = [V_T + i for i in range(4)] if (o * NT + jt) % 2 == 0 else [V_T + 4 + i for i in range(4)]
-    ops = [f"v_accvgpr_read_b32 v{t[r]}, a{HACC(o, jt) + r}" for r in range(4)]
-    ops += [f"v_fma_f32 v{t[r]}, v{t[r]}, v{V_SC}, v{BIAS(o) + r}" for r in range(4)]
+    ops = [f"v_fma_f32 v{t[r]}, v{HACC(o, jt) + r}, s{S_SC}, v{BIAS(o) + r}" for r in range(4)]
     ops += [f"v_max_f32 v{t[r]}, v{t[r]}, 0" for r in range(4)]
     hh = HB(buf, jt, "h") + 2 * o
     ll = HB(buf, jt, "l") + 2 * o
@@ -142,7 +148,7 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     for p in range(4):
         if kind == "A":
             o = o_or_b
-            groups.append(pair_mfmas(lambda jt: HACC(o, jt), p, lambda jt, part: XB(p, jt, part), first=(p == 0)))
+            groups.append(pair_mfmas(lambda jt: HACC(o, jt), p, lambda jt, part: XB(p, jt, part), first=(p == 0), dst="v", bsrc=XB_SRC(p)))
         else:
             b = o_or_b
             groups.append(pair_mfmas(lambda jt: YACC(4 * b + p, jt), p, lambda jt, part: HB(hb_cur, jt, part)))
@@ -163,7 +169,10 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     out += weave(groups[1], parts[1], tile_reads(3))
     out.append("s_waitcnt vmcnt(6) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
     out.append("s_barrier")
-    out += weave(groups[2], parts[2], handoff(next_reads, with_aux, label), misc_per=3)
+    h = handoff(next_reads, with_aux, label)
+    if is_a0:
+        h = [f"v_readfirstlane_b32 s{S_SC}, v{V_SC}"] + h   # aux block landed (lgkmcnt(0) above)
+    out += weave(groups[2], parts[2], h, misc_per=3)
     out += weave(groups[3], parts[3], [])
     return out
 
@@ -192,7 +201,8 @@ def generate():
     # xb from the wave-private LDS block
     A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
     for i in range(24):
-        A(f"ds_read_b128 {vr(4 * i)}, v{V_TMP} offset:{1024 * i}")
+        dst = vr(4 * i) if i < 18 else ar(96 + 4 * (i - 18))
+        A(f"ds_read_b128 {dst}, v{V_TMP} offset:{1024 * i}")
     for i in range(96):
         A(f"v_accvgpr_write_b32 a{i}, 0")
     A("s_waitcnt lgkmcnt(0)")

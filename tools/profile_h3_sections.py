@@ -21,7 +21,7 @@ _lib.load().tw_debug_set_flags(16 | extra)
 for rep in range(3):
     acts, out = m.debug_netblock(0, 0, at.cuda(), xc.cuda(), x_v.cuda(), mask.cuda(), zo.cuda(), 3)
 torch.cuda.synchronize()
-ts = acts.reshape(-1)[:64].contiguous().view(torch.int64).cpu().tolist()
+ts = acts.reshape(-1)[:128].contiguous().view(torch.int64).cpu().tolist()
 L = 3
 names = ["start", "in_mlp"]
 for l in range(L):
@@ -37,3 +37,12 @@ for i in range(1, len(names)):
     agg[key] = agg.get(key, 0) + d
     print(f"  {names[i]:16s} {d:9d}  {100.0 * d / total:5.1f} %")
 print({k: f"{100.0 * v / total:.1f}%" for k, v in agg.items()})
+
+# finer split of one layer (asm build only): glue code around the two asm blocks
+l = 1
+a0, a1, f0, f1 = ts[40 + 4 * l: 44 + 4 * l]
+if a0 and a1 > a0:
+    prev = t[1 + 4 * l]            # end of layer l-1 (or in_mlp)
+    print(f"layer {l}: x^T write {a0 - prev}, attention asm {a1 - a0}, y readback+scale {t[2 + 4 * l] - a1}, "
+          f"LN1 {t[3 + 4 * l] - t[2 + 4 * l]}, split+xb write {f0 - t[3 + 4 * l]}, FFN asm {f1 - f0}, "
+          f"y readback+bias {t[4 + 4 * l] - f1}, LN2 {t[5 + 4 * l] - t[4 + 4 * l]}")
