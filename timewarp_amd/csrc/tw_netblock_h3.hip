@@ -844,7 +844,37 @@ netblock_h3_kernel(const H3Params p) {
     for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) x[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
-    h3_mlp_chain<NT, 2, 8, true>(u, x, pipe, p.hid_chunks, lane);
+    if constexpr (ASM) {
+      // generated asm (tools/gen_h3_ffn_asm.py --shape=in): u in, x out through the wave-private LDS block
+      char* priv = (char*)xt_hi;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          *(h8*)(priv + ((ks * NT + jt) * 2) * 1024 + lane * 16) = u[ks].h[jt];
+          *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = u[ks].l[jt];
+        }
+      int cur = __builtin_amdgcn_readfirstlane(pipe.cur);
+      const char* gn = pipe.gnext;
+      const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+      const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
+      const int chunks = __builtin_amdgcn_readfirstlane(p.hid_chunks);
+      asm volatile(
+#include "tw_h3_in_asm.inc"
+          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+          :
+#include "tw_h3_in_clobbers.inc"
+      );
+      pipe.cur = cur;
+      pipe.gnext = gn;
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) x[ot][jt] = *(const f4*)(priv + (ot * NT + jt) * 1024 + lane * 16);
+    } else {
+      h3_mlp_chain<NT, 2, 8, true>(u, x, pipe, p.hid_chunks, lane);
+    }
     const float sc = h3_load_f1(scales + 1);
     f4 bb[8];
     h3_load8_f4(side + p.side_in2b + 4 * g, bb);
@@ -1057,7 +1087,35 @@ netblock_h3_kernel(const H3Params p) {
     to_bop<NT, 4>(x, xb);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) o[0][jt] = (f4){0.f, 0.f, 0.f, 0.f};
-    h3_mlp_chain<NT, 4, 1, true>(xb, o, pipe, p.hid_chunks, lane);
+    if constexpr (ASM) {
+      // generated asm (tools/gen_h3_ffn_asm.py --shape=out)
+      char* priv = (char*)xt_hi;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          *(h8*)(priv + ((ks * NT + jt) * 2) * 1024 + lane * 16) = xb[ks].h[jt];
+          *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = xb[ks].l[jt];
+        }
+      int cur = __builtin_amdgcn_readfirstlane(pipe.cur);
+      const char* gn = pipe.gnext;
+      const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+      const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
+      const int chunks = __builtin_amdgcn_readfirstlane(p.hid_chunks);
+      asm volatile(
+#include "tw_h3_out_asm.inc"
+          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+          :
+#include "tw_h3_out_clobbers.inc"
+      );
+      pipe.cur = cur;
+      pipe.gnext = gn;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) o[0][jt] = *(const f4*)(priv + jt * 1024 + lane * 16);
+    } else {
+      h3_mlp_chain<NT, 4, 1, true>(xb, o, pipe, p.hid_chunks, lane);
+    }
     const float sc = h3_load_f1(scales + 2 + 3 * p.n_layers + 1);
     const f4 bb = h3_load_f4(side + p.side_out2b + 4 * g);
 #pragma unroll

@@ -21,6 +21,16 @@ Stage order (must match h3_pack_weights):  A0(0) A1(0) | A0(c+1) A1(c+1) B0(c) B
 import sys
 
 NT = 3
+# Shapes of the three chunked MLPs (same schedule, one generated file each):
+#   ffn : 128 -> 32-unit chunk (ReLU) -> 128     A = 2 stages (o = 0, 1; 4 k-steps),  B = 2 stages (ot 0-3, 4-7)
+#   in  :  64 -> 32-unit chunk (SiLU) -> 128     A = 1 stage  (pairs = o x 2 k-steps), B = 2 stages
+#   out : 128 -> 32-unit chunk (SiLU) ->  16     A = 2 stages,                         B = 1 stage with one tile pair
+SHAPES = {
+    "ffn": dict(ks_in=4, ot_out=8, silu=False, tag="ffn"),
+    "in": dict(ks_in=2, ot_out=8, silu=True, tag="in"),
+    "out": dict(ks_in=4, ot_out=1, silu=True, tag="out"),
+}
+SHAPE = SHAPES["ffn"]
 # xb[ks][jt]: k-steps 0..2 in VGPRs v0..v71, k-step 3 in AGPRs a96..a119 (MFMA B operands may be AGPRs; this makes
 # room for the hidden accumulators in v72..v95 without asking the compiler for more registers)
 XB = lambda ks, jt, part: (8 * (3 * ks + jt) if ks < 3 else 96 + 8 * jt) + (0 if part == "h" else 4)
@@ -28,6 +38,7 @@ XB_SRC = lambda ks: "v" if ks < 3 else "a"
 SLOT = lambda p, part: 96 + 8 * p + (0 if part == "h" else 4)
 HB = lambda buf, jt, part: 128 + 24 * buf + 8 * jt + (0 if part == "h" else 4)
 BIAS = lambda o: 176 + 4 * o
+V_U = 204  # SiLU temporaries v204..v207 (clobbered only by the shapes that use SiLU)
 V_SC, V_T, V_TILE, V_AUX, V_SCADDR, V_GN, V_TMP, V_LANE16, V_G16 = 184, 186, 194, 195, 196, 198, 200, 202, 203  # tuples even-aligned
 YACC = lambda ot, jt: 4 * (3 * ot + jt)
 HACC = lambda o, jt: 72 + 4 * (3 * o + jt)   # VGPRs: the epilogue reads them without a v_accvgpr_read
@@ -65,7 +76,16 @@ def epi_unit(o, jt, buf, relu=True):
     accumulate in VGPRs and the scale sits in an SGPR: every VALU op costs register-file cycles the MFMAs need)."""
     t = [V_T + i for i in range(4)] if (o * NT + jt) % 2 == 0 else [V_T + 4 + i for i in range(4)]
     ops = [f"v_fma_f32 v{t[r]}, v{HACC(o, jt) + r}, s{S_SC}, v{BIAS(o) + r}" for r in range(4)]
-    ops += [f"v_max_f32 v{t[r]}, v{t[r]}, 0" for r in range(4)]
+    if SHAPE["silu"]:
+        # v * 1 / (1 + 2^(-v log2 e)) with the hardware exp2 / rcp
+        u = [V_U + r for r in range(4)]
+        ops += [f"v_mul_f32 v{u[r]}, 0xbfb8aa3b, v{t[r]}" for r in range(4)]
+        ops += [f"v_exp_f32 v{u[r]}, v{u[r]}" for r in range(4)]
+        ops += [f"v_add_f32 v{u[r]}, 1.0, v{u[r]}" for r in range(4)]
+        ops += [f"v_rcp_f32 v{u[r]}, v{u[r]}" for r in range(4)]
+        ops += [f"v_mul_f32 v{t[r]}, v{t[r]}, v{u[r]}" for r in range(4)]
+    else:
+        ops += [f"v_max_f32 v{t[r]}, v{t[r]}, 0" for r in range(4)]
     hh = HB(buf, jt, "h") + 2 * o
     ll = HB(buf, jt, "l") + 2 * o
     ops += [f"v_cvt_pk_f16_f32 v{hh}, v{t[0]}, v{t[1]}", f"v_cvt_pk_f16_f32 v{hh + 1}, v{t[2]}, v{t[3]}"]
@@ -110,12 +130,12 @@ def handoff(next_reads, with_aux, label):
     ]
     if with_aux:
         h += [["s_cmp_lg_u32 %[wave], 0",
-               f"s_cbranch_scc1 .Lh3ffn_noaux_{label}_%=",
+               f"s_cbranch_scc1 .Lh3mlp_noaux_{label}_%=",
                f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
                f"s_add_u32 m0, s{S_REL}, {TILES}",
                "s_nop 0",
                f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off",
-               f".Lh3ffn_noaux_{label}_%=:"]]
+               f".Lh3mlp_noaux_{label}_%=:"]]
     h += [f"v_lshl_add_u64 {vr(V_GN, 2)}, {vr(V_GN, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]"]
     return h
 
@@ -143,15 +163,22 @@ def weave(mfmas, valu, misc, valu_per=2, misc_per=2):
 
 
 def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
-    """One 4-pair stage.  kind 'A': hacc[o] += W1tile(ks) . xb[ks];  kind 'B': yacc[4b+oo] += W2tile . hb."""
+    """One 4-pair stage.  kind 'A': hacc[o] += W1tile . xb[ks] (ks_in = 4: stage = one o, pairs = k-steps; ks_in = 2:
+    the single A stage holds both o, pair = 2 o + ks);  kind 'B': yacc[4b+p] += W2tile(p) . hb (pairs beyond ot_out
+    do not exist: no MFMAs, no tile reads)."""
+    ks_in, ot_out = SHAPE["ks_in"], SHAPE["ot_out"]
     groups = []
     for p in range(4):
         if kind == "A":
-            o = o_or_b
-            groups.append(pair_mfmas(lambda jt: HACC(o, jt), p, lambda jt, part: XB(p, jt, part), first=(p == 0), dst="v", bsrc=XB_SRC(p)))
+            o, ks = (o_or_b, p) if ks_in == 4 else (p // 2, p % 2)
+            groups.append(pair_mfmas(lambda jt: HACC(o, jt), p, lambda jt, part: XB(ks, jt, part), first=(ks == 0), dst="v", bsrc=XB_SRC(ks)))
         else:
             b = o_or_b
-            groups.append(pair_mfmas(lambda jt: YACC(4 * b + p, jt), p, lambda jt, part: HB(hb_cur, jt, part)))
+            if 4 * b + p < ot_out:
+                groups.append(pair_mfmas(lambda jt: YACC(4 * b + p, jt), p, lambda jt, part: HB(hb_cur, jt, part)))
+            else:
+                groups.append([])
+    live = [bool(g) for g in groups]
     aux = 3 if is_a0 else 0
     epi = list(epi_ops)
     share = -(-len(epi) // 4)
@@ -159,14 +186,14 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     out = []
     # outstanding LDS reads at entry: p0.hi p0.lo p1.hi p1.lo (+3 aux)
     out.append("s_waitcnt lgkmcnt(2)")
-    first_misc = tile_reads(2)
+    first_misc = tile_reads(2) if live[2] else []
     if is_a0:
         # bias / scale of this chunk: read here (not at the previous hand-off) so the previous chunk's epilogue,
         # still running in the stage before, keeps its values
         first_misc = [f"v_add_u32 v{V_AUX}, s{S_OFF}, v{V_G16}", f"v_mov_b32 v{V_SCADDR}, s{S_OFF}"] + aux_reads() + first_misc
     out += weave(groups[0], parts[0], first_misc, misc_per=3)
     out.append(f"s_waitcnt lgkmcnt({2 + aux})" if aux else "s_waitcnt lgkmcnt(2)")
-    out += weave(groups[1], parts[1], tile_reads(3))
+    out += weave(groups[1], parts[1], tile_reads(3) if live[3] else [])
     out.append("s_waitcnt vmcnt(6) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
     out.append("s_barrier")
     h = handoff(next_reads, with_aux, label)
@@ -198,57 +225,73 @@ def generate():
     A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
     A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
     A(f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}")
-    # xb from the wave-private LDS block
+    ks_in, ot_out = SHAPE["ks_in"], SHAPE["ot_out"]
+    ffn = SHAPE["tag"] == "ffn"
+    n_a, n_b = (2 if ks_in == 4 else 1), (ot_out + 3) // 4
+    # input operand (split activations) from the wave-private LDS block: 2 images per (ks, jt)
     A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-    for i in range(24):
+    for i in range(2 * NT * ks_in):
         dst = vr(4 * i) if i < 18 else ar(96 + 4 * (i - 18))
         A(f"ds_read_b128 {dst}, v{V_TMP} offset:{1024 * i}")
-    for i in range(96):
+    for i in range(4 * NT * ot_out):
         A(f"v_accvgpr_write_b32 a{i}, 0")
     A("s_waitcnt lgkmcnt(0)")
     # first stage's reads
     for r in tile_reads(0) + tile_reads(1):
         A(r)
-    # ---- prologue: A0(0) A1(0), epilogue of chunk 0 (not hidden)
-    L += stage("A", 0, 0, [], True, True, "p0", True)
-    L += stage("A", 1, 0, [], True, True, "p1", False)
+
+    def a_stages(buf, tag, aux_of):
+        out = []
+        for o in range(n_a):
+            out += stage("A", o, buf, [], True, aux_of("A", o), f"{tag}a{o}", o == 0)
+        return out
+
+    def b_stages(buf, tag, epi, aux_of, last=False):
+        out = []
+        per = -(-len(epi) // n_b)
+        for b_ in range(n_b):
+            out += stage("B", b_, buf, epi[b_ * per:(b_ + 1) * per], not (last and b_ == n_b - 1), aux_of("B", b_),
+                         f"{tag}b{b_}", False)
+        return out
+
+    always = lambda kind, idx: True
+    # FFN steady state: the stage fetched by a hand-off is 5 ahead = the kind after this one; only A0 stages carry a
+    # bias/scale block, so B1 fetches one.  A1 keeps the aux DMA as well: in the last trips its hand-off fetches the
+    # first stage AFTER the FFN (an A0 of out_mlp in the last layer).  The short in/out MLPs always move it.
+    steady = (lambda kind, idx: (kind, idx) in (("A", 1), ("B", 1))) if ffn else always
+
+    # ---- prologue: A(0), epilogue of chunk 0 (not hidden)
+    L += a_stages(0, "p", always)
     A("s_nop 7")
     for o in range(2):
         for jt in range(NT):
             L += epi_unit(o, jt, 0)
     A(f"s_sub_u32 s{S_CNT}, %[chunks], 1")
     A(f"s_cmp_eq_u32 s{S_CNT}, 0")
-    A("s_cbranch_scc1 .Lh3ffn_tail_%=")
+    A("s_cbranch_scc1 .Lh3mlp_tail_%=")
     # ---- steady state, two chunks per loop trip so the hb double buffer alternates statically
-    #      trip: A(c+1) B(c)[epi c+1 -> buf1]  A(c+2) B(c+1)[epi c+2 -> buf0]; needs (chunks-1) even -> handled below
-    A(".Lh3ffn_loop_%=:")
+    #      trip: A(c+1) B(c)[epi c+1 -> buf1]  A(c+2) B(c+1)[epi c+2 -> buf0]
+    A(".Lh3mlp_loop_%=:")
     for half, (cur_buf, nxt_buf) in enumerate(((0, 1), (1, 0))):
         epi = []
         for o in range(2):
             for jt in range(NT):
                 epi += epi_unit(o, jt, nxt_buf)
-        # in the steady state the stage fetched by a hand-off is 5 ahead = the kind after this one; only A0 stages
-        # carry a bias/scale block, so B1 fetches one.  A1 keeps the aux DMA as well: in the last trips its
-        # hand-off fetches the first stage AFTER the FFN (an A0 of out_mlp in the last layer).
-        L += stage("A", 0, cur_buf, [], True, False, f"l{half}a0", True)
-        L += stage("A", 1, cur_buf, [], True, True, f"l{half}a1", False)
-        L += stage("B", 0, cur_buf, epi[:60], True, False, f"l{half}b0", False)
-        L += stage("B", 1, cur_buf, epi[60:], True, True, f"l{half}b1", False)
+        L += a_stages(cur_buf, f"l{half}", steady)
+        L += b_stages(cur_buf, f"l{half}", epi, steady)
         A(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
         A(f"s_cmp_eq_u32 s{S_CNT}, 0")
         if half == 0:
-            A("s_cbranch_scc1 .Lh3ffn_tail1_%=")
+            A("s_cbranch_scc1 .Lh3mlp_tail1_%=")
         else:
-            A("s_cbranch_scc0 .Lh3ffn_loop_%=")
+            A("s_cbranch_scc0 .Lh3mlp_loop_%=")
     # ---- tails: last chunk's B stages (hb in buf0 after an even number of loop halves, buf1 after odd)
-    A(".Lh3ffn_tail_%=:")
-    L += stage("B", 0, 0, [], True, True, "t0b0", False)
-    L += stage("B", 1, 0, [], False, True, "t0b1", False)
-    A("s_branch .Lh3ffn_done_%=")
-    A(".Lh3ffn_tail1_%=:")
-    L += stage("B", 0, 1, [], True, True, "t1b0", False)
-    L += stage("B", 1, 1, [], False, True, "t1b1", False)
-    A(".Lh3ffn_done_%=:")
+    A(".Lh3mlp_tail_%=:")
+    L += b_stages(0, "t0", [], always, last=True)
+    A("s_branch .Lh3mlp_done_%=")
+    A(".Lh3mlp_tail1_%=:")
+    L += b_stages(1, "t1", [], always, last=True)
+    A(".Lh3mlp_done_%=:")
     # ring slot index back to the caller: cur = (S_OFF - ring) / STAGE, 0..4
     A(f"s_sub_u32 s{S_REL}, s{S_OFF}, %[ring]")
     A("s_mov_b32 %[cur], 0")
@@ -259,7 +302,7 @@ def generate():
     A("s_nop 15")
     A("s_nop 15")
     A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-    for i in range(24):
+    for i in range(NT * ot_out):
         for r in range(4):
             A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
         A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
@@ -272,20 +315,28 @@ def generate():
 
 
 def main():
+    global SHAPE
+    shape = "ffn"
+    for a in sys.argv[1:]:
+        if a.startswith("--shape="):
+            shape = a.split("=", 1)[1]
+    SHAPE = SHAPES[shape]
     lines = generate()
-    out = ["// GENERATED by tools/gen_h3_ffn_asm.py - do not edit.  Body of the FFN asm statement (see the generator",
-           "// for the register map and the schedule)."]
+    base = f"timewarp_amd/csrc/tw_h3_{SHAPE['tag']}_asm.inc"
+    out = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape} - do not edit.  Body of the {shape} MLP asm statement",
+           "// (see the generator for the register map and the schedule)."]
     for l in lines:
         out.append('"' + l + '\\n\\t"')
-    open(sys.argv[1] if len(sys.argv) > 1 else "timewarp_amd/csrc/tw_h3_ffn_asm.inc", "w").write("\n".join(out) + "\n")
-    clob = [f'"v{i}"' for i in range(204)] + [f'"a{i}"' for i in range(120)] + [f'"s{i}"' for i in range(84, 96)] + \
+    open(base, "w").write("\n".join(out) + "\n")
+    n_v = 208 if SHAPE["silu"] else 204
+    clob = [f'"v{i}"' for i in range(n_v)] + [f'"a{i}"' for i in range(120)] + [f'"s{i}"' for i in range(84, 96)] + \
            ['"vcc"', '"scc"', '"memory"']
-    cl = ["// GENERATED by tools/gen_h3_ffn_asm.py - clobber list of the FFN asm statement."]
+    cl = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape} - clobber list of the {shape} MLP asm statement."]
     for i in range(0, len(clob), 12):
         cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
-    open((sys.argv[1] if len(sys.argv) > 1 else "timewarp_amd/csrc/tw_h3_ffn_asm.inc").replace("_asm.inc", "_clobbers.inc"), "w").write("\n".join(cl) + "\n")
+    open(base.replace("_asm.inc", "_clobbers.inc"), "w").write("\n".join(cl) + "\n")
     n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
-    print(f"{len(lines)} instructions, {n_mfma} MFMAs")
+    print(f"{shape}: {len(lines)} instructions, {n_mfma} MFMAs")
 
 
 main()
