@@ -18,7 +18,11 @@ Register map (all private to the asm statement, listed as clobbers):
   v202 lane*16, v203 (lane>>4)*16
   a0..a95     yacc[ot][jt] (4 each);  v72..v95 hacc[o][jt] (VGPRs: read by the epilogue directly);  s95 scale
 Stage order (must match h3_pack_weights):  A0(0) A1(0) | A0(c+1) A1(c+1) B0(c) B1(c) ... | B0(n-1) B1(n-1)."""
+import os
 import sys
+
+# timing experiments only (results become wrong): comma-separated flags in H3_FFN_EXPERIMENT: noepi, nobarrier
+EXPERIMENT = set(filter(None, os.environ.get("H3_FFN_EXPERIMENT", "").split(",")))
 
 NT = 3
 # Shapes of the three chunked MLPs (same schedule, one generated file each):
@@ -180,7 +184,7 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
                 groups.append([])
     live = [bool(g) for g in groups]
     aux = 3 if is_a0 else 0
-    epi = list(epi_ops)
+    epi = [] if "noepi" in EXPERIMENT else list(epi_ops)
     share = -(-len(epi) // 4)
     parts = [epi[i * share:(i + 1) * share] for i in range(4)]
     out = []
@@ -195,7 +199,8 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     out.append(f"s_waitcnt lgkmcnt({2 + aux})" if aux else "s_waitcnt lgkmcnt(2)")
     out += weave(groups[1], parts[1], tile_reads(3) if live[3] else [])
     out.append("s_waitcnt vmcnt(6) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
-    out.append("s_barrier")
+    if "nobarrier" not in EXPERIMENT:
+        out.append("s_barrier")
     h = handoff(next_reads, with_aux, label)
     if is_a0:
         h = [f"v_readfirstlane_b32 s{S_SC}, v{V_SC}"] + h   # aux block landed (lgkmcnt(0) above)
