@@ -233,3 +233,22 @@ def test_sample_trajectory_segments_and_resume(tmp_path):
     assert sample_trajectory(b2, None, "cpu", None, None, out, "pep", 80, 20, sampler=fake_sampler, verbose=False) == 2
     assert np.allclose(calls[-2][0, 0, 0], 0.040, atol=1e-6)                    # resumed from the saved row
     assert len(os.listdir(out)) == 4
+
+
+def test_generated_asm_includes_are_current(tmp_path):
+    """The committed tw_h3_*_asm.inc / *_clobbers.inc files are exactly what the generators in tools/ emit (a build
+    needs hipcc only; this keeps the committed text from going stale)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("H3_")}
+    for args in (["tools/gen_h3_ffn_asm.py", "--shape=ffn"], ["tools/gen_h3_ffn_asm.py", "--shape=in"],
+                 ["tools/gen_h3_ffn_asm.py", "--shape=out"], ["tools/gen_h3_attn_asm.py"]):
+        subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
+                       stdout=subprocess.DEVNULL)
+    names = sorted(os.listdir(tmp_path))
+    assert len(names) == 8
+    for n in names:
+        with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
+            assert a.read() == b.read(), n

@@ -327,7 +327,11 @@ def generate():
 
 def main():
     lines = generate()
-    base = sys.argv[1] if len(sys.argv) > 1 else "timewarp_amd/csrc/tw_h3_attn_asm.inc"
+    out_dir = "timewarp_amd/csrc"
+    for a in sys.argv[1:]:
+        if a.startswith("--out-dir="):
+            out_dir = a.split("=", 1)[1]
+    base = os.path.join(out_dir, "tw_h3_attn_asm.inc")
     out = ["// GENERATED by tools/gen_h3_attn_asm.py - do not edit.  Body of the attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")

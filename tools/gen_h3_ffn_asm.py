@@ -321,13 +321,15 @@ def generate():
 
 def main():
     global SHAPE
-    shape = "ffn"
+    shape, out_dir = "ffn", "timewarp_amd/csrc"
     for a in sys.argv[1:]:
         if a.startswith("--shape="):
             shape = a.split("=", 1)[1]
+        if a.startswith("--out-dir="):
+            out_dir = a.split("=", 1)[1]
     SHAPE = SHAPES[shape]
     lines = generate()
-    base = f"timewarp_amd/csrc/tw_h3_{SHAPE['tag']}_asm.inc"
+    base = os.path.join(out_dir, f"tw_h3_{SHAPE['tag']}_asm.inc")
     out = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape} - do not edit.  Body of the {shape} MLP asm statement",
            "// (see the generator for the register map and the schedule)."]
     for l in lines:
