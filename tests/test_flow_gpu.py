@@ -170,7 +170,12 @@ def test_full_dense_ad_golden():
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
 
 
-@pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25])])
+H3_ATOM_COUNTS = (12, 16, 22, 24, 48)  # molecule sizes for which the 48-token wave layout (NT = 3) is the chosen one
+
+
+@pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25]),
+                                    (12, [12, 12, 9, 12, 11, 12, 12, 5, 12]), (16, [16, 13, 16, 16, 16, 10, 16]),
+                                    (24, [24, 21, 24]), (48, [48, 40, 33])])
 def test_fused_batched_padding_vs_oracle(V, lens):
     """Ragged batch (different conditioning state per row, padded atoms) on the fused path against
     the oracle: pins the per-row score fragments and the mask handling
@@ -187,7 +192,7 @@ def test_fused_batched_padding_vs_oracle(V, lens):
     for b, n in enumerate(lens):
         mask[b, n:] = True
     ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
-    for path in (FUSED, SIMPLE) + ((H3,) if V == 22 else ()):
+    for path in (FUSED, SIMPLE) + ((H3,) if V in H3_ATOM_COUNTS else ()):
         m = H.tw_kernel_model(sd, path=path)
         out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
                                y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
