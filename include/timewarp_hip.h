@@ -222,8 +222,14 @@ int tw_chirality_changed(const float* coords, const int32_t* centres, const floa
 int tw_profile_begin(void);
 int tw_profile_end(double* total_ms, int64_t* launches);
 
-/* Timing experiments on the split-fp16 kernel (results become WRONG): bit 0 = no weight LDS-DMA after
- * the prologue, bit 1 = no workgroup barriers.  0 restores normal operation. */
+/* Debug / measurement switches of the split-fp16 kernel.  0 restores normal operation.
+ *   bit 0 (1)  no weight LDS-DMA after the prologue   } timing experiments on the compiled-C++ sections only:
+ *   bit 1 (2)  no workgroup barriers                  } results become WRONG
+ *   bit 2 (4)  tw_debug_netblock dumps the attention output (before the first LayerNorm) instead of the layer output
+ *   bit 3 (8)  run the compiled-C++ variant of the kernel (attention / FFN / in / out sections as C++ instead of the
+ *              generated asm blocks); same results, slower - the A/B reference for the asm
+ *   bit 4 (16) tw_debug_netblock: wave 0 of workgroup 0 writes s_memtime stamps of the section boundaries into the
+ *              dump buffer instead of activations (tools/profile_h3_sections.py) */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every
