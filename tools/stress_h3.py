@@ -22,7 +22,7 @@ for label, args in (("B4", (4, 22, [22, 20, 22, 17], 4)), ("B8", (8, 22, [22]*8,
     c = case(*args)
     ref = ll(m1, c)
     bad, worst = 0, 0.0
-    N = 30
+    N = int(os.environ.get("STRESS_N", "30"))
     junk = torch.empty(1 << 29, dtype=torch.float32, device="cuda")  # 2 GiB: evicts L2 and the Infinity Cache
     for it in range(N):
         junk.fill_(float(it))
