@@ -48,7 +48,10 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3_RING 5                   // stage buffers: 1 being read + 4 in flight (~1 us of LDS-DMA latency)
 #define H3_XT_BYTES (128 * H3_XT * 2)  // one of (hi, lo)
 #define H3_WAVE_LDS (2 * H3_XT_BYTES)
-#define H3_LDS_BYTES (H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS)
+#define H3_SIDE_LAYER_FLOATS 656      // per-layer side block: n1w n1b b2 n2w n2b [128 each], wc scale, w2 scale, pad
+#define H3_SIDE_LDS_OFFSET (H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS)
+#define H3_SIDE_LDS_BYTES 3072        // three 1 KiB LDS-DMA chunks (the block is 2624 B; the rest of LDS up to 160 KiB)
+#define H3_LDS_BYTES (H3_SIDE_LDS_OFFSET + H3_SIDE_LDS_BYTES)
 #define H3_TARGET_MAX 4096.0f       // |w| * 2^s is scaled up to just below this
 
 // stage sequence per net (each 9 KiB = 4 tile pairs + aux); the A and B stages of the chunked MLPs are
@@ -77,11 +80,11 @@ static H3Geom h3_geom(const tw_flow_desc& d) {
   int64_t o = 0;
   g.side_in2b = o; o += 128;
   g.side_layers = o;
-  g.side_layer_size = 128 * 5;
+  g.side_layer_size = H3_SIDE_LAYER_FLOATS;
   o += g.L * g.side_layer_size;
   g.side_out2b = o; o += 16;
   g.side_scales = o; o += 4 + 3 * g.L;
-  g.side_size = (o + 63) / 64 * 64;
+  g.side_size = (o + 63) / 64 * 64 + 256;  // + slack: the per-layer block is fetched as three whole KiB
   g.net_stride_bytes = (g.stages * H3_STAGE_BYTES + g.side_size * 4 + 1023) / 1024 * 1024;
   return g;
 }
@@ -281,6 +284,8 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         if ((rc = copy(lb + L.layer.b2, 128, sl + 256, 128))) return rc;
         if ((rc = copy(lb + L.layer.n2w, 128, sl + 384, 128))) return rc;
         if ((rc = copy(lb + L.layer.n2b, 128, sl + 512, 128))) return rc;
+        if ((rc = copy(lsc + 0, 1, sl + 640, 1))) return rc;  // folded-attention scale
+        if ((rc = copy(lsc + 2, 1, sl + 641, 1))) return rc;  // W2 scale
       }
       // ---- OUT
       float* osc = scales + 2 + 3 * d.n_layers;
@@ -510,9 +515,13 @@ __device__ __forceinline__ float h3_xor_sum(float v) {
 template <int NT>
 __device__ __forceinline__ void h3_add_layernorm(f4 (&x)[8][NT], const f4 (&y)[8][NT], const float* lnw_lane,
                                                  const float* lnb_lane, float eps) {
+  // lnw_lane / lnb_lane point into the layer's side block in LDS (staged there by LDS-DMA at the top of the layer)
   f4 w[8], b[8];
-  h3_load8_f4(lnw_lane, w);
-  h3_load8_f4(lnb_lane, b);
+#pragma unroll
+  for (int ft = 0; ft < 8; ++ft) {
+    w[ft] = *(const f4*)(lnw_lane + 16 * ft);
+    b[ft] = *(const f4*)(lnb_lane + 16 * ft);
+  }
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     float s = 0.f;
@@ -889,9 +898,22 @@ netblock_h3_kernel(const H3Params p) {
 
   const char* sf_base = p.sfrag + (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * H3_SF_BYTES);
 
+  const float* sl = (const float*)(lds + H3_SIDE_LDS_OFFSET);  // this layer's side block, staged in LDS
   for (int l = 0; l < p.n_layers; ++l) {
-    const float* sl = side + p.side_layers + (int64_t)l * p.side_layer_size;
-    const float* lsc = scales + 2 + 3 * l;
+    // Stage the layer's LayerNorm parameters, FFN output bias and the two output scales (2.6 KB) in LDS: wave 0
+    // issues three 1 KiB LDS-DMA chunks and nobody waits for them here - they are older than every weight-stage
+    // DMA of the layer, so the first stage hand-off (vmcnt wait + barrier) covers them long before the first use.
+    // The barrier keeps the previous layer's last reads of the block ahead of the overwrite.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave == 0) {
+      const char* src = (const char*)(side + p.side_layers + (int64_t)l * p.side_layer_size) + lane * 16;
+      char* dst = lds + H3_SIDE_LDS_OFFSET;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
     // x -> transposed fp16 hi/lo tile in LDS
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
@@ -1011,7 +1033,7 @@ netblock_h3_kernel(const H3Params p) {
         }
     }
     {
-      const float sc = h3_load_f1(lsc);
+      const float sc = sl[640];
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
@@ -1065,9 +1087,10 @@ netblock_h3_kernel(const H3Params p) {
       } else {
         h3_mlp_chain<NT, 4, 8, false>(xb, y, pipe, p.ff_chunks, lane);
       }
-      const float sc = h3_load_f1(lsc + 2);
+      const float sc = sl[641];
       f4 bb[8];
-      h3_load8_f4(sl + 256 + 4 * g, bb);
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot) bb[ot] = *(const f4*)(sl + 256 + 4 * g + 16 * ot);
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot) {
 #pragma unroll
