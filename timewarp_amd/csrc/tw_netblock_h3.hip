@@ -547,11 +547,10 @@ __device__ __forceinline__ void h3_add_layernorm(f4 (&x)[8][NT], const f4 (&y)[8
 
 // The weight pipeline: a ring of H3_RING stage buffers in LDS, refilled by LDS-DMA.  `advance`:
 //   1. s_waitcnt vmcnt(0): every LDS-DMA this wave has issued has landed (stated in asm: hipcc neither
-//      counts LDS-DMA nor reliably waits for it).  Counted waits (leaving younger stages in flight
-//      across the barrier) were tried and produced stale tiles - completion order between LDS-DMA and
-//      the kernel's ordinary loads is evidently not the issue order - so the DMA queue is drained here;
-//      the ring still keeps RING-1 stages of prefetch distance because the drain happens one full
-//      stage of compute after the youngest fetch was issued;
+//      counts LDS-DMA nor reliably waits for it).  This C++ hand-off simply drains the queue; the ring still
+//      keeps RING-1 stages of prefetch distance because the drain happens one full stage of compute after
+//      the youngest fetch was issued.  (Counted waits, vmcnt(6) = three stages left in flight, are what the
+//      generated asm sections use; here they measured correct but not faster.)
 //   2. raw s_barrier: every wave has finished reading the current stage and all shares have landed;
 //   3. refill the buffer just released with stage s+RING.
 // Each wave moves 2 KiB of every stage; wave 0 additionally moves the 1 KiB aux block.
