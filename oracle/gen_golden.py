@@ -592,6 +592,14 @@ def main():
     gen_learnable_golden()
     gen_chebyshev_golden()
 
+    # ---- (8) the reference's own smallest test molecule as data (testdata/smallest_molecule: 2 frames x 65 atoms,
+    #          elements from PDB columns 77-78) for the config-0 plumbing test
+    z = np.load("/root/reference/testdata/smallest_molecule/2olx-traj-arrays.npz")
+    els = [l[76:78].strip() for l in open("/root/reference/testdata/smallest_molecule/2olx-traj-state0.pdb")
+           if l.startswith(("ATOM", "HETATM"))]
+    np.savez_compressed(os.path.join(OUT, "smallest_molecule.npz"), positions=z["positions"], velocities=z["velocities"],
+                        forces=z["forces"], elements=np.array(els))
+
     # ---- (6) alanine-dipeptide topology as data (22 atoms) ---------------------------------------
     np.savez_compressed(os.path.join(OUT, "ad_topology.npz"), coords_nm=ad_x.numpy(), atom_types=ad_t.numpy(),
                         atom_names=np.array(AD_NAMES))

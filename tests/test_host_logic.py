@@ -252,3 +252,44 @@ def test_generated_asm_includes_are_current(tmp_path):
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n
+
+
+def test_euler_maruyama_baseline_and_sample_driver():
+    """BASELINE config 0 (gaussian_baseline.yaml plumbing): the product's EulerMaruyamaGaussian against the
+    reference's distribution parameters and log-likelihood (golden euler_maruyama.npz), and the `sample.py` driver
+    (utils/sampling_utils.sample) on the reference's smallest test molecule: 100 conditional samples, one at a time."""
+    import timewarp_amd as tw
+    from timewarp_amd.dataloader import DenseMolDynBatch, ELEMENT_VOCAB
+    from timewarp_amd.utils.sampling_utils import sample, sample_from_trajectory
+
+    d, sd = H.load("euler_maruyama")
+    m = tw.model_constructor(tw.ModelConfig(model_type="euler_maruyama_gaussian")).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        pc, pv = m._get_y_dist(d["atom_types"], d["x_coords"], d["x_velocs"], d["x_forces"])
+        ll = m.log_likelihood(atom_types=d["atom_types"], x_coords=d["x_coords"], x_velocs=d["x_velocs"], x_forces=d["x_forces"],
+                              y_coords=d["y_coords"], y_velocs=d["y_velocs"], adj_list=None, edge_batch_idx=None,
+                              masked_elements=d["masked"])
+    for got, key in ((pc.loc, "coord_mean"), (pc.scale, "coord_std"), (pv.loc, "veloc_mean"), (pv.scale, "veloc_std"), (ll, "loglik")):
+        assert H.rel_err(got, d[key]) < 2e-6, key
+    cm, cs, vm, vs = fo.euler_maruyama_dist(sd, d["atom_types"], d["x_coords"], d["x_velocs"], d["x_forces"])
+    assert H.rel_err(pc.loc, cm) < 2e-6 and H.rel_err(pv.scale, vs) < 2e-6
+
+    z = np.load(os.path.join(H.GOLDEN, "smallest_molecule.npz"))
+    at = torch.tensor([[ELEMENT_VOCAB[e] for e in z["elements"]]])
+    x, v, f = (torch.from_numpy(z[k][:1]) for k in ("positions", "velocities", "forces"))
+    V = x.shape[1]
+    batch = DenseMolDynBatch(names=["2olx"], atom_types=at, adj_list=torch.zeros((0, 2), dtype=torch.int64),
+                             edge_batch_idx=torch.zeros((0,), dtype=torch.int64), atom_coords=x, atom_velocs=v, atom_forces=f,
+                             atom_coord_targets=x, atom_veloc_targets=v, atom_force_targets=f,
+                             masked_elements=torch.zeros(1, V, dtype=torch.bool))
+    torch.manual_seed(0)
+    yc, yv = sample(m, batch, 100)
+    assert yc.shape == (100, V, 3) and yv.shape == (100, V, 3) and yc.dtype == np.float64
+    with torch.no_grad():
+        pc, pv = m._get_y_dist(at, x, v, f)
+    # sample mean within 5 standard errors of the analytic mean, everywhere
+    assert (np.abs(yc.mean(0) - pc.loc[0].numpy()) < 5 * pc.scale[0].numpy() / 10 + 1e-6).all()
+    assert (np.abs(yv.mean(0) - pv.loc[0].numpy()) < 5 * pv.scale[0].numpy() / 10 + 1e-6).all()
+    cs_, vs_ = sample_from_trajectory(m, [batch, batch], 3)
+    assert len(cs_) == 2 and cs_[0].shape == (3, V, 3)
