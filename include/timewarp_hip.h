@@ -138,6 +138,17 @@ int tw_flow_sample_with_logp(const tw_flow_desc* desc, const float* raw, const f
                              float* out_logp, int64_t n_samples, int64_t n_cond, int32_t n_atoms,
                              int32_t path, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Extension: the same without the reference's n_cond == 1 || n_samples == 1 restriction (flow.py:326 broadcasts a
+ * [B,V,1] mask into [S*B,V,3]); rows are ordered sample-major, row = sample * n_cond + cond, as the reference's
+ * reshape would produce.  Used to evaluate several chains' proposals in one launch. */
+int tw_flow_sample_with_logp_multi(const tw_flow_desc* desc, const float* raw, const float* packed,
+                                   const int32_t* atom_types, const float* x_coords,
+                                   const float* x_velocs, const uint8_t* masked,
+                                   const float* z_coords, const float* z_velocs, float* y_coords,
+                                   float* y_velocs, float* out_logp, int64_t n_samples, int64_t n_cond,
+                                   int32_t n_atoms, int32_t path, void* workspace,
+                                   int64_t workspace_bytes, void* stream);
+
 /* compute_kernel_attention_scores (modules/layers/kernel_attention.py:69-121):
  * out [n_cond, n_heads, n_atoms, n_atoms].  use_mm != 0 selects torch.cdist's matmul
  * formulation (the reference gets it for n_atoms > 25). */
@@ -208,6 +219,15 @@ int tw_mh_accept(const float* energy, const float* p_xy, const float* p_yx, cons
                  const float* y_coords, const float* y_velocs, float* x_coords, float* x_velocs,
                  float* out_exponent, float* out_p_acc, uint8_t* out_accepted, int32_t* result,
                  int64_t n_proposals, int32_t n_atoms, void* stream);
+
+/* Extension (no reference counterpart): n_chains independent chains evaluated in one flow
+ * call of n_chains conditioning states x n_proposals samples.  Every per-proposal array is in the row order of that
+ * call, index = proposal * n_chains + chain; x_coords / x_velocs [n_chains, n_atoms, 3]; result int32 [n_chains, 4].
+ * Per chain exactly the semantics of tw_mh_accept. */
+int tw_mh_accept_chains(const float* energy, const float* p_xy, const float* p_yx, const float* u,
+                        const float* y_coords, const float* y_velocs, float* x_coords, float* x_velocs,
+                        float* out_exponent, float* out_p_acc, uint8_t* out_accepted, int32_t* result,
+                        int64_t n_proposals, int64_t n_chains, int32_t n_atoms, void* stream);
 
 /* check_symmetry_change (utils/chirality.py:40-80): sign of the triple product at each
  * chirality centre vs reference_signs; out_changed [n_rows] uint8.  centres [n_centres,4] int32. */

@@ -165,3 +165,64 @@ def test_deferred_iterations_equal_synchronous_ones():
         for f in ("acceptance_indicator", "acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin",
                   "energies_pot_delta", "energies_kin_delta"):
             assert np.array_equal(getattr(a[3], f), getattr(b[3], f)), f
+
+
+def test_multichain_equals_single_chains():
+    """Three chains evaluated in lock-step (one flow call of 3 x S rows per iteration, per-chain accept on the device)
+    reproduce, chain by chain and bit for bit, three separate sample_with_model runs driven by the same per-chain
+    noise streams - states, velocities, accept counts and all nine ChainStats arrays, including the final clip."""
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.utils.evaluation_utils import DeviceNoise, sample_with_model
+    from timewarp_amd.utils.multichain import sample_with_model_chains
+
+    z, sd = load_mh()
+    model = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2,
+                              lengthscales=(0.1, 0.5, 1.2), path=2)
+    at = torch.from_numpy(z["atom_types"])
+    x0, v0 = torch.from_numpy(z["x0"]), torch.from_numpy(z["v0"])
+    g = torch.Generator().manual_seed(31)
+    starts = [(x0 + 0.03 * torch.randn(x0.shape, generator=g), v0 + 0.1 * torch.randn(v0.shape, generator=g)) for _ in range(3)]
+    energy = mo.SyntheticEnergy(x0.clone().cuda())
+    masses = torch.from_numpy(z["masses"])
+    dev = torch.device("cuda")
+    N, S = 70, 10
+    for kw in (dict(), dict(random_velocs=True, resample_velocs=True)):
+        singles = []
+        for c, (xc, vc) in enumerate(starts):
+            singles.append(sample_with_model(single_state_batch("t", at, xc, vc), model, dev, energy, masses, N, accept=True,
+                                             num_proposal_steps=S, disable_tqdm=True, noise=DeviceNoise(dev, seed=500 + c), **kw))
+        multi = sample_with_model_chains([single_state_batch("t", at, xc, vc) for xc, vc in starts], model, dev, energy, masses,
+                                         N, S, noises=[DeviceNoise(dev, seed=500 + c) for c in range(3)], sync_every=4, **kw)
+        for a, b in zip(singles, multi):
+            assert a[0].shape == b[0].shape and a[2] == b[2]
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            for f in ("acceptance_indicator", "acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin",
+                      "energies_pot_delta", "energies_kin_delta"):
+                assert np.array_equal(getattr(a[3], f), getattr(b[3], f)), f
+
+
+def test_multichain_full_size_split_fp16():
+    """Same equivalence on the product configuration: full-size flow on the split-fp16 kernels, AMBER energy kernel,
+    alanine dipeptide, two chains x 16 proposals."""
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.utils.evaluation_utils import DeviceNoise, sample_with_model
+    from timewarp_amd.utils.multichain import sample_with_model_chains
+
+    sd = synthetic.synth_state_dict(H.full_kernel_sd(), 0, calibrated=True, coords_log_scale=-7.0, velocs_log_scale=0.0)
+    model = H.tw_kernel_model(sd, path=3)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    energy = AmberPotentialEnergyTorch.alanine_dipeptide()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(1)
+    starts = [coords + 0.002 * torch.randn(coords.shape, generator=g) for _ in range(2)]
+    kw = dict(random_velocs=True, resample_velocs=True)
+    singles = [sample_with_model(single_state_batch("ad", types, xc), model, dev, energy, masses, 12, accept=True,
+                                 num_proposal_steps=16, disable_tqdm=True, noise=DeviceNoise(dev, seed=40 + c), **kw)
+               for c, xc in enumerate(starts)]
+    multi = sample_with_model_chains([single_state_batch("ad", types, xc) for xc in starts], model, dev, energy, masses, 12, 16,
+                                     noises=[DeviceNoise(dev, seed=40 + c) for c in range(2)], sync_every=2, **kw)
+    for a, b in zip(singles, multi):
+        assert a[0].shape == b[0].shape and a[2] == b[2]
+        assert np.allclose(a[0], b[0], rtol=0, atol=1e-6) and np.allclose(a[3].exponent, b[3].exponent, rtol=1e-5, atol=1e-4)

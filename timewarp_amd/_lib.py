@@ -91,12 +91,17 @@ SIGNATURES = {
         C.c_int,
         [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I64, _P],
     ),
+    "tw_flow_sample_with_logp_multi": (
+        C.c_int,
+        [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I64, _P],
+    ),
     "tw_kernel_scores": (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "tw_kernel_scores_cheb": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "tw_centre": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
     "tw_kinetic_energy": (C.c_int, [_P, _P, _I32, _F, _P, _I64, _I32, _P]),
     "tw_amber_energy": (C.c_int, [C.POINTER(ForceField), _P, _P, _P, _I64, _P]),
     "tw_mh_accept": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
+    "tw_mh_accept_chains": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _P]),
     "tw_chirality_changed": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _I32, _P]),
     "tw_debug_set_flags": (C.c_int, [C.c_int]),
     "tw_profile_begin": (C.c_int, []),

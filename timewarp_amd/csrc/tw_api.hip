@@ -12,7 +12,7 @@ int launch_kinetic(const float* v, const float* masses, int random_velocs, float
                    hipStream_t s);
 int launch_mh_accept(const float* energy, const float* p_xy, const float* p_yx, const float* u, const float* yc,
                      const float* yv, float* xc, float* xv, float* out_exp, float* out_pacc, uint8_t* out_acc,
-                     int32_t* result, int64_t S, int V, hipStream_t s);
+                     int32_t* result, int64_t S, int V, hipStream_t s, int64_t n_chains = 1);
 int launch_chirality(const float* coords, const int32_t* centres, const float* ref, int n_centres, uint8_t* changed,
                      int64_t n_rows, int V, hipStream_t s);
 int amber_energy(const tw_forcefield* ff, const float* coords, double* out, double* terms, int64_t n, hipStream_t s);
@@ -183,15 +183,15 @@ int tw_flow_log_likelihood(const tw_flow_desc* desc, const float* raw, const flo
   return launch_prior_logp(zc, zv, masked, n_rows, raw + L.prior, delta, -1.f, out_logp, n_rows, n_atoms, s);
 }
 
-int tw_flow_sample_with_logp(const tw_flow_desc* desc, const float* raw, const float* packed, const int32_t* atom_types,
-                             const float* x_coords, const float* x_velocs, const uint8_t* masked, const float* z_coords,
-                             const float* z_velocs, float* y_coords, float* y_velocs, float* out_logp, int64_t n_samples,
-                             int64_t n_cond, int32_t n_atoms, int32_t path, void* workspace, int64_t workspace_bytes,
-                             void* stream) {
+static int sample_with_logp_impl(const tw_flow_desc* desc, const float* raw, const float* packed, const int32_t* atom_types,
+                                 const float* x_coords, const float* x_velocs, const uint8_t* masked, const float* z_coords,
+                                 const float* z_velocs, float* y_coords, float* y_velocs, float* out_logp, int64_t n_samples,
+                                 int64_t n_cond, int32_t n_atoms, int32_t path, void* workspace, int64_t workspace_bytes,
+                                 void* stream, bool multi) {
   int rc = check_desc(desc);
   if (rc) return rc;
   TW_REQUIRE(n_samples >= 0 && n_cond > 0 && n_atoms > 0, "bad sizes");
-  TW_REQUIRE(n_cond == 1 || n_samples == 1,
+  TW_REQUIRE(multi || n_cond == 1 || n_samples == 1,
              "the reference's mask broadcast (flow.py:326) needs n_cond == 1 or n_samples == 1");
   const int64_t n_rows = n_samples * n_cond;
   if (n_rows == 0) return TW_OK;
@@ -228,6 +228,26 @@ int tw_flow_sample_with_logp(const tw_flow_desc* desc, const float* raw, const f
   // flow.py:303-310: y = (x_centred + com) + residual
   return launch_uncentre_add(xc, com, rc_, n_cond, y_coords, n_atoms, desc->displacement, n_rows, s);
 }
+
+extern "C" {
+int tw_flow_sample_with_logp(const tw_flow_desc* desc, const float* raw, const float* packed, const int32_t* atom_types,
+                             const float* x_coords, const float* x_velocs, const uint8_t* masked, const float* z_coords,
+                             const float* z_velocs, float* y_coords, float* y_velocs, float* out_logp, int64_t n_samples,
+                             int64_t n_cond, int32_t n_atoms, int32_t path, void* workspace, int64_t workspace_bytes,
+                             void* stream) {
+  return sample_with_logp_impl(desc, raw, packed, atom_types, x_coords, x_velocs, masked, z_coords, z_velocs, y_coords,
+                               y_velocs, out_logp, n_samples, n_cond, n_atoms, path, workspace, workspace_bytes, stream, false);
+}
+
+int tw_flow_sample_with_logp_multi(const tw_flow_desc* desc, const float* raw, const float* packed,
+                                   const int32_t* atom_types, const float* x_coords, const float* x_velocs,
+                                   const uint8_t* masked, const float* z_coords, const float* z_velocs, float* y_coords,
+                                   float* y_velocs, float* out_logp, int64_t n_samples, int64_t n_cond, int32_t n_atoms,
+                                   int32_t path, void* workspace, int64_t workspace_bytes, void* stream) {
+  return sample_with_logp_impl(desc, raw, packed, atom_types, x_coords, x_velocs, masked, z_coords, z_velocs, y_coords,
+                               y_velocs, out_logp, n_samples, n_cond, n_atoms, path, workspace, workspace_bytes, stream, true);
+}
+}  // extern "C"
 
 int tw_kernel_scores(const float* x_coords, const uint8_t* masked, const float* lengthscales, int32_t n_heads,
                      int64_t n_cond, int32_t n_atoms, int32_t normalise, int32_t use_mm, float* out, void* stream) {
@@ -277,6 +297,18 @@ int tw_mh_accept(const float* energy, const float* p_xy, const float* p_yx, cons
   TW_REQUIRE(n_proposals > 0 && n_proposals < (1LL << 30), "bad n_proposals");
   return launch_mh_accept(energy, p_xy, p_yx, u, y_coords, y_velocs, x_coords, x_velocs, out_exponent, out_p_acc,
                           out_accepted, result, n_proposals, n_atoms, (hipStream_t)stream);
+}
+
+int tw_mh_accept_chains(const float* energy, const float* p_xy, const float* p_yx, const float* u, const float* y_coords,
+                        const float* y_velocs, float* x_coords, float* x_velocs, float* out_exponent, float* out_p_acc,
+                        uint8_t* out_accepted, int32_t* result, int64_t n_proposals, int64_t n_chains, int32_t n_atoms,
+                        void* stream) {
+  TW_REQUIRE(energy && p_xy && p_yx && u && out_exponent && out_p_acc && out_accepted && result, "NULL pointer argument");
+  TW_REQUIRE((x_coords == nullptr) == (x_velocs == nullptr), "x_coords and x_velocs must both be given or both be NULL");
+  TW_REQUIRE(!x_coords || (y_coords && y_velocs), "state update needs y_coords / y_velocs");
+  TW_REQUIRE(n_proposals > 0 && n_proposals < (1LL << 30) && n_chains > 0 && n_chains < (1LL << 20), "bad sizes");
+  return launch_mh_accept(energy, p_xy, p_yx, u, y_coords, y_velocs, x_coords, x_velocs, out_exponent, out_p_acc,
+                          out_accepted, result, n_proposals, n_atoms, (hipStream_t)stream, n_chains);
 }
 
 int tw_chirality_changed(const float* coords, const int32_t* centres, const float* reference_signs, int32_t n_centres,

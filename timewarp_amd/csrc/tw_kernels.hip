@@ -306,23 +306,27 @@ __global__ void kinetic_kernel(const float* __restrict__ v, const float* __restr
 // ------------------------------------------------------------------------------------------------
 // MH accept step (evaluation_utils.py:659-677): single workgroup, first-true scan + state update
 // ------------------------------------------------------------------------------------------------
+// One block per chain c; proposal s of chain c lives at index s * n_chains + c of every per-proposal array
+// (the row order of a [S, C] flow call); n_chains = 1 is the reference's single chain.
 __global__ void mh_accept_kernel(const float* __restrict__ energy, const float* __restrict__ p_xy,
                                  const float* __restrict__ p_yx, const float* __restrict__ u,
                                  const float* __restrict__ yc, const float* __restrict__ yv,
                                  float* __restrict__ xc, float* __restrict__ xv, float* __restrict__ out_exp,
                                  float* __restrict__ out_pacc, uint8_t* __restrict__ out_acc,
-                                 int32_t* __restrict__ result, int64_t S, int V) {
+                                 int32_t* __restrict__ result, int64_t S, int V, int64_t C) {
   __shared__ int first;
+  const int64_t c = blockIdx.x;
   if (threadIdx.x == 0) first = 0x7fffffff;
   __syncthreads();
   int local = 0x7fffffff;
   for (int64_t s = threadIdx.x; s < S; s += blockDim.x) {
-    const float e = energy[s] + p_xy[s] - p_yx[s];
+    const int64_t i = s * C + c;
+    const float e = energy[i] + p_xy[i] - p_yx[i];
     const float p = fminf(1.f, expf(-e));
-    const bool acc = u[s] < p;
-    out_exp[s] = e;
-    out_pacc[s] = p;
-    out_acc[s] = acc ? 1 : 0;
+    const bool acc = u[i] < p;
+    out_exp[i] = e;
+    out_pacc[i] = p;
+    out_acc[i] = acc ? 1 : 0;
     if (acc && (int)s < local) local = (int)s;
   }
   atomicMin(&first, local);
@@ -331,14 +335,14 @@ __global__ void mh_accept_kernel(const float* __restrict__ energy, const float* 
   const bool any = k != 0x7fffffff;
   if (any && xc && xv)
     for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) {
-      xc[i] = yc[(int64_t)k * 3 * V + i];
-      xv[i] = yv[(int64_t)k * 3 * V + i];
+      xc[c * 3 * V + i] = yc[((int64_t)k * C + c) * 3 * V + i];
+      xv[c * 3 * V + i] = yv[((int64_t)k * C + c) * 3 * V + i];
     }
   if (threadIdx.x == 0) {
-    result[0] = any ? k : (int)(S - 1);
-    result[1] = any ? 1 : 0;
-    result[2] = 0;
-    result[3] = 0;
+    result[4 * c + 0] = any ? k : (int)(S - 1);
+    result[4 * c + 1] = any ? 1 : 0;
+    result[4 * c + 2] = 0;
+    result[4 * c + 3] = 0;
   }
 }
 
@@ -722,9 +726,9 @@ int launch_kinetic(const float* v, const float* masses, int random_velocs, float
 }
 int launch_mh_accept(const float* energy, const float* p_xy, const float* p_yx, const float* u, const float* yc,
                      const float* yv, float* xc, float* xv, float* out_exp, float* out_pacc, uint8_t* out_acc,
-                     int32_t* result, int64_t S, int V, hipStream_t s) {
-  hipLaunchKernelGGL(mh_accept_kernel, dim3(1), dim3(256), 0, s, energy, p_xy, p_yx, u, yc, yv, xc, xv, out_exp,
-                     out_pacc, out_acc, result, S, V);
+                     int32_t* result, int64_t S, int V, hipStream_t s, int64_t n_chains) {
+  hipLaunchKernelGGL(mh_accept_kernel, dim3((unsigned)n_chains), dim3(256), 0, s, energy, p_xy, p_yx, u, yc, yv, xc, xv,
+                     out_exp, out_pacc, out_acc, result, S, V, n_chains);
   TW_LAUNCH_CHECK();
   return TW_OK;
 }

@@ -136,17 +136,18 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
                                      adj_list: Optional[Tensor], edge_batch_idx: Optional[Tensor],
                                      masked_elements: Tensor, num_samples: int, logger=None,
                                      z_coords: Optional[Tensor] = None, z_velocs: Optional[Tensor] = None,
-                                     ) -> Tuple[Tensor, Tensor, Tensor]:
+                                     allow_multi: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
         """Samples y ~ p(.|x) and their log-density: ([S,B,V,3], [S,B,V,3], [S,B]) (flow.py:242-336).
 
         Extension over the reference signature: `z_coords` / `z_velocs` [S,B,V,3] may carry the
         latent noise explicitly (already scaled by exp(prior log-scale)); when omitted it is drawn
-        on the device in the reference's order (coords first, flow.py:274-275)."""
+        on the device in the reference's order (coords first, flow.py:274-275).  `allow_multi=True` lifts the
+        reference's B == 1 or S == 1 restriction (several chains' proposals in one launch)."""
         at, mk, xc, xv = self._prep(atom_types, masked_elements, x_coords, x_velocs)
         dev = xc.device
         B, V = xc.shape[0], xc.shape[1]
         S = int(num_samples)
-        if not (B == 1 or S == 1):
+        if not (B == 1 or S == 1 or allow_multi):
             # flow.py:326 multiplies a [B,V,1] mask into [S*B,V,3]: torch raises for B>1 and S>1
             raise RuntimeError(f"The size of tensor a ({B}) must match the size of tensor b ({S * B}) at non-singleton dimension 0")
         if z_coords is None:
@@ -165,7 +166,8 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         lib = _lib.load()
         desc = self.dims.to_desc()
         with torch.cuda.device(dev):
-            _lib.check(lib.tw_flow_sample_with_logp(
+            entry = lib.tw_flow_sample_with_logp_multi if allow_multi else lib.tw_flow_sample_with_logp
+            _lib.check(entry(
                 C.byref(desc), raw.data_ptr(), _lib.ptr(packed), at.data_ptr(), xc.data_ptr(), xv.data_ptr(),
                 mk.data_ptr(), zc.data_ptr(), zv.data_ptr(), y_c.data_ptr(), y_v.data_ptr(), logp.data_ptr(),
                 S, B, V, self.execution_path, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),

@@ -104,21 +104,26 @@ def check_symmetry_change(coords: torch.Tensor, chirality_centers: torch.Tensor,
 
 
 class DeviceNoise:
-    """Random draws from the device generator, in the reference's order and shapes."""
+    """Random draws on the device, in the reference's order and shapes: from the default generator, or - with
+    `seed` - from a private generator (one independent, reproducible stream per chain)."""
 
-    def __init__(self, device):
+    def __init__(self, device, seed: Optional[int] = None):
         self.device = device
+        self.gen = None
+        if seed is not None:
+            self.gen = torch.Generator(device=device)
+            self.gen.manual_seed(int(seed))
 
     def randn_like(self, t):
-        return torch.randn_like(t)
+        return torch.randn(t.shape, device=t.device, dtype=t.dtype, generator=self.gen)
 
     def latents(self, S, B, V, scale_c, scale_v):
-        zc = torch.randn((S, B, V, 3), device=self.device) * scale_c
-        zv = torch.randn((S, B, V, 3), device=self.device) * scale_v
+        zc = torch.randn((S, B, V, 3), device=self.device, generator=self.gen) * scale_c
+        zv = torch.randn((S, B, V, 3), device=self.device, generator=self.gen) * scale_v
         return zc, zv
 
     def uniform(self, S):
-        return torch.rand(S, device=self.device)
+        return torch.rand(S, device=self.device, generator=self.gen)
 
     def rotation(self):
         # uniform SO(3) via QR of a Gaussian matrix (the reference uses scipy's Rotation.random())
