@@ -347,22 +347,24 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
     dist[i] = h3_pair_dist(xs + q * V * 3, r / V, r % V);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < mpw * H * V; i += blockDim.x) {
-    const int q = i / (H * V), h = (i / V) % H, a = i % V;
+  // grid.y = head: every block recomputes the (cheap) distances and handles the fragments of its own head
+  const int h = blockIdx.y;
+  for (int i = threadIdx.x; i < mpw * V; i += blockDim.x) {
+    const int q = i / V, a = i % V;
     float sum = 0.f;
     for (int m = 0; m < V; ++m) {
       float sc = dist[(q * V + a) * V + m] / ls[h];
       float e = msk[q * V + m] ? 0.f : expf(-(sc * sc));
       sum += fabsf(e);
     }
-    denom[i] = sum + 1e-5f;
+    denom[(q * H + h) * V + a] = sum + 1e-5f;
   }
   __syncthreads();
-  // one thread per (head, jt, lane, key slot 0..11): slots 0..7 -> k-step 0, 8..11 -> k-step 1
-  const int total = H * H3_NT * 64 * 12;
+  // one thread per (jt, lane, key slot 0..11): slots 0..7 -> k-step 0, 8..11 -> k-step 1
+  const int total = H3_NT * 64 * 12;
   char* out = sfrag + blk * (int64_t)H * H3_NT * H3_SF_BYTES;
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    const int slot = i % 12, lane = (i / 12) % 64, jt = (i / (12 * 64)) % H3_NT, h = i / (12 * 64 * H3_NT);
+    const int slot = i % 12, lane = (i / 12) % 64, jt = i / (12 * 64);
     const int tq = 16 * jt + (lane & 15);
     const int tk = slot < 8 ? 8 * (lane >> 4) + slot : 32 + 4 * (lane >> 4) + (slot - 8);
     float val = 0.f;
@@ -1258,7 +1260,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
   const int V = a.n_atoms;
   const int64_t nblocks = shared ? 1 : (a.n_rows + fg.mpw - 1) / fg.mpw;
   size_t shm = (size_t)(fg.mpw * V * 3 + fg.mpw * V * V + fg.mpw * d.n_heads * V) * 4 + (size_t)fg.mpw * V;
-  hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks), dim3(256), shm, a.stream, a.x_coords, a.masked,
+  hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks, (unsigned)d.n_heads), dim3(256), shm, a.stream, a.x_coords, a.masked,
                      a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, V, fg.mpw, a.n_rows, a.n_cond, d.normalise, sfrag);
   TW_LAUNCH_CHECK();
   return TW_OK;
