@@ -183,6 +183,7 @@ class MetropolisHastingsChain:
         self.V = self.x_coords.shape[1]
         self.use_chirality = chirality_centers is not None and reference_signs is not None
         self.chirality_centers, self.reference_signs = chirality_centers, reference_signs
+        self._const = None
         if initialize_randomly:
             print("Initializaing chain at a random point rather than a data sample.")
             yc, yv, _ = self._propose(self.noise.randn_like(self.x_coords), self.noise.randn_like(self.x_velocs), 1)
@@ -198,13 +199,23 @@ class MetropolisHastingsChain:
         self.S = self.s_max if not adaptive_parallelism else compute_num_proposal_steps(self.p_bar, max_num_proposal_steps=self.s_max)
         self.sgn = 1.0 if random_velocs else -1.0
 
+    def _constants(self, S):
+        """Per-chain constants in the dtypes / shapes the C ABI takes (int32 atom types, uint8 mask, both also
+        repeated S times for the reverse-move likelihood) and the prior scales: built once instead of per iteration."""
+        if self._const is None or self._const[0] != S:
+            at = self.atom_types.to(torch.int32).contiguous()
+            mk = self.masked.to(torch.uint8).contiguous()
+            sc = torch.exp(self.model.coords_prior_log_scale.detach()).to(self.device)
+            sv = torch.exp(self.model.velocs_prior_log_scale.detach()).to(self.device)
+            self._const = (S, at, mk, at.expand(S, self.V).contiguous(), mk.expand(S, self.V).contiguous(), sc, sv)
+        return self._const[1:]
+
     def _propose(self, xc, xv, S):
-        sc = torch.exp(self.model.coords_prior_log_scale.detach()).to(self.device)
-        sv = torch.exp(self.model.velocs_prior_log_scale.detach()).to(self.device)
+        at, mk, _, _, sc, sv = self._constants(S)
         zc, zv = self.noise.latents(S, 1, self.V, sc, sv)
         return self.model.conditional_sample_with_logp(
-            atom_types=self.atom_types, x_coords=xc, x_velocs=xv, adj_list=self.adj_list, edge_batch_idx=self.ebi,
-            masked_elements=self.masked, num_samples=S, z_coords=zc, z_velocs=zv)
+            atom_types=at, x_coords=xc, x_velocs=xv, adj_list=self.adj_list, edge_batch_idx=self.ebi,
+            masked_elements=mk, num_samples=S, z_coords=zc, z_velocs=zv)
 
     def _evaluate(self):
         """Everything of one iteration up to the accept test: proposals, energies, both log-likelihoods.
@@ -234,11 +245,12 @@ class MetropolisHastingsChain:
         e_pot = e_pot_y - e_pot_x
         energy = (e_pot + e_kin).contiguous()
 
-        sgn = self.sgn
+        _, _, at_s, mk_s, _, _ = self._constants(S)
+        # reverse move: velocities negated unless they are treated as resampled Gaussians (evaluation_utils.py:648-657)
+        rx_v, ry_v = (x_velocs, y_v) if self.sgn == 1.0 else (-x_velocs, -y_v)
         p_yx = model.log_likelihood(
-            atom_types=self.atom_types.expand(S, V), y_coords=x_coords.expand(S, V, 3),
-            y_velocs=(sgn * x_velocs).expand(S, V, 3), x_coords=y_c, x_velocs=sgn * y_v, adj_list=self.adj_list,
-            edge_batch_idx=self.ebi, masked_elements=self.masked.expand(S, V))
+            atom_types=at_s, y_coords=x_coords.expand(S, V, 3), y_velocs=rx_v.expand(S, V, 3), x_coords=y_c, x_velocs=ry_v,
+            adj_list=self.adj_list, edge_batch_idx=self.ebi, masked_elements=mk_s)
         p_xy = p_xy.reshape(S).contiguous()
         self.proposals += S
         return x_coords, x_velocs, y_c, y_v, energy, p_xy, p_yx, e_pot_y, e_kin_y, e_pot, e_kin
