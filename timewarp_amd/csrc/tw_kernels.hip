@@ -412,18 +412,25 @@ __global__ void build_input_kernel(const float* __restrict__ emb, const int32_t*
   }
 }
 
-// Y[M,N] = act(X[M,K] W[N,K]^T + b): 64x64 tile, 16x16 threads, 4x4 micro-tile, fp32 FMA.
+// Y[M,N] = act(X[M,K] W[N,K]^T + b) on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32
+// accumulate).  Block = 4 waves = a 64 x 64 output tile; wave w owns rows 16w..16w+15 and all 64 columns (four
+// 16 x 16 accumulators); X and W tiles of 16 k-values are staged through LDS, k-major with a padded row
+// (conflict-free fragment reads: lanes read consecutive m / n for a fixed k).
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+typedef float lin_f4 __attribute__((ext_vector_type(4)));
 template <int ACT>
 __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                       const float* __restrict__ bias, float* __restrict__ Y,
                                                       int64_t M, int N, int K) {
-  __shared__ float xs[16][65];
-  __shared__ float wsh[16][65];
-  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+  __shared__ float xs[16][68];
+  __shared__ float wsh[16][68];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
   const int64_t m0 = (int64_t)blockIdx.y * 64;
   const int n0 = blockIdx.x * 64;
-  float acc[4][4] = {};
+  lin_f4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < K; k0 += 16) {
     for (int i = threadIdx.x; i < 64 * 16; i += 256) {
       const int r = i / 16, kk = i % 16;
@@ -434,28 +441,26 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float a[4], b[4];
+    for (int ks = 0; ks < 4; ++ks) {
+      // A fragment: lane (i16, g) holds X[m = 16 wave + i16][k = 4 ks + g]; B fragment: W[n = 16 j + i16][k = 4 ks + g]
+      const float a = xs[4 * ks + g][16 * wave + i16];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = xs[kk][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = wsh[kk][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+      for (int j = 0; j < 4; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wsh[4 * ks + g][16 * j + i16], acc[j], 0, 0, 0);
     }
     __syncthreads();
   }
+  // D layout: lane (i16, g) holds rows 4 g + r (r = 0..3) of column i16
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + ty * 4 + i;
-    if (m >= M) continue;
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + 16 * j + i16;
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
-      if (n >= N) continue;
-      float v = acc[i][j] + (bias ? bias[n] : 0.f);
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + 16 * wave + 4 * g + r;
+      if (m >= M) continue;
+      float v = acc[j][r] + bv;
       if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
       if (ACT == ACT_SILU) v = v / (1.f + expf(-v));
       Y[m * N + n] = v;
