@@ -35,9 +35,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));  // raw 128-bit register tuple
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
-#ifndef H3_DEBUG_SYNC
-#define H3_DEBUG_SYNC 0
-#endif
 #define H3_NT 3
 #define H3_TOK (16 * H3_NT)
 #define H3_XT 56                    // halfs per feature row of the transposed X tile
@@ -217,7 +214,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
   float* up = scratch + 8;  // scratch[8] holds the current 2^s
   int rc;
   // stage index of the A / B stages of chunk `ch` in the pipelined order  A(0) | A(1) B(0) | ... | B(n-1)
-  auto a_off = [](int ch, int n, int A, int B) -> int64_t { return ch == 0 ? 0 : A + (int64_t)(ch - 1) * (A + B); };
+  auto a_off = [](int ch, int /*n*/, int A, int B) -> int64_t { return ch == 0 ? 0 : A + (int64_t)(ch - 1) * (A + B); };
   auto b_off = [](int ch, int n, int A, int B) -> int64_t { return A + (int64_t)ch * (A + B) + (ch < n - 1 ? A : 0); };
   for (int c = 0; c < d.n_coupling; ++c)
     for (int net = 0; net < 2; ++net) {
