@@ -413,40 +413,67 @@ __global__ void build_input_kernel(const float* __restrict__ emb, const int32_t*
 }
 
 // Y[M,N] = act(X[M,K] W[N,K]^T + b) on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32
-// accumulate).  Block = 4 waves = a 64 x 64 output tile; wave w owns rows 16w..16w+15 and all 64 columns (four
-// 16 x 16 accumulators); X and W tiles of 16 k-values are staged through LDS, k-major with a padded row
-// (conflict-free fragment reads: lanes read consecutive m / n for a fixed k).
+// accumulate).  Block = 4 waves = a 128 x 64 output tile; wave w owns rows 32w..32w+31 and all 64 columns (2 x 4
+// 16 x 16 accumulators, each A / B fragment reused 4 / 2 times); X and W tiles of 16 k-values are staged through LDS,
+// k-major with padded rows (fragment reads: lanes read consecutive m / n for a fixed k - conflict free).
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 typedef float lin_f4 __attribute__((ext_vector_type(4)));
+#define LIN_BM 128
+#define LIN_BN 64
 template <int ACT>
 __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                       const float* __restrict__ bias, float* __restrict__ Y,
                                                       int64_t M, int N, int K) {
-  __shared__ float xs[16][68];
-  __shared__ float wsh[16][68];
+  __shared__ float xs[16][LIN_BM + 4];
+  __shared__ float wsh[16][LIN_BN + 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int64_t m0 = (int64_t)blockIdx.y * 64;
-  const int n0 = blockIdx.x * 64;
-  lin_f4 acc[4];
+  const int64_t m0 = (int64_t)blockIdx.y * LIN_BM;
+  const int n0 = blockIdx.x * LIN_BN;
+  lin_f4 acc[2][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
+  const bool k_vec = (K % 4) == 0;  // rows of X / W are 16-byte aligned: stage with float4 loads
   for (int k0 = 0; k0 < K; k0 += 16) {
-    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
-      const int r = i / 16, kk = i % 16;
-      const int64_t m = m0 + r;
-      const int n = n0 + r;
-      xs[kk][r] = (m < M && k0 + kk < K) ? X[m * K + k0 + kk] : 0.f;
-      wsh[kk][r] = (n < N && k0 + kk < K) ? W[(int64_t)n * K + k0 + kk] : 0.f;
+    // 4 consecutive k of one row per thread-iteration
+    for (int i = threadIdx.x; i < (LIN_BM + LIN_BN) * 4; i += 256) {
+      const bool is_x = i < LIN_BM * 4;
+      const int r = (is_x ? i : i - LIN_BM * 4) / 4, kq = 4 * (i % 4);
+      const int64_t row = is_x ? m0 + r : (int64_t)n0 + r;
+      const bool row_ok = is_x ? row < M : row < N;
+      const float* src = (is_x ? X : W) + row * K + k0 + kq;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (row_ok) {
+        if (k_vec && k0 + kq + 3 < K) {
+          const lin_f4 q = *(const lin_f4*)src;
+          v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + kq + e < K) v[e] = src[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (is_x) xs[kq + e][r] = v[e];
+        else wsh[kq + e][r] = v[e];
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      // A fragment: lane (i16, g) holds X[m = 16 wave + i16][k = 4 ks + g]; B fragment: W[n = 16 j + i16][k = 4 ks + g]
-      const float a = xs[4 * ks + g][16 * wave + i16];
+      // A fragment: lane (i16, g) holds X[m][k = 4 ks + g]; B fragment: W[n = 16 j + i16][k = 4 ks + g]
+      float a[2], b[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wsh[4 * ks + g][16 * j + i16], acc[j], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) a[i] = xs[4 * ks + g][32 * wave + 16 * i + i16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = wsh[4 * ks + g][16 * j + i16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -457,20 +484,22 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X
     if (n >= N) continue;
     const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t m = m0 + 16 * wave + 4 * g + r;
-      if (m >= M) continue;
-      float v = acc[j][r] + bv;
-      if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
-      if (ACT == ACT_SILU) v = v / (1.f + expf(-v));
-      Y[m * N + n] = v;
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + 32 * wave + 16 * i + 4 * g + r;
+        if (m >= M) continue;
+        float v = acc[i][j][r] + bv;
+        if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+        if (ACT == ACT_SILU) v = v / (1.f + expf(-v));
+        Y[m * N + n] = v;
+      }
   }
 }
 
 static int launch_linear(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K,
                          int act, hipStream_t s) {
-  dim3 grid((N + 63) / 64, (unsigned)((M + 63) / 64));
+  dim3 grid((N + LIN_BN - 1) / LIN_BN, (unsigned)((M + LIN_BM - 1) / LIN_BM));
   if (act == ACT_NONE) hipLaunchKernelGGL(linear_kernel<ACT_NONE>, grid, dim3(256), 0, s, X, W, b, Y, M, N, K);
   else if (act == ACT_RELU) hipLaunchKernelGGL(linear_kernel<ACT_RELU>, grid, dim3(256), 0, s, X, W, b, Y, M, N, K);
   else hipLaunchKernelGGL(linear_kernel<ACT_SILU>, grid, dim3(256), 0, s, X, W, b, Y, M, N, K);
