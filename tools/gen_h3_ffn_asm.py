@@ -21,7 +21,9 @@ Stage order (must match h3_pack_weights):  A0(0) A1(0) | A0(c+1) A1(c+1) B0(c) B
 import os
 import sys
 
-# timing experiments only (results become wrong): comma-separated flags in H3_FFN_EXPERIMENT: noepi, nobarrier
+# experiments: comma-separated flags in H3_FFN_EXPERIMENT.  noepi, nobarrier: timing only (results become wrong).
+# pairsync: one barrier per PAIR of stages, both slots refilled after it - correct, but measured 2.5 % slower (the
+# refill then runs only two stages ahead of its use and the LDS-DMA latency shows).
 EXPERIMENT = set(filter(None, os.environ.get("H3_FFN_EXPERIMENT", "").split(",")))
 
 NT = 3
@@ -47,6 +49,7 @@ V_SC, V_T, V_TILE, V_AUX, V_SCADDR, V_GN, V_TMP, V_LANE16, V_G16 = 184, 186, 194
 YACC = lambda ot, jt: 4 * (3 * ot + jt)
 HACC = lambda o, jt: 72 + 4 * (3 * o + jt)   # VGPRs: the epilogue reads them without a v_accvgpr_read
 S_SC = 95
+S_PREV = 93   # pair-sync: slot of the first stage of a pair, released together with the second
 # scratch SGPRs (clobbered)
 S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT = 84, 85, 86, 88, 90, 92, 94  # pairs are even-aligned
 STAGE, TILES = 9216, 8192
@@ -144,6 +147,44 @@ def handoff(next_reads, with_aux, label):
     return h
 
 
+def handoff_light(label):
+    """Pair-sync, first stage of a pair: no barrier and no refill - remember the slot, move on, start reading the
+    partner stage (its DMA shares landed before the previous pair's barrier)."""
+    return [
+        f"s_mov_b32 s{S_PREV}, s{S_OFF}",
+        f"s_add_u32 s{S_OFF}, s{S_OFF}, {STAGE}",
+        [f"s_cmp_eq_u32 s{S_OFF}, s{S_END}", f"s_cselect_b32 s{S_OFF}, %[ring], s{S_OFF}"],
+        f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}",
+    ] + tile_reads(0) + tile_reads(1)
+
+
+def handoff_heavy(next_reads, label):
+    """Pair-sync, second stage of a pair (after the barrier): both slots of the pair are refilled."""
+    h = [
+        f"s_mov_b32 s{S_REL}, s{S_OFF}",
+        f"s_add_u32 s{S_OFF}, s{S_OFF}, {STAGE}",
+        [f"s_cmp_eq_u32 s{S_OFF}, s{S_END}", f"s_cselect_b32 s{S_OFF}, %[ring], s{S_OFF}"],
+    ]
+    if next_reads:
+        h += [f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}"] + tile_reads(0) + tile_reads(1)
+    for k, slot in enumerate((S_PREV, S_REL)):
+        h += [
+            f"s_add_u32 m0, s{slot}, s{S_W2048}",
+            "s_nop 0",
+            f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off",
+            f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off offset:1024",
+            ["s_cmp_lg_u32 %[wave], 0",
+             f"s_cbranch_scc1 .Lh3mlp_noaux_{label}{k}_%=",
+             f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
+             f"s_add_u32 m0, s{slot}, {TILES}",
+             "s_nop 0",
+             f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off",
+             f".Lh3mlp_noaux_{label}{k}_%=:"],
+            f"v_lshl_add_u64 {vr(V_GN, 2)}, {vr(V_GN, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]",
+        ]
+    return h
+
+
 def weave(mfmas, valu, misc, valu_per=2, misc_per=2):
     """Each MFMA is followed by up to `valu_per` VALU ops and `misc_per` other items, spread so the queues
     empty by the last MFMA (leftovers are appended)."""
@@ -198,10 +239,21 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     out += weave(groups[0], parts[0], first_misc, misc_per=3)
     out.append(f"s_waitcnt lgkmcnt({2 + aux})" if aux else "s_waitcnt lgkmcnt(2)")
     out += weave(groups[1], parts[1], tile_reads(3) if live[3] else [])
-    out.append("s_waitcnt vmcnt(6) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
-    if "nobarrier" not in EXPERIMENT:
-        out.append("s_barrier")
-    h = handoff(next_reads, with_aux, label)
+    pairsync = "pairsync" in EXPERIMENT and SHAPE["tag"] == "ffn"
+    if pairsync and o_or_b == 0:
+        out.append("s_waitcnt lgkmcnt(0)")
+        h = handoff_light(label)
+    elif pairsync:
+        # the two stages of the next pair must have landed; one younger stage may be in flight (2 DMAs, 3 for wave 0)
+        out += ["s_cmp_eq_u32 %[wave], 0", f"s_cbranch_scc1 .Lh3mlp_w0_{label}_%=", "s_waitcnt vmcnt(2) lgkmcnt(0)",
+                f"s_branch .Lh3mlp_w1_{label}_%=", f".Lh3mlp_w0_{label}_%=:", "s_waitcnt vmcnt(3) lgkmcnt(0)",
+                f".Lh3mlp_w1_{label}_%=:", "s_barrier"]
+        h = handoff_heavy(next_reads, label)
+    else:
+        out.append("s_waitcnt vmcnt(6) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
+        if "nobarrier" not in EXPERIMENT:
+            out.append("s_barrier")
+        h = handoff(next_reads, with_aux, label)
     if is_a0:
         h = [f"v_readfirstlane_b32 s{S_SC}, v{V_SC}"] + h   # aux block landed (lgkmcnt(0) above)
     out += weave(groups[2], parts[2], h, misc_per=3)
