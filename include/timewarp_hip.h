@@ -188,7 +188,7 @@ typedef struct {
   int32_t n_angles;     /* angle_idx [n_angles,3],      angle_par [n_angles,2] = (theta0, k)    */
   int32_t n_torsions;   /* torsion_idx [n_torsions,4],  torsion_par [n_torsions,3] = (n, phase, k) */
   int32_t n_exceptions; /* exc_idx [n_exceptions,2],    exc_par [n_exceptions,3] = (qq, sigma, eps); 1-2/1-3 have zeros */
-  int32_t has_gbsa;     /* GBSAOBCForce present */
+  int32_t has_gbsa;     /* 0: no implicit solvent; 1: GBSA-OBC II (GBSAOBCForce, amber99_obc.xml); 2: GBSA-OBC I (obc1.xml) */
   double cutoff;        /* nonbondedCutoff (nm); <= 0 means NoCutoff */
   double rf_dielectric; /* reaction-field dielectric (78.3 default; OpenMM uses 1.0 when GBSA is present) */
   double solute_dielectric, solvent_dielectric; /* GBSA: 1.0 / 78.5 */

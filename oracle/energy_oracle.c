@@ -108,7 +108,10 @@ static double energy_one(const oracle_ff* ff, const double* x, double* terms) {
     }
   free(excl);
   if (ff->has_gbsa) {
-    const double offset = 0.009, alpha = 1.0, beta = 0.8, gamma = 4.85, probe = 0.14;
+    const double offset = 0.009, probe = 0.14;
+    /* has_gbsa 1: OBC-II (GBSAOBCForce), 2: OBC-I (the tanh coefficients of OpenMM's implicit/obc1.xml) */
+    const double alpha = ff->has_gbsa == 2 ? 0.8 : 1.0, beta = ff->has_gbsa == 2 ? 0.0 : 0.8,
+                 gamma = ff->has_gbsa == 2 ? 2.909125 : 4.85;
     double* born = (double*)malloc(sizeof(double) * V);
     for (int i = 0; i < V; ++i) {
       double rad_i = ff->atom_par[5 * i + 3], off_i = rad_i - offset, sum = 0.0;

@@ -58,11 +58,16 @@ def oracle_energy(tables, coords):
     return out, terms
 
 
-def test_amber_energy_kernel_vs_c_oracle():
+@pytest.mark.parametrize("gb", [1, 2, 0])
+def test_amber_energy_kernel_vs_c_oracle(gb):
+    """gb = 1: GBSA-OBC II (amber99_obc.xml), 2: GBSA-OBC I (implicit/obc1.xml coefficients), 0: no implicit solvent."""
+    import dataclasses
     from timewarp_amd.energy import AmberPotentialEnergyTorch
 
     e = AmberPotentialEnergyTorch.alanine_dipeptide()
     assert abs(e.kbT - 2.57748) < 1e-4  # SURVEY a15: R * 310 K
+    if gb != 1:
+        e = AmberPotentialEnergyTorch(dataclasses.replace(e.tables, has_gbsa=gb))
     d, _ = H.load("kernel_full_ad")
     g = torch.Generator().manual_seed(1)
     x = d["x_coords"] + torch.randn(64, 22, 3, generator=g) * 0.01

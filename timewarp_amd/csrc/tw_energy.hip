@@ -119,9 +119,12 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
     e_nb += 4.0 * eps * (sr6 * sr6 - sr6);
     e_nb += TW_ONE_4PI_EPS0 * pi[0] * pj[0] * (use_cut ? (1.0 / r + krf * r2 - crf) : 1.0 / r);
   }
-  // GBSAOBCForce (OBC-II alpha=1 beta=0.8 gamma=4.85, dielectric offset 0.009 nm, probe 0.14 nm)
+  // GBSA-OBC (has_gbsa 1: OBC-II alpha=1 beta=0.8 gamma=4.85 = GBSAOBCForce / amber99_obc.xml; 2: OBC-I alpha=0.8
+  // beta=0 gamma=2.909125 = implicit/obc1.xml; dielectric offset 0.009 nm, probe 0.14 nm)
   if (ff.has_gbsa) {
-    const double offset = 0.009, alpha = 1.0, beta = 0.8, gamma = 4.85, probe = 0.14;
+    const double offset = 0.009, probe = 0.14;
+    const double alpha = ff.has_gbsa == 2 ? 0.8 : 1.0, beta = ff.has_gbsa == 2 ? 0.0 : 0.8,
+                 gamma = ff.has_gbsa == 2 ? 2.909125 : 4.85;
     for (int i = lane; i < V; i += 64) {
       const double rad_i = ff.atom_par[5 * i + 3];
       const double off_i = rad_i - offset;

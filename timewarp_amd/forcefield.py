@@ -39,7 +39,7 @@ class ForceFieldTables:
     exc_idx: np.ndarray       # [ne,2]
     exc_par: np.ndarray       # [ne,3] (qq, sigma, eps)
     atom_par: np.ndarray      # [V,5] (q, sigma, eps, gb_radius, gb_scale)
-    has_gbsa: bool = True
+    has_gbsa: int = 1  # 0: none, 1: GBSA-OBC II (GBSAOBCForce / amber99_obc.xml), 2: GBSA-OBC I (implicit/obc1.xml)
     cutoff: float = 2.0
     rf_dielectric: float = 1.0  # OpenMM sets the reaction-field dielectric to 1 when a GB force is present
     solute_dielectric: float = 1.0
@@ -210,7 +210,7 @@ def tables_from_openmm_system(system) -> ForceFieldTables:  # pragma: no cover -
     nm, kj, rad = u.nanometer, u.kilojoule_per_mole, u.radian
     out: Dict[str, list] = {k: [] for k in ("bi", "bp", "ai", "ap", "ti", "tp", "ei", "ep")}
     atom_par = np.zeros((system.getNumParticles(), 5))
-    kw = dict(has_gbsa=False, cutoff=0.0, rf_dielectric=78.3)
+    kw = dict(has_gbsa=0, cutoff=0.0, rf_dielectric=78.3)
     for force in system.getForces():
         if isinstance(force, openmm.HarmonicBondForce):
             for b in range(force.getNumBonds()):
@@ -236,13 +236,53 @@ def tables_from_openmm_system(system) -> ForceFieldTables:  # pragma: no cover -
                 kw["cutoff"] = force.getCutoffDistance().value_in_unit(nm)
             kw["rf_dielectric"] = force.getReactionFieldDielectric()
         elif isinstance(force, openmm.GBSAOBCForce):
-            kw["has_gbsa"] = True
+            kw["has_gbsa"] = 1
             for i in range(force.getNumParticles()):
                 _, radius, scale = force.getParticleParameters(i)
                 atom_par[i, 3:5] = (radius.value_in_unit(nm), scale)
             kw["solute_dielectric"] = force.getSoluteDielectric()
             kw["solvent_dielectric"] = force.getSolventDielectric()
             kw["surface_area_energy"] = force.getSurfaceAreaEnergy().value_in_unit(kj / nm**2)
+        elif isinstance(force, openmm.CustomGBForce):
+            # amber14's implicit/obc1.xml (T1B-peptides preset, simulation/md.py) builds GBSA-OBC I as a CustomGBForce
+            # (openmm.app.internal.customgbforces.GBSAOBC1Force): per-particle parameters (charge, or, sr) with
+            # or = radius - 0.009 nm and sr = scale * or; recognised by its tanh coefficients.  Untested here (no OpenMM).
+            exprs = " ".join(force.getComputedValueParameters(i)[1] for i in range(force.getNumComputedValues()))
+            if "2.909125" not in exprs:
+                raise NotImplementedError("CustomGBForce other than GBSA-OBC I (implicit/obc1.xml) is not supported")
+            kw["has_gbsa"] = 2
+            names = [force.getPerParticleParameterName(i) for i in range(force.getNumPerParticleParameters())]
+            for i in range(force.getNumParticles()):
+                par = dict(zip(names, force.getParticleParameters(i)))
+                o_r = par.get("or", par.get("radius"))
+                s_r = par.get("sr", par.get("scale"))
+                radius = o_r + 0.009 if "or" in par else o_r
+                scale = s_r / o_r if "sr" in par else s_r
+                atom_par[i, 3:5] = (radius, scale)
+            gp = {force.getGlobalParameterName(i): force.getGlobalParameterDefaultValue(i) for i in range(force.getNumGlobalParameters())}
+            kw["solute_dielectric"] = gp.get("soluteDielectric", 1.0)
+            kw["solvent_dielectric"] = gp.get("solventDielectric", 78.5)
+            kw["surface_area_energy"] = 2.25936
+        elif isinstance(force, openmm.CustomGBForce):
+            # amber14's implicit/obc1.xml (T1B-peptides preset, simulation/md.py) builds GBSA-OBC I as a CustomGBForce
+            # (openmm.app.internal.customgbforces.GBSAOBC1Force): per-particle parameters (charge, or, sr) with
+            # or = radius - 0.009 nm and sr = scale * or; recognised by its tanh coefficients.  Untested here (no OpenMM).
+            exprs = " ".join(force.getComputedValueParameters(i)[1] for i in range(force.getNumComputedValues()))
+            if "2.909125" not in exprs:
+                raise NotImplementedError("CustomGBForce other than GBSA-OBC I (implicit/obc1.xml) is not supported")
+            kw["has_gbsa"] = 2
+            names = [force.getPerParticleParameterName(i) for i in range(force.getNumPerParticleParameters())]
+            for i in range(force.getNumParticles()):
+                par = dict(zip(names, force.getParticleParameters(i)))
+                o_r = par.get("or", par.get("radius"))
+                s_r = par.get("sr", par.get("scale"))
+                radius = o_r + 0.009 if "or" in par else o_r
+                scale = s_r / o_r if "sr" in par else s_r
+                atom_par[i, 3:5] = (radius, scale)
+            gp = {force.getGlobalParameterName(i): force.getGlobalParameterDefaultValue(i) for i in range(force.getNumGlobalParameters())}
+            kw["solute_dielectric"] = gp.get("soluteDielectric", 1.0)
+            kw["solvent_dielectric"] = gp.get("solventDielectric", 78.5)
+            kw["surface_area_energy"] = 2.25936
     f = lambda a, w: np.asarray(a, dtype=np.float64).reshape(-1, w)
     g = lambda a, w: np.asarray(a, dtype=np.int32).reshape(-1, w)
     return ForceFieldTables(g(out["bi"], 2), f(out["bp"], 2), g(out["ai"], 3), f(out["ap"], 2), g(out["ti"], 4),
