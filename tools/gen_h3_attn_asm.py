@@ -137,8 +137,11 @@ def handoff(next_reads, label):
         "s_nop 0",
         f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off",
         f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off offset:1024",
-        # the stages fetched from here (five ahead) include the FFN's first A stage, which carries a bias/scale block
+        # Only the FFN's A0 stages carry a bias/scale block; the hand-offs that fetch them (five ahead) all belong to the
+        # layer's LAST head, so wave 0 moves the aux block there only and is not the straggler at every barrier.
         ["s_cmp_lg_u32 %[wave], 0",
+         f"s_cbranch_scc1 .Lh3att_noaux_{label}_%=",
+         f"s_cmp_lg_u32 s{S_CNT}, 1",
          f"s_cbranch_scc1 .Lh3att_noaux_{label}_%=",
          f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
          f"s_add_u32 m0, s{S_REL}, {TILES}",
@@ -283,16 +286,11 @@ def generate():
             vm = 18 if ks == 2 else 6   # the 12 fragment loads sit in the same queue behind the stage DMAs
         else:
             # mixing of (h + 1, 0): needs the new score fragments; skipped after the last head.  Newer than the 12
-            # fragment loads are the DMAs of two hand-offs: 4 for waves 1-3, up to 6 for wave 0 (aux blocks).
+            # fragment loads are the DMAs of two hand-offs: 4 for every wave (aux blocks move in the last head only,
+            # where this block is skipped).
             A(f"s_cmp_eq_u32 s{S_CNT}, 1")
             A("s_cbranch_scc1 .Lh3att_nomix_%=")
-            A("s_cmp_eq_u32 %[wave], 0")
-            A("s_cbranch_scc1 .Lh3att_w0_%=")
             A("s_waitcnt vmcnt(4)")
-            A("s_branch .Lh3att_w1_%=")
-            A(".Lh3att_w0_%=:")
-            A("s_waitcnt vmcnt(6)")
-            A(".Lh3att_w1_%=:")
             L += mixing_part(0, True)
             A(".Lh3att_nomix_%=:")
             vm = 6
