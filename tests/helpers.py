@@ -66,7 +66,8 @@ def tw_kernel_model(sd, emb=32, d_model=128, ff=2048, hidden=256, n_coupling=8, 
                              emb, [hidden], n_coupling, n_layers, enc))
     m = tw.model_constructor(cfg)
     m.load_state_dict(sd)
-    m.execution_path = path
+    if path is not None:  # None: keep the constructor's default (TW_EXECUTION_PATH)
+        m.execution_path = path
     return m.to(device).eval()
 
 
@@ -79,7 +80,8 @@ def tw_dense_model(sd, emb=32, d_model=128, ff=2048, hidden=256, n_coupling=8, n
         emb, d_model, [hidden], n_coupling, n_layers, tw.TransformerConfig(n_head, ff, 0.0), rff))
     m = tw.model_constructor(cfg)
     m.load_state_dict(sd)
-    m.execution_path = path
+    if path is not None:  # None: keep the constructor's default (TW_EXECUTION_PATH)
+        m.execution_path = path
     return m.to(device).eval()
 
 

@@ -164,6 +164,24 @@ def test_full_kernel_v60_golden(path):
     H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5)
 
 
+def test_preferred_split_fp16_path_falls_back_per_call(monkeypatch):
+    """TW_EXECUTION_PATH=h3: the split-fp16 kernel where it applies (22 atoms), the fp32 kernels elsewhere (60 atoms)."""
+    from timewarp_amd.modules import flow
+
+    monkeypatch.setenv("TW_EXECUTION_PATH", "h3")
+    m = H.tw_kernel_model(H.full_kernel_sd(), path=None)
+    assert m.execution_path == flow.PREFER_SPLIT_FP16
+    assert m._path_for(22) == H3 and m._path_for(60) == 0
+    d, _ = H.load("kernel_full_ad")
+    H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
+    assert m._dev_weights["h3"] is not None and m._dev_weights["f32"] is None  # the 22-atom calls ran on the h3 stream
+    d, _ = H.load("kernel_full_v60")
+    H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5)
+    assert m._dev_weights["f32"] is not None
+    dense = H.tw_dense_model(H.full_dense_sd(), path=None)
+    assert dense._path_for(22) == 0
+
+
 def test_full_dense_ad_golden():
     d, _ = H.load("dense_full_ad")
     m = H.tw_dense_model(H.full_dense_sd(), path=SIMPLE)

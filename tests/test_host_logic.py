@@ -87,6 +87,26 @@ def test_dense_constructor_keys_and_module_prefix():
         tw.model_constructor(tw.ModelConfig("equivariant_nvp"))
 
 
+def test_execution_path_from_environment(monkeypatch):
+    import timewarp_amd as tw
+    from timewarp_amd import _lib, synthetic
+    from timewarp_amd.modules import flow
+
+    cfg = synthetic.kernel_transformer_nvp_config()
+    monkeypatch.delenv("TW_EXECUTION_PATH", raising=False)
+    assert tw.model_constructor(cfg).execution_path == _lib.TW_PATH_AUTO
+    for name, want in [("f32", _lib.TW_PATH_FUSED), ("simple", _lib.TW_PATH_SIMPLE), ("H3", flow.PREFER_SPLIT_FP16)]:
+        monkeypatch.setenv("TW_EXECUTION_PATH", name)
+        assert tw.model_constructor(cfg).execution_path == want
+    m = tw.model_constructor(cfg)
+    assert m._path_for(22) == _lib.TW_PATH_FUSED_H3 and m._path_for(60) == _lib.TW_PATH_AUTO
+    monkeypatch.setenv("TW_EXECUTION_PATH", "fp8")
+    with pytest.raises(ValueError, match="TW_EXECUTION_PATH"):
+        tw.model_constructor(cfg)
+    # the atom counts that select the 48-token wave layout (csrc/tw_netblock.hip::fused_geom)
+    assert [flow._wave_tiles(v) for v in (12, 16, 22, 24, 48, 7, 30, 60, 64, 65)] == [3, 3, 3, 3, 3, 4, 4, 4, 4, 0]
+
+
 def test_holder_modules_refuse_to_compute():
     import timewarp_amd as tw
     from timewarp_amd import synthetic

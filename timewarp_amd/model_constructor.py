@@ -6,13 +6,16 @@ NVP flows on the sampling hot path and the Euler-Maruyama plumbing baseline; any
 `model_type` raises NotImplementedError exactly like the reference's final branch."""
 from __future__ import annotations
 
+import os
+from typing import Optional
+
 import torch.nn as nn
 
 from . import _lib
 from .model_configs import duck_get as g
 from .modules import layers as L
 from .modules.baselines import EulerMaruyamaGaussian
-from .modules.flow import ConditionalFlowDensityModel
+from .modules.flow import PREFER_SPLIT_FP16, ConditionalFlowDensityModel
 from .weights import DENSE, KERNEL, FlowDims
 
 ELEMENT_VOCAB = ("C", "H", "N", "O", "S")  # dataloader.py:24-25
@@ -33,6 +36,20 @@ def model_constructor(config) -> nn.Module:
     raise NotImplementedError(f"{model_type} is not a recognised model.")
 
 
+_PATH_NAMES = {"auto": _lib.TW_PATH_AUTO, "f32": _lib.TW_PATH_FUSED, "simple": _lib.TW_PATH_SIMPLE,
+               "h3": PREFER_SPLIT_FP16, "split_fp16": PREFER_SPLIT_FP16}
+
+
+def default_execution_path() -> int:
+    """Execution path of models built without an explicit one: the environment variable TW_EXECUTION_PATH
+    (auto | f32 | simple | h3), so that unmodified reference scripts can choose the kernel family.  "h3" is the
+    split-fp16 MFMA kernel where it applies (falls back to auto per call elsewhere); unset means auto (fp32 kernels)."""
+    name = os.environ.get("TW_EXECUTION_PATH", "auto").strip().lower()
+    if name not in _PATH_NAMES:
+        raise ValueError(f"TW_EXECUTION_PATH={name!r}: expected one of {sorted(_PATH_NAMES)}")
+    return _PATH_NAMES[name]
+
+
 def _density_flags(cfg):
     cfd = g(cfg, "conditional_flow_density")
     return (
@@ -50,7 +67,7 @@ def _single_hidden(cfg) -> int:
     return int(hidden[0])
 
 
-def custom_transformer_nvp_constructor(config, execution_path: int = _lib.TW_PATH_AUTO) -> ConditionalFlowDensityModel:
+def custom_transformer_nvp_constructor(config, execution_path: Optional[int] = None) -> ConditionalFlowDensityModel:
     """custom_transformer_nvp_constructor (model_constructor.py:153-197), attention_type 'kernel'."""
     n_coupling = int(g(config, "num_coupling_layers"))
     assert n_coupling % 2 == 0, "Real NVP should have an even number of coupling layers"
@@ -102,10 +119,11 @@ def custom_transformer_nvp_constructor(config, execution_path: int = _lib.TW_PAT
     srg, icv, disp = _density_flags(config)
     dims = FlowDims(KERNEL, n_coupling, n_layers, d_model, d_ff, hidden, emb, H, 0, len(ELEMENT_VOCAB), pos_mod,
                     disp, icv, bool(normalise), 1e-5, learnable_lengthscales=attention_type == "learnable_kernel", cheb_order=cheb_order, cheb_force_zero=cheb_zero)
-    return ConditionalFlowDensityModel(flow, dims, scale_requires_grad=srg, execution_path=execution_path)
+    path = default_execution_path() if execution_path is None else execution_path
+    return ConditionalFlowDensityModel(flow, dims, scale_requires_grad=srg, execution_path=path)
 
 
-def transformer_nvp_constructor(config, execution_path: int = _lib.TW_PATH_AUTO) -> ConditionalFlowDensityModel:
+def transformer_nvp_constructor(config, execution_path: Optional[int] = None) -> ConditionalFlowDensityModel:
     """transformer_nvp_constructor (model_constructor.py:200-238): dense softmax attention."""
     n_coupling = int(g(config, "num_coupling_layers"))
     assert n_coupling % 2 == 0, "Real NVP should have an even number of coupling layers"
@@ -137,4 +155,5 @@ def transformer_nvp_constructor(config, execution_path: int = _lib.TW_PATH_AUTO)
     srg, icv, disp = _density_flags(config)
     dims = FlowDims(DENSE, n_coupling, n_layers, d_model, d_ff, hidden, emb, n_head, enc_dim, len(ELEMENT_VOCAB),
                     pos_mod, disp, icv, True, 1e-5)
-    return ConditionalFlowDensityModel(flow, dims, scale_requires_grad=srg, execution_path=execution_path)
+    path = default_execution_path() if execution_path is None else execution_path
+    return ConditionalFlowDensityModel(flow, dims, scale_requires_grad=srg, execution_path=path)

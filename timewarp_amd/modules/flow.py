@@ -18,6 +18,27 @@ from ..weights import FlowDims, pack_raw, strip_module_prefix
 from .density_model_base import ConditionalDensityModel
 
 
+def _wave_tiles(n_atoms: int) -> int:
+    """Token tiles per wave the fused kernels pick for molecules of `n_atoms` (csrc/tw_netblock.hip::fused_geom): the
+    better filled of 3 and 4 tiles of 16 tokens; 0 if a molecule does not fit in 64 tokens."""
+    best, best_num, best_den = 0, -1, 1
+    if n_atoms <= 0 or n_atoms > 64:
+        return 0
+    for nt in (3, 4):
+        mpw = (16 * nt) // n_atoms
+        if mpw == 0:
+            continue
+        num, den = mpw * n_atoms, 16 * nt
+        if best == 0 or num * best_den > best_num * den:
+            best, best_num, best_den = nt, num, den
+    return best
+
+
+# execution_path value of ConditionalFlowDensityModel only (not a C-ABI path): the split-fp16 kernel where it applies
+# (kernel attention with the Gaussian basis, d_model 128, molecules that select the 48-token wave layout), else AUTO.
+PREFER_SPLIT_FP16 = -1
+
+
 class ConditionalFlowDensityModel(ConditionalDensityModel):
     def __init__(self, flow: nn.Module, dims: FlowDims, scale_requires_grad: bool = True,
                  execution_path: int = _lib.TW_PATH_AUTO):
@@ -46,7 +67,15 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         """Re-pack the device weight buffers after parameters were modified in place."""
         self._dirty = True
 
-    def _weights(self, device: torch.device):
+    def _path_for(self, n_atoms: int) -> int:
+        """The C-ABI execution path of a call on molecules of `n_atoms` atoms."""
+        if self.execution_path != PREFER_SPLIT_FP16:
+            return self.execution_path
+        desc = self.dims.to_desc()
+        ok = _lib.load().tw_flow_packed_h3_bytes(C.byref(desc)) > 0 and _wave_tiles(n_atoms) == 3
+        return _lib.TW_PATH_FUSED_H3 if ok else _lib.TW_PATH_AUTO
+
+    def _weights(self, device: torch.device, path: Optional[int] = None):
         """(raw, packed) device buffers; `packed` is the stream of the active execution path (the
         f32 fragment stream, or the split-fp16 stage stream for TW_PATH_FUSED_H3), built lazily."""
         if self.training:
@@ -63,7 +92,8 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         w = self._dev_weights
         lib = _lib.load()
         desc = self.dims.to_desc()
-        if self.execution_path == _lib.TW_PATH_FUSED_H3:
+        path = self.execution_path if path is None else path
+        if path == _lib.TW_PATH_FUSED_H3:
             if w["h3"] is None:
                 n = lib.tw_flow_packed_h3_bytes(C.byref(desc))
                 if n <= 0:
@@ -74,7 +104,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
                                                    _lib.stream_ptr(device)), "tw_flow_pack_h3")
                 w["h3"] = buf
             return w["raw"], w["h3"]
-        if w["f32"] is None and self.execution_path != _lib.TW_PATH_SIMPLE:
+        if w["f32"] is None and path != _lib.TW_PATH_SIMPLE:
             n = lib.tw_flow_packed_floats(C.byref(desc))
             if n > 0:
                 buf = torch.empty(n, dtype=torch.float32, device=device)
@@ -112,7 +142,8 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         at, mk, xc, xv, yc, yv = self._prep(atom_types, masked_elements, x_coords, x_velocs, y_coords, y_velocs)
         dev = xc.device
         B, V = xc.shape[0], xc.shape[1]
-        raw, packed = self._weights(dev)
+        path = self._path_for(V)
+        raw, packed = self._weights(dev, path)
         ws = self._ws(dev, B, V)
         out = torch.empty(B, dtype=torch.float32, device=dev)
         lib = _lib.load()
@@ -120,7 +151,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         with torch.cuda.device(dev):
             _lib.check(lib.tw_flow_log_likelihood(
                 C.byref(desc), raw.data_ptr(), _lib.ptr(packed), at.data_ptr(), xc.data_ptr(), xv.data_ptr(),
-                yc.data_ptr(), yv.data_ptr(), mk.data_ptr(), out.data_ptr(), B, V, self.execution_path,
+                yc.data_ptr(), yv.data_ptr(), mk.data_ptr(), out.data_ptr(), B, V, path,
                 ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "tw_flow_log_likelihood")
         return out
 
@@ -158,7 +189,8 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         zv = _lib.require_gpu_tensor(z_velocs.to(dev), torch.float32, "z_velocs")
         if tuple(zc.shape) != (S, B, V, 3) or tuple(zv.shape) != (S, B, V, 3):
             raise ValueError("z_coords / z_velocs must have shape [num_samples, B, V, 3]")
-        raw, packed = self._weights(dev)
+        path = self._path_for(V)
+        raw, packed = self._weights(dev, path)
         ws = self._ws(dev, S * B, V)
         y_c = torch.empty((S, B, V, 3), dtype=torch.float32, device=dev)
         y_v = torch.empty((S, B, V, 3), dtype=torch.float32, device=dev)
@@ -170,7 +202,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
             _lib.check(entry(
                 C.byref(desc), raw.data_ptr(), _lib.ptr(packed), at.data_ptr(), xc.data_ptr(), xv.data_ptr(),
                 mk.data_ptr(), zc.data_ptr(), zv.data_ptr(), y_c.data_ptr(), y_v.data_ptr(), logp.data_ptr(),
-                S, B, V, self.execution_path, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
+                S, B, V, path, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
                 "tw_flow_sample_with_logp")
         return y_c, y_v, logp
 
@@ -184,7 +216,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         dev = xc.device
         n_cond, V = xc.shape[0], xc.shape[1]
         N = zo.shape[0]
-        raw, packed = self._weights(dev)
+        raw, packed = self._weights(dev, path)
         ws = self._ws(dev, N, V)
         L, dm = self.dims.n_layers, self.dims.d_model
         dump = torch.zeros((L + 1) * N * V * dm + N * V * 3, dtype=torch.float32, device=dev)
