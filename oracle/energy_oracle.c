@@ -1,10 +1,9 @@
 /* CPU oracle for the AMBER-style potential energy.  TEST INFRASTRUCTURE ONLY.
  *
- * PARITY UNPINNED.  The reference obtains E_pot from OpenMM 7.7 (timewarp-environment.yml:22)
- * through bgflow (utils/openmm/openmm_bridge.py:11,17,206-221,281-294; the System is built in
- * simulation/md.py:128-187).  Neither package, nor OpenMM's force-field XML files, exist in the
- * reference tree or in this image, so this file restates the *published* Reference-platform
- * algorithms of OpenMM's forces from general knowledge:
+ * The reference obtains E_pot from OpenMM 7.7 (timewarp-environment.yml:22) through bgflow
+ * (utils/openmm/openmm_bridge.py:11,17,206-221,281-294; the System is built in simulation/md.py:128-187).  Neither
+ * package, nor OpenMM's force-field XML files, exist in the reference tree or in this image, so this file restates the
+ * published algorithms of OpenMM's forces:
  *   HarmonicBondForce      E = 1/2 k (r - r0)^2
  *   HarmonicAngleForce     E = 1/2 k (theta - theta0)^2
  *   PeriodicTorsionForce   E = k (1 + cos(n phi - phase))
@@ -12,10 +11,16 @@
  *                          inside the cutoff; exceptions (1-4) without cutoff / reaction field
  *   GBSAOBCForce           OBC-II Born radii (alpha 1, beta 0.8, gamma 4.85, offset 0.009 nm),
  *                          GB pair + self energy, ACE surface term 4 pi sigma (r+0.14)^2 (r/B)^6
- * The only known-answer data in the reference for this boundary (simulation/tests/test_md.py:35-83
- * against simulation/testdata/implicit-2olx-traj-cpu-arrays.npz) needs the full amber99sb-ildn
- * parameter set for NNQQ, which is not available here; therefore parity of this oracle (and of
- * the HIP kernel that is checked against it) with OpenMM is NOT established.
+ *
+ * PINNED (has_gbsa = 1, the amber99sbildn + amber99_obc preset of alanine dipeptide and T1-peptides) against the
+ * reference's own OpenMM known-answer data, simulation/testdata/implicit-2olx-traj-cpu-arrays.npz -- the file
+ * simulation/tests/test_md.py:35-83 checks OpenMM with: 40 frames of the 65-atom peptide NNQQ, E_pot and forces.
+ * With the parameter tables of timewarp_amd/forcefield.py this code reproduces the 40 energies to 2e-3 kJ/mol (of
+ * -1690) and the 7800 force components to 0.008 kJ/mol/nm rms (of 933), the float32 noise of the file
+ * (tests/test_energy_kat.py; analysis in tools/pin_energy/fit_2olx.py).  Two asparagine side-chain torsion series
+ * of those tables are fitted to the file (their ILDN values could not be recalled offline); every formula in this
+ * file and every other parameter is pinned independently of them (same test file).
+ * NOT pinned: has_gbsa = 2 (GBSA-OBC I coefficients of implicit/obc1.xml, amber14 preset) -- no known-answer data.
  *
  * Build: make -C oracle   ->  oracle/_build/libenergy_oracle.so
  */
@@ -168,5 +173,12 @@ int oracle_amber_energy(const oracle_ff* ff, const float* coords, double* out, d
     out[n] = energy_one(ff, x, terms ? terms + 5 * n : 0);
   }
   free(x);
+  return 0;
+}
+
+/* the same on float64 coordinates (finite-difference forces in tests/test_energy_kat.py) */
+int oracle_amber_energy_f64(const oracle_ff* ff, const double* coords, double* out, double* terms, int64_t n_rows) {
+  const int V = ff->n_atoms;
+  for (int64_t n = 0; n < n_rows; ++n) out[n] = energy_one(ff, coords + n * 3 * V, terms ? terms + 5 * n : 0);
   return 0;
 }

@@ -9,7 +9,7 @@ extension is missing).
 Pinning: `oracle/gen_golden.py` imports the real reference from /root/reference (in the
 build container only) and writes `tests/golden/*.npz`; `tests/test_oracle_golden.py`
 checks every function below against those vectors.  The oracle is therefore *pinned* for
-the flow (both attention variants).  See `energy_oracle.c` for the (unpinned) energy.
+the flow (both attention variants).  See `energy_oracle.c` for the energy.
 
 Every function cites the reference file:line (relative to /root/reference) it follows.
 All tensors are torch CPU tensors; weights come from a reference-named ``state_dict``

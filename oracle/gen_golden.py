@@ -426,6 +426,22 @@ def gen_chebyshev_golden():
         print(tag, "ok")
 
 
+def gen_energy_kat():
+    """(9) the reference's own known-answer data for the energy boundary, as data: the 40 frames of NNQQ that
+    simulation/tests/test_md.py:35-83 checks OpenMM against (positions, E_pot/E_kin, forces, velocities) plus the atom /
+    residue names of its state0 PDB (amber99sbildn + amber99_obc, preset T1-peptides = the alanine-dipeptide preset)."""
+    base = "/root/reference/simulation/testdata/implicit-2olx-traj-cpu-"
+    z = np.load(base + "arrays.npz")
+    names, res, rid, els = [], [], [], []
+    for line in open(base + "state0.pdb"):
+        if line.startswith(("ATOM", "HETATM")):
+            names.append(line[12:16].strip()); res.append(line[17:20].strip()); rid.append(int(line[22:26]))
+            els.append(line[76:78].strip())
+    np.savez_compressed(os.path.join(OUT, "energy_kat_2olx.npz"), positions=z["positions"], velocities=z["velocities"],
+                        forces=z["forces"], energies=z["energies"], atom_names=np.array(names),
+                        residue_names=np.array(res), residue_ids=np.array(rid, dtype=np.int32), elements=np.array(els))
+
+
 def tiny_kernel_model():
     torch.manual_seed(1234)
     tiny = kernel_model(emb=4, d_model=8, ff=16, mlp_hidden=[8], n_coupling=2, n_layers=2,
@@ -440,6 +456,9 @@ def main():
     if "--only-sob" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         gen_sob_golden(tiny_kernel_model())
+        return
+    if "--only-energy-kat" in sys.argv:
+        gen_energy_kat()
         return
     if "--only-cheb" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
@@ -591,6 +610,7 @@ def main():
     gen_sob_golden(tiny)
     gen_learnable_golden()
     gen_chebyshev_golden()
+    gen_energy_kat()
 
     # ---- (8) the reference's own smallest test molecule as data (testdata/smallest_molecule: 2 frames x 65 atoms,
     #          elements from PDB columns 77-78) for the config-0 plumbing test

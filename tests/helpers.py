@@ -1,5 +1,7 @@
 """Shared test helpers: golden loading and the name-seeded full-size weights."""
+import ctypes as C
 import os
+import subprocess
 
 import numpy as np
 import torch
@@ -119,3 +121,33 @@ def assert_case_close(out, d, prefix="", tol=1e-5):
         for k in ("s_logp", "logp_yx"):
             e = rel_err(out[k], d[prefix + k])
             assert e < tol, (k, e)
+
+
+# ---------------------------------------------------------------------------------------------
+# C energy oracle (oracle/energy_oracle.c)
+# ---------------------------------------------------------------------------------------------
+class _OracleFF(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_atoms", "n_bonds", "n_angles", "n_torsions", "n_exceptions", "has_gbsa")] + \
+               [(n, C.c_double) for n in ("cutoff", "rf_dielectric", "solute_dielectric", "solvent_dielectric", "surface_area_energy")] + \
+               [(n, C.c_void_p) for n in ("bond_idx", "bond_par", "angle_idx", "angle_par", "torsion_idx", "torsion_par", "exc_idx", "exc_par", "atom_par")]
+
+
+def oracle_energy(tables, coords, dtype=np.float32):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "_build", "libenergy_oracle.so")
+    if not os.path.exists(so):  # test infrastructure: gcc only
+        subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    lib = C.CDLL(so)
+    arrs = [np.ascontiguousarray(a) for a in (
+        tables.bond_idx.astype(np.int32), tables.bond_par, tables.angle_idx.astype(np.int32), tables.angle_par,
+        tables.torsion_idx.astype(np.int32), tables.torsion_par, tables.exc_idx.astype(np.int32), tables.exc_par, tables.atom_par)]
+    ff = _OracleFF(tables.n_atoms, len(arrs[0]), len(arrs[2]), len(arrs[4]), len(arrs[6]), int(tables.has_gbsa),
+                   tables.cutoff, tables.rf_dielectric, tables.solute_dielectric, tables.solvent_dielectric,
+                   tables.surface_area_energy, *[a.ctypes.data for a in arrs])
+    x = np.ascontiguousarray(coords, dtype=dtype)
+    n = x.shape[0]
+    out, terms = np.zeros(n), np.zeros((n, 5))
+    fn = lib.oracle_amber_energy if dtype == np.float32 else lib.oracle_amber_energy_f64
+    fn(C.byref(ff), x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                            terms.ctypes.data_as(C.c_void_p), C.c_int64(n))
+    return out, terms

@@ -1,8 +1,5 @@
 """The product MH loop (HIP) replayed on the reference's recorded traces, plus the energy kernel
 against the C oracle."""
-import ctypes as C
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -36,26 +33,7 @@ def test_sample_with_model_replays_reference(name):
     check_against_golden(z, name, coords, velocs, accepted, stats)
 
 
-class _OracleFF(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("n_atoms", "n_bonds", "n_angles", "n_torsions", "n_exceptions", "has_gbsa")] + \
-               [(n, C.c_double) for n in ("cutoff", "rf_dielectric", "solute_dielectric", "solvent_dielectric", "surface_area_energy")] + \
-               [(n, C.c_void_p) for n in ("bond_idx", "bond_par", "angle_idx", "angle_par", "torsion_idx", "torsion_par", "exc_idx", "exc_par", "atom_par")]
-
-
-def oracle_energy(tables, coords):
-    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libenergy_oracle.so"))
-    arrs = [np.ascontiguousarray(a) for a in (
-        tables.bond_idx.astype(np.int32), tables.bond_par, tables.angle_idx.astype(np.int32), tables.angle_par,
-        tables.torsion_idx.astype(np.int32), tables.torsion_par, tables.exc_idx.astype(np.int32), tables.exc_par, tables.atom_par)]
-    ff = _OracleFF(tables.n_atoms, len(arrs[0]), len(arrs[2]), len(arrs[4]), len(arrs[6]), int(tables.has_gbsa),
-                   tables.cutoff, tables.rf_dielectric, tables.solute_dielectric, tables.solvent_dielectric,
-                   tables.surface_area_energy, *[a.ctypes.data for a in arrs])
-    x = np.ascontiguousarray(coords, dtype=np.float32)
-    n = x.shape[0]
-    out, terms = np.zeros(n), np.zeros((n, 5))
-    lib.oracle_amber_energy(C.byref(ff), x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
-                            terms.ctypes.data_as(C.c_void_p), C.c_int64(n))
-    return out, terms
+oracle_energy = H.oracle_energy
 
 
 @pytest.mark.parametrize("gb", [1, 2, 0])

