@@ -167,12 +167,14 @@ def main():
 
     from timewarp_amd import _lib, distributed
 
-    rank, world, local = distributed.init_from_env("nccl")
+    # TW_DIST_BACKEND=gloo + one GPU shared by all ranks is a plumbing check of the N>1 path on a 1-GPU box
+    # (tools/README.md); the driver's runs use RCCL ("nccl") with one GPU per rank.
+    rank, world, local = distributed.init_from_env(os.environ.get("TW_DIST_BACKEND", "nccl"))
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count() if "TW_DIST_BACKEND" in os.environ else local)
     torch.cuda.set_device(device)
     lib = _lib.load()
 
