@@ -481,6 +481,7 @@ def make_template(
     lengthscales: Tuple[float, ...] = (0.1, 0.2, 0.5, 0.7, 1.0, 1.2),
     rff_dim: int = 0,
     n_elements: int = 5,
+    cheb_order: int = 0,
 ) -> StateDict:
     """Names and shapes of the reference state_dict, zeros except buffers.
     kernel: value_dim = d_model, heads = len(lengthscales) (custom_attention_encoder.py:170-189)."""
@@ -507,6 +508,8 @@ def make_template(
                 if spec.variant == "kernel":
                     q = f"{p}.encoder_layers.{l}"
                     t[f"{q}.self_attn.values_proj.weight"] = torch.zeros(h * d_model, d_model)
+                    if spec.attention_type == "chebyshev_kernel":  # kernel_attention.py:300-304
+                        t[f"{q}.self_attn.attention.cheb_coeffs"] = torch.zeros(h, cheb_order)
                     t[f"{q}.self_attn.attention.lengthscales"] = torch.tensor(lengthscales, dtype=torch.float32)
                     t[f"{q}.self_attn.attention._out_projection.weight"] = torch.zeros(d_model, h * d_model)
                 else:

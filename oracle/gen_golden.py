@@ -426,6 +426,29 @@ def gen_chebyshev_golden():
         print(tag, "ok")
 
 
+def gen_chebyshev_full_golden():
+    """Full-size chebyshev_kernel model (order 6) on alanine dipeptide, name-seeded weights (cheb_coeffs included, so
+    every attention layer has different coefficients): the case the fused kernels' per-layer score fragments need."""
+    ad_x, ad_t = ad_topology()
+    m = kernel_model(emb=32, d_model=128, ff=2048, mlp_hidden=[256], n_coupling=8, n_layers=3,
+                     lengthscales=[0.1, 0.2, 0.5, 0.7, 1.0, 1.2], attention_type="chebyshev_kernel", cheb_order=6,
+                     force_asymptotic_zero=True)
+    for name, p_ in list(m.named_parameters()):  # expand()ed parameter -> dense, so load_state_dict can write it
+        if name.endswith("cheb_coeffs"):
+            p_.data = p_.detach().clone()
+    m.load_state_dict(fo.synth_state_dict(m.state_dict(), base_seed=0))
+    g = torch.Generator().manual_seed(12)
+    x_c = ad_x[None].clone()
+    x_v = torch.randn(1, 22, 3, generator=g) * 0.5
+    mask = torch.zeros(1, 22, dtype=torch.bool)
+    y_c = x_c + torch.randn(1, 22, 3, generator=g) * 0.01
+    y_v = torch.randn(1, 22, 3, generator=g) * 0.5
+    d = base_inputs(ad_t[None], x_c, x_v, mask, y_c, y_v)
+    d.update(run_case(m, ad_t[None], x_c, x_v, mask, y_c, y_v, 8, 2025))
+    np.savez_compressed(os.path.join(OUT, "kernel_cheb_full_ad.npz"), **d)
+    print("kernel_cheb_full_ad ok")
+
+
 def gen_energy_kat():
     """(9) the reference's own known-answer data for the energy boundary, as data: the 40 frames of NNQQ that
     simulation/tests/test_md.py:35-83 checks OpenMM against (positions, E_pot/E_kin, forces, velocities) plus the atom /
@@ -459,6 +482,9 @@ def main():
         return
     if "--only-energy-kat" in sys.argv:
         gen_energy_kat()
+        return
+    if "--only-cheb-full" in sys.argv:
+        gen_chebyshev_full_golden()
         return
     if "--only-cheb" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
@@ -610,6 +636,7 @@ def main():
     gen_sob_golden(tiny)
     gen_learnable_golden()
     gen_chebyshev_golden()
+    gen_chebyshev_full_golden()
     gen_energy_kat()
 
     # ---- (8) the reference's own smallest test molecule as data (testdata/smallest_molecule: 2 frames x 65 atoms,

@@ -39,6 +39,16 @@ def full_kernel_sd(calibrated=False):
     return _cache[key]
 
 
+FULL_CHEB_SPEC = fo.FlowSpec(variant="kernel", attention_type="chebyshev_kernel", force_asymptotic_zero=True)
+
+
+def full_cheb_sd():
+    """Full-size chebyshev_kernel model, order 6, name-seeded (cheb_coeffs too: different in every attention layer)."""
+    if "c" not in _cache:
+        _cache["c"] = fo.synth_state_dict(fo.make_template(FULL_CHEB_SPEC, cheb_order=6), 0)
+    return _cache["c"]
+
+
 def full_dense_sd():
     if "d" not in _cache:
         _cache["d"] = fo.synth_state_dict(fo.make_template(FULL_DENSE_SPEC), 0)

@@ -92,12 +92,22 @@ def test_full_learnable_lengthscales_fused(path):
 
 @pytest.mark.parametrize("name,fz", [("kernel_cheb_tiny", False), ("kernel_cheb_zero_tiny", True)])
 def test_tiny_chebyshev_attention(name, fz):
-    """attention_type "chebyshev_kernel" (per-op path; the fused kernels decline it) against reference vectors."""
+    """attention_type "chebyshev_kernel" on the per-op path (tiny model: the fused kernels need d_model 128)."""
     d, sd = H.load(name)
     m = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2, lengthscales=(0.1, 0.5, 1.2),
                           path=0, attention_type="chebyshev_kernel", cheb_order=6, force_asymptotic_zero=fz)
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
     H.assert_case_close(H.run_model_case(m, d, "b1_"), d, "b1_", tol=TOL)
+
+
+@pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])
+def test_full_chebyshev_attention_all_paths(path):
+    """Full-size chebyshev_kernel model against reference vectors: the fused kernels take one score-fragment set per
+    (net, layer) of the coupling layer in flight, because every attention layer owns its coefficients."""
+    d, _ = H.load("kernel_cheb_full_ad")
+    m = H.tw_kernel_model(H.full_cheb_sd(), path=path, attention_type="chebyshev_kernel", cheb_order=6,
+                          force_asymptotic_zero=True)
+    H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
 
 
 def test_chebyshev_scores_kernel_vs_oracle():

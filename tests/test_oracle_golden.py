@@ -80,6 +80,12 @@ def test_kernel_full_ad(name, calibrated):
     _check_case(d, H.full_kernel_sd(calibrated), H.FULL_KERNEL_SPEC)
 
 
+def test_kernel_chebyshev_full_ad():
+    """Full-size chebyshev_kernel model with different coefficients in every attention layer (name-seeded)."""
+    d, _ = H.load("kernel_cheb_full_ad")
+    _check_case(d, H.full_cheb_sd(), H.FULL_CHEB_SPEC)
+
+
 def test_kernel_full_trace_and_scores():
     d, _ = H.load("kernel_full_ad")
     sd, spec = H.full_kernel_sd(), H.FULL_KERNEL_SPEC

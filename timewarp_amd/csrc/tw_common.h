@@ -113,6 +113,45 @@ struct FlowArgs {
   int64_t ws_bytes;
   hipStream_t stream;
 };
+// basis value for scaled distance sc: Gaussian exp(-sc^2), or sum_c coeff[c] R_c(sc^2) with the three-term recursion
+// of chebyshev_expansion (kernel_attention.py:37-66), evaluated in the same order as the reference's stacked terms
+__device__ __forceinline__ float basis_value(float sc, const float* __restrict__ coeff, int order, float coeff_mean) {
+  if (order <= 0) return expf(-(sc * sc));
+  const float x = sc * sc;
+  const float rf = (x - 1.0f) / (x + 1.0f);
+  float rprev = 1.0f, rcur = rf;
+  float acc = (coeff[0] - coeff_mean) * rprev;
+  if (order >= 2) acc += (coeff[1] - coeff_mean) * rcur;
+  for (int c = 2; c < order; ++c) {
+    const float rnext = 2.0f * rf * rcur - rprev;
+    acc += (coeff[c] - coeff_mean) * rnext;
+    rprev = rcur;
+    rcur = rnext;
+  }
+  return acc;
+}
+
+// Which basis the score-fragment producers of the fused paths evaluate.  order == 0: the Gaussian, one variant.
+// chebyshev_kernel: every attention layer of both nets of a coupling layer owns its coefficients, so a coupling
+// layer has 2 * n_layers variants; variant v = net * n_layers + layer reads coeff0 + net * net_stride + layer * layer_stride.
+struct ScoreBasis {
+  const float* coeff0;
+  int64_t net_stride, layer_stride;  // floats
+  int order, force_zero, n_layers, n_variants;
+};
+__device__ __forceinline__ const float* basis_coeffs(const ScoreBasis& b, int variant, int head, float* mean) {
+  *mean = 0.f;
+  if (b.order <= 0) return nullptr;
+  const float* cf = b.coeff0 + (variant / b.n_layers) * b.net_stride + (variant % b.n_layers) * b.layer_stride + (int64_t)head * b.order;
+  if (b.force_zero) {
+    float m = 0.f;
+    for (int c = 0; c < b.order; ++c) m += cf[c];
+    *mean = m / (float)b.order;
+  }
+  return cf;
+}
+ScoreBasis score_basis(const tw_flow_desc& d, const RawLayout& L, const float* raw, int coupling);
+
 int flow_pass_simple(const FlowArgs& a);
 int flow_pass_fused(const FlowArgs& a);
 int64_t simple_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms);

@@ -108,24 +108,6 @@ __device__ __forceinline__ float pair_distance(const float* x, int q, int m, int
   return sqrtf(fmaxf(acc, 0.f));
 }
 
-// basis value for scaled distance sc: Gaussian exp(-sc^2), or sum_c coeff[c] R_c(sc^2) with the three-term recursion
-// of chebyshev_expansion (kernel_attention.py:37-66), evaluated in the same order as the reference's stacked terms
-__device__ __forceinline__ float basis_value(float sc, const float* __restrict__ coeff, int order, float coeff_mean) {
-  if (order <= 0) return expf(-(sc * sc));
-  const float x = sc * sc;
-  const float rf = (x - 1.0f) / (x + 1.0f);
-  float rprev = 1.0f, rcur = rf;
-  float acc = (coeff[0] - coeff_mean) * rprev;
-  if (order >= 2) acc += (coeff[1] - coeff_mean) * rcur;
-  for (int c = 2; c < order; ++c) {
-    const float rnext = 2.0f * rf * rcur - rprev;
-    acc += (coeff[c] - coeff_mean) * rnext;
-    rprev = rcur;
-    rcur = rnext;
-  }
-  return acc;
-}
-
 __global__ void scores_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
                               const float* __restrict__ ls, int H, int V, int normalise, int use_mm,
                               float* __restrict__ out, const float* __restrict__ coeffs, int order, int force_zero) {
@@ -680,6 +662,19 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
   if ((rc = launch_linear(w.h0, nb + L.net.out2_w, nb + L.net.out2_b, out, M, 3, d.d_hidden, ACT_NONE, s))) return rc;
   if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump + (d.n_layers + 1) * act_sz, out, M * 3 * 4, hipMemcpyDeviceToDevice, s));
   return TW_OK;
+}
+
+ScoreBasis score_basis(const tw_flow_desc& d, const RawLayout& L, const float* raw, int coupling) {
+  ScoreBasis b{nullptr, 0, 0, 0, 0, d.n_layers, 1};
+  if (d.variant == 0 && d.cheb_order > 0) {
+    b.coeff0 = raw + net_base(L, coupling, 0) + L.net.layers + L.layer.cheb;
+    b.net_stride = net_base(L, coupling, 1) - net_base(L, coupling, 0);
+    b.layer_stride = L.layer.size;
+    b.order = d.cheb_order;
+    b.force_zero = d.cheb_force_zero;
+    b.n_variants = 2 * d.n_layers;
+  }
+  return b;
 }
 
 static int simple_scores(const FlowArgs& a, const RawLayout& L, const SimpleWs& w) {

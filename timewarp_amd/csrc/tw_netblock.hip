@@ -226,7 +226,8 @@ __device__ __forceinline__ float pair_dist(const float* x, int q, int m, int use
 
 __global__ void score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
                                   const float* __restrict__ ls, int H, int V, int mpw, int nt, int64_t n_rows,
-                                  int64_t n_cond, int normalise, int use_mm, float* __restrict__ sfrag) {
+                                  int64_t n_cond, int normalise, int use_mm, float* __restrict__ sfrag, ScoreBasis basis,
+                                  int64_t variant_floats) {
   extern __shared__ float sm[];
   float* xs = sm;                        // [mpw][V*3]
   float* dist = xs + mpw * V * 3;        // [mpw][V*V]
@@ -254,10 +255,12 @@ __global__ void score_frag_kernel(const float* __restrict__ x, const uint8_t* __
   for (int i = threadIdx.x; i < mpw * H * V; i += blockDim.x) {
     const int q = i / (H * V), h = (i / V) % H, a = i % V;
     const float l = ls[h];
+    float cmean;
+    const float* cf = basis_coeffs(basis, blockIdx.y, h, &cmean);  // grid.y = basis variant (chebyshev_kernel: net x layer)
     float sum = 0.f;
     for (int m = 0; m < V; ++m) {
       float sc = dist[(q * V + a) * V + m] / l;
-      float e = msk[q * V + m] ? 0.f : expf(-(sc * sc));
+      float e = msk[q * V + m] ? 0.f : basis_value(sc, cf, basis.order, cmean);
       sum += fabsf(e);
     }
     denom[i] = sum + 1e-5f;
@@ -265,7 +268,7 @@ __global__ void score_frag_kernel(const float* __restrict__ x, const uint8_t* __
   __syncthreads();
   const int ntt = nt * nt;
   const int total = H * ntt * 64 * 4;
-  float* out = sfrag + blk * (int64_t)total;
+  float* out = sfrag + blockIdx.y * variant_floats + blk * (int64_t)total;
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const int sp = i & 3, lane = (i >> 2) & 63, tile = (i >> 8) % ntt, h = i / (ntt * 256);
     const int jt = tile / nt, mt = tile % nt;
@@ -275,8 +278,10 @@ __global__ void score_frag_kernel(const float* __restrict__ x, const uint8_t* __
     if (mq == mk && mq < mpw) {
       const int a = tq % V, m = tk % V;
       if (!msk[mq * V + m]) {
+        float cmean;
+        const float* cf = basis_coeffs(basis, blockIdx.y, h, &cmean);
         float sc = dist[(mq * V + a) * V + m] / ls[h];
-        float e = expf(-(sc * sc));
+        float e = basis_value(sc, cf, basis.order, cmean);
         val = normalise ? e / denom[(mq * H + h) * V + a] : e;
       }
     }
@@ -299,6 +304,7 @@ struct NBParams {
   const float* z_other;
   const float* sfrag;
   int sfrag_shared;
+  int64_t sf_variant_floats;  // chebyshev_kernel: floats between the fragment sets of (net, layer) variants; else 0
   float* out[2];
   float* dump;
   int64_t n_rows, n_cond;
@@ -508,10 +514,12 @@ netblock_kernel(const NBParams p) {
   }
   dump_x(x, 0);
 
-  const float* sf_base = p.sfrag + (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * NT * TILE_F) + lane * 4;
+  const float* sf_net = p.sfrag + (int64_t)(net * p.n_layers) * p.sf_variant_floats +
+                        (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * NT * TILE_F) + lane * 4;
 
   // ---- encoder layers ---------------------------------------------------------------------------
   for (int l = 0; l < p.n_layers; ++l) {
+    const float* sf_base = sf_net + l * p.sf_variant_floats;  // the layer's own score fragments (chebyshev_kernel), else shared
     const float* sl = side + p.side_layers + (int64_t)l * p.side_layer_size;
     // x -> LDS (token-major) so the mixing MFMA can read it as an A operand
 #pragma unroll
@@ -680,7 +688,8 @@ static FusedWs fused_ws(const tw_flow_desc& d, int64_t n_rows, int V, int64_t n_
   w.s_out = take(n_rows * V * 3);
   w.t_out = take(n_rows * V * 3);
   w.nblk_scores = nblocks;  // sized for the per-block case; the shared case uses 1
-  w.sfrag = take(nblocks * d.n_heads * g.nt * g.nt * TILE_F);
+  // chebyshev_kernel: one fragment set per (net, layer) of the coupling layer in flight
+  w.sfrag = take((d.cheb_order > 0 ? 2 * d.n_layers : 1) * nblocks * d.n_heads * g.nt * g.nt * TILE_F);
   (void)n_cond;
   w.bytes = p - (char*)base;
   return w;
@@ -690,21 +699,27 @@ int64_t fused_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms
   return fused_ws(d, n_rows, n_atoms, n_rows, nullptr).bytes;
 }
 
-static int launch_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom& g, float* sfrag, bool shared) {
+// Score fragments of coupling layer c.  With the Gaussian basis they do not depend on c (one call per flow pass);
+// chebyshev_kernel needs them per coupling layer: 2 * n_layers variants, `*variant_floats` apart (0 if one variant).
+static int launch_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom& g, float* sfrag, bool shared, int c,
+                              int64_t* variant_floats) {
   const tw_flow_desc& d = *a.desc;
   const int V = a.n_atoms;
   const int64_t nblocks = shared ? 1 : (a.n_rows + g.mpw - 1) / g.mpw;
+  const ScoreBasis basis = score_basis(d, L, a.raw, c);
+  const int64_t vf = basis.n_variants > 1 ? nblocks * d.n_heads * g.nt * g.nt * TILE_F : 0;
   size_t shm = (size_t)(g.mpw * V * 3 + g.mpw * V * V + g.mpw * d.n_heads * V) * 4 + (size_t)g.mpw * V;
-  hipLaunchKernelGGL(score_frag_kernel, dim3((unsigned)nblocks), dim3(256), shm, a.stream, a.x_coords, a.masked,
-                     a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, V, g.mpw, g.nt, a.n_rows, a.n_cond, d.normalise, V > 25,
-                     sfrag);
+  hipLaunchKernelGGL(score_frag_kernel, dim3((unsigned)nblocks, (unsigned)basis.n_variants), dim3(256), shm, a.stream, a.x_coords,
+                     a.masked, a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, V, g.mpw, g.nt, a.n_rows, a.n_cond,
+                     d.normalise, V > 25, sfrag, basis, vf);
   TW_LAUNCH_CHECK();
+  *variant_floats = vf;
   return TW_OK;
 }
 
 static int launch_netblock(const FlowArgs& a, const RawLayout& L, const FusedGeom& g, int c, int net_sel,
-                           const float* z_other, const float* sfrag, bool shared, float* s_out, float* t_out,
-                           float* dump) {
+                           const float* z_other, const float* sfrag, int64_t sf_variant_floats, bool shared, float* s_out,
+                           float* t_out, float* dump) {
   const tw_flow_desc& d = *a.desc;
   const StreamGeom sg = stream_geom(d);
   const PackedLayout P = packed_layout(d);
@@ -725,6 +740,7 @@ static int launch_netblock(const FlowArgs& a, const RawLayout& L, const FusedGeo
   p.z_other = z_other;
   p.sfrag = sfrag;
   p.sfrag_shared = shared ? 1 : 0;
+  p.sf_variant_floats = sf_variant_floats;
   p.out[0] = s_out;
   p.out[1] = t_out;
   p.dump = dump;
@@ -778,13 +794,15 @@ int flow_pass_fused(const FlowArgs& a) {
   }
   const bool shared = a.n_cond == 1;  // every conformation is conditioned on the same x: one fragment set
   int rc;
-  if ((rc = launch_score_frags(a, L, g, w.sfrag, shared))) return rc;
+  int64_t vf = 0;
+  if (d.cheb_order == 0 && (rc = launch_score_frags(a, L, g, w.sfrag, shared, 0, &vf))) return rc;
   for (int i = 0; i < d.n_coupling; ++i) {
     const int c = a.reverse ? d.n_coupling - 1 - i : i;
     const bool positions = (c % 2) == d.pos_mod2;
     const float* z_other = positions ? a.z_velocs : a.z_coords;
     float* z_t = positions ? a.z_coords : a.z_velocs;
-    if ((rc = launch_netblock(a, L, g, c, -1, z_other, w.sfrag, shared, w.s_out, w.t_out, nullptr))) return rc;
+    if (d.cheb_order > 0 && (rc = launch_score_frags(a, L, g, w.sfrag, shared, c, &vf))) return rc;
+    if ((rc = launch_netblock(a, L, g, c, -1, z_other, w.sfrag, vf, shared, w.s_out, w.t_out, nullptr))) return rc;
     if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, z_t, a.delta_logp, a.n_rows, a.n_atoms, a.reverse,
                               a.stream)))
       return rc;
@@ -804,8 +822,9 @@ int debug_netblock_fused(const FlowArgs& a, int c, int net, const float* z_other
   }
   const bool shared = a.n_cond == 1;
   int rc;
-  if ((rc = launch_score_frags(a, L, g, w.sfrag, shared))) return rc;
-  return launch_netblock(a, L, g, c, net, z_other, w.sfrag, shared, w.s_out, w.t_out, dump);
+  int64_t vf = 0;
+  if ((rc = launch_score_frags(a, L, g, w.sfrag, shared, c, &vf))) return rc;
+  return launch_netblock(a, L, g, c, net, z_other, w.sfrag, vf, shared, w.s_out, w.t_out, dump);
 }
 
 }  // namespace tw

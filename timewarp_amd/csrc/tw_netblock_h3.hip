@@ -93,7 +93,7 @@ int64_t h3_packed_bytes(const tw_flow_desc& d) {
 
 bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom fg;
-  return d.variant == 0 && d.cheb_order == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
+  return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
          fused_geom(n_atoms, &fg) && fg.nt == H3_NT;
 }
 
@@ -321,7 +321,8 @@ __device__ __forceinline__ float h3_pair_dist(const float* x, int q, int m) {
 
 __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
                                      const float* __restrict__ ls, int H, int V, int mpw, int64_t n_rows,
-                                     int64_t n_cond, int normalise, char* __restrict__ sfrag) {
+                                     int64_t n_cond, int normalise, char* __restrict__ sfrag, ScoreBasis basis,
+                                     int64_t variant_bytes) {
   extern __shared__ float sm[];
   float* xs = sm;
   float* dist = xs + mpw * V * 3;
@@ -344,14 +345,17 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
     dist[i] = h3_pair_dist(xs + q * V * 3, r / V, r % V);
   }
   __syncthreads();
-  // grid.y = head: every block recomputes the (cheap) distances and handles the fragments of its own head
+  // grid.y = head, grid.z = basis variant (chebyshev_kernel: net x layer): every block recomputes the (cheap)
+  // distances and handles the fragments of its own head and variant
   const int h = blockIdx.y;
+  float cmean;
+  const float* cf = basis_coeffs(basis, blockIdx.z, h, &cmean);
   for (int i = threadIdx.x; i < mpw * V; i += blockDim.x) {
     const int q = i / V, a = i % V;
     float sum = 0.f;
     for (int m = 0; m < V; ++m) {
       float sc = dist[(q * V + a) * V + m] / ls[h];
-      float e = msk[q * V + m] ? 0.f : expf(-(sc * sc));
+      float e = msk[q * V + m] ? 0.f : basis_value(sc, cf, basis.order, cmean);
       sum += fabsf(e);
     }
     denom[(q * H + h) * V + a] = sum + 1e-5f;
@@ -359,7 +363,7 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
   __syncthreads();
   // one thread per (jt, lane, key slot 0..11): slots 0..7 -> k-step 0, 8..11 -> k-step 1
   const int total = H3_NT * 64 * 12;
-  char* out = sfrag + blk * (int64_t)H * H3_NT * H3_SF_BYTES;
+  char* out = sfrag + blockIdx.z * variant_bytes + blk * (int64_t)H * H3_NT * H3_SF_BYTES;
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const int slot = i % 12, lane = (i / 12) % 64, jt = i / (12 * 64);
     const int tq = 16 * jt + (lane & 15);
@@ -370,7 +374,7 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
       const int a = tq % V, m = tk % V;
       if (!msk[mq * V + m]) {
         float sc = dist[(mq * V + a) * V + m] / ls[h];
-        float e = expf(-(sc * sc));
+        float e = basis_value(sc, cf, basis.order, cmean);
         val = normalise ? e / denom[(mq * H + h) * V + a] : e;
       }
     }
@@ -402,6 +406,7 @@ struct H3Params {
   const float* z_other;
   const char* sfrag;
   int sfrag_shared;
+  int64_t sf_variant_bytes;  // chebyshev_kernel: bytes between the fragment sets of (net, layer) variants; else 0
   float* out[2];
   float* dump;
   int64_t n_rows, n_cond;
@@ -894,10 +899,12 @@ netblock_h3_kernel(const H3Params p) {
   if (!(p.debug & 16)) dump_x(x, 0);
   stamp(1);
 
-  const char* sf_base = p.sfrag + (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * H3_SF_BYTES);
+  const char* sf_net = p.sfrag + (int64_t)(net * p.n_layers) * p.sf_variant_bytes +
+                       (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * H3_SF_BYTES);
 
   const float* sl = (const float*)(lds + H3_SIDE_LDS_OFFSET);  // this layer's side block, staged in LDS
   for (int l = 0; l < p.n_layers; ++l) {
+    const char* sf_base = sf_net + l * p.sf_variant_bytes;  // the layer's own score fragments (chebyshev_kernel), else shared
     // Stage the layer's LayerNorm parameters, FFN output bias and the two output scales (2.6 KB) in LDS: wave 0
     // issues three 1 KiB LDS-DMA chunks and nobody waits for them here - they are older than every weight-stage
     // DMA of the layer, so the first stage hand-off (vmcnt wait + barrier) covers them long before the first use.
@@ -1167,6 +1174,7 @@ netblock_h3_kernel(const H3Params p) {
 struct H3Ws {
   float *s_out, *t_out;
   char* sfrag;
+  int64_t sf_variant_bytes;  // per-block layout: bytes of one fragment set over all blocks
   int64_t bytes;
 };
 
@@ -1183,8 +1191,11 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
   const int64_t nblocks = (n_rows + g.mpw - 1) / g.mpw;
   w.s_out = (float*)take(n_rows * V * 3 * 4);
   w.t_out = (float*)take(n_rows * V * 3 * 4);
+  // chebyshev_kernel: one fragment set per (net, layer) of the coupling layer in flight
   // + one head of slack: the attention asm block prefetches the "next head" also after the last one
-  w.sfrag = take((nblocks * d.n_heads + 1) * H3_NT * H3_SF_BYTES);
+  const int64_t variants = d.cheb_order > 0 ? 2 * d.n_layers : 1;
+  w.sf_variant_bytes = nblocks * d.n_heads * H3_NT * H3_SF_BYTES;
+  w.sfrag = take(variants * w.sf_variant_bytes + H3_NT * H3_SF_BYTES);
   w.bytes = p - (char*)base;
   return w;
 }
@@ -1196,7 +1207,7 @@ int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms) {
 }
 
 static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg, int c, int net_sel, const float* z_other,
-                     const char* sfrag, bool shared, float* s_out, float* t_out, float* dump) {
+                     const char* sfrag, int64_t sf_variant_bytes, bool shared, float* s_out, float* t_out, float* dump) {
   const tw_flow_desc& d = *a.desc;
   const H3Geom g = h3_geom(d);
   H3Params p;
@@ -1215,6 +1226,7 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.z_other = z_other;
   p.sfrag = sfrag;
   p.sfrag_shared = shared ? 1 : 0;
+  p.sf_variant_bytes = sf_variant_bytes;
   p.out[0] = s_out;
   p.out[1] = t_out;
   p.dump = dump;
@@ -1252,14 +1264,21 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   return TW_OK;
 }
 
-static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg, char* sfrag, bool shared) {
+// Score fragments of coupling layer c.  With the Gaussian basis they do not depend on c (one call per flow pass);
+// chebyshev_kernel needs them per coupling layer: 2 * n_layers variants, `*variant_bytes` apart (0 if one variant).
+static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg, const H3Ws& w, bool shared, int c,
+                          int64_t* variant_bytes) {
   const tw_flow_desc& d = *a.desc;
   const int V = a.n_atoms;
   const int64_t nblocks = shared ? 1 : (a.n_rows + fg.mpw - 1) / fg.mpw;
+  const ScoreBasis basis = score_basis(d, L, a.raw, c);
+  const int64_t vb = basis.n_variants > 1 ? nblocks * d.n_heads * H3_NT * H3_SF_BYTES : 0;
   size_t shm = (size_t)(fg.mpw * V * 3 + fg.mpw * V * V + fg.mpw * d.n_heads * V) * 4 + (size_t)fg.mpw * V;
-  hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks, (unsigned)d.n_heads), dim3(256), shm, a.stream, a.x_coords, a.masked,
-                     a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, V, fg.mpw, a.n_rows, a.n_cond, d.normalise, sfrag);
+  hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks, (unsigned)d.n_heads, (unsigned)basis.n_variants), dim3(256), shm,
+                     a.stream, a.x_coords, a.masked, a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, V, fg.mpw,
+                     a.n_rows, a.n_cond, d.normalise, w.sfrag, basis, vb);
   TW_LAUNCH_CHECK();
+  *variant_bytes = vb;
   return TW_OK;
 }
 
@@ -1275,13 +1294,15 @@ int flow_pass_h3(const FlowArgs& a) {
   }
   const bool shared = a.n_cond == 1;
   int rc;
-  if ((rc = h3_score_frags(a, L, fg, w.sfrag, shared))) return rc;
+  int64_t vb = 0;
+  if (d.cheb_order == 0 && (rc = h3_score_frags(a, L, fg, w, shared, 0, &vb))) return rc;
   for (int i = 0; i < d.n_coupling; ++i) {
     const int c = a.reverse ? d.n_coupling - 1 - i : i;
     const bool positions = (c % 2) == d.pos_mod2;
     const float* z_other = positions ? a.z_velocs : a.z_coords;
     float* z_t = positions ? a.z_coords : a.z_velocs;
-    if ((rc = h3_launch(a, L, fg, c, -1, z_other, w.sfrag, shared, w.s_out, w.t_out, nullptr))) return rc;
+    if (d.cheb_order > 0 && (rc = h3_score_frags(a, L, fg, w, shared, c, &vb))) return rc;
+    if ((rc = h3_launch(a, L, fg, c, -1, z_other, w.sfrag, vb, shared, w.s_out, w.t_out, nullptr))) return rc;
     if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, z_t, a.delta_logp, a.n_rows, a.n_atoms, a.reverse,
                               a.stream)))
       return rc;
@@ -1301,8 +1322,9 @@ int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, f
   }
   const bool shared = a.n_cond == 1;
   int rc;
-  if ((rc = h3_score_frags(a, L, fg, w.sfrag, shared))) return rc;
-  return h3_launch(a, L, fg, c, net, z_other, w.sfrag, shared, w.s_out, w.t_out, dump);
+  int64_t vb = 0;
+  if ((rc = h3_score_frags(a, L, fg, w, shared, c, &vb))) return rc;
+  return h3_launch(a, L, fg, c, net, z_other, w.sfrag, vb, shared, w.s_out, w.t_out, dump);
 }
 
 }  // namespace tw
