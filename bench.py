@@ -67,6 +67,49 @@ def build_chain(device, seed, proposals, path):
     return chain, model
 
 
+def attention_block(model, device, proposals, avg_launch_ms):
+    """The north-star's second figure: algorithmic FLOP rate of the attention block (values_proj + A.V + out_proj,
+    SURVEY 8d) against the bf16/f16 dense MFMA peak.  Measured on one extra, untimed launch of the dominant kernel with
+    its s_memtime section stamps switched on (tw_debug_set_flags bit 4; wave 0 of workgroup 0 stamps the shader clock at
+    the section boundaries): share of the launch spent in the attention sections x the live average launch time."""
+    from timewarp_amd import _lib, synthetic
+
+    types, coords, _ = synthetic.alanine_dipeptide_state()
+    g = torch.Generator().manual_seed(5)
+    at = types[None].to(device)
+    xc = (coords - coords.mean(0, keepdim=True))[None].to(device)
+    xv = (torch.randn(1, V_ATOMS, 3, generator=g) * 0.5).to(device)
+    zo = (torch.randn(proposals, V_ATOMS, 3, generator=g) * 0.5).to(device)
+    mask = torch.zeros(1, V_ATOMS, dtype=torch.bool, device=device)
+    lib = _lib.load()
+    lib.tw_debug_set_flags(16)
+    try:
+        for _ in range(2):
+            acts, _ = model.debug_netblock(0, 0, at, xc, xv, mask, zo, _lib.TW_PATH_FUSED_H3)
+        torch.cuda.synchronize()
+    finally:
+        lib.tw_debug_set_flags(0)
+    n_layers = model.dims.n_layers
+    ts = acts.reshape(-1)[:64].contiguous().view(torch.int64).cpu().tolist()
+    # stamps: 0 start, 1 in_mlp, then per layer (attention, add+LN1, FFN, add+LN2), out_mlp
+    total = ts[2 + 4 * n_layers] - ts[0]
+    att = sum(ts[2 + 4 * l] - ts[1 + 4 * l] for l in range(n_layers))
+    share = att / total
+    d = model.dims
+    flop_token_layer = 2 * d.d_model * d.n_heads * d.d_model * 2 + 2 * d.n_heads * V_ATOMS * d.d_model
+    flop_launch = flop_token_layer * n_layers * 2 * proposals * V_ATOMS  # both coupling nets of one coupling layer
+    achieved = flop_launch / (share * avg_launch_ms * 1e-3) / 1e12
+    return {
+        "what": "values_proj + A.V + out_proj of all encoder layers (SURVEY 8d), algorithmic FLOPs / time in the attention "
+                "sections of the dominant kernel",
+        "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F16_MFMA_PEAK_TFLOPS,
+        "share_of_launch": share, "algorithmic_flop_per_launch": float(flop_launch),
+        "executed_over_algorithmic": "2.26 (3-term fp16 split x 1/2 from folding out_proj into values_proj per head "
+                                     "+ the K=48 block-diagonal mixing on K=32+16 MFMAs)",
+        "method": "s_memtime section stamps of one untimed launch (tw_debug_set_flags 16) x live average launch time",
+    }
+
+
 def cpu_baseline(proposals):
     """The oracle (oracle/flow_oracle.py + oracle/mh_oracle.py + oracle/energy_oracle.c) on this
     box's host cores: full 1000-proposal MH iterations, bounded to ~10-30 s of CPU work."""
@@ -271,6 +314,8 @@ def main():
                 "algorithmic_flop_per_launch": flop_per_launch,
             },
         }
+        if args.path == "h3" and args.proposals == S_PROPOSALS:
+            out["roofline"]["attention_block"] = attention_block(model, device, args.proposals, avg_ms)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.proposals)
         print(json.dumps(out), flush=True)
