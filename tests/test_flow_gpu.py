@@ -232,6 +232,50 @@ def test_fused_batched_padding_vs_oracle(V, lens):
         assert abs(float(one[0] - out[1])) < 1e-4 * max(1.0, abs(float(out[1])))
 
 
+@pytest.mark.parametrize("V,lens,paths", [(64, [64, 51], (FUSED, SIMPLE)), (70, [70, 44, 70], (0, SIMPLE)), (100, [100, 87], (0,))])
+def test_large_molecules_vs_oracle(V, lens, paths):
+    """Maximum sizes: 64 atoms is the largest molecule a fused wave holds (4 tiles); beyond it TW_PATH_AUTO has to fall
+    back to the per-op path.  All above 25 atoms, so the scores follow torch.cdist's matmul branch."""
+    sd = H.full_kernel_sd()
+    g = torch.Generator().manual_seed(300 + V)
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.6
+    x_v = torch.randn(B, V, 3, generator=g) * 0.5
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+    y_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    for path in paths:
+        m = H.tw_kernel_model(sd, path=path)
+        out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                               y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
+        assert H.rel_err(out, ref) < 2e-5, (path, H.rel_err(out, ref))
+    if V > 64:
+        with pytest.raises(RuntimeError, match="unsupported"):
+            H.tw_kernel_model(sd, path=FUSED).log_likelihood(
+                atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(), y_velocs=y_v.cuda(),
+                adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+
+
+@pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])
+def test_empty_batch_and_zero_samples(path):
+    """Empty inputs: B = 0 rows / num_samples = 0 return empty tensors of the right shapes without launching anything."""
+    m = H.tw_kernel_model(H.full_kernel_sd(), path=path)
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    ll = m.log_likelihood(atom_types=torch.zeros(0, 22, dtype=torch.int64, device="cuda"), x_coords=z(0, 22, 3), x_velocs=z(0, 22, 3),
+                          y_coords=z(0, 22, 3), y_velocs=z(0, 22, 3), adj_list=None, edge_batch_idx=None,
+                          masked_elements=torch.zeros(0, 22, dtype=torch.bool, device="cuda"))
+    assert tuple(ll.shape) == (0,)
+    d, _ = H.load("kernel_full_ad")
+    yc, yv, lp = m.conditional_sample_with_logp(
+        atom_types=d["atom_types"].cuda(), x_coords=d["x_coords"].cuda(), x_velocs=d["x_velocs"].cuda(), adj_list=None,
+        edge_batch_idx=None, masked_elements=d["masked"].cuda(), num_samples=0)
+    assert tuple(yc.shape) == (0, 1, 22, 3) and tuple(yv.shape) == (0, 1, 22, 3) and tuple(lp.shape) == (0, 1)
+
+
 def test_roundtrip_full_size_S1000():
     """BASELINE size (S=1000 proposals, 22 atoms): size-independent property -- pushing the
     sampled (y, v) back through the density direction recovers log p to fp32 round-off."""
