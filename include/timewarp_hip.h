@@ -242,6 +242,13 @@ int tw_chirality_changed(const float* coords, const int32_t* centres, const floa
 int tw_profile_begin(void);
 int tw_profile_end(double* total_ms, int64_t* launches);
 
+/* Safety net for TW_PATH_FUSED_H3 (no counterpart in the reference): *out_flag = 1 if, since the last reset, any
+ * coupling net on the current device returned a non-finite scale or shift.  The split-fp16 kernel holds its operands in
+ * fp16 (|value| < 65504); a checkpoint whose activations leave that range produces inf/NaN there, which the exact-f32
+ * paths would not.  Synchronous (a device-to-host copy of one int): call it where the caller synchronises anyway.
+ * `reset` != 0 clears the flag. */
+int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
+
 /* Debug / measurement switches of the split-fp16 kernel.  0 restores normal operation.
  *   bit 0 (1)  no weight LDS-DMA after the prologue   } timing experiments on the compiled-C++ sections only:
  *   bit 1 (2)  no workgroup barriers                  } results become WRONG

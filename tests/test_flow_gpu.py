@@ -276,6 +276,30 @@ def test_empty_batch_and_zero_samples(path):
     assert tuple(yc.shape) == (0, 1, 22, 3) and tuple(yv.shape) == (0, 1, 22, 3) and tuple(lp.shape) == (0, 1)
 
 
+def test_split_fp16_overflow_is_reported():
+    """Weights that push activations past the fp16 range: the split-fp16 path must say so instead of returning NaN
+    log-densities silently; the exact-f32 path on the same weights stays finite and raises nothing."""
+    sd = {k: v.clone() for k, v in H.full_kernel_sd().items()}
+    for k in sd:
+        if k.endswith("in_mlp._layers.2.weight"):
+            sd[k] *= 1.0e7  # in_mlp output ~1e6-1e7: representable in fp32, not in fp16
+    d, _ = H.load("kernel_full_ad")
+    args = dict(atom_types=d["atom_types"].cuda(), x_coords=d["x_coords"].cuda(), x_velocs=d["x_velocs"].cuda(),
+                y_coords=d["y_coords"].cuda(), y_velocs=d["y_velocs"].cuda(), adj_list=None, edge_batch_idx=None,
+                masked_elements=d["masked"].cuda())
+    m32 = H.tw_kernel_model(sd, path=FUSED)
+    assert torch.isfinite(m32.log_likelihood(**args)).all()
+    m32.check_finite()
+    m = H.tw_kernel_model(sd, path=H3)
+    m.log_likelihood(**args)
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        m.check_finite()
+    m.check_finite()  # the flag was reset by the failing check
+    good = H.tw_kernel_model(H.full_kernel_sd(), path=H3)
+    good.log_likelihood(**args)
+    good.check_finite()
+
+
 def test_roundtrip_full_size_S1000():
     """BASELINE size (S=1000 proposals, 22 atoms): size-independent property -- pushing the
     sampled (y, v) back through the density direction recovers log p to fp32 round-off."""

@@ -103,6 +103,7 @@ SIGNATURES = {
     "tw_mh_accept": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "tw_mh_accept_chains": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _P]),
     "tw_chirality_changed": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _I32, _P]),
+    "tw_flow_nonfinite": (C.c_int, [_I32, C.POINTER(C.c_int32)]),
     "tw_debug_set_flags": (C.c_int, [C.c_int]),
     "tw_profile_begin": (C.c_int, []),
     "tw_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

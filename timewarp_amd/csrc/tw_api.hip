@@ -318,6 +318,14 @@ int tw_chirality_changed(const float* coords, const int32_t* centres, const floa
                           (hipStream_t)stream);
 }
 
+int tw_flow_nonfinite(int32_t reset, int32_t* out_flag) {
+  TW_REQUIRE(out_flag != nullptr, "NULL pointer argument");
+  int v = 0;
+  int rc = nonfinite_flag(reset, &v);
+  *out_flag = v;
+  return rc;
+}
+
 int tw_debug_set_flags(int flags) {
   tw::g_debug_flags = flags;
   return TW_OK;

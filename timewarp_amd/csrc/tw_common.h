@@ -169,6 +169,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
 int flow_pass_h3(const FlowArgs& a);
 int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
 extern int g_debug_flags;
+int nonfinite_flag(int reset, int* out);
 int profile_mark(hipStream_t s, bool begin);
 int profile_begin();
 int profile_end(double* total_ms, int64_t* launches);

@@ -194,20 +194,40 @@ int launch_centre(const float* x, const uint8_t* masked, float* xc, float* com, 
 //   forward: z' = z*exp(s)+t, logdet = +sum log(exp(s)); reverse: z' = (z-t)/exp(s), logdet = -sum
 //   delta_logp -= logdet (nvp.py:86)
 // ------------------------------------------------------------------------------------------------
+// Sticky per-device flag: some coupling net returned a non-finite scale or shift.  The split-fp16 path keeps its
+// operands in fp16 (|value| < 65504); a checkpoint whose activations leave that range shows up here as inf/NaN, and
+// the host can tell the user to switch to the exact-f32 path instead of sampling with NaN log-densities
+// (tw_flow_nonfinite; checked where the MH loop synchronises anyway).
+__device__ int g_nonfinite = 0;
+
+int nonfinite_flag(int reset, int* out) {
+  int v = 0;
+  TW_HIP_CHECK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_nonfinite), sizeof(int)));
+  if (reset && v) {
+    const int zero = 0;
+    TW_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_nonfinite), &zero, sizeof(int)));
+  }
+  *out = v;
+  return TW_OK;
+}
+
 __global__ void coupling_kernel(const float* __restrict__ s_raw, const float* __restrict__ t,
                                 const uint8_t* __restrict__ masked, int64_t n_cond, float* __restrict__ z,
                                 float* __restrict__ delta_logp, int V, int reverse) {
   const int64_t n = blockIdx.x;
   const int64_t c = n % n_cond;
   float acc = 0.f;
+  bool bad = false;
   for (int i = threadIdx.x; i < 3 * V; i += 64) {
     const int64_t idx = n * 3 * V + i;
     const float scale = expf(s_raw[idx]);
     const float shift = t[idx];
+    bad |= !(isfinite(s_raw[idx]) && isfinite(shift));
     const float keep = masked[c * V + i / 3] ? 0.f : 1.f;
     acc += logf(scale) * keep;
     z[idx] = reverse ? (z[idx] - shift) / scale : z[idx] * scale + shift;
   }
+  if (bad) atomicOr(&g_nonfinite, 1);
   acc = wave_sum(acc);
   if (threadIdx.x == 0) {
     const float logdet = reverse ? -acc : acc;

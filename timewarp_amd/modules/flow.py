@@ -53,6 +53,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         self._dev_weights = None  # {"device", "raw", "f32", "h3"}
         self._workspace = None
         self._dirty = True
+        self.used_split_fp16 = False  # some call ran on the split-fp16 kernel (see check_finite)
 
     # ------------------------------------------------------------------ weight cache
     def _apply(self, fn, *a, **k):
@@ -69,11 +70,28 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
 
     def _path_for(self, n_atoms: int) -> int:
         """The C-ABI execution path of a call on molecules of `n_atoms` atoms."""
-        if self.execution_path != PREFER_SPLIT_FP16:
-            return self.execution_path
-        desc = self.dims.to_desc()
-        ok = _lib.load().tw_flow_packed_h3_bytes(C.byref(desc)) > 0 and _wave_tiles(n_atoms) == 3
-        return _lib.TW_PATH_FUSED_H3 if ok else _lib.TW_PATH_AUTO
+        path = self.execution_path
+        if path == PREFER_SPLIT_FP16:
+            desc = self.dims.to_desc()
+            ok = _lib.load().tw_flow_packed_h3_bytes(C.byref(desc)) > 0 and _wave_tiles(n_atoms) == 3
+            path = _lib.TW_PATH_FUSED_H3 if ok else _lib.TW_PATH_AUTO
+        if path == _lib.TW_PATH_FUSED_H3:
+            self.used_split_fp16 = True
+        return path
+
+    def check_finite(self, device=None) -> None:
+        """Raise if the split-fp16 kernel produced non-finite coupling parameters since the last check (its operands are
+        fp16: activations beyond +-65504 overflow).  Synchronises; the MH loop calls it where it reads results back."""
+        if not self.used_split_fp16:
+            return
+        flag = C.c_int32(0)
+        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+            _lib.check(_lib.load().tw_flow_nonfinite(1, C.byref(flag)), "tw_flow_nonfinite")
+        if flag.value:
+            raise RuntimeError(
+                "timewarp_amd: the split-fp16 execution path returned non-finite scale/shift values - this checkpoint's "
+                "activations leave the fp16 range.  Use the exact-f32 kernels (TW_EXECUTION_PATH=f32, or "
+                "model.execution_path = TW_PATH_AUTO).")
 
     def _weights(self, device: torch.device, path: Optional[int] = None):
         """(raw, packed) device buffers; `packed` is the stream of the active execution path (the

@@ -278,6 +278,8 @@ class MetropolisHastingsChain:
             u = self.noise.uniform(S).to(device, torch.float32).contiguous()
             ex, p_acc, acc, res = _mh_accept(energy, p_xy, p_yx, u)
             k_true, any_acc = (int(v) for v in res[:2].tolist())  # the one host sync of the iteration
+            if hasattr(self.model, "check_finite"):
+                self.model.check_finite(device)
             if any_acc:
                 self.accepted += 1
             k = k_true if remaining is None else min(k_true, remaining)  # NB: N - i, not N - i - 1
@@ -329,6 +331,8 @@ class MetropolisHastingsChain:
         if not self._pending:
             return 0
         results = torch.stack([p[0] for p in self._pending]).cpu().tolist()
+        if hasattr(self.model, "check_finite"):
+            self.model.check_finite(self.device)  # split-fp16 overflow guard; the copy above already synchronised
         emitted = 0
         for (k_true, any_acc, _, _), (_, old_c, old_v, new_c, new_v, acc, per_proposal) in zip(results, self._pending):
             self.accepted += int(any_acc)
