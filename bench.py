@@ -159,14 +159,18 @@ def cpu_baseline(proposals):
             tables.rf_dielectric, tables.solute_dielectric, tables.solvent_dielectric, tables.surface_area_energy,
             *[a.ctypes.data for a in arrs])
 
+    energy_seconds = [0.0]
+
     class CEnergy:
         kbT = 8.314462618e-3 * 310.0
 
         def __call__(self, coords):
+            t_e = time.perf_counter()
             x = np.ascontiguousarray(coords.reshape(-1, V_ATOMS, 3).numpy(), dtype=np.float32)
             out = np.zeros(x.shape[0])
             lib.oracle_amber_energy(C.byref(ff), x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), None,
                                     C.c_int64(x.shape[0]))
+            energy_seconds[0] += time.perf_counter() - t_e
             return torch.from_numpy(out).to(torch.float32)[:, None]
 
     class Noise:
@@ -193,6 +197,7 @@ def cpu_baseline(proposals):
     # warm-up on a small batch (thread pools, allocator)
     mo.sample_with_model(types[None], coords[None], velocs[None], mask, model, CEnergy(), masses, 1, Noise(),
                          num_proposal_steps=16, **MH_MODE)
+    energy_seconds[0] = 0.0
     iters, accepted, t0 = 0, 0, time.perf_counter()
     x_c, x_v = coords[None], velocs[None]
     while True:
@@ -212,6 +217,10 @@ def cpu_baseline(proposals):
                   f"energies via oracle/energy_oracle.c on 1 core, accept scan) in {elapsed:.2f} s",
         "proposals_per_s": iters * proposals / elapsed,
         "s_per_iteration": elapsed / iters,
+        # model part and energy part separately (the energy stand-in for OpenMM is the scalar C oracle)
+        "energy_s_per_iteration": energy_seconds[0] / iters,
+        "model_s_per_iteration": (elapsed - energy_seconds[0]) / iters,
+        "model_threads": threads, "energy_threads": 1,
     }
 
 
