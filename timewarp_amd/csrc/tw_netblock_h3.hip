@@ -322,7 +322,7 @@ __device__ __forceinline__ float h3_pair_dist(const float* x, int q, int m) {
 __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
                                      const float* __restrict__ ls, int H, int V, int mpw, int64_t n_rows,
                                      int64_t n_cond, int normalise, char* __restrict__ sfrag, ScoreBasis basis,
-                                     int64_t variant_bytes) {
+                                     int64_t variant_bytes, int windowed) {
   extern __shared__ float sm[];
   float* xs = sm;
   float* dist = xs + mpw * V * 3;
@@ -368,7 +368,10 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const int slot = i % 12, lane = (i / 12) % 64, jt = i / (12 * 64);
     const int tq = 16 * jt + (lane & 15);
-    const int tk = slot < 8 ? 8 * (lane >> 4) + slot : 32 + 4 * (lane >> 4) + (slot - 8);
+    // windowed (h3_windowed): query tile 2 only has keys in [16, 48) - its K = 32 block covers those, its K = 16 block
+    // is not used (nor is tile 0's, whose keys all lie in [0, 32))
+    const int k32_base = (windowed && jt == 2) ? 16 : 0;
+    const int tk = slot < 8 ? k32_base + 8 * (lane >> 4) + slot : 32 + 4 * (lane >> 4) + (slot - 8);
     float val = 0.f;
     const int mq = tq / V, mk = tk / V;
     if (mq == mk && mq < mpw) {
@@ -412,6 +415,7 @@ struct H3Params {
   const char* sfrag;
   int sfrag_shared;
   int64_t sf_variant_bytes;  // chebyshev_kernel: bytes between the fragment sets of (net, layer) variants; else 0
+  int windowed;              // block-diagonal mixing with per-tile key windows (h3_windowed); asm variant only
   float* out[2];
   float* dump;
   int64_t n_rows, n_cond;
@@ -955,13 +959,24 @@ netblock_h3_kernel(const H3Params p) {
       const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
       const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
       const int heads = __builtin_amdgcn_readfirstlane(p.H);
-      asm volatile(
+      if (p.windowed) {
+        // two or more molecules per wave: 24 instead of 36 mixing MFMAs per k-step (gen_h3_attn_asm.py --mode=windowed)
+        asm volatile(
+#include "tw_h3_attnw_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp)
+            :
+#include "tw_h3_attnw_clobbers.inc"
+        );
+      } else {
+        asm volatile(
 #include "tw_h3_attn_asm.inc"
-          : [cur] "+s"(cur), [gn] "+v"(gn)
-          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp)
-          :
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp)
+            :
 #include "tw_h3_attn_clobbers.inc"
-      );
+        );
+      }
       pipe.cur = cur;
       pipe.gnext = gn;
       stamp(40 + 4 * l + 1);
@@ -1207,6 +1222,17 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
 
 int g_debug_flags = 0;
 
+// Per-tile key windows for the mixing (gen_h3_attn_asm.py --mode=windowed): every molecule that has a token in query
+// tile 0 ends before token 32, and every molecule with a token in tile 2 starts at token 16 or later.  True for all
+// multi-molecule wave layouts of 48 tokens (V <= 24); the compiled-C++ variant of the kernel keeps the full 48 keys.
+static bool h3_windowed(const FusedGeom& fg, int V) {
+  if (g_debug_flags & 8) return false;
+  if (fg.mpw < 2) return false;
+  const int end0 = (15 / V + 1) * V, start2 = (32 / V) * V;
+  return end0 <= 32 && start2 >= 16;
+}
+
+
 int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms) {
   return h3_ws(d, n_rows, n_atoms, nullptr).bytes;
 }
@@ -1232,6 +1258,7 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.sfrag = sfrag;
   p.sfrag_shared = shared ? 1 : 0;
   p.sf_variant_bytes = sf_variant_bytes;
+  p.windowed = h3_windowed(fg, a.n_atoms) ? 1 : 0;
   p.out[0] = s_out;
   p.out[1] = t_out;
   p.dump = dump;
@@ -1281,7 +1308,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
   size_t shm = (size_t)(fg.mpw * V * 3 + fg.mpw * V * V + fg.mpw * d.n_heads * V) * 4 + (size_t)fg.mpw * V;
   hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks, (unsigned)d.n_heads, (unsigned)basis.n_variants), dim3(256), shm,
                      a.stream, a.x_coords, a.masked, a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, V, fg.mpw,
-                     a.n_rows, a.n_cond, d.normalise, w.sfrag, basis, vb);
+                     a.n_rows, a.n_cond, d.normalise, w.sfrag, basis, vb, h3_windowed(fg, V) ? 1 : 0);
   TW_LAUNCH_CHECK();
   *variant_bytes = vb;
   return TW_OK;

@@ -41,6 +41,13 @@ YACC = lambda ot, jt: 4 * (3 * ot + jt)
 S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT, S_K3072, S_K6144 = 84, 85, 86, 88, 90, 92, 93, 94, 96
 N_V, N_A = 212, 96
 EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(",")))
+# --mode=windowed: waves that hold two or more molecules.  The score matrix is block diagonal, so query tile 0 only has
+# keys in [0, 32) and query tile 2 only in [16, 48): each takes ONE K=32 mixing MFMA per term (tile 2 with its X^T
+# operand read 16 tokens further in, into a96..a111) and only tile 1 keeps the K=16 tail - 24 instead of 36 mixing
+# MFMAs per k-step (the K=16 shape costs a full slot).  The fragment producer lays tile 2's K=32 block over keys 16..47
+# for this mode (csrc: h3_score_frag_kernel `windowed`).  Single-molecule waves keep the full 48 keys (--mode=full).
+WINDOWED = "--mode=windowed" in sys.argv
+A2 = lambda t, part: 96 + 8 * t + (0 if part == "h" else 4)   # AGPRs
 
 
 def vr(base, n=4):
@@ -51,9 +58,10 @@ def ar(base, n=4):
     return f"a[{base}:{base + n - 1}]"
 
 
-def mfma32(d, a, b, zero=False, dreg="v"):
+def mfma32(d, a, b, zero=False, dreg="v", areg="v"):
     dd = vr(d) if dreg == "v" else ar(d)
-    return f"v_mfma_f32_16x16x32_f16 {dd}, {vr(a)}, {vr(b)}, {'0' if zero else dd}"
+    aa = vr(a) if areg == "v" else ar(a)
+    return f"v_mfma_f32_16x16x32_f16 {dd}, {aa}, {vr(b)}, {'0' if zero else dd}"
 
 
 def mfma16(d, a, b, zero=False):
@@ -62,10 +70,14 @@ def mfma16(d, a, b, zero=False):
 
 def xt_reads(ks, t, buf):
     off = XT_ROW * 16 * (2 * ks + t)
-    return [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
-            f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_LO}",
-            f"ds_read_b64 {vr(XA(buf, 'a1h'), 2)}, v{V_XT1} offset:{off}",
-            f"ds_read_b64 {vr(XA(buf, 'a1l'), 2)}, v{V_XT1} offset:{off + XT_LO}"]
+    out = [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
+           f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_LO}",
+           f"ds_read_b64 {vr(XA(buf, 'a1h'), 2)}, v{V_XT1} offset:{off}",
+           f"ds_read_b64 {vr(XA(buf, 'a1l'), 2)}, v{V_XT1} offset:{off + XT_LO}"]
+    if WINDOWED:   # keys 16..47 for query tile 2: the same rows, 16 tokens (32 bytes) further in
+        out += [f"ds_read_b128 {ar(A2(buf, 'h'))}, v{V_XT0} offset:{off + 32}",
+                f"ds_read_b128 {ar(A2(buf, 'l'))}, v{V_XT0} offset:{off + XT_LO + 32}"]
+    return out
 
 
 def mixing_mfmas():
@@ -78,9 +90,13 @@ def mixing_mfmas():
     for a32, b32, a16, b16 in (("a0h", "s0h", "a1h", "s1h"), ("a0h", "s0l", "a1h", "s1l"), ("a0l", "s0h", "a1l", "s1h")):
         for t in range(2):
             for jt in range(NT):
-                out.append(mfma32(ACC(t, jt), XA(t, a32), SF(jt, b32), zero=first))
+                if WINDOWED and jt == 2:
+                    out.append(mfma32(ACC(t, jt), A2(t, a32[2]), SF(jt, b32), zero=first, areg="a"))
+                else:
+                    out.append(mfma32(ACC(t, jt), XA(t, a32), SF(jt, b32), zero=first))
         for t in range(2):
-            for jt in range(NT):
+            for jt in ((1,) if WINDOWED else range(NT)):
+                # windowed: the chain of (t, 1) still has four other MFMAs between its K=32 and its K=16 member
                 out.append(mfma16(ACC(t, jt), XA(t, a16), SF(jt, b16)))
         first = False
     return out
@@ -329,13 +345,13 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--out-dir="):
             out_dir = a.split("=", 1)[1]
-    base = os.path.join(out_dir, "tw_h3_attn_asm.inc")
-    out = ["// GENERATED by tools/gen_h3_attn_asm.py - do not edit.  Body of the attention asm statement."]
+    base = os.path.join(out_dir, "tw_h3_attnw_asm.inc" if WINDOWED else "tw_h3_attn_asm.inc")
+    out = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''} - do not edit.  Body of the attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")
-    clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A)] + [f'"s{i}"' for i in range(84, 98)] + \
+    clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A + (16 if WINDOWED else 0))] + [f'"s{i}"' for i in range(84, 98)] + \
            ['"vcc"', '"scc"', '"memory"']
-    cl = ["// GENERATED by tools/gen_h3_attn_asm.py - clobber list of the attention asm statement."]
+    cl = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''} - clobber list of the attention asm statement."]
     for i in range(0, len(clob), 12):
         cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
     open(base.replace("_asm.inc", "_clobbers.inc"), "w").write("\n".join(cl) + "\n")
