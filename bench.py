@@ -133,7 +133,8 @@ def attention_block(model, device, proposals, avg_launch_ms):
 
 def cpu_baseline(proposals):
     """The oracle (oracle/flow_oracle.py + oracle/mh_oracle.py + oracle/energy_oracle.c) on this
-    box's host cores: full 1000-proposal MH iterations, bounded to ~10-30 s of CPU work."""
+    box's host cores: a thread-count sweep on a tenth of the workload, then 3 full 1000-proposal MH iterations at the
+    fastest setting (>= 3 timed iterations, thread count stated, n = 1 reported)."""
     from oracle import flow_oracle as fo
     from oracle import mh_oracle as mo
     from timewarp_amd import synthetic
@@ -186,41 +187,100 @@ def cpu_baseline(proposals):
         def uniform(self, S):
             return torch.rand(S, generator=self.g)
 
-    threads = torch.get_num_threads()
     spec = fo.FlowSpec(variant="kernel")
     sd = fo.synth_state_dict(fo.make_template(spec), 0, calibrated=True, **CALIBRATION)
     model = mo.OracleModel(sd, spec)
     types, coords, masses = synthetic.alanine_dipeptide_state()
     velocs = torch.zeros(V_ATOMS, 3)
     mask = torch.zeros(1, V_ATOMS, dtype=torch.bool)
-    kw = dict(num_proposal_steps=proposals, **MH_MODE)
-    # warm-up on a small batch (thread pools, allocator)
-    mo.sample_with_model(types[None], coords[None], velocs[None], mask, model, CEnergy(), masses, 1, Noise(),
-                         num_proposal_steps=16, **MH_MODE)
-    energy_seconds[0] = 0.0
-    iters, accepted, t0 = 0, 0, time.perf_counter()
-    x_c, x_v = coords[None], velocs[None]
-    while True:
-        c, v, acc, _ = mo.sample_with_model(types[None], x_c, x_v, mask, model, CEnergy(), masses, 1, Noise(), **kw)
-        x_c, x_v = torch.from_numpy(c[-1:]), torch.from_numpy(v[-1:])
-        iters += 1
-        accepted += acc
-        elapsed = time.perf_counter() - t0
-        if elapsed > 10.0 or iters >= 3:
-            break
+
+    def run(n_iter, S, threads):
+        """n_iter MH iterations of S proposals on `threads` torch threads; (seconds, accepted, energy seconds)."""
+        torch.set_num_threads(threads)
+        kw = dict(num_proposal_steps=S, **MH_MODE)
+        # warm-up at this thread count (thread pool, allocator)
+        mo.sample_with_model(types[None], coords[None], velocs[None], mask, model, CEnergy(), masses, 1, Noise(),
+                             num_proposal_steps=16, **MH_MODE)
+        energy_seconds[0] = 0.0
+        noise = Noise()  # one stream for the whole run
+        accepted, t0 = 0, time.perf_counter()
+        x_c, x_v = coords[None], velocs[None]
+        for _ in range(n_iter):
+            c, v, acc, _ = mo.sample_with_model(types[None], x_c, x_v, mask, model, CEnergy(), masses, 1, noise, **kw)
+            x_c, x_v = torch.from_numpy(c[-1:]), torch.from_numpy(v[-1:])
+            accepted += acc
+        return time.perf_counter() - t0, accepted, energy_seconds[0]
+
+    # SURVEY 8d: thread count stated, n = 1 reported, >= 3 timed iterations.  Sweep torch's intra-op threads on a
+    # 100-proposal iteration (a tenth of the workload, ~1-4 s per setting), then time 3 full iterations at the best one.
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    candidates = sorted({n for n in (1, 8, 16, 32, 64, ncpu) if n <= ncpu})
+    sweep_S = max(1, proposals // 10)
+    sweep = {}
+    for n in candidates:
+        sec, _, esec = run(1, sweep_S, n)
+        sweep[n] = {"model_s": sec - esec, "proposals_per_s": sweep_S / sec}
+    best = max(sweep, key=lambda n: sweep[n]["proposals_per_s"])
+    iters = 3
+    elapsed, accepted, esec = run(iters, proposals, best)
+    torch.set_num_threads(default_threads)
+    n1 = sweep[1]
     return {
         "value": accepted / elapsed,
         "unit": "MH-accepted samples/s",
-        "cores": threads,
+        "cores": best,
         "kind": "port",
-        "sample": f"{iters} full MH iteration(s) of {proposals} proposals (flow reverse+forward via oracle/flow_oracle.py on torch-CPU fp32, "
-                  f"energies via oracle/energy_oracle.c on 1 core, accept scan) in {elapsed:.2f} s",
+        "sample": f"{iters} full MH iterations of {proposals} proposals (flow reverse+forward via oracle/flow_oracle.py on torch-CPU fp32 "
+                  f"with {best} threads - the fastest of {candidates} on a {sweep_S}-proposal iteration; energies via "
+                  f"oracle/energy_oracle.c on 1 core; accept scan) in {elapsed:.2f} s",
         "proposals_per_s": iters * proposals / elapsed,
         "s_per_iteration": elapsed / iters,
         # SURVEY 8d: model part and energy part separately (the energy stand-in for OpenMM is the scalar C oracle)
-        "energy_s_per_iteration": energy_seconds[0] / iters,
-        "model_s_per_iteration": (elapsed - energy_seconds[0]) / iters,
-        "model_threads": threads, "energy_threads": 1,
+        "energy_s_per_iteration": esec / iters,
+        "model_s_per_iteration": (elapsed - esec) / iters,
+        "model_threads": best, "energy_threads": 1, "host_logical_cpus": ncpu,
+        "thread_sweep_proposals_per_s": {str(n): round(v["proposals_per_s"], 2) for n, v in sweep.items()},
+        "single_thread": {"cores": 1, "proposals_per_s": n1["proposals_per_s"],
+                          "sample": f"one {sweep_S}-proposal MH iteration on 1 torch thread",
+                          "s_per_1000_proposal_iteration_extrapolated": proposals / n1["proposals_per_s"]},
+    }
+
+
+def alt_path_record(device, seed, proposals, steps, sync_every):
+    """The same workload on the path a plain `model_constructor` user gets (TW_PATH_AUTO = the exact-f32 fused kernel),
+    timed after the main region on a second chain so the driver's record carries both numbers."""
+    from timewarp_amd import _lib
+
+    pinfo = PATHS["f32"]
+    lib = _lib.load()
+    chain, _ = build_chain(device, seed, proposals, _lib.TW_PATH_AUTO)
+    with torch.no_grad():
+        chain.step_deferred()
+        chain.flush()
+    torch.cuda.synchronize()
+    acc0 = chain.accepted
+    lib.tw_profile_begin()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for it in range(steps):
+            chain.step_deferred()
+            if (it + 1) % sync_every == 0:
+                chain.flush()
+        chain.trajectory()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches = C.c_double(0.0), C.c_int64(0)
+    lib.tw_profile_end(C.byref(k_ms), C.byref(k_launches))
+    avg_ms = k_ms.value / max(int(k_launches.value), 1)
+    achieved = FLOP_PER_SAMPLE_PASS * proposals / N_COUPLING / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    return {
+        "execution_path": "auto (TW_PATH_AUTO: exact-f32 fused kernel, what model_constructor selects by default)",
+        "dtype": pinfo["dtype"], "value": (chain.accepted - acc0) / elapsed, "unit": "MH-accepted samples/s",
+        "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+        "roofline": {"bound": "mfma", "kernel": pinfo["kernel"], "achieved": achieved, "peak": pinfo["peak"],
+                     "unit": "TFLOP/s", "frac": achieved / pinfo["peak"], "avg_launch_ms": avg_ms,
+                     "launches": int(k_launches.value)},
     }
 
 
@@ -347,6 +407,9 @@ def main():
         }
         if args.path == "h3" and args.proposals == S_PROPOSALS:
             out["roofline"]["attention_block"] = attention_block(model, device, args.proposals, avg_ms)
+        if world == 1 and args.path != "f32":
+            out["alt_path"] = alt_path_record(device, distributed.chain_seed(args.seed, rank), args.proposals,
+                                              max(4, args.steps // 4), args.sync_every)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.proposals)
         print(json.dumps(out), flush=True)

@@ -41,7 +41,7 @@ class FlowSpec:
     layer_norm_eps: float = 1e-5
     use_displacement_as_target: bool = True
     ignore_conditional_velocity: bool = False
-    normalise_kernel_values: bool = True
+    normalise_kernel_values: bool = True  # a config field the reference never acts on (scores are always normalised)
     attention_type: str = "kernel"  # "kernel" | "learnable_kernel" | "chebyshev_kernel" (kernel_attention.py:159-339)
     force_asymptotic_zero: bool = False  # chebyshev_kernel only
 
@@ -170,7 +170,7 @@ def kernel_netblock(
         layer_scores = scores
         if layer_scores is None:
             att = f"{p}.self_attn.attention."
-            layer_scores = kernel_scores(positions, masked, sd[att + "lengthscales"], spec.normalise_kernel_values,
+            layer_scores = kernel_scores(positions, masked, sd[att + "lengthscales"], True,
                                          sd[att + "cheb_coeffs"], spec.force_asymptotic_zero)
         a = kernel_self_attention(sd, f"{p}.self_attn", h, layer_scores)
         h = encoder_layer_tail(sd, p, h, a, spec.layer_norm_eps)
@@ -285,7 +285,9 @@ def flow_pass(
             ls = torch.exp(sd[att + "log_lengthscales"])  # kernel_attention.py:251-252
         else:
             ls = sd[att + "lengthscales"]
-        scores = kernel_scores(x_coords, masked, ls, spec.normalise_kernel_values)
+        # always normalised: KernelAttention.forward (kernel_attention.py:197-206) does not pass its
+        # normalise_kernel_values on, and compute_kernel_attention_scores defaults to True (:75)
+        scores = kernel_scores(x_coords, masked, ls, True)
     order = range(spec.num_coupling_layers)
     if reverse:
         order = reversed(order)

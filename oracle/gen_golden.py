@@ -94,10 +94,10 @@ def ad_topology():
 
 
 def kernel_model(emb, d_model, ff, mlp_hidden, n_coupling, n_layers, lengthscales, attention_type="kernel",
-                 cheb_order=None, force_asymptotic_zero=None):
+                 cheb_order=None, force_asymptotic_zero=None, normalise=True):
     enc = CustomAttentionEncoderLayerConfig(
         d_model=d_model, dim_feedforward=ff, dropout=0.0, num_heads=len(lengthscales),
-        attention_type=attention_type, lengthscales=list(lengthscales), normalise_kernel_values=True,
+        attention_type=attention_type, lengthscales=list(lengthscales), normalise_kernel_values=normalise,
         cheb_order=cheb_order, force_asymptotic_zero=force_asymptotic_zero,
     )
     cfg = CustomAttentionTransformerNVPConfig(
@@ -444,7 +444,7 @@ def gen_chebyshev_full_golden():
     y_c = x_c + torch.randn(1, 22, 3, generator=g) * 0.01
     y_v = torch.randn(1, 22, 3, generator=g) * 0.5
     d = base_inputs(ad_t[None], x_c, x_v, mask, y_c, y_v)
-    d.update(run_case(m, ad_t[None], x_c, x_v, mask, y_c, y_v, 8, 2025))
+    d.update(run_case(m, ad_t[None], x_c, x_v, mask, y_c, y_v, S_FULL, 2025))
     np.savez_compressed(os.path.join(OUT, "kernel_cheb_full_ad.npz"), **d)
     print("kernel_cheb_full_ad ok")
 
@@ -475,31 +475,34 @@ def tiny_kernel_model():
     return tiny
 
 
-def main():
-    if "--only-sob" in sys.argv:
-        os.makedirs(OUT, exist_ok=True)
-        gen_sob_golden(tiny_kernel_model())
-        return
-    if "--only-energy-kat" in sys.argv:
-        gen_energy_kat()
-        return
-    if "--only-cheb-full" in sys.argv:
-        gen_chebyshev_full_golden()
-        return
-    if "--only-cheb" in sys.argv:
-        os.makedirs(OUT, exist_ok=True)
-        gen_chebyshev_golden()
-        return
-    if "--only-learnable" in sys.argv:
-        os.makedirs(OUT, exist_ok=True)
-        gen_learnable_golden()
-        return
-    os.makedirs(OUT, exist_ok=True)
-    torch.set_num_threads(8)
-    ad_x, ad_t = ad_topology()
+S_FULL = 64  # proposals per full-size case: 16 waves / 4 workgroups of the fused kernels per net
 
+
+def gen_nonorm_golden():
+    """Tiny kernel model built with normalise_kernel_values=False.  KernelAttention.forward never passes the flag on
+    to compute_kernel_attention_scores (kernel_attention.py:197-206; its default is True, :75), so the reference
+    L1-normalises regardless: these vectors pin that the build does the same."""
+    torch.manual_seed(1234)
+    m = kernel_model(emb=4, d_model=8, ff=16, mlp_hidden=[8], n_coupling=2, n_layers=2, lengthscales=[0.1, 0.5, 1.2],
+                     normalise=False)
+    with torch.no_grad():
+        m.coords_prior_log_scale.fill_(-0.3)
+        m.velocs_prior_log_scale.fill_(0.2)
+    g = torch.Generator().manual_seed(7)
+    at, x_c, x_v, mask, y_c, y_v = padded_batch(g, 3, 7, [7, 5, 6])
+    d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
+    d.update(run_case(m, at, x_c, x_v, mask, y_c, y_v, 0, 0))
+    d.update(np_sd(m.state_dict()))
+    at1, x1, v1, m1, yc1, yv1 = padded_batch(g, 1, 7, [5])
+    r = run_case(m, at1, x1, v1, m1, yc1, yv1, 4, 99)
+    d.update({"b1_" + k: v for k, v in base_inputs(at1, x1, v1, m1, yc1, yv1).items()})
+    d.update({"b1_" + k: v for k, v in r.items()})
+    np.savez_compressed(os.path.join(OUT, "kernel_nonorm_tiny.npz"), **d)
+    print("kernel_nonorm_tiny ok")
+
+
+def gen_tiny_kernel(tiny):
     # ---- (1) tiny kernel model, reference-initialised weights stored in full ------------------
-    tiny = tiny_kernel_model()
     g = torch.Generator().manual_seed(7)
     at, x_c, x_v, mask, y_c, y_v = padded_batch(g, 3, 7, [7, 5, 6])
     d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
@@ -513,9 +516,14 @@ def main():
     np.savez_compressed(os.path.join(OUT, "kernel_tiny.npz"), **d)
     print("kernel_tiny", {k: v.shape for k, v in d.items() if not k.startswith("sd::")})
 
-    # ---- (2) full-size kernel model on alanine dipeptide, name-seeded weights -------------------
-    full = kernel_model(emb=32, d_model=128, ff=2048, mlp_hidden=[256], n_coupling=8, n_layers=3,
+
+def full_kernel_reference_model():
+    return kernel_model(emb=32, d_model=128, ff=2048, mlp_hidden=[256], n_coupling=8, n_layers=3,
                         lengthscales=[0.1, 0.2, 0.5, 0.7, 1.0, 1.2])
+
+
+def gen_full_kernel(full, ad_x, ad_t):
+    # ---- (2) full-size kernel model on alanine dipeptide, name-seeded weights -------------------
     for tag, calibrated in (("kernel_full_ad", False), ("kernel_full_ad_calibrated", True)):
         sd = fo.synth_state_dict(full.state_dict(), base_seed=0, calibrated=calibrated)
         full.load_state_dict(sd)
@@ -526,7 +534,7 @@ def main():
         y_c = x_c + torch.randn(1, 22, 3, generator=g) * 0.01
         y_v = torch.randn(1, 22, 3, generator=g) * 0.5
         at = ad_t[None]
-        S = 8
+        S = S_FULL
         d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
         # layer trace of the first net evaluated in the reverse pass (chain[7].scale_transformer)
         trace = {}
@@ -536,19 +544,9 @@ def main():
                 trace.setdefault(key, o[:2].detach().numpy().copy())
             return hook
 
-        if not calibrated:
-            net = full.flow.chain[7].scale_transformer
-            hooks = [net.in_mlp.register_forward_hook(saver("tr_in_mlp"))]
-            for l in range(3):
-                hooks.append(net.encoder_layers[l].register_forward_hook(saver(f"tr_enc{l}")))
-            hooks.append(net.out_mlp.register_forward_hook(saver("tr_out_mlp")))
         d.update(run_case(full, at, x_c, x_v, mask, y_c, y_v, S, 2024))
         if not calibrated:
-            for h in hooks:
-                h.remove()
-            # the hooks fired first inside log_likelihood (forward pass, B=1): recompute for the
-            # reverse pass explicitly so the trace belongs to the sampling call
-            trace.clear()
+            net = full.flow.chain[7].scale_transformer
             hooks = [net.in_mlp.register_forward_hook(saver("tr_in_mlp"))]
             for l in range(3):
                 hooks.append(net.encoder_layers[l].register_forward_hook(saver(f"tr_enc{l}")))
@@ -567,6 +565,8 @@ def main():
         np.savez_compressed(os.path.join(OUT, tag + ".npz"), **d)
         print(tag, {k: v.shape for k, v in d.items()})
 
+
+def gen_v60(full):
     # ---- (3) V=60: pins the cdist matmul branch (kernel_attention.py:98-102) --------------------
     sd = fo.synth_state_dict(full.state_dict(), base_seed=0)
     full.load_state_dict(sd)
@@ -579,14 +579,16 @@ def main():
     y_c = x_c + torch.randn(1, V, 3, generator=g) * 0.01
     y_v = torch.randn(1, V, 3, generator=g) * 0.5
     d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
-    d.update(run_case(full, at, x_c, x_v, mask, y_c, y_v, 4, 606))
+    d.update(run_case(full, at, x_c, x_v, mask, y_c, y_v, S_FULL, 606))
     com = x_c.mean(dim=1, keepdim=True)
     d["scores"] = compute_kernel_attention_scores(
         x_c - com, x_c - com, mask, torch.tensor([0.1, 0.2, 0.5, 0.7, 1.0, 1.2])).numpy()
     np.savez_compressed(os.path.join(OUT, "kernel_full_v60.npz"), **d)
     print("kernel_full_v60", {k: v.shape for k, v in d.items()})
 
-    # ---- (4) dense softmax variant: tiny (stored weights, padding, RFF) and full-size ------------
+
+def gen_dense_tiny():
+    # ---- (4a) dense softmax variant, tiny (stored weights, padding, RFF) --------------------------
     torch.manual_seed(4321)
     dt = dense_model(emb=4, d_model=8, ff=16, mlp_hidden=[8], n_coupling=2, n_layers=2, n_head=2,
                      rff=RFFPositionEncoderConfig(4, 1.0, 1.0))
@@ -602,6 +604,9 @@ def main():
     np.savez_compressed(os.path.join(OUT, "dense_tiny.npz"), **d)
     print("dense_tiny ok")
 
+
+def gen_dense_full(ad_x, ad_t):
+    # ---- (4b) dense softmax variant, full size on alanine dipeptide ------------------------------
     dfull = dense_model(emb=32, d_model=128, ff=2048, mlp_hidden=[256], n_coupling=8, n_layers=3, n_head=8)
     dfull.load_state_dict(fo.synth_state_dict(dfull.state_dict(), base_seed=0))
     g = torch.Generator().manual_seed(12)
@@ -611,10 +616,20 @@ def main():
     y_c = x_c + torch.randn(1, 22, 3, generator=g) * 0.01
     y_v = torch.randn(1, 22, 3, generator=g) * 0.5
     d = base_inputs(ad_t[None], x_c, x_v, mask, y_c, y_v)
-    d.update(run_case(dfull, ad_t[None], x_c, x_v, mask, y_c, y_v, 8, 2025))
+    d.update(run_case(dfull, ad_t[None], x_c, x_v, mask, y_c, y_v, S_FULL, 2025))
     np.savez_compressed(os.path.join(OUT, "dense_full_ad.npz"), **d)
     print("dense_full_ad ok")
+    # a padded full-size batch (nn.MultiheadAttention's src_key_padding_mask, transformer_block.py:57-68): log-likelihood
+    # of three molecules of 22 / 17 / 20 real atoms
+    g = torch.Generator().manual_seed(13)
+    at, x_c, x_v, mask, y_c, y_v = padded_batch(g, 3, 22, [22, 17, 20])
+    d = base_inputs(at, x_c, x_v, mask, y_c, y_v)
+    d.update(run_case(dfull, at, x_c, x_v, mask, y_c, y_v, 0, 0))
+    np.savez_compressed(os.path.join(OUT, "dense_full_padded.npz"), **d)
+    print("dense_full_padded ok")
 
+
+def gen_euler_maruyama():
     # ---- (5) EulerMaruyamaGaussian (cfg 1 plumbing) ----------------------------------------------
     em = model_constructor(ModelConfig(model_type="euler_maruyama_gaussian")).eval()
     g = torch.Generator().manual_seed(5)
@@ -631,14 +646,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "euler_maruyama.npz"), **d)
     print("euler_maruyama ok")
 
-    # ---- (7) the MH loop itself: the reference's sample_with_model driven with a synthetic energy --
-    gen_mh_goldens(tiny)
-    gen_sob_golden(tiny)
-    gen_learnable_golden()
-    gen_chebyshev_golden()
-    gen_chebyshev_full_golden()
-    gen_energy_kat()
 
+def gen_data_fixtures(ad_x, ad_t):
     # ---- (8) the reference's own smallest test molecule as data (testdata/smallest_molecule: 2 frames x 65 atoms,
     #          elements from PDB columns 77-78) for the config-0 plumbing test
     z = np.load("/root/reference/testdata/smallest_molecule/2olx-traj-arrays.npz")
@@ -646,10 +655,43 @@ def main():
            if l.startswith(("ATOM", "HETATM"))]
     np.savez_compressed(os.path.join(OUT, "smallest_molecule.npz"), positions=z["positions"], velocities=z["velocities"],
                         forces=z["forces"], elements=np.array(els))
-
     # ---- (6) alanine-dipeptide topology as data (22 atoms) ---------------------------------------
     np.savez_compressed(os.path.join(OUT, "ad_topology.npz"), coords_nm=ad_x.numpy(), atom_types=ad_t.numpy(),
                         atom_names=np.array(AD_NAMES))
+
+
+def main():
+    """python oracle/gen_golden.py [--only NAME ...]; NAME in SECTIONS; no flag = everything."""
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ad_x, ad_t = ad_topology()
+    cache = {}
+
+    def full():
+        if "full" not in cache:
+            cache["full"] = full_kernel_reference_model()
+        return cache["full"]
+
+    sections = {
+        "tiny": lambda: gen_tiny_kernel(tiny_kernel_model()),
+        "nonorm": gen_nonorm_golden,
+        "full": lambda: gen_full_kernel(full(), ad_x, ad_t),
+        "v60": lambda: gen_v60(full()),
+        "dense-tiny": gen_dense_tiny,
+        "dense-full": lambda: gen_dense_full(ad_x, ad_t),
+        "em": gen_euler_maruyama,
+        "mh": lambda: gen_mh_goldens(tiny_kernel_model()),  # (7) the MH loop itself, driven with a synthetic energy
+        "sob": lambda: gen_sob_golden(tiny_kernel_model()),
+        "learnable": gen_learnable_golden,
+        "cheb": gen_chebyshev_golden,
+        "cheb-full": gen_chebyshev_full_golden,
+        "energy-kat": gen_energy_kat,
+        "data": lambda: gen_data_fixtures(ad_x, ad_t),
+    }
+    only = [a for a in sys.argv[1:] if a in sections]
+    for name, fn in sections.items():
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":

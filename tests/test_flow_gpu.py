@@ -52,6 +52,17 @@ def test_tiny_kernel_simple_path():
     H.assert_case_close(H.run_model_case(m, d, "b1_"), d, "b1_", tol=TOL)
 
 
+def test_tiny_kernel_normalise_flag_is_ignored():
+    """normalise_kernel_values=False in the config: the reference still normalises (kernel_attention.py:197-206 never
+    forwards the flag); vectors generated from a reference model built that way."""
+    d, sd = H.load("kernel_nonorm_tiny")
+    m = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2,
+                          lengthscales=(0.1, 0.5, 1.2), path=SIMPLE, normalise=False)
+    assert m.flow.chain[0].scale_transformer.encoder_layers[0].self_attn.attention.normalise_kernel_values is False
+    H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
+    H.assert_case_close(H.run_model_case(m, d, "b1_"), d, "b1_", tol=TOL)
+
+
 def test_tiny_learnable_lengthscales():
     """attention_type "learnable_kernel", per-layer log_lengthscales all different: forward and reverse
     passes use the lengthscales of the layer the reference evaluates first (weights.py LENGTHSCALES)."""
@@ -260,6 +271,30 @@ def test_large_molecules_vs_oracle(V, lens, paths):
                 adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
 
 
+def test_per_op_path_lds_limit():
+    """150 atoms: the per-op kernels' V x V score tile needs > 64 KiB of LDS (raised limit) and still matches the
+    oracle; 256 atoms exceed the CU's 160 KiB and are refused with a message instead of failing at launch."""
+    sd = H.full_kernel_sd()
+    g = torch.Generator().manual_seed(77)
+    m = H.tw_kernel_model(sd, path=0)
+    for V, ok in ((150, True), (256, False)):
+        at = torch.randint(0, 5, (2, V), generator=g)
+        x_c = torch.randn(2, V, 3, generator=g) * 0.8
+        x_v = torch.randn(2, V, 3, generator=g) * 0.5
+        y_c = x_c + torch.randn(2, V, 3, generator=g) * 0.02
+        y_v = torch.randn(2, V, 3, generator=g) * 0.5
+        mask = torch.zeros(2, V, dtype=torch.bool)
+        mask[1, V - 9:] = True
+        call = lambda: m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                                        y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+        if ok:
+            ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+            assert H.rel_err(call().cpu(), ref) < 2e-5
+        else:
+            with pytest.raises(RuntimeError, match="LDS"):
+                call()
+
+
 @pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])
 def test_empty_batch_and_zero_samples(path):
     """Empty inputs: B = 0 rows / num_samples = 0 return empty tensors of the right shapes without launching anything."""
@@ -300,14 +335,18 @@ def test_split_fp16_overflow_is_reported():
     good.check_finite()
 
 
-def test_roundtrip_full_size_S1000():
-    """BASELINE size (S=1000 proposals, 22 atoms): size-independent property -- pushing the
-    sampled (y, v) back through the density direction recovers log p to fp32 round-off."""
-    m = H.tw_kernel_model(H.full_kernel_sd(calibrated=True), path=FUSED)
-    d, _ = H.load("kernel_full_ad_calibrated")
+@pytest.mark.parametrize("path", [FUSED, H3])
+def test_full_size_S1000_rows_vs_oracle(path):
+    """BASELINE size (S = 1000 proposals, 22 atoms, 125 workgroups per coupling net) on both fused kernels - the
+    split-fp16 one is bench.py's default.  (1) 48 rows spread over the launch - all 8 rows of the first, the middle and
+    the last workgroup of each net, 24 random ones in between - against the oracle: proposals, velocities, log p(y|x),
+    and the reverse-move density log p(x~|y~) of those same rows (per-row conditioning, forward pass).  (2) all 1000
+    rows: the size-independent round trip - pushing (y, v) back through the density direction recovers log p."""
+    sd = H.full_kernel_sd()
+    m = H.tw_kernel_model(sd, path=path)
+    d, _ = H.load("kernel_full_ad")
     S = 1000
     g = torch.Generator().manual_seed(5)
-    sd = H.full_kernel_sd(calibrated=True)
     zc, zv = fo.draw_latents(sd, S, (1, 22, 3), g)
     at, xc, xv, mk = d["atom_types"].cuda(), d["x_coords"].cuda(), d["x_velocs"].cuda(), d["masked"].cuda()
     yc, yv, lp = m.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None,
@@ -318,10 +357,22 @@ def test_roundtrip_full_size_S1000():
                           masked_elements=mk.repeat(S, 1))
     assert torch.isfinite(lp).all() and torch.isfinite(ll).all()
     assert H.rel_err(ll.cpu(), lp.squeeze(1).cpu()) < TOL
-    # first 8 rows against the oracle
+    # reverse-move density of every row (velocities negated, evaluation_utils.py:648-657)
+    p_yx = m.log_likelihood(atom_types=at.repeat(S, 1), x_coords=yc.squeeze(1), x_velocs=-yv.squeeze(1),
+                            y_coords=xc.repeat(S, 1, 1), y_velocs=-xv.repeat(S, 1, 1), adj_list=None,
+                            edge_batch_idx=None, masked_elements=mk.repeat(S, 1)).cpu()
+    rows = list(range(0, 8)) + list(range(496, 504)) + list(range(992, 1000))
+    rest = [r for r in torch.randperm(S, generator=g).tolist() if r not in rows][:24]
+    rows = torch.tensor(sorted(rows + rest))
+    assert len(rows) == 48
     ryc, ryv, rlp = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, d["atom_types"], d["x_coords"],
-                                                    d["x_velocs"], d["masked"], zc[:8], zv[:8])
-    assert H.rel_err(yc[:8].cpu(), ryc) < TOL and H.rel_err(lp[:8].cpu(), rlp) < TOL
+                                                    d["x_velocs"], d["masked"], zc[rows], zv[rows])
+    assert H.rel_err(yc.cpu()[rows], ryc) < TOL and H.rel_err(yv.cpu()[rows], ryv) < TOL
+    assert H.rel_err(lp.cpu()[rows], rlp) < TOL and H.elem_rel_err(lp.cpu()[rows], rlp) < TOL
+    n = len(rows)
+    r_yx = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, d["atom_types"].repeat(n, 1), ryc.squeeze(1), -ryv.squeeze(1),
+                             d["x_coords"].repeat(n, 1, 1), -d["x_velocs"].repeat(n, 1, 1), d["masked"].repeat(n, 1))
+    assert H.rel_err(p_yx[rows], r_yx) < TOL and H.elem_rel_err(p_yx[rows], r_yx) < TOL
 
 
 def test_fused_equals_simple_large_batch():

@@ -314,3 +314,161 @@ def test_euler_maruyama_baseline_and_sample_driver():
     assert (np.abs(yv.mean(0) - pv.loc[0].numpy()) < 5 * pv.scale[0].numpy() / 10 + 1e-6).all()
     cs_, vs_ = sample_from_trajectory(m, [batch, batch], 3)
     assert len(cs_) == 2 and cs_[0].shape == (3, V, 3)
+
+
+# ---------------------------------------------------------------------------------------------
+# The drop-in energy route: an openmm.System as the reference's scripts build it -> tw_forcefield tables
+# (evaluate.py:290-301, sample_trajectory.py:190-202, utils/openmm/openmm_bridge.py:252-307).  OpenMM is not in this
+# image: the stand-ins below carry the OpenMM 7.7 getters the reader uses and return Quantity-like values in
+# NON-MD units (Angstrom, kcal/mol, degrees), so the unit conversion is exercised as well.
+# ---------------------------------------------------------------------------------------------
+class _Q:
+    """Quantity stand-in: `to_md` = factor from the unit the value is written in to OpenMM's MD unit system."""
+
+    def __init__(self, value, to_md):
+        self.value, self.to_md = value, to_md
+
+    def value_in_unit_system(self, system):
+        assert system == "md_unit_system"
+        return self.value * self.to_md
+
+
+def _install_fake_openmm_unit(monkeypatch):
+    import sys
+    import types
+
+    mm, unit = types.ModuleType("openmm"), types.ModuleType("openmm.unit")
+    unit.md_unit_system = "md_unit_system"
+    mm.unit = unit
+    monkeypatch.setitem(sys.modules, "openmm", mm)
+    monkeypatch.setitem(sys.modules, "openmm.unit", unit)
+
+
+def _mock_openmm_system(t, extra_forces=(), obc1_custom=False, method=1):
+    ANG, KCAL, DEG = 0.1, 4.184, np.pi / 180.0
+
+    class HarmonicBondForce:
+        def getNumBonds(self): return len(t.bond_idx)
+        def getBondParameters(self, b):
+            return int(t.bond_idx[b, 0]), int(t.bond_idx[b, 1]), _Q(t.bond_par[b, 0] / ANG, ANG), _Q(t.bond_par[b, 1] / (KCAL / ANG**2), KCAL / ANG**2)
+
+    class HarmonicAngleForce:
+        def getNumAngles(self): return len(t.angle_idx)
+        def getAngleParameters(self, a):
+            return (*map(int, t.angle_idx[a]), _Q(t.angle_par[a, 0] / DEG, DEG), _Q(t.angle_par[a, 1] / KCAL, KCAL))
+
+    class PeriodicTorsionForce:
+        def getNumTorsions(self): return len(t.torsion_idx)
+        def getTorsionParameters(self, i):
+            return (*map(int, t.torsion_idx[i]), int(t.torsion_par[i, 0]), _Q(t.torsion_par[i, 1] / DEG, DEG), _Q(t.torsion_par[i, 2] / KCAL, KCAL))
+
+    class NonbondedForce:
+        NoCutoff, CutoffNonPeriodic, CutoffPeriodic = 0, 1, 2
+        def getNonbondedMethod(self): return method
+        def getNumParticles(self): return t.n_atoms
+        def getParticleParameters(self, i):
+            return _Q(t.atom_par[i, 0], 1.0), _Q(t.atom_par[i, 1] / ANG, ANG), _Q(t.atom_par[i, 2] / KCAL, KCAL)
+        def getNumExceptions(self): return len(t.exc_idx)
+        def getExceptionParameters(self, e):
+            return int(t.exc_idx[e, 0]), int(t.exc_idx[e, 1]), _Q(t.exc_par[e, 0], 1.0), _Q(t.exc_par[e, 1] / ANG, ANG), _Q(t.exc_par[e, 2] / KCAL, KCAL)
+        def getCutoffDistance(self): return _Q(t.cutoff / ANG, ANG)
+        def getReactionFieldDielectric(self): return t.rf_dielectric
+
+    class GBSAOBCForce:
+        def getNumParticles(self): return t.n_atoms
+        def getParticleParameters(self, i): return _Q(t.atom_par[i, 0], 1.0), _Q(t.atom_par[i, 3] / ANG, ANG), t.atom_par[i, 4]
+        def getSoluteDielectric(self): return t.solute_dielectric
+        def getSolventDielectric(self): return t.solvent_dielectric
+        def getSurfaceAreaEnergy(self): return _Q(t.surface_area_energy / (KCAL / ANG**2), KCAL / ANG**2)
+
+    class CustomGBForce:  # GBSA-OBC I as openmm.app.internal.customgbforces.GBSAOBC1Force lays it out (plain floats)
+        def getNumComputedValues(self): return 2
+        def getComputedValueParameters(self, i):
+            return [("I", "step(r+sr2-or1)*0.5*(1/L-1/U+0.25*(r-sr2^2/r)*(1/(U^2)-1/(L^2))+0.5*log(L/U)/r); ...", 1),
+                    ("B", "1/(1/or-tanh(0.8*psi+2.909125*psi^3)/radius); psi=I*or; radius=or+offset; offset=0.009", 0)][i]
+        def getNumEnergyTerms(self): return 2
+        def getEnergyTermParameters(self, i):
+            return [("28.3919551*(radius+0.14)^2*(radius/B)^6-0.5*138.935485*(1/soluteDielectric-1/solventDielectric)*charge^2/B; radius=or+offset; offset=0.009", 0),
+                    ("-138.935485*(1/soluteDielectric-1/solventDielectric)*charge1*charge2/f; ...", 2)][i]
+        def getNumPerParticleParameters(self): return 3
+        def getPerParticleParameterName(self, i): return ["charge", "or", "sr"][i]
+        def getNumParticles(self): return t.n_atoms
+        def getParticleParameters(self, i):
+            o_r = t.atom_par[i, 3] - 0.009
+            return (t.atom_par[i, 0], o_r, t.atom_par[i, 4] * o_r)
+        def getNumGlobalParameters(self): return 2
+        def getGlobalParameterName(self, i): return ["solventDielectric", "soluteDielectric"][i]
+        def getGlobalParameterDefaultValue(self, i): return [t.solvent_dielectric, t.solute_dielectric][i]
+
+    class CMMotionRemover:
+        pass
+
+    forces = [HarmonicBondForce(), HarmonicAngleForce(), PeriodicTorsionForce(), NonbondedForce(),
+              CustomGBForce() if obc1_custom else GBSAOBCForce(), CMMotionRemover(), *extra_forces]
+
+    class System:
+        def getNumParticles(self): return t.n_atoms
+        def getForces(self): return forces
+
+    return System()
+
+
+def _tables_equal(a, b):
+    for f in ("bond_idx", "angle_idx", "torsion_idx", "exc_idx"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    for f in ("bond_par", "angle_par", "torsion_par", "exc_par", "atom_par"):
+        assert np.allclose(getattr(a, f), getattr(b, f), rtol=1e-12, atol=1e-15), f
+    for f in ("has_gbsa", "cutoff", "rf_dielectric", "solute_dielectric", "solvent_dielectric", "surface_area_energy"):
+        assert getattr(a, f) == pytest.approx(getattr(b, f), rel=1e-12), f
+
+
+def test_tables_from_openmm_system_round_trip(monkeypatch):
+    """System -> tables must give back alanine_dipeptide_amber99sb() exactly (indices) / to rounding (unit-converted
+    parameters), for the GBSAOBCForce preset and for GBSA-OBC I delivered as a CustomGBForce."""
+    import dataclasses
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.forcefield import alanine_dipeptide_amber99sb, tables_from_openmm_system
+
+    _install_fake_openmm_unit(monkeypatch)
+    t = alanine_dipeptide_amber99sb()
+    _tables_equal(tables_from_openmm_system(_mock_openmm_system(t)), t)
+    t1 = dataclasses.replace(t, has_gbsa=2, solvent_dielectric=78.5)
+    _tables_equal(tables_from_openmm_system(_mock_openmm_system(t1, obc1_custom=True)), t1)
+    # NoCutoff: the cutoff stays 0 (= none)
+    assert tables_from_openmm_system(_mock_openmm_system(t, method=0)).cutoff == 0.0
+
+    class LangevinIntegrator:
+        def getTemperature(self): return _Q(36.85, 1.0)  # value already in kelvin here
+
+    integ = LangevinIntegrator()
+    e = AmberPotentialEnergyTorch.from_openmm(_mock_openmm_system(t), integ, platform_name="CUDA", platform_properties={})
+    assert e.num_particles == 22 and e.get_integrator() is integ
+    assert e.kbT == pytest.approx(8.314462618e-3 * 36.85)
+    _tables_equal(e.tables, t)
+    assert AmberPotentialEnergyTorch.alanine_dipeptide().kbT == pytest.approx(2.57748, abs=1e-5)  # SURVEY a15
+
+
+def test_tables_from_openmm_system_refuses_unknown_forces(monkeypatch):
+    """A force whose energy the kernel would not evaluate is an error (it would bias the acceptance silently)."""
+    from timewarp_amd.forcefield import alanine_dipeptide_amber99sb, tables_from_openmm_system
+
+    _install_fake_openmm_unit(monkeypatch)
+    t = alanine_dipeptide_amber99sb()
+    for name in ("CMAPTorsionForce", "CustomTorsionForce", "CustomNonbondedForce", "CustomBondForce"):
+        with pytest.raises(NotImplementedError, match=name):
+            tables_from_openmm_system(_mock_openmm_system(t, extra_forces=(type(name, (), {})(),)))
+    tables_from_openmm_system(_mock_openmm_system(t, extra_forces=(type("MonteCarloBarostat", (), {})(),)))  # energy-free
+    with pytest.raises(NotImplementedError, match="periodic"):
+        tables_from_openmm_system(_mock_openmm_system(t, method=2))
+    with pytest.raises(NotImplementedError):
+        tables_from_openmm_system(_mock_openmm_system(t, obc1_custom=True), allow_custom_gb_obc1=False)
+
+
+def test_energy_callable_checks_shapes():
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+
+    e = AmberPotentialEnergyTorch.alanine_dipeptide()
+    with pytest.raises(AssertionError, match="number of particles"):
+        e(torch.zeros(3, 21, 3))
+    with pytest.raises(AssertionError, match="size 3"):
+        e(torch.zeros(3, 22, 2))

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import flow_oracle as fo
 from oracle import mh_oracle as mo
 from tests import helpers as H
 from tests.test_mh_oracle import SCENARIOS, check_against_golden, load_mh, replay
@@ -57,6 +58,51 @@ def test_amber_energy_kernel_vs_c_oracle(gb):
     assert e(x.cuda()).shape == (64, 1) and e(x.cuda()).dtype == torch.float32
 
 
+MH_FULL_CASES = [("bench", True, 0, 40), ("scaled", True, 1, 130), ("scaled", False, 1, 130)]
+
+
+@pytest.mark.parametrize("path", [1, 3])
+@pytest.mark.parametrize("kind,random_velocs,seed,num_samples", MH_FULL_CASES)
+def test_full_size_mh_iterations_vs_oracle(path, kind, random_velocs, seed, num_samples):
+    """Whole MH iterations at the bench configuration - full-size kernel_transformer_nvp flow (exact-f32 and
+    split-fp16 fused kernels), AMBER energy kernel, alanine dipeptide, 64 proposals per iteration - against
+    oracle/mh_oracle.sample_with_model + oracle/energy_oracle.c on the same host-drawn noise: emitted states and
+    velocities, accept count, accept indicators (= first-accepted indices), and all eight per-state statistics
+    (reference evaluation_utils.py:609-713, flow.py:242-336)."""
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.utils.evaluation_utils import sample_with_model
+
+    S = 64
+    sd = H.mh_state_dict(kind, random_velocs)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    v0 = torch.randn(1, 22, 3, generator=torch.Generator().manual_seed(9)) * 0.05
+    kw = dict(accept=True, num_proposal_steps=S)
+    if random_velocs:
+        kw.update(random_velocs=True, resample_velocs=True)
+    energy = AmberPotentialEnergyTorch.alanine_dipeptide()
+    ref = mo.sample_with_model(types[None], coords[None], v0, torch.zeros(1, 22, dtype=torch.bool),
+                               mo.OracleModel(sd, H.FULL_KERNEL_SPEC), H.OracleAmberEnergy(energy.tables), masses,
+                               num_samples, H.HostNoise(seed), **kw)
+    model = H.tw_kernel_model(sd, path=path)
+    got = sample_with_model(single_state_batch("ad", types, coords, v0[0]), model, torch.device("cuda"), energy, masses,
+                            num_samples, disable_tqdm=True, noise=H.HostNoise(seed, "cuda"), **kw)
+    (rc, rv, racc, rs), (gc, gv, gacc, gs) = ref, got
+    assert racc >= 1 and rc.shape[0] > S  # at least one accepted proposal, more than one iteration
+    assert gc.shape == rc.shape and gacc == racc
+    assert np.array_equal(gs.acceptance_indicator.astype(bool), rs.acceptance_indicator.astype(bool))
+    assert H.rel_err(gc, rc) < 1e-5 and H.rel_err(gv, rv) < 1e-5
+    assert H.rel_err(gs.p_xy, rs.p_xy) < 1e-5 and H.rel_err(gs.p_yx, rs.p_yx) < 1e-5
+    assert H.elem_rel_err(gs.p_xy, rs.p_xy) < 1e-5 and H.elem_rel_err(gs.p_yx, rs.p_yx) < 1e-5
+    assert H.rel_err(gs.energies_pot, rs.energies_pot) < 1e-5 and H.rel_err(gs.energies_kin, rs.energies_kin) < 1e-5
+    # differences of O(100) quantities: absolute bars at 1e-5 of the magnitude of what is subtracted
+    scale = float(np.abs(rs.p_xy).max() + np.abs(rs.energies_pot).max() + np.abs(rs.energies_kin).max())
+    for f in ("exponent", "energies_pot_delta", "energies_kin_delta"):
+        assert np.abs(getattr(gs, f) - getattr(rs, f)).max() < 1e-5 * scale, f
+    assert np.abs(gs.acceptance - rs.acceptance).max() < 2e-5 * scale  # p_acc = min(1, e^-exponent)
+
+
 def test_accept_kernel_first_index_and_clipping():
     from timewarp_amd.utils.evaluation_utils import _mh_accept
 
@@ -73,6 +119,61 @@ def test_accept_kernel_first_index_and_clipping():
     assert int(res[0]) == int(a_ref.nonzero()[0]) and int(res[1]) == 1
     ex, p_acc, acc, res = _mh_accept((energy + 1e4).cuda(), pxy.cuda(), pyx.cuda(), u.cuda())
     assert int(res[0]) == S - 1 and int(res[1]) == 0
+
+
+def test_accept_kernel_rejects_non_finite_exponents():
+    """torch.min(1, exp(-exp)) propagates NaN and `rand < NaN` is False (reference evaluation_utils.py:665-668): a
+    proposal whose exponent is NaN (or +inf) is rejected and the chain state stays put; -inf is accepted (p = 1).
+    Checked for tw_mh_accept and tw_mh_accept_chains, with the state update done on the device."""
+    from timewarp_amd import _lib
+    from timewarp_amd.utils.evaluation_utils import _mh_accept
+
+    S, V = 64, 5
+    nan, inf = float("nan"), float("inf")
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    yc, yv = torch.randn(S, V, 3, generator=g), torch.randn(S, V, 3, generator=g)
+    x0c, x0v = torch.randn(1, V, 3, generator=g), torch.randn(1, V, 3, generator=g)
+    u = torch.rand(S, generator=g) * 0.5
+    big = torch.full((S,), 1e4)  # exp(-1e4) = 0: rejected
+    zero = torch.zeros(S)
+    for field in range(3):  # the non-finite value arrives through the energy, p_xy or p_yx
+        for bad in (nan, inf if field != 2 else -inf):
+            args = [big.clone(), zero.clone(), zero.clone()]
+            args[field][:] = bad
+            xc, xv = x0c.clone().to(dev), x0v.clone().to(dev)
+            ex, p_acc, acc, res = _mh_accept(args[0].to(dev), args[1].to(dev), args[2].to(dev), u.to(dev), yc.to(dev), yv.to(dev), xc, xv)
+            e_ref = args[0] + args[1] - args[2]
+            p_ref = torch.min(torch.tensor(1.0), torch.exp(-e_ref))
+            assert (acc.cpu() == 0).all() and res[:2].tolist() == [S - 1, 0], (field, bad)
+            assert torch.equal(torch.isnan(p_acc.cpu()), torch.isnan(p_ref))
+            assert torch.equal(xc.cpu(), x0c) and torch.equal(xv.cpu(), x0v)
+    # a NaN row in front of a genuinely accepted one: the first accepted index skips it
+    e = big.clone()
+    e[3], e[7] = nan, -inf
+    xc, xv = x0c.clone().to(dev), x0v.clone().to(dev)
+    ex, p_acc, acc, res = _mh_accept(e.to(dev), zero.to(dev), zero.to(dev), u.to(dev), yc.to(dev), yv.to(dev), xc, xv)
+    assert res[:2].tolist() == [7, 1] and acc.cpu().nonzero().flatten().tolist() == [7]
+    assert torch.equal(xc.cpu()[0], yc[7]) and torch.equal(xv.cpu()[0], yv[7])
+    # two chains in one call (row = proposal * n_chains + chain): chain 0 all-NaN, chain 1 accepts proposal 5
+    C_ = 2
+    e2 = torch.full((S, C_), 1e4)
+    e2[:, 0] = nan
+    e2[5, 1] = -1.0
+    yc2, yv2 = torch.randn(S, C_, V, 3, generator=g), torch.randn(S, C_, V, 3, generator=g)
+    x2c, x2v = torch.randn(C_, V, 3, generator=g), torch.randn(C_, V, 3, generator=g)
+    xc, xv = x2c.clone().to(dev), x2v.clone().to(dev)
+    outs = [torch.empty(S * C_, dtype=dt, device=dev) for dt in (torch.float32, torch.float32, torch.uint8)]
+    res = torch.empty(C_, 4, dtype=torch.int32, device=dev)
+    z2 = torch.zeros(S * C_, device=dev)
+    u2 = torch.full((S * C_,), 0.25, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.tw_mh_accept_chains(e2.reshape(-1).to(dev).data_ptr(), z2.data_ptr(), z2.data_ptr(), u2.data_ptr(),
+                                       yc2.to(dev).data_ptr(), yv2.to(dev).data_ptr(), xc.data_ptr(), xv.data_ptr(),
+                                       outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), res.data_ptr(), S, C_, V,
+                                       _lib.stream_ptr(dev)), "tw_mh_accept_chains")
+    assert res.cpu()[:, :2].tolist() == [[S - 1, 0], [5, 1]]
+    assert torch.equal(xc.cpu()[0], x2c[0]) and torch.equal(xc.cpu()[1], yc2[5, 1]) and torch.equal(xv.cpu()[1], yv2[5, 1])
 
 
 @pytest.mark.parametrize("tag,random_velocs", [("fixedv", False), ("randv", True)])
@@ -209,3 +310,118 @@ def test_multichain_full_size_split_fp16():
     for a, b in zip(singles, multi):
         assert a[0].shape == b[0].shape and a[2] == b[2]
         assert np.allclose(a[0], b[0], rtol=0, atol=1e-6) and np.allclose(a[3].exponent, b[3].exponent, rtol=1e-5, atol=1e-4)
+
+
+def _assert_chain_matches_oracle(got, ref, tol=2e-5, stat_tol=1e-4):
+    (gc, gv, gacc, gs), (rc, rv, racc, rs) = got, ref
+    assert gc.shape == rc.shape and gacc == racc
+    assert np.array_equal(np.asarray(gs.acceptance_indicator).astype(bool), np.asarray(rs.acceptance_indicator).astype(bool))
+    assert H.rel_err(gc, rc) < tol and H.rel_err(gv, rv) < tol
+    for f in ("acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin", "energies_pot_delta", "energies_kin_delta"):
+        a, b = np.asarray(getattr(gs, f), np.float64), np.asarray(getattr(rs, f), np.float64)
+        assert a.shape == b.shape and H.rel_err(a, b) < stat_tol, (f, H.rel_err(a, b))
+
+
+def test_multichain_vs_oracle_per_chain():
+    """Lock-step chains against the ORACLE (not against the product's own single chains): every chain of
+    sample_with_model_chains must equal oracle/mh_oracle.sample_with_model run on that chain alone with the same
+    per-chain host noise - states, velocities, accept counts, indicators and statistics, including the final clip."""
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.utils.multichain import sample_with_model_chains
+
+    z, sd = load_mh()
+    model = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2,
+                              lengthscales=(0.1, 0.5, 1.2), path=2)
+    at = torch.from_numpy(z["atom_types"])
+    x0, v0 = torch.from_numpy(z["x0"]), torch.from_numpy(z["v0"])
+    g = torch.Generator().manual_seed(31)
+    starts = [(x0 + 0.03 * torch.randn(x0.shape, generator=g), v0 + 0.1 * torch.randn(v0.shape, generator=g)) for _ in range(3)]
+    masses = torch.from_numpy(z["masses"])
+    mask = torch.zeros(1, x0.shape[1], dtype=torch.bool)
+    dev = torch.device("cuda")
+    N, S = 70, 10
+    oracle_model = mo.OracleModel(sd, H.TINY_KERNEL_SPEC)
+    for kw in (dict(), dict(random_velocs=True, resample_velocs=True)):
+        refs = [mo.sample_with_model(at, xc, vc, mask, oracle_model, mo.SyntheticEnergy(x0.clone()), masses, N,
+                                     H.HostNoise(700 + c), accept=True, num_proposal_steps=S, **kw)
+                for c, (xc, vc) in enumerate(starts)]
+        multi = sample_with_model_chains([single_state_batch("t", at, xc, vc) for xc, vc in starts], model, dev,
+                                         mo.SyntheticEnergy(x0.clone().cuda()), masses, N, S,
+                                         noises=[H.HostNoise(700 + c, "cuda") for c in range(3)], sync_every=4, **kw)
+        assert sum(r[2] for r in refs) > 0
+        for got, ref in zip(multi, refs):
+            _assert_chain_matches_oracle(got, ref)
+
+
+def test_multichain_full_size_vs_oracle():
+    """The same on the product configuration: full-size flow (split-fp16 kernels), AMBER energy kernel, two chains x
+    32 proposals, weights whose coupling nets matter ("scaled", tests/helpers.py), each chain against the oracle."""
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.utils.multichain import sample_with_model_chains
+
+    sd = H.mh_state_dict("scaled", True)
+    model = H.tw_kernel_model(sd, path=3)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    energy = AmberPotentialEnergyTorch.alanine_dipeptide()
+    g = torch.Generator().manual_seed(1)
+    starts = [coords + 0.0005 * torch.randn(coords.shape, generator=g) for _ in range(2)]
+    kw = dict(random_velocs=True, resample_velocs=True)
+    N, S = 70, 32
+    mask = torch.zeros(1, 22, dtype=torch.bool)
+    refs = [mo.sample_with_model(types[None], xc[None], torch.zeros(1, 22, 3), mask, mo.OracleModel(sd, H.FULL_KERNEL_SPEC),
+                                 H.OracleAmberEnergy(energy.tables), masses, N, H.HostNoise(40 + c), accept=True,
+                                 num_proposal_steps=S, **kw) for c, xc in enumerate(starts)]
+    multi = sample_with_model_chains([single_state_batch("ad", types, xc) for xc in starts], model, torch.device("cuda"),
+                                     energy, masses, N, S, noises=[H.HostNoise(40 + c, "cuda") for c in range(2)],
+                                     sync_every=2, **kw)
+    for got, ref in zip(multi, refs):
+        _assert_chain_matches_oracle(got, ref, tol=1e-5, stat_tol=2e-4)
+
+
+@pytest.mark.parametrize("path", [1, 3])
+def test_sample_drivers_with_hip_flow_vs_oracle(path):
+    """`sample` / `sample_from_trajectory` (reference utils/sampling_utils.py:17-181, the sample.py drivers) running the
+    HIP flow: S x conditional_sample(num_samples=1) with the latents drawn on the device in the reference's order
+    (coords, then velocities, flow.py:274-275).  Re-seeding the device generator reproduces those draws, which the
+    oracle then turns into the expected samples."""
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.utils.sampling_utils import sample, sample_from_trajectory
+
+    sd = H.full_kernel_sd()
+    model = H.tw_kernel_model(sd, path=path)
+    types, coords, _ = synthetic.alanine_dipeptide_state()
+    g = torch.Generator().manual_seed(3)
+    dev = torch.device("cuda")
+    batches = [single_state_batch("ad", types, coords + 0.01 * torch.randn(coords.shape, generator=g),
+                                  0.5 * torch.randn(22, 3, generator=g)) for _ in range(2)]
+    S = 5
+    sc, sv = torch.exp(sd["coords_prior_log_scale"]), torch.exp(sd["velocs_prior_log_scale"])
+    mask = torch.zeros(1, 22, dtype=torch.bool)
+
+    def expected(seed, bs):
+        torch.cuda.manual_seed(seed)
+        out = []
+        for b in bs:
+            zc, zv = [], []
+            for _ in range(S):
+                zc.append((torch.randn((1, 1, 22, 3), device=dev) * sc.to(dev)).cpu())
+                zv.append((torch.randn((1, 1, 22, 3), device=dev) * sv.to(dev)).cpu())
+            yc, yv, _ = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, b.atom_types, b.atom_coords, b.atom_velocs, mask,
+                                                        torch.cat(zc), torch.cat(zv))
+            out.append((yc.squeeze(1).numpy(), yv.squeeze(1).numpy()))
+        return out
+
+    torch.cuda.manual_seed(77)
+    c, v = sample(model, batches[0], S, device=dev)
+    assert c.shape == (S, 22, 3) and c.dtype == np.float64 and v.dtype == np.float64  # sampling_utils.py:117-141
+    (ec, ev), = expected(77, batches[:1])
+    assert H.rel_err(c, ec) < 1e-5 and H.rel_err(v, ev) < 1e-5
+    torch.cuda.manual_seed(78)
+    cs, vs = sample_from_trajectory(model, batches, S, device=dev)
+    exp = expected(78, batches)
+    assert len(cs) == len(vs) == 2
+    for (ec, ev), c, v in zip(exp, cs, vs):
+        assert H.rel_err(c, ec) < 1e-5 and H.rel_err(v, ev) < 1e-5

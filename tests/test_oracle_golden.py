@@ -35,6 +35,18 @@ def test_kernel_tiny_batch_and_sampling():
     _check_case(d, sd, H.TINY_KERNEL_SPEC, "b1_")
 
 
+def test_kernel_normalise_flag_is_ignored():
+    """A model configured with normalise_kernel_values=False: the reference still L1-normalises its scores
+    (kernel_attention.py:197-206 never forwards the flag), and so does the oracle whatever its spec says."""
+    import dataclasses
+
+    d, sd = H.load("kernel_nonorm_tiny")
+    for flag in (False, True):
+        spec = dataclasses.replace(H.TINY_KERNEL_SPEC, normalise_kernel_values=flag)
+        _check_case(d, sd, spec)
+        _check_case(d, sd, spec, "b1_")
+
+
 def test_kernel_learnable_lengthscales():
     """attention_type "learnable_kernel" with different log_lengthscales per layer: a flow call uses the
     lengthscales of the first attention layer it evaluates (the reference's score cache ignores them)."""

@@ -119,12 +119,13 @@ def lib_path() -> str:
 
 
 def load(build_if_missing: bool = True) -> C.CDLL:
-    """Load (building with hipcc first if the .so is absent or stale and hipcc is available)."""
+    """Load (building with hipcc first if the .so is absent or stale - by content hash of csrc/ - and hipcc is
+    available; a fresh library makes build_library() return at once)."""
     global _LIB
     if _LIB is not None:
         return _LIB
     path = _build.LIB_PATH
-    if build_if_missing and (not os.path.exists(path)):
+    if build_if_missing and (_build.hipcc_path() is not None or not os.path.exists(path)):
         _build.build_library()
     if not os.path.exists(path):
         raise RuntimeError(

@@ -1,6 +1,7 @@
 // Glue kernels (scores, centring, coupling, prior log-prob, kinetic energy, MH accept, chirality)
 // and the SIMPLE flow path: one plain HIP kernel per reference torch op.  The simple path is the
-// always-available HIP implementation (all variants, any atom count); the fused f32-MFMA path
+// always-available HIP implementation (all variants; molecules up to ~180 atoms, whose V x V scores fit the CU's
+// LDS - larger ones are refused with a message, TW_LDS_LIMIT); the fused f32-MFMA path
 // (tw_netblock.hip) is the fast one for the kernel variant.
 #include <stdarg.h>
 
@@ -145,10 +146,23 @@ __global__ void scores_kernel(const float* __restrict__ x, const uint8_t* __rest
   }
 }
 
+// The per-op kernels hold one molecule's V x V score / distance matrix in LDS.  Up to 64 KiB of dynamic LDS launches
+// as is; up to the CU's 160 KiB after raising the kernel's limit; beyond that (V > ~180) the call is refused with a
+// message instead of failing at launch.
+#define TW_LDS_LIMIT(kernel, bytes, V)                                                                        \
+  do {                                                                                                        \
+    TW_REQUIRE((bytes) <= (size_t)160 * 1024,                                                                 \
+               "n_atoms = %d needs %zu bytes of LDS per molecule on the per-op path (V x V scores), the CU has 163840", \
+               (int)(V), (size_t)(bytes));                                                                    \
+    if ((bytes) > (size_t)64 * 1024)                                                                          \
+      TW_HIP_CHECK(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+  } while (0)
+
 int launch_scores(const float* x, const uint8_t* masked, const float* ls, int H, int64_t B, int V,
                   int normalise, int use_mm, float* out, hipStream_t s, const float* coeffs, int order, int force_zero) {
   if (B == 0) return TW_OK;
   size_t shm = (size_t)(3 * V + V * V) * sizeof(float);
+  TW_LDS_LIMIT(scores_kernel, shm, V);
   hipLaunchKernelGGL(scores_kernel, dim3((unsigned)B), dim3(256), shm, s, x, masked, ls, H, V, normalise,
                      use_mm, out, coeffs, order, force_zero);
   TW_LAUNCH_CHECK();
@@ -324,7 +338,10 @@ __global__ void mh_accept_kernel(const float* __restrict__ energy, const float* 
   for (int64_t s = threadIdx.x; s < S; s += blockDim.x) {
     const int64_t i = s * C + c;
     const float e = energy[i] + p_xy[i] - p_yx[i];
-    const float p = fminf(1.f, expf(-e));
+    // torch.min(1, exp(-e)) propagates NaN and `rand < NaN` is False (evaluation_utils.py:665-668): a proposal with
+    // a non-finite exponent is rejected.  fminf alone would return 1 for a NaN exponent and accept it.
+    const float ee = expf(-e);
+    const float p = (ee != ee) ? ee : fminf(1.f, ee);
     const bool acc = u[i] < p;
     out_exp[i] = e;
     out_pacc[i] = p;
@@ -655,6 +672,7 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
           return rc;
       }
       if ((rc = launch_linear(w.h, lb + L.layer.wv, nullptr, w.vals, M, HD, d.d_model, ACT_NONE, s))) return rc;
+      TW_LDS_LIMIT(attend_kernel, (size_t)V * V * 4, V);
       hipLaunchKernelGGL(attend_kernel, dim3((unsigned)a.n_rows, d.n_heads), dim3(128), (size_t)V * V * 4, s, w.scores,
                          w.vals, w.att, a.n_cond, d.n_heads, V, d.d_model);
       TW_LAUNCH_CHECK();
@@ -662,6 +680,7 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
     } else {
       if ((rc = launch_linear(w.h, lb + L.layer.in_w, lb + L.layer.in_b, w.vals, M, 3 * d.d_model, d.d_model, ACT_NONE, s))) return rc;
       const int dh = d.d_model / d.n_heads;
+      TW_LDS_LIMIT(sdpa_kernel, (size_t)(3 * V * dh + V * V) * 4, V);
       hipLaunchKernelGGL(sdpa_kernel, dim3((unsigned)a.n_rows, d.n_heads), dim3(128),
                          (size_t)(3 * V * dh + V * V) * 4, s, w.vals, a.masked, a.n_cond, w.att, V, d.d_model,
                          d.n_heads);

@@ -15,9 +15,11 @@ GAS_CONSTANT = 8.314462618e-3  # kJ/(mol K), as openmm.unit.MOLAR_GAS_CONSTANT_R
 
 
 class AmberPotentialEnergyTorch:
-    def __init__(self, tables: ForceFieldTables, temperature: float = 310.0):
+    def __init__(self, tables: ForceFieldTables, temperature: float = 310.0, integrator=None):
         self.tables = tables
         self.temperature = float(temperature)
+        self.num_particles = tables.n_atoms  # openmm_bridge.py:279
+        self._integrator = integrator
         self._dev = {}
 
     @classmethod
@@ -29,12 +31,17 @@ class AmberPotentialEnergyTorch:
     def from_openmm(cls, system, integrator=None, platform_name=None, platform_properties=None, **_):
         """Same positional arguments as OpenmmPotentialEnergyTorch(system, integrator, platform_name=...)
         (evaluate.py:296-301); the platform arguments are irrelevant here and ignored."""
+        from .forcefield import _md
+
         temperature = 310.0
         if integrator is not None and hasattr(integrator, "getTemperature"):
-            import openmm.unit as u
+            temperature = _md(integrator.getTemperature())  # kelvin in OpenMM's MD unit system
+        return cls(tables_from_openmm_system(system), temperature, integrator)
 
-            temperature = integrator.getTemperature().value_in_unit(u.kelvin)
-        return cls(tables_from_openmm_system(system), temperature)
+    def get_integrator(self):
+        """openmm_bridge.py:296-297: the integrator the energy object was built with (None for the built-in presets,
+        which carry their temperature themselves)."""
+        return self._integrator
 
     @property
     def kbT(self) -> float:
@@ -50,6 +57,9 @@ class AmberPotentialEnergyTorch:
     @torch.no_grad()
     def energy_and_terms(self, coords: torch.Tensor, want_terms: bool = False):
         V = self.tables.n_atoms
+        # the reference's two assertions (openmm_bridge.py:286-291)
+        assert coords.size(-1) == 3, f"last dimension is expected to be of size 3 but it is {coords.size(-1)}"
+        assert coords.size(-2) == V, f"size {coords.size()} does not align with expected number of particles {V}"
         x = _lib.require_gpu_tensor(coords.reshape(-1, V, 3), torch.float32, "coords")
         n = x.shape[0]
         dev = x.device

@@ -360,68 +360,105 @@ def tables_from_pdb(path: str) -> ForceFieldTables:
     return amber99sbildn_obc_tables(names, res, rid)
 
 
-def tables_from_openmm_system(system) -> ForceFieldTables:  # pragma: no cover - needs OpenMM
-    """Extract the tables from an `openmm.System` (what evaluate.py:290-301 /
-    sample_trajectory.py:190-202 build).  Mirrors the Force API of OpenMM 7.7."""
-    import openmm
-    import openmm.unit as u
+def _md(x) -> float:
+    """Value of an OpenMM `Quantity` in OpenMM's MD unit system (nm, kJ/mol, elementary charge, radian, kelvin) - the
+    units of `tw_forcefield` - or the number itself (getters of unitless values and of CustomGBForce return floats)."""
+    if hasattr(x, "value_in_unit_system"):
+        import openmm.unit as u
 
-    nm, kj, rad = u.nanometer, u.kilojoule_per_mole, u.radian
+        return float(x.value_in_unit_system(u.md_unit_system))
+    return float(x)
+
+
+# Forces that contribute no potential energy (simulation/md.py:160-187 adds none of these itself; OpenMM's
+# createSystem adds CMMotionRemover); anything else that is not handled below is an error, not a silent skip.
+_ENERGY_FREE_FORCES = ("CMMotionRemover", "AndersenThermostat", "MonteCarloBarostat", "MonteCarloAnisotropicBarostat",
+                       "MonteCarloMembraneBarostat", "MonteCarloFlexibleBarostat")
+_NO_CUTOFF, _CUTOFF_NON_PERIODIC = 0, 1  # openmm.NonbondedForce.NoCutoff / CutoffNonPeriodic
+
+
+def tables_from_openmm_system(system, allow_custom_gb_obc1: bool = True) -> ForceFieldTables:
+    """Extract the tables from an `openmm.System` (what evaluate.py:290-301 / sample_trajectory.py:190-202 build with
+    simulation/md.py:128-187).  Mirrors the Force getters of OpenMM 7.7; forces are recognised by class name, so any
+    object with those getters works (tests/test_host_logic.py drives it with a stand-in System).  A force that
+    carries energy and is not one of HarmonicBond / HarmonicAngle / PeriodicTorsion / Nonbonded (NoCutoff or
+    CutoffNonPeriodic) / GBSAOBC / CustomGB-as-OBC-I raises NotImplementedError: dropping it would bias the MH
+    acceptance silently."""
     out: Dict[str, list] = {k: [] for k in ("bi", "bp", "ai", "ap", "ti", "tp", "ei", "ep")}
     atom_par = np.zeros((system.getNumParticles(), 5))
     kw = dict(has_gbsa=0, cutoff=0.0, rf_dielectric=78.3)
+    seen = set()
     for force in system.getForces():
-        if isinstance(force, openmm.HarmonicBondForce):
+        kind = type(force).__name__
+        if kind in _ENERGY_FREE_FORCES:
+            continue
+        if kind in seen and kind in ("NonbondedForce", "GBSAOBCForce", "CustomGBForce"):
+            raise NotImplementedError(f"two {kind} objects in one System")
+        seen.add(kind)
+        if kind == "HarmonicBondForce":
             for b in range(force.getNumBonds()):
                 i, j, r0, k = force.getBondParameters(b)
-                out["bi"].append((i, j)); out["bp"].append((r0.value_in_unit(nm), k.value_in_unit(kj / nm**2)))
-        elif isinstance(force, openmm.HarmonicAngleForce):
+                out["bi"].append((i, j)); out["bp"].append((_md(r0), _md(k)))
+        elif kind == "HarmonicAngleForce":
             for a in range(force.getNumAngles()):
                 i, j, k_, t0, k = force.getAngleParameters(a)
-                out["ai"].append((i, j, k_)); out["ap"].append((t0.value_in_unit(rad), k.value_in_unit(kj / rad**2)))
-        elif isinstance(force, openmm.PeriodicTorsionForce):
+                out["ai"].append((i, j, k_)); out["ap"].append((_md(t0), _md(k)))
+        elif kind == "PeriodicTorsionForce":
             for t in range(force.getNumTorsions()):
                 a, b, c, d, per, phase, k = force.getTorsionParameters(t)
-                out["ti"].append((a, b, c, d)); out["tp"].append((float(per), phase.value_in_unit(rad), k.value_in_unit(kj)))
-        elif isinstance(force, openmm.NonbondedForce):
+                out["ti"].append((a, b, c, d)); out["tp"].append((float(per), _md(phase), _md(k)))
+        elif kind == "NonbondedForce":
+            method = int(force.getNonbondedMethod())
+            if method not in (_NO_CUTOFF, _CUTOFF_NON_PERIODIC):
+                raise NotImplementedError("periodic nonbonded methods (CutoffPeriodic / Ewald / PME) are not supported")
             for i in range(force.getNumParticles()):
                 q, sig, eps = force.getParticleParameters(i)
-                atom_par[i, 0:3] = (q.value_in_unit(u.elementary_charge), sig.value_in_unit(nm), eps.value_in_unit(kj))
+                atom_par[i, 0:3] = (_md(q), _md(sig), _md(eps))
             for e in range(force.getNumExceptions()):
                 i, j, qq, sig, eps = force.getExceptionParameters(e)
                 out["ei"].append((i, j))
-                out["ep"].append((qq.value_in_unit(u.elementary_charge**2), sig.value_in_unit(nm), eps.value_in_unit(kj)))
-            if force.getNonbondedMethod() != openmm.NonbondedForce.NoCutoff:
-                kw["cutoff"] = force.getCutoffDistance().value_in_unit(nm)
-            kw["rf_dielectric"] = force.getReactionFieldDielectric()
-        elif isinstance(force, openmm.GBSAOBCForce):
+                out["ep"].append((_md(qq), _md(sig), _md(eps)))
+            if method == _CUTOFF_NON_PERIODIC:
+                kw["cutoff"] = _md(force.getCutoffDistance())
+            kw["rf_dielectric"] = float(force.getReactionFieldDielectric())
+        elif kind == "GBSAOBCForce":
             kw["has_gbsa"] = 1
             for i in range(force.getNumParticles()):
                 _, radius, scale = force.getParticleParameters(i)
-                atom_par[i, 3:5] = (radius.value_in_unit(nm), scale)
-            kw["solute_dielectric"] = force.getSoluteDielectric()
-            kw["solvent_dielectric"] = force.getSolventDielectric()
-            kw["surface_area_energy"] = force.getSurfaceAreaEnergy().value_in_unit(kj / nm**2)
-        elif isinstance(force, openmm.CustomGBForce):
-            # amber14's implicit/obc1.xml (T1B-peptides preset, simulation/md.py) builds GBSA-OBC I as a CustomGBForce
-            # (openmm.app.internal.customgbforces.GBSAOBC1Force): per-particle parameters (charge, or, sr) with
-            # or = radius - 0.009 nm and sr = scale * or; recognised by its tanh coefficients.  Untested here (no OpenMM).
+                atom_par[i, 3:5] = (_md(radius), _md(scale))
+            kw["solute_dielectric"] = float(force.getSoluteDielectric())
+            kw["solvent_dielectric"] = float(force.getSolventDielectric())
+            kw["surface_area_energy"] = _md(force.getSurfaceAreaEnergy())
+        elif kind in ("CustomGBForce", "GBSAOBC1Force") and allow_custom_gb_obc1:
+            # amber14's implicit/obc1.xml (T1B-peptides preset, simulation/md.py:153-159) builds GBSA-OBC I as a
+            # CustomGBForce (openmm.app.internal.customgbforces.GBSAOBC1Force): per-particle parameters
+            # (charge, or, sr) with or = radius - 0.009 nm and sr = scale * or; recognised by its tanh coefficients.
+            # No known-answer data exists for this mode (parity unpinned, DESIGN section 2).
             exprs = " ".join(force.getComputedValueParameters(i)[1] for i in range(force.getNumComputedValues()))
             if "2.909125" not in exprs:
                 raise NotImplementedError("CustomGBForce other than GBSA-OBC I (implicit/obc1.xml) is not supported")
             kw["has_gbsa"] = 2
             names = [force.getPerParticleParameterName(i) for i in range(force.getNumPerParticleParameters())]
             for i in range(force.getNumParticles()):
-                par = dict(zip(names, force.getParticleParameters(i)))
+                par = dict(zip(names, (_md(v) for v in force.getParticleParameters(i))))
                 o_r = par.get("or", par.get("radius"))
                 s_r = par.get("sr", par.get("scale"))
                 radius = o_r + 0.009 if "or" in par else o_r
                 scale = s_r / o_r if "sr" in par else s_r
                 atom_par[i, 3:5] = (radius, scale)
             gp = {force.getGlobalParameterName(i): force.getGlobalParameterDefaultValue(i) for i in range(force.getNumGlobalParameters())}
-            kw["solute_dielectric"] = gp.get("soluteDielectric", 1.0)
-            kw["solvent_dielectric"] = gp.get("solventDielectric", 78.5)
+            kw["solute_dielectric"] = float(gp.get("soluteDielectric", 1.0))
+            kw["solvent_dielectric"] = float(gp.get("solventDielectric", 78.5))
+            # the ACE term's coefficient is written into the energy expression, 28.3919551 = 4 pi * 2.25936 kJ/mol/nm^2
+            energy_terms = " ".join(force.getEnergyTermParameters(i)[0] for i in range(force.getNumEnergyTerms()))
+            if "28.3919551" not in energy_terms:
+                raise NotImplementedError("GBSA-OBC I CustomGBForce without the standard ACE surface term (28.3919551)")
             kw["surface_area_energy"] = 2.25936
+        else:
+            raise NotImplementedError(
+                f"openmm force {kind!r} is not evaluated by the HIP energy kernel (supported: HarmonicBondForce, "
+                "HarmonicAngleForce, PeriodicTorsionForce, NonbondedForce without periodic boundary, GBSAOBCForce, "
+                "GBSA-OBC I as CustomGBForce); its energy would be missing from the MH acceptance")
     f = lambda a, w: np.asarray(a, dtype=np.float64).reshape(-1, w)
     g = lambda a, w: np.asarray(a, dtype=np.int32).reshape(-1, w)
     return ForceFieldTables(g(out["bi"], 2), f(out["bp"], 2), g(out["ai"], 3), f(out["ap"], 2), g(out["ti"], 4),

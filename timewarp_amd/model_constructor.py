@@ -117,8 +117,12 @@ def custom_transformer_nvp_constructor(config, execution_path: Optional[int] = N
     ]
     flow = L.ConditionalSequentialFlow(chain, nn.Embedding(len(ELEMENT_VOCAB), emb))
     srg, icv, disp = _density_flags(config)
+    # normalise = True whatever the config says: KernelAttention.forward (kernel_attention.py:197-206, inherited by the
+    # learnable-lengthscale and Chebyshev classes) never hands `normalise_kernel_values` to
+    # compute_kernel_attention_scores, whose default is True (:75) - reference models always L1-normalise.  The flag
+    # stays on the attention modules as an attribute, as in the reference (golden kernel_nonorm_tiny.npz).
     dims = FlowDims(KERNEL, n_coupling, n_layers, d_model, d_ff, hidden, emb, H, 0, len(ELEMENT_VOCAB), pos_mod,
-                    disp, icv, bool(normalise), 1e-5, learnable_lengthscales=attention_type == "learnable_kernel", cheb_order=cheb_order, cheb_force_zero=cheb_zero)
+                    disp, icv, True, 1e-5, learnable_lengthscales=attention_type == "learnable_kernel", cheb_order=cheb_order, cheb_force_zero=cheb_zero)
     path = default_execution_path() if execution_path is None else execution_path
     return ConditionalFlowDensityModel(flow, dims, scale_requires_grad=srg, execution_path=path)
 

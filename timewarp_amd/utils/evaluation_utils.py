@@ -110,9 +110,12 @@ class DeviceNoise:
     def __init__(self, device, seed: Optional[int] = None):
         self.device = device
         self.gen = None
+        self.host_gen = None  # the rotation matrix is drawn on the host (3 x 3, fp64)
         if seed is not None:
             self.gen = torch.Generator(device=device)
             self.gen.manual_seed(int(seed))
+            self.host_gen = torch.Generator()
+            self.host_gen.manual_seed(int(seed))
 
     def randn_like(self, t):
         return torch.randn(t.shape, device=t.device, dtype=t.dtype, generator=self.gen)
@@ -127,7 +130,7 @@ class DeviceNoise:
 
     def rotation(self):
         # uniform SO(3) via QR of a Gaussian matrix (the reference uses scipy's Rotation.random())
-        q, r = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))
+        q, r = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64, generator=self.host_gen))
         q = q * torch.sign(torch.diagonal(r))
         if torch.det(q) < 0:
             q[:, 0] = -q[:, 0]
