@@ -203,10 +203,72 @@ def test_preferred_split_fp16_path_falls_back_per_call(monkeypatch):
     assert dense._path_for(22) == 0
 
 
-def test_full_dense_ad_golden():
+@pytest.mark.parametrize("path", [SIMPLE, FUSED, 0])
+def test_full_dense_ad_golden(path):
+    """transformer_nvp (dense softmax attention, BASELINE config 4) on the per-op path, on the fused f32-MFMA dense
+    net-block kernel, and through TW_PATH_AUTO (which must pick the fused kernel for this configuration)."""
     d, _ = H.load("dense_full_ad")
-    m = H.tw_dense_model(H.full_dense_sd(), path=SIMPLE)
+    m = H.tw_dense_model(H.full_dense_sd(), path=path)
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
+    if path == 0:
+        assert m._dev_weights["f32"] is not None  # the fused kernel's weight stream was built and used
+
+
+@pytest.mark.parametrize("path", [SIMPLE, FUSED])
+def test_full_dense_padded_golden(path):
+    """Padded batch (22 / 17 / 20 real atoms) through nn.MultiheadAttention's src_key_padding_mask
+    (transformer_block.py:57-68): reference vectors."""
+    d, _ = H.load("dense_full_padded")
+    m = H.tw_dense_model(H.full_dense_sd(), path=path)
+    out = m.log_likelihood(atom_types=d["atom_types"].cuda(), x_coords=d["x_coords"].cuda(), x_velocs=d["x_velocs"].cuda(),
+                           y_coords=d["y_coords"].cuda(), y_velocs=d["y_velocs"].cuda(), adj_list=None, edge_batch_idx=None,
+                           masked_elements=d["masked"].cuda()).cpu()
+    assert H.rel_err(out, d["loglik"]) < TOL
+
+
+@pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25]),
+                                    (16, [16, 13, 16, 16, 16, 10, 16]), (48, [48, 40, 33]), (60, [60, 44]), (64, [64, 51])])
+def test_fused_dense_batched_padding_vs_oracle(V, lens):
+    """Ragged batches on the fused dense kernel against the oracle: 3- and 4-tile waves, several molecules per wave,
+    padded keys, one molecule filling the whole wave."""
+    sd = H.full_dense_sd()
+    g = torch.Generator().manual_seed(200 + V)
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.3
+    x_v = torch.randn(B, V, 3, generator=g) * 0.5
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+    y_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    ref = fo.log_likelihood(sd, H.FULL_DENSE_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    for path in (FUSED, SIMPLE):
+        m = H.tw_dense_model(sd, path=path)
+        out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                               y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
+        assert H.rel_err(out, ref) < TOL, (path, H.rel_err(out, ref))
+
+
+def test_fused_dense_S1000_roundtrip():
+    """BASELINE config 4 size (1000 proposals): reverse pass then forward pass recover log p; 16 spread rows vs oracle."""
+    sd = H.full_dense_sd()
+    m = H.tw_dense_model(sd, path=FUSED)
+    d, _ = H.load("dense_full_ad")
+    S = 1000
+    g = torch.Generator().manual_seed(6)
+    zc, zv = fo.draw_latents(sd, S, (1, 22, 3), g)
+    at, xc, xv, mk = d["atom_types"].cuda(), d["x_coords"].cuda(), d["x_velocs"].cuda(), d["masked"].cuda()
+    yc, yv, lp = m.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None, edge_batch_idx=None,
+                                                masked_elements=mk, num_samples=S, z_coords=zc.cuda(), z_velocs=zv.cuda())
+    ll = m.log_likelihood(atom_types=at.repeat(S, 1), x_coords=xc.repeat(S, 1, 1), x_velocs=xv.repeat(S, 1, 1),
+                          y_coords=yc.squeeze(1), y_velocs=yv.squeeze(1), adj_list=None, edge_batch_idx=None,
+                          masked_elements=mk.repeat(S, 1))
+    assert H.rel_err(ll.cpu(), lp.squeeze(1).cpu()) < TOL
+    rows = torch.tensor([0, 1, 7, 8, 250, 251, 499, 500, 503, 504, 750, 901, 992, 997, 998, 999])
+    ryc, ryv, rlp = fo.conditional_sample_with_logp(sd, H.FULL_DENSE_SPEC, d["atom_types"], d["x_coords"], d["x_velocs"],
+                                                    d["masked"], zc[rows], zv[rows])
+    assert H.rel_err(yc.cpu()[rows], ryc) < TOL and H.rel_err(yv.cpu()[rows], ryv) < TOL and H.rel_err(lp.cpu()[rows], rlp) < TOL
 
 
 H3_ATOM_COUNTS = (12, 16, 22, 24, 48)  # molecule sizes for which the 48-token wave layout (NT = 3) is the chosen one

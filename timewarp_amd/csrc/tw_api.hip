@@ -34,6 +34,7 @@ static int check_desc(const tw_flow_desc* d) {
 
 static bool fused_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom g;
+  if (d.variant == 1) return dense_fused_supported(d, n_atoms);
   return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb % 4 == 0 &&
          d.d_emb + 9 <= 48 && fused_geom(n_atoms, &g);
 }

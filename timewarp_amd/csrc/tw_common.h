@@ -161,6 +161,13 @@ int launch_coupling(const float* s_raw, const float* t, const uint8_t* masked, i
 int pack_weights(const tw_flow_desc& d, const float* raw, float* packed, hipStream_t s);
 int debug_netblock_simple(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
 int debug_netblock_fused(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
+// fused dense-softmax net-block (tw_netblock_dense.hip); reached through the five functions above when variant == 1
+bool dense_fused_supported(const tw_flow_desc& d, int n_atoms);
+PackedLayout dense_packed_layout(const tw_flow_desc& d);
+int dense_pack_weights(const tw_flow_desc& d, const float* raw, float* packed, hipStream_t s);
+int64_t dense_fused_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms);
+int flow_pass_fused_dense(const FlowArgs& a);
+int debug_netblock_fused_dense(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
 // split-fp16 fused path (tw_netblock_h3.hip); FlowArgs::packed points at the h3 stream (bytes)
 bool h3_supported(const tw_flow_desc& d, int n_atoms);
 int64_t h3_packed_bytes(const tw_flow_desc& d);

@@ -1,6 +1,6 @@
 """Flow-pass timings of the BASELINE configs that are parity cases rather than the bench line:
 cfg 3 (kernel flow, ~60 atoms, 512 proposals: exact-f32 fused kernel with 64-token waves) and cfg 4 (dense softmax
-transformer_nvp on alanine dipeptide: per-op path)."""
+transformer_nvp on alanine dipeptide: fused dense kernel and per-op path)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import helpers as H
@@ -29,12 +29,13 @@ flop = 16 * V * (4478976 + 4608 * V) * S
 print(f"cfg3 kernel flow V={V} S={S} fused-f32: {ms:.2f} ms per reverse pass, {flop / ms / 1e9:.1f} TFLOP/s algorithmic")
 # cfg 4
 V, S = 22, 1000
-md = H.tw_dense_model(H.full_dense_sd(), path=2)
 at = torch.randint(0, 5, (1, V), generator=g).cuda()
 xc = (torch.randn(1, V, 3, generator=g) * 0.3).cuda()
 xv = (torch.randn(1, V, 3, generator=g) * 0.5).cuda()
 mk = torch.zeros(1, V, dtype=torch.bool).cuda()
-ms = timed(lambda: md.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None, edge_batch_idx=None,
-                                                   masked_elements=mk, num_samples=S), iters=2)
 flop = 16 * V * 3726336 * S
-print(f"cfg4 dense flow V={V} S={S} per-op path: {ms:.1f} ms per reverse pass, {flop / ms / 1e9:.1f} TFLOP/s algorithmic")
+for path, name, iters in ((1, "fused f32-MFMA dense net-block kernel", 5), (2, "per-op path", 2)):
+    md = H.tw_dense_model(H.full_dense_sd(), path=path)
+    ms = timed(lambda: md.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None, edge_batch_idx=None,
+                                                       masked_elements=mk, num_samples=S), iters=iters)
+    print(f"cfg4 dense flow V={V} S={S} {name}: {ms:.2f} ms per reverse pass, {flop / ms / 1e9:.1f} TFLOP/s algorithmic")
