@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 2
+#define TW_ABI_VERSION 3
 
 typedef enum {
   TW_OK = 0,
@@ -228,6 +228,40 @@ int tw_mh_accept_chains(const float* energy, const float* p_xy, const float* p_y
                         const float* y_coords, const float* y_velocs, float* x_coords, float* x_velocs,
                         float* out_exponent, float* out_p_acc, uint8_t* out_accepted, int32_t* result,
                         int64_t n_proposals, int64_t n_chains, int32_t n_atoms, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One whole iteration of the loop body of sample_with_model (utils/evaluation_utils.py:609-713) in one call, for the
+ * case the reference's scripts run: B = 1 conditioning state, S parallel proposals, accept = True.  Equivalent to
+ *   tw_flow_sample_with_logp (proposals y, log p(y|x))  ->  tw_amber_energy (y and x)  ->  tw_kinetic_energy (y and x)
+ *   ->  tw_chirality_changed  ->  tw_flow_log_likelihood (reverse move, velocities negated unless random_velocs)
+ *   ->  tw_mh_accept
+ * with the elementwise steps in between done on the device; the glue is four small launches instead of ~70.
+ *   zy_coords / zy_velocs [n_proposals + 1, n_atoms, 3]: IN the latent noise of the S proposals, already multiplied by
+ *     exp(prior log-scale) (rows 0..S-1; flow.py:274-275, coords drawn first); OUT the proposals y_coords / y_velocs in
+ *     those rows.  Row S of zy_coords is scratch (the current state rides along in the energy launch).
+ *   x_coords / x_velocs [n_atoms, 3]: the current state (x_velocs already resampled if the caller resamples);
+ *   new_coords / new_velocs [n_atoms, 3]: y[k] if a proposal was accepted, else the current state.
+ *   u [S]: the uniform draws of the accept test.
+ *   out_stats [8, S]: p_acc, log p(y|x), log p(x~|y~), exponent, E_pot(y)/kT (+2000 on a chirality change), E_kin(y),
+ *     E_pot(y)/kT - E_pot(x)/kT, E_kin(y) - E_kin(x)  (the ChainStats columns, evaluation_utils.py:721-728);
+ *   out_accepted [S]; result int32[4] = {first accepted index or S-1, any accepted, 0, 0}  (as tw_mh_accept).
+ * The caller applies the reference's clip k = min(k, N - i) (:680) when it emits the chain states. */
+typedef struct {
+  int32_t random_velocs;       /* compute_kinetic_energy form and the sign of the reverse move's velocities */
+  int32_t n_centres;           /* chirality guard (utils/chirality.py): 0 = off */
+  const int32_t* centres;      /* [n_centres, 4] */
+  const float* reference_signs;/* [n_centres] */
+  const float* masses;         /* [n_atoms]; may be NULL when random_velocs */
+  float kbT;                   /* kJ/mol */
+} tw_mh_options;
+
+int64_t tw_mh_iteration_workspace_bytes(const tw_flow_desc* desc, int64_t n_proposals, int32_t n_atoms);
+int tw_mh_iteration(const tw_flow_desc* desc, const float* raw, const void* packed, int32_t path,
+                    const tw_forcefield* ff, const tw_mh_options* opt, const int32_t* atom_types,
+                    const uint8_t* masked, int32_t n_atoms, const float* x_coords, const float* x_velocs,
+                    float* zy_coords, float* zy_velocs, const float* u, float* new_coords, float* new_velocs,
+                    float* out_stats, uint8_t* out_accepted, int32_t* result, int64_t n_proposals,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* check_symmetry_change (utils/chirality.py:40-80): sign of the triple product at each
  * chirality centre vs reference_signs; out_changed [n_rows] uint8.  centres [n_centres,4] int32. */

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/timewarp_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().tw_abi_version() == 2
+    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_raw_layout_matches_library_and_oracle_template():
@@ -168,6 +168,26 @@ def test_forcefield_tables_alanine_dipeptide():
     assert len(t.exc_idx) > n12_13 and (t.exc_par[:n12_13, 0] == 0).all()
     pairs = {tuple(p) for p in t.exc_idx.tolist()}
     assert len(pairs) == len(t.exc_idx)  # no duplicates
+
+
+def test_alanine_dipeptide_charges_against_the_pinned_conventions():
+    """The ACE / ALA / NME charge rows are the one part of the alanine-dipeptide table the NNQQ known-answer file cannot
+    exercise (tests/test_energy_kat.py pins every type, bond, angle, torsion, LJ and GB class they use).  What can
+    still be checked: ff94 gives every non-terminal residue the same backbone N / H / C / O charges, so the ALA row must
+    carry exactly the values the pinned ASN and GLN rows carry; ACE's C / O and NME's N / H are those same backbone
+    charges (C of ACE -0.0001 as in the ff94 library, so that the cap is neutral); every residue is neutral; hydrogens on one carbon are equal."""
+    from timewarp_amd.forcefield import RESIDUES
+
+    q = {r: RESIDUES[r]["charges"] for r in ("ACE", "ALA", "NME", "ASN", "GLN")}
+    for atom in ("N", "H", "C", "O"):
+        assert q["ALA"][atom] == q["ASN"][atom] == q["GLN"][atom], atom
+    assert q["ACE"]["O"] == q["ALA"]["O"] and abs(q["ACE"]["C"] - q["ALA"]["C"]) <= 1.0001e-4
+    assert q["NME"]["N"] == q["ALA"]["N"] and q["NME"]["H"] == q["ALA"]["H"]
+    for r in q:
+        assert abs(sum(q[r].values())) < 1e-9, r
+    assert q["ACE"]["HH31"] == q["ACE"]["HH32"] == q["ACE"]["HH33"]
+    assert q["NME"]["HH31"] == q["NME"]["HH32"] == q["NME"]["HH33"]
+    assert q["ALA"]["HB1"] == q["ALA"]["HB2"] == q["ALA"]["HB3"]
 
 
 def test_proposal_step_schedule_matches_oracle():

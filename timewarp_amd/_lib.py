@@ -70,6 +70,20 @@ class ForceField(C.Structure):
     ]
 
 
+class MHOptions(C.Structure):
+    """Mirror of `tw_mh_options`."""
+
+    _fields_ = [
+        ("random_velocs", C.c_int32),
+        ("n_centres", C.c_int32),
+        ("centres", C.c_void_p),
+        ("reference_signs", C.c_void_p),
+        ("masses", C.c_void_p),
+        ("kbT", C.c_float),
+    ]
+
+
+ABI_VERSION = 3
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 _DESC = C.POINTER(FlowDesc)
@@ -103,6 +117,9 @@ SIGNATURES = {
     "tw_mh_accept": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "tw_mh_accept_chains": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _P]),
     "tw_chirality_changed": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _I32, _P]),
+    "tw_mh_iteration_workspace_bytes": (_I64, [_DESC, _I64, _I32]),
+    "tw_mh_iteration": (C.c_int, [_DESC, _P, _P, _I32, C.POINTER(ForceField), C.POINTER(MHOptions), _P, _P, _I32, _P, _P, _P, _P,
+                                  _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P]),
     "tw_flow_nonfinite": (C.c_int, [_I32, C.POINTER(C.c_int32)]),
     "tw_debug_set_flags": (C.c_int, [C.c_int]),
     "tw_profile_begin": (C.c_int, []),
@@ -137,7 +154,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tw_abi_version() != 2:
+    if lib.tw_abi_version() != ABI_VERSION:
         raise RuntimeError("timewarp_amd: ABI version mismatch between _lib.py and libtimewarp_hip.so")
     _LIB = lib
     return lib

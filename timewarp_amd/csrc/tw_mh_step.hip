@@ -1,0 +1,337 @@
+// One whole Metropolis-Hastings iteration of `sample_with_model` (reference utils/evaluation_utils.py:609-713) as
+// ONE C-ABI call: proposals + log p(y|x) (flow reverse pass), potential / kinetic energies, chirality guard,
+// log p(x~|y~) (flow forward pass), exponent, p_acc, accept test, first accepted index, new chain state.
+//
+// Why: driven op by op (tw_flow_sample_with_logp, tw_amber_energy, tw_kinetic_energy, tw_flow_log_likelihood,
+// tw_mh_accept + a dozen elementwise torch ops) an iteration is ~85 launches, of which the 16 net-block launches are
+// 95 % of the time and the other ~70 cost ~4-5 us each plus a boundary: 0.36 ms of a 7.1 ms iteration (r01 profile).
+// Here the glue is four kernels - begin, finish, begin_ll, accept - around the two flow passes and one energy launch
+// over S + 1 conformations (the current state rides along as row S); nothing is copied: the latent buffers the caller
+// hands in become the proposals in place, and the accept kernel writes the new state into buffers of its own.
+#include "tw_common.h"
+
+extern "C" int tw_flow_pass(const tw_flow_desc* desc, const float* raw, const float* packed, const int32_t* atom_types,
+                            const float* x_coords, const float* x_velocs, const uint8_t* masked, int64_t n_cond,
+                            float* z_coords, float* z_velocs, float* delta_logp, int64_t n_rows, int32_t n_atoms,
+                            int32_t reverse, int32_t path, void* workspace, int64_t workspace_bytes, void* stream);
+extern "C" int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_t n_atoms);
+
+namespace tw {
+int amber_energy(const tw_forcefield* ff, const float* coords, double* out, double* terms, int64_t n, hipStream_t s);
+
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Normal(0, e^ls).log_prob summed over the unmasked atoms of one row (flow.py:191-203 / 322-334); one wave, same
+// arithmetic as prior_logp_kernel
+__device__ __forceinline__ float row_prior(const float* zc, const float* zv, const uint8_t* mk, const float* prior, int V) {
+  const float sc = expf(prior[0]), sv = expf(prior[1]);
+  const float var_c = sc * sc, var_v = sv * sv;
+  const float lsc = logf(sc), lsv = logf(sv);
+  const float half_log_2pi = 0.91893853320467274178f;
+  float ac = 0.f, av = 0.f;
+  for (int i = threadIdx.x; i < 3 * V; i += 64) {
+    const float keep = mk[i / 3] ? 0.f : 1.f;
+    const float a = zc[i], b = zv[i];
+    ac += keep * (-(a * a) / (2.f * var_c) - lsc - half_log_2pi);
+    av += keep * (-(b * b) / (2.f * var_v) - lsv - half_log_2pi);
+  }
+  return wsum(ac) + wsum(av);
+}
+
+// compute_kinetic_energy (evaluation_utils.py:416-436) of one row; one wave, same arithmetic as kinetic_kernel
+__device__ __forceinline__ float row_kinetic(const float* v, const float* masses, int random_velocs, float kbT, int V) {
+  float acc = 0.f;
+  for (int a = threadIdx.x; a < V; a += 64) {
+    const float* p = v + a * 3;
+    const float s = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    acc += random_velocs ? s : masses[a] * s;
+  }
+  acc = wsum(acc);
+  return random_velocs ? 0.5f * acc : 0.5f * acc / kbT;
+}
+
+// masked arithmetic mean of one row's coordinates (molecule_utils.py:15-29); same arithmetic as centre_kernel
+__device__ __forceinline__ void row_com(const float* x, const uint8_t* mk, int V, float (&com)[3]) {
+  float sx = 0, sy = 0, sz = 0, cnt = 0;
+  for (int a = threadIdx.x; a < V; a += 64) {
+    const float keep = mk[a] ? 0.f : 1.f;
+    sx += keep * x[a * 3 + 0];
+    sy += keep * x[a * 3 + 1];
+    sz += keep * x[a * 3 + 2];
+    cnt += keep;
+  }
+  sx = wsum(sx); sy = wsum(sy); sz = wsum(sz); cnt = wsum(cnt);
+  com[0] = sx / cnt; com[1] = sy / cnt; com[2] = sz / cnt;
+}
+
+// Block n < S: prior log-density of the (still untouched) latents of proposal n, delta_logp = 0.
+// Block S: the conditioning state - centred coordinates, centre of mass, kinetic energy (evaluated once instead of on
+// S identical copies, evaluation_utils.py:620-629) - and its coordinates as row S of the energy batch.
+__global__ void mh_begin_kernel(const float* __restrict__ x_coords, const float* __restrict__ x_velocs,
+                                const uint8_t* __restrict__ masked, const float* __restrict__ masses,
+                                const float* __restrict__ prior, float* __restrict__ zc, const float* __restrict__ zv,
+                                float* __restrict__ xc, float* __restrict__ com_out, float* __restrict__ prior0,
+                                float* __restrict__ delta, float* __restrict__ ekin_x, const int32_t* __restrict__ types,
+                                int32_t* __restrict__ types_rep, uint8_t* __restrict__ masked_rep, int random_velocs,
+                                float kbT, int64_t S, int V) {
+  const int64_t n = blockIdx.x;
+  if (n < S) {
+    // the forward pass conditions every row on its own proposal (n_cond = S): per-row copies of the atom types / mask
+    for (int a = threadIdx.x; a < V; a += 64) {
+      types_rep[n * V + a] = types[a];
+      masked_rep[n * V + a] = masked[a];
+    }
+    const float p = row_prior(zc + n * 3 * V, zv + n * 3 * V, masked, prior, V);
+    if (threadIdx.x == 0) {
+      prior0[n] = p;
+      delta[n] = 0.f;
+    }
+    return;
+  }
+  float com[3];
+  row_com(x_coords, masked, V, com);
+  for (int i = threadIdx.x; i < 3 * V; i += 64) {
+    xc[i] = x_coords[i] - com[i % 3];
+    zc[S * 3 * V + i] = x_coords[i];
+  }
+  if (threadIdx.x < 3) com_out[threadIdx.x] = com[threadIdx.x];
+  const float ek = row_kinetic(x_velocs, masses, random_velocs, kbT, V);
+  if (threadIdx.x == 0) ekin_x[0] = ek;
+}
+
+// After the reverse pass (per proposal n): log p(y|x) = prior(z) + delta_logp, y = (x_centred + com) + residual in
+// place (flow.py:303-334), E_kin(y), chirality guard (chirality.py:40-80), and everything the forward pass of the
+// reverse move needs (evaluation_utils.py:648-657; flow.py:148-157): residual target x - y, target velocities sgn x_v,
+// conditioning velocities sgn y_v, centred conditioning positions y - com(y), delta_logp = 0.
+__global__ void mh_finish_kernel(float* __restrict__ zc /* residual in, y out */, const float* __restrict__ yv,
+                                 const float* __restrict__ x_coords, const float* __restrict__ x_velocs,
+                                 const float* __restrict__ xc, const float* __restrict__ com,
+                                 const uint8_t* __restrict__ masked, const float* __restrict__ masses,
+                                 const float* __restrict__ prior0, float* __restrict__ delta, float* __restrict__ p_xy,
+                                 float* __restrict__ ekin_y, uint8_t* __restrict__ chir, const int32_t* __restrict__ centres,
+                                 const float* __restrict__ ref_signs, int n_centres, float* __restrict__ t_c,
+                                 float* __restrict__ t_v, float* __restrict__ c_v, float* __restrict__ c_c,
+                                 int displacement, int random_velocs, float kbT, int V) {
+  extern __shared__ float ys[];  // [3V] the proposal's coordinates
+  const int64_t n = blockIdx.x;
+  const float sgn = random_velocs ? 1.f : -1.f;
+  float* zrow = zc + n * 3 * V;
+  for (int i = threadIdx.x; i < 3 * V; i += 64) {
+    const float base = xc[i] + com[i % 3];
+    const float y = displacement ? base + zrow[i] : zrow[i];
+    zrow[i] = y;
+    ys[i] = y;
+    t_c[n * 3 * V + i] = displacement ? x_coords[i] - y : x_coords[i];
+    t_v[n * 3 * V + i] = sgn * x_velocs[i];
+    c_v[n * 3 * V + i] = sgn * yv[n * 3 * V + i];
+  }
+  __syncthreads();
+  float cy[3];
+  row_com(ys, masked, V, cy);
+  for (int i = threadIdx.x; i < 3 * V; i += 64) c_c[n * 3 * V + i] = ys[i] - cy[i % 3];
+  const float ek = row_kinetic(yv + n * 3 * V, masses, random_velocs, kbT, V);
+  if (threadIdx.x == 0) {
+    p_xy[n] = prior0[n] + delta[n];
+    delta[n] = 0.f;
+    ekin_y[n] = ek;
+    bool ch = false;
+    for (int c = 0; c < n_centres; ++c) {
+      const int i0 = centres[4 * c], i1 = centres[4 * c + 1], i2 = centres[4 * c + 2], i3 = centres[4 * c + 3];
+      float a[3], b[3], d[3];
+      for (int k = 0; k < 3; ++k) {
+        a[k] = ys[3 * i1 + k] - ys[3 * i0 + k];
+        b[k] = ys[3 * i2 + k] - ys[3 * i0 + k];
+        d[k] = ys[3 * i3 + k] - ys[3 * i0 + k];
+      }
+      const float cx = b[1] * d[2] - b[2] * d[1];
+      const float cyy = b[2] * d[0] - b[0] * d[2];
+      const float cz = b[0] * d[1] - b[1] * d[0];
+      const float dot = a[0] * cx + a[1] * cyy + a[2] * cz;
+      const float s = (dot > 0.f) ? 1.f : ((dot < 0.f) ? -1.f : 0.f);
+      if (s != ref_signs[c]) ch = true;
+    }
+    chir[n] = ch ? 1 : 0;
+  }
+}
+
+// log p(x~|y~) = prior(z) - delta_logp of the forward pass, one wave per proposal
+__global__ void mh_pyx_kernel(const float* __restrict__ zc, const float* __restrict__ zv, const uint8_t* __restrict__ masked,
+                              const float* __restrict__ prior, const float* __restrict__ delta, float* __restrict__ p_yx, int V) {
+  const int64_t n = blockIdx.x;
+  const float p = row_prior(zc + n * 3 * V, zv + n * 3 * V, masked, prior, V);
+  if (threadIdx.x == 0) p_yx[n] = p - delta[n];
+}
+
+// evaluation_utils.py:628-677 for one chain, single workgroup: energies in kT units (the float32 cast and the
+// multiplication by the reciprocal of kbT are what `energy_fn(x) / kbT` does on the op-by-op path), chirality penalty,
+// exponent, p_acc = min(1, e^-exponent) with NaN propagating as torch.min does, u < p_acc, first accepted index,
+// new state = y[k] or the (resampled) current state.  stats [8, S]: p_acc, p_xy, p_yx, exponent, e_pot_y, e_kin_y,
+// e_pot delta, e_kin delta.
+__global__ void mh_accept_full_kernel(const double* __restrict__ e_pot, const float* __restrict__ ekin_y,
+                                      const float* __restrict__ ekin_x, const uint8_t* __restrict__ chir,
+                                      const float* __restrict__ p_xy, const float* __restrict__ p_yx,
+                                      const float* __restrict__ u, const float* __restrict__ yc, const float* __restrict__ yv,
+                                      const float* __restrict__ x_coords, const float* __restrict__ x_velocs,
+                                      float* __restrict__ new_c, float* __restrict__ new_v, float* __restrict__ stats,
+                                      uint8_t* __restrict__ out_acc, int32_t* __restrict__ result, float inv_kbT,
+                                      int64_t S, int V) {
+  __shared__ int first;
+  if (threadIdx.x == 0) first = 0x7fffffff;
+  __syncthreads();
+  const float epx = (float)e_pot[S] * inv_kbT;
+  const float ekx = ekin_x[0];
+  int local = 0x7fffffff;
+  for (int64_t s = threadIdx.x; s < S; s += blockDim.x) {
+    float epy = (float)e_pot[s] * inv_kbT;
+    if (chir[s]) epy = epy + 2000.f;
+    const float eky = ekin_y[s];
+    const float dkin = eky - ekx;
+    const float dpot = epy - epx;
+    const float energy = dpot + dkin;
+    const float e = energy + p_xy[s] - p_yx[s];
+    const float ee = expf(-e);
+    const float p = (ee != ee) ? ee : fminf(1.f, ee);
+    const bool acc = u[s] < p;
+    stats[0 * S + s] = p;
+    stats[1 * S + s] = p_xy[s];
+    stats[2 * S + s] = p_yx[s];
+    stats[3 * S + s] = e;
+    stats[4 * S + s] = epy;
+    stats[5 * S + s] = eky;
+    stats[6 * S + s] = dpot;
+    stats[7 * S + s] = dkin;
+    out_acc[s] = acc ? 1 : 0;
+    if (acc && (int)s < local) local = (int)s;
+  }
+  atomicMin(&first, local);
+  __syncthreads();
+  const int k = first;
+  const bool any = k != 0x7fffffff;
+  for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) {
+    new_c[i] = any ? yc[(int64_t)k * 3 * V + i] : x_coords[i];
+    new_v[i] = any ? yv[(int64_t)k * 3 * V + i] : x_velocs[i];
+  }
+  if (threadIdx.x == 0) {
+    result[0] = any ? k : (int)(S - 1);
+    result[1] = any ? 1 : 0;
+    result[2] = 0;
+    result[3] = 0;
+  }
+}
+
+struct StepWs {
+  float *xc, *com, *prior0, *delta, *ekin_x, *ekin_y, *p_xy, *p_yx, *t_c, *t_v, *c_v, *c_c;
+  double* e_pot;
+  uint8_t *chir, *masked_rep;
+  int32_t* types_rep;
+  char* flow;
+  int64_t flow_bytes, bytes;
+};
+
+StepWs step_ws(const tw_flow_desc* d, int64_t S, int V, void* base) {
+  StepWs w;
+  char* p = (char*)base;
+  auto take = [&](int64_t bytes) {
+    char* r = p;
+    p += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  const int64_t el = S * V * 3 * 4;
+  w.xc = (float*)take(V * 3 * 4);
+  w.com = (float*)take(16);
+  w.prior0 = (float*)take(S * 4);
+  w.delta = (float*)take(S * 4);
+  w.ekin_x = (float*)take(16);
+  w.ekin_y = (float*)take(S * 4);
+  w.p_xy = (float*)take(S * 4);
+  w.p_yx = (float*)take(S * 4);
+  w.e_pot = (double*)take((S + 1) * 8);
+  w.chir = (uint8_t*)take(S);
+  w.masked_rep = (uint8_t*)take(S * V);
+  w.types_rep = (int32_t*)take(S * V * 4);
+  w.t_c = (float*)take(el);
+  w.t_v = (float*)take(el);
+  w.c_v = (float*)take(el);
+  w.c_c = (float*)take(el);
+  w.flow = p;
+  w.flow_bytes = tw_flow_workspace_bytes(d, S, V);
+  p += (w.flow_bytes + 255) / 256 * 256;
+  w.bytes = p - (char*)base;
+  return w;
+}
+
+}  // namespace
+}  // namespace tw
+
+using namespace tw;
+
+extern "C" {
+
+int64_t tw_mh_iteration_workspace_bytes(const tw_flow_desc* desc, int64_t n_proposals, int32_t n_atoms) {
+  if (!desc || n_proposals <= 0 || n_atoms <= 0) return -1;
+  if (tw_flow_workspace_bytes(desc, n_proposals, n_atoms) < 0) return -1;
+  return step_ws(desc, n_proposals, n_atoms, nullptr).bytes;
+}
+
+int tw_mh_iteration(const tw_flow_desc* desc, const float* raw, const void* packed, int32_t path, const tw_forcefield* ff,
+                    const tw_mh_options* opt, const int32_t* atom_types, const uint8_t* masked, int32_t n_atoms,
+                    const float* x_coords, const float* x_velocs, float* zy_coords, float* zy_velocs, const float* u,
+                    float* new_coords, float* new_velocs, float* out_stats, uint8_t* out_accepted, int32_t* result,
+                    int64_t n_proposals, void* workspace, int64_t workspace_bytes, void* stream) {
+  TW_REQUIRE(desc && raw && ff && opt && atom_types && masked && x_coords && x_velocs && zy_coords && zy_velocs && u &&
+                 new_coords && new_velocs && out_stats && out_accepted && result && workspace,
+             "NULL pointer argument");
+  TW_REQUIRE(n_proposals > 0 && n_proposals < (1LL << 30) && n_atoms > 0, "bad sizes");
+  TW_REQUIRE(ff->n_atoms == n_atoms, "force field is for %d atoms, the molecule has %d", ff->n_atoms, n_atoms);
+  TW_REQUIRE(opt->kbT > 0.f, "kbT must be positive");
+  TW_REQUIRE(opt->random_velocs || opt->masses, "masses are needed unless random_velocs");
+  TW_REQUIRE(opt->n_centres == 0 || (opt->centres && opt->reference_signs), "chirality guard needs centres and signs");
+  TW_REQUIRE(!desc->ignore_cond_velocity, "ignore_conditional_velocity models take the op-by-op route");
+  const int64_t S = n_proposals;
+  const int V = n_atoms;
+  hipStream_t s = (hipStream_t)stream;
+  const StepWs w = step_ws(desc, S, V, workspace);
+  if (w.flow_bytes < 0) return TW_ERR_INVALID;
+  if (w.bytes > workspace_bytes) {
+    set_error("workspace too small: need %lld bytes, have %lld", (long long)w.bytes, (long long)workspace_bytes);
+    return TW_ERR_WORKSPACE;
+  }
+  const RawLayout L = raw_layout(*desc);
+  const float* prior = raw + L.prior;
+  const float* masses = opt->masses ? opt->masses : x_velocs;  // never read when random_velocs
+  int rc;
+  hipLaunchKernelGGL(mh_begin_kernel, dim3((unsigned)(S + 1)), dim3(64), 0, s, x_coords, x_velocs, masked, masses, prior,
+                     zy_coords, zy_velocs, w.xc, w.com, w.prior0, w.delta, w.ekin_x, atom_types, w.types_rep, w.masked_rep,
+                     opt->random_velocs, opt->kbT, S, V);
+  TW_LAUNCH_CHECK();
+  // proposals: flow reverse pass on the latents, in place (flow.py:284-300)
+  if ((rc = tw_flow_pass(desc, raw, (const float*)packed, atom_types, w.xc, x_velocs, masked, 1, zy_coords, zy_velocs, w.delta,
+                         S, V, 1, path, w.flow, w.flow_bytes, stream)))
+    return rc;
+  hipLaunchKernelGGL(mh_finish_kernel, dim3((unsigned)S), dim3(64), (size_t)3 * V * sizeof(float), s, zy_coords, zy_velocs,
+                     x_coords, x_velocs, w.xc, w.com, masked, masses, w.prior0, w.delta, w.p_xy, w.ekin_y, w.chir,
+                     opt->centres, opt->reference_signs, opt->n_centres, w.t_c, w.t_v, w.c_v, w.c_c, desc->displacement,
+                     opt->random_velocs, opt->kbT, V);
+  TW_LAUNCH_CHECK();
+  // potential energy of the S proposals and of the current state (row S) in one launch
+  if ((rc = amber_energy(ff, zy_coords, w.e_pot, nullptr, S + 1, s))) return rc;
+  // reverse move: flow forward pass, every row conditioned on its own proposal (evaluation_utils.py:648-657)
+  if ((rc = tw_flow_pass(desc, raw, (const float*)packed, w.types_rep, w.c_c, w.c_v, w.masked_rep, S, w.t_c, w.t_v, w.delta, S,
+                         V, 0, path, w.flow, w.flow_bytes, stream)))
+    return rc;
+  hipLaunchKernelGGL(mh_pyx_kernel, dim3((unsigned)S), dim3(64), 0, s, w.t_c, w.t_v, masked, prior, w.delta, w.p_yx, V);
+  TW_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mh_accept_full_kernel, dim3(1), dim3(1024), 0, s, w.e_pot, w.ekin_y, w.ekin_x, w.chir, w.p_xy, w.p_yx, u,
+                     zy_coords, zy_velocs, x_coords, x_velocs, new_coords, new_velocs, out_stats, out_accepted, result,
+                     1.0f / opt->kbT, S, V);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+
+}  // extern "C"

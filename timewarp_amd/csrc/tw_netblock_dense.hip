@@ -12,8 +12,8 @@
 //                     q scaled by 1/sqrt(dh))                                                      -> 36 MFMA groups
 //     the three tiles go to a wave-private LDS block [token][16]; every lane then does the softmax attention of ITS
 //     tokens (the D/B layout gives lane (g, i16) token 16 jt + i16 and features 4g..4g+3): scores against the keys of
-//     the token's own molecule in two passes (max, then exp / sum / P.V for its four features), padded keys skipped
-//     (= -inf in nn.MultiheadAttention).  Exact fp32 on the VALU: 2 x 16 FMAs per (query, key), ~4 % of the launch.
+//     the token's own molecule (the four lanes of a token split the keys and park the scores in LDS), then
+//     exp / sum / P.V for its four features; padded keys are -inf as in nn.MultiheadAttention.  fp32 on the VALU.
 //     The result IS the B operand tile `ft = h` of out_proj:  y[ot] += W_out(ot, h) . o_h              -> 8 tiles
 //   y += out_proj.bias;  x = LN1(x + y);  FFN as in the kernel variant;  x = LN2(x + y)
 //
@@ -28,6 +28,7 @@ namespace tw {
 
 #define DH 16       // head dimension = one 16-wide MFMA tile
 #define QS 20       // LDS row stride (floats) of the q / k / v tiles: conflict-free 16-byte writes and reads
+#define PS 65       // LDS row stride (floats) of the score tile [token][key <= 64]
 
 bool dense_fused_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom g;
@@ -185,9 +186,10 @@ netblock_dense_kernel(const DNParams p) {
   if (blk >= p.nblocks) return;
 
   // wave-private q / k / v tiles of the head in flight: [16 NT tokens][QS]
-  float* qs = lds + wave * (3 * 16 * NT * QS);
+  float* qs = lds + wave * (16 * NT * (3 * QS + PS));
   float* ks = qs + 16 * NT * QS;
   float* vs = ks + 16 * NT * QS;
+  float* ps = vs + 16 * NT * QS;
   const float* net_base = p.packed + (int64_t)net * p.net_stride;
   const float* side = net_base + p.tiles_per_net * TILE_F;
   const float* wp = net_base + lane * 4;
@@ -306,8 +308,10 @@ netblock_dense_kernel(const DNParams p) {
         *(f4*)(ks + row) = qkv[1][jt];
         *(f4*)(vs + row) = qkv[2][jt];
       }
-      // softmax attention of this lane's tokens over the keys of their molecule (same wave wrote the tiles: LDS
-      // operations of one wave complete in order, the compiler's lgkmcnt wait covers the read-after-write)
+      // Softmax attention of this lane's tokens over the keys of their molecule.  The four lanes that share a token
+      // (g = 0..3) split the score pass - lane g takes keys g, g + 4, ... - and leave the scores in the wave-private
+      // tile ps[token][key]; the second pass (all keys, this lane's four output features) reads them back.  One wave
+      // wrote what it reads: LDS operations of a wave complete in order.  Padded keys get -inf (nn.MultiheadAttention).
       f4 oh[NT];
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
@@ -317,40 +321,40 @@ netblock_dense_kernel(const DNParams p) {
         const unsigned long long km = keymask[jt];
         const float* kb = ks + tok_mol0[jt] * QS;
         const float* vb = vs + tok_mol0[jt] * QS + 4 * g;
+        float* prow = ps + (16 * jt + i16) * PS;
         float mx = -INFINITY;
-        for (int m = 0; m < p.V; ++m) {
-          if (!((km >> m) & 1ull)) continue;
-          float acc = 0.f;
+        for (int m = g; m < p.V; m += 4) {
+          f4 k4[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f4 k4 = *(const f4*)(kb + m * QS + 4 * i);
-            acc = fmaf(q4[i][0], k4[0], acc);
-            acc = fmaf(q4[i][1], k4[1], acc);
-            acc = fmaf(q4[i][2], k4[2], acc);
-            acc = fmaf(q4[i][3], k4[3], acc);
+          for (int i = 0; i < 4; ++i) k4[i] = *(const f4*)(kb + m * QS + 4 * i);
+          float a0 = q4[0][0] * k4[0][0], a1 = q4[1][0] * k4[1][0], a2 = q4[2][0] * k4[2][0], a3 = q4[3][0] * k4[3][0];
+#pragma unroll
+          for (int r = 1; r < 4; ++r) {
+            a0 = fmaf(q4[0][r], k4[0][r], a0);
+            a1 = fmaf(q4[1][r], k4[1][r], a1);
+            a2 = fmaf(q4[2][r], k4[2][r], a2);
+            a3 = fmaf(q4[3][r], k4[3][r], a3);
           }
-          mx = fmaxf(mx, acc);
+          const float sc = ((km >> m) & 1ull) ? (a0 + a1) + (a2 + a3) : -INFINITY;
+          prow[m] = sc;
+          mx = fmaxf(mx, sc);
         }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
         f4 o = (f4){0.f, 0.f, 0.f, 0.f};
-        for (int m = 0; m < p.V; ++m) {
-          if (!((km >> m) & 1ull)) continue;
-          float acc = 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f4 k4 = *(const f4*)(kb + m * QS + 4 * i);
-            acc = fmaf(q4[i][0], k4[0], acc);
-            acc = fmaf(q4[i][1], k4[1], acc);
-            acc = fmaf(q4[i][2], k4[2], acc);
-            acc = fmaf(q4[i][3], k4[3], acc);
+        if (km) {  // tokens outside every molecule (tile padding) have no keys
+          const float mxl = mx * 1.44269504088896340736f;
+          for (int m = 0; m < p.V; ++m) {
+            // e^(s - max) with the hardware exp2 (1 ulp); exp2(-inf) = 0 for padded keys
+            const float e = __builtin_amdgcn_exp2f(fmaf(prow[m], 1.44269504088896340736f, -mxl));
+            sum += e;
+            const f4 v4 = *(const f4*)(vb + m * QS);
+            o = o + v4 * e;
           }
-          const float e = expf(acc - mx);
-          sum += e;
-          const f4 v4 = *(const f4*)(vb + m * QS);
-          o = o + v4 * e;
+          o = o * (1.0f / sum);
         }
-        // tokens outside every molecule (tile padding) have no keys: keep them finite
-        oh[jt] = km ? o * (1.0f / sum) : (f4){0.f, 0.f, 0.f, 0.f};
+        oh[jt] = o;
       }
       // y += W_out(:, head h) . o_h   (8 tiles)
 #pragma unroll
@@ -470,13 +474,23 @@ static int dense_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& 
   p.net_sel = net_sel;
   const int wgs_per_net = (p.nblocks + 3) / 4;
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
-  const size_t shm = (size_t)4 * 3 * 16 * g.nt * QS * sizeof(float);
+  const size_t shm = (size_t)4 * 16 * g.nt * (3 * QS + PS) * sizeof(float);
   int prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
-  if (g.nt == 3)
+  static bool attr3 = false, attr4 = false;  // > 64 KiB of dynamic LDS needs the kernel's limit raised once
+  if (g.nt == 3) {
+    if (!attr3) {
+      TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_dense_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr3 = true;
+    }
     hipLaunchKernelGGL(netblock_dense_kernel<3>, dim3(grid), dim3(256), shm, a.stream, p);
-  else
+  } else {
+    if (!attr4) {
+      TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_dense_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr4 = true;
+    }
     hipLaunchKernelGGL(netblock_dense_kernel<4>, dim3(grid), dim3(256), shm, a.stream, p);
+  }
   TW_LAUNCH_CHECK();
   if ((prc = profile_mark(a.stream, false))) return prc;
   return TW_OK;

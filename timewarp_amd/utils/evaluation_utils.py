@@ -18,6 +18,7 @@ result: E_pot and E_kin of the current state are evaluated once instead of on S 
 (evaluation_utils.py:620-629)."""
 from __future__ import annotations
 
+import ctypes as C
 import pickle
 from dataclasses import astuple, dataclass
 from typing import Optional
@@ -125,6 +126,12 @@ class DeviceNoise:
         zv = torch.randn((S, B, V, 3), device=self.device, generator=self.gen) * scale_v
         return zc, zv
 
+    def latents_into(self, zc, zv, S, std_c: float, std_v: float):
+        """The same draws as `latents` (same generator, same order, same values: randn * std), written into the first S
+        rows of caller-owned [S + 1, V, 3] buffers - what tw_mh_iteration takes."""
+        zc[:S].normal_(0.0, std_c, generator=self.gen)
+        zv[:S].normal_(0.0, std_v, generator=self.gen)
+
     def uniform(self, S):
         return torch.rand(S, device=self.device, generator=self.gen)
 
@@ -201,6 +208,87 @@ class MetropolisHastingsChain:
         self.s_max = num_proposal_steps
         self.S = self.s_max if not adaptive_parallelism else compute_num_proposal_steps(self.p_bar, max_num_proposal_steps=self.s_max)
         self.sgn = 1.0 if random_velocs else -1.0
+        self._fused = self._fused_iteration_available()
+
+    # ---- whole iteration in one C-ABI call (tw_mh_iteration) ----------------------------------------------------
+    def _fused_iteration_available(self) -> bool:
+        """tw_mh_iteration serves the case the reference's scripts run - the HIP flow as proposal, the AMBER energy
+        kernel, the accept test on - unless TW_MH_FUSED=0.  Anything else (another energy callable, accept=False,
+        an ignore_conditional_velocity model) takes the op-by-op route below; both give the same numbers."""
+        import os
+        from ..energy import AmberPotentialEnergyTorch
+        from ..modules.flow import ConditionalFlowDensityModel
+
+        if os.environ.get("TW_MH_FUSED", "1") == "0" or not self.accept:
+            return False
+        return (isinstance(self.model, ConditionalFlowDensityModel) and isinstance(self.energy_fn, AmberPotentialEnergyTorch)
+                and not self.model.dims.ignore_cond_velocity and self.x_coords.is_cuda
+                and self.energy_fn.tables.n_atoms == self.V)
+
+    def _fused_constants(self, S):
+        if getattr(self, "_fconst", None) is None or self._fconst["S"] != S:
+            dev = self.device
+            lib = _lib.load()
+            desc = self.model.dims.to_desc()
+            opt = _lib.MHOptions()
+            opt.random_velocs = int(self.random_velocs)
+            keep = {"masses": self.masses.contiguous()}
+            opt.masses = keep["masses"].data_ptr()
+            opt.kbT = float(self.kbT)
+            opt.n_centres = 0
+            if self.use_chirality:
+                keep["centres"] = self.chirality_centers.to(dev, torch.int32).contiguous()
+                keep["signs"] = self.reference_signs.to(dev, torch.float32).reshape(-1).contiguous()
+                opt.n_centres = int(keep["centres"].shape[0])
+                opt.centres, opt.reference_signs = keep["centres"].data_ptr(), keep["signs"].data_ptr()
+            need = lib.tw_mh_iteration_workspace_bytes(C.byref(desc), S, self.V)
+            if need < 0:
+                raise RuntimeError("tw_mh_iteration_workspace_bytes failed: " + lib.tw_last_error().decode())
+            self._fconst = dict(S=S, desc=desc, opt=opt, keep=keep, ws=torch.empty(int(need), dtype=torch.uint8, device=dev),
+                                std_c=float(torch.exp(self.model.coords_prior_log_scale.detach())),
+                                std_v=float(torch.exp(self.model.velocs_prior_log_scale.detach())))
+        return self._fconst
+
+    def _iteration_fused(self):
+        """Draws + tw_mh_iteration.  Returns what `_evaluate` + `_mh_accept` return together."""
+        S, V, dev = self.S, self.V, self.device
+        noise, model = self.noise, self.model
+        x_coords, x_velocs = self.x_coords, self.x_velocs
+        if self.random_velocs and self.resample_velocs:
+            x_velocs = noise.randn_like(x_velocs)
+        if self.rotate:
+            Q = noise.rotation().to(x_coords)
+            x_coords = (x_coords @ Q.T).contiguous()
+            x_velocs = (x_velocs @ Q.T).contiguous()
+        fc = self._fused_constants(S)
+        at, mk, _, _, sc, sv = self._constants(S)
+        zc = torch.empty((S + 1, V, 3), dtype=torch.float32, device=dev)
+        zv = torch.empty((S + 1, V, 3), dtype=torch.float32, device=dev)
+        if hasattr(noise, "latents_into"):
+            noise.latents_into(zc, zv, S, fc["std_c"], fc["std_v"])
+        else:  # replayed / host-drawn noise
+            a, b = noise.latents(S, 1, V, sc, sv)
+            zc[:S].copy_(a.reshape(S, V, 3))
+            zv[:S].copy_(b.reshape(S, V, 3))
+        u = noise.uniform(S).to(dev, torch.float32).contiguous()
+        path = model._path_for(V)
+        raw, packed = model._weights(dev, path)
+        ff = self.energy_fn._device_ff(dev)
+        new_c = torch.empty_like(x_coords)
+        new_v = torch.empty_like(x_velocs)
+        stats = torch.empty((8, S), dtype=torch.float32, device=dev)
+        acc = torch.empty(S, dtype=torch.uint8, device=dev)
+        res = torch.empty(4, dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.tw_mh_iteration(
+                C.byref(fc["desc"]), raw.data_ptr(), _lib.ptr(packed), path, C.byref(ff.struct), C.byref(fc["opt"]),
+                at.data_ptr(), mk.data_ptr(), V, x_coords.data_ptr(), x_velocs.data_ptr(), zc.data_ptr(), zv.data_ptr(),
+                u.data_ptr(), new_c.data_ptr(), new_v.data_ptr(), stats.data_ptr(), acc.data_ptr(), res.data_ptr(), S,
+                fc["ws"].data_ptr(), fc["ws"].numel(), _lib.stream_ptr(dev)), "tw_mh_iteration")
+        self.proposals += S
+        per_proposal = tuple(zip(("acc", "pxy", "pyx", "exp", "epot", "ekin", "dpot", "dkin"), stats.unbind(0)))
+        return x_coords, x_velocs, zc[:S], zv[:S], new_c, new_v, acc, res, per_proposal
 
     def _constants(self, S):
         """Per-chain constants in the dtypes / shapes the C ABI takes (int32 atom types, uint8 mask, both also
@@ -275,6 +363,22 @@ class MetropolisHastingsChain:
         = num_samples - i applies the reference's clip `k = min(k, N - i)` (:680)."""
         self.flush()
         S, device = self.S, self.device
+        if self._fused:
+            x_coords, x_velocs, y_c, y_v, new_c, new_v, acc, res, per_proposal = self._iteration_fused()
+            k_true, any_acc = (int(v) for v in res[:2].tolist())  # the one host sync of the iteration
+            if hasattr(self.model, "check_finite"):
+                self.model.check_finite(device)
+            self.accepted += int(any_acc)
+            k = k_true if remaining is None else min(k_true, remaining)  # NB: N - i, not N - i - 1
+            moved = bool(any_acc) and k == k_true
+            self.p_bar = self.smoothing * (1 - (not any_acc)) + (1 - self.smoothing) ** k * self.p_bar
+            if self.adaptive:
+                self.S = compute_num_proposal_steps(self.p_bar, max_num_proposal_steps=self.s_max)
+            if not moved:
+                new_c, new_v = x_coords.clone(), x_velocs.clone()
+            self._emit(k, x_coords, x_velocs, new_c, new_v, acc, per_proposal)
+            self.x_coords, self.x_velocs = new_c, new_v
+            return k + 1
         x_coords, x_velocs, y_c, y_v, energy, p_xy, p_yx, e_pot_y, e_kin_y, e_pot, e_kin = self._evaluate()
 
         if self.accept:
@@ -319,6 +423,11 @@ class MetropolisHastingsChain:
         clip `k = min(k, N - i)` cannot bind (the caller keeps N - i > S)."""
         assert self.can_defer()
         S, device = self.S, self.device
+        if self._fused:
+            x_coords, x_velocs, _, _, new_c, new_v, acc, res, per_proposal = self._iteration_fused()
+            self._pending.append((res, x_coords, x_velocs, new_c, new_v, acc, per_proposal))
+            self.x_coords, self.x_velocs = new_c, new_v
+            return
         x_coords, x_velocs, y_c, y_v, energy, p_xy, p_yx, e_pot_y, e_kin_y, e_pot, e_kin = self._evaluate()
         u = self.noise.uniform(S).to(device, torch.float32).contiguous()
         new_c, new_v = x_coords.clone(), x_velocs.clone()  # becomes y[k] inside the kernel if a proposal is accepted

@@ -25,6 +25,10 @@ import sys
 # pairsync: one barrier per PAIR of stages, both slots refilled after it - correct, but measured 2.5 % slower (the
 # refill then runs only two stages ahead of its use and the LDS-DMA latency shows).
 EXPERIMENT = set(filter(None, os.environ.get("H3_FFN_EXPERIMENT", "").split(",")))
+# FFN: the epilogue of chunk c + 1 (96 VALU ops) is spread over the second A stage of chunk c + 1 and both B stages of
+# chunk c, in gaps that hold nothing else (`nospread`: the r01 placement - all of it in the B stages, beside the LDS
+# reads and the hand-off - measured slower)
+SPREAD = "nospread" not in EXPERIMENT
 
 NT = 3
 # Shapes of the three chunked MLPs (same schedule, one generated file each):
@@ -50,6 +54,7 @@ YACC = lambda ot, jt: 4 * (3 * ot + jt)
 HACC = lambda o, jt: 72 + 4 * (3 * o + jt)   # VGPRs: the epilogue reads them without a v_accvgpr_read
 S_SC = 95
 S_PREV = 93   # pair-sync: slot of the first stage of a pair, released together with the second
+S_ROT = 83    # auxrot: the wave that moves the next bias/scale block (rotates 0..3 so no wave is always the slowest)
 # scratch SGPRs (clobbered)
 S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT = 84, 85, 86, 88, 90, 92, 94  # pairs are even-aligned
 STAGE, TILES = 9216, 8192
@@ -136,7 +141,10 @@ def handoff(next_reads, with_aux, label):
         f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off offset:1024",
     ]
     if with_aux:
-        h += [["s_cmp_lg_u32 %[wave], 0",
+        who = f"s{S_ROT}" if "auxrot" in EXPERIMENT else "0"
+        if "auxrot" in EXPERIMENT:
+            h += [f"s_add_u32 s{S_ROT}, s{S_ROT}, 1", f"s_and_b32 s{S_ROT}, s{S_ROT}, 3"]
+        h += [[f"s_cmp_lg_u32 %[wave], {who}",
                f"s_cbranch_scc1 .Lh3mlp_noaux_{label}_%=",
                f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
                f"s_add_u32 m0, s{S_REL}, {TILES}",
@@ -207,6 +215,43 @@ def weave(mfmas, valu, misc, valu_per=2, misc_per=2):
     return out
 
 
+def place_valu(lines, valu, cap_empty=2):
+    """`lines`: a stage's instructions with the MFMAs and everything that has a fixed place (LDS reads, waits, the
+    barrier, the hand-off).  Distribute `valu` (order kept) over the gaps behind the MFMAs, preferring gaps that hold
+    nothing else: an MFMA issues every 16 cycles and the wave issues about one instruction per 4, so a gap takes two or
+    three fillers for free and every further one delays the next MFMA."""
+    if not valu:
+        return lines
+    gaps = []  # (index of the MFMA line, weight of the other items behind it)
+    idx = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
+    # scalar instructions issue beside a VALU op for free (tools/probe/mfma_valu_overlap.hip: three s_mov per MFMA cost
+    # nothing); vector, LDS and DMA instructions each take the slot a VALU op would
+    heavy = lambda l: not (l.endswith(":") or l.startswith("s_")) or l.startswith("s_waitcnt") or l.startswith("s_barrier")
+    for k, i in enumerate(idx):
+        end = idx[k + 1] if k + 1 < len(idx) else len(lines)
+        gaps.append((i, sum(1 for l in lines[i + 1:end] if heavy(l))))
+    cap = cap_empty
+    while True:
+        caps = [max(0, cap - n) for _, n in gaps]
+        if sum(caps) >= len(valu):
+            break
+        cap += 1
+    total, placed, out, pos, cum = sum(caps), 0, [], 0, 0
+    take = {}
+    for (i, _), c in zip(gaps, caps):
+        cum += c
+        want = -(-len(valu) * cum // total)  # ceil: fill early rather than late
+        take[i] = min(c, want - placed)
+        placed += take[i]
+    assert placed == len(valu), (placed, len(valu))
+    for i, l in enumerate(lines):
+        out.append(l)
+        if i in take:
+            out.extend(valu[pos:pos + take[i]])
+            pos += take[i]
+    return out
+
+
 def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     """One 4-pair stage.  kind 'A': hacc[o] += W1tile . xb[ks] (ks_in = 4: stage = one o, pairs = k-steps; ks_in = 2:
     the single A stage holds both o, pair = 2 o + ks);  kind 'B': yacc[4b+p] += W2tile(p) . hb (pairs beyond ot_out
@@ -226,8 +271,9 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     live = [bool(g) for g in groups]
     aux = 3 if is_a0 else 0
     epi = [] if "noepi" in EXPERIMENT else list(epi_ops)
+    spread = SPREAD and (SHAPE["tag"] == "ffn" or "spreadio" in EXPERIMENT)
     share = -(-len(epi) // 4)
-    parts = [epi[i * share:(i + 1) * share] for i in range(4)]
+    parts = [[] for _ in range(4)] if spread else [epi[i * share:(i + 1) * share] for i in range(4)]
     out = []
     # outstanding LDS reads at entry: p0.hi p0.lo p1.hi p1.lo (+3 aux)
     out.append("s_waitcnt lgkmcnt(2)")
@@ -258,6 +304,8 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
         h = [f"v_readfirstlane_b32 s{S_SC}, v{V_SC}"] + h   # aux block landed (lgkmcnt(0) above)
     out += weave(groups[2], parts[2], h, misc_per=3)
     out += weave(groups[3], parts[3], [])
+    if spread:
+        out = place_valu(out, epi)
     return out
 
 
@@ -274,9 +322,15 @@ def generate():
     A(f"s_mov_b32 s{S_W2048 + 1}, 0")
     A(f"s_mov_b32 s{S_STRIDE}, {STAGE}")
     A(f"s_mov_b32 s{S_STRIDE + 1}, 0")
-    A(f"s_mov_b32 s{S_AUXOFF}, {TILES}")
+    if "auxrot" in EXPERIMENT:
+        # the aux block sits at stage + TILES whoever moves it: take this wave's 2 KiB offset out of its DMA source
+        A(f"s_sub_u32 s{S_AUXOFF}, {TILES}, s{S_W2048}")
+    else:
+        A(f"s_mov_b32 s{S_AUXOFF}, {TILES}")
     A(f"s_mov_b32 s{S_AUXOFF + 1}, 0")
     A(f"s_add_u32 s{S_END}, %[ring], {5 * STAGE}")
+    if "auxrot" in EXPERIMENT:
+        A(f"s_mov_b32 s{S_ROT}, 0")
     # DMA source of this wave = gnext + wave*2048
     A(f"v_lshl_add_u64 {vr(V_GN, 2)}, %[gn], 0, s[{S_W2048}:{S_W2048 + 1}]")
     A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
@@ -297,10 +351,10 @@ def generate():
     for r in tile_reads(0) + tile_reads(1):
         A(r)
 
-    def a_stages(buf, tag, aux_of):
+    def a_stages(buf, tag, aux_of, epi_of=None):
         out = []
         for o in range(n_a):
-            out += stage("A", o, buf, [], True, aux_of("A", o), f"{tag}a{o}", o == 0)
+            out += stage("A", o, buf, epi_of[o] if epi_of else [], True, aux_of("A", o), f"{tag}a{o}", o == 0)
         return out
 
     def b_stages(buf, tag, epi, aux_of, last=False):
@@ -320,9 +374,11 @@ def generate():
     # ---- prologue: A(0), epilogue of chunk 0 (not hidden)
     L += a_stages(0, "p", always)
     A("s_nop 7")
+    spread4 = ffn and SPREAD and "spread4" in EXPERIMENT
     for o in range(2):
         for jt in range(NT):
-            L += epi_unit(o, jt, 0)
+            # spread4: the last unit's tail is left to the next A0 stage (or to the code in front of the final B stages)
+            L += epi_unit(o, jt, 0)[:4] if spread4 and (o, jt) == (1, NT - 1) else epi_unit(o, jt, 0)
     A(f"s_sub_u32 s{S_CNT}, %[chunks], 1")
     A(f"s_cmp_eq_u32 s{S_CNT}, 0")
     A("s_cbranch_scc1 .Lh3mlp_tail_%=")
@@ -330,11 +386,22 @@ def generate():
     #      trip: A(c+1) B(c)[epi c+1 -> buf1]  A(c+2) B(c+1)[epi c+2 -> buf0]
     A(".Lh3mlp_loop_%=:")
     for half, (cur_buf, nxt_buf) in enumerate(((0, 1), (1, 0))):
-        epi = []
-        for o in range(2):
-            for jt in range(NT):
-                epi += epi_unit(o, jt, nxt_buf)
-        L += a_stages(cur_buf, f"l{half}", steady)
+        units = [epi_unit(o, jt, nxt_buf) for o in range(2) for jt in range(NT)]
+        if ffn and SPREAD:
+            # hacc[0] is complete after stage A0: two of its three units run under A1, the rest under B0 and B1
+            # (B0 starts with the last hacc[0] unit, so hacc[1] - finished by A1's last MFMAs - is read well after it)
+            a_epi = {0: [], 1: units[0] + units[1]}
+            epi = units[2] + units[3] + units[4] + units[5]
+            if "spread4" in EXPERIMENT:
+                # fourth window: the tail of the last unit (everything behind its bias/scale fma) runs under stage A0 of
+                # the NEXT chunk - hacc[1] is not rewritten before A1, the bias registers are only re-read by A0
+                stream = [op for u_ in units for op in u_]
+                a_epi = {0: epi_unit(1, NT - 1, cur_buf)[4:], 1: stream[:28]}   # A0: the tail left over from the chunk before
+                epi = stream[28:84]
+        else:
+            a_epi = None
+            epi = [op for u_ in units for op in u_]
+        L += a_stages(cur_buf, f"l{half}", steady, a_epi)
         L += b_stages(cur_buf, f"l{half}", epi, steady)
         A(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
         A(f"s_cmp_eq_u32 s{S_CNT}, 0")
@@ -344,9 +411,13 @@ def generate():
             A("s_cbranch_scc0 .Lh3mlp_loop_%=")
     # ---- tails: last chunk's B stages (hb in buf0 after an even number of loop halves, buf1 after odd)
     A(".Lh3mlp_tail_%=:")
+    if spread4:
+        L += epi_unit(1, NT - 1, 0)[4:] + ["s_nop 1"]
     L += b_stages(0, "t0", [], always, last=True)
     A("s_branch .Lh3mlp_done_%=")
     A(".Lh3mlp_tail1_%=:")
+    if spread4:
+        L += epi_unit(1, NT - 1, 1)[4:] + ["s_nop 1"]
     L += b_stages(1, "t1", [], always, last=True)
     A(".Lh3mlp_done_%=:")
     # ring slot index back to the caller: cur = (S_OFF - ring) / STAGE, 0..4
@@ -388,7 +459,7 @@ def main():
         out.append('"' + l + '\\n\\t"')
     open(base, "w").write("\n".join(out) + "\n")
     n_v = 208 if SHAPE["silu"] else 204
-    clob = [f'"v{i}"' for i in range(n_v)] + [f'"a{i}"' for i in range(120)] + [f'"s{i}"' for i in range(84, 96)] + \
+    clob = [f'"v{i}"' for i in range(n_v)] + [f'"a{i}"' for i in range(120)] + [f'"s{i}"' for i in range(83 if "auxrot" in EXPERIMENT else 84, 96)] + \
            ['"vcc"', '"scc"', '"memory"']
     cl = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape} - clobber list of the {shape} MLP asm statement."]
     for i in range(0, len(clob), 12):
