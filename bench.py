@@ -284,6 +284,33 @@ def alt_path_record(device, seed, proposals, steps, sync_every):
     }
 
 
+def end_timed_region(traj, t0, device, world):
+    """The N > 1 leg of the measurement contract: the one collective of the path (all-gather of the trajectories, inside
+    the timed region), barrier + device synchronisation on both sides of the clock, MAX of the elapsed time over ranks.
+    Device-agnostic so that tests/test_distributed_cpu.py can run it under gloo; returns (gathered list, seconds)."""
+    from timewarp_amd import distributed
+
+    sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
+    gathered, _ = distributed.gather_trajectories(traj)  # no-op at N = 1
+    sync()
+    if world > 1:
+        torch.distributed.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return gathered, float(t.item())
+
+
+def whole_job_rates(accepted, proposals, states, elapsed, device):
+    """Sums of the per-rank counters over the job / the max-over-ranks time: `value` and its two companions."""
+    from timewarp_amd import distributed
+
+    accepted, proposals, states = distributed.all_reduce_counters([accepted, proposals, states], device)
+    return accepted / elapsed, proposals / elapsed, states / elapsed, accepted
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,22 +360,12 @@ def main():
             if (it + 1) % args.sync_every == 0:
                 chain.flush()
         traj, _ = chain.trajectory()
-        gathered, _ = distributed.gather_trajectories(traj)  # the one collective (no-op at N=1)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        gathered, elapsed = end_timed_region(traj, t0, device, world)
     k_ms, k_launches = C.c_double(0.0), C.c_int64(0)
     lib.tw_profile_end(C.byref(k_ms), C.byref(k_launches))
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
     states = sum(x.shape[0] for x in chain.chain_c) - states0
-    accepted, proposals, states = distributed.all_reduce_counters(
-        [chain.accepted - acc0, chain.proposals - prop0, states], device)
+    value, proposals_per_s, states_per_s, accepted = whole_job_rates(chain.accepted - acc0, chain.proposals - prop0, states,
+                                                                       elapsed, device)
 
     if rank == 0:
         launches = max(int(k_launches.value), 1)
@@ -367,7 +384,7 @@ def main():
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "MH-accepted samples/sec (whole node), alanine-dipeptide kernel_transformer_nvp",
-            "value": accepted / elapsed,
+            "value": value,
             "unit": "MH-accepted samples/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -387,8 +404,8 @@ def main():
                 "setup_prewarm": f"{PREWARM_PASSES} untimed flow passes on throw-away inputs before the warm-up steps (GPU clock ramp)",
                 "execution_path": args.path,
             },
-            "proposals_per_s": proposals / elapsed,
-            "chain_states_per_s": states / elapsed,
+            "proposals_per_s": proposals_per_s,
+            "chain_states_per_s": states_per_s,
             "accepted_per_step": accepted / (args.steps * world),
             "roofline": {
                 "bound": "mfma",

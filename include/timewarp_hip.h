@@ -13,7 +13,8 @@
  *   - return value: 0 on success, a negative tw_status otherwise; tw_last_error() gives the
  *     message of the last failure on the calling thread.  No entry point allocates or frees
  *     caller memory; workspaces are caller-provided (tw_flow_workspace_bytes);
- *   - thread-safety: re-entrant across streams; no global state except the error string.
+ *   - thread-safety: re-entrant across streams; no global state except the error string (tw_mh_iteration keeps
+ *     one helper stream and two events per device and calling thread, created on first use).
  */
 #ifndef TIMEWARP_HIP_H
 #define TIMEWARP_HIP_H
@@ -290,7 +291,9 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *   bit 3 (8)  run the compiled-C++ variant of the kernel (attention / FFN / in / out sections as C++ instead of the
  *              generated asm blocks); same results, slower - the A/B reference for the asm
  *   bit 4 (16) tw_debug_netblock: wave 0 of workgroup 0 writes s_memtime stamps of the section boundaries into the
- *              dump buffer instead of activations (tools/profile_h3_sections.py) */
+ *              dump buffer instead of activations (tools/profile_h3_sections.py)
+ *   bit 5 (32) split-fp16 flow pass: every affine coupling update as its own launch instead of in the next net-block
+ *              launch's prologue (A/B switch; same results up to the summation order of the log-determinant) */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

@@ -46,6 +46,45 @@ def test_gather_trajectories_two_ranks_gloo():
     assert results == {0: True, 1: True}
 
 
+def _bench_worker(rank, world, port, q):
+    """bench.py's own N > 1 leg (end_timed_region + whole_job_rates) under gloo on CPU tensors: rank r 'ran' for
+    0.1 (r + 1) s and accepted 10 (r + 1) samples."""
+    import sys
+    import time
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from timewarp_amd import distributed
+
+    distributed.init_from_env("gloo")
+    traj = torch.full((3 + rank, 22, 3), float(rank))
+    t0 = time.perf_counter() - 0.1 * (rank + 1)  # pretend this rank started 0.1 (r + 1) s ago
+    gathered, elapsed = bench.end_timed_region(traj, t0, "cpu", world)
+    value, prop_s, states_s, accepted = bench.whole_job_rates(10.0 * (rank + 1), 1000.0, 50.0, elapsed, "cpu")
+    ok = len(gathered) == world and all(g.shape == (3 + r, 22, 3) and bool((g == r).all()) for r, g in enumerate(gathered))
+    ok = ok and 0.1 * world <= elapsed < 0.1 * world + 5.0          # max over ranks, same on every rank
+    ok = ok and accepted == sum(10.0 * (r + 1) for r in range(world))  # whole-job sum
+    ok = ok and abs(value - accepted / elapsed) < 1e-9 and abs(prop_s - 1000.0 * world / elapsed) < 1e-6
+    q.put((rank, bool(ok), elapsed))
+    dist.destroy_process_group()
+
+
+def test_bench_multi_rank_leg_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in results) == [0, 1] and all(r[1] for r in results)
+    assert abs(results[0][2] - results[1][2]) < 1e-12  # both ranks hold the same max-over-ranks time
+
+
 def test_single_process_is_a_no_op():
     from timewarp_amd import distributed
 

@@ -156,8 +156,26 @@ int flow_pass_simple(const FlowArgs& a);
 int flow_pass_fused(const FlowArgs& a);
 int64_t simple_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms);
 int64_t fused_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms);
+// z_out = affine coupling of z_in (nullptr: in place on z_out)
 int launch_coupling(const float* s_raw, const float* t, const uint8_t* masked, int64_t n_cond,
-                    float* z, float* delta_logp, int64_t n_rows, int V, int reverse, hipStream_t s);
+                    float* z_out, float* delta_logp, int64_t n_rows, int V, int reverse, hipStream_t s,
+                    const float* z_in = nullptr);
+int* nonfinite_flag_device_ptr();  // address of the sticky non-finite flag (for kernels of other translation units)
+
+// The affine coupling (layers/nvp.py:89-183) of the PREVIOUS coupling layer, applied by the next net-block launch in
+// its prologue instead of by a launch of its own: the variable it transforms is exactly the next layer's conditioning
+// input z_other, so every workgroup recomputes the values of its own rows from (s, t, z_in); the workgroups of net 0
+// also store them (z_out - a different buffer than z_in, which the workgroups of net 1 are still reading) and apply
+// the row's log-determinant to delta_logp.
+struct PrevCoupling {
+  const float* s_raw;  // nullptr: nothing pending, z_other is read from memory
+  const float* t;
+  const float* z_in;
+  float* z_out;
+  float* delta_logp;
+  int* nonfinite;
+  int reverse;
+};
 int pack_weights(const tw_flow_desc& d, const float* raw, float* packed, hipStream_t s);
 int debug_netblock_simple(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
 int debug_netblock_fused(const FlowArgs& a, int c, int net, const float* z_other, float* dump);

@@ -225,8 +225,14 @@ int nonfinite_flag(int reset, int* out) {
   return TW_OK;
 }
 
+int* nonfinite_flag_device_ptr() {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_nonfinite)) != hipSuccess) return nullptr;
+  return (int*)p;
+}
+
 __global__ void coupling_kernel(const float* __restrict__ s_raw, const float* __restrict__ t,
-                                const uint8_t* __restrict__ masked, int64_t n_cond, float* __restrict__ z,
+                                const uint8_t* __restrict__ masked, int64_t n_cond, const float* z_in, float* z,
                                 float* __restrict__ delta_logp, int V, int reverse) {
   const int64_t n = blockIdx.x;
   const int64_t c = n % n_cond;
@@ -239,7 +245,7 @@ __global__ void coupling_kernel(const float* __restrict__ s_raw, const float* __
     bad |= !(isfinite(s_raw[idx]) && isfinite(shift));
     const float keep = masked[c * V + i / 3] ? 0.f : 1.f;
     acc += logf(scale) * keep;
-    z[idx] = reverse ? (z[idx] - shift) / scale : z[idx] * scale + shift;
+    z[idx] = reverse ? (z_in[idx] - shift) / scale : z_in[idx] * scale + shift;
   }
   if (bad) atomicOr(&g_nonfinite, 1);
   acc = wave_sum(acc);
@@ -250,9 +256,9 @@ __global__ void coupling_kernel(const float* __restrict__ s_raw, const float* __
 }
 
 int launch_coupling(const float* s_raw, const float* t, const uint8_t* masked, int64_t n_cond, float* z,
-                    float* delta_logp, int64_t n_rows, int V, int reverse, hipStream_t s) {
+                    float* delta_logp, int64_t n_rows, int V, int reverse, hipStream_t s, const float* z_in) {
   if (n_rows == 0) return TW_OK;
-  hipLaunchKernelGGL(coupling_kernel, dim3((unsigned)n_rows), dim3(64), 0, s, s_raw, t, masked, n_cond, z,
+  hipLaunchKernelGGL(coupling_kernel, dim3((unsigned)n_rows), dim3(64), 0, s, s_raw, t, masked, n_cond, z_in ? z_in : z, z,
                      delta_logp, V, reverse);
   TW_LAUNCH_CHECK();
   return TW_OK;

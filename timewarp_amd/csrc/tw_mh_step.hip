@@ -319,14 +319,32 @@ int tw_mh_iteration(const tw_flow_desc* desc, const float* raw, const void* pack
                      opt->centres, opt->reference_signs, opt->n_centres, w.t_c, w.t_v, w.c_v, w.c_c, desc->displacement,
                      opt->random_velocs, opt->kbT, V);
   TW_LAUNCH_CHECK();
-  // potential energy of the S proposals and of the current state (row S) in one launch
-  if ((rc = amber_energy(ff, zy_coords, w.e_pot, nullptr, S + 1, s))) return rc;
+  // Potential energy of the S proposals and of the current state (row S) in one launch - on a side stream: it depends
+  // on the proposals only and nothing needs it before the accept test, so it runs beside the forward pass (whose
+  // net-block workgroups leave a few CUs free) instead of between two launches of the main stream.
+  static thread_local hipStream_t sides[32] = {};
+  static thread_local hipEvent_t evs[32][2] = {};
+  int dev_id = 0;
+  TW_HIP_CHECK(hipGetDevice(&dev_id));
+  TW_REQUIRE(dev_id >= 0 && dev_id < 32, "device index %d out of range", dev_id);
+  if (!sides[dev_id]) {  // one side stream and event pair per device and calling thread, created on first use
+    TW_HIP_CHECK(hipStreamCreateWithFlags(&sides[dev_id], hipStreamNonBlocking));
+    TW_HIP_CHECK(hipEventCreateWithFlags(&evs[dev_id][0], hipEventDisableTiming));
+    TW_HIP_CHECK(hipEventCreateWithFlags(&evs[dev_id][1], hipEventDisableTiming));
+  }
+  hipStream_t side = sides[dev_id];
+  hipEvent_t ev_y = evs[dev_id][0], ev_e = evs[dev_id][1];
+  TW_HIP_CHECK(hipEventRecord(ev_y, s));
+  TW_HIP_CHECK(hipStreamWaitEvent(side, ev_y, 0));
+  if ((rc = amber_energy(ff, zy_coords, w.e_pot, nullptr, S + 1, side))) return rc;
+  TW_HIP_CHECK(hipEventRecord(ev_e, side));
   // reverse move: flow forward pass, every row conditioned on its own proposal (evaluation_utils.py:648-657)
   if ((rc = tw_flow_pass(desc, raw, (const float*)packed, w.types_rep, w.c_c, w.c_v, w.masked_rep, S, w.t_c, w.t_v, w.delta, S,
                          V, 0, path, w.flow, w.flow_bytes, stream)))
     return rc;
   hipLaunchKernelGGL(mh_pyx_kernel, dim3((unsigned)S), dim3(64), 0, s, w.t_c, w.t_v, masked, prior, w.delta, w.p_yx, V);
   TW_LAUNCH_CHECK();
+  TW_HIP_CHECK(hipStreamWaitEvent(s, ev_e, 0));
   hipLaunchKernelGGL(mh_accept_full_kernel, dim3(1), dim3(1024), 0, s, w.e_pot, w.ekin_y, w.ekin_x, w.chir, w.p_xy, w.p_yx, u,
                      zy_coords, zy_velocs, x_coords, x_velocs, new_coords, new_velocs, out_stats, out_accepted, result,
                      1.0f / opt->kbT, S, V);

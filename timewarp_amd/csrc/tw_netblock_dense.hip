@@ -313,48 +313,75 @@ netblock_dense_kernel(const DNParams p) {
       // tile ps[token][key]; the second pass (all keys, this lane's four output features) reads them back.  One wave
       // wrote what it reads: LDS operations of a wave complete in order.  Padded keys get -inf (nn.MultiheadAttention).
       f4 oh[NT];
+      float mx[NT];
+      // pass 1: scores of the keys this lane group owns; the NT tokens of the lane are independent chains
+      {
+        f4 q4[NT][4];
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        f4 q4[4];
+        for (int jt = 0; jt < NT; ++jt) {
+          mx[jt] = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q4[i] = *(const f4*)(qs + (16 * jt + i16) * QS + 4 * i);
-        const unsigned long long km = keymask[jt];
-        const float* kb = ks + tok_mol0[jt] * QS;
-        const float* vb = vs + tok_mol0[jt] * QS + 4 * g;
-        float* prow = ps + (16 * jt + i16) * PS;
-        float mx = -INFINITY;
+          for (int i = 0; i < 4; ++i) q4[jt][i] = *(const f4*)(qs + (16 * jt + i16) * QS + 4 * i);
+        }
         for (int m = g; m < p.V; m += 4) {
-          f4 k4[4];
+          f4 k4[NT][4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) k4[i] = *(const f4*)(kb + m * QS + 4 * i);
-          float a0 = q4[0][0] * k4[0][0], a1 = q4[1][0] * k4[1][0], a2 = q4[2][0] * k4[2][0], a3 = q4[3][0] * k4[3][0];
+          for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-          for (int r = 1; r < 4; ++r) {
-            a0 = fmaf(q4[0][r], k4[0][r], a0);
-            a1 = fmaf(q4[1][r], k4[1][r], a1);
-            a2 = fmaf(q4[2][r], k4[2][r], a2);
-            a3 = fmaf(q4[3][r], k4[3][r], a3);
+            for (int i = 0; i < 4; ++i) k4[jt][i] = *(const f4*)(ks + (tok_mol0[jt] + m) * QS + 4 * i);
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) {
+            float a0 = q4[jt][0][0] * k4[jt][0][0], a1 = q4[jt][1][0] * k4[jt][1][0];
+            float a2 = q4[jt][2][0] * k4[jt][2][0], a3 = q4[jt][3][0] * k4[jt][3][0];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) {
+              a0 = fmaf(q4[jt][0][r], k4[jt][0][r], a0);
+              a1 = fmaf(q4[jt][1][r], k4[jt][1][r], a1);
+              a2 = fmaf(q4[jt][2][r], k4[jt][2][r], a2);
+              a3 = fmaf(q4[jt][3][r], k4[jt][3][r], a3);
+            }
+            const float sc = ((keymask[jt] >> m) & 1ull) ? (a0 + a1) + (a2 + a3) : -INFINITY;
+            ps[(16 * jt + i16) * PS + m] = sc;
+            mx[jt] = fmaxf(mx[jt], sc);
           }
-          const float sc = ((km >> m) & 1ull) ? (a0 + a1) + (a2 + a3) : -INFINITY;
-          prow[m] = sc;
-          mx = fmaxf(mx, sc);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-        f4 o = (f4){0.f, 0.f, 0.f, 0.f};
-        if (km) {  // tokens outside every molecule (tile padding) have no keys
-          const float mxl = mx * 1.44269504088896340736f;
-          for (int m = 0; m < p.V; ++m) {
-            // e^(s - max) with the hardware exp2 (1 ulp); exp2(-inf) = 0 for padded keys
-            const float e = __builtin_amdgcn_exp2f(fmaf(prow[m], 1.44269504088896340736f, -mxl));
-            sum += e;
-            const f4 v4 = *(const f4*)(vb + m * QS);
-            o = o + v4 * e;
-          }
-          o = o * (1.0f / sum);
+      }
+      // pass 2: e^(s - max) (hardware exp2, 1 ulp; 0 for padded keys), sum, P.V for this lane's four features; keys in
+      // blocks of four so the LDS reads of a block are in flight together
+      {
+        float sum[NT], mxl[NT];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          float m_ = fmaxf(mx[jt], __shfl_xor(mx[jt], 16));
+          m_ = fmaxf(m_, __shfl_xor(m_, 32));
+          mxl[jt] = m_ * 1.44269504088896340736f;
+          sum[jt] = 0.f;
+          oh[jt] = (f4){0.f, 0.f, 0.f, 0.f};
         }
-        oh[jt] = o;
+        for (int m0 = 0; m0 < p.V; m0 += 4) {
+          float sc[NT][4];
+          f4 vv[NT][4];
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int m = min(m0 + j, p.V - 1);
+              sc[jt][j] = ps[(16 * jt + i16) * PS + m];
+              vv[jt][j] = *(const f4*)(vs + (tok_mol0[jt] + m) * QS + 4 * g);
+            }
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float e = __builtin_amdgcn_exp2f(fmaf(sc[jt][j], 1.44269504088896340736f, -mxl[jt]));
+              e = (m0 + j < p.V) ? e : 0.f;
+              sum[jt] += e;
+              oh[jt] = oh[jt] + vv[jt][j] * e;
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)  // tokens outside every molecule (tile padding) have no keys: keep them finite
+          oh[jt] = keymask[jt] ? oh[jt] * (1.0f / sum[jt]) : (f4){0.f, 0.f, 0.f, 0.f};
       }
       // y += W_out(:, head h) . o_h   (8 tiles)
 #pragma unroll

@@ -424,6 +424,8 @@ struct H3Params {
   float eps;
   int net_sel;
   int debug;  // timing experiments only: bit 0 = no weight DMA after the prologue, bit 1 = no barriers
+  const uint8_t* masked;
+  PrevCoupling prev;  // the previous coupling layer's update, applied here (flow_pass_h3)
 };
 
 template <int NT>
@@ -801,6 +803,60 @@ netblock_h3_kernel(const H3Params p) {
     tok_row[jt] = ok ? n : -1;
     tok_atom[jt] = t - q * p.V;
   }
+  // z_other of this lane's tokens: from memory, or - when the previous coupling layer's update is still pending - that
+  // update applied on the fly (PrevCoupling, tw_common.h; same arithmetic as coupling_kernel)
+  float zo[NT][3];
+  {
+    float part[NT];
+    bool bad = false;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const int64_t n = tok_row[jt];
+      part[jt] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) zo[jt][k] = 0.f;
+      if (n < 0) continue;
+      const int64_t idx = (n * p.V + tok_atom[jt]) * 3;
+      if (p.prev.s_raw) {
+        float ld = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float sr = p.prev.s_raw[idx + k], shift = p.prev.t[idx + k];
+          const float scale = expf(sr);
+          bad |= !(isfinite(sr) && isfinite(shift));
+          const float z = p.prev.z_in[idx + k];
+          zo[jt][k] = p.prev.reverse ? (z - shift) / scale : z * scale + shift;
+          ld += logf(scale);
+        }
+        part[jt] = p.masked[(n % p.n_cond) * p.V + tok_atom[jt]] ? 0.f : ld;
+        if (net == 0 && g == 0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) p.prev.z_out[idx + k] = zo[jt][k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) zo[jt][k] = p.z_other[idx + k];
+      }
+    }
+    if (p.prev.s_raw && net == 0) {
+      // log-determinant per conformation: the tokens' partial sums through the (still unused) wave-private LDS block,
+      // added up in atom order by one lane per molecule; delta_logp -= logdet (nvp.py:86)
+      if (bad) atomicOr(p.prev.nonfinite, 1);
+      float* scr = (float*)xt_hi;
+      if (g == 0) {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) scr[16 * jt + i16] = part[jt];
+      }
+      if (lane < p.mpw) {
+        const int64_t n = (int64_t)blk * p.mpw + lane;
+        if (active && n < p.n_rows) {
+          float acc = 0.f;
+          for (int a = 0; a < p.V; ++a) acc += scr[lane * p.V + a];
+          p.prev.delta_logp[n] -= p.prev.reverse ? -acc : acc;
+        }
+      }
+    }
+  }
   // u in B-operand element order: k-step ks, element e  <->  feature 32 ks + 16 (e/4) + 4 g + e%4
   BOp<NT> u[2];
 #pragma unroll
@@ -819,7 +875,7 @@ netblock_h3_kernel(const H3Params p) {
           if (f < p.d_emb) val = p.emb[ty * p.d_emb + f];
           else if (f < p.d_emb + 3) val = p.xc[(c * p.V + a) * 3 + (f - p.d_emb)];
           else if (f < p.d_emb + 6) val = p.xv[(c * p.V + a) * 3 + (f - p.d_emb - 3)];
-          else if (f < p.d_emb + 9) val = p.z_other[(n * p.V + a) * 3 + (f - p.d_emb - 6)];
+          else if (f < p.d_emb + 9) val = zo[jt][f - p.d_emb - 6];
         }
         const _Float16 hi = (_Float16)val;
         u[ks].h[jt][e] = hi;
@@ -1193,6 +1249,7 @@ netblock_h3_kernel(const H3Params p) {
 // ================================================================================================
 struct H3Ws {
   float *s_out, *t_out;
+  float *s_out2, *t_out2, *zc_alt, *zv_alt;  // second s/t set and second copies of the two variables (PrevCoupling)
   char* sfrag;
   int64_t sf_variant_bytes;  // per-block layout: bytes of one fragment set over all blocks
   int64_t bytes;
@@ -1211,6 +1268,10 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
   const int64_t nblocks = (n_rows + g.mpw - 1) / g.mpw;
   w.s_out = (float*)take(n_rows * V * 3 * 4);
   w.t_out = (float*)take(n_rows * V * 3 * 4);
+  w.s_out2 = (float*)take(n_rows * V * 3 * 4);
+  w.t_out2 = (float*)take(n_rows * V * 3 * 4);
+  w.zc_alt = (float*)take(n_rows * V * 3 * 4);
+  w.zv_alt = (float*)take(n_rows * V * 3 * 4);
   // chebyshev_kernel: one fragment set per (net, layer) of the coupling layer in flight
   // + one head of slack: the attention asm block prefetches the "next head" also after the last one
   const int64_t variants = d.cheb_order > 0 ? 2 * d.n_layers : 1;
@@ -1238,7 +1299,8 @@ int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms) {
 }
 
 static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg, int c, int net_sel, const float* z_other,
-                     const char* sfrag, int64_t sf_variant_bytes, bool shared, float* s_out, float* t_out, float* dump) {
+                     const char* sfrag, int64_t sf_variant_bytes, bool shared, float* s_out, float* t_out, float* dump,
+                     const PrevCoupling& prev = PrevCoupling{}) {
   const tw_flow_desc& d = *a.desc;
   const H3Geom g = h3_geom(d);
   H3Params p;
@@ -1275,6 +1337,8 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.eps = d.ln_eps;
   p.net_sel = net_sel;
   p.debug = g_debug_flags;
+  p.masked = a.masked;
+  p.prev = prev;
   const int wgs_per_net = (p.nblocks + 3) / 4;
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
   static bool attr = false;
@@ -1328,17 +1392,53 @@ int flow_pass_h3(const FlowArgs& a) {
   int rc;
   int64_t vb = 0;
   if (d.cheb_order == 0 && (rc = h3_score_frags(a, L, fg, w, shared, 0, &vb))) return rc;
+  // The coupling update of layer i is applied by the launch of layer i + 1 (PrevCoupling): the variable it transforms
+  // is that launch's conditioning input.  Both variables alternate between the caller's buffer and a workspace copy,
+  // the (s, t) outputs between two sets: a launch reads what its predecessor wrote while it writes its own.
+  float* caller[2] = {a.z_coords, a.z_velocs};
+  float* cur[2] = {a.z_coords, a.z_velocs};
+  float* alt[2] = {w.zc_alt, w.zv_alt};
+  float* sbuf[2] = {w.s_out, w.s_out2};
+  float* tbuf[2] = {w.t_out, w.t_out2};
+  int* flag = nonfinite_flag_device_ptr();
+  TW_REQUIRE(flag != nullptr, "hipGetSymbolAddress(g_nonfinite) failed");
+  PrevCoupling prev{};
+  int tv = 0;
+  if (g_debug_flags & 32) {  // A/B switch: every coupling update as its own launch (the r01 sequence)
+    for (int i = 0; i < d.n_coupling; ++i) {
+      const int c = a.reverse ? d.n_coupling - 1 - i : i;
+      const bool positions = (c % 2) == d.pos_mod2;
+      if (d.cheb_order > 0 && (rc = h3_score_frags(a, L, fg, w, shared, c, &vb))) return rc;
+      if ((rc = h3_launch(a, L, fg, c, -1, positions ? a.z_velocs : a.z_coords, w.sfrag, vb, shared, w.s_out, w.t_out, nullptr)))
+        return rc;
+      if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, positions ? a.z_coords : a.z_velocs, a.delta_logp,
+                                a.n_rows, a.n_atoms, a.reverse, a.stream)))
+        return rc;
+    }
+    return TW_OK;
+  }
   for (int i = 0; i < d.n_coupling; ++i) {
     const int c = a.reverse ? d.n_coupling - 1 - i : i;
     const bool positions = (c % 2) == d.pos_mod2;
-    const float* z_other = positions ? a.z_velocs : a.z_coords;
-    float* z_t = positions ? a.z_coords : a.z_velocs;
+    tv = positions ? 0 : 1;     // the variable this layer transforms
+    const int ov = 1 - tv;      // its conditioning input - the variable the previous layer transformed
+    if (prev.s_raw) {
+      prev.z_in = cur[ov];
+      prev.z_out = alt[ov];
+    }
     if (d.cheb_order > 0 && (rc = h3_score_frags(a, L, fg, w, shared, c, &vb))) return rc;
-    if ((rc = h3_launch(a, L, fg, c, -1, z_other, w.sfrag, vb, shared, w.s_out, w.t_out, nullptr))) return rc;
-    if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, z_t, a.delta_logp, a.n_rows, a.n_atoms, a.reverse,
-                              a.stream)))
-      return rc;
+    if ((rc = h3_launch(a, L, fg, c, -1, cur[ov], w.sfrag, vb, shared, sbuf[i & 1], tbuf[i & 1], nullptr, prev))) return rc;
+    if (prev.s_raw) std::swap(cur[ov], alt[ov]);
+    prev = PrevCoupling{sbuf[i & 1], tbuf[i & 1], nullptr, nullptr, a.delta_logp, flag, a.reverse};
   }
+  // the last layer's update has no successor: its own small launch, straight into the caller's buffer
+  if ((rc = launch_coupling(prev.s_raw, prev.t, a.masked, a.n_cond, caller[tv], a.delta_logp, a.n_rows, a.n_atoms, a.reverse,
+                            a.stream, cur[tv])))
+    return rc;
+  const int ov = 1 - tv;
+  if (cur[ov] != caller[ov])
+    TW_HIP_CHECK(hipMemcpyAsync(caller[ov], cur[ov], (size_t)a.n_rows * a.n_atoms * 3 * sizeof(float), hipMemcpyDeviceToDevice,
+                                a.stream));
   return TW_OK;
 }
 

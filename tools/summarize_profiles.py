@@ -1,0 +1,84 @@
+"""Summaries of the rocprofv3 outputs that tools/profile_round.sh leaves under gpurun_out/ (run on the GPU box):
+  --traffic  DIR_FETCH DIR_WRITE OUT.json   FETCH_SIZE / WRITE_SIZE per launch of the net-block kernels (gfx950 correction)
+  --sq       DIR1 DIR2 ... OUT.md           SQ counters of netblock_h3 per wave
+  --stats    DIR OUT.csv                    copy of the kernel-stats CSV of a --kernel-trace --stats run"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def counters(d):
+    rows = []
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        with open(f) as fh:
+            rows += list(csv.DictReader(fh))
+    return rows
+
+
+def traffic(d_fetch, d_write, out):
+    res = {"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 3 --warmup 1 "
+                      "--no-cpu-baseline (one pass per counter: FETCH_SIZE, WRITE_SIZE)",
+           "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (rocprofv3); bytes = value * 1024; FETCH_SIZE doubled for the "
+                    "16 B/lane coalesced streams of these kernels (MI355X_MICROARCH.md section HBM)"}
+    per = defaultdict(lambda: defaultdict(list))
+    for name, d in (("FETCH_SIZE", d_fetch), ("WRITE_SIZE", d_write)):
+        for r in counters(d):
+            if r["Counter_Name"] == name:
+                per[r["Kernel_Name"]][name].append(float(r["Counter_Value"]))
+    for k, v in per.items():
+        if "netblock" not in k:
+            continue
+        key = "netblock_h3_kernel" if "h3" in k else ("netblock_dense_kernel" if "dense" in k else "netblock_kernel")
+        f = sum(v["FETCH_SIZE"]) / max(len(v["FETCH_SIZE"]), 1)
+        w = sum(v["WRITE_SIZE"]) / max(len(v["WRITE_SIZE"]), 1)
+        res[key] = {"kernel": k, "dispatches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
+                    "traffic_bytes_per_launch_corrected": (2 * f + w) * 1024,
+                    "traffic_bytes_per_launch_uncorrected": (f + w) * 1024,
+                    "note": "fabric-side L2 requests (Infinity-Cache hits are counted): the 8 XCD L2s each stream one net's "
+                            "weight stages out of the Infinity Cache; not HBM-limited"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({k: v for k, v in res.items() if k.startswith("netblock")}, indent=1))
+
+
+def sq(dirs, out):
+    acc = defaultdict(list)
+    for d in dirs:
+        for r in counters(d):
+            if "netblock_h3" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    waves = 1000.0
+    lines = ["# SQ counters, `tw::netblock_h3_kernel<3, true>` (r02 build)", "",
+             "`bash tools/profile_round.sh` on the GPU box: four `rocprofv3 --kernel-trace --pmc <4 counters> --kernel-include-regex "
+             "netblock_h3` passes over `python tools/time_flow.py --iters 2 --paths 3` (1000-proposal alanine-dipeptide flow passes). "
+             "Averages per launch divided by the 1000 waves of a launch; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles, "
+             "SQ_VALU_MFMA_BUSY_CYCLES counts clocks.", "", "| counter | per wave |", "|---|---|"]
+    vals = {k: sum(v) / len(v) / waves for k, v in acc.items()}
+    for k in sorted(vals):
+        lines.append(f"| {k} | {vals[k] / 1e3:.1f} k |")
+    if "SQ_WAVE_CYCLES" in vals and "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
+        lines += ["", f"matrix pipe busy: {vals['SQ_VALU_MFMA_BUSY_CYCLES'] / 4 / vals['SQ_WAVE_CYCLES'] * 100:.1f} % of the wave cycles; "
+                      f"parked at waits / barriers: {vals.get('SQ_WAIT_ANY', 0) / vals['SQ_WAVE_CYCLES'] * 100:.1f} %; "
+                      f"non-MFMA VALU instructions per MFMA: "
+                      f"{(vals.get('SQ_INSTS_VALU', 0) - vals.get('SQ_INSTS_MFMA', 0)) / max(vals.get('SQ_INSTS_MFMA', 1), 1):.2f}"]
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[-3:]))
+
+
+def stats(d, out):
+    f = glob.glob(os.path.join(d, "*", "*_kernel_stats.csv"))
+    shutil.copy(f[0], out)
+    print(open(out).read()[:1500])
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    if mode == "--traffic":
+        traffic(*sys.argv[2:5])
+    elif mode == "--sq":
+        sq(sys.argv[2:-1], sys.argv[-1])
+    elif mode == "--stats":
+        stats(sys.argv[2], sys.argv[3])
