@@ -374,13 +374,13 @@ def main():
         # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied), summarised in profiles/
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if args.proposals == S_PROPOSALS and os.path.exists(pmc):
             with open(pmc) as f:
                 rec = json.load(f).get("netblock_h3_kernel" if args.path == "h3" else "netblock_kernel")
             if rec:
                 traffic = rec["traffic_bytes_per_launch_corrected"]
-                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "MH-accepted samples/sec (whole node), alanine-dipeptide kernel_transformer_nvp",
