@@ -314,8 +314,8 @@ def whole_job_rates(accepted, proposals, states, elapsed, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=S_PROPOSALS)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--sync-every", type=int, default=8,
