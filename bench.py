@@ -217,8 +217,13 @@ def cpu_baseline(proposals):
     default_threads = torch.get_num_threads()
     candidates = sorted({n for n in (1, 8, 16, 32, 64, ncpu) if n <= ncpu})
     sweep_S = max(1, proposals // 10)
-    sweep = {}
+    sweep, skipped = {}, []
     for n in candidates:
+        # past the optimum the rate only falls (oversubscribed host threads: 256 threads ran at 0.4 proposals/s, four
+        # minutes for this one setting): stop once a setting is more than 2.5x slower than the best seen
+        if sweep and sweep[max(sweep)]["proposals_per_s"] * 2.5 < max(v["proposals_per_s"] for v in sweep.values()):
+            skipped.append(n)
+            continue
         sec, _, esec = run(1, sweep_S, n)
         sweep[n] = {"model_s": sec - esec, "proposals_per_s": sweep_S / sec}
     best = max(sweep, key=lambda n: sweep[n]["proposals_per_s"])
@@ -232,7 +237,7 @@ def cpu_baseline(proposals):
         "cores": best,
         "kind": "port",
         "sample": f"{iters} full MH iterations of {proposals} proposals (flow reverse+forward via oracle/flow_oracle.py on torch-CPU fp32 "
-                  f"with {best} threads - the fastest of {candidates} on a {sweep_S}-proposal iteration; energies via "
+                  f"with {best} threads - the fastest of {sorted(sweep)} on a {sweep_S}-proposal iteration; energies via "
                   f"oracle/energy_oracle.c on 1 core; accept scan) in {elapsed:.2f} s",
         "proposals_per_s": iters * proposals / elapsed,
         "s_per_iteration": elapsed / iters,
@@ -241,6 +246,7 @@ def cpu_baseline(proposals):
         "model_s_per_iteration": (elapsed - esec) / iters,
         "model_threads": best, "energy_threads": 1, "host_logical_cpus": ncpu,
         "thread_sweep_proposals_per_s": {str(n): round(v["proposals_per_s"], 2) for n, v in sweep.items()},
+        "thread_sweep_skipped": skipped,
         "single_thread": {"cores": 1, "proposals_per_s": n1["proposals_per_s"],
                           "sample": f"one {sweep_S}-proposal MH iteration on 1 torch thread",
                           "s_per_1000_proposal_iteration_extrapolated": proposals / n1["proposals_per_s"]},

@@ -254,9 +254,8 @@ int tw_kernel_scores(const float* x_coords, const uint8_t* masked, const float* 
                      int64_t n_cond, int32_t n_atoms, int32_t normalise, int32_t use_mm, float* out, void* stream) {
   TW_REQUIRE(x_coords && masked && lengthscales && out, "NULL pointer argument");
   TW_REQUIRE(n_heads > 0 && n_cond >= 0 && n_atoms > 0, "bad sizes");
-  TW_REQUIRE((size_t)(3 * n_atoms + n_atoms * n_atoms) * 4 <= 64 * 1024, "n_atoms too large for the scores kernel");
   return launch_scores(x_coords, masked, lengthscales, n_heads, n_cond, n_atoms, normalise, use_mm, out,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream);  // refuses molecules whose V x V tile exceeds the CU's LDS (TW_LDS_LIMIT)
 }
 
 int tw_kernel_scores_cheb(const float* x_coords, const uint8_t* masked, const float* lengthscales, const float* cheb_coeffs,
@@ -264,7 +263,6 @@ int tw_kernel_scores_cheb(const float* x_coords, const uint8_t* masked, const fl
                           int32_t normalise, int32_t use_mm, float* out, void* stream) {
   TW_REQUIRE(x_coords && masked && lengthscales && cheb_coeffs && out, "NULL pointer argument");
   TW_REQUIRE(n_heads > 0 && n_cond >= 0 && n_atoms > 0 && cheb_order >= 1, "bad sizes");
-  TW_REQUIRE((size_t)(3 * n_atoms + n_atoms * n_atoms) * 4 <= 64 * 1024, "n_atoms too large for the scores kernel");
   return launch_scores(x_coords, masked, lengthscales, n_heads, n_cond, n_atoms, normalise, use_mm, out,
                        (hipStream_t)stream, cheb_coeffs, cheb_order, force_zero);
 }
