@@ -163,6 +163,7 @@ struct DNParams {
   int H, n_layers, ff_chunks, hid_chunks, d_emb;
   float eps;
   int net_sel;
+  int debug;  // timing experiments (tw_debug_set_flags): 64 = no softmax section (o_h = v_h), 128 = also no LDS round trip
 };
 
 template <int NT>
@@ -301,6 +302,7 @@ netblock_dense_kernel(const DNParams p) {
           TW_PIN();
         }
       // to the wave-private LDS tiles, [token][feature]
+      if (!(p.debug & 128))
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
         const int row = (16 * jt + i16) * QS + 4 * g;
@@ -314,6 +316,10 @@ netblock_dense_kernel(const DNParams p) {
       // wrote what it reads: LDS operations of a wave complete in order.  Padded keys get -inf (nn.MultiheadAttention).
       f4 oh[NT];
       float mx[NT];
+      if (p.debug & 64) {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) oh[jt] = qkv[2][jt] + qkv[0][jt] * qkv[1][jt];
+      } else {
       // pass 1: scores of the keys this lane group owns; the NT tokens of the lane are independent chains
       {
         f4 q4[NT][4];
@@ -382,6 +388,7 @@ netblock_dense_kernel(const DNParams p) {
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)  // tokens outside every molecule (tile padding) have no keys: keep them finite
           oh[jt] = keymask[jt] ? oh[jt] * (1.0f / sum[jt]) : (f4){0.f, 0.f, 0.f, 0.f};
+      }
       }
       // y += W_out(:, head h) . o_h   (8 tiles)
 #pragma unroll
@@ -499,6 +506,7 @@ static int dense_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& 
   p.d_emb = d.d_emb;
   p.eps = d.ln_eps;
   p.net_sel = net_sel;
+  p.debug = g_debug_flags;
   const int wgs_per_net = (p.nblocks + 3) / 4;
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
   const size_t shm = (size_t)4 * 16 * g.nt * (3 * QS + PS) * sizeof(float);
