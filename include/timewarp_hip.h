@@ -273,7 +273,9 @@ int tw_chirality_changed(const float* coords, const int32_t* centres, const floa
 /* Measurement hooks (bench.py roofline leg): between tw_profile_begin() and tw_profile_end() every
  * launch of the dominant kernel (the fused net-block kernel) is bracketed by hipEvents recorded on
  * the launch stream.  tw_profile_end synchronises those events and returns (host pointers) the
- * summed kernel time in milliseconds and the number of launches.  Not thread-safe. */
+ * summed kernel time in milliseconds and the number of launches (of the bracketed ones: with TW_PROFILE_STRIDE=n in the
+ * environment at tw_profile_begin only every n-th launch is bracketed - two event records cost a few microseconds of
+ * stream time per launch).  Not thread-safe. */
 int tw_profile_begin(void);
 int tw_profile_end(double* total_ms, int64_t* launches);
 

@@ -16,6 +16,7 @@
 //    fp64 at pack time; the per-head mixing A_h X is an MFMA against block-diagonal score
 //    fragments, with X transposed through a wave-private LDS tile.
 //  * blockIdx -> (net, block) is XCD-aware: XCDs 0-3 stream the scale net, 4-7 the shift net.
+#include <stdlib.h>
 #include <utility>
 #include <vector>
 
@@ -486,10 +487,17 @@ netblock_kernel(const NBParams p) {
 // ================================================================================================
 // optional timing of the net-block launches (bench.py's roofline leg): HIP events on the launch stream
 static bool g_profile = false;
+static int g_profile_stride = 1;   // TW_PROFILE_STRIDE: bracket every n-th launch only (an event record costs ~1-2 us of stream time)
+static int64_t g_profile_seen = 0; // launches since profile_begin
+static bool g_profile_open = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
 static size_t g_events_used = 0;
 
 int profile_begin() {
+  const char* st = getenv("TW_PROFILE_STRIDE");
+  g_profile_stride = st && atoi(st) > 0 ? atoi(st) : 1;
+  g_profile_seen = 0;
+  g_profile_open = false;
   g_profile = true;
   g_events_used = 0;
   return TW_OK;
@@ -499,6 +507,8 @@ int profile_begin() {
 int profile_mark(hipStream_t s, bool begin) {
   if (!g_profile) return TW_OK;
   if (begin) {
+    g_profile_open = (g_profile_seen++ % g_profile_stride) == 0;
+    if (!g_profile_open) return TW_OK;
     if (g_events_used == g_events.size()) {
       hipEvent_t e0, e1;
       TW_HIP_CHECK(hipEventCreate(&e0));
@@ -508,6 +518,7 @@ int profile_mark(hipStream_t s, bool begin) {
     TW_HIP_CHECK(hipEventRecord(g_events[g_events_used].first, s));
     ++g_events_used;
   } else {
+    if (!g_profile_open) return TW_OK;
     TW_HIP_CHECK(hipEventRecord(g_events[g_events_used - 1].second, s));
   }
   return TW_OK;
