@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle (torch on the CPU) is the checker in most tests: on the GPU box's 256 logical CPUs torch's default thread
+    # count oversubscribes these small matrices (bench.py's thread sweep: 16 threads 179 proposals/s, 64 threads 41)
+    import torch
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")
