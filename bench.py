@@ -220,8 +220,8 @@ def cpu_baseline(proposals):
     sweep, skipped = {}, []
     for n in candidates:
         # past the optimum the rate only falls (oversubscribed host threads: 256 threads ran at 0.4 proposals/s, four
-        # minutes for this one setting): stop once a setting is more than 2.5x slower than the best seen
-        if sweep and sweep[max(sweep)]["proposals_per_s"] * 2.5 < max(v["proposals_per_s"] for v in sweep.values()):
+        # minutes for this one setting): stop once a setting is more than 1.5x slower than the best seen
+        if sweep and sweep[max(sweep)]["proposals_per_s"] * 1.5 < max(v["proposals_per_s"] for v in sweep.values()):
             skipped.append(n)
             continue
         sec, _, esec = run(1, sweep_S, n)
