@@ -5,9 +5,10 @@
 // Why: driven op by op (tw_flow_sample_with_logp, tw_amber_energy, tw_kinetic_energy, tw_flow_log_likelihood,
 // tw_mh_accept + a dozen elementwise torch ops) an iteration is ~85 launches, of which the 16 net-block launches are
 // 95 % of the time and the other ~70 cost ~4-5 us each plus a boundary: 0.36 ms of a 7.1 ms iteration (r01 profile).
-// Here the glue is four kernels - begin, finish, begin_ll, accept - around the two flow passes and one energy launch
-// over S + 1 conformations (the current state rides along as row S); nothing is copied: the latent buffers the caller
-// hands in become the proposals in place, and the accept kernel writes the new state into buffers of its own.
+// Here the glue is four kernels - mh_begin, mh_finish, mh_pyx, mh_accept_full - around the two flow passes and one
+// energy launch over S + 1 conformations (the current state rides along as row S; it runs on a side stream beside the
+// forward pass); nothing is copied: the latent buffers the caller hands in become the proposals in place, and the accept
+// kernel writes the new state into buffers of its own.
 #include "tw_common.h"
 
 extern "C" int tw_flow_pass(const tw_flow_desc* desc, const float* raw, const float* packed, const int32_t* atom_types,

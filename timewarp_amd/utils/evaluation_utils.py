@@ -10,6 +10,8 @@ return values.  Every numeric step of an iteration runs on the GPU through libti
     log p(x|y) of the reverse   tw_flow_log_likelihood        (model.log_likelihood)
     exponent, p_acc, u < p_acc, first accepted index          tw_mh_accept
 
+When the proposal is the HIP flow and the energy the AMBER kernel, the whole list above is ONE call, tw_mh_iteration
+(csrc/tw_mh_step.hip; same bits as the op-by-op route, which serves every other combination).
 The host reads back 8 bytes per iteration (first accepted index, any-accepted flag) - batched over
 `sync_every` iterations, the accept kernel moving the chain state on the device meanwhile; chain states
 and ChainStats stay on the device until the loop ends (the reference does >= 10 D2H copies per
