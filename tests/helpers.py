@@ -75,7 +75,7 @@ def elem_rel_err(a, b):
 # ---------------------------------------------------------------------------------------------
 def tw_kernel_model(sd, emb=32, d_model=128, ff=2048, hidden=256, n_coupling=8, n_layers=3,
                     lengthscales=(0.1, 0.2, 0.5, 0.7, 1.0, 1.2), path=0, device="cuda", attention_type="kernel",
-                    cheb_order=None, force_asymptotic_zero=None, normalise=True):
+                    cheb_order=None, force_asymptotic_zero=None, normalise=True, pos_mod2=0):
     import timewarp_amd as tw
 
     enc = tw.CustomAttentionEncoderLayerConfig(d_model=d_model, dim_feedforward=ff, dropout=0.0,
@@ -84,7 +84,7 @@ def tw_kernel_model(sd, emb=32, d_model=128, ff=2048, hidden=256, n_coupling=8, 
                                                cheb_order=cheb_order, force_asymptotic_zero=force_asymptotic_zero)
     cfg = tw.ModelConfig("custom_attention_transformer_nvp",
                          custom_transformer_nvp_config=tw.CustomAttentionTransformerNVPConfig(
-                             emb, [hidden], n_coupling, n_layers, enc))
+                             emb, [hidden], n_coupling, n_layers, enc, position_layer_index_mod_2=pos_mod2))
     m = tw.model_constructor(cfg)
     m.load_state_dict(sd)
     if path is not None:  # None: keep the constructor's default (TW_EXECUTION_PATH)

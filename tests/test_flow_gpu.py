@@ -439,6 +439,34 @@ def test_full_size_S1000_rows_vs_oracle(path):
     assert H.rel_err(p_yx[rows], r_yx) < TOL and H.elem_rel_err(p_yx[rows], r_yx) < TOL
 
 
+@pytest.mark.parametrize("n_coupling,pos_mod2", [(2, 0), (2, 1), (4, 1), (6, 0)])
+def test_other_layer_counts_and_velocity_first_flows(n_coupling, pos_mod2):
+    """Coupling-layer counts (even, as the constructor demands) and `position_layer_index_mod_2` other than the shipped 8 / 0: the split-fp16 flow pass
+    applies layer i's coupling update in layer i + 1's launch and ping-pongs both variables between the caller's buffers
+    and workspace copies - where the results end up depends on the parity of both numbers.  Full-width nets (the fused
+    kernels need d_model 128), one encoder layer each; all three paths against the oracle, both directions."""
+    spec = fo.FlowSpec(variant="kernel", num_coupling_layers=n_coupling, num_transformer_layers=1,
+                       position_layer_index_mod_2=pos_mod2)
+    sd = fo.synth_state_dict(fo.make_template(spec), 3)
+    d, _ = H.load("kernel_full_ad")
+    at, xc, xv, mk = d["atom_types"], d["x_coords"], d["x_velocs"], d["masked"]
+    zc, zv = d["z_coords"][:9], d["z_velocs"][:9]
+    ref = fo.conditional_sample_with_logp(sd, spec, at, xc, xv, mk, zc, zv)
+    ll_ref = fo.log_likelihood(sd, spec, at.repeat(9, 1), ref[0].squeeze(1), ref[1].squeeze(1), xc.repeat(9, 1, 1),
+                               xv.repeat(9, 1, 1), mk.repeat(9, 1))
+    for path in (SIMPLE, FUSED, H3):
+        m = H.tw_kernel_model(sd, n_coupling=n_coupling, n_layers=1, path=path, pos_mod2=pos_mod2)
+        got = m.conditional_sample_with_logp(atom_types=at.cuda(), x_coords=xc.cuda(), x_velocs=xv.cuda(), adj_list=None,
+                                             edge_batch_idx=None, masked_elements=mk.cuda(), num_samples=9,
+                                             z_coords=zc.cuda(), z_velocs=zv.cuda())
+        for a, b in zip(got, ref):
+            assert H.rel_err(a.cpu(), b) < TOL, (path, H.rel_err(a.cpu(), b))
+        ll = m.log_likelihood(atom_types=at.repeat(9, 1).cuda(), x_coords=ref[0].squeeze(1).cuda(), x_velocs=ref[1].squeeze(1).cuda(),
+                              y_coords=xc.repeat(9, 1, 1).cuda(), y_velocs=xv.repeat(9, 1, 1).cuda(), adj_list=None,
+                              edge_batch_idx=None, masked_elements=mk.repeat(9, 1).cuda())
+        assert H.rel_err(ll.cpu(), ll_ref) < TOL, (path, H.rel_err(ll.cpu(), ll_ref))
+
+
 def test_fused_equals_simple_large_batch():
     sd = H.full_kernel_sd()
     d, _ = H.load("kernel_full_ad")
