@@ -29,6 +29,11 @@ EXPERIMENT = set(filter(None, os.environ.get("H3_FFN_EXPERIMENT", "").split(",")
 # chunk c, in gaps that hold nothing else (`nospread`: the r01 placement - all of it in the B stages, beside the LDS
 # reads and the hand-off - measured slower)
 SPREAD = "nospread" not in EXPERIMENT
+# in / out MLPs (SiLU: 36 VALU ops per 4 values, 216 per chunk): `iotail` lets the units whose accumulators are ready last
+# only do their scale/bias fma (which reads hacc and the bias registers) in the B stages of the chunk before and finish
+# under the A stage(s) of the NEXT chunk - out: o = 0 units under A1, o = 1 tails under the next A0 instead of everything
+# beside the 9 MFMAs of its single B stage; in: three tails under the next A stage
+IOTAIL = "iotail" in EXPERIMENT
 
 NT = 3
 # Shapes of the three chunked MLPs (same schedule, one generated file each):
@@ -83,10 +88,15 @@ def pair_mfmas(acc_of_jt, slot, bop_of_jt, first=False, dst="a", bsrc="v"):
     return out
 
 
-def epi_unit(o, jt, buf, relu=True):
+V_T3 = 208  # third set of epilogue temporaries (iotail: three units' scale/bias results wait for the next A stage)
+
+
+def epi_unit(o, jt, buf, relu=True, tset=None):
     """hacc[o][jt] -> dwords 2o, 2o+1 of hb[buf].h[jt] / .l[jt]: 16 VALU ops (the hidden pre-activations
     accumulate in VGPRs and the scale sits in an SGPR: every VALU op costs register-file cycles the MFMAs need)."""
-    t = [V_T + i for i in range(4)] if (o * NT + jt) % 2 == 0 else [V_T + 4 + i for i in range(4)]
+    if tset is None:
+        tset = (o * NT + jt) % 2
+    t = [(V_T, V_T + 4, V_T3)[tset] + i for i in range(4)]
     ops = [f"v_fma_f32 v{t[r]}, v{HACC(o, jt) + r}, s{S_SC}, v{BIAS(o) + r}" for r in range(4)]
     if SHAPE["silu"]:
         # v * 1 / (1 + 2^(-v log2 e)) with the hardware exp2 / rcp
@@ -271,7 +281,7 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     live = [bool(g) for g in groups]
     aux = 3 if is_a0 else 0
     epi = [] if "noepi" in EXPERIMENT else list(epi_ops)
-    spread = SPREAD and (SHAPE["tag"] == "ffn" or "spreadio" in EXPERIMENT)
+    spread = SPREAD and (SHAPE["tag"] == "ffn" or "spreadio" in EXPERIMENT or IOTAIL)
     share = -(-len(epi) // 4)
     parts = [[] for _ in range(4)] if spread else [epi[i * share:(i + 1) * share] for i in range(4)]
     out = []
@@ -371,14 +381,28 @@ def generate():
     # first stage AFTER the FFN (an A0 of out_mlp in the last layer).  The short in/out MLPs always move it.
     steady = (lambda kind, idx: (kind, idx) in (("A", 1), ("B", 1))) if ffn else always
 
+    iotail = IOTAIL and SPREAD and not ffn
+    UNITS = [(o, jt) for o in range(2) for jt in range(NT)]
+
+    def io_units(buf):
+        return [epi_unit(o, jt, buf, tset=k % 3) for k, (o, jt) in enumerate(UNITS)]
+
+    def io_tail(buf):  # what the last three units still have to do after their scale/bias fma
+        u_ = io_units(buf)
+        return u_[3][4:] + u_[4][4:] + u_[5][4:]
+
     # ---- prologue: A(0), epilogue of chunk 0 (not hidden)
     L += a_stages(0, "p", always)
     A("s_nop 7")
     spread4 = ffn and SPREAD and "spread4" in EXPERIMENT
-    for o in range(2):
-        for jt in range(NT):
-            # spread4: the last unit's tail is left to the next A0 stage (or to the code in front of the final B stages)
-            L += epi_unit(o, jt, 0)[:4] if spread4 and (o, jt) == (1, NT - 1) else epi_unit(o, jt, 0)
+    if iotail:
+        u_ = io_units(0)
+        L += u_[0] + u_[1] + u_[2] + u_[3][:4] + u_[4][:4] + u_[5][:4]   # the three tails: first A stage of the loop / exit code
+    else:
+        for o in range(2):
+            for jt in range(NT):
+                # spread4: the last unit's tail is left to the next A0 stage (or to the code in front of the final B stages)
+                L += epi_unit(o, jt, 0)[:4] if spread4 and (o, jt) == (1, NT - 1) else epi_unit(o, jt, 0)
     A(f"s_sub_u32 s{S_CNT}, %[chunks], 1")
     A(f"s_cmp_eq_u32 s{S_CNT}, 0")
     A("s_cbranch_scc1 .Lh3mlp_tail_%=")
@@ -398,6 +422,14 @@ def generate():
                 stream = [op for u_ in units for op in u_]
                 a_epi = {0: epi_unit(1, NT - 1, cur_buf)[4:], 1: stream[:28]}   # A0: the tail left over from the chunk before
                 epi = stream[28:84]
+        elif iotail:
+            u_ = io_units(nxt_buf)
+            if n_a == 2:   # out: hacc[0] is ready after A0 -> its units under A1; o = 1: fma under B, tails under the next A0
+                a_epi = {0: io_tail(cur_buf), 1: u_[0] + u_[1] + u_[2]}
+                epi = u_[3][:4] + u_[4][:4] + u_[5][:4]
+            else:          # in: one A stage holds both o
+                a_epi = {0: io_tail(cur_buf)}
+                epi = u_[0] + u_[1] + u_[2] + u_[3][:4] + u_[4][:4] + u_[5][:4]
         else:
             a_epi = None
             epi = [op for u_ in units for op in u_]
@@ -411,11 +443,15 @@ def generate():
             A("s_cbranch_scc0 .Lh3mlp_loop_%=")
     # ---- tails: last chunk's B stages (hb in buf0 after an even number of loop halves, buf1 after odd)
     A(".Lh3mlp_tail_%=:")
+    if iotail:
+        L += io_tail(0) + ["s_nop 1"]
     if spread4:
         L += epi_unit(1, NT - 1, 0)[4:] + ["s_nop 1"]
     L += b_stages(0, "t0", [], always, last=True)
     A("s_branch .Lh3mlp_done_%=")
     A(".Lh3mlp_tail1_%=:")
+    if iotail:
+        L += io_tail(1) + ["s_nop 1"]
     if spread4:
         L += epi_unit(1, NT - 1, 1)[4:] + ["s_nop 1"]
     L += b_stages(1, "t1", [], always, last=True)
@@ -458,7 +494,7 @@ def main():
     for l in lines:
         out.append('"' + l + '\\n\\t"')
     open(base, "w").write("\n".join(out) + "\n")
-    n_v = 208 if SHAPE["silu"] else 204
+    n_v = (212 if IOTAIL else 208) if SHAPE["silu"] else 204
     clob = [f'"v{i}"' for i in range(n_v)] + [f'"a{i}"' for i in range(120)] + [f'"s{i}"' for i in range(83 if "auxrot" in EXPERIMENT else 84, 96)] + \
            ['"vcc"', '"scc"', '"memory"']
     cl = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape} - clobber list of the {shape} MLP asm statement."]
