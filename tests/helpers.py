@@ -210,7 +210,7 @@ class OracleAmberEnergy:
         return torch.from_numpy(out).to(torch.float32)[:, None]
 
 
-def mh_state_dict(kind, random_velocs):
+def mh_state_dict(kind, random_velocs, out_scale=1e-4, coords_log_scale=-7.0):
     """Full-size kernel_transformer_nvp weights for the MH-iteration parity tests.
     "bench": exactly bench.py's calibration (identity flow: last out_mlp layer zeroed; coordinate prior e^-7).
     "scaled": the last out_mlp layers scaled by 1e-4 instead of zeroed - every coupling net's output now moves the
@@ -221,7 +221,7 @@ def mh_state_dict(kind, random_velocs):
     sd = dict(fo.synth_state_dict(fo.make_template(FULL_KERNEL_SPEC), 0))
     for k in sd:
         if ".out_mlp._layers.2." in k:
-            sd[k] = sd[k] * 1e-4
-    sd["coords_prior_log_scale"] = torch.tensor(-7.0)
+            sd[k] = sd[k] * out_scale
+    sd["coords_prior_log_scale"] = torch.tensor(float(coords_log_scale))
     sd["velocs_prior_log_scale"] = torch.tensor(0.0 if random_velocs else -3.0)
     return sd

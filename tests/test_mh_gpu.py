@@ -469,3 +469,39 @@ def test_fused_iteration_equals_op_by_op_route(monkeypatch, random_velocs, chira
     for f in ("acceptance_indicator", "acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin",
               "energies_pot_delta", "energies_kin_delta"):
         assert np.array_equal(getattr(a[3], f), getattr(b[3], f)), f
+
+
+def test_mh_iterations_on_a_65_atom_peptide_vs_oracle():
+    """The tetrapeptide NNQQ of the reference's own OpenMM test data (65 atoms, amber99sb-ildn + GBSA-OBC tables pinned by
+    that file, tests/test_energy_kat.py): whole MH iterations with the full-size flow - above 64 atoms TW_PATH_AUTO runs
+    the per-op kernels (scores from torch.cdist's matmul branch) - through tw_mh_iteration, against the oracle loop and
+    the C energy oracle on shared host noise.  The BASELINE tetrapeptide configuration's MH half on a real molecule."""
+    from tests.test_energy_kat import kat, kat_tables
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.forcefield import ELEMENT_MASSES
+    from timewarp_amd.utils.evaluation_utils import MetropolisHastingsChain, sample_with_model
+
+    z = kat()
+    tables = kat_tables(z)
+    vocab = {"C": 0, "H": 1, "N": 2, "O": 3, "S": 4}
+    els = [str(e) for e in z["elements"]]
+    types = torch.tensor([vocab[e] for e in els])
+    masses = torch.tensor([ELEMENT_MASSES[e] for e in els], dtype=torch.float32)
+    coords = torch.from_numpy(z["positions"][0]).float()
+    sd = H.mh_state_dict("scaled", True, out_scale=3e-5, coords_log_scale=-7.5)  # 65 atoms: smaller moves for the same acceptance
+    energy = AmberPotentialEnergyTorch(tables)
+    S, N = 16, 40
+    kw = dict(accept=True, num_proposal_steps=S, random_velocs=True, resample_velocs=True)
+    ref = mo.sample_with_model(types[None], coords[None], torch.zeros(1, 65, 3), torch.zeros(1, 65, dtype=torch.bool),
+                               mo.OracleModel(sd, H.FULL_KERNEL_SPEC), H.OracleAmberEnergy(tables), masses, N,
+                               H.HostNoise(2), **kw)
+    model = H.tw_kernel_model(sd, path=0)
+    dev = torch.device("cuda")
+    chain = MetropolisHastingsChain(single_state_batch("nnqq", types, coords), model, dev, energy, masses,
+                                    noise=H.HostNoise(2, "cuda"), **kw)
+    assert chain._fused and model._path_for(65) == 0
+    got = sample_with_model(single_state_batch("nnqq", types, coords), model, dev, energy, masses, N, disable_tqdm=True,
+                            noise=H.HostNoise(2, "cuda"), **kw)
+    assert ref[2] >= 1
+    _assert_chain_matches_oracle(got, ref, tol=2e-5, stat_tol=2e-4)
