@@ -319,84 +319,107 @@ __device__ __forceinline__ float h3_pair_dist(const float* x, int q, int m) {
   return sqrtf(dx * dx + dy * dy + dz * dz);
 }
 
+// One workgroup per wave-block (all heads): distances and basis values once per (pair, head), rows normalised in LDS, then
+// one thread per (head, query tile, lane) assembles that lane's 16 + 16 + 8 + 8 fragment bytes and stores them whole.
+// (The first version ran one workgroup per (block, head) and one thread per fragment element: its runtime integer
+// divisions and the basis values recomputed per element made it 42 us per 1000-row forward pass against 16 us now, bit-identical output:
+// profiles/r02_ab_score_frag.txt.)
 __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
                                      const float* __restrict__ ls, int H, int V, int mpw, int64_t n_rows,
                                      int64_t n_cond, int normalise, char* __restrict__ sfrag, ScoreBasis basis,
                                      int64_t variant_bytes, int windowed) {
   extern __shared__ float sm[];
-  float* xs = sm;
-  float* dist = xs + mpw * V * 3;
-  float* denom = dist + mpw * V * V;
-  uint8_t* msk = (uint8_t*)(denom + mpw * H * V);
+  const int MV = mpw * V, MVV = MV * V;
+  float* xs = sm;                // [MV][3]
+  float* E = xs + MV * 3;        // [H][MV][V]: basis values, then normalised scores
+  float* cmean_s = E + H * MVV;  // [H]
+  uint8_t* msk = (uint8_t*)(cmean_s + H);  // [MV]
+  uint8_t* tmol = msk + MV;                // [16 NT] token -> molecule of the block (255: padding token)
+  uint8_t* tatm = tmol + 16 * H3_NT;       // [16 NT] token -> atom
   const int64_t blk = blockIdx.x;
-  for (int i = threadIdx.x; i < mpw * V * 3; i += blockDim.x) {
-    int64_t n = blk * mpw + i / (V * 3);
+  const int nthr = blockDim.x, t = threadIdx.x;
+  for (int i = t; i < MV; i += nthr) {
+    const int q = i / V, a = i - q * V;
+    int64_t n = blk * mpw + q;
     if (n >= n_rows) n = n_rows - 1;
-    xs[i] = x[(n % n_cond) * V * 3 + i % (V * 3)];
+    const int64_t src = (n % n_cond) * V + a;
+    xs[3 * i] = x[3 * src];
+    xs[3 * i + 1] = x[3 * src + 1];
+    xs[3 * i + 2] = x[3 * src + 2];
+    msk[i] = masked[src];
   }
-  for (int i = threadIdx.x; i < mpw * V; i += blockDim.x) {
-    int64_t n = blk * mpw + i / V;
-    if (n >= n_rows) n = n_rows - 1;
-    msk[i] = masked[(n % n_cond) * V + i % V];
+  for (int i = t; i < 16 * H3_NT; i += nthr) {
+    const int q = i / V;
+    tmol[i] = q < mpw ? (uint8_t)q : (uint8_t)255;
+    tatm[i] = (uint8_t)(i - q * V);
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < mpw * V * V; i += blockDim.x) {
-    const int q = i / (V * V), r = i % (V * V);
-    dist[i] = h3_pair_dist(xs + q * V * 3, r / V, r % V);
-  }
-  __syncthreads();
-  // grid.y = head, grid.z = basis variant (chebyshev_kernel: net x layer): every block recomputes the (cheap)
-  // distances and handles the fragments of its own head and variant
-  const int h = blockIdx.y;
-  float cmean;
-  const float* cf = basis_coeffs(basis, blockIdx.z, h, &cmean);
-  for (int i = threadIdx.x; i < mpw * V; i += blockDim.x) {
-    const int q = i / V, a = i % V;
-    float sum = 0.f;
-    for (int m = 0; m < V; ++m) {
-      float sc = dist[(q * V + a) * V + m] / ls[h];
-      float e = msk[q * V + m] ? 0.f : basis_value(sc, cf, basis.order, cmean);
-      sum += fabsf(e);
+  const float* cf0 = nullptr;
+  if (basis.order > 0) {
+    if (t < H) {
+      float cm;
+      basis_coeffs(basis, blockIdx.z, t, &cm);
+      cmean_s[t] = cm;
     }
-    denom[(q * H + h) * V + a] = sum + 1e-5f;
+    cf0 = basis.coeff0 + ((int)blockIdx.z / basis.n_layers) * basis.net_stride +
+          ((int)blockIdx.z % basis.n_layers) * basis.layer_stride;
+  } else if (t < H) {
+    cmean_s[t] = 0.f;
   }
   __syncthreads();
-  // one thread per (jt, lane, key slot 0..11): slots 0..7 -> k-step 0, 8..11 -> k-step 1
-  __shared__ __attribute__((aligned(16))) char frag[H3_NT * H3_SF_BYTES];
-  const int total = H3_NT * 64 * 12;
+  for (int i = t; i < MVV; i += nthr) {
+    const int qa = i / V, m = i - qa * V;
+    const int q = tmol[qa];
+    const float dd = h3_pair_dist(xs + q * V * 3, qa - q * V, m);
+    const bool dead = msk[q * V + m] != 0;
+    for (int h = 0; h < H; ++h) {
+      const float sc = dd / ls[h];
+      E[h * MVV + i] = dead ? 0.f : basis_value(sc, cf0 + (int64_t)h * basis.order, basis.order, cmean_s[h]);
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < H * MV; i += nthr) {
+    float* row = E + (int64_t)i * V;  // (h, q, a) rows are contiguous
+    float sum = 0.f;
+    for (int m = 0; m < V; ++m) sum += fabsf(row[m]);
+    const float den = sum + 1e-5f;
+    if (normalise)
+      for (int m = 0; m < V; ++m) row[m] = row[m] / den;
+  }
+  __syncthreads();
   char* out = sfrag + blockIdx.z * variant_bytes + blk * (int64_t)H * H3_NT * H3_SF_BYTES;
-  for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    const int slot = i % 12, lane = (i / 12) % 64, jt = i / (12 * 64);
-    const int tq = 16 * jt + (lane & 15);
+  for (int i = t; i < H * H3_NT * 64; i += nthr) {
+    const int lane = i & 63, hj = i >> 6;
+    const int h = hj / H3_NT, jt = hj - h * H3_NT;
+    const int tq = 16 * jt + (lane & 15), g = lane >> 4;
+    const int mq = tmol[tq];
+    const float* row = E + h * MVV + ((mq == 255 ? 0 : mq) * V + tatm[tq]) * V;
     // windowed (h3_windowed): query tile 2 only has keys in [16, 48) - its K = 32 block covers those, its K = 16 block
     // is not used (nor is tile 0's, whose keys all lie in [0, 32))
-    const int k32_base = (windowed && jt == 2) ? 16 : 0;
-    const int tk = slot < 8 ? k32_base + 8 * (lane >> 4) + slot : 32 + 4 * (lane >> 4) + (slot - 8);
-    float val = 0.f;
-    const int mq = tq / V, mk = tk / V;
-    if (mq == mk && mq < mpw) {
-      const int a = tq % V, m = tk % V;
-      if (!msk[mq * V + m]) {
-        float sc = dist[(mq * V + a) * V + m] / ls[h];
-        float e = basis_value(sc, cf, basis.order, cmean);
-        val = normalise ? e / denom[(mq * H + h) * V + a] : e;
-      }
+    const int k0 = ((windowed && jt == 2) ? 16 : 0) + 8 * g, k1 = 32 + 4 * g;
+    h8 hi0, lo0;
+    h4 hi1, lo1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int tk = k0 + e;
+      const float val = (mq != 255 && tmol[tk] == mq) ? row[tatm[tk]] : 0.f;
+      const _Float16 hi = (_Float16)val;
+      hi0[e] = hi;
+      lo0[e] = (_Float16)(val - (float)hi);
     }
-    const _Float16 hi = (_Float16)val;
-    const _Float16 lo = (_Float16)(val - (float)hi);
-    // assembled in LDS, written out below in 16-byte pieces (2-byte scattered global stores made this kernel 45 us)
-    char* base = frag + jt * H3_SF_BYTES;
-    if (slot < 8) {
-      ((_Float16*)(base + lane * 16))[slot] = hi;
-      ((_Float16*)(base + 1024 + lane * 16))[slot] = lo;
-    } else {
-      ((_Float16*)(base + 2048 + lane * 8))[slot - 8] = hi;
-      ((_Float16*)(base + 2560 + lane * 8))[slot - 8] = lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int tk = k1 + e;
+      const float val = (mq != 255 && tmol[tk] == mq) ? row[tatm[tk]] : 0.f;
+      const _Float16 hi = (_Float16)val;
+      hi1[e] = hi;
+      lo1[e] = (_Float16)(val - (float)hi);
     }
+    char* base = out + (int64_t)hj * H3_SF_BYTES;
+    *(h8*)(base + lane * 16) = hi0;
+    *(h8*)(base + 1024 + lane * 16) = lo0;
+    *(h4*)(base + 2048 + lane * 8) = hi1;
+    *(h4*)(base + 2560 + lane * 8) = lo1;
   }
-  __syncthreads();
-  u4* dst = (u4*)(out + (int64_t)h * H3_NT * H3_SF_BYTES);
-  for (int i = threadIdx.x; i < H3_NT * H3_SF_BYTES / 16; i += blockDim.x) dst[i] = ((const u4*)frag)[i];
 }
 
 // ================================================================================================
@@ -1369,10 +1392,15 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
   const int64_t nblocks = shared ? 1 : (a.n_rows + fg.mpw - 1) / fg.mpw;
   const ScoreBasis basis = score_basis(d, L, a.raw, c);
   const int64_t vb = basis.n_variants > 1 ? nblocks * d.n_heads * H3_NT * H3_SF_BYTES : 0;
-  size_t shm = (size_t)(fg.mpw * V * 3 + fg.mpw * V * V + fg.mpw * d.n_heads * V) * 4 + (size_t)fg.mpw * V;
-  hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks, (unsigned)d.n_heads, (unsigned)basis.n_variants), dim3(256), shm,
-                     a.stream, a.x_coords, a.masked, a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, V, fg.mpw,
-                     a.n_rows, a.n_cond, d.normalise, w.sfrag, basis, vb, h3_windowed(fg, V) ? 1 : 0);
+  const unsigned nv = (unsigned)basis.n_variants;
+  const float* ls = a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0);
+  const int win = h3_windowed(fg, V) ? 1 : 0;
+  const int MV = fg.mpw * V;
+  size_t shm = (size_t)(MV * 3 + d.n_heads * MV * V + d.n_heads) * 4 + (size_t)MV + 32 * H3_NT;
+  TW_REQUIRE(shm <= 64 * 1024, "score fragments: %zu bytes of LDS for %d atoms x %d heads", shm, V, d.n_heads);
+  // a lone block (all proposals share x) is latency-bound: spread it over 16 waves
+  hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks, 1, nv), dim3(shared ? 1024 : 512), shm, a.stream, a.x_coords,
+                     a.masked, ls, d.n_heads, V, fg.mpw, a.n_rows, a.n_cond, d.normalise, w.sfrag, basis, vb, win);
   TW_LAUNCH_CHECK();
   *variant_bytes = vb;
   return TW_OK;
