@@ -189,7 +189,32 @@ class SyntheticEnergy:
         return e[:, None]
 
 
-def gen_mh_goldens(model):
+MH_SCENARIOS = {
+    "s10": dict(accept=True, num_proposal_steps=10, num_samples=25),
+    "s10_randv": dict(accept=True, num_proposal_steps=10, num_samples=25, random_velocs=True, resample_velocs=True),
+    "adaptive": dict(accept=True, num_proposal_steps=10, num_samples=30, adaptive_parallelism=True),
+    "noaccept_s1": dict(accept=False, num_proposal_steps=1, num_samples=6),
+    "chirality": dict(accept=True, num_proposal_steps=10, num_samples=20, chirality=True),
+    # rotate=True is not generated: the reference itself raises there ((Q @ x.T).T on a [1,V,3] tensor,
+    # utils/evaluation_utils.py:604-607)
+    "init_random": dict(accept=True, num_proposal_steps=4, num_samples=8, initialize_randomly=True),
+}
+# OpenMM steps inside the chain (evaluation_utils.py:558-565, 594-602, 623-626) with oracle/fake_sim.FakeSimulation in
+# the Simulation's place (`fake_sim=True` -> a fresh one per scenario); openmm_on_proposal needs one proposal per
+# iteration (openmm_step squeezes dimension 0)
+MH_OPENMM_SCENARIOS = {
+    "omm_current": dict(accept=True, num_proposal_steps=10, num_samples=20, fake_sim=True, num_openmm_steps=3,
+                        openmm_on_current=True),
+    "omm_current_randv": dict(accept=True, num_proposal_steps=10, num_samples=20, random_velocs=True, resample_velocs=True,
+                              fake_sim=True, num_openmm_steps=2, openmm_on_current=True),
+    "omm_proposal": dict(accept=True, num_proposal_steps=1, num_samples=10, fake_sim=True, num_openmm_steps=2,
+                         openmm_on_proposal=True),
+    "omm_both_noaccept": dict(accept=False, num_proposal_steps=1, num_samples=6, fake_sim=True, num_openmm_steps=1,
+                              openmm_on_proposal=True, openmm_on_current=True),
+}
+
+
+def gen_mh_goldens(model, scenarios=None, out_name="mh_tiny.npz"):
     """Run the REAL sample_with_model (utils/evaluation_utils.py:468-745) on CPU with the tiny
     kernel model, a synthetic energy and recorded noise; store inputs, noise and all outputs."""
     from timewarp.utils import evaluation_utils as eu
@@ -219,16 +244,7 @@ def gen_mh_goldens(model):
             if ".out_mlp._layers.2." in k:
                 v.mul_(0.002)
     ref_signs = None
-    scenarios = {
-        "s10": dict(accept=True, num_proposal_steps=10, num_samples=25),
-        "s10_randv": dict(accept=True, num_proposal_steps=10, num_samples=25, random_velocs=True, resample_velocs=True),
-        "adaptive": dict(accept=True, num_proposal_steps=10, num_samples=30, adaptive_parallelism=True),
-        "noaccept_s1": dict(accept=False, num_proposal_steps=1, num_samples=6),
-        "chirality": dict(accept=True, num_proposal_steps=10, num_samples=20, chirality=True),
-        # rotate=True is not generated: the reference itself raises there ((Q @ x.T).T on a [1,V,3] tensor,
-        # utils/evaluation_utils.py:604-607)
-        "init_random": dict(accept=True, num_proposal_steps=4, num_samples=8, initialize_randomly=True),
-    }
+    scenarios = MH_SCENARIOS if scenarios is None else scenarios
     out = dict(atom_types=at.numpy(), x0=x0.numpy(), v0=v0.numpy(), masses=masses.numpy(), centres=centres.numpy())
     out.update(np_sd(model.state_dict()))
     for name, kw in scenarios.items():
@@ -265,6 +281,9 @@ def gen_mh_goldens(model):
 
         chir = kw.pop("chirality", False)
         extra = {}
+        if kw.pop("fake_sim", False):
+            from oracle.fake_sim import FakeSimulation
+            extra["sim"] = FakeSimulation()
         if chir:
             from timewarp.utils.chirality import compute_chirality_sign
             extra = dict(chirality_centers=centres, reference_signs=compute_chirality_sign(x0, centres))
@@ -295,7 +314,7 @@ def gen_mh_goldens(model):
         print("mh", name, "states", coords.shape[0], "accepted", accepted, "iters", len(rec["rand"]),
               "mean p_acc", float(np.mean(stats.acceptance)))
     model.load_state_dict(sd)
-    np.savez_compressed(os.path.join(OUT, "mh_tiny.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, out_name), **out)
 
 
 def gen_sob_golden(model):
@@ -681,6 +700,7 @@ def main():
         "dense-full": lambda: gen_dense_full(ad_x, ad_t),
         "em": gen_euler_maruyama,
         "mh": lambda: gen_mh_goldens(tiny_kernel_model()),  # (7) the MH loop itself, driven with a synthetic energy
+        "mh-omm": lambda: gen_mh_goldens(tiny_kernel_model(), MH_OPENMM_SCENARIOS, "mh_tiny_openmm.npz"),  # (7b) with OpenMM steps
         "sob": lambda: gen_sob_golden(tiny_kernel_model()),
         "learnable": gen_learnable_golden,
         "cheb": gen_chebyshev_golden,

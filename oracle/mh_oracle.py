@@ -8,7 +8,8 @@ from an explicit noise source so that a run can be replayed.
 Pinning: `oracle/gen_golden.py::gen_mh_goldens` runs the REAL reference function (imported from
 /root/reference with its third-party imports stubbed; the energy is a synthetic callable passed in
 as an argument) and records inputs, every random draw and all outputs in
-tests/golden/mh_tiny.npz; tests/test_mh_oracle.py replays them through this file.
+tests/golden/mh_tiny.npz (and, with oracle/fake_sim.FakeSimulation as the OpenMM Simulation, in mh_tiny_openmm.npz);
+tests/test_mh_oracle.py replays them through this file.
 """
 from __future__ import annotations
 
@@ -125,12 +126,24 @@ class ChainStats:
     energies_kin_delta: np.ndarray
 
 
+def openmm_step(sim, coords, velocs, num_steps=1):
+    """evaluation_utils.py:439-466 (the branch with velocities, the only one the loop takes)."""
+    sim.context.setPositions(coords.cpu().numpy().squeeze(0))
+    sim.context.setVelocities(velocs.cpu().numpy().squeeze(0))
+    sim.step(num_steps)
+    state = sim.context.getState(getPositions=True, getVelocities=True)
+    c = torch.from_numpy(state.getPositions(asNumpy=True)._value).reshape(coords.shape).to(coords)
+    v = torch.from_numpy(state.getVelocities(asNumpy=True)._value).reshape(coords.shape).to(coords)
+    return c, v
+
+
 def sample_with_model(atom_types, x_coords, x_velocs, masked, model: OracleModel, energy, masses, num_samples: int,
                       noise, accept=False, random_velocs=False, resample_velocs=False, initialize_randomly=False,
                       num_proposal_steps=1, adaptive_parallelism=False, acceptance_rate_smoothing_factor=0.01,
-                      reference_signs=None, chirality_centers=None):
-    """evaluation_utils.py:517-745 (OpenMM-stepping and rotate options omitted: they need OpenMM /
-    raise in the reference).  Inputs are [1,V,...] tensors (B == 1 is asserted at :517)."""
+                      reference_signs=None, chirality_centers=None, num_openmm_steps=0, sim=None,
+                      openmm_on_proposal=False, openmm_on_current=False):
+    """evaluation_utils.py:517-745 (the rotate option omitted: it raises in the reference).  `sim`: anything with the
+    five calls of `openmm_step`.  Inputs are [1,V,...] tensors (B == 1 is asserted at :517)."""
     assert x_coords.size(0) == 1, "only batch-size of 1 is supported"
     names = ["ind", "acc", "pxy", "pyx", "exp", "epot", "ekin", "dpot", "dkin"]
     rec = {n: [] for n in names}
@@ -144,6 +157,16 @@ def sample_with_model(atom_types, x_coords, x_velocs, masked, model: OracleModel
         yc, yv, _ = model.conditional_sample_with_logp(atom_types, rc, rv, masked, zc, zv)
         x_coords, x_velocs = yc.squeeze(0), yv.squeeze(0)
     kbT = energy.kbT
+    velocs_std = (kbT / masses.unsqueeze(0).unsqueeze(-1)).sqrt()  # :556
+    on_current = openmm_on_current and num_openmm_steps > 0 and sim is not None
+
+    def step_current(x_c, x_v):  # :558-565 and :594-602
+        if random_velocs:
+            return openmm_step(sim, x_c, x_v * velocs_std, num_openmm_steps)[0], x_v
+        return openmm_step(sim, x_c, x_v, num_openmm_steps)
+
+    if on_current:
+        x_coords, x_velocs = step_current(x_coords, x_velocs)
     coords_out, velocs_out = [x_coords.numpy().copy()], [x_velocs.numpy().copy()]  # :566-567
     accepted = 0
     p_bar = 1e-3  # :575
@@ -153,10 +176,14 @@ def sample_with_model(atom_types, x_coords, x_velocs, masked, model: OracleModel
     while i < num_samples:  # :589
         if random_velocs and resample_velocs:
             x_velocs = noise.randn_like(x_velocs)  # :590-592
+        if on_current:
+            x_coords, x_velocs = step_current(x_coords, x_velocs)
         zc, zv = noise.latents(S, B, V, sc, sv)
         y_c, y_v, p_xy = model.conditional_sample_with_logp(atom_types, x_coords, x_velocs, masked, zc, zv)  # :609-617
         y_c, y_v = y_c.squeeze(1), y_v.squeeze(1)
         X_c, X_v = x_coords.repeat(S, 1, 1), x_velocs.repeat(S, 1, 1)  # :620-621
+        if openmm_on_proposal and sim is not None and num_openmm_steps > 0:  # :623-626
+            y_c, _ = openmm_step(sim, y_c, y_v * velocs_std, num_openmm_steps)
         e_pot_x = (energy(X_c) / kbT).squeeze(-1)  # :628
         e_kin_x = compute_kinetic_energy(X_v, masses, random_velocs, kbT)
         e_kin_y = compute_kinetic_energy(y_v, masses, random_velocs, kbT)

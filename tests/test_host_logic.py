@@ -492,3 +492,34 @@ def test_energy_callable_checks_shapes():
         e(torch.zeros(3, 21, 3))
     with pytest.raises(AssertionError, match="size 3"):
         e(torch.zeros(3, 22, 2))
+
+
+def test_openmm_step_drives_the_callers_simulation():
+    """evaluation_utils.py:439-466: positions (and velocities, or a temperature draw) in, `num_steps` steps, float32
+    tensors shaped like the input back; nothing but the Simulation's own methods is touched."""
+    from oracle import mh_oracle as mo
+    from oracle.fake_sim import FakeSimulation
+    from timewarp_amd.utils.evaluation_utils import openmm_step
+
+    g = torch.Generator().manual_seed(3)
+    c, v = torch.randn(1, 7, 3, generator=g) * 0.3, torch.randn(1, 7, 3, generator=g)
+    a = openmm_step(FakeSimulation(), c, v, num_steps=4)
+    b = mo.openmm_step(FakeSimulation(), c, v, num_steps=4)
+    assert a[0].shape == c.shape and a[0].dtype == torch.float32
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert not torch.equal(a[0], c)
+
+    class Integrator:
+        def getTemperature(self):
+            return 310.0
+
+    class ThermalSim(FakeSimulation):
+        def __init__(self):
+            super().__init__()
+            ctx = self.context
+            ctx.setVelocitiesToTemperature = lambda t: ctx.setVelocities(np.full(ctx.pos.shape, t / 310.0))
+
+    w = openmm_step(ThermalSim(), c, None, num_steps=1, integrator=Integrator())
+    assert torch.isfinite(w[0]).all() and w[1].shape == c.shape
+    with pytest.raises(ValueError):
+        openmm_step(FakeSimulation(), c, None)

@@ -7,7 +7,7 @@ import torch
 from oracle import flow_oracle as fo
 from oracle import mh_oracle as mo
 from tests import helpers as H
-from tests.test_mh_oracle import SCENARIOS, check_against_golden, load_mh, replay
+from tests.test_mh_oracle import OPENMM_SCENARIOS, SCENARIOS, check_against_golden, load_mh, replay
 
 pytestmark = pytest.mark.gpu
 
@@ -32,6 +32,28 @@ def test_sample_with_model_replays_reference(name):
         batch, model, torch.device("cuda"), energy, torch.from_numpy(z["masses"]), disable_tqdm=True,
         noise=replay(z, name, device="cuda"), **kw, **extra)
     check_against_golden(z, name, coords, velocs, accepted, stats)
+
+
+@pytest.mark.parametrize("name", list(OPENMM_SCENARIOS))
+def test_sample_with_model_replays_reference_with_openmm_steps(name):
+    """OpenMM steps on the current state / on the proposal (evaluation_utils.py:558-565, 594-602, 623-626): the runs were
+    recorded from the reference with oracle/fake_sim.FakeSimulation in the Simulation's place; the product drives the
+    same object through the same five calls."""
+    from oracle.fake_sim import FakeSimulation
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.utils.evaluation_utils import sample_with_model
+
+    z, sd = load_mh("mh_tiny_openmm.npz")
+    model = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2,
+                              lengthscales=(0.1, 0.5, 1.2), path=2)
+    x0, v0 = torch.from_numpy(z["x0"]), torch.from_numpy(z["v0"])
+    batch = single_state_batch("tiny", torch.from_numpy(z["atom_types"]), x0, v0)
+    sim = FakeSimulation()
+    coords, velocs, accepted, stats = sample_with_model(
+        batch, model, torch.device("cuda"), mo.SyntheticEnergy(x0.clone().cuda()), torch.from_numpy(z["masses"]),
+        disable_tqdm=True, noise=replay(z, name, device="cuda"), sim=sim, **OPENMM_SCENARIOS[name])
+    check_against_golden(z, name, coords, velocs, accepted, stats)
+    assert sim.calls > 0
 
 
 oracle_energy = H.oracle_energy

@@ -16,13 +16,22 @@ SCENARIOS = {
     "chirality": dict(accept=True, num_proposal_steps=10, num_samples=20, chirality=True),
     "init_random": dict(accept=True, num_proposal_steps=4, num_samples=8, initialize_randomly=True),
 }
+# OpenMM steps inside the chain, recorded from the reference with oracle/fake_sim.FakeSimulation as the Simulation
+OPENMM_SCENARIOS = {
+    "omm_current": dict(accept=True, num_proposal_steps=10, num_samples=20, num_openmm_steps=3, openmm_on_current=True),
+    "omm_current_randv": dict(accept=True, num_proposal_steps=10, num_samples=20, random_velocs=True, resample_velocs=True,
+                              num_openmm_steps=2, openmm_on_current=True),
+    "omm_proposal": dict(accept=True, num_proposal_steps=1, num_samples=10, num_openmm_steps=2, openmm_on_proposal=True),
+    "omm_both_noaccept": dict(accept=False, num_proposal_steps=1, num_samples=6, num_openmm_steps=1, openmm_on_proposal=True,
+                              openmm_on_current=True),
+}
 STAT_FIELDS = ("acceptance_indicator", "acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin",
                "energies_pot_delta", "energies_kin_delta")
 
 
-def load_mh():
+def load_mh(file="mh_tiny.npz"):
     import os
-    z = np.load(os.path.join(H.GOLDEN, "mh_tiny.npz"))
+    z = np.load(os.path.join(H.GOLDEN, file))
     sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
     return z, sd
 
@@ -63,6 +72,23 @@ def test_mh_oracle_replays_reference(name):
         torch.from_numpy(z["atom_types"]), x0, v0, torch.zeros(1, x0.shape[1], dtype=torch.bool), model, energy,
         torch.from_numpy(z["masses"]), noise=replay(z, name), **kw, **extra)
     check_against_golden(z, name, coords, velocs, accepted, stats)
+
+
+@pytest.mark.parametrize("name", list(OPENMM_SCENARIOS))
+def test_mh_oracle_replays_reference_with_openmm_steps(name):
+    """evaluation_utils.py:558-565, 594-602, 623-626: the Simulation is the caller's object; the recorded runs used
+    oracle/fake_sim.FakeSimulation, and so does the replay."""
+    from oracle.fake_sim import FakeSimulation
+
+    z, sd = load_mh("mh_tiny_openmm.npz")
+    x0, v0 = torch.from_numpy(z["x0"]), torch.from_numpy(z["v0"])
+    sim = FakeSimulation()
+    coords, velocs, accepted, stats = mo.sample_with_model(
+        torch.from_numpy(z["atom_types"]), x0, v0, torch.zeros(1, x0.shape[1], dtype=torch.bool),
+        mo.OracleModel(sd, H.TINY_KERNEL_SPEC), mo.SyntheticEnergy(x0.clone()), torch.from_numpy(z["masses"]),
+        noise=replay(z, name), sim=sim, **OPENMM_SCENARIOS[name])
+    check_against_golden(z, name, coords, velocs, accepted, stats)
+    assert sim.calls > 0
 
 
 def test_compute_num_proposal_steps():

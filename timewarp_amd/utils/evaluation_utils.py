@@ -166,6 +166,24 @@ def _mh_accept(energy, p_xy, p_yx, u, y_c=None, y_v=None, x_c=None, x_v=None):
     return ex, p_acc, acc, res
 
 
+def openmm_step(sim, coords: torch.Tensor, velocs: Optional[torch.Tensor] = None, num_steps: int = 1, integrator=None):
+    """`num_steps` integration steps of the caller's `openmm.app.Simulation` from (coords, velocs); returns the new
+    (coords, velocs) as tensors like `coords`.  Same calls, in the same order, as the reference's function
+    (evaluation_utils.py:439-466) - nothing here imports OpenMM, the Simulation object is the caller's."""
+    sim.context.setPositions(coords.detach().cpu().numpy().squeeze(0))
+    if velocs is not None:
+        sim.context.setVelocities(velocs.detach().cpu().numpy().squeeze(0))
+    elif integrator is not None:
+        sim.context.setVelocitiesToTemperature(integrator.getTemperature())
+    else:
+        raise ValueError("either `velocs` or `integrator` needs to be specified")
+    sim.step(num_steps)
+    state = sim.context.getState(getPositions=True, getVelocities=True)
+    coords_new = torch.from_numpy(np.asarray(state.getPositions(asNumpy=True)._value)).reshape(coords.shape).to(coords)
+    velocs_new = torch.from_numpy(np.asarray(state.getVelocities(asNumpy=True)._value)).reshape(coords.shape).to(coords)
+    return coords_new, velocs_new
+
+
 class MetropolisHastingsChain:
     """State and one-iteration `step()` of the loop in `sample_with_model` (reference
     evaluation_utils.py:517-745).  `sample_with_model` drives it until enough states are emitted;
@@ -176,7 +194,7 @@ class MetropolisHastingsChain:
     def __init__(self, batch, model, device, energy_fn, masses, accept=False, random_velocs=False,
                  resample_velocs=False, initialize_randomly=False, num_proposal_steps=1, adaptive_parallelism=False,
                  acceptance_rate_smoothing_factor=0.01, rotate=False, reference_signs=None, chirality_centers=None,
-                 noise=None):
+                 noise=None, sim=None, num_openmm_steps=0, openmm_on_proposal=False, openmm_on_current=False):
         assert batch.atom_coords.size(0) == 1, "only batch-size of 1 is supported"
         self.device = device = torch.device(device)
         self.model, self.energy_fn = model, energy_fn
@@ -201,6 +219,14 @@ class MetropolisHastingsChain:
             yc, yv, _ = self._propose(self.noise.randn_like(self.x_coords), self.noise.randn_like(self.x_velocs), 1)
             self.x_coords, self.x_velocs = yc.squeeze(0).contiguous(), yv.squeeze(0).contiguous()
         self.kbT = energy_fn.kbT
+        # OpenMM steps on the current state / on the proposal (evaluation_utils.py:556-565, 594-602, 623-626): a host
+        # round trip through the caller's Simulation per iteration, so these chains take the op-by-op route
+        self.sim, self.n_omm = sim, int(num_openmm_steps)
+        self.omm_current = bool(openmm_on_current) and self.n_omm > 0 and sim is not None
+        self.omm_proposal = bool(openmm_on_proposal) and self.n_omm > 0 and sim is not None
+        self.velocs_std = (self.kbT / self.masses.unsqueeze(0).unsqueeze(-1)).sqrt()
+        if self.omm_current:
+            self.x_coords, self.x_velocs = self._openmm_on_current(self.x_coords, self.x_velocs)
         self.chain_c, self.chain_v = [self.x_coords.clone()], [self.x_velocs.clone()]
         self.rec = {k: [] for k in self.KEYS}
         self._pending = []
@@ -221,7 +247,7 @@ class MetropolisHastingsChain:
         from ..energy import AmberPotentialEnergyTorch
         from ..modules.flow import ConditionalFlowDensityModel
 
-        if os.environ.get("TW_MH_FUSED", "1") == "0" or not self.accept:
+        if os.environ.get("TW_MH_FUSED", "1") == "0" or not self.accept or self.omm_current or self.omm_proposal:
             return False
         return (isinstance(self.model, ConditionalFlowDensityModel) and isinstance(self.energy_fn, AmberPotentialEnergyTorch)
                 and not self.model.dims.ignore_cond_velocity and self.x_coords.is_cuda
@@ -310,6 +336,13 @@ class MetropolisHastingsChain:
             atom_types=at, x_coords=xc, x_velocs=xv, adj_list=self.adj_list, edge_batch_idx=self.ebi,
             masked_elements=mk, num_samples=S, z_coords=zc, z_velocs=zv)
 
+    def _openmm_on_current(self, x_coords, x_velocs):
+        if self.random_velocs:  # the velocities are standard-normal draws: scaled for the integrator, kept as they are
+            c, _ = openmm_step(self.sim, x_coords, x_velocs * self.velocs_std, num_steps=self.n_omm)
+            return c.contiguous(), x_velocs
+        c, v = openmm_step(self.sim, x_coords, x_velocs, num_steps=self.n_omm)
+        return c.contiguous(), v.contiguous()
+
     def _evaluate(self):
         """Everything of one iteration up to the accept test: proposals, energies, both log-likelihoods.
         Returns the (possibly resampled / rotated) current state and the per-proposal quantities."""
@@ -318,6 +351,8 @@ class MetropolisHastingsChain:
         x_coords, x_velocs = self.x_coords, self.x_velocs
         if self.random_velocs and self.resample_velocs:
             x_velocs = noise.randn_like(x_velocs)
+        if self.omm_current:
+            x_coords, x_velocs = self._openmm_on_current(x_coords, x_velocs)
         if self.rotate:
             # the reference's (Q @ x.T).T raises for a [1,V,3] tensor; this applies the intended rotation
             Q = noise.rotation().to(x_coords)
@@ -326,6 +361,9 @@ class MetropolisHastingsChain:
 
         y_c, y_v, p_xy = self._propose(x_coords, x_velocs, S)
         y_c, y_v = y_c.squeeze(1), y_v.squeeze(1)
+        if self.omm_proposal:  # one proposal per iteration (openmm_step squeezes dimension 0), as in the reference
+            y_c, _ = openmm_step(self.sim, y_c, y_v * self.velocs_std, num_steps=self.n_omm)
+            y_c = y_c.contiguous()
         # current state: one evaluation broadcast over the S proposals
         e_pot_x = (self.energy_fn(x_coords) / kbT).squeeze(-1)
         e_kin_x = compute_kinetic_energy(x_velocs, self.masses, random_velocs=self.random_velocs, kbT=kbT)
@@ -417,7 +455,7 @@ class MetropolisHastingsChain:
     # ---- deferred bookkeeping: the accept kernel moves the state on the device, the host reads the results later
     def can_defer(self) -> bool:
         """Deferred iterations need the accept test, a fixed proposal count and no per-iteration host decision."""
-        return self.accept and not self.adaptive and not self.rotate
+        return self.accept and not self.adaptive and not self.rotate and not (self.omm_current or self.omm_proposal)
 
     def step_deferred(self) -> None:
         """One MH iteration without a host synchronisation: `tw_mh_accept` writes x <- y[k] itself and the
@@ -497,15 +535,15 @@ def sample_with_model(
 
     Arguments, semantics and returns follow the reference function; `noise` (extension) supplies
     the random draws (default: the device generator); `sync_every` (extension) is the number of iterations
-    queued per host synchronisation (1 = read the accept result every iteration).  Returns
+    queued per host synchronisation (1 = read the accept result every iteration).  `sim` is the caller's
+    `openmm.app.Simulation` (only its context / step / getState calls are used: `openmm_step`).  Returns
     (sampled_coords [1+n,V,3] float32 numpy, sampled_velocs, accepted:int, ChainStats)."""
-    if sim is not None and num_openmm_steps > 0 and (openmm_on_proposal or openmm_on_current):
-        raise NotImplementedError("OpenMM integration steps inside the chain need OpenMM; outside this build's scope")
     chain = MetropolisHastingsChain(
         batch, model, device, openmm_potential_energy_torch, masses, accept=accept, random_velocs=random_velocs,
         resample_velocs=resample_velocs, initialize_randomly=initialize_randomly, num_proposal_steps=num_proposal_steps,
         adaptive_parallelism=adaptive_parallelism, acceptance_rate_smoothing_factor=acceptance_rate_smoothing_factor,
-        rotate=rotate, reference_signs=reference_signs, chirality_centers=chirality_centers, noise=noise)
+        rotate=rotate, reference_signs=reference_signs, chirality_centers=chirality_centers, noise=noise, sim=sim,
+        num_openmm_steps=num_openmm_steps, openmm_on_proposal=openmm_on_proposal, openmm_on_current=openmm_on_current)
     print("Sample with the model using Metropolis Hastings" if accept else "Sample with the model by accepting every setp")
     i = 0
     pbar = tqdm(total=num_samples, disable=disable_tqdm)
