@@ -281,7 +281,7 @@ def alt_path_record(device, seed, proposals, steps, sync_every):
     avg_ms = k_ms.value / max(int(k_launches.value), 1)
     achieved = FLOP_PER_SAMPLE_PASS * proposals / N_COUPLING / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     return {
-        "execution_path": "auto (TW_PATH_AUTO: exact-f32 fused kernel, what model_constructor selects by default)",
+        "execution_path": "f32 (exact-f32 fused kernel: TW_EXECUTION_PATH=f32 / the C ABI's TW_PATH_AUTO; model_constructor's default is h3)",
         "dtype": pinfo["dtype"], "value": (chain.accepted - acc0) / elapsed, "unit": "MH-accepted samples/s",
         "steps": steps, "ms_per_step": elapsed / steps * 1e3,
         "roofline": {"bound": "mfma", "kernel": pinfo["kernel"], "achieved": achieved, "peak": pinfo["peak"],

@@ -94,8 +94,9 @@ def test_execution_path_from_environment(monkeypatch):
 
     cfg = synthetic.kernel_transformer_nvp_config()
     monkeypatch.delenv("TW_EXECUTION_PATH", raising=False)
-    assert tw.model_constructor(cfg).execution_path == _lib.TW_PATH_AUTO
-    for name, want in [("f32", _lib.TW_PATH_FUSED), ("simple", _lib.TW_PATH_SIMPLE), ("H3", flow.PREFER_SPLIT_FP16)]:
+    assert tw.model_constructor(cfg).execution_path == flow.PREFER_SPLIT_FP16  # the measured path is the default
+    for name, want in [("auto", _lib.TW_PATH_AUTO), ("f32", _lib.TW_PATH_FUSED), ("simple", _lib.TW_PATH_SIMPLE),
+                       ("H3", flow.PREFER_SPLIT_FP16)]:
         monkeypatch.setenv("TW_EXECUTION_PATH", name)
         assert tw.model_constructor(cfg).execution_path == want
     m = tw.model_constructor(cfg)
