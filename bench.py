@@ -254,8 +254,8 @@ def cpu_baseline(proposals):
 
 
 def alt_path_record(device, seed, proposals, steps, sync_every):
-    """The same workload on the path a plain `model_constructor` user gets (TW_PATH_AUTO = the exact-f32 fused kernel),
-    timed after the main region on a second chain so the driver's record carries both numbers."""
+    """The same workload on the exact-f32 fused kernel (TW_EXECUTION_PATH=f32; the C ABI's TW_PATH_AUTO), timed after the
+    main region on a second chain so the driver's record carries both kernel families."""
     from timewarp_amd import _lib
 
     pinfo = PATHS["f32"]
