@@ -297,7 +297,8 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *   bit 5 (32) split-fp16 flow pass: every affine coupling update as its own launch instead of in the next net-block
  *              launch's prologue (A/B switch; same results up to the summation order of the log-determinant)
  *   bit 6 (64), bit 7 (128) fused dense kernel, timing experiments (results WRONG): no softmax section / also no LDS round
- *              trip of q, k, v - what the attention block costs beyond its MFMAs (0.8 of 11.4 ms per 1000-proposal pass) */
+ *              trip of q, k, v - what the attention block costs beyond its MFMAs (0.8 of 11.4 ms per 1000-proposal pass)
+ *   bit 10 (1024) split-fp16 kernel: do not zero the padding tokens of a wave between sections (A/B switch; results equal) */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

@@ -984,6 +984,20 @@ netblock_h3_kernel(const H3Params p) {
       for (int jt = 0; jt < NT; ++jt) x[ot][jt] = x[ot][jt] * sc + bb[ot];
     }
   }
+  // Padding tokens (4 of a wave's 48 with 22-atom molecules) carry zeros instead of whatever the biases and LayerNorms
+  // make of them.  No real token ever sees them (their score rows and columns are zero); the point is power: the launch
+  // is power-limited, all-zero operand columns switch less, and the chip answers with clock (-0.6 % per pass, A/B on
+  // one box, for 48 multiplications per call).  tw_debug_set_flags bit 10 (1024) turns it off.
+  auto zero_pad = [&]() {
+    if (p.debug & 1024) return;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const float keep = tok_row[jt] < 0 ? 0.f : 1.f;
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) x[ft][jt] = x[ft][jt] * keep;
+    }
+  };
+  zero_pad();
   if (!(p.debug & 16)) dump_x(x, 0);
   stamp(1);
 
@@ -1146,6 +1160,7 @@ netblock_h3_kernel(const H3Params p) {
     if (p.debug & 4) dump_x(y, l + 1);
     stamp(2 + 4 * l + 0);
     h3_add_layernorm<NT>(x, y, sl + 4 * g, sl + 128 + 4 * g, p.eps);
+    zero_pad();
     stamp(2 + 4 * l + 1);
 
     // FFN
@@ -1203,6 +1218,7 @@ netblock_h3_kernel(const H3Params p) {
     }
     stamp(2 + 4 * l + 2);
     h3_add_layernorm<NT>(x, y, sl + 384 + 4 * g, sl + 512 + 4 * g, p.eps);
+    zero_pad();
     if (!(p.debug & (4 | 16))) dump_x(x, l + 1);
     stamp(2 + 4 * l + 3);
   }
