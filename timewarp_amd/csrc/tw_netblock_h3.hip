@@ -988,11 +988,14 @@ netblock_h3_kernel(const H3Params p) {
   // make of them.  No real token ever sees them (their score rows and columns are zero); the point is power: the launch
   // is power-limited, all-zero operand columns switch less, and the chip answers with clock (-0.6 % per pass, A/B on
   // one box, for 48 multiplications per call).  tw_debug_set_flags bit 10 (1024) turns it off.
+  unsigned padmask = 0;  // bit jt: this lane's token of tile jt is padding (one register across the layer loop)
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) padmask |= (tok_row[jt] < 0 ? 1u : 0u) << jt;
+  if (p.debug & 1024) padmask = 0;
   auto zero_pad = [&]() {
-    if (p.debug & 1024) return;
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
-      const float keep = tok_row[jt] < 0 ? 0.f : 1.f;
+      const float keep = ((padmask >> jt) & 1u) ? 0.f : 1.f;
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) x[ft][jt] = x[ft][jt] * keep;
     }
