@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 3
+#define TW_ABI_VERSION 4
 
 typedef enum {
   TW_OK = 0,
@@ -56,7 +56,8 @@ typedef struct {
   float ln_eps;         /* 1e-5 */
   int32_t cheb_order;   /* kernel variant: 0 = Gaussian basis exp(-s^2) (attention_type "kernel"/"learnable_kernel");
                            > 0 = attention_type "chebyshev_kernel": rational Chebyshev expansion of that order of s^2
-                           with per-layer coefficients (kernel_attention.py:12-66, 255-339); simple path only */
+                           with per-layer coefficients (kernel_attention.py:12-66, 255-339); all execution paths (the
+                           fused kernels take one score-fragment set per (net, layer) of the coupling layer in flight) */
   int32_t cheb_force_zero; /* force_asymptotic_zero: subtract each head's mean coefficient */
 } tw_flow_desc;
 
@@ -100,9 +101,15 @@ int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_
 #define TW_PATH_FUSED 1  /* fused f32-MFMA net-block kernel (kernel variant, n_atoms <= 64) */
 #define TW_PATH_SIMPLE 2 /* one plain HIP kernel per reference op (all variants) */
 #define TW_PATH_FUSED_H3 3 /* fused split-fp16 kernel: every fp32 product as 3 half-precision MFMAs with fp32
-                              accumulation (2^-22 operand representation); kernel variant, n_atoms <= 24;
-                              needs |activations| < 65504.  `packed` must then point at the
-                              tw_flow_pack_h3 stream.  Never chosen by TW_PATH_AUTO. */
+                              accumulation (2^-22 operand representation); kernel variant, n_atoms <= 48
+                              (48-token waves holding floor(48 / n_atoms) molecules); needs |activations| < 65504.
+                              `packed` must then point at the tw_flow_pack_h3 stream.  Never chosen by
+                              TW_PATH_AUTO. */
+
+/* 1 if `path` can run this configuration on molecules of n_atoms atoms (TW_PATH_AUTO / TW_PATH_SIMPLE: always), else 0.
+ * What a caller asks before it requests TW_PATH_FUSED / TW_PATH_FUSED_H3 by name (those fail with TW_ERR_INVALID on an
+ * unsupported shape instead of falling back). */
+int tw_flow_path_supported(const tw_flow_desc* desc, int32_t n_atoms, int32_t path);
 
 /* ConditionalSequentialFlow.forward (modules/model_wrappers/flow.py:51-103) over
  * NVPCouplingLayer.forward (modules/layers/nvp.py:22-183) with

@@ -194,7 +194,7 @@ def test_preferred_split_fp16_path_falls_back_per_call(monkeypatch):
     monkeypatch.setenv("TW_EXECUTION_PATH", "h3")
     m = H.tw_kernel_model(H.full_kernel_sd(), path=None)
     assert m.execution_path == flow.PREFER_SPLIT_FP16
-    assert m._path_for(22) == H3 and m._path_for(60) == 0
+    assert m._path_for(22) == H3 and m._path_for(30) == H3 and m._path_for(60) == 0
     d, _ = H.load("kernel_full_ad")
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
     assert m._dev_weights["h3"] is not None and m._dev_weights["f32"] is None  # the 22-atom calls ran on the h3 stream
@@ -273,12 +273,14 @@ def test_fused_dense_S1000_roundtrip():
     assert H.rel_err(yc.cpu()[rows], ryc) < TOL and H.rel_err(yv.cpu()[rows], ryv) < TOL and H.rel_err(lp.cpu()[rows], rlp) < TOL
 
 
-H3_ATOM_COUNTS = (12, 16, 22, 24, 48)  # molecule sizes for which the 48-token wave layout (NT = 3) is the chosen one
+H3_MAX_ATOMS = 48  # the split-fp16 kernel runs 48-token waves: floor(48 / V) molecules each, whatever the f32 kernels pick
 
 
 @pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25]),
                                     (12, [12, 12, 9, 12, 11, 12, 12, 5, 12]), (16, [16, 13, 16, 16, 16, 10, 16]),
-                                    (24, [24, 21, 24]), (48, [48, 40, 33])])
+                                    (24, [24, 21, 24]), (48, [48, 40, 33]), (17, [17, 17, 12, 17, 15]),
+                                    (20, [20, 18, 20]), (21, [21, 21, 21, 9, 21]), (32, [32, 26, 32]), (40, [40, 31]),
+                                    (5, [5] * 19 + [3, 4])])
 def test_fused_batched_padding_vs_oracle(V, lens):
     """Ragged batch (different conditioning state per row, padded atoms) on the fused path against
     the oracle: pins the per-row score fragments and the mask handling
@@ -295,7 +297,7 @@ def test_fused_batched_padding_vs_oracle(V, lens):
     for b, n in enumerate(lens):
         mask[b, n:] = True
     ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
-    for path in (FUSED, SIMPLE) + ((H3,) if V in H3_ATOM_COUNTS else ()):
+    for path in (FUSED, SIMPLE) + ((H3,) if V <= H3_MAX_ATOMS else ()):
         m = H.tw_kernel_model(sd, path=path)
         out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
                                y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
@@ -375,27 +377,58 @@ def test_empty_batch_and_zero_samples(path):
     assert tuple(yc.shape) == (0, 1, 22, 3) and tuple(yv.shape) == (0, 1, 22, 3) and tuple(lp.shape) == (0, 1)
 
 
-def test_split_fp16_overflow_is_reported():
-    """Weights that push activations past the fp16 range: the split-fp16 path must say so instead of returning NaN
-    log-densities silently; the exact-f32 path on the same weights stays finite and raises nothing."""
+def _overflowing_sd():
+    """Weights that push activations past the fp16 range: in_mlp output ~1e6-1e7, representable in fp32, not in fp16."""
     sd = {k: v.clone() for k, v in H.full_kernel_sd().items()}
     for k in sd:
         if k.endswith("in_mlp._layers.2.weight"):
-            sd[k] *= 1.0e7  # in_mlp output ~1e6-1e7: representable in fp32, not in fp16
+            sd[k] *= 1.0e7
+    return sd
+
+
+def test_split_fp16_overflow_demotes_to_f32():
+    """A checkpoint whose activations leave the fp16 range: the split-fp16 path neither returns NaN log-densities nor
+    raises - the call notices (tw_flow_nonfinite), the model moves to the exact-f32 kernels with one warning and the
+    call is redone there, so its result IS the f32 kernel's.  Inside `deferred_range_check()` (what the MH loops use)
+    nothing synchronises and `check_finite` is the raising form of the same flag."""
+    from timewarp_amd import _lib
+
+    sd = _overflowing_sd()
     d, _ = H.load("kernel_full_ad")
     args = dict(atom_types=d["atom_types"].cuda(), x_coords=d["x_coords"].cuda(), x_velocs=d["x_velocs"].cuda(),
                 y_coords=d["y_coords"].cuda(), y_velocs=d["y_velocs"].cuda(), adj_list=None, edge_batch_idx=None,
                 masked_elements=d["masked"].cuda())
     m32 = H.tw_kernel_model(sd, path=FUSED)
-    assert torch.isfinite(m32.log_likelihood(**args)).all()
+    ref = m32.log_likelihood(**args)
+    assert torch.isfinite(ref).all()
     m32.check_finite()
     m = H.tw_kernel_model(sd, path=H3)
-    m.log_likelihood(**args)
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        out = m.log_likelihood(**args)
+    assert m.demoted and m.execution_path == _lib.TW_PATH_AUTO and torch.equal(out, ref)
+    S = 8
+    sargs = dict(atom_types=args["atom_types"], x_coords=args["x_coords"], x_velocs=args["x_velocs"], adj_list=None,
+                 edge_batch_idx=None, masked_elements=args["masked_elements"], num_samples=S,
+                 z_coords=d["z_coords"][:S].cuda(), z_velocs=d["z_velocs"][:S].cuda())
+    m = H.tw_kernel_model(sd, path=None)  # the constructor's default: split-fp16 where it applies
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        got = m.conditional_sample_with_logp(**sargs)
+    for a, b in zip(got, m32.conditional_sample_with_logp(**sargs)):
+        assert torch.equal(a, b)
+    # deferred: the caller looks at the flag itself
+    m = H.tw_kernel_model(sd, path=H3)
+    with m.deferred_range_check():
+        m.log_likelihood(**args)
+    assert not m.demoted
     with pytest.raises(RuntimeError, match="fp16 range"):
         m.check_finite()
     m.check_finite()  # the flag was reset by the failing check
     good = H.tw_kernel_model(H.full_kernel_sd(), path=H3)
-    good.log_likelihood(**args)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        good.log_likelihood(**args)
+    assert not good.demoted
     good.check_finite()
 
 
@@ -437,6 +470,46 @@ def test_full_size_S1000_rows_vs_oracle(path):
     r_yx = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, d["atom_types"].repeat(n, 1), ryc.squeeze(1), -ryv.squeeze(1),
                              d["x_coords"].repeat(n, 1, 1), -d["x_velocs"].repeat(n, 1, 1), d["masked"].repeat(n, 1))
     assert H.rel_err(p_yx[rows], r_yx) < TOL and H.elem_rel_err(p_yx[rows], r_yx) < TOL
+
+
+def test_full_size_v60_S512_rows_vs_oracle():
+    """BASELINE config 3 at full size: 60 atoms, 512 proposals on the fused kernel (64-token waves, 1024 waves = one
+    round of the chip).  40 rows spread over the launch - the 4 rows of the first, a middle and the last workgroup of each
+    net, 28 random ones - against the oracle: proposals, velocities, log p(y|x) and the reverse-move density; and all 512
+    rows through the size-independent round trip.  2e-5: above 25 atoms the scores carry torch.cdist's matmul noise."""
+    tol = 2e-5
+    sd = H.full_kernel_sd()
+    m = H.tw_kernel_model(sd, path=FUSED)
+    d, _ = H.load("kernel_full_v60")
+    V = d["x_coords"].shape[1]
+    assert V == 60
+    S = 512
+    g = torch.Generator().manual_seed(11)
+    zc, zv = fo.draw_latents(sd, S, (1, V, 3), g)
+    at, xc, xv, mk = d["atom_types"].cuda(), d["x_coords"].cuda(), d["x_velocs"].cuda(), d["masked"].cuda()
+    yc, yv, lp = m.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None,
+                                                edge_batch_idx=None, masked_elements=mk, num_samples=S,
+                                                z_coords=zc.cuda(), z_velocs=zv.cuda())
+    ll = m.log_likelihood(atom_types=at.repeat(S, 1), x_coords=xc.repeat(S, 1, 1), x_velocs=xv.repeat(S, 1, 1),
+                          y_coords=yc.squeeze(1), y_velocs=yv.squeeze(1), adj_list=None, edge_batch_idx=None,
+                          masked_elements=mk.repeat(S, 1))
+    assert torch.isfinite(lp).all() and torch.isfinite(ll).all()
+    assert H.rel_err(ll.cpu(), lp.squeeze(1).cpu()) < tol
+    p_yx = m.log_likelihood(atom_types=at.repeat(S, 1), x_coords=yc.squeeze(1), x_velocs=-yv.squeeze(1),
+                            y_coords=xc.repeat(S, 1, 1), y_velocs=-xv.repeat(S, 1, 1), adj_list=None,
+                            edge_batch_idx=None, masked_elements=mk.repeat(S, 1)).cpu()
+    rows = list(range(0, 4)) + list(range(256, 260)) + list(range(508, 512))
+    rest = [r for r in torch.randperm(S, generator=g).tolist() if r not in rows][:28]
+    rows = torch.tensor(sorted(rows + rest))
+    assert len(rows) == 40
+    ryc, ryv, rlp = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, d["atom_types"], d["x_coords"],
+                                                    d["x_velocs"], d["masked"], zc[rows], zv[rows])
+    assert H.rel_err(yc.cpu()[rows], ryc) < tol and H.rel_err(yv.cpu()[rows], ryv) < tol
+    assert H.rel_err(lp.cpu()[rows], rlp) < tol and H.elem_rel_err(lp.cpu()[rows], rlp) < tol
+    n = len(rows)
+    r_yx = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, d["atom_types"].repeat(n, 1), ryc.squeeze(1), -ryv.squeeze(1),
+                             d["x_coords"].repeat(n, 1, 1), -d["x_velocs"].repeat(n, 1, 1), d["masked"].repeat(n, 1))
+    assert H.rel_err(p_yx[rows], r_yx) < tol and H.elem_rel_err(p_yx[rows], r_yx) < tol
 
 
 @pytest.mark.parametrize("n_coupling,pos_mod2", [(2, 0), (2, 1), (4, 1), (6, 0)])

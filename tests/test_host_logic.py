@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/timewarp_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_raw_layout_matches_library_and_oracle_template():
@@ -104,8 +104,15 @@ def test_execution_path_from_environment(monkeypatch):
     monkeypatch.setenv("TW_EXECUTION_PATH", "fp8")
     with pytest.raises(ValueError, match="TW_EXECUTION_PATH"):
         tw.model_constructor(cfg)
-    # the atom counts that select the 48-token wave layout (csrc/tw_netblock.hip::fused_geom)
-    assert [flow._wave_tiles(v) for v in (12, 16, 22, 24, 48, 7, 30, 60, 64, 65)] == [3, 3, 3, 3, 3, 4, 4, 4, 4, 0]
+    # every molecule that fits a 48-token wave runs on the split-fp16 kernel (tw_flow_path_supported), the rest on AUTO
+    monkeypatch.setenv("TW_EXECUTION_PATH", "h3")
+    assert [m._path_for(v) for v in (1, 7, 12, 17, 21, 30, 40, 48, 49, 64, 65)] == [3] * 8 + [0] * 3
+    # ... unless the score-fragment producer's LDS tile would not fit the CU: 48 atoms x 18 heads
+    many = synthetic.kernel_transformer_nvp_config()
+    many.custom_transformer_nvp_config.encoder_layer_config.lengthscales = [0.1 * (i + 1) for i in range(18)]
+    many.custom_transformer_nvp_config.encoder_layer_config.num_heads = 18
+    mm = tw.model_constructor(many)
+    assert mm._path_for(22) == 3 and mm._path_for(48) == 0
 
 
 def test_holder_modules_refuse_to_compute():

@@ -125,6 +125,107 @@ def test_full_size_mh_iterations_vs_oracle(path, kind, random_velocs, seed, num_
     assert np.abs(gs.acceptance - rs.acceptance).max() < 2e-5 * scale  # p_acc = min(1, e^-exponent)
 
 
+@pytest.mark.parametrize("path", [1, 3])
+@pytest.mark.parametrize("init_random,smoothing,seed", [(False, 0.3, 4), (True, 0.1, 5)])
+def test_adaptive_parallelism_and_random_init_through_mh_iteration(path, init_random, smoothing, seed):
+    """`adaptive_parallelism=True` (the proposal count S follows the smoothed acceptance rate, reference
+    evaluation_utils.py:575-584, 685-697) and `initialize_randomly=True` (:540-553) on the product route: full-size flow
+    on both fused kernels, AMBER energy kernel, tw_mh_iteration - whose workspace and per-S constants are re-sized
+    whenever S changes - against oracle/mh_oracle.sample_with_model on shared host noise.  S has to change at least
+    twice during the run.  From the data sample (scaled weights: accepts and rejections alternate) and from a random
+    flow sample (a 22-atom cloud far from any minimum: downhill proposals are accepted at once, S falls every iteration)."""
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.utils import evaluation_utils as eu
+
+    S_max, N = 64, 60
+    sd = H.mh_state_dict("scaled", True)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    kw = dict(accept=True, num_proposal_steps=S_max, random_velocs=True, resample_velocs=True, adaptive_parallelism=True,
+              acceptance_rate_smoothing_factor=smoothing, initialize_randomly=init_random)
+    energy = AmberPotentialEnergyTorch.alanine_dipeptide()
+    ref = mo.sample_with_model(types[None], coords[None], torch.zeros(1, 22, 3), torch.zeros(1, 22, dtype=torch.bool),
+                               mo.OracleModel(sd, H.FULL_KERNEL_SPEC), H.OracleAmberEnergy(energy.tables), masses, N,
+                               H.HostNoise(seed), **kw)
+    model = H.tw_kernel_model(sd, path=path)
+    sizes = []
+    real = eu.MetropolisHastingsChain._iteration_fused
+
+    def spy(self):
+        sizes.append(self.S)
+        return real(self)
+
+    eu.MetropolisHastingsChain._iteration_fused = spy
+    try:
+        got = eu.sample_with_model(single_state_batch("ad", types, coords), model, torch.device("cuda"), energy, masses, N,
+                                   disable_tqdm=True, noise=H.HostNoise(seed, "cuda"), **kw)
+    finally:
+        eu.MetropolisHastingsChain._iteration_fused = real
+    changes = sum(1 for a, b in zip(sizes, sizes[1:]) if a != b)
+    assert len(sizes) >= 3 and changes >= 2, sizes  # every iteration went through tw_mh_iteration; S changed
+    assert ref[2] >= 2
+    if init_random:  # the chain starts from the flow sample, not from the data sample
+        assert np.abs(got[0][0] - coords.numpy()).max() > 0.1
+    # random cloud: E_pot ~ 1.2e7 kJ/mol, where the energy callable's float32 output has a quantum of 1 kJ/mol = 0.4 kT
+    # against energy differences of a few thousand kT - a proposal whose last coordinate bit differs shows up as 1e-4
+    _assert_chain_matches_oracle(got, ref, tol=1e-5, stat_tol=5e-4 if init_random else 2e-4)
+
+
+@pytest.mark.parametrize("mode", ["sync", "deferred", "multichain"])
+def test_split_fp16_overflow_is_redone_on_the_f32_kernels(mode):
+    """A checkpoint whose activations leave the fp16 range must not abort a chain hours in: when the range flag is up
+    at a read-back, the model is demoted to the exact-f32 kernels and the iterations since the last read-back are
+    replayed there from the recorded draws.  The resulting chain is bit for bit the chain the f32 kernels produce from
+    the start with the same noise - one synchronous iteration at a time, with deferred read-backs (4 iterations parked
+    when the flag is seen), and for lock-step chains."""
+    from tests.test_flow_gpu import _overflowing_sd
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.utils.evaluation_utils import DeviceNoise, sample_with_model
+    from timewarp_amd.utils.multichain import sample_with_model_chains
+
+    sd = _overflowing_sd()
+    for k in sd:
+        if ".out_mlp._layers.2." in k:
+            sd[k] = sd[k] * 1e-4
+    sd["coords_prior_log_scale"] = torch.tensor(-7.0)
+    sd["velocs_prior_log_scale"] = torch.tensor(0.0)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    energy = AmberPotentialEnergyTorch.alanine_dipeptide()
+    dev = torch.device("cuda")
+    kw = dict(random_velocs=True, resample_velocs=True)
+    S, N = 16, 60
+
+    def run(path):
+        model = H.tw_kernel_model(sd, path=path)
+        if mode == "multichain":
+            g = torch.Generator().manual_seed(1)
+            starts = [coords + 0.0005 * torch.randn(coords.shape, generator=g) for _ in range(2)]
+            out = sample_with_model_chains([single_state_batch("ad", types, xc) for xc in starts], model, dev, energy, masses,
+                                           N, S, noises=[DeviceNoise(dev, seed=40 + c) for c in range(2)], sync_every=3, **kw)
+        else:
+            noise = H.HostNoise(8, "cuda") if mode == "sync" else None  # host noise forces one read-back per iteration
+            torch.cuda.manual_seed(123)
+            out = [sample_with_model(single_state_batch("ad", types, coords), model, dev, energy, masses, 5 * S + 3, accept=True,
+                                     num_proposal_steps=S, disable_tqdm=True, noise=noise, sync_every=4, **kw)]
+        return out, model
+
+    ref, m32 = run(1)
+    assert not m32.demoted
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        got, m = run(3)
+    assert m.demoted
+    for a, b in zip(got, ref):
+        assert a[0].shape == b[0].shape and a[2] == b[2]
+        assert np.isfinite(a[3].exponent).all()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        for f in ("acceptance_indicator", "acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin",
+                  "energies_pot_delta", "energies_kin_delta"):
+            assert np.array_equal(getattr(a[3], f), getattr(b[3], f)), f
+
+
 def test_accept_kernel_first_index_and_clipping():
     from timewarp_amd.utils.evaluation_utils import _mh_accept
 

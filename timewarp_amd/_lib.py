@@ -83,7 +83,7 @@ class MHOptions(C.Structure):
     ]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 _DESC = C.POINTER(FlowDesc)
@@ -98,6 +98,7 @@ SIGNATURES = {
     "tw_flow_pack": (C.c_int, [_DESC, _P, _P, _P]),
     "tw_flow_packed_h3_bytes": (_I64, [_DESC]),
     "tw_flow_pack_h3": (C.c_int, [_DESC, _P, _P, _P]),
+    "tw_flow_path_supported": (C.c_int, [_DESC, _I32, _I32]),
     "tw_flow_workspace_bytes": (_I64, [_DESC, _I64, _I32]),
     "tw_flow_pass": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I64, _P]),
     "tw_flow_log_likelihood": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _I64, _P]),

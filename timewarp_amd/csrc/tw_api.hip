@@ -92,6 +92,17 @@ int64_t tw_flow_packed_h3_bytes(const tw_flow_desc* desc) {
   return h3_packed_bytes(*desc);
 }
 
+int tw_flow_path_supported(const tw_flow_desc* desc, int32_t n_atoms, int32_t path) {
+  if (check_desc(desc) || n_atoms <= 0) return 0;
+  switch (path) {
+    case TW_PATH_AUTO:
+    case TW_PATH_SIMPLE: return 1;
+    case TW_PATH_FUSED: return fused_supported(*desc, n_atoms) ? 1 : 0;
+    case TW_PATH_FUSED_H3: return h3_supported(*desc, n_atoms) ? 1 : 0;
+    default: return 0;
+  }
+}
+
 int tw_flow_pack_h3(const tw_flow_desc* desc, const float* raw, void* packed_h3, void* stream) {
   int rc = check_desc(desc);
   if (rc) return rc;

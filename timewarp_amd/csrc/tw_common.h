@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/timewarp_hip.h"
 
 namespace tw {
@@ -29,6 +31,21 @@ void set_error(const char* fmt, ...);
       return TW_ERR_INVALID;         \
     }                                \
   } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON ONE DEVICE: a process that drives several GPUs
+// (tw_mh_iteration keeps per-device state for that) has to raise it on each.  One instance per kernel; bit = device ordinal.
+struct LdsLimit {
+  std::atomic<unsigned long long> done{0};
+  int ensure(const void* fn, int bytes) {
+    int dev = 0;
+    TW_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;
+    if (done.load(std::memory_order_acquire) & bit) return TW_OK;
+    TW_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(bit, std::memory_order_release);
+    return TW_OK;
+  }
+};
 
 // ------------------------------------------------------------------------------------------
 // Raw (canonical row-major) weight layout -- mirrored by timewarp_amd/weights.py
@@ -85,6 +102,8 @@ struct FusedGeom {
   int tile_mask; // bit (jt*nt+mt) set when score tile (jt,mt) can be non-zero
 };
 bool fused_geom(int n_atoms, FusedGeom* g);
+// the layout with exactly `nt` token tiles per wave (the split-fp16 kernels run 48-token waves for every n_atoms <= 48)
+bool fused_geom_nt(int n_atoms, int nt, FusedGeom* g);
 
 // launchers implemented in the .hip files ----------------------------------------------------
 // coeffs == nullptr / order == 0: Gaussian basis; else rational-Chebyshev basis with coeffs [H, order]

@@ -25,6 +25,21 @@
 
 namespace tw {
 
+bool fused_geom_nt(int V, int nt, FusedGeom* g) {
+  if (V <= 0 || nt <= 0 || V > 16 * nt) return false;
+  g->nt = nt;
+  g->mpw = (16 * nt) / V;
+  int mask = 0;
+  for (int q = 0; q < g->mpw; ++q) {
+    int t0 = (q * V) / 16, t1 = ((q + 1) * V - 1) / 16;
+    for (int a = t0; a <= t1; ++a)
+      for (int b = t0; b <= t1; ++b) mask |= 1 << (a * nt + b);
+  }
+  g->tile_mask = mask;
+  return true;
+}
+
+// the better filled of 3 and 4 token tiles per wave (what the f32 kernels run)
 bool fused_geom(int V, FusedGeom* g) {
   if (V <= 0 || V > 64) return false;
   int best_nt = 0, best_num = -1, best_den = 1;
@@ -37,16 +52,7 @@ bool fused_geom(int V, FusedGeom* g) {
     }
   }
   if (best_nt == 0) return false;
-  g->nt = best_nt;
-  g->mpw = (16 * best_nt) / V;
-  int mask = 0;
-  for (int q = 0; q < g->mpw; ++q) {
-    int t0 = (q * V) / 16, t1 = ((q + 1) * V - 1) / 16;
-    for (int a = t0; a <= t1; ++a)
-      for (int b = t0; b <= t1; ++b) mask |= 1 << (a * best_nt + b);
-  }
-  g->tile_mask = mask;
-  return true;
+  return fused_geom_nt(V, best_nt, g);
 }
 
 // ---- weight stream geometry (floats), shared by the packer and the kernel ------------------------
@@ -634,18 +640,12 @@ static int launch_netblock(const FlowArgs& a, const RawLayout& L, const FusedGeo
   const size_t shm = (size_t)4 * 16 * g.nt * XS * sizeof(float);
   int prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
-  static bool attr3 = false, attr4 = false;
+  static LdsLimit lim3, lim4;
   if (g.nt == 3) {
-    if (!attr3) {
-      TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      attr3 = true;
-    }
+    if ((prc = lim3.ensure((const void*)netblock_kernel<3>, (int)shm))) return prc;
     hipLaunchKernelGGL(netblock_kernel<3>, dim3(grid), dim3(256), shm, a.stream, p);
   } else {
-    if (!attr4) {
-      TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      attr4 = true;
-    }
+    if ((prc = lim4.ensure((const void*)netblock_kernel<4>, (int)shm))) return prc;
     hipLaunchKernelGGL(netblock_kernel<4>, dim3(grid), dim3(256), shm, a.stream, p);
   }
   TW_LAUNCH_CHECK();

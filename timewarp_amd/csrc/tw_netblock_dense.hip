@@ -512,18 +512,12 @@ static int dense_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& 
   const size_t shm = (size_t)4 * 16 * g.nt * (3 * QS + PS) * sizeof(float);
   int prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
-  static bool attr3 = false, attr4 = false;  // > 64 KiB of dynamic LDS needs the kernel's limit raised once
+  static LdsLimit lim3, lim4;  // > 64 KiB of dynamic LDS needs the kernel's limit raised, once per device
   if (g.nt == 3) {
-    if (!attr3) {
-      TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_dense_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      attr3 = true;
-    }
+    if ((prc = lim3.ensure((const void*)netblock_dense_kernel<3>, (int)shm))) return prc;
     hipLaunchKernelGGL(netblock_dense_kernel<3>, dim3(grid), dim3(256), shm, a.stream, p);
   } else {
-    if (!attr4) {
-      TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_dense_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      attr4 = true;
-    }
+    if ((prc = lim4.ensure((const void*)netblock_dense_kernel<4>, (int)shm))) return prc;
     hipLaunchKernelGGL(netblock_dense_kernel<4>, dim3(grid), dim3(256), shm, a.stream, p);
   }
   TW_LAUNCH_CHECK();

@@ -14,7 +14,8 @@
 //    1 KiB of bias/scale) shared by the 4 waves of a workgroup, in a 5-deep ring, one barrier per stage;
 //  * the mixing A_h X runs on the same 3-product scheme from an fp16 hi/lo copy of X stored
 //    TRANSPOSED in LDS ([feature][token], row stride 56 halfs -> conflict-free ds_read_b128).
-// Only NT = 3 (<= 24 atoms per molecule ... 2x22) is supported; other sizes use the f32 kernel.
+// Waves hold 48 tokens (NT = 3): every molecule of up to 48 atoms, floor(48 / V) molecules per wave; larger ones use
+// the f32 kernel.
 //
 // Toolchain note (ROCm 7.2 hipcc, gfx950): a dependent accumulation chain that alternates
 // v_mfma_f32_16x16x32_f16 (K=32) and v_mfma_f32_16x16x16_f16 (K=16) on ONE accumulator is emitted back
@@ -91,10 +92,20 @@ int64_t h3_packed_bytes(const tw_flow_desc& d) {
   return g.net_stride_bytes * 2 * d.n_coupling + (H3_RING + 1) * H3_STAGE_BYTES;  // DMA prefetch overrun slack
 }
 
+// LDS of h3_score_frag_kernel: [MV][3] coordinates, [H][MV][V] basis values / scores, [H] means, masks and token maps.
+// Up to 64 KiB launches as is; up to the CU's 160 KiB after raising the kernel's limit; h3_supported refuses the rest
+// (e.g. 48 atoms x 18 heads), so such shapes fall back to the exact-f32 kernels instead of failing at launch.
+#define H3_SF_LDS_MAX ((size_t)160 * 1024)
+static size_t h3_sf_lds_bytes(int H, int V, int mpw) {
+  const size_t MV = (size_t)mpw * V;
+  return (MV * 3 + (size_t)H * MV * V + H) * 4 + MV + 32 * H3_NT;
+}
+
 bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom fg;
   return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
-         fused_geom(n_atoms, &fg) && fg.nt == H3_NT;
+         fused_geom_nt(n_atoms, H3_NT, &fg) &&
+         h3_sf_lds_bytes(d.n_heads, n_atoms, fg.mpw) <= H3_SF_LDS_MAX;
 }
 
 // ================================================================================================
@@ -314,9 +325,23 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
 // ================================================================================================
 #define H3_SF_BYTES 3072
 
-__device__ __forceinline__ float h3_pair_dist(const float* x, int q, int m) {
-  float dx = x[3 * q] - x[3 * m], dy = x[3 * q + 1] - x[3 * m + 1], dz = x[3 * q + 2] - x[3 * m + 2];
-  return sqrtf(dx * dx + dy * dy + dz * dz);
+// use_mm: torch.cdist's matmul formulation, which the reference gets above 25 atoms (same arithmetic as
+// tw_netblock.hip::pair_dist / tw_kernels.hip::pair_distance)
+__device__ __forceinline__ float h3_pair_dist(const float* x, int q, int m, int use_mm) {
+  const float qx = x[3 * q], qy = x[3 * q + 1], qz = x[3 * q + 2];
+  const float mx = x[3 * m], my = x[3 * m + 1], mz = x[3 * m + 2];
+  if (!use_mm) {
+    float dx = qx - mx, dy = qy - my, dz = qz - mz;
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+  }
+  const float qn = qx * qx + qy * qy + qz * qz;
+  const float mn = mx * mx + my * my + mz * mz;
+  float acc = (-2.f * qx) * mx;
+  acc = fmaf(-2.f * qy, my, acc);
+  acc = fmaf(-2.f * qz, mz, acc);
+  acc = acc + qn;
+  acc = acc + mn;
+  return sqrtf(fmaxf(acc, 0.f));
 }
 
 // One workgroup per wave-block (all heads): distances and basis values once per (pair, head), rows normalised in LDS, then
@@ -327,7 +352,7 @@ __device__ __forceinline__ float h3_pair_dist(const float* x, int q, int m) {
 __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
                                      const float* __restrict__ ls, int H, int V, int mpw, int64_t n_rows,
                                      int64_t n_cond, int normalise, char* __restrict__ sfrag, ScoreBasis basis,
-                                     int64_t variant_bytes, int windowed) {
+                                     int64_t variant_bytes, int windowed, int use_mm) {
   extern __shared__ float sm[];
   const int MV = mpw * V, MVV = MV * V;
   float* xs = sm;                // [MV][3]
@@ -369,7 +394,7 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
   for (int i = t; i < MVV; i += nthr) {
     const int qa = i / V, m = i - qa * V;
     const int q = tmol[qa];
-    const float dd = h3_pair_dist(xs + q * V * 3, qa - q * V, m);
+    const float dd = h3_pair_dist(xs + q * V * 3, qa - q * V, m, use_mm);
     const bool dead = msk[q * V + m] != 0;
     for (int h = 0; h < H; ++h) {
       const float sc = dd / ls[h];
@@ -1299,7 +1324,7 @@ struct H3Ws {
 
 static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
   FusedGeom g;
-  fused_geom(V, &g);
+  fused_geom_nt(V, H3_NT, &g);
   H3Ws w;
   char* p = (char*)base;
   auto take = [&](int64_t bytes) {
@@ -1383,15 +1408,10 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.prev = prev;
   const int wgs_per_net = (p.nblocks + 3) / 4;
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
-  static bool attr = false;
-  if (!attr) {
-    TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_h3_kernel<H3_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)H3_LDS_BYTES));
-    TW_HIP_CHECK(hipFuncSetAttribute((const void*)netblock_h3_kernel<H3_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)H3_LDS_BYTES));
-    attr = true;
-  }
+  static LdsLimit lim_asm, lim_cpp;
   int prc;
+  if ((prc = lim_asm.ensure((const void*)netblock_h3_kernel<H3_NT, true>, (int)H3_LDS_BYTES))) return prc;
+  if ((prc = lim_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false>, (int)H3_LDS_BYTES))) return prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
   if (g_debug_flags & 8)
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
@@ -1414,12 +1434,16 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
   const unsigned nv = (unsigned)basis.n_variants;
   const float* ls = a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0);
   const int win = h3_windowed(fg, V) ? 1 : 0;
-  const int MV = fg.mpw * V;
-  size_t shm = (size_t)(MV * 3 + d.n_heads * MV * V + d.n_heads) * 4 + (size_t)MV + 32 * H3_NT;
-  TW_REQUIRE(shm <= 64 * 1024, "score fragments: %zu bytes of LDS for %d atoms x %d heads", shm, V, d.n_heads);
+  const size_t shm = h3_sf_lds_bytes(d.n_heads, V, fg.mpw);
+  TW_REQUIRE(shm <= H3_SF_LDS_MAX, "score fragments: %zu bytes of LDS for %d atoms x %d heads", shm, V, d.n_heads);
+  if (shm > (size_t)64 * 1024) {
+    static LdsLimit lim;
+    int lrc;
+    if ((lrc = lim.ensure((const void*)h3_score_frag_kernel, (int)H3_SF_LDS_MAX))) return lrc;
+  }
   // a lone block (all proposals share x) is latency-bound: spread it over 16 waves
   hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks, 1, nv), dim3(shared ? 1024 : 512), shm, a.stream, a.x_coords,
-                     a.masked, ls, d.n_heads, V, fg.mpw, a.n_rows, a.n_cond, d.normalise, w.sfrag, basis, vb, win);
+                     a.masked, ls, d.n_heads, V, fg.mpw, a.n_rows, a.n_cond, d.normalise, w.sfrag, basis, vb, win, V > 25 ? 1 : 0);
   TW_LAUNCH_CHECK();
   *variant_bytes = vb;
   return TW_OK;
@@ -1428,7 +1452,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
 int flow_pass_h3(const FlowArgs& a) {
   const tw_flow_desc& d = *a.desc;
   FusedGeom fg;
-  TW_REQUIRE(fused_geom(a.n_atoms, &fg) && fg.nt == H3_NT, "split-fp16 path: unsupported atom count %d", a.n_atoms);
+  TW_REQUIRE(fused_geom_nt(a.n_atoms, H3_NT, &fg), "split-fp16 path: unsupported atom count %d", a.n_atoms);
   const RawLayout L = raw_layout(d);
   const H3Ws w = h3_ws(d, a.n_rows, a.n_atoms, a.ws);
   if (w.bytes > a.ws_bytes) {
@@ -1492,7 +1516,7 @@ int flow_pass_h3(const FlowArgs& a) {
 int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, float* dump) {
   const tw_flow_desc& d = *a.desc;
   FusedGeom fg;
-  TW_REQUIRE(fused_geom(a.n_atoms, &fg) && fg.nt == H3_NT, "split-fp16 path: unsupported atom count %d", a.n_atoms);
+  TW_REQUIRE(fused_geom_nt(a.n_atoms, H3_NT, &fg), "split-fp16 path: unsupported atom count %d", a.n_atoms);
   const RawLayout L = raw_layout(d);
   const H3Ws w = h3_ws(d, a.n_rows, a.n_atoms, a.ws);
   if (w.bytes > a.ws_bytes) {

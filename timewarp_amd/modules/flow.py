@@ -7,6 +7,7 @@ carry no autograd graph (training is outside this build's scope, SURVEY.md secti
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from typing import Optional, Tuple
 
 import torch
@@ -18,24 +19,9 @@ from ..weights import FlowDims, pack_raw, strip_module_prefix
 from .density_model_base import ConditionalDensityModel
 
 
-def _wave_tiles(n_atoms: int) -> int:
-    """Token tiles per wave the fused kernels pick for molecules of `n_atoms` (csrc/tw_netblock.hip::fused_geom): the
-    better filled of 3 and 4 tiles of 16 tokens; 0 if a molecule does not fit in 64 tokens."""
-    best, best_num, best_den = 0, -1, 1
-    if n_atoms <= 0 or n_atoms > 64:
-        return 0
-    for nt in (3, 4):
-        mpw = (16 * nt) // n_atoms
-        if mpw == 0:
-            continue
-        num, den = mpw * n_atoms, 16 * nt
-        if best == 0 or num * best_den > best_num * den:
-            best, best_num, best_den = nt, num, den
-    return best
-
-
-# execution_path value of ConditionalFlowDensityModel only (not a C-ABI path): the split-fp16 kernel where it applies
-# (kernel attention with the Gaussian basis, d_model 128, molecules that select the 48-token wave layout), else AUTO.
+# execution_path value of ConditionalFlowDensityModel only (not a C-ABI path): the split-fp16 kernel wherever the
+# library supports it for the call's molecule size (tw_flow_path_supported: kernel attention, d_model 128, up to 48
+# atoms), else AUTO.
 PREFER_SPLIT_FP16 = -1
 
 
@@ -53,7 +39,9 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         self._dev_weights = None  # {"device", "raw", "f32", "h3"}
         self._workspace = None
         self._dirty = True
-        self.used_split_fp16 = False  # some call ran on the split-fp16 kernel (see check_finite)
+        self.used_split_fp16 = False  # some call ran on the split-fp16 kernel since the last demotion (range guard)
+        self.demoted = False          # the range guard has moved this model to the exact-f32 kernels
+        self._defer_range_check = 0
 
     # ------------------------------------------------------------------ weight cache
     def _apply(self, fn, *a, **k):
@@ -73,21 +61,68 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         path = self.execution_path
         if path == PREFER_SPLIT_FP16:
             desc = self.dims.to_desc()
-            ok = _lib.load().tw_flow_packed_h3_bytes(C.byref(desc)) > 0 and _wave_tiles(n_atoms) == 3
+            ok = _lib.load().tw_flow_path_supported(C.byref(desc), int(n_atoms), _lib.TW_PATH_FUSED_H3) == 1
             path = _lib.TW_PATH_FUSED_H3 if ok else _lib.TW_PATH_AUTO
         if path == _lib.TW_PATH_FUSED_H3:
             self.used_split_fp16 = True
         return path
 
-    def check_finite(self, device=None) -> None:
-        """Raise if the split-fp16 kernel produced non-finite coupling parameters since the last check (its operands are
-        fp16: activations beyond +-65504 overflow).  Synchronises; the MH loop calls it where it reads results back."""
+    # ------------------------------------------------------------------ split-fp16 range guard
+    # The split-fp16 kernel holds its operands in fp16: a checkpoint whose activations leave +-65504 makes it return
+    # non-finite scale / shift values where the exact-f32 kernels would not.  The coupling step raises a sticky device
+    # flag (tw_flow_nonfinite).  Policy: never sample through it and never abort a chain over it - the model is DEMOTED
+    # to the exact-f32 kernels (execution_path = TW_PATH_AUTO, one warning) and the affected work is redone there: a
+    # public call re-runs itself, the MH loops replay the iterations since their last read-back from the recorded
+    # draws (utils/evaluation_utils.py).  `check_finite` is the raising form for callers that drive the C ABI themselves.
+    def split_fp16_overflowed(self, device=None) -> bool:
+        """True if a split-fp16 launch produced non-finite coupling parameters since the last call (reads and clears
+        the device flag; synchronises).  Always False for a model that never ran on that kernel."""
         if not self.used_split_fp16:
-            return
+            return False
         flag = C.c_int32(0)
         with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
             _lib.check(_lib.load().tw_flow_nonfinite(1, C.byref(flag)), "tw_flow_nonfinite")
-        if flag.value:
+        return bool(flag.value)
+
+    def demote_to_f32(self) -> None:
+        """Leave the split-fp16 kernel for good: every later call runs on the exact-f32 kernels."""
+        if self.execution_path in (PREFER_SPLIT_FP16, _lib.TW_PATH_FUSED_H3):
+            warnings.warn(
+                "timewarp_amd: this checkpoint's activations leave the fp16 range (+-65504) on the split-fp16 kernel; "
+                "switching this model to the exact-f32 kernels and redoing the affected calls there "
+                "(TW_EXECUTION_PATH=f32 selects them from the start).", RuntimeWarning, stacklevel=3)
+            self.execution_path = _lib.TW_PATH_AUTO
+        self.used_split_fp16 = False
+        self.demoted = True
+
+    class _Deferred:
+        def __init__(self, model):
+            self.model = model
+
+        def __enter__(self):
+            self.model._defer_range_check += 1
+
+        def __exit__(self, *exc):
+            self.model._defer_range_check -= 1
+
+    def deferred_range_check(self):
+        """Context manager: public calls inside it do not synchronise to look at the range flag - the caller does
+        (split_fp16_overflowed) where it reads results back, and redoes the work itself (the MH loops)."""
+        return self._Deferred(self)
+
+    def _guarded(self, device, n_atoms: int, run):
+        """run(path) on the call's execution path; on a split-fp16 range overflow, demote and run again."""
+        path = self._path_for(n_atoms)
+        out = run(path)
+        if path == _lib.TW_PATH_FUSED_H3 and self._defer_range_check == 0 and self.split_fp16_overflowed(device):
+            self.demote_to_f32()
+            out = run(self._path_for(n_atoms))
+        return out
+
+    def check_finite(self, device=None) -> None:
+        """Raise if the split-fp16 kernel produced non-finite coupling parameters since the last check.  For callers of
+        the C ABI / `deferred_range_check` users that prefer an error over the demotion above.  Synchronises."""
+        if self.split_fp16_overflowed(device):
             raise RuntimeError(
                 "timewarp_amd: the split-fp16 execution path returned non-finite scale/shift values - this checkpoint's "
                 "activations leave the fp16 range.  Use the exact-f32 kernels (TW_EXECUTION_PATH=f32, or "
@@ -160,18 +195,21 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         at, mk, xc, xv, yc, yv = self._prep(atom_types, masked_elements, x_coords, x_velocs, y_coords, y_velocs)
         dev = xc.device
         B, V = xc.shape[0], xc.shape[1]
-        path = self._path_for(V)
-        raw, packed = self._weights(dev, path)
         ws = self._ws(dev, B, V)
         out = torch.empty(B, dtype=torch.float32, device=dev)
         lib = _lib.load()
         desc = self.dims.to_desc()
-        with torch.cuda.device(dev):
-            _lib.check(lib.tw_flow_log_likelihood(
-                C.byref(desc), raw.data_ptr(), _lib.ptr(packed), at.data_ptr(), xc.data_ptr(), xv.data_ptr(),
-                yc.data_ptr(), yv.data_ptr(), mk.data_ptr(), out.data_ptr(), B, V, path,
-                ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "tw_flow_log_likelihood")
-        return out
+
+        def run(path):
+            raw, packed = self._weights(dev, path)
+            with torch.cuda.device(dev):
+                _lib.check(lib.tw_flow_log_likelihood(
+                    C.byref(desc), raw.data_ptr(), _lib.ptr(packed), at.data_ptr(), xc.data_ptr(), xv.data_ptr(),
+                    yc.data_ptr(), yv.data_ptr(), mk.data_ptr(), out.data_ptr(), B, V, path,
+                    ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "tw_flow_log_likelihood")
+            return out
+
+        return self._guarded(dev, V, run)
 
     def conditional_sample(self, atom_types, x_coords, x_velocs, adj_list, edge_batch_idx, masked_elements,
                            num_samples: int, logger=None) -> Tuple[Tensor, Tensor]:
@@ -207,22 +245,25 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         zv = _lib.require_gpu_tensor(z_velocs.to(dev), torch.float32, "z_velocs")
         if tuple(zc.shape) != (S, B, V, 3) or tuple(zv.shape) != (S, B, V, 3):
             raise ValueError("z_coords / z_velocs must have shape [num_samples, B, V, 3]")
-        path = self._path_for(V)
-        raw, packed = self._weights(dev, path)
         ws = self._ws(dev, S * B, V)
         y_c = torch.empty((S, B, V, 3), dtype=torch.float32, device=dev)
         y_v = torch.empty((S, B, V, 3), dtype=torch.float32, device=dev)
         logp = torch.empty((S, B), dtype=torch.float32, device=dev)
         lib = _lib.load()
         desc = self.dims.to_desc()
-        with torch.cuda.device(dev):
-            entry = lib.tw_flow_sample_with_logp_multi if allow_multi else lib.tw_flow_sample_with_logp
-            _lib.check(entry(
-                C.byref(desc), raw.data_ptr(), _lib.ptr(packed), at.data_ptr(), xc.data_ptr(), xv.data_ptr(),
-                mk.data_ptr(), zc.data_ptr(), zv.data_ptr(), y_c.data_ptr(), y_v.data_ptr(), logp.data_ptr(),
-                S, B, V, path, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
-                "tw_flow_sample_with_logp")
-        return y_c, y_v, logp
+
+        def run(path):
+            raw, packed = self._weights(dev, path)
+            with torch.cuda.device(dev):
+                entry = lib.tw_flow_sample_with_logp_multi if allow_multi else lib.tw_flow_sample_with_logp
+                _lib.check(entry(
+                    C.byref(desc), raw.data_ptr(), _lib.ptr(packed), at.data_ptr(), xc.data_ptr(), xv.data_ptr(),
+                    mk.data_ptr(), zc.data_ptr(), zv.data_ptr(), y_c.data_ptr(), y_v.data_ptr(), logp.data_ptr(),
+                    S, B, V, path, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
+                    "tw_flow_sample_with_logp")
+            return y_c, y_v, logp
+
+        return self._guarded(dev, V, run)
 
     # ------------------------------------------------------------------ inspection (tests)
     @torch.no_grad()

@@ -146,6 +146,94 @@ class DeviceNoise:
         return q.to(torch.float32).to(self.device)
 
 
+class RecordingNoise:
+    """A noise source that keeps what it hands out, in draw order, so that the iterations since the last read-back can
+    be redone on other kernels with the SAME random numbers (the split-fp16 range guard, modules/flow.py).  Wraps any
+    object with the DeviceNoise protocol; `mark()` forgets everything drawn so far."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.log = []
+
+    def mark(self):
+        self.log = []
+
+    def randn_like(self, t):
+        r = self.inner.randn_like(t)
+        self.log.append(r)
+        return r
+
+    def latents(self, S, B, V, scale_c, scale_v):
+        zc, zv = self.inner.latents(S, B, V, scale_c, scale_v)
+        self.log.append((zc, zv))
+        return zc, zv
+
+    def latents_into(self, zc, zv, S, std_c, std_v, scale_c=None, scale_v=None):
+        if hasattr(self.inner, "latents_into"):
+            self.inner.latents_into(zc, zv, S, std_c, std_v)
+        else:  # replayed / host-drawn noise
+            a, b = self.inner.latents(S, 1, zc.shape[1], scale_c, scale_v)
+            zc[:S].copy_(a.reshape(S, -1, 3))
+            zv[:S].copy_(b.reshape(S, -1, 3))
+        self.log.append((zc[:S].clone(), zv[:S].clone()))  # the caller's buffers become the proposals
+
+    def uniform(self, S):
+        u = self.inner.uniform(S)
+        self.log.append(u)
+        return u
+
+    def rotation(self):
+        q = self.inner.rotation()
+        self.log.append(q)
+        return q
+
+
+class ReplayDraws:
+    """Hands a RecordingNoise log back, draw by draw."""
+
+    def __init__(self, log):
+        self.log = list(log)
+
+    def _pop(self):
+        return self.log.pop(0)
+
+    def randn_like(self, t):
+        return self._pop()
+
+    def latents(self, S, B, V, scale_c, scale_v):
+        zc, zv = self._pop()
+        return zc.reshape(S, B, V, 3), zv.reshape(S, B, V, 3)
+
+    def latents_into(self, zc, zv, S, std_c, std_v, scale_c=None, scale_v=None):
+        a, b = self._pop()
+        zc[:S].copy_(a.reshape(S, -1, 3))
+        zv[:S].copy_(b.reshape(S, -1, 3))
+
+    def uniform(self, S):
+        return self._pop()
+
+    def rotation(self):
+        return self._pop()
+
+
+def _range_guarded(model) -> bool:
+    """The model may run on the split-fp16 kernel (and so needs the range guard's recorded draws)."""
+    return hasattr(model, "split_fp16_overflowed") and not getattr(model, "demoted", False) and \
+        getattr(model, "execution_path", 0) in (-1, _lib.TW_PATH_FUSED_H3)
+
+
+class _no_defer:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _deferred(model):
+    return model.deferred_range_check() if hasattr(model, "deferred_range_check") else _no_defer()
+
+
 def _mh_accept(energy, p_xy, p_yx, u, y_c=None, y_v=None, x_c=None, x_v=None):
     """tw_mh_accept.  With y_c/y_v [S,V,3] and x_c/x_v [1,V,3] the kernel also moves the chain state on the device
     (x <- y[k] if any proposal was accepted), so the host does not have to look at the result before it queues the
@@ -199,6 +287,12 @@ class MetropolisHastingsChain:
         self.device = device = torch.device(device)
         self.model, self.energy_fn = model, energy_fn
         self.noise = noise or DeviceNoise(device)
+        # split-fp16 range guard: keep the draws since the last read-back so that those iterations can be redone on the
+        # exact-f32 kernels if the model's activations turn out to leave the fp16 range (_redo_on_f32)
+        self._guard = _range_guarded(model)
+        self._unwrapped_noise = self.noise
+        if self._guard:
+            self.noise = RecordingNoise(self.noise)
         f32 = torch.float32
         self.accept, self.random_velocs, self.resample_velocs, self.rotate = accept, random_velocs, resample_velocs, rotate
         self.adaptive, self.smoothing = adaptive_parallelism, acceptance_rate_smoothing_factor
@@ -292,7 +386,9 @@ class MetropolisHastingsChain:
         at, mk, _, _, sc, sv = self._constants(S)
         zc = torch.empty((S + 1, V, 3), dtype=torch.float32, device=dev)
         zv = torch.empty((S + 1, V, 3), dtype=torch.float32, device=dev)
-        if hasattr(noise, "latents_into"):
+        if isinstance(noise, (RecordingNoise, ReplayDraws)):
+            noise.latents_into(zc, zv, S, fc["std_c"], fc["std_v"], sc, sv)
+        elif hasattr(noise, "latents_into"):
             noise.latents_into(zc, zv, S, fc["std_c"], fc["std_v"])
         else:  # replayed / host-drawn noise
             a, b = noise.latents(S, 1, V, sc, sv)
@@ -398,59 +494,98 @@ class MetropolisHastingsChain:
         for name, t in per_proposal:
             self.rec[name].append(t[: k + 1])
 
+    # ---- one iteration = _compute (device work, no host read) + bookkeeping once the accept result is on the host
+    def _compute(self):
+        """Everything of one MH iteration up to and including the accept kernel, which also writes the next chain state
+        (x <- y[k] if a proposal was accepted) into buffers of its own.  No host synchronisation.  Returns
+        (res, x_coords, x_velocs, new_c, new_v, acc, per_proposal); `res` int32[4] = {first accepted index or S-1, any}."""
+        S, device = self.S, self.device
+        if self._fused:
+            x_coords, x_velocs, _, _, new_c, new_v, acc, res, per_proposal = self._iteration_fused()
+            return res, x_coords, x_velocs, new_c, new_v, acc, per_proposal
+        with _deferred(self.model):  # the range flag is looked at where the accept result is read back
+            x_coords, x_velocs, y_c, y_v, energy, p_xy, p_yx, e_pot_y, e_kin_y, e_pot, e_kin = self._evaluate()
+        u = self.noise.uniform(S).to(device, torch.float32).contiguous()
+        new_c, new_v = x_coords.clone(), x_velocs.clone()  # becomes y[k] inside the kernel if a proposal is accepted
+        ex, p_acc, acc, res = _mh_accept(energy, p_xy, p_yx, u, y_c.contiguous(), y_v.contiguous(), new_c, new_v)
+        return res, x_coords, x_velocs, new_c, new_v, acc, (
+            ("acc", p_acc), ("pxy", p_xy), ("pyx", p_yx), ("exp", ex), ("epot", e_pot_y), ("ekin", e_kin_y),
+            ("dpot", e_pot), ("dkin", e_kin))
+
+    def _overflowed(self) -> bool:
+        """Split-fp16 range guard, asked right after a host read-back (which has synchronised)."""
+        return self._guard and self.model.split_fp16_overflowed(self.device)
+
+    def _redo_on_f32(self, start_c, start_v, n_iterations: int):
+        """The model's activations left the fp16 range somewhere in the last `n_iterations` iterations: demote the model
+        to the exact-f32 kernels and run those iterations again from their starting state with the recorded draws.
+        Returns their `_compute` tuples; the chain continues on the f32 kernels with its ordinary noise source."""
+        self.model.demote_to_f32()
+        recorder = self.noise
+        self.noise = ReplayDraws(recorder.log)
+        self.x_coords, self.x_velocs = start_c, start_v
+        self.proposals -= n_iterations * self.S
+        outs = []
+        try:
+            for _ in range(n_iterations):
+                out = self._compute()
+                outs.append(out)
+                self.x_coords, self.x_velocs = out[3], out[4]
+        finally:
+            self.noise = recorder.inner
+            self._guard = False
+        return outs
+
     def step(self, remaining: Optional[int] = None) -> int:
         """One MH iteration; returns the number of chain states emitted (k + 1).  `remaining`
         = num_samples - i applies the reference's clip `k = min(k, N - i)` (:680)."""
         self.flush()
         S, device = self.S, self.device
-        if self._fused:
-            x_coords, x_velocs, y_c, y_v, new_c, new_v, acc, res, per_proposal = self._iteration_fused()
-            k_true, any_acc = (int(v) for v in res[:2].tolist())  # the one host sync of the iteration
-            if hasattr(self.model, "check_finite"):
-                self.model.check_finite(device)
+        start_c, start_v = self.x_coords, self.x_velocs
+        if self._guard:
+            self.noise.mark()
+        if self.accept:
+            out = self._compute()
+            k_true, any_acc = (int(v) for v in out[0][:2].tolist())  # the one host sync of the iteration
+            if self._overflowed():
+                out, = self._redo_on_f32(start_c, start_v, 1)
+                k_true, any_acc = (int(v) for v in out[0][:2].tolist())
+            _, x_coords, x_velocs, new_c, new_v, acc, per_proposal = out
             self.accepted += int(any_acc)
             k = k_true if remaining is None else min(k_true, remaining)  # NB: N - i, not N - i - 1
             moved = bool(any_acc) and k == k_true
             self.p_bar = self.smoothing * (1 - (not any_acc)) + (1 - self.smoothing) ** k * self.p_bar
             if self.adaptive:
                 self.S = compute_num_proposal_steps(self.p_bar, max_num_proposal_steps=self.s_max)
-            if not moved:
+            if not moved:  # nothing accepted, or the clip cut the emitted rows short of the accepted proposal
                 new_c, new_v = x_coords.clone(), x_velocs.clone()
             self._emit(k, x_coords, x_velocs, new_c, new_v, acc, per_proposal)
-            self.x_coords, self.x_velocs = new_c, new_v
+            self.x_coords, self.x_velocs = new_c.contiguous(), new_v.contiguous()
             return k + 1
-        x_coords, x_velocs, y_c, y_v, energy, p_xy, p_yx, e_pot_y, e_kin_y, e_pot, e_kin = self._evaluate()
-
-        if self.accept:
-            u = self.noise.uniform(S).to(device, torch.float32).contiguous()
-            ex, p_acc, acc, res = _mh_accept(energy, p_xy, p_yx, u)
-            k_true, any_acc = (int(v) for v in res[:2].tolist())  # the one host sync of the iteration
-            if hasattr(self.model, "check_finite"):
-                self.model.check_finite(device)
-            if any_acc:
-                self.accepted += 1
-            k = k_true if remaining is None else min(k_true, remaining)  # NB: N - i, not N - i - 1
-            moved = bool(any_acc) and k == k_true
-            self.p_bar = self.smoothing * (1 - (not any_acc)) + (1 - self.smoothing) ** k * self.p_bar
-            if self.adaptive:
-                self.S = compute_num_proposal_steps(self.p_bar, max_num_proposal_steps=self.s_max)
-        elif S == 1:
-            ex = energy + p_xy - p_yx
-            p_acc = torch.clamp(torch.exp(-ex), max=1.0)
-            k, moved = 0, True
-            self.accepted += 1
-            acc = torch.ones(1, dtype=torch.bool, device=device)
-        else:
+        if S != 1:
             raise ValueError("Number of proposals has to be one if everything is accepted!")
-
-        # emitted rows: k copies of the old state, then row k (the accepted proposal, if the chain moved)
-        new_c = (y_c[k: k + 1] if moved else x_coords).clone()
-        new_v = (y_v[k: k + 1] if moved else x_velocs).clone()
-        self._emit(k, x_coords, x_velocs, new_c, new_v, acc,
+        with _deferred(self.model):
+            ev = self._evaluate()
+        if self._overflowed():  # synchronises
+            self.model.demote_to_f32()
+            self.noise, self._guard = ReplayDraws(self.noise.log), False
+            self.x_coords, self.x_velocs = start_c, start_v
+            self.proposals -= S
+            try:
+                ev = self._evaluate()
+            finally:
+                self.noise = self._unwrapped_noise
+        x_coords, x_velocs, y_c, y_v, energy, p_xy, p_yx, e_pot_y, e_kin_y, e_pot, e_kin = ev
+        ex = energy + p_xy - p_yx
+        p_acc = torch.clamp(torch.exp(-ex), max=1.0)
+        self.accepted += 1
+        acc = torch.ones(1, dtype=torch.bool, device=device)
+        new_c, new_v = y_c[0:1].clone(), y_v[0:1].clone()
+        self._emit(0, x_coords, x_velocs, new_c, new_v, acc,
                    (("acc", p_acc), ("pxy", p_xy), ("pyx", p_yx), ("exp", ex), ("epot", e_pot_y), ("ekin", e_kin_y),
                     ("dpot", e_pot), ("dkin", e_kin)))
         self.x_coords, self.x_velocs = new_c.contiguous(), new_v.contiguous()
-        return k + 1
+        return 1
 
     # ---- deferred bookkeeping: the accept kernel moves the state on the device, the host reads the results later
     def can_defer(self) -> bool:
@@ -458,24 +593,17 @@ class MetropolisHastingsChain:
         return self.accept and not self.adaptive and not self.rotate and not (self.omm_current or self.omm_proposal)
 
     def step_deferred(self) -> None:
-        """One MH iteration without a host synchronisation: `tw_mh_accept` writes x <- y[k] itself and the
+        """One MH iteration without a host synchronisation: the accept kernel writes x <- y[k] itself and the
         iteration's device tensors are parked until `flush()`.  Identical results to `step()` as long as the
         clip `k = min(k, N - i)` cannot bind (the caller keeps N - i > S)."""
         assert self.can_defer()
-        S, device = self.S, self.device
-        if self._fused:
-            x_coords, x_velocs, _, _, new_c, new_v, acc, res, per_proposal = self._iteration_fused()
-            self._pending.append((res, x_coords, x_velocs, new_c, new_v, acc, per_proposal))
-            self.x_coords, self.x_velocs = new_c, new_v
-            return
-        x_coords, x_velocs, y_c, y_v, energy, p_xy, p_yx, e_pot_y, e_kin_y, e_pot, e_kin = self._evaluate()
-        u = self.noise.uniform(S).to(device, torch.float32).contiguous()
-        new_c, new_v = x_coords.clone(), x_velocs.clone()  # becomes y[k] inside the kernel if a proposal is accepted
-        ex, p_acc, acc, res = _mh_accept(energy, p_xy, p_yx, u, y_c.contiguous(), y_v.contiguous(), new_c, new_v)
-        self._pending.append((res, x_coords, x_velocs, new_c, new_v, acc,
-                              (("acc", p_acc), ("pxy", p_xy), ("pyx", p_yx), ("exp", ex), ("epot", e_pot_y),
-                               ("ekin", e_kin_y), ("dpot", e_pot), ("dkin", e_kin))))
-        self.x_coords, self.x_velocs = new_c, new_v
+        if not self._pending:
+            self._pending_start = (self.x_coords, self.x_velocs)
+            if self._guard:
+                self.noise.mark()
+        out = self._compute()
+        self._pending.append(out)
+        self.x_coords, self.x_velocs = out[3], out[4]
 
     def flush(self) -> int:
         """Read back the parked iterations (one D2H copy for all of them) and do their bookkeeping; returns the
@@ -483,8 +611,9 @@ class MetropolisHastingsChain:
         if not self._pending:
             return 0
         results = torch.stack([p[0] for p in self._pending]).cpu().tolist()
-        if hasattr(self.model, "check_finite"):
-            self.model.check_finite(self.device)  # split-fp16 overflow guard; the copy above already synchronised
+        if self._overflowed():  # split-fp16 range guard; the copy above already synchronised
+            self._pending = self._redo_on_f32(*self._pending_start, len(self._pending))
+            results = torch.stack([p[0] for p in self._pending]).cpu().tolist()
         emitted = 0
         for (k_true, any_acc, _, _), (_, old_c, old_v, new_c, new_v, acc, per_proposal) in zip(results, self._pending):
             self.accepted += int(any_acc)

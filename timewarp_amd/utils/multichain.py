@@ -15,7 +15,8 @@ from typing import List, Optional, Sequence
 import torch
 
 from .. import _lib
-from .evaluation_utils import ChainStats, DeviceNoise, check_symmetry_change, compute_kinetic_energy
+from .evaluation_utils import (ChainStats, DeviceNoise, RecordingNoise, ReplayDraws, _deferred, _range_guarded,
+                               check_symmetry_change, compute_kinetic_energy)
 
 
 def _accept_chains(energy, p_xy, p_yx, u, y_c, y_v, x_c, x_v):
@@ -49,6 +50,10 @@ class MetropolisHastingsChains:
         self.model, self.energy_fn, self.S = model, energy_fn, int(num_proposal_steps)
         self.noises = list(noises) if noises is not None else [DeviceNoise(device) for _ in range(C)]
         assert len(self.noises) == C
+        # split-fp16 range guard (modules/flow.py): keep the draws since the last read-back, see flush()
+        self._guard = _range_guarded(model)
+        if self._guard:
+            self.noises = [RecordingNoise(n) for n in self.noises]
         f32 = torch.float32
         self.random_velocs, self.resample_velocs = random_velocs, resample_velocs
         self.x_coords = torch.cat([b.atom_coords.to(device, f32) for b in batches], dim=0).contiguous()
@@ -74,6 +79,11 @@ class MetropolisHastingsChains:
         """One iteration of every chain, no host synchronisation."""
         S, C, V, dev = self.S, self.C, self.V, self.device
         model, kbT = self.model, self.kbT
+        if not self._pending:
+            self._pending_start = (self.x_coords, self.x_velocs)
+            if self._guard:
+                for n in self.noises:
+                    n.mark()
         x_c, x_v = self.x_coords, self.x_velocs
         if self.random_velocs and self.resample_velocs:
             x_v = torch.cat([n.randn_like(x_v[c:c + 1]) for c, n in enumerate(self.noises)], dim=0)
@@ -82,9 +92,10 @@ class MetropolisHastingsChains:
         lat = [n.latents(S, 1, V, sc, sv) for n in self.noises]
         z_c = torch.cat([l[0] for l in lat], dim=1).contiguous()
         z_v = torch.cat([l[1] for l in lat], dim=1).contiguous()
-        y_c, y_v, p_xy = model.conditional_sample_with_logp(
-            atom_types=self.atom_types, x_coords=x_c, x_velocs=x_v, adj_list=None, edge_batch_idx=None,
-            masked_elements=self.masked, num_samples=S, z_coords=z_c, z_velocs=z_v, allow_multi=True)
+        with _deferred(model):  # the range flag is looked at in flush(), where the results are read back
+            y_c, y_v, p_xy = model.conditional_sample_with_logp(
+                atom_types=self.atom_types, x_coords=x_c, x_velocs=x_v, adj_list=None, edge_batch_idx=None,
+                masked_elements=self.masked, num_samples=S, z_coords=z_c, z_velocs=z_v, allow_multi=True)
         rows_c, rows_v = y_c.reshape(S * C, V, 3), y_v.reshape(S * C, V, 3)
         e_pot_x = (self.energy_fn(x_c) / kbT).reshape(C)
         e_kin_x = compute_kinetic_energy(x_v, self.masses, random_velocs=self.random_velocs, kbT=kbT)
@@ -97,10 +108,11 @@ class MetropolisHastingsChains:
         e_pot = e_pot_y - e_pot_x[None]
         energy = (e_pot + e_kin).contiguous()
         sgn = self.sgn
-        p_yx = model.log_likelihood(
-            atom_types=self.atom_types.repeat(S, 1), y_coords=x_c.repeat(S, 1, 1), y_velocs=(sgn * x_v).repeat(S, 1, 1),
-            x_coords=rows_c, x_velocs=sgn * rows_v, adj_list=None, edge_batch_idx=None,
-            masked_elements=self.masked.repeat(S, 1)).reshape(S, C).contiguous()
+        with _deferred(model):
+            p_yx = model.log_likelihood(
+                atom_types=self.atom_types.repeat(S, 1), y_coords=x_c.repeat(S, 1, 1), y_velocs=(sgn * x_v).repeat(S, 1, 1),
+                x_coords=rows_c, x_velocs=sgn * rows_v, adj_list=None, edge_batch_idx=None,
+                masked_elements=self.masked.repeat(S, 1)).reshape(S, C).contiguous()
         p_xy = p_xy.reshape(S, C).contiguous()
         self.proposals += S * C
         u = torch.stack([n.uniform(S).to(dev, torch.float32) for n in self.noises], dim=1).contiguous()
@@ -117,6 +129,21 @@ class MetropolisHastingsChains:
         if not self._pending:
             return
         results = torch.stack([p[0] for p in self._pending]).cpu().tolist()  # [iterations][C][4]
+        if self._guard and self.model.split_fp16_overflowed(self.device):
+            # the model's activations left the fp16 range: the parked iterations again, on the exact-f32 kernels, from
+            # their starting states and with the recorded draws; the chains then continue there
+            self.model.demote_to_f32()
+            n_iter, recorders = len(self._pending), self.noises
+            self.noises = [ReplayDraws(r.log) for r in recorders]
+            self.x_coords, self.x_velocs = self._pending_start
+            self.proposals -= n_iter * self.S * self.C
+            self._pending, self._guard = [], False
+            try:
+                for _ in range(n_iter):
+                    self.step_deferred()
+            finally:
+                self.noises = [r.inner for r in recorders]
+            results = torch.stack([p[0] for p in self._pending]).cpu().tolist()
         V = self.V
         for per_chain, (_, old_c, old_v, new_c, new_v, acc, per_proposal) in zip(results, self._pending):
             for c, (k_true, any_acc, _, _) in enumerate(per_chain):
