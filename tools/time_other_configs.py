@@ -27,6 +27,20 @@ ms = timed(lambda: m.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_
                                                   masked_elements=mk, num_samples=S))
 flop = 16 * V * (4478976 + 4608 * V) * S
 print(f"cfg3 kernel flow V={V} S={S} fused-f32: {ms:.2f} ms per reverse pass, {flop / ms / 1e9:.1f} TFLOP/s algorithmic")
+# molecule sizes between the bench case and cfg 3: the split-fp16 kernel takes every molecule that fits a 48-token wave
+for V, S in ((17, 1000), (30, 1000), (40, 1000), (48, 1000)):
+    at = torch.randint(0, 5, (1, V), generator=g).cuda()
+    xc = (torch.randn(1, V, 3, generator=g) * 0.35).cuda()
+    xv = (torch.randn(1, V, 3, generator=g) * 0.5).cuda()
+    mk = torch.zeros(1, V, dtype=torch.bool).cuda()
+    flop = 16 * V * (4478976 + 4608 * V) * S
+    res = {}
+    for path, name in ((1, "fused-f32"), (3, "split-fp16")):
+        mm = H.tw_kernel_model(H.full_kernel_sd(), path=path)
+        res[path] = timed(lambda: mm.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None,
+                                                                  edge_batch_idx=None, masked_elements=mk, num_samples=S))
+        print(f"kernel flow V={V} S={S} {name}: {res[path]:.2f} ms per reverse pass, {flop / res[path] / 1e9:.1f} TFLOP/s algorithmic")
+    print(f"  V={V}: split-fp16 / f32 speed-up {res[1] / res[3]:.2f}x")
 # cfg 4
 V, S = 22, 1000
 at = torch.randint(0, 5, (1, V), generator=g).cuda()
