@@ -29,6 +29,7 @@ class _State:
 class _Context:
     def __init__(self):
         self.pos = self.vel = None
+        self.allow_thermal = False
 
     def setPositions(self, p):
         self.pos = np.array(p, dtype=np.float64)
@@ -39,15 +40,27 @@ class _Context:
         assert self.vel.shape == self.pos.shape
 
     def setVelocitiesToTemperature(self, temperature):
-        raise AssertionError("the MH loop always passes velocities")
+        # sample_on_single_conditional (evaluation_utils.py:376-378) asks for thermal velocities when it treats the
+        # conditioning velocities as resampled; the MH loop never does.  A fixed, temperature-scaled pattern.
+        if not self.allow_thermal:
+            raise AssertionError("the MH loop always passes velocities")
+        i = np.arange(self.pos.size, dtype=np.float64).reshape(self.pos.shape)
+        self.vel = 0.05 * np.sqrt(float(temperature) / 300.0) * np.cos(0.7 * i + 0.3)
 
     def getState(self, getPositions=False, getVelocities=False, **kwargs):
         return _State(self.pos, self.vel)
 
 
+class _Integrator:
+    def getTemperature(self):
+        return 310.0
+
+
 class FakeSimulation:
-    def __init__(self, dt=0.004, pull=6.0, damping=0.95):
+    def __init__(self, dt=0.004, pull=6.0, damping=0.95, allow_thermal=False):
         self.context = _Context()
+        self.context.allow_thermal = allow_thermal
+        self.integrator = _Integrator()
         self.dt, self.pull, self.damping = dt, pull, damping
         self.calls = 0
 

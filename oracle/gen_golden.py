@@ -392,6 +392,66 @@ def gen_sob_golden(model):
     np.savez_compressed(os.path.join(OUT, "sob_tiny.npz"), **out)
 
 
+SOSC_NAMES = ("y_coords_model", "y_velocs_model", "traj_coords", "traj_velocs", "traj_coords_conditioning")
+
+
+def gen_sosc_golden(model):
+    """Run the REAL sample_on_single_conditional (utils/evaluation_utils.py:356-413) on CPU with the tiny kernel model and
+    oracle/fake_sim.FakeSimulation as the OpenMM Simulation; store inputs, recorded noise and the five outputs."""
+    from timewarp.utils import evaluation_utils as eu
+    from timewarp.dataloader import DenseMolDynBatch
+    from oracle.fake_sim import FakeSimulation
+
+    V = 7
+    g = torch.Generator().manual_seed(191)
+    at = torch.randint(0, 5, (1, V), generator=g)
+    x0 = torch.randn(1, V, 3, generator=g) * 0.3
+    v0 = torch.randn(1, V, 3, generator=g)
+    batch = DenseMolDynBatch(
+        names=["tiny"], atom_types=at, adj_list=torch.zeros((0, 2), dtype=torch.int64),
+        edge_batch_idx=torch.zeros((0,), dtype=torch.int64), atom_coords=x0, atom_velocs=v0,
+        atom_forces=torch.zeros_like(x0), atom_coord_targets=x0, atom_veloc_targets=v0,
+        atom_force_targets=torch.zeros_like(x0), masked_elements=torch.zeros(1, V, dtype=torch.bool))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        model.coords_prior_log_scale.fill_(-3.0)
+        model.velocs_prior_log_scale.fill_(0.0)
+    out = dict(atom_types=at.numpy(), x0=x0.numpy(), v0=v0.numpy(), num_samples=np.array(5), step_width=np.array(3))
+    out.update(np_sd(model.state_dict()))
+    for tag, rv in (("fixedv", False), ("randv", True)):
+        rec = {"normal": [], "randn_like": []}
+        orig_rsample = torch.distributions.Normal.rsample
+        orig_randn_like = torch.randn_like
+
+        def rsample(self, shape=torch.Size()):
+            r = orig_rsample(self, shape)
+            rec["normal"].append(r.detach().numpy().copy().reshape(-1))
+            return r
+
+        def randn_like(t, **k):
+            r = orig_randn_like(t, **k)
+            rec["randn_like"].append(r.numpy().copy().reshape(-1))
+            return r
+
+        torch.distributions.Normal.rsample = rsample
+        torch.randn_like = randn_like
+        try:
+            torch.manual_seed(555)
+            res = eu.sample_on_single_conditional(batch, model, 5, FakeSimulation(allow_thermal=True), 3, rv, torch.device("cpu"))
+        finally:
+            torch.distributions.Normal.rsample = orig_rsample
+            torch.randn_like = orig_randn_like
+        for n, a in zip(SOSC_NAMES, res):
+            out[f"{tag}/{n}"] = np.asarray(a)
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros((0,), np.float32)
+        out[f"{tag}/noise_normal"] = cat(rec["normal"])
+        out[f"{tag}/noise_normal_sizes"] = np.array([len(a) for a in rec["normal"]])
+        out[f"{tag}/noise_randn_like"] = cat(rec["randn_like"])
+        print("sosc", tag, {n: np.asarray(a).shape for n, a in zip(SOSC_NAMES, res)})
+    model.load_state_dict(sd)
+    np.savez_compressed(os.path.join(OUT, "sosc_tiny.npz"), **out)
+
+
 def gen_learnable_golden():
     """Tiny learnable-lengthscale model (attention_type "learnable_kernel") with DIFFERENT
     log_lengthscales in every attention layer: pins which layer's lengthscales a flow call uses."""
@@ -702,6 +762,7 @@ def main():
         "mh": lambda: gen_mh_goldens(tiny_kernel_model()),  # (7) the MH loop itself, driven with a synthetic energy
         "mh-omm": lambda: gen_mh_goldens(tiny_kernel_model(), MH_OPENMM_SCENARIOS, "mh_tiny_openmm.npz"),  # (7b) with OpenMM steps
         "sob": lambda: gen_sob_golden(tiny_kernel_model()),
+        "sosc": lambda: gen_sosc_golden(tiny_kernel_model()),  # sample_on_single_conditional with the fake Simulation
         "learnable": gen_learnable_golden,
         "cheb": gen_chebyshev_golden,
         "cheb-full": gen_chebyshev_full_golden,

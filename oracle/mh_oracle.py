@@ -265,3 +265,31 @@ def sample_on_batches(batches, model: OracleModel, energy, masses, noise, random
     sq = lambda a: a.squeeze(1)
     return (sq(arr["y_c"]), sq(arr["y_v"]), sq(arr["t_c"]), sq(arr["t_v"]), sq(arr["c_c"]), sq(arr["c_v"]),
             arr["p_yx"], arr["p_xy"], arr["p_yx_tr"], arr["p_xy_tr"], arr["acc"])
+
+
+def sample_on_single_conditional(atom_types, x_coords, x_velocs, masked, model: OracleModel, num_samples, sim, step_width,
+                                 random_velocs, noise):
+    """Restatement of utils/evaluation_utils.py:356-413: `num_samples` model samples and `num_samples` OpenMM segments of
+    `step_width` steps, all from the one conditioning state.  Returns the reference's five arrays."""
+    positions, velocities, yc_all, yv_all = [], [], [], []
+    sc, sv = model.scales()
+    B, V = x_coords.shape[0], x_coords.shape[1]
+    for _ in range(num_samples):
+        sim.context.setPositions(x_coords.numpy().squeeze(0))                      # :375
+        if random_velocs:
+            sim.context.setVelocitiesToTemperature(sim.integrator.getTemperature())  # :377
+            sim.context.getState(getPositions=True, getVelocities=True)
+            xv = noise.randn_like(x_velocs)                                         # :380
+        else:
+            xv = x_velocs
+            sim.context.setVelocities(xv.numpy().squeeze(0))                        # :383
+        zc, zv = noise.latents(1, B, V, sc, sv)
+        y_c, y_v, _ = model.conditional_sample_with_logp(atom_types, x_coords, xv.float(), masked, zc, zv)  # :385-393
+        sim.step(step_width)                                                        # :395
+        state = sim.context.getState(getPositions=True, getVelocities=True)
+        positions.append(state.getPositions(asNumpy=True)._value)
+        velocities.append(state.getVelocities(asNumpy=True)._value)
+        yc_all.append(y_c.numpy())
+        yv_all.append(y_v.numpy())
+    return (np.array(yc_all).squeeze(1).squeeze(1), np.array(yv_all).squeeze(1).squeeze(1), np.array(positions),
+            np.array(velocities), np.array(x_coords.numpy()))

@@ -46,6 +46,47 @@ def test_gather_trajectories_two_ranks_gloo():
     assert results == {0: True, 1: True}
 
 
+def _ragged_worker(rank, world, port, q, lengths):
+    """Unequal trajectory lengths including ranks that hold nothing, then a round in which NO rank holds anything."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from timewarp_amd import distributed
+
+    distributed.init_from_env("gloo")
+
+    def traj(r):
+        g = torch.Generator().manual_seed(distributed.chain_seed(7, r))
+        return torch.randn(lengths[r], 22, 3, generator=g), torch.rand(lengths[r], generator=g)
+
+    coords, acc = traj(rank)
+    all_c, all_s = distributed.gather_trajectories(coords, {"acceptance": acc})
+    ok = len(all_c) == world
+    for r in range(world):
+        rc, ra = traj(r)
+        ok = ok and all_c[r].shape == (lengths[r], 22, 3) and torch.equal(all_c[r], rc) and torch.equal(all_s["acceptance"][r], ra)
+    none_c, none_s = distributed.gather_trajectories(torch.zeros(0, 22, 3), {"acceptance": torch.zeros(0)})
+    ok = ok and len(none_c) == world and all(c.shape == (0, 22, 3) for c in none_c)
+    ok = ok and all(a.shape == (0,) for a in none_s["acceptance"])
+    total = distributed.all_reduce_counters([float(lengths[rank])], "cpu")
+    ok = ok and total == [float(sum(lengths))]
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gather_trajectories_four_ranks_ragged_and_empty_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    lengths = [6, 0, 11, 1]
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 4, port, q, lengths)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {0: True, 1: True, 2: True, 3: True}
+
+
 def _bench_worker(rank, world, port, q):
     """bench.py's own N > 1 leg (end_timed_region + whole_job_rates) under gloo on CPU tensors: rank r 'ran' for
     0.1 (r + 1) s and accepted 10 (r + 1) samples."""
@@ -65,6 +106,9 @@ def _bench_worker(rank, world, port, q):
     value, prop_s, states_s, accepted = bench.whole_job_rates(10.0 * (rank + 1), 1000.0, 50.0, elapsed, "cpu")
     ok = len(gathered) == world and all(g.shape == (3 + r, 22, 3) and bool((g == r).all()) for r, g in enumerate(gathered))
     ok = ok and 0.1 * world <= elapsed < 0.1 * world + 5.0          # max over ranks, same on every rank
+    per_rank = bench.end_timed_region.per_rank_seconds               # what the JSON line reports as per_rank_ms
+    ok = ok and len(per_rank) == world and abs(max(per_rank) - elapsed) < 1e-12
+    ok = ok and all(per_rank[r] >= 0.1 * (r + 1) for r in range(world)) and per_rank[0] < per_rank[-1] + 1.0
     ok = ok and accepted == sum(10.0 * (r + 1) for r in range(world))  # whole-job sum
     ok = ok and abs(value - accepted / elapsed) < 1e-9 and abs(prop_s - 1000.0 * world / elapsed) < 1e-6
     q.put((rank, bool(ok), elapsed))

@@ -324,6 +324,29 @@ def test_sample_on_batches_replays_reference(tag, random_velocs):
     check_sob(z, tag, res)
 
 
+@pytest.mark.parametrize("tag,random_velocs", [("fixedv", False), ("randv", True)])
+def test_sample_on_single_conditional_replays_reference(tag, random_velocs):
+    """Product sample_on_single_conditional (reference evaluation_utils.py:356-413) against vectors recorded from the
+    reference's own function, oracle/fake_sim.FakeSimulation standing in for the OpenMM Simulation on both sides."""
+    from oracle.fake_sim import FakeSimulation
+    from tests.test_mh_oracle import check_sosc, load_sosc, sob_replay
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.utils.evaluation_utils import sample_on_single_conditional
+
+    z, sd = load_sosc()
+    model = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2,
+                              lengthscales=(0.1, 0.5, 1.2), path=2)
+    batch = single_state_batch("tiny", torch.from_numpy(z["atom_types"]), torch.from_numpy(z["x0"]), torch.from_numpy(z["v0"]))
+    sim = FakeSimulation(allow_thermal=True)
+    res = sample_on_single_conditional(batch, model, int(z["num_samples"]), sim, int(z["step_width"]), random_velocs,
+                                       torch.device("cuda"), noise=sob_replay(z, tag, device="cuda"))
+    check_sosc(z, tag, res)
+    assert sim.calls == int(z["num_samples"])
+    # without injected noise: device draws, same shapes
+    res2 = sample_on_single_conditional(batch, model, 2, FakeSimulation(allow_thermal=True), 1, random_velocs, torch.device("cuda"))
+    assert res2[0].shape == (2, 7, 3) and res2[2].shape == (2, 7, 3) and np.isfinite(res2[0]).all()
+
+
 def test_sample_trajectory_writes_and_resumes(tmp_path):
     """Two segments of a real MH chain on the GPU, then a resumed third one."""
     from timewarp_amd.dataloader import single_state_batch

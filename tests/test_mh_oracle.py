@@ -133,3 +133,36 @@ def test_sample_on_batches_oracle_replays_reference(tag, random_velocs):
     energy = mo.SyntheticEnergy(torch.from_numpy(z["x_ref"]).clone())
     res = mo.sample_on_batches(batches, model, energy, torch.from_numpy(z["masses"]), sob_replay(z, tag), random_velocs)
     check_sob(z, tag, res)
+
+
+# ------------------------------------------------------------------ sample_on_single_conditional (evaluation_utils.py:356-413)
+SOSC_NAMES = ("y_coords_model", "y_velocs_model", "traj_coords", "traj_velocs", "traj_coords_conditioning")
+
+
+def load_sosc():
+    import os
+    z = np.load(os.path.join(H.GOLDEN, "sosc_tiny.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    return z, sd
+
+
+def check_sosc(z, tag, res, tol=2e-5):
+    for n, a in zip(SOSC_NAMES, res):
+        b = z[f"{tag}/{n}"]
+        assert np.asarray(a).shape == b.shape, n
+        assert H.rel_err(np.asarray(a, np.float64), b.astype(np.float64)) < tol, n
+
+
+@pytest.mark.parametrize("tag,random_velocs", [("fixedv", False), ("randv", True)])
+def test_sample_on_single_conditional_oracle_replays_reference(tag, random_velocs):
+    """Recorded from the reference's own function with oracle/fake_sim.FakeSimulation (thermal velocities allowed) as
+    the Simulation: five model samples and five 3-step segments from one conditioning state."""
+    from oracle.fake_sim import FakeSimulation
+
+    z, sd = load_sosc()
+    x0, v0 = torch.from_numpy(z["x0"]), torch.from_numpy(z["v0"])
+    res = mo.sample_on_single_conditional(
+        torch.from_numpy(z["atom_types"]), x0, v0, torch.zeros(1, x0.shape[1], dtype=torch.bool),
+        mo.OracleModel(sd, H.TINY_KERNEL_SPEC), int(z["num_samples"]), FakeSimulation(allow_thermal=True), int(z["step_width"]),
+        random_velocs, sob_replay(z, tag))
+    check_sosc(z, tag, res)

@@ -144,7 +144,19 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         return _LIB
     path = _build.LIB_PATH
     if build_if_missing and (_build.hipcc_path() is not None or not os.path.exists(path)):
-        _build.build_library()
+        try:
+            _build.build_library()
+        except (OSError, RuntimeError) as e:
+            # a read-only install, or a compiler that is present but unusable: an existing library that passes the ABI
+            # check below is still the HIP path - load it and say so, instead of failing on the rebuild
+            if not os.path.exists(path):
+                raise
+            import warnings
+            warnings.warn(f"timewarp_amd: could not rebuild {path} ({e}); loading the existing library", RuntimeWarning)
+    elif os.path.exists(path) and _build.stale():
+        import warnings
+        warnings.warn(f"timewarp_amd: {path} was not built from the csrc/ sources next to it (content hash differs or is "
+                      "missing) and there is no hipcc here to rebuild it; loading it as it is", RuntimeWarning)
     if not os.path.exists(path):
         raise RuntimeError(
             f"timewarp_amd: {path} is missing. Build it with `python -m timewarp_amd.build` "

@@ -48,6 +48,10 @@ def gather_trajectories(coords: torch.Tensor, extras: Dict[str, torch.Tensor] = 
     n_max = max(lens)
     V = coords.shape[1]
     width = V * 3 + len(extras)
+    if n_max == 0:  # nobody has anything: no payload collective (a zero-byte all-gather is backend-dependent)
+        empty = coords.new_zeros((0, V, 3), dtype=torch.float32)
+        return [empty.clone() for _ in range(world)], {k: [coords.new_zeros((0,), dtype=torch.float32) for _ in range(world)]
+                                                       for k in extras}
     payload = torch.zeros((n_max, width), dtype=torch.float32, device=dev)
     payload[: coords.shape[0], : V * 3] = coords.reshape(coords.shape[0], V * 3)
     for j, (k, v) in enumerate(extras.items()):

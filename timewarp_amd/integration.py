@@ -12,7 +12,7 @@ After `install()` the reference's scripts run unchanged:
   * our model classes are registered as virtual subclasses of the reference's ABCs, so
     `isinstance(model, ConditionalDensityModel)` and the `functools.singledispatch` in
     utils/sampling_utils.py:17-68 and utils/loss_utils.py:91-141 resolve them;
-  * `sample_with_model`, `sample_on_batches` and `OpenmmPotentialEnergyTorch` are replaced by the HIP-backed versions
+  * `sample_with_model`, `sample_on_batches`, `sample_on_single_conditional` and `OpenmmPotentialEnergyTorch` are replaced by the HIP-backed versions
     (the energy one reads its tables out of the `openmm.System` it is given).
 """
 from __future__ import annotations
@@ -69,8 +69,10 @@ def install(replace_energy: bool = True, replace_mh_loop: bool = True) -> dict:
         if eu is not None:
             eu.sample_with_model = _eu.sample_with_model
             eu.sample_on_batches = _eu.sample_on_batches
+            eu.sample_on_single_conditional = _eu.sample_on_single_conditional
             patched["timewarp.utils.evaluation_utils.sample_with_model"] = True
             patched["timewarp.utils.evaluation_utils.sample_on_batches"] = True
+            patched["timewarp.utils.evaluation_utils.sample_on_single_conditional"] = True
     if replace_energy:
         for name in ("timewarp.utils.openmm.openmm_bridge", "timewarp.utils.evaluation_utils"):
             mod = _try_import(name)

@@ -758,3 +758,47 @@ def sample_on_batches(batches, model, device, openmm_potential_energy_torch, dat
     sq = lambda a: a.squeeze(1)  # the reference assumes one conditioning state per batch here (:315-320)
     return (sq(arr["y_c"]), sq(arr["y_v"]), sq(arr["t_c"]), sq(arr["t_v"]), sq(arr["c_c"]), sq(arr["c_v"]),
             arr["p_yx"], arr["p_xy"], arr["p_yx_tr"], arr["p_xy_tr"], arr["acc"])
+
+
+def sample_on_single_conditional(batch, model, num_samples, sim, step_width, random_velocs, device, noise=None):
+    """`num_samples` model samples y ~ p(.|x) and `num_samples` OpenMM segments of `step_width` steps, all from the single
+    conditioning state in `batch` (reference utils/evaluation_utils.py:356-413, called from evaluate.py:576).  Same
+    arguments and the same five return arrays; `sim` is the caller's `openmm.app.Simulation` (its context / integrator /
+    step calls, in the reference's order - nothing here imports OpenMM).  `noise` (extension) injects the random draws,
+    as in `sample_with_model`; without it the velocity draw and the latents come from the device generator."""
+    device = torch.device(device)
+    positions, velocities, y_coords_model, y_velocs_model = [], [], [], []
+    at = batch.atom_types.to(device)
+    x_c = batch.atom_coords.to(device, torch.float32).contiguous()
+    mk = batch.masked_elements.to(device)
+    adj = batch.adj_list.to(device) if batch.adj_list is not None else None
+    ebi = batch.edge_batch_idx.to(device) if batch.edge_batch_idx is not None else None
+    B, V = x_c.shape[0], x_c.shape[1]
+    with torch.no_grad():
+        for _ in tqdm(range(num_samples)):
+            sim.context.setPositions(batch.atom_coords.numpy().squeeze(0))
+            if random_velocs:
+                sim.context.setVelocitiesToTemperature(sim.integrator.getTemperature())
+                sim.context.getState(getPositions=True, getVelocities=True)
+                x_v = (noise.randn_like(batch.atom_velocs) if noise is not None
+                       else torch.randn(batch.atom_velocs.shape, device=device)).to(device, torch.float32)
+            else:
+                sim.context.setVelocities(batch.atom_velocs.numpy().squeeze(0))
+                x_v = batch.atom_velocs.to(device, torch.float32)
+            kw = dict(atom_types=at, x_coords=x_c, x_velocs=x_v.contiguous(), adj_list=adj, edge_batch_idx=ebi,
+                      masked_elements=mk, num_samples=1)
+            if noise is not None:
+                sc = torch.exp(model.coords_prior_log_scale.detach()).to(device)
+                sv = torch.exp(model.velocs_prior_log_scale.detach()).to(device)
+                z_c, z_v = noise.latents(1, B, V, sc, sv)
+                y_c, y_v, _ = model.conditional_sample_with_logp(z_coords=z_c, z_velocs=z_v, **kw)
+            else:
+                y_c, y_v = model.conditional_sample(**kw)
+            sim.step(step_width)
+            state = sim.context.getState(getPositions=True, getVelocities=True)
+            positions.append(state.getPositions(asNumpy=True)._value)
+            velocities.append(state.getVelocities(asNumpy=True)._value)
+            y_coords_model.append(y_c.detach().cpu().numpy())
+            y_velocs_model.append(y_v.detach().cpu().numpy())
+    return (np.array(y_coords_model).squeeze(1).squeeze(1), np.array(y_velocs_model).squeeze(1).squeeze(1),
+            np.array(positions), np.array(velocities), np.array(batch.atom_coords.numpy()))
