@@ -127,7 +127,13 @@ def run_model_case(model, d, prefix="", device="cuda"):
             atom_types=g("atom_types").repeat(S, 1), x_coords=gy, x_velocs=-gv,
             y_coords=g("x_coords").repeat(S, 1, 1), y_velocs=-g("x_velocs").repeat(S, 1, 1), adj_list=None,
             edge_batch_idx=None, masked_elements=g("masked").repeat(S, 1)).cpu()
+    assert_not_demoted(model)
     return out
+
+
+def assert_not_demoted(model):
+    """A parity test of the split-fp16 kernels must not pass because the range guard moved the model to the f32 kernels."""
+    assert not getattr(model, "demoted", False), "the split-fp16 range guard fired: this test ran on the f32 kernels"
 
 
 def assert_case_close(out, d, prefix="", tol=1e-5):

@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
 SIMPLE, FUSED, H3 = 2, 1, 3
+H3_MAX_ATOMS = 48  # the split-fp16 kernels run 48-token waves: floor(48 / V) molecules each, whatever the f32 kernels pick
 
 
 def test_library_sees_gpu():
@@ -98,6 +99,7 @@ def test_full_learnable_lengthscales_fused(path):
     ll_ref = fo.log_likelihood(sd, spec, at, xc, xv, d["y_coords"], d["y_velocs"], mk)
     ll = m.log_likelihood(atom_types=at.cuda(), x_coords=xc.cuda(), x_velocs=xv.cuda(), y_coords=d["y_coords"].cuda(),
                           y_velocs=d["y_velocs"].cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda())
+    H.assert_not_demoted(m)
     assert H.rel_err(ll.cpu(), ll_ref) < 1e-5
 
 
@@ -163,6 +165,7 @@ def test_netblock_stages_vs_reference_trace(path):
     S = 2
     acts, out = m.debug_netblock(7, 0, d["atom_types"].cuda(), xc.cuda(), d["x_velocs"].cuda(), d["masked"].cuda(),
                                  d["z_coords"][:S, 0].cuda(), path)
+    H.assert_not_demoted(m)
     names = ["tr_in_mlp", "tr_enc0", "tr_enc1", "tr_enc2"]
     for i, n in enumerate(names):
         e = H.rel_err(acts[i].cpu(), d[n])
@@ -202,13 +205,14 @@ def test_preferred_split_fp16_path_falls_back_per_call(monkeypatch):
     H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5)
     assert m._dev_weights["f32"] is not None
     dense = H.tw_dense_model(H.full_dense_sd(), path=None)
-    assert dense._path_for(22) == 0
+    assert dense._path_for(22) == H3 and dense._path_for(60) == 0  # the dense flow has a split-fp16 kernel of its own
 
 
-@pytest.mark.parametrize("path", [SIMPLE, FUSED, 0])
+@pytest.mark.parametrize("path", [SIMPLE, FUSED, 0, H3])
 def test_full_dense_ad_golden(path):
     """transformer_nvp (dense softmax attention, BASELINE config 4) on the per-op path, on the fused f32-MFMA dense
-    net-block kernel, and through TW_PATH_AUTO (which must pick the fused kernel for this configuration)."""
+    net-block kernel, through TW_PATH_AUTO (which must pick the fused kernel for this configuration) and on the
+    split-fp16 dense kernel (q k^T and P.V on the half-precision matrix pipe as well)."""
     d, _ = H.load("dense_full_ad")
     m = H.tw_dense_model(H.full_dense_sd(), path=path)
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
@@ -216,7 +220,7 @@ def test_full_dense_ad_golden(path):
         assert m._dev_weights["f32"] is not None  # the fused kernel's weight stream was built and used
 
 
-@pytest.mark.parametrize("path", [SIMPLE, FUSED])
+@pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])
 def test_full_dense_padded_golden(path):
     """Padded batch (22 / 17 / 20 real atoms) through nn.MultiheadAttention's src_key_padding_mask
     (transformer_block.py:57-68): reference vectors."""
@@ -225,6 +229,7 @@ def test_full_dense_padded_golden(path):
     out = m.log_likelihood(atom_types=d["atom_types"].cuda(), x_coords=d["x_coords"].cuda(), x_velocs=d["x_velocs"].cuda(),
                            y_coords=d["y_coords"].cuda(), y_velocs=d["y_velocs"].cuda(), adj_list=None, edge_batch_idx=None,
                            masked_elements=d["masked"].cuda()).cpu()
+    H.assert_not_demoted(m)
     assert H.rel_err(out, d["loglik"]) < TOL
 
 
@@ -245,17 +250,19 @@ def test_fused_dense_batched_padding_vs_oracle(V, lens):
     for b, n in enumerate(lens):
         mask[b, n:] = True
     ref = fo.log_likelihood(sd, H.FULL_DENSE_SPEC, at, x_c, x_v, y_c, y_v, mask)
-    for path in (FUSED, SIMPLE):
+    for path in (FUSED, SIMPLE) + ((H3,) if V <= H3_MAX_ATOMS else ()):
         m = H.tw_dense_model(sd, path=path)
         out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
                                y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
+        H.assert_not_demoted(m)
         assert H.rel_err(out, ref) < TOL, (path, H.rel_err(out, ref))
 
 
-def test_fused_dense_S1000_roundtrip():
+@pytest.mark.parametrize("path", [FUSED, H3])
+def test_fused_dense_S1000_roundtrip(path):
     """BASELINE config 4 size (1000 proposals): reverse pass then forward pass recover log p; 16 spread rows vs oracle."""
     sd = H.full_dense_sd()
-    m = H.tw_dense_model(sd, path=FUSED)
+    m = H.tw_dense_model(sd, path=path)
     d, _ = H.load("dense_full_ad")
     S = 1000
     g = torch.Generator().manual_seed(6)
@@ -266,14 +273,12 @@ def test_fused_dense_S1000_roundtrip():
     ll = m.log_likelihood(atom_types=at.repeat(S, 1), x_coords=xc.repeat(S, 1, 1), x_velocs=xv.repeat(S, 1, 1),
                           y_coords=yc.squeeze(1), y_velocs=yv.squeeze(1), adj_list=None, edge_batch_idx=None,
                           masked_elements=mk.repeat(S, 1))
+    H.assert_not_demoted(m)
     assert H.rel_err(ll.cpu(), lp.squeeze(1).cpu()) < TOL
     rows = torch.tensor([0, 1, 7, 8, 250, 251, 499, 500, 503, 504, 750, 901, 992, 997, 998, 999])
     ryc, ryv, rlp = fo.conditional_sample_with_logp(sd, H.FULL_DENSE_SPEC, d["atom_types"], d["x_coords"], d["x_velocs"],
                                                     d["masked"], zc[rows], zv[rows])
     assert H.rel_err(yc.cpu()[rows], ryc) < TOL and H.rel_err(yv.cpu()[rows], ryv) < TOL and H.rel_err(lp.cpu()[rows], rlp) < TOL
-
-
-H3_MAX_ATOMS = 48  # the split-fp16 kernel runs 48-token waves: floor(48 / V) molecules each, whatever the f32 kernels pick
 
 
 @pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25]),
@@ -301,6 +306,7 @@ def test_fused_batched_padding_vs_oracle(V, lens):
         m = H.tw_kernel_model(sd, path=path)
         out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
                                y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
+        H.assert_not_demoted(m)
         assert H.rel_err(out, ref) < TOL, (path, H.rel_err(out, ref))
         # batched == per item (tests/test_batching.py)
         one = m.log_likelihood(atom_types=at[1:2].cuda(), x_coords=x_c[1:2].cuda(), x_velocs=x_v[1:2].cuda(),
@@ -453,6 +459,7 @@ def test_full_size_S1000_rows_vs_oracle(path):
                           y_coords=yc.squeeze(1), y_velocs=yv.squeeze(1), adj_list=None, edge_batch_idx=None,
                           masked_elements=mk.repeat(S, 1))
     assert torch.isfinite(lp).all() and torch.isfinite(ll).all()
+    H.assert_not_demoted(m)
     assert H.rel_err(ll.cpu(), lp.squeeze(1).cpu()) < TOL
     # reverse-move density of every row (velocities negated, evaluation_utils.py:648-657)
     p_yx = m.log_likelihood(atom_types=at.repeat(S, 1), x_coords=yc.squeeze(1), x_velocs=-yv.squeeze(1),
@@ -538,6 +545,7 @@ def test_other_layer_counts_and_velocity_first_flows(n_coupling, pos_mod2):
                               y_coords=xc.repeat(9, 1, 1).cuda(), y_velocs=xv.repeat(9, 1, 1).cuda(), adj_list=None,
                               edge_batch_idx=None, masked_elements=mk.repeat(9, 1).cuda())
         assert H.rel_err(ll.cpu(), ll_ref) < TOL, (path, H.rel_err(ll.cpu(), ll_ref))
+        H.assert_not_demoted(m)
 
 
 def test_fused_equals_simple_large_batch():
@@ -553,6 +561,7 @@ def test_fused_equals_simple_large_batch():
             atom_types=d["atom_types"].cuda(), x_coords=d["x_coords"].cuda(), x_velocs=d["x_velocs"].cuda(),
             adj_list=None, edge_batch_idx=None, masked_elements=d["masked"].cuda(), num_samples=S,
             z_coords=zc.cuda(), z_velocs=zv.cuda()))
+        H.assert_not_demoted(m)
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert H.rel_err(a.cpu(), b.cpu()) < TOL

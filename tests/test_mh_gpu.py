@@ -110,6 +110,7 @@ def test_full_size_mh_iterations_vs_oracle(path, kind, random_velocs, seed, num_
     model = H.tw_kernel_model(sd, path=path)
     got = sample_with_model(single_state_batch("ad", types, coords, v0[0]), model, torch.device("cuda"), energy, masses,
                             num_samples, disable_tqdm=True, noise=H.HostNoise(seed, "cuda"), **kw)
+    H.assert_not_demoted(model)
     (rc, rv, racc, rs), (gc, gv, gacc, gs) = ref, got
     assert racc >= 1 and (racc >= 2 or rc.shape[0] > S + 1)  # accepted proposals, and more than one iteration
     assert gc.shape == rc.shape and gacc == racc
@@ -162,6 +163,7 @@ def test_adaptive_parallelism_and_random_init_through_mh_iteration(path, init_ra
                                    disable_tqdm=True, noise=H.HostNoise(seed, "cuda"), **kw)
     finally:
         eu.MetropolisHastingsChain._iteration_fused = real
+    H.assert_not_demoted(model)
     changes = sum(1 for a, b in zip(sizes, sizes[1:]) if a != b)
     assert len(sizes) >= 3 and changes >= 2, sizes  # every iteration went through tw_mh_iteration; S changed
     assert ref[2] >= 2
@@ -523,6 +525,7 @@ def test_multichain_full_size_vs_oracle():
     multi = sample_with_model_chains([single_state_batch("ad", types, xc) for xc in starts], model, torch.device("cuda"),
                                      energy, masses, N, S, noises=[H.HostNoise(40 + c, "cuda") for c in range(2)],
                                      sync_every=2, **kw)
+    H.assert_not_demoted(model)
     for got, ref in zip(multi, refs):
         _assert_chain_matches_oracle(got, ref, tol=1e-5, stat_tol=2e-4)
 

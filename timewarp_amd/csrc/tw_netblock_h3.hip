@@ -50,6 +50,15 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3_SIDE_LDS_OFFSET (H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS)
 #define H3_SIDE_LDS_BYTES 3072        // three 1 KiB LDS-DMA chunks (the block is 2624 B; the rest of LDS up to 160 KiB)
 #define H3_LDS_BYTES (H3_SIDE_LDS_OFFSET + H3_SIDE_LDS_BYTES)
+// dense softmax variant (transformer_nvp): no transposed X tile, so the wave-private block only carries the 24 register
+// images the asm sections exchange operands through; the layer's side block grows by the in_proj / out_proj biases
+#define H3D_WAVE_LDS (24 * 1024)
+#define H3D_SIDE_LAYER_FLOATS 1280    // 656 as above (slot 642: out_proj scale) + in_proj bias [384] at 656 + out_proj bias [128] at 1040
+#define H3D_SIDE_LDS_OFFSET (H3_RING * H3_STAGE_BYTES + 4 * H3D_WAVE_LDS)
+#define H3D_SIDE_LDS_BYTES 5120       // five 1 KiB LDS-DMA chunks
+#define H3D_LDS_BYTES (H3D_SIDE_LDS_OFFSET + H3D_SIDE_LDS_BYTES)
+#define H3D_INB 656
+#define H3D_OUTB 1040
 #define H3_TARGET_MAX 4096.0f       // |w| * 2^s is scaled up to just below this
 
 // stage sequence per net (each 9 KiB = 4 tile pairs + aux); the A and B stages of the chunked MLPs are
@@ -59,6 +68,8 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 //          can start as soon as the mixing has produced xm[ks])
 //          ff_chunks x { A: [W1 chunk o=0 (4 ks) + aux(b1 chunk, scale1)][o=1]  B: [W2 chunk ot 0-3][ot 4-7] }
 //   OUT  : hid_chunks x { A: [W0 chunk o=0 + aux][o=1]  B: [W2 chunk (1 pair)] }
+// dense variant, attention part of a layer (4 H stages instead of 8 H):  per head pair (2 hp, 2 hp + 1):
+//          per head [in_proj rows of q_h: 4 ks][k_h][v_h], then [out_proj k-step hp: ot 0-3][ot 4-7]
 // side floats per net: in2_b[128] { n1w n1b [128] b2[128] n2w n2b [128] } out2_b[16]
 //                      scales: in0, in2, per layer (wc, w1, w2), out0, out2  (as 2^-s multipliers)
 struct H3Geom {
@@ -74,11 +85,12 @@ static H3Geom h3_geom(const tw_flow_desc& d) {
   g.ff_chunks = d.d_ff / 32;
   g.H = d.n_heads;
   g.L = d.n_layers;
-  g.stages = 3LL * g.hid_chunks + (int64_t)g.L * (8LL * g.H + 4LL * g.ff_chunks) + 3LL * g.hid_chunks;
+  const int64_t att_stages = d.variant == 1 ? 4LL * g.H : 8LL * g.H;
+  g.stages = 3LL * g.hid_chunks + (int64_t)g.L * (att_stages + 4LL * g.ff_chunks) + 3LL * g.hid_chunks;
   int64_t o = 0;
   g.side_in2b = o; o += 128;
   g.side_layers = o;
-  g.side_layer_size = H3_SIDE_LAYER_FLOATS;
+  g.side_layer_size = d.variant == 1 ? H3D_SIDE_LAYER_FLOATS : H3_SIDE_LAYER_FLOATS;
   o += g.L * g.side_layer_size;
   g.side_out2b = o; o += 16;
   g.side_scales = o; o += 4 + 3 * g.L;
@@ -103,6 +115,9 @@ static size_t h3_sf_lds_bytes(int H, int V, int mpw) {
 
 bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom fg;
+  if (d.variant == 1)  // dense softmax attention: 8 heads of 16 = one MFMA tile each; no RFF features (input width <= 64)
+    return d.d_model == 128 && d.n_heads == 8 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_rff == 0 &&
+           d.d_emb + 9 <= 64 && fused_geom_nt(n_atoms, H3_NT, &fg);
   return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
          fused_geom_nt(n_atoms, H3_NT, &fg) &&
          h3_sf_lds_bytes(d.n_heads, n_atoms, fg.mpw) <= H3_SF_LDS_MAX;
@@ -255,6 +270,26 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         const float* lb = nb + L.net.layers + (int64_t)l * L.layer.size;
         float* sl = side + g.side_layers + (int64_t)l * g.side_layer_size;
         float* lsc = scales + 2 + 3 * l;
+        if (d.variant == 1) {
+          // dense: in_proj [384, 128] (one scale) as per-head stages q_h | k_h | v_h of four k-steps each, and after every
+          // second head the k-step of out_proj [128, 128] (second scale) those two heads feed
+          float* osc = sl + 642;
+          if ((rc = absmax(lb + L.layer.in_w, (int64_t)384 * 128, up, lsc + 0))) return rc;
+          for (int h = 0; h < d.n_heads; ++h)
+            for (int part = 0; part < 3; ++part) {
+              char* a = st + (int64_t)((h / 2) * 8 + (h % 2) * 3 + part) * H3_STAGE_BYTES;
+              if ((rc = block(lb + L.layer.in_w, 128, 384, 128, part * 128 + 16 * h, 0, 1, 4, up, a))) return rc;
+            }
+          if ((rc = absmax(lb + L.layer.out_w, (int64_t)128 * 128, up, osc))) return rc;
+          for (int hp = 0; hp < d.n_heads / 2; ++hp)
+            for (int hf = 0; hf < 2; ++hf) {
+              char* b = st + (int64_t)(hp * 8 + 6 + hf) * H3_STAGE_BYTES;
+              if ((rc = block(lb + L.layer.out_w, 128, 128, 128, 64 * hf, 32 * hp, 4, 1, up, b))) return rc;
+            }
+          st += (int64_t)4 * d.n_heads * H3_STAGE_BYTES;
+          if ((rc = copy(lb + L.layer.in_b, 384, sl + H3D_INB, 384))) return rc;
+          if ((rc = copy(lb + L.layer.out_b, 128, sl + H3D_OUTB, 128))) return rc;
+        } else {
         // folded attention: one scale for all heads of the layer
         TW_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float), s));
         hipLaunchKernelGGL(h3_fold_absmax_kernel, dim3(16, d.n_heads), dim3(256), 0, s, lb + L.layer.wv, lb + L.layer.wo,
@@ -270,6 +305,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
               TW_LAUNCH_CHECK();
             }
         st += (int64_t)8 * d.n_heads * H3_STAGE_BYTES;
+        }
         if ((rc = absmax(lb + L.layer.w1, (int64_t)d.d_ff * 128, up, lsc + 1))) return rc;
         for (int ch = 0; ch < g.ff_chunks; ++ch)
           for (int o = 0; o < 2; ++o) {
@@ -506,6 +542,44 @@ __device__ __forceinline__ void split8(const f4 a, const f4 b, h8& hi, h8& lo) {
     lo[e] = (_Float16)(a[e] - (float)ha);
     lo[e + 4] = (_Float16)(b[e] - (float)hb);
   }
+}
+
+// one D tile -> split K = 16 operand
+__device__ __forceinline__ void split4(const f4 a, h4& hi, h4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 ha = (_Float16)a[e];
+    hi[e] = ha;
+    lo[e] = (_Float16)(a[e] - (float)ha);
+  }
+}
+
+// max / sum over the four lanes that share (lane & 15): v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16- and
+// 32-lane blocks between two registers without touching the LDS:
+//   v_permlane16_swap a, b:  a' = [a.r0, b.r0, a.r2, b.r2],  b' = [a.r1, b.r1, a.r3, b.r3]   (rows of 16 lanes)
+//   v_permlane32_swap a, b:  a' = [a.lo32, b.lo32],          b' = [a.hi32, b.hi32]
+// so with two copies of one value every lane ends up holding its own and its partner's.  Inline asm: hipcc (ROCm 7.2)
+// folds the SECOND result of __builtin_amdgcn_permlane{16,32}_swap into the first when both inputs are the same value
+// (tools/probe/permlane_swap_probe.hip); the s_nop covers the VALU-write -> permlane-swap hazard the compiler would pad.
+__device__ __forceinline__ void h3_swap16(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void h3_swap32(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float h3_quad_max(float v) {
+  float a = v, b = v;
+  h3_swap16(a, b);
+  a = b = fmaxf(a, b);
+  h3_swap32(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float h3_quad_sum(float v) {
+  float a = v, b = v;
+  h3_swap16(a, b);
+  a = b = a + b;
+  h3_swap32(a, b);
+  return a + b;
 }
 
 template <int NT, int KS>
@@ -811,10 +885,23 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
 // sections as compiled C++ (tw_debug_set_flags bit 3; kept as the readable statement of what the asm computes and
 // for A/B checks).  Two instantiations rather than a runtime branch: with both variants in one function the
 // register allocator spilled 88 VGPRs to scratch.
-template <int NT, bool ASM>
+// DENSE = true: the dense softmax variant (transformer_nvp, nn.TransformerEncoderLayer post-norm, 8 heads of 16;
+// transformer_block.py:18-72).  Same in / FFN / out sections and weight pipeline; the attention block is
+//   per head h:  q_h, k_h = W_{q,k}[16 h ..] . x^T  (standard orientation: D tile = [feature][token], which IS the
+//                K = 16 MFMA operand layout: k_h as A, q_h as B);  v_h with the operands swapped,
+//                D = x . W_v^T = [token][feature]: lane = feature, registers = tokens - the A operand of P.V;
+//                S^T[key][query] = k_h q_h^T / 4 on K = 16 MFMAs (3-term split);  masked softmax over the keys of the
+//                query's molecule in registers (the four lanes of a query meet through v_permlane swaps);
+//                O^T[d][query] = V^T P^T on K = 32 (key tiles 0, 1) + K = 16 (tile 2) MFMAs -> standard orientation;
+//   per head pair: the two O tiles are one 32-deep k-step of out_proj:  y += W_o[:, 32 hp ..] . O
+// Nothing is transposed through memory and nothing leaves the registers.
+template <int NT, bool ASM, bool DENSE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_h3_kernel(const H3Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int WAVE_LDS = DENSE ? H3D_WAVE_LDS : H3_WAVE_LDS;
+  constexpr int SIDE_LDS_OFFSET = DENSE ? H3D_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET;
+  constexpr int SIDE_CHUNKS = DENSE ? 5 : 3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, i16 = lane & 15;
@@ -836,7 +923,7 @@ netblock_h3_kernel(const H3Params p) {
   const char* net_base = p.packed + (int64_t)net * p.net_stride_bytes;
   const float* side = (const float*)(net_base + p.stages * H3_STAGE_BYTES);
   const float* scales = side + p.side_scales;
-  _Float16* xt_hi = (_Float16*)(lds + H3_RING * H3_STAGE_BYTES + wave * H3_WAVE_LDS);
+  _Float16* xt_hi = (_Float16*)(lds + H3_RING * H3_STAGE_BYTES + wave * WAVE_LDS);
   _Float16* xt_lo = xt_hi + 128 * H3_XT;
 
   // ---- token bookkeeping and input features (ordinary loads: before the DMA pipeline starts) ----
@@ -931,7 +1018,7 @@ netblock_h3_kernel(const H3Params p) {
       }
   }
   // zero the transposed tile once: its pad columns are multiplied by zero scores and must be finite
-  for (int i = lane; i < H3_WAVE_LDS / 16; i += 64) ((f4*)xt_hi)[i] = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < WAVE_LDS / 16; i += 64) ((f4*)xt_hi)[i] = (f4){0.f, 0.f, 0.f, 0.f};
 
   // ---- start the weight pipeline ----
   H3Pipe pipe;
@@ -1020,9 +1107,11 @@ netblock_h3_kernel(const H3Params p) {
   auto zero_pad = [&]() {
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
-      const float keep = ((padmask >> jt) & 1u) ? 0.f : 1.f;
+      const bool pad = (padmask >> jt) & 1u;
 #pragma unroll
-      for (int ft = 0; ft < 8; ++ft) x[ft][jt] = x[ft][jt] * keep;
+      for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[ft][jt][r] = pad ? 0.f : x[ft][jt][r];
     }
   };
   zero_pad();
@@ -1032,7 +1121,23 @@ netblock_h3_kernel(const H3Params p) {
   const char* sf_net = p.sfrag + (int64_t)(net * p.n_layers) * p.sf_variant_bytes +
                        (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * H3_SF_BYTES);
 
-  const float* sl = (const float*)(lds + H3_SIDE_LDS_OFFSET);  // this layer's side block, staged in LDS
+  const float* sl = (const float*)(lds + SIDE_LDS_OFFSET);  // this layer's side block, staged in LDS
+  // dense: which key tokens of the wave each of this lane's query tokens may attend to - the unmasked atoms of the
+  // query's own molecule (src_key_padding_mask, transformer_block.py:57-68) - pre-shifted by 4 g so that the bit of
+  // key 16 mt + 4 g + r (the S^T accumulator element this lane holds) sits at position 16 mt + r
+  unsigned long long kvalid[NT];
+  if constexpr (DENSE) {
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      unsigned long long m = 0ull;
+      if (tok_row[jt] >= 0) {
+        const int q = (16 * jt + i16) / p.V;
+        const uint8_t* mk = p.masked + (tok_row[jt] % p.n_cond) * p.V;
+        for (int a = 0; a < p.V; ++a) m |= mk[a] ? 0ull : (1ull << (q * p.V + a));
+      }
+      kvalid[jt] = m >> (4 * g);
+    }
+  }
   for (int l = 0; l < p.n_layers; ++l) {
     const char* sf_base = sf_net + l * p.sf_variant_bytes;  // the layer's own score fragments (chebyshev_kernel), else shared
     // Stage the layer's LayerNorm parameters, FFN output bias and the two output scales (2.6 KB) in LDS: wave 0
@@ -1043,25 +1148,27 @@ netblock_h3_kernel(const H3Params p) {
     __builtin_amdgcn_s_barrier();
     if (wave == 0) {
       const char* src = (const char*)(side + p.side_layers + (int64_t)l * p.side_layer_size) + lane * 16;
-      char* dst = lds + H3_SIDE_LDS_OFFSET;
+      char* dst = lds + SIDE_LDS_OFFSET;
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < SIDE_CHUNKS; ++i)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
                                          (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
     }
-    // x -> transposed fp16 hi/lo tile in LDS
+    // x -> transposed fp16 hi/lo tile in LDS (operand of the mixing; the dense variant has none)
+    if constexpr (!DENSE) {
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
+      for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-      for (int ft = 0; ft < 8; ++ft)
+        for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = x[ft][jt][r];
-          const _Float16 hi = (_Float16)v;
-          const int idx = (16 * ft + 4 * g + r) * H3_XT + 16 * jt + i16;
-          xt_hi[idx] = hi;
-          xt_lo[idx] = (_Float16)(v - (float)hi);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const float v = x[ft][jt][r];
+            const _Float16 hi = (_Float16)v;
+            const int idx = (16 * ft + 4 * g + r) * H3_XT + 16 * jt + i16;
+            xt_hi[idx] = hi;
+            xt_lo[idx] = (_Float16)(v - (float)hi);
+          }
+    }
 
     f4 y[8][NT];
 #pragma unroll
@@ -1070,7 +1177,139 @@ netblock_h3_kernel(const H3Params p) {
       for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
 
     stamp(40 + 4 * l + 0);
-    if constexpr (ASM) {
+    if constexpr (DENSE) {
+      static_assert(NT == 3, "key tiles 0, 1 form the K = 32 part of P.V, tile 2 the K = 16 part");
+      BOp<NT> xb[4];
+      to_bop<NT, 4>(x, xb);
+      constexpr float LOG2E = 1.44269504088896340736f;
+      for (int hp = 0; hp < p.H / 2; ++hp) {
+        f4 oh[2][NT];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int h = 2 * hp + hh;
+          f4 qa[NT], ka[NT], va[NT];
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) qa[jt] = ka[jt] = va[jt] = (f4){0.f, 0.f, 0.f, 0.f};
+          {  // q_h = W_q[16 h ..] . x^T
+            H3Tiles w;
+            w.load(pipe.stage(), lane);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              w.ready(ks);
+              mma3<NT>(w.hi(ks), w.lo(ks), xb[ks], qa);
+              w.done(ks);
+            }
+            pipe.advance();
+          }
+          {  // k_h
+            H3Tiles w;
+            w.load(pipe.stage(), lane);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              w.ready(ks);
+              mma3<NT>(w.hi(ks), w.lo(ks), xb[ks], ka);
+              w.done(ks);
+            }
+            pipe.advance();
+          }
+          {  // v_h, operands swapped: va[jt] = x[tokens of tile jt] . W_v[16 h ..]^T  (lane = feature, registers = tokens)
+            H3Tiles w;
+            w.load(pipe.stage(), lane);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              w.ready(ks);
+#pragma unroll
+              for (int jt = 0; jt < NT; ++jt) va[jt] = mfma32(xb[ks].h[jt], w.hi(ks), va[jt]);
+#pragma unroll
+              for (int jt = 0; jt < NT; ++jt) va[jt] = mfma32(xb[ks].l[jt], w.hi(ks), va[jt]);
+#pragma unroll
+              for (int jt = 0; jt < NT; ++jt) va[jt] = mfma32(xb[ks].h[jt], w.lo(ks), va[jt]);
+              w.done(ks);
+            }
+            pipe.advance();
+          }
+          // scale, bias, 1 / sqrt(16) on q; fp16 hi / lo operands
+          h4 qh[NT], ql[NT], kh[NT], kl[NT], vh2, vl2;
+          h8 vh01, vl01;
+          {
+            const f4 bq = *(const f4*)(sl + H3D_INB + 16 * h + 4 * g);
+            const f4 bk = *(const f4*)(sl + H3D_INB + 128 + 16 * h + 4 * g);
+            const float bv = sl[H3D_INB + 256 + 16 * h + i16];
+            const float sc_in = sl[640];  // (the side block has landed: three stage hand-offs lie behind us)
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+              split4((qa[jt] * sc_in + bq) * 0.25f, qh[jt], ql[jt]);
+              split4(ka[jt] * sc_in + bk, kh[jt], kl[jt]);
+              va[jt] = va[jt] * sc_in + bv;
+            }
+            split8(va[0], va[1], vh01, vl01);
+            split4(va[2], vh2, vl2);
+          }
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) {
+            // S^T[key tile mt][query tile jt]: this lane holds keys 16 mt + 4 g + r of its query 16 jt + i16
+            f4 sc[NT];
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) sc[mt] = mfma16(kh[mt], qh[jt], (f4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) sc[mt] = mfma16(kh[mt], ql[jt], sc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) sc[mt] = mfma16(kl[mt], qh[jt], sc[mt]);
+            // keys outside the query's molecule and padded atoms drop out.  -3e4 rather than -inf: e^(-3e4 - max) is 0 for
+            // any real row, and the rows of padding tokens - no keys at all - stay finite (uniform weights) instead of
+            // turning into NaN that 0-weights would not remove from the P.V products of their neighbours
+            constexpr float MASKED = -3.0e4f;
+            float mx = MASKED;
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                sc[mt][r] = ((kvalid[jt] >> (16 * mt + r)) & 1ull) ? sc[mt][r] : MASKED;
+                mx = fmaxf(mx, sc[mt][r]);
+              }
+            mx = h3_quad_max(mx) * LOG2E;
+            float sum = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                sc[mt][r] = __builtin_amdgcn_exp2f(fmaf(sc[mt][r], LOG2E, -mx));
+                sum += sc[mt][r];
+              }
+            sum = h3_quad_sum(sum);
+            h8 ph01, pl01;
+            h4 ph2, pl2;
+            split8(sc[0], sc[1], ph01, pl01);
+            split4(sc[2], ph2, pl2);
+            // O^T[feature][query]; the K = 32 and the K = 16 part in separate accumulators (mixed-shape chains, see above)
+            f4 o32 = mfma32(vh01, ph01, (f4){0.f, 0.f, 0.f, 0.f});
+            f4 o16 = mfma16(vh2, ph2, (f4){0.f, 0.f, 0.f, 0.f});
+            o32 = mfma32(vh01, pl01, o32);
+            o16 = mfma16(vh2, pl2, o16);
+            o32 = mfma32(vl01, ph01, o32);
+            o16 = mfma16(vl2, ph2, o16);
+            oh[hh][jt] = (o32 + o16) * __builtin_amdgcn_rcpf(sum);
+          }
+        }
+        // y += W_o[:, 32 hp .. 32 hp + 31] . O(heads 2 hp, 2 hp + 1)
+        BOp<NT> ob;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) split8(oh[0][jt], oh[1][jt], ob.h[jt], ob.l[jt]);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          H3Tiles w;
+          w.load(pipe.stage(), lane);
+#pragma unroll
+          for (int oo = 0; oo < 4; ++oo) {
+            w.ready(oo);
+            mma3<NT>(w.hi(oo), w.lo(oo), ob, y[4 * half + oo]);
+            w.done(oo);
+          }
+          pipe.advance();
+        }
+      }
+      stamp(40 + 4 * l + 1);
+    } else if constexpr (ASM) {
       // Hand-scheduled attention block (tools/gen_h3_attn_asm.py): all heads, mixing + Wc GEMM; reads the
       // transposed copy of x written above, returns y through the same wave-private LDS block.
       char* priv = (char*)xt_hi;
@@ -1178,7 +1417,15 @@ netblock_h3_kernel(const H3Params p) {
           pipe.advance();
         }
     }
-    {
+    if constexpr (DENSE) {
+      const float sc = sl[642];  // out_proj scale and bias
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot) {
+        const f4 bo = *(const f4*)(sl + H3D_OUTB + 16 * ot + 4 * g);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) y[ot][jt] = y[ot][jt] * sc + bo;
+      }
+    } else {
       const float sc = sl[640];
 #pragma unroll
       for (int ot = 0; ot < 8; ++ot)
@@ -1342,7 +1589,7 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
   // chebyshev_kernel: one fragment set per (net, layer) of the coupling layer in flight
   // + one head of slack: the attention asm block prefetches the "next head" also after the last one
   const int64_t variants = d.cheb_order > 0 ? 2 * d.n_layers : 1;
-  w.sf_variant_bytes = nblocks * d.n_heads * H3_NT * H3_SF_BYTES;
+  w.sf_variant_bytes = d.variant == 1 ? 0 : nblocks * d.n_heads * H3_NT * H3_SF_BYTES;  // dense: no score fragments
   w.sfrag = take(variants * w.sf_variant_bytes + H3_NT * H3_SF_BYTES);
   w.bytes = p - (char*)base;
   return w;
@@ -1408,12 +1655,19 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.prev = prev;
   const int wgs_per_net = (p.nblocks + 3) / 4;
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
-  static LdsLimit lim_asm, lim_cpp;
+  static LdsLimit lim_asm, lim_cpp, lim_dense, lim_dense_cpp;
   int prc;
   if ((prc = lim_asm.ensure((const void*)netblock_h3_kernel<H3_NT, true>, (int)H3_LDS_BYTES))) return prc;
   if ((prc = lim_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false>, (int)H3_LDS_BYTES))) return prc;
+  if ((prc = lim_dense.ensure((const void*)netblock_h3_kernel<H3_NT, true, true>, (int)H3D_LDS_BYTES))) return prc;
+  if ((prc = lim_dense_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false, true>, (int)H3D_LDS_BYTES))) return prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
-  if (g_debug_flags & 8)
+  if (d.variant == 1) {
+    if (g_debug_flags & 8)
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
+    else
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
+  } else if (g_debug_flags & 8)
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
   else
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
@@ -1462,7 +1716,8 @@ int flow_pass_h3(const FlowArgs& a) {
   const bool shared = a.n_cond == 1;
   int rc;
   int64_t vb = 0;
-  if (d.cheb_order == 0 && (rc = h3_score_frags(a, L, fg, w, shared, 0, &vb))) return rc;
+  const bool kernel_attention = d.variant == 0;  // the dense variant computes its scores inside the net-block launch
+  if (kernel_attention && d.cheb_order == 0 && (rc = h3_score_frags(a, L, fg, w, shared, 0, &vb))) return rc;
   // The coupling update of layer i is applied by the launch of layer i + 1 (PrevCoupling): the variable it transforms
   // is that launch's conditioning input.  Both variables alternate between the caller's buffer and a workspace copy,
   // the (s, t) outputs between two sets: a launch reads what its predecessor wrote while it writes its own.
@@ -1479,7 +1734,7 @@ int flow_pass_h3(const FlowArgs& a) {
     for (int i = 0; i < d.n_coupling; ++i) {
       const int c = a.reverse ? d.n_coupling - 1 - i : i;
       const bool positions = (c % 2) == d.pos_mod2;
-      if (d.cheb_order > 0 && (rc = h3_score_frags(a, L, fg, w, shared, c, &vb))) return rc;
+      if (kernel_attention && d.cheb_order > 0 && (rc = h3_score_frags(a, L, fg, w, shared, c, &vb))) return rc;
       if ((rc = h3_launch(a, L, fg, c, -1, positions ? a.z_velocs : a.z_coords, w.sfrag, vb, shared, w.s_out, w.t_out, nullptr)))
         return rc;
       if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, positions ? a.z_coords : a.z_velocs, a.delta_logp,
@@ -1497,7 +1752,7 @@ int flow_pass_h3(const FlowArgs& a) {
       prev.z_in = cur[ov];
       prev.z_out = alt[ov];
     }
-    if (d.cheb_order > 0 && (rc = h3_score_frags(a, L, fg, w, shared, c, &vb))) return rc;
+    if (kernel_attention && d.cheb_order > 0 && (rc = h3_score_frags(a, L, fg, w, shared, c, &vb))) return rc;
     if ((rc = h3_launch(a, L, fg, c, -1, cur[ov], w.sfrag, vb, shared, sbuf[i & 1], tbuf[i & 1], nullptr, prev))) return rc;
     if (prev.s_raw) std::swap(cur[ov], alt[ov]);
     prev = PrevCoupling{sbuf[i & 1], tbuf[i & 1], nullptr, nullptr, a.delta_logp, flag, a.reverse};
@@ -1526,7 +1781,7 @@ int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, f
   const bool shared = a.n_cond == 1;
   int rc;
   int64_t vb = 0;
-  if ((rc = h3_score_frags(a, L, fg, w, shared, c, &vb))) return rc;
+  if (d.variant == 0 && (rc = h3_score_frags(a, L, fg, w, shared, c, &vb))) return rc;
   return h3_launch(a, L, fg, c, net, z_other, w.sfrag, vb, shared, w.s_out, w.t_out, dump);
 }
 

@@ -48,7 +48,7 @@ xc = (torch.randn(1, V, 3, generator=g) * 0.3).cuda()
 xv = (torch.randn(1, V, 3, generator=g) * 0.5).cuda()
 mk = torch.zeros(1, V, dtype=torch.bool).cuda()
 flop = 16 * V * 3726336 * S
-for path, name, iters in ((1, "fused f32-MFMA dense net-block kernel", 5), (2, "per-op path", 2)):
+for path, name, iters in ((3, "split-fp16 dense net-block kernel", 5), (1, "fused f32-MFMA dense net-block kernel", 5), (2, "per-op path", 2)):
     md = H.tw_dense_model(H.full_dense_sd(), path=path)
     ms = timed(lambda: md.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None, edge_batch_idx=None,
                                                        masked_elements=mk, num_samples=S), iters=iters)
