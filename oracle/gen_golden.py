@@ -708,6 +708,29 @@ def gen_dense_full(ad_x, ad_t):
     print("dense_full_padded ok")
 
 
+def gen_dense_posenc_full(ad_x, ad_t):
+    """transformer_nvp_posenc.yaml at full size (128 random Fourier features of the conditioning positions,
+    rff_position_encoder.py:41-137) on alanine dipeptide.  The Gaussian vectors are buffers drawn when the reference
+    builds the model (Gamma-distributed scales: some are large, so cos / sin see arguments of tens of radians); they are
+    stored with the vectors, every other weight is regenerated from the name-seeded recipe on both sides."""
+    torch.manual_seed(31)
+    dfull = dense_model(emb=32, d_model=128, ff=2048, mlp_hidden=[256], n_coupling=8, n_layers=3, n_head=8,
+                        rff=RFFPositionEncoderConfig(128, 1.0, 1.0))
+    dfull.load_state_dict(fo.synth_state_dict(dfull.state_dict(), base_seed=0))
+    g = torch.Generator().manual_seed(14)
+    x_c = ad_x[None].clone()
+    x_v = torch.randn(1, 22, 3, generator=g) * 0.5
+    mask = torch.zeros(1, 22, dtype=torch.bool)
+    y_c = x_c + torch.randn(1, 22, 3, generator=g) * 0.01
+    y_v = torch.randn(1, 22, 3, generator=g) * 0.5
+    d = base_inputs(ad_t[None], x_c, x_v, mask, y_c, y_v)
+    d.update(run_case(dfull, ad_t[None], x_c, x_v, mask, y_c, y_v, 16, 2026))
+    gv = {k: v for k, v in dfull.state_dict().items() if k.endswith("gaussian_vectors")}
+    d.update(np_sd(gv))
+    print("dense_posenc_full_ad ok; |G| max", max(float(v.abs().max()) for v in gv.values()))
+    np.savez_compressed(os.path.join(OUT, "dense_posenc_full_ad.npz"), **d)
+
+
 def gen_euler_maruyama():
     # ---- (5) EulerMaruyamaGaussian (cfg 1 plumbing) ----------------------------------------------
     em = model_constructor(ModelConfig(model_type="euler_maruyama_gaussian")).eval()
@@ -758,6 +781,7 @@ def main():
         "v60": lambda: gen_v60(full()),
         "dense-tiny": gen_dense_tiny,
         "dense-full": lambda: gen_dense_full(ad_x, ad_t),
+        "dense-posenc": lambda: gen_dense_posenc_full(ad_x, ad_t),
         "em": gen_euler_maruyama,
         "mh": lambda: gen_mh_goldens(tiny_kernel_model()),  # (7) the MH loop itself, driven with a synthetic energy
         "mh-omm": lambda: gen_mh_goldens(tiny_kernel_model(), MH_OPENMM_SCENARIOS, "mh_tiny_openmm.npz"),  # (7b) with OpenMM steps

@@ -55,6 +55,19 @@ def full_dense_sd():
     return _cache["d"]
 
 
+def full_dense_posenc_sd():
+    """transformer_nvp_posenc.yaml at full size: name-seeded weights, the position encoders' Gaussian vectors (buffers
+    the reference draws at construction) from the golden file."""
+    if "dp" not in _cache:
+        _, gv = load("dense_posenc_full_ad")
+        t = fo.make_template(FULL_DENSE_SPEC, rff_dim=128)
+        for k, v in gv.items():
+            assert k in t and t[k].shape == v.shape, k
+            t[k] = v
+        _cache["dp"] = fo.synth_state_dict(t, 0)
+    return _cache["dp"]
+
+
 def rel_err(a, b):
     """max |a - b| / max |b|: error relative to the scale of the tensor (coordinates, whose elements pass through 0)."""
     a = torch.as_tensor(a, dtype=torch.float64)

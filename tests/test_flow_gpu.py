@@ -220,6 +220,21 @@ def test_full_dense_ad_golden(path):
         assert m._dev_weights["f32"] is not None  # the fused kernel's weight stream was built and used
 
 
+@pytest.mark.parametrize("path", [SIMPLE, FUSED, 0, None])
+def test_full_dense_posenc_golden(path):
+    """transformer_nvp_posenc.yaml at full size (128 random Fourier features of the conditioning positions appended to
+    the in-MLP's input, rff_position_encoder.py:57-62): per-op path, the fused f32 dense kernel (cos / sin in its
+    prologue, eleven input tiles), TW_PATH_AUTO and the constructor's default - which must both land on the fused f32
+    kernel: the split-fp16 in-MLP section takes 64 input features."""
+    d, _ = H.load("dense_posenc_full_ad")
+    m = H.tw_dense_model(H.full_dense_posenc_sd(), rff_dim=128, path=path)
+    if path is None:
+        assert m._path_for(22) == 0
+    H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
+    if path in (0, None):
+        assert m._dev_weights["f32"] is not None
+
+
 @pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])
 def test_full_dense_padded_golden(path):
     """Padded batch (22 / 17 / 20 real atoms) through nn.MultiheadAttention's src_key_padding_mask

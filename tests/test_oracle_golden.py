@@ -134,6 +134,12 @@ def test_dense_tiny_and_full():
     _check_case(d, H.full_dense_sd(), H.FULL_DENSE_SPEC)
 
 
+def test_dense_posenc_full():
+    """transformer_nvp_posenc.yaml (128 random Fourier position features, rff_position_encoder.py:41-137) at full size."""
+    d, _ = H.load("dense_posenc_full_ad")
+    _check_case(d, H.full_dense_posenc_sd(), H.FULL_DENSE_SPEC)
+
+
 def test_euler_maruyama():
     d, sd = H.load("euler_maruyama")
     cm, cs, vm, vs = fo.euler_maruyama_dist(sd, d["atom_types"], d["x_coords"], d["x_velocs"], d["x_forces"])

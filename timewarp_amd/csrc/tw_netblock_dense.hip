@@ -19,8 +19,9 @@
 //
 // Weight stream per net (tiles in consumption order): IN hid_chunks x 24 | per layer: 8 heads x (24 + 8) then
 // ff_chunks x 32 | OUT hid_chunks x 24;  side floats: in0_b in2_b { in_proj_b[384] out_proj_b[128] n1w n1b b1[ff] b2
-// n2w n2b } out0_b out2_b.  Supported: d_model 128, 8 heads, input width <= 48 (no RFF features, as in
-// configs/transformer_nvp.yaml), molecules of <= 64 atoms; other dense configurations use the per-op path.
+// n2w n2b } out0_b out2_b.  Supported: d_model 128, 8 heads, molecules of <= 64 atoms, input width <= 48 (no position
+// features, configs/transformer_nvp.yaml) or 32 + 9 + 128 random Fourier features (configs/transformer_nvp_posenc.yaml: cos / sin
+// of the conditioning positions computed in the prologue, eleven input tiles); other dense configurations use the per-op path.
 #include "tw_common.h"
 #include "tw_nb_f32.h"
 
@@ -30,10 +31,20 @@ namespace tw {
 #define QS 20       // LDS row stride (floats) of the q / k / v tiles: conflict-free 16-byte writes and reads
 #define PS 65       // LDS row stride (floats) of the score tile [token][key <= 64]
 
+// input width of the in-MLP in 16-feature tiles: 3 (atom embedding + 9, no position features: transformer_nvp.yaml) or 11
+// (32 + 9 + 128 random Fourier features of the conditioning positions: transformer_nvp_posenc.yaml); 0 = not supported
+static int dense_in_tiles(const tw_flow_desc& d) {
+  if (d.d_rff == 0 && d.d_emb + 9 <= 48) return 3;
+  if (d.d_rff == 128 && d.d_emb == 32) return 11;
+  return 0;
+}
+// weight tiles of one in-MLP chunk: W0 chunk 2 x FT_IN, W2 chunk 8 x 2, padded to a multiple of the ring depth
+static int dense_in_body(int ft_in) { return (2 * ft_in + 16 + RING - 1) / RING * RING; }
+
 bool dense_fused_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom g;
   return d.variant == 1 && d.d_model == 128 && d.n_heads == 8 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 &&
-         d.d_emb % 4 == 0 && d.d_rff == 0 && d.d_emb + 9 <= 48 && fused_geom(n_atoms, &g);
+         d.d_emb % 4 == 0 && dense_in_tiles(d) > 0 && fused_geom(n_atoms, &g);
 }
 
 struct DenseGeom {
@@ -49,7 +60,7 @@ static DenseGeom dense_geom(const tw_flow_desc& d) {
   s.hid_chunks = d.d_hidden / 32;
   s.ff_chunks = d.d_ff / 32;
   s.L = d.n_layers;
-  s.in_tiles = (int64_t)s.hid_chunks * 24;
+  s.in_tiles = (int64_t)s.hid_chunks * dense_in_body(dense_in_tiles(d));
   s.layer_tiles = (int64_t)d.n_heads * 32 + (int64_t)s.ff_chunks * 32;
   s.out_tiles = (int64_t)s.hid_chunks * 24;
   s.tiles = s.in_tiles + s.L * s.layer_tiles + s.out_tiles;
@@ -95,10 +106,11 @@ int dense_pack_weights(const tw_flow_desc& d, const float* raw, float* packed, h
       const float* nb = raw + net_base(L, c, net);
       float* pn = packed + (int64_t)(c * 2 + net) * P.net_stride;
       float* t = pn;  // tile cursor
+      const int ft_in = dense_in_tiles(d), in_body = dense_in_body(ft_in);
       for (int ch = 0; ch < g.hid_chunks; ++ch) {
-        if ((rc = pack_block(nb + L.net.in0_w, L.d_in, d.d_hidden, L.d_in, 32 * ch, 0, 2, 3, t, s))) return rc;
-        if ((rc = pack_block(nb + L.net.in2_w, d.d_hidden, 128, d.d_hidden, 0, 32 * ch, 8, 2, t + 6 * TILE_F, s))) return rc;
-        t += 24 * TILE_F;
+        if ((rc = pack_block(nb + L.net.in0_w, L.d_in, d.d_hidden, L.d_in, 32 * ch, 0, 2, ft_in, t, s))) return rc;
+        if ((rc = pack_block(nb + L.net.in2_w, d.d_hidden, 128, d.d_hidden, 0, 32 * ch, 8, 2, t + 2 * ft_in * TILE_F, s))) return rc;
+        t += in_body * TILE_F;
       }
       for (int l = 0; l < d.n_layers; ++l) {
         const float* lb = nb + L.net.layers + (int64_t)l * L.layer.size;
@@ -155,6 +167,8 @@ struct DNParams {
   const float* xc;
   const float* xv;
   const float* z_other;
+  const float* rff;  // [3, d_rff / 2] Gaussian vectors of this coupling layer's position encoder (d_rff > 0)
+  int d_rff;
   const uint8_t* masked;
   float* out[2];
   float* dump;
@@ -166,7 +180,7 @@ struct DNParams {
   int debug;  // timing experiments (tw_debug_set_flags): 64 = no softmax section (o_h = v_h), 128 = also no LDS round trip
 };
 
-template <int NT>
+template <int NT, int FT_IN = 3>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_dense_kernel(const DNParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -219,25 +233,34 @@ netblock_dense_kernel(const DNParams p) {
     keymask[jt] = m;
   }
 
-  // ---- input features u = [emb(type), x_coords, x_velocs, z_other] padded to 48 -------------
-  f4 u[3][NT];
+  // ---- input features u = [emb(type), x_coords, x_velocs, z_other (, rff(x_coords))] padded to 16 FT_IN -------------
+  f4 u[FT_IN][NT];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     const int64_t n = tok_row[jt];
     const int64_t c = n < 0 ? 0 : n % p.n_cond;
     const int a = tok_atom[jt];
     const int ty = n < 0 ? 0 : p.types[c * p.V + a];
+    const float* px = p.xc + (c * p.V + a) * 3;
 #pragma unroll
-    for (int ft = 0; ft < 3; ++ft)
+    for (int ft = 0; ft < FT_IN; ++ft)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = 16 * ft + 4 * g + r;
         float val = 0.f;
         if (n >= 0) {
           if (f < p.d_emb) val = p.emb[ty * p.d_emb + f];
-          else if (f < p.d_emb + 3) val = p.xc[(c * p.V + a) * 3 + (f - p.d_emb)];
+          else if (f < p.d_emb + 3) val = px[f - p.d_emb];
           else if (f < p.d_emb + 6) val = p.xv[(c * p.V + a) * 3 + (f - p.d_emb - 3)];
           else if (f < p.d_emb + 9) val = p.z_other[(n * p.V + a) * 3 + (f - p.d_emb - 6)];
+          else if (FT_IN > 3 && f < p.d_emb + 9 + p.d_rff) {
+            // rff_position_encoder.py:57-62: sqrt(1/n) * [cos(x G), sin(x G)]; same arithmetic as build_input_kernel
+            const int nvec = p.d_rff / 2;
+            const int j = f - p.d_emb - 9;
+            const int col = j % nvec;
+            const float ip = px[0] * p.rff[0 * nvec + col] + px[1] * p.rff[1 * nvec + col] + px[2] * p.rff[2 * nvec + col];
+            val = sqrtf(1.0f / nvec) * (j < nvec ? cosf(ip) : sinf(ip));
+          }
         }
         u[ft][jt][r] = val;
       }
@@ -265,7 +288,7 @@ netblock_dense_kernel(const DNParams p) {
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) x[ot][jt] = bb;
     }
-    mlp_chain<NT, 3, 8, 24, true>(u, x, wp, ring, side + p.side_in0b + 4 * g, p.hid_chunks);
+    mlp_chain<NT, FT_IN, 8, (2 * FT_IN + 16 + RING - 1) / RING * RING, true>(u, x, wp, ring, side + p.side_in0b + 4 * g, p.hid_chunks);
   }
   dump_x(x, 0);
 
@@ -490,6 +513,8 @@ static int dense_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& 
   p.xc = a.x_coords;
   p.xv = a.x_velocs;
   p.z_other = z_other;
+  p.rff = d.d_rff > 0 ? a.raw + L.chain + (int64_t)c * L.coupling_size + L.rff : nullptr;
+  p.d_rff = d.d_rff;
   p.masked = a.masked;
   p.out[0] = s_out;
   p.out[1] = t_out;
@@ -512,13 +537,20 @@ static int dense_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& 
   const size_t shm = (size_t)4 * 16 * g.nt * (3 * QS + PS) * sizeof(float);
   int prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
-  static LdsLimit lim3, lim4;  // > 64 KiB of dynamic LDS needs the kernel's limit raised, once per device
-  if (g.nt == 3) {
+  static LdsLimit lim3, lim4, lim3r, lim4r;  // > 64 KiB of dynamic LDS needs the kernel's limit raised, once per device
+  const bool rff = dense_in_tiles(d) == 11;
+  if (g.nt == 3 && !rff) {
     if ((prc = lim3.ensure((const void*)netblock_dense_kernel<3>, (int)shm))) return prc;
     hipLaunchKernelGGL(netblock_dense_kernel<3>, dim3(grid), dim3(256), shm, a.stream, p);
-  } else {
+  } else if (!rff) {
     if ((prc = lim4.ensure((const void*)netblock_dense_kernel<4>, (int)shm))) return prc;
     hipLaunchKernelGGL(netblock_dense_kernel<4>, dim3(grid), dim3(256), shm, a.stream, p);
+  } else if (g.nt == 3) {
+    if ((prc = lim3r.ensure((const void*)netblock_dense_kernel<3, 11>, (int)shm))) return prc;
+    hipLaunchKernelGGL((netblock_dense_kernel<3, 11>), dim3(grid), dim3(256), shm, a.stream, p);
+  } else {
+    if ((prc = lim4r.ensure((const void*)netblock_dense_kernel<4, 11>, (int)shm))) return prc;
+    hipLaunchKernelGGL((netblock_dense_kernel<4, 11>), dim3(grid), dim3(256), shm, a.stream, p);
   }
   TW_LAUNCH_CHECK();
   if ((prc = profile_mark(a.stream, false))) return prc;

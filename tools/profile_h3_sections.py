@@ -6,8 +6,10 @@ from oracle import flow_oracle as fo
 from tests import helpers as H
 from timewarp_amd import _lib
 
-extra = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-sd = H.full_kernel_sd()
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+extra = int(args[0]) if args else 0
+DENSE = "--dense" in sys.argv   # the split-fp16 dense-softmax kernel (transformer_nvp) instead of the kernel-attention one
+sd = H.full_dense_sd() if DENSE else H.full_kernel_sd()
 N, V = 1000, 22
 g = torch.Generator().manual_seed(2)
 at = torch.randint(0, 5, (1, V), generator=g)
@@ -16,7 +18,7 @@ x_v = torch.randn(1, V, 3, generator=g) * 0.5
 zo = torch.randn(N, V, 3, generator=g) * 0.5
 mask = torch.zeros(1, V, dtype=torch.bool)
 xc = x_c - fo.centre_of_mass(x_c, mask)
-m = H.tw_kernel_model(sd, path=3)
+m = H.tw_dense_model(sd, path=3) if DENSE else H.tw_kernel_model(sd, path=3)
 _lib.load().tw_debug_set_flags(16 | extra)
 for rep in range(3):
     acts, out = m.debug_netblock(0, 0, at.cuda(), xc.cuda(), x_v.cuda(), mask.cuda(), zo.cuda(), 3)
