@@ -13,7 +13,7 @@
 //    are staged through LDS by LDS-DMA (global_load_lds, 16 B/lane) in 9 KiB stages (4 tile pairs +
 //    1 KiB of bias/scale) shared by the 4 waves of a workgroup, in a 5-deep ring, one barrier per stage;
 //  * the mixing A_h X runs on the same 3-product scheme from an fp16 hi/lo copy of X stored
-//    TRANSPOSED in LDS ([feature][token], row stride 56 halfs -> conflict-free ds_read_b128).
+//    TRANSPOSED in LDS ([feature][token], row stride 48 halfs -> conflict-free ds_read_b128).
 // Waves hold 48 tokens (NT = 3): every molecule of up to 48 atoms, floor(48 / V) molecules per wave; larger ones use
 // the f32 kernel.
 //
@@ -38,7 +38,9 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 #define H3_NT 3
 #define H3_TOK (16 * H3_NT)
-#define H3_XT 56                    // halfs per feature row of the transposed X tile
+#define H3_XT 48
+// ^ halfs per feature row of the transposed X tile: the 48 tokens, no padding.  Row stride 24 dwords is conflict-free for
+//   the ds_read_b128 lane groups of gfx950; 56 halfs (the r01/r02 value) was 2-way (tools/gen_h3_attn_asm.py)
 #define H3_PAIR_BYTES 2048          // one (hi, lo) tile pair: 16 out x 32 k
 #define H3_STAGE_PAIRS 4
 #define H3_STAGE_TILE_BYTES 8192    // 4 pairs

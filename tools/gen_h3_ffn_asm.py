@@ -21,7 +21,7 @@ Stage order (must match h3_pack_weights):  A0(0) A1(0) | A0(c+1) A1(c+1) B0(c) B
 import os
 import sys
 
-# experiments: comma-separated flags in H3_FFN_EXPERIMENT.  noepi, nobarrier: timing only (results become wrong).
+# experiments: comma-separated flags in H3_FFN_EXPERIMENT.  noepi, nobarrier, nodma: timing only (results become wrong).
 # pairsync: one barrier per PAIR of stages, both slots refilled after it - correct, but measured 2.5 % slower (the
 # refill then runs only two stages ahead of its use and the LDS-DMA latency shows).
 EXPERIMENT = set(filter(None, os.environ.get("H3_FFN_EXPERIMENT", "").split(",")))
@@ -150,6 +150,12 @@ def handoff(next_reads, with_aux, label):
         f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off",
         f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off offset:1024",
     ]
+    if "nodma" in EXPERIMENT:
+        # timing experiment: no weight DMA after the kernel's prologue - the ring keeps serving the first five stages
+        # (finite, random-looking operands: the clock sees the same switching activity), every vmcnt wait is satisfied at
+        # once; results are WRONG.  What remains is issue + LDS + barriers: the difference to `base` is what the stream costs.
+        h = [x for x in h if not (isinstance(x, str) and x.startswith("global_load_lds"))]
+        with_aux = False
     if with_aux:
         who = f"s{S_ROT}" if "auxrot" in EXPERIMENT else "0"
         if "auxrot" in EXPERIMENT:
