@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 SIMPLE, FUSED, H3 = 2, 1, 3
 H3_MAX_ATOMS = 48  # the split-fp16 kernels run 48-token waves: floor(48 / V) molecules each, whatever the f32 kernels pick
+H3_WIDE_MAX_ATOMS = 160  # kernel attention only: larger molecules are packed over a workgroup's 192 token slots ("wide")
 
 
 def test_library_sees_gpu():
@@ -182,9 +183,10 @@ def test_full_kernel_ad_golden(path, name, calibrated):
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
 
 
-@pytest.mark.parametrize("path", [SIMPLE, FUSED])
+@pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])
 def test_full_kernel_v60_golden(path):
-    """60 atoms: 4-tile waves in the fused kernel and torch.cdist's matmul branch for the scores."""
+    """60 atoms: 4-tile waves in the fused f32 kernel, three molecules per workgroup in the split-fp16 kernel's wide
+    layout, and torch.cdist's matmul branch for the scores."""
     d, _ = H.load("kernel_full_v60")
     m = H.tw_kernel_model(H.full_kernel_sd(), path=path)
     H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5)
@@ -197,13 +199,13 @@ def test_preferred_split_fp16_path_falls_back_per_call(monkeypatch):
     monkeypatch.setenv("TW_EXECUTION_PATH", "h3")
     m = H.tw_kernel_model(H.full_kernel_sd(), path=None)
     assert m.execution_path == flow.PREFER_SPLIT_FP16
-    assert m._path_for(22) == H3 and m._path_for(30) == H3 and m._path_for(60) == 0
+    assert m._path_for(22) == H3 and m._path_for(30) == H3 and m._path_for(60) == H3 and m._path_for(161) == 0
     d, _ = H.load("kernel_full_ad")
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
     assert m._dev_weights["h3"] is not None and m._dev_weights["f32"] is None  # the 22-atom calls ran on the h3 stream
     d, _ = H.load("kernel_full_v60")
     H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5)
-    assert m._dev_weights["f32"] is not None
+    assert m._dev_weights["f32"] is None  # 60 atoms run on the split-fp16 kernel too (wide layout)
     dense = H.tw_dense_model(H.full_dense_sd(), path=None)
     assert dense._path_for(22) == H3 and dense._path_for(60) == 0  # the dense flow has a split-fp16 kernel of its own
 
@@ -300,7 +302,8 @@ def test_fused_dense_S1000_roundtrip(path):
                                     (12, [12, 12, 9, 12, 11, 12, 12, 5, 12]), (16, [16, 13, 16, 16, 16, 10, 16]),
                                     (24, [24, 21, 24]), (48, [48, 40, 33]), (17, [17, 17, 12, 17, 15]),
                                     (20, [20, 18, 20]), (21, [21, 21, 21, 9, 21]), (32, [32, 26, 32]), (40, [40, 31]),
-                                    (5, [5] * 19 + [3, 4])])
+                                    (5, [5] * 19 + [3, 4]), (60, [60, 44, 60, 60, 51, 60, 60]), (49, [49, 49, 30, 49]),
+                                    (64, [64, 51, 64, 64])])
 def test_fused_batched_padding_vs_oracle(V, lens):
     """Ragged batch (different conditioning state per row, padded atoms) on the fused path against
     the oracle: pins the per-row score fragments and the mask handling
@@ -317,7 +320,7 @@ def test_fused_batched_padding_vs_oracle(V, lens):
     for b, n in enumerate(lens):
         mask[b, n:] = True
     ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
-    for path in (FUSED, SIMPLE) + ((H3,) if V <= H3_MAX_ATOMS else ()):
+    for path in (FUSED, SIMPLE, H3):
         m = H.tw_kernel_model(sd, path=path)
         out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
                                y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
@@ -330,10 +333,12 @@ def test_fused_batched_padding_vs_oracle(V, lens):
         assert abs(float(one[0] - out[1])) < 1e-4 * max(1.0, abs(float(out[1])))
 
 
-@pytest.mark.parametrize("V,lens,paths", [(64, [64, 51], (FUSED, SIMPLE)), (70, [70, 44, 70], (0, SIMPLE)), (100, [100, 87], (0,))])
+@pytest.mark.parametrize("V,lens,paths", [(64, [64, 51], (FUSED, SIMPLE)), (70, [70, 44, 70], (0, SIMPLE, H3)),
+                                          (100, [100, 87], (0, H3)), (96, [96, 90, 96], (H3,)), (160, [160, 131], (H3,))])
 def test_large_molecules_vs_oracle(V, lens, paths):
-    """Maximum sizes: 64 atoms is the largest molecule a fused wave holds (4 tiles); beyond it TW_PATH_AUTO has to fall
-    back to the per-op path.  All above 25 atoms, so the scores follow torch.cdist's matmul branch."""
+    """Maximum sizes: 64 atoms is the largest molecule a fused f32 wave holds (4 tiles); beyond it TW_PATH_AUTO has to fall
+    back to the per-op path, while the split-fp16 kernel's wide layout goes on to 160 atoms (two, then one molecule per
+    workgroup).  All above 25 atoms, so the scores follow torch.cdist's matmul branch."""
     sd = H.full_kernel_sd()
     g = torch.Generator().manual_seed(300 + V)
     B = len(lens)
@@ -350,6 +355,7 @@ def test_large_molecules_vs_oracle(V, lens, paths):
         m = H.tw_kernel_model(sd, path=path)
         out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
                                y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
+        H.assert_not_demoted(m)
         assert H.rel_err(out, ref) < 2e-5, (path, H.rel_err(out, ref))
     if V > 64:
         with pytest.raises(RuntimeError, match="unsupported"):
@@ -494,14 +500,15 @@ def test_full_size_S1000_rows_vs_oracle(path):
     assert H.rel_err(p_yx[rows], r_yx) < TOL and H.elem_rel_err(p_yx[rows], r_yx) < TOL
 
 
-def test_full_size_v60_S512_rows_vs_oracle():
-    """BASELINE config 3 at full size: 60 atoms, 512 proposals on the fused kernel (64-token waves, 1024 waves = one
-    round of the chip).  40 rows spread over the launch - the 4 rows of the first, a middle and the last workgroup of each
+@pytest.mark.parametrize("path", [FUSED, H3])
+def test_full_size_v60_S512_rows_vs_oracle(path):
+    """BASELINE config 3 at full size: 60 atoms, 512 proposals on the fused f32 kernel (64-token waves, 1024 waves = one
+    round of the chip) and on the split-fp16 kernel's wide layout (three molecules per workgroup, 171 workgroups per net).  40 rows spread over the launch - the 4 rows of the first, a middle and the last workgroup of each
     net, 28 random ones - against the oracle: proposals, velocities, log p(y|x) and the reverse-move density; and all 512
     rows through the size-independent round trip.  2e-5: above 25 atoms the scores carry torch.cdist's matmul noise."""
     tol = 2e-5
     sd = H.full_kernel_sd()
-    m = H.tw_kernel_model(sd, path=FUSED)
+    m = H.tw_kernel_model(sd, path=path)
     d, _ = H.load("kernel_full_v60")
     V = d["x_coords"].shape[1]
     assert V == 60

@@ -100,19 +100,19 @@ def test_execution_path_from_environment(monkeypatch):
         monkeypatch.setenv("TW_EXECUTION_PATH", name)
         assert tw.model_constructor(cfg).execution_path == want
     m = tw.model_constructor(cfg)
-    assert m._path_for(22) == _lib.TW_PATH_FUSED_H3 and m._path_for(60) == _lib.TW_PATH_AUTO
+    assert m._path_for(22) == _lib.TW_PATH_FUSED_H3 and m._path_for(60) == _lib.TW_PATH_FUSED_H3
     monkeypatch.setenv("TW_EXECUTION_PATH", "fp8")
     with pytest.raises(ValueError, match="TW_EXECUTION_PATH"):
         tw.model_constructor(cfg)
     # every molecule that fits a 48-token wave runs on the split-fp16 kernel (tw_flow_path_supported), the rest on AUTO
     monkeypatch.setenv("TW_EXECUTION_PATH", "h3")
-    assert [m._path_for(v) for v in (1, 7, 12, 17, 21, 30, 40, 48, 49, 64, 65)] == [3] * 8 + [0] * 3
+    assert [m._path_for(v) for v in (1, 7, 12, 17, 21, 30, 40, 48, 49, 64, 65, 160, 161, 200)] == [3] * 12 + [0] * 2
     # ... unless the score-fragment producer's LDS tile would not fit the CU: 48 atoms x 18 heads
     many = synthetic.kernel_transformer_nvp_config()
     many.custom_transformer_nvp_config.encoder_layer_config.lengthscales = [0.1 * (i + 1) for i in range(18)]
     many.custom_transformer_nvp_config.encoder_layer_config.num_heads = 18
     mm = tw.model_constructor(many)
-    assert mm._path_for(22) == 3 and mm._path_for(48) == 0
+    assert mm._path_for(22) == 3 and mm._path_for(48) == 0 and mm._path_for(60) == 3  # (wide: one head at a time)
 
 
 def test_holder_modules_refuse_to_compute():
@@ -293,11 +293,11 @@ def test_generated_asm_includes_are_current(tmp_path):
     env = {k: v for k, v in os.environ.items() if not k.startswith("H3_")}
     for args in (["tools/gen_h3_ffn_asm.py", "--shape=ffn"], ["tools/gen_h3_ffn_asm.py", "--shape=in"],
                  ["tools/gen_h3_ffn_asm.py", "--shape=out"], ["tools/gen_h3_attn_asm.py"],
-                 ["tools/gen_h3_attn_asm.py", "--mode=windowed"]):
+                 ["tools/gen_h3_attn_asm.py", "--mode=windowed"], ["tools/gen_h3_attn_wide_asm.py"]):
         subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
                        stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 10
+    assert len(names) == 12
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n

@@ -61,6 +61,15 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3D_LDS_BYTES (H3D_SIDE_LDS_OFFSET + H3D_SIDE_LDS_BYTES)
 #define H3D_INB 656
 #define H3D_OUTB 1040
+// "wide" layout (49 .. 160 atoms): a workgroup's 4 x 48 token slots hold floor(192 / V) whole molecules back to back, the
+// transposed copy of X is ONE tile shared by the workgroup over the four wave-private blocks (tools/gen_h3_attn_wide_asm.py)
+#define H3W_WAVE_LDS 28672
+#define H3W_XT_ROW 416                  // bytes per feature row: 192 tokens + 16 pad (104 dwords: conflict-free ds_read_b128)
+#define H3W_XT_LO (128 * H3W_XT_ROW)
+#define H3W_NG 5                        // K = 32 key groups in a wave's key window
+#define H3W_FRAG_HEAD (H3W_NG * H3_NT * 2048)  // score fragments of one (wave, head): [group][query tile][hi 1 KiB | lo 1 KiB]
+#define H3W_SIDE_LDS_OFFSET (H3_RING * H3_STAGE_BYTES + 4 * H3W_WAVE_LDS)
+#define H3W_LDS_BYTES (H3W_SIDE_LDS_OFFSET + H3_SIDE_LDS_BYTES)
 #define H3_TARGET_MAX 4096.0f       // |w| * 2^s is scaled up to just below this
 
 // stage sequence per net (each 9 KiB = 4 tile pairs + aux); the A and B stages of the chunked MLPs are
@@ -115,8 +124,42 @@ static size_t h3_sf_lds_bytes(int H, int V, int mpw) {
   return (MV * 3 + (size_t)H * MV * V + H) * 4 + MV + 32 * H3_NT;
 }
 
+// Wide layout: molecules per workgroup and, per wave, the byte offset of its key window in a row of the shared X^T tile.
+// Wave w's query tokens [48 w, 48 w + 48) touch the molecules overlapping that range; their keys span key tiles
+// first .. last; the window is H3W_NG groups of 32 keys from tile K0 = min(first, 12 - 2 NG) (it never leaves the 192
+// tokens).  false if a wave needs more than H3W_NG groups (V > 160) or the molecule does not fit a workgroup.
+struct H3Wide {
+  int mpwg;
+  int win[4];  // bytes: 32 * K0
+};
+static bool h3_wide_geom(int V, H3Wide* w) {
+  if (V <= 16 * H3_NT || V > 64 * H3_NT) return false;
+  w->mpwg = (64 * H3_NT) / V;
+  for (int wave = 0; wave < 4; ++wave) {
+    const int lo = 16 * H3_NT * wave, hi = lo + 16 * H3_NT - 1;
+    int m0 = lo / V, m1 = hi / V;
+    if (m1 >= w->mpwg) m1 = w->mpwg - 1;
+    int k0 = 0;
+    if (m0 <= m1) {
+      const int first = (m0 * V) / 16, last = ((m1 + 1) * V - 1) / 16;
+      if ((last - first + 2) / 2 > H3W_NG) return false;
+      k0 = first < 12 - 2 * H3W_NG ? first : 12 - 2 * H3W_NG;
+    }
+    w->win[wave] = 32 * k0;
+  }
+  return true;
+}
+static size_t h3w_sf_lds_bytes(int V, int mpwg) {
+  const size_t MV = (size_t)mpwg * V;
+  return (MV * 3 + MV * V) * 4 + MV + 16;
+}
+
 bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom fg;
+  H3Wide wd;
+  if (d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
+      h3_wide_geom(n_atoms, &wd))
+    return h3w_sf_lds_bytes(n_atoms, wd.mpwg) <= H3_SF_LDS_MAX;
   if (d.variant == 1)  // dense softmax attention: 8 heads of 16 = one MFMA tile each; no RFF features (input width <= 64)
     return d.d_model == 128 && d.n_heads == 8 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_rff == 0 &&
            d.d_emb + 9 <= 64 && fused_geom_nt(n_atoms, H3_NT, &fg);
@@ -485,6 +528,78 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
   }
 }
 
+// Wide layout: fragments of one head of one workgroup block.  grid (blocks, heads, basis variants).  Output per
+// (wave w, head h): H3W_NG groups x 3 query tiles x [hi | lo] KiB; element (lane, e) of (group gi, tile jt) =
+//   S[query token 48 w + 16 jt + (lane & 15)][key token 16 (K0_w + 2 gi) + 8 (lane >> 4) + e]
+// with S the block-diagonal matrix of the block's molecules' normalised scores (zero outside a molecule / masked keys).
+struct H3WideWin { int w[4]; };
+__global__ void h3w_score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
+                                      const float* __restrict__ ls, int H, int V, int mpwg, int64_t n_rows,
+                                      int64_t n_cond, int normalise, char* __restrict__ sfrag, ScoreBasis basis,
+                                      int64_t variant_bytes, int use_mm, H3WideWin win) {
+  extern __shared__ float sm[];
+  const int MV = mpwg * V;
+  float* xs = sm;                         // [MV][3]
+  float* E = xs + MV * 3;                 // [MV][V]: basis values, then normalised scores, of this head
+  uint8_t* msk = (uint8_t*)(E + MV * V);  // [MV]
+  const int64_t blk = blockIdx.x;
+  const int h = blockIdx.y;
+  const int nthr = blockDim.x, t = threadIdx.x;
+  for (int i = t; i < MV; i += nthr) {
+    const int q = i / V, a = i - q * V;
+    int64_t n = blk * mpwg + q;
+    if (n >= n_rows) n = n_rows - 1;
+    const int64_t src = (n % n_cond) * V + a;
+    xs[3 * i] = x[3 * src];
+    xs[3 * i + 1] = x[3 * src + 1];
+    xs[3 * i + 2] = x[3 * src + 2];
+    msk[i] = masked[src];
+  }
+  float cmean = 0.f;
+  const float* cf = nullptr;
+  if (basis.order > 0) cf = basis_coeffs(basis, blockIdx.z, h, &cmean);
+  __syncthreads();
+  const float lh = ls[h];
+  for (int i = t; i < MV * V; i += nthr) {
+    const int qa = i / V, m = i - qa * V;
+    const int q = qa / V;
+    const float dd = h3_pair_dist(xs + q * V * 3, qa - q * V, m, use_mm);
+    E[i] = msk[q * V + m] ? 0.f : basis_value(dd / lh, cf, basis.order, cmean);
+  }
+  __syncthreads();
+  for (int i = t; i < MV; i += nthr) {
+    float* row = E + (int64_t)i * V;
+    float sum = 0.f;
+    for (int m = 0; m < V; ++m) sum += fabsf(row[m]);
+    const float den = sum + 1e-5f;
+    if (normalise)
+      for (int m = 0; m < V; ++m) row[m] = row[m] / den;
+  }
+  __syncthreads();
+  char* out = sfrag + blockIdx.z * variant_bytes + blk * (int64_t)4 * H * H3W_FRAG_HEAD;
+  for (int i = t; i < 4 * H3W_NG * H3_NT * 64; i += nthr) {
+    const int lane = i & 63, rest = i >> 6;
+    const int jt = rest % H3_NT, gi = (rest / H3_NT) % H3W_NG, w = rest / (H3_NT * H3W_NG);
+    const int tq = 16 * H3_NT * w + 16 * jt + (lane & 15);
+    const int mq = tq / V;
+    const bool qok = mq < mpwg;
+    const float* row = E + (int64_t)(qok ? tq : 0) * V;  // row of (molecule mq, atom tq - mq V): index mq V + (tq - mq V) = tq
+    const int k0 = 16 * (win.w[w] / 32 + 2 * gi) + 8 * (lane >> 4);
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int tk = k0 + e;
+      const float val = (qok && tk / V == mq) ? row[tk - mq * V] : 0.f;
+      const _Float16 hh = (_Float16)val;
+      hi[e] = hh;
+      lo[e] = (_Float16)(val - (float)hh);
+    }
+    char* base = out + ((int64_t)(w * H + h) * (H3W_NG * H3_NT) + gi * H3_NT + jt) * 2048;
+    *(h8*)(base + lane * 16) = hi;
+    *(h8*)(base + 1024 + lane * 16) = lo;
+  }
+}
+
 // ================================================================================================
 // the kernel
 // ================================================================================================
@@ -502,6 +617,7 @@ struct H3Params {
   int sfrag_shared;
   int64_t sf_variant_bytes;  // chebyshev_kernel: bytes between the fragment sets of (net, layer) variants; else 0
   int windowed;              // block-diagonal mixing with per-tile key windows (h3_windowed); asm variant only
+  int win[4];                // wide layout: byte offset of each wave's key window in a row of the shared X^T tile
   float* out[2];
   float* dump;
   int64_t n_rows, n_cond;
@@ -897,12 +1013,15 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
 //                O^T[d][query] = V^T P^T on K = 32 (key tiles 0, 1) + K = 16 (tile 2) MFMAs -> standard orientation;
 //   per head pair: the two O tiles are one 32-deep k-step of out_proj:  y += W_o[:, 32 hp ..] . O
 // Nothing is transposed through memory and nothing leaves the registers.
-template <int NT, bool ASM, bool DENSE = false>
+// WIDE = true (kernel attention, asm sections only): molecules of 49 .. 160 atoms, packed back to back over the workgroup's
+// 192 token slots; token-local sections unchanged, attention through the shared X^T tile (tw_h3_attns_asm.inc).
+template <int NT, bool ASM, bool DENSE = false, bool WIDE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_h3_kernel(const H3Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int WAVE_LDS = DENSE ? H3D_WAVE_LDS : H3_WAVE_LDS;
-  constexpr int SIDE_LDS_OFFSET = DENSE ? H3D_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET;
+  static_assert(!WIDE || (ASM && !DENSE), "the wide layout exists for the asm build of the kernel-attention variant");
+  constexpr int WAVE_LDS = DENSE ? H3D_WAVE_LDS : (WIDE ? H3W_WAVE_LDS : H3_WAVE_LDS);
+  constexpr int SIDE_LDS_OFFSET = DENSE ? H3D_SIDE_LDS_OFFSET : (WIDE ? H3W_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET);
   constexpr int SIDE_CHUNKS = DENSE ? 5 : 3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -918,9 +1037,12 @@ netblock_h3_kernel(const H3Params p) {
     wg = blockIdx.x;
   }
   // every wave of the workgroup takes part in the weight pipeline, even if it owns no rows
+  // narrow layouts: wave-block blk holds p.mpw whole molecules; wide: workgroup wg holds p.mpw molecules over its 192 slots
   const int blk = wg * 4 + wave;
-  const bool active = blk < p.nblocks;
-  if (wg * 4 >= p.nblocks) return;  // whole workgroup idle (uniform)
+  const bool active = WIDE ? true : blk < p.nblocks;
+  if (WIDE ? wg >= p.nblocks : wg * 4 >= p.nblocks) return;  // whole workgroup idle (uniform)
+  const int64_t row0 = (WIDE ? (int64_t)wg : (int64_t)blk) * p.mpw;  // first conformation of this wave's / workgroup's block
+  const int slot0 = WIDE ? 16 * NT * wave : 0;                       // this wave's first token slot in the block
 
   const char* net_base = p.packed + (int64_t)net * p.net_stride_bytes;
   const float* side = (const float*)(net_base + p.stages * H3_STAGE_BYTES);
@@ -933,9 +1055,9 @@ netblock_h3_kernel(const H3Params p) {
   int tok_atom[NT];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
-    const int t = 16 * jt + i16;
+    const int t = slot0 + 16 * jt + i16;
     const int q = t / p.V;
-    const int64_t n = (int64_t)blk * p.mpw + q;
+    const int64_t n = row0 + q;
     const bool ok = active && q < p.mpw && n < p.n_rows;
     tok_row[jt] = ok ? n : -1;
     tok_atom[jt] = t - q * p.V;
@@ -975,6 +1097,32 @@ netblock_h3_kernel(const H3Params p) {
         for (int k = 0; k < 3; ++k) zo[jt][k] = p.z_other[idx + k];
       }
     }
+    if constexpr (WIDE) {
+      // molecules span waves: the tokens' partial sums meet in a workgroup-shared LDS array (192 floats at the start of
+      // the wave-private blocks, which nothing uses yet); wave 0 adds them up in atom order.  Both nets take the barriers.
+      if (p.prev.s_raw) {
+        float* scr = (float*)(lds + H3_RING * H3_STAGE_BYTES);
+        if (net == 0) {
+          if (bad) atomicOr(p.prev.nonfinite, 1);
+          if (g == 0) {
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) scr[slot0 + 16 * jt + i16] = part[jt];
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (net == 0 && wave == 0 && lane < p.mpw) {
+          const int64_t n = row0 + lane;
+          if (n < p.n_rows) {
+            float acc = 0.f;
+            for (int a = 0; a < p.V; ++a) acc += scr[lane * p.V + a];
+            p.prev.delta_logp[n] -= p.prev.reverse ? -acc : acc;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else
     if (p.prev.s_raw && net == 0) {
       // log-determinant per conformation: the tokens' partial sums through the (still unused) wave-private LDS block,
       // added up in atom order by one lane per molecule; delta_logp -= logdet (nvp.py:86)
@@ -1121,7 +1269,8 @@ netblock_h3_kernel(const H3Params p) {
   stamp(1);
 
   const char* sf_net = p.sfrag + (int64_t)(net * p.n_layers) * p.sf_variant_bytes +
-                       (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * H3_SF_BYTES);
+                       (WIDE ? (int64_t)((p.sfrag_shared ? 0 : wg * 4) + wave) * p.H * H3W_FRAG_HEAD
+                             : (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * H3_SF_BYTES));
 
   const float* sl = (const float*)(lds + SIDE_LDS_OFFSET);  // this layer's side block, staged in LDS
   // dense: which key tokens of the wave each of this lane's query tokens may attend to - the unmasked atoms of the
@@ -1157,7 +1306,25 @@ netblock_h3_kernel(const H3Params p) {
                                          (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
     }
     // x -> transposed fp16 hi/lo tile in LDS (operand of the mixing; the dense variant has none)
-    if constexpr (!DENSE) {
+    if constexpr (WIDE) {
+      // the workgroup's shared tile [feature][192 tokens] over the four wave-private blocks (every wave has passed the
+      // barrier above, so nobody still reads operands there); a barrier before anyone mixes against other waves' columns
+      char* xts = lds + H3_RING * H3_STAGE_BYTES;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = x[ft][jt][r];
+            const _Float16 hi = (_Float16)v;
+            const int off = (16 * ft + 4 * g + r) * H3W_XT_ROW + 2 * (slot0 + 16 * jt + i16);
+            *(_Float16*)(xts + off) = hi;
+            *(_Float16*)(xts + H3W_XT_LO + off) = (_Float16)(v - (float)hi);
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else if constexpr (!DENSE) {
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -1321,7 +1488,19 @@ netblock_h3_kernel(const H3Params p) {
       const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
       const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
       const int heads = __builtin_amdgcn_readfirstlane(p.H);
-      if (p.windowed) {
+      if constexpr (WIDE) {
+        // wide layout (tools/gen_h3_attn_wide_asm.py): mixing against the wave's key window of the shared X^T tile
+        const unsigned xt_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(lds + H3_RING * H3_STAGE_BYTES);
+        const int win = __builtin_amdgcn_readfirstlane(wave == 0 ? p.win[0] : wave == 1 ? p.win[1] : wave == 2 ? p.win[2] : p.win[3]);
+        asm volatile(
+#include "tw_h3_attns_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
+              [win] "s"(win)
+            :
+#include "tw_h3_attns_clobbers.inc"
+        );
+      } else if (p.windowed) {
         // two or more molecules per wave: 24 instead of 36 mixing MFMAs per k-step (gen_h3_attn_asm.py --mode=windowed)
         asm volatile(
 #include "tw_h3_attnw_asm.inc"
@@ -1571,9 +1750,23 @@ struct H3Ws {
   int64_t bytes;
 };
 
+// molecules per block and number of blocks for n_rows conformations: wave-blocks (<= 48 atoms) or workgroup blocks (wide)
+static bool h3_layout(int V, FusedGeom* fg, H3Wide* wd, bool* wide) {
+  *wide = h3_wide_geom(V, wd);
+  if (*wide) {
+    fg->nt = H3_NT;
+    fg->mpw = wd->mpwg;
+    fg->tile_mask = 0;
+    return true;
+  }
+  return fused_geom_nt(V, H3_NT, fg);
+}
+
 static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
   FusedGeom g;
-  fused_geom_nt(V, H3_NT, &g);
+  H3Wide wd;
+  bool wide = false;
+  h3_layout(V, &g, &wd, &wide);
   H3Ws w;
   char* p = (char*)base;
   auto take = [&](int64_t bytes) {
@@ -1591,8 +1784,10 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
   // chebyshev_kernel: one fragment set per (net, layer) of the coupling layer in flight
   // + one head of slack: the attention asm block prefetches the "next head" also after the last one
   const int64_t variants = d.cheb_order > 0 ? 2 * d.n_layers : 1;
-  w.sf_variant_bytes = d.variant == 1 ? 0 : nblocks * d.n_heads * H3_NT * H3_SF_BYTES;  // dense: no score fragments
-  w.sfrag = take(variants * w.sf_variant_bytes + H3_NT * H3_SF_BYTES);
+  if (d.variant == 1) w.sf_variant_bytes = 0;  // dense: no score fragments
+  else if (wide) w.sf_variant_bytes = nblocks * 4 * d.n_heads * H3W_FRAG_HEAD;
+  else w.sf_variant_bytes = nblocks * d.n_heads * H3_NT * H3_SF_BYTES;
+  w.sfrag = take(variants * w.sf_variant_bytes + (wide ? H3W_FRAG_HEAD : H3_NT * H3_SF_BYTES));
   w.bytes = p - (char*)base;
   return w;
 }
@@ -1636,7 +1831,10 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.sfrag = sfrag;
   p.sfrag_shared = shared ? 1 : 0;
   p.sf_variant_bytes = sf_variant_bytes;
-  p.windowed = h3_windowed(fg, a.n_atoms) ? 1 : 0;
+  H3Wide wd{};
+  const bool wide = d.variant == 0 && h3_wide_geom(a.n_atoms, &wd);
+  p.windowed = (!wide && h3_windowed(fg, a.n_atoms)) ? 1 : 0;
+  for (int i = 0; i < 4; ++i) p.win[i] = wide ? wd.win[i] : 0;
   p.out[0] = s_out;
   p.out[1] = t_out;
   p.dump = dump;
@@ -1655,16 +1853,19 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.debug = g_debug_flags;
   p.masked = a.masked;
   p.prev = prev;
-  const int wgs_per_net = (p.nblocks + 3) / 4;
+  const int wgs_per_net = wide ? p.nblocks : (p.nblocks + 3) / 4;  // wide: one block per workgroup
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
-  static LdsLimit lim_asm, lim_cpp, lim_dense, lim_dense_cpp;
+  static LdsLimit lim_asm, lim_cpp, lim_dense, lim_dense_cpp, lim_wide;
   int prc;
   if ((prc = lim_asm.ensure((const void*)netblock_h3_kernel<H3_NT, true>, (int)H3_LDS_BYTES))) return prc;
   if ((prc = lim_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false>, (int)H3_LDS_BYTES))) return prc;
   if ((prc = lim_dense.ensure((const void*)netblock_h3_kernel<H3_NT, true, true>, (int)H3D_LDS_BYTES))) return prc;
   if ((prc = lim_dense_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false, true>, (int)H3D_LDS_BYTES))) return prc;
+  if ((prc = lim_wide.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
-  if (d.variant == 1) {
+  if (wide) {
+    hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+  } else if (d.variant == 1) {
     if (g_debug_flags & 8)
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
     else
@@ -1686,6 +1887,26 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
   const int V = a.n_atoms;
   const int64_t nblocks = shared ? 1 : (a.n_rows + fg.mpw - 1) / fg.mpw;
   const ScoreBasis basis = score_basis(d, L, a.raw, c);
+  H3Wide wd;
+  if (h3_wide_geom(V, &wd)) {
+    const int64_t vbw = basis.n_variants > 1 ? nblocks * 4 * d.n_heads * H3W_FRAG_HEAD : 0;
+    const float* lsw = a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0);
+    const size_t shmw = h3w_sf_lds_bytes(V, wd.mpwg);
+    TW_REQUIRE(shmw <= H3_SF_LDS_MAX, "score fragments: %zu bytes of LDS for %d atoms", shmw, V);
+    if (shmw > (size_t)64 * 1024) {
+      static LdsLimit limw;
+      int lrc;
+      if ((lrc = limw.ensure((const void*)h3w_score_frag_kernel, (int)H3_SF_LDS_MAX))) return lrc;
+    }
+    H3WideWin win;
+    for (int i = 0; i < 4; ++i) win.w[i] = wd.win[i];
+    hipLaunchKernelGGL(h3w_score_frag_kernel, dim3((unsigned)nblocks, (unsigned)d.n_heads, (unsigned)basis.n_variants), dim3(512),
+                       shmw, a.stream, a.x_coords, a.masked, lsw, d.n_heads, V, wd.mpwg, a.n_rows, a.n_cond, d.normalise, w.sfrag,
+                       basis, vbw, V > 25 ? 1 : 0, win);
+    TW_LAUNCH_CHECK();
+    *variant_bytes = vbw;
+    return TW_OK;
+  }
   const int64_t vb = basis.n_variants > 1 ? nblocks * d.n_heads * H3_NT * H3_SF_BYTES : 0;
   const unsigned nv = (unsigned)basis.n_variants;
   const float* ls = a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0);
@@ -1708,7 +1929,10 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
 int flow_pass_h3(const FlowArgs& a) {
   const tw_flow_desc& d = *a.desc;
   FusedGeom fg;
-  TW_REQUIRE(fused_geom_nt(a.n_atoms, H3_NT, &fg), "split-fp16 path: unsupported atom count %d", a.n_atoms);
+  H3Wide wdg;
+  bool wide_layout = false;
+  TW_REQUIRE(h3_layout(a.n_atoms, &fg, &wdg, &wide_layout) && !(wide_layout && d.variant != 0),
+             "split-fp16 path: unsupported atom count %d", a.n_atoms);
   const RawLayout L = raw_layout(d);
   const H3Ws w = h3_ws(d, a.n_rows, a.n_atoms, a.ws);
   if (w.bytes > a.ws_bytes) {
@@ -1773,7 +1997,10 @@ int flow_pass_h3(const FlowArgs& a) {
 int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, float* dump) {
   const tw_flow_desc& d = *a.desc;
   FusedGeom fg;
-  TW_REQUIRE(fused_geom_nt(a.n_atoms, H3_NT, &fg), "split-fp16 path: unsupported atom count %d", a.n_atoms);
+  H3Wide wdg;
+  bool wide_layout = false;
+  TW_REQUIRE(h3_layout(a.n_atoms, &fg, &wdg, &wide_layout) && !(wide_layout && d.variant != 0),
+             "split-fp16 path: unsupported atom count %d", a.n_atoms);
   const RawLayout L = raw_layout(d);
   const H3Ws w = h3_ws(d, a.n_rows, a.n_atoms, a.ws);
   if (w.bytes > a.ws_bytes) {
