@@ -51,7 +51,7 @@ def sq(dirs, out):
             if "netblock_h3" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     waves = 1000.0
-    lines = ["# SQ counters, `tw::netblock_h3_kernel<3, true>` (r02 build)", "",
+    lines = ["# SQ counters, `tw::netblock_h3_kernel<3, true>` (r03 build)", "",
              "`bash tools/profile_round.sh` on the GPU box: four `rocprofv3 --kernel-trace --pmc <4 counters> --kernel-include-regex "
              "netblock_h3` passes over `python tools/time_flow.py --iters 2 --paths 3` (1000-proposal alanine-dipeptide flow passes). "
              "Averages per launch divided by the 1000 waves of a launch; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles, "
