@@ -620,11 +620,13 @@ def test_fused_iteration_equals_op_by_op_route(monkeypatch, random_velocs, chira
         assert np.array_equal(getattr(a[3], f), getattr(b[3], f)), f
 
 
-def test_mh_iterations_on_a_65_atom_peptide_vs_oracle():
+@pytest.mark.parametrize("path", [0, 3])
+def test_mh_iterations_on_a_65_atom_peptide_vs_oracle(path):
     """The tetrapeptide NNQQ of the reference's own OpenMM test data (65 atoms, amber99sb-ildn + GBSA-OBC tables pinned by
     that file, tests/test_energy_kat.py): whole MH iterations with the full-size flow - above 64 atoms TW_PATH_AUTO runs
-    the per-op kernels (scores from torch.cdist's matmul branch) - through tw_mh_iteration, against the oracle loop and
-    the C energy oracle on shared host noise.  The BASELINE tetrapeptide configuration's MH half on a real molecule."""
+    the per-op kernels, the split-fp16 kernel its wide layout with two molecules per workgroup (scores from torch.cdist's
+    matmul branch either way) - through tw_mh_iteration, against the oracle loop and the C energy oracle on shared host
+    noise.  The BASELINE tetrapeptide configuration's MH half on a real molecule."""
     from tests.test_energy_kat import kat, kat_tables
     from timewarp_amd.dataloader import single_state_batch
     from timewarp_amd.energy import AmberPotentialEnergyTorch
@@ -645,12 +647,48 @@ def test_mh_iterations_on_a_65_atom_peptide_vs_oracle():
     ref = mo.sample_with_model(types[None], coords[None], torch.zeros(1, 65, 3), torch.zeros(1, 65, dtype=torch.bool),
                                mo.OracleModel(sd, H.FULL_KERNEL_SPEC), H.OracleAmberEnergy(tables), masses, N,
                                H.HostNoise(2), **kw)
-    model = H.tw_kernel_model(sd, path=0)
+    model = H.tw_kernel_model(sd, path=path)
     dev = torch.device("cuda")
     chain = MetropolisHastingsChain(single_state_batch("nnqq", types, coords), model, dev, energy, masses,
                                     noise=H.HostNoise(2, "cuda"), **kw)
-    assert chain._fused and model._path_for(65) == 0
+    assert chain._fused and model._path_for(65) == path
     got = sample_with_model(single_state_batch("nnqq", types, coords), model, dev, energy, masses, N, disable_tqdm=True,
                             noise=H.HostNoise(2, "cuda"), **kw)
     assert ref[2] >= 1
+    H.assert_not_demoted(model)
     _assert_chain_matches_oracle(got, ref, tol=2e-5, stat_tol=2e-4)
+
+
+@pytest.mark.parametrize("path", [1, 3])
+def test_dense_flow_mh_iterations_vs_oracle(path):
+    """BASELINE config 4 as a sampler: whole MH iterations with the full-size dense-softmax flow (transformer_nvp) on the
+    fused f32 and the split-fp16 dense kernels through tw_mh_iteration, AMBER energy kernel, alanine dipeptide, 64
+    proposals, against the oracle loop on shared host noise (coupling nets scaled so that proposals are accepted)."""
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.utils.evaluation_utils import MetropolisHastingsChain, sample_with_model
+
+    sd = dict(H.full_dense_sd())
+    for k in sd:
+        if ".out_mlp._layers.2." in k:
+            sd[k] = sd[k] * 1e-4
+    sd["coords_prior_log_scale"] = torch.tensor(-7.0)
+    sd["velocs_prior_log_scale"] = torch.tensor(0.0)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    energy = AmberPotentialEnergyTorch.alanine_dipeptide()
+    S, N = 64, 130
+    kw = dict(accept=True, num_proposal_steps=S, random_velocs=True, resample_velocs=True)
+    ref = mo.sample_with_model(types[None], coords[None], torch.zeros(1, 22, 3), torch.zeros(1, 22, dtype=torch.bool),
+                               mo.OracleModel(sd, H.FULL_DENSE_SPEC), H.OracleAmberEnergy(energy.tables), masses, N,
+                               H.HostNoise(6), **kw)
+    model = H.tw_dense_model(sd, path=path)
+    dev = torch.device("cuda")
+    chain = MetropolisHastingsChain(single_state_batch("ad", types, coords), model, dev, energy, masses,
+                                    noise=H.HostNoise(6, "cuda"), **kw)
+    assert chain._fused
+    got = sample_with_model(single_state_batch("ad", types, coords), model, dev, energy, masses, N, disable_tqdm=True,
+                            noise=H.HostNoise(6, "cuda"), **kw)
+    assert ref[2] >= 1
+    H.assert_not_demoted(model)
+    _assert_chain_matches_oracle(got, ref, tol=1e-5, stat_tol=2e-4)

@@ -28,6 +28,16 @@ class AmberPotentialEnergyTorch:
         return cls(alanine_dipeptide_amber99sb(), temperature)
 
     @classmethod
+    def from_preset(cls, preset_or_dataset: str, atom_names, residue_names, residue_ids, temperature: float = 310.0):
+        """The energy of `get_system(model, preset)` (simulation/md.py:128-187) without OpenMM: `preset_or_dataset` as in
+        md.py:31-37 ("alanine-dipeptide", "T1-peptides", "T1B-peptides", ...), the topology as per-atom names, residue
+        names and residue ids.  amber99sb-ildn + OBC II is pinned by the reference's known-answer file; amber14 + OBC I
+        ("T1B-peptides", the 4AA preset) is PARITY UNPINNED and limited to ACE / NME / ALA / GLY (forcefield.py)."""
+        from .forcefield import tables_for_preset
+
+        return cls(tables_for_preset(preset_or_dataset, atom_names, residue_names, residue_ids), temperature)
+
+    @classmethod
     def from_openmm(cls, system, integrator=None, platform_name=None, platform_properties=None, **_):
         """Same positional arguments as OpenmmPotentialEnergyTorch(system, integrator, platform_name=...)
         (evaluate.py:296-301); the platform arguments are irrelevant here and ignored."""

@@ -239,10 +239,14 @@ def _improper(centre: int, nb: List[int], ty: List[str], el: List[str]):
 
 
 def amber99sbildn_obc_tables(atom_names: Sequence[str], residue_names: Sequence[str],
-                             residue_ids: Sequence[int]) -> ForceFieldTables:
+                             residue_ids: Sequence[int], family: str = "amber99") -> ForceFieldTables:
     """Tables of `ForceField("amber99sbildn.xml", "amber99_obc.xml").createSystem(topology, CutoffNonPeriodic, 2 nm,
     constraints=None)` (simulation/md.py:150-173) for a single chain made of the residues in `RESIDUES`, atoms in any
-    order.  A first residue carrying H2/H3 selects the NH3+ variant, a last residue carrying OXT the COO- variant."""
+    order.  A first residue carrying H2/H3 selects the NH3+ variant, a last residue carrying OXT the COO- variant.
+    `family="amber14"`: the amber14-all + implicit/obc1 preset instead (amber14_obc1_tables below: parity UNPINNED)."""
+    fam = _FAMILIES[family]
+    RESIDUES, _TORSION_SPECIFIC, _TORSION_GENERIC = fam["residues"], fam["torsion_specific"], fam["torsion_generic"]
+    parent = fam["parent_type"]  # ff14SB's renamed carbon types keep their parm99 parents' bond / angle / LJ numbers
     n = len(atom_names)
     rids = list(dict.fromkeys(residue_ids))
     index = {(r, a): i for i, (a, r) in enumerate(zip(atom_names, residue_ids))}
@@ -259,7 +263,7 @@ def amber99sbildn_obc_tables(atom_names: Sequence[str], residue_names: Sequence[
         if pos == len(rids) - 1 and "OXT" in have:
             key = "C" + res
         if key not in RESIDUES:
-            raise NotImplementedError(f"no amber99sb-ildn template for residue {key!r} (have {sorted(RESIDUES)})")
+            raise NotImplementedError(f"no {fam['label']} template for residue {key!r} (have {sorted(RESIDUES)})")
         tpl = RESIDUES[key]
         if have != set(tpl["names"]):
             raise ValueError(f"residue {key} {rid}: atoms {sorted(have)} do not match the template {sorted(tpl['names'])}")
@@ -275,13 +279,13 @@ def amber99sbildn_obc_tables(atom_names: Sequence[str], residue_names: Sequence[
     nb = _neighbours(n, bonds)
     bond_par = []
     for i, j in bonds:
-        k, r0 = _BOND[tuple(sorted((ty[i], ty[j])))]
+        k, r0 = _BOND[tuple(sorted((parent(ty[i]), parent(ty[j]))))]
         bond_par.append((r0 * 0.1, 2.0 * k * KCAL * 100.0))
     angle_idx, angle_par = [], []
     for j in range(n):
         for i, k in combinations(sorted(nb[j]), 2):
-            a, c = sorted((ty[i], ty[k]))
-            kk, t0 = _ANGLE[(a, ty[j], c)]
+            a, c = sorted((parent(ty[i]), parent(ty[k])))
+            kk, t0 = _ANGLE[(a, parent(ty[j]), c)]
             angle_idx.append((i, j, k))
             angle_par.append((math.radians(t0), 2.0 * kk * KCAL))
     torsion_idx, torsion_par, pairs14 = [], [], set()
@@ -294,7 +298,7 @@ def amber99sbildn_obc_tables(atom_names: Sequence[str], residue_names: Sequence[
                     continue
                 pairs14.add((min(a, d), max(a, d)))
                 terms = None
-                if local[b] == "ASN" and residue_ids[a] == residue_ids[b] == residue_ids[c] == residue_ids[d]:
+                if fam["asn_fitted"] and local[b] == "ASN" and residue_ids[a] == residue_ids[b] == residue_ids[c] == residue_ids[d]:
                     nm4 = (atom_names[a], atom_names[b], atom_names[c], atom_names[d])
                     terms = _ASN_FITTED_TORSIONS.get(nm4) or _ASN_FITTED_TORSIONS.get(nm4[::-1])
                 if terms is None:
@@ -307,15 +311,15 @@ def amber99sbildn_obc_tables(atom_names: Sequence[str], residue_names: Sequence[
                     torsion_par.append((float(per), math.radians(phase), kk * KCAL))
     for c in range(n):
         if len(nb[c]) == 3:
-            imp = _improper(c, nb[c], ty, el)
+            imp = _improper(c, nb[c], [parent(t) for t in ty], el)
             if imp is not None:
                 torsion_idx.append(imp[0])
                 torsion_par.append((2.0, math.pi, imp[1] * KCAL))
-    sigma = [_LJ[t][0] * 2.0 / 2.0 ** (1.0 / 6.0) * 0.1 for t in ty]
-    eps = [_LJ[t][1] * KCAL for t in ty]
+    sigma = [_LJ[parent(t)][0] * 2.0 / 2.0 ** (1.0 / 6.0) * 0.1 for t in ty]
+    eps = [_LJ[parent(t)][1] * KCAL for t in ty]
     atom_par = []
     for i in range(n):
-        rad = _gb_radius(el[i], len(nb[i]), el[nb[i][0]])
+        rad = fam["gb_radius"](el[i], len(nb[i]), el[nb[i][0]])
         atom_par.append((q[i], sigma[i], eps[i], rad, _GB_SCALE[el[i]]))
     # exceptions: 1-2 and 1-3 fully excluded, 1-4 scaled (Coulomb 1/1.2, LJ 1/2)
     excl = set()
@@ -335,8 +339,103 @@ def amber99sbildn_obc_tables(atom_names: Sequence[str], residue_names: Sequence[
     g = lambda a, w: np.asarray(a, dtype=np.int32).reshape(-1, w)
     # GBSAOBCForce's own default solvent dielectric (78.3; createSystem does not override it), surface term 2.25936
     return ForceFieldTables(g(bonds, 2), f(bond_par, 2), g(angle_idx, 3), f(angle_par, 2), g(torsion_idx, 4),
-                            f(torsion_par, 3), g(exc_idx, 2), f(exc_par, 3), f(atom_par, 5), has_gbsa=1,
-                            solvent_dielectric=78.3)
+                            f(torsion_par, 3), g(exc_idx, 2), f(exc_par, 3), f(atom_par, 5), has_gbsa=fam["has_gbsa"],
+                            solvent_dielectric=fam["solvent_dielectric"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# amber14-all (ff14SB) + implicit/obc1 (GBSA-OBC I): the `T1B-peptides` / 4AA / 2AA preset, simulation/md.py:31-32, 153-159
+#
+# PARITY UNPINNED.  The reference holds no known-answer data for this preset and OpenMM's XML files are not available
+# offline, so nothing below could be checked against OpenMM.  What is here is ff14SB as published, for the residues whose
+# parameters could be written down with confidence, and nothing else:
+#   * residues ACE, NME, ALA, GLY and the charged-terminus forms NALA / CALA / NGLY / CGLY.  ff14SB keeps the ff94 charges
+#     and the parm99 bond / angle / van der Waals numbers; it renames the alpha carbon CX (same bond, angle, LJ parameters
+#     as CT) and refits side-chain torsions PER RESIDUE - which is why no residue with a rotatable side chain is offered:
+#     ASN / GLN (the 99SB-ILDN entries above) and every other residue raise NotImplementedError under this family.
+#   * backbone torsions of frcmod.ff14SB: phi and psi as in ff99SB; phi' (C-N-CX-CT) 0.8 / 1.8 / 2.0 kcal/mol for n = 3 / 2 / 1
+#     and psi' (CT-CX-C-N) 0.4 / 0.2 / 0.2, all with phase 0 - RECALLED values, the least certain numbers in this file.
+#   * GBSA-OBC I: alpha = 0.8, beta = 0, gamma = 2.909125 in the kernel and the C oracle (has_gbsa = 2, equal at 1e-10); the
+#     mbondi2 radii AMBER prescribes for igb = 2 (H 0.12 nm, 0.13 on nitrogen; C 0.17; N 0.155; O 0.15), the OBC scale
+#     factors by element (the ones the known-answer file pins for OBC II), solvent dielectric 78.5.  Which radius set
+#     OpenMM's implicit/obc1.xml actually assigns is NOT known here.
+# What can be checked is checked in tests/test_host_logic.py: every template is neutral / +-1, every type resolves, the
+# amber14 tables of alanine dipeptide differ from the pinned amber99 ones ONLY in the phi' / psi' series, the GB mode and the
+# GB radii.  With OpenMM present, `tables_from_openmm_system` is the route that needs none of this.
+# ---------------------------------------------------------------------------------------------------
+def _gb_radius_mbondi2(element: str, n_bonds: int, partner_element: str) -> float:
+    if element == "H":
+        return 0.13 if partner_element == "N" else 0.12
+    return {"C": 0.17, "N": 0.155, "O": 0.15}[element]
+
+
+_GLY_BONDS = "N-H N-CA CA-HA2 CA-HA3 CA-C C-O"
+_RESIDUES_FF14SB = {
+    "ACE": RESIDUES["ACE"],
+    "NME": RESIDUES["NME"],
+    "ALA": _res("N H CX H1 CT HC HC HC C O",
+                [-0.4157, 0.2719, 0.0337, 0.0823, -0.1825, 0.0603, 0.0603, 0.0603, 0.5973, -0.5679],
+                "N H CA HA CB HB1 HB2 HB3 C O", _BB + "CB-HB1 CB-HB2 CB-HB3"),
+    "GLY": _res("N H CX H1 H1 C O", [-0.4157, 0.2719, -0.0252, 0.0698, 0.0698, 0.5973, -0.5679],
+                "N H CA HA2 HA3 C O", _GLY_BONDS),
+    "NALA": _res("N3 H H H CX HP CT HC HC HC C O",
+                 [0.1414, 0.1997, 0.1997, 0.1997, 0.0962, 0.0889, -0.0597, 0.0300, 0.0300, 0.0300, 0.6163, -0.5722],
+                 "N H H2 H3 CA HA CB HB1 HB2 HB3 C O", _BB + "N-H2 N-H3 CB-HB1 CB-HB2 CB-HB3"),
+    "CALA": _res("N H CX H1 CT HC HC HC C O2 O2",
+                 [-0.3821, 0.2681, -0.1747, 0.1067, -0.2093, 0.0764, 0.0764, 0.0764, 0.7731, -0.8055, -0.8055],
+                 "N H CA HA CB HB1 HB2 HB3 C O OXT", _BB + "C-OXT CB-HB1 CB-HB2 CB-HB3"),
+    "NGLY": _res("N3 H H H CX HP HP C O", [0.2943, 0.1642, 0.1642, 0.1642, -0.0100, 0.0895, 0.0895, 0.6163, -0.5722],
+                 "N H H2 H3 CA HA2 HA3 C O", _GLY_BONDS + " N-H2 N-H3"),
+    "CGLY": _res("N H CX H1 H1 C O2 O2", [-0.3821, 0.2681, -0.2493, 0.1056, 0.1056, 0.7231, -0.7855, -0.7855],
+                 "N H CA HA2 HA3 C O OXT", _GLY_BONDS + " C-OXT"),
+}
+_TORSION_SPECIFIC_FF14SB = {
+    ("C", "N", "CX", "C"): [(0.42, 0.0, 3), (0.27, 0.0, 2)],                        # phi  (as ff99SB)
+    ("N", "CX", "C", "N"): [(0.55, 180.0, 3), (1.58, 180.0, 2), (0.45, 180.0, 1)],  # psi  (as ff99SB)
+    ("C", "N", "CX", "CT"): [(0.80, 0.0, 3), (1.80, 0.0, 2), (2.00, 0.0, 1)],       # phi' (ff14SB; recalled)
+    ("CT", "CX", "C", "N"): [(0.40, 0.0, 3), (0.20, 0.0, 2), (0.20, 0.0, 1)],       # psi' (ff14SB; recalled)
+    ("H", "N", "C", "O"): [(2.50, 180.0, 2), (2.00, 0.0, 1)],
+    ("HC", "CT", "C", "O"): [(0.80, 0.0, 1), (0.08, 180.0, 3)],
+    ("H1", "CX", "C", "O"): [(0.80, 0.0, 1), (0.08, 180.0, 3)],
+    ("HC", "CT", "CX", "H1"): [(1.40 / 9.0, 0.0, 3)],
+}
+_TORSION_GENERIC_FF14SB = {
+    ("C", "N"): [(2.50, 180.0, 2)],
+    ("CT", "CX"): [(1.40 / 9.0, 0.0, 3)],      # X-CT-CX-X as X-CT-CT-X
+    ("C", "CT"): [], ("C", "CX"): [],
+    ("CT", "N"): [], ("CX", "N"): [],
+    ("CX", "N3"): [(1.40 / 9.0, 0.0, 3)],
+}
+_FAMILIES = {
+    "amber99": dict(label="amber99sb-ildn", residues=RESIDUES, torsion_specific=_TORSION_SPECIFIC,
+                    torsion_generic=_TORSION_GENERIC, parent_type=lambda t: t, asn_fitted=True, gb_radius=_gb_radius,
+                    has_gbsa=1, solvent_dielectric=78.3),  # GBSAOBCForce's own default (createSystem does not override it)
+    "amber14": dict(label="amber14 (ff14SB, parity unpinned)", residues=_RESIDUES_FF14SB,
+                    torsion_specific=_TORSION_SPECIFIC_FF14SB, torsion_generic=_TORSION_GENERIC_FF14SB,
+                    parent_type=lambda t: "CT" if t == "CX" else t, asn_fitted=False, gb_radius=_gb_radius_mbondi2,
+                    has_gbsa=2, solvent_dielectric=78.5),
+}
+PRESET_FAMILY = {  # simulation/md.py:31-37 (dataset -> preset) and :153-159 (preset -> force-field files)
+    "T1B-peptides": "amber14", "amber14-implicit": "amber14",
+    "T1-peptides": "amber99", "HP-1400": "amber99", "HP-4000": "amber99", "alanine-dipeptide": "amber99",
+    "amber99-implicit-old": "amber99", "amber99-implicit": "amber99",
+}
+
+
+def amber14_obc1_tables(atom_names: Sequence[str], residue_names: Sequence[str], residue_ids: Sequence[int]) -> ForceFieldTables:
+    """amber14-all + implicit/obc1 tables (the T1B-peptides / 4AA preset) for chains of ACE / NME / ALA / GLY (+ charged
+    termini).  PARITY UNPINNED - see the section comment; other residues raise NotImplementedError."""
+    return amber99sbildn_obc_tables(atom_names, residue_names, residue_ids, family="amber14")
+
+
+def tables_for_preset(preset_or_dataset: str, atom_names: Sequence[str], residue_names: Sequence[str],
+                      residue_ids: Sequence[int]) -> ForceFieldTables:
+    """The reference's `get_system(model, preset)` (simulation/md.py:128-187) without OpenMM: tables for a dataset or
+    preset name and a topology given as per-atom (name, residue name, residue id)."""
+    if preset_or_dataset not in PRESET_FAMILY:
+        raise ValueError(f"unknown dataset / preset {preset_or_dataset!r} (known: {sorted(PRESET_FAMILY)}); explicit-solvent "
+                         "presets (amber14-explicit) are periodic and not supported")
+    return amber99sbildn_obc_tables(atom_names, residue_names, residue_ids, family=PRESET_FAMILY[preset_or_dataset])
 
 
 def alanine_dipeptide_amber99sb() -> ForceFieldTables:
