@@ -700,6 +700,10 @@ __device__ __forceinline__ float h3_quad_sum(float v) {
   return a + b;
 }
 
+// sum over the four lanes that share (lane & 15): same association as the former __shfl_xor(16) / __shfl_xor(32) pair
+// ((a + b) in both partners, then the two pair sums), so the LayerNorms are bit-identical - without the two LDS round trips
+__device__ __forceinline__ float h3_xor_sum(float v) { return h3_quad_sum(v); }
+
 template <int NT, int KS>
 __device__ __forceinline__ void to_bop(const f4 (&x)[2 * KS][NT], BOp<NT> (&b)[KS]) {
 #pragma unroll
@@ -761,11 +765,7 @@ __device__ __forceinline__ void h3_load_sf3(const char* p16, const char* p8, u4 
       : "memory");
 }
 
-__device__ __forceinline__ float h3_xor_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
+
 
 template <int NT>
 __device__ __forceinline__ void h3_add_layernorm(f4 (&x)[8][NT], const f4 (&y)[8][NT], const float* lnw_lane,
@@ -1325,6 +1325,8 @@ netblock_h3_kernel(const H3Params p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     } else if constexpr (!DENSE) {
+      // (pairing two tokens per store through DPP - half the LDS stores - was built and measured: 5.0 k -> 8.4 k cycles per
+      // layer, the extra VALU and exec masking cost more than the store port saves; profiles/r03_ab_glue.txt)
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
