@@ -319,18 +319,38 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
           // dense: in_proj [384, 128] (one scale) as per-head stages q_h | k_h | v_h of four k-steps each, and after every
           // second head the k-step of out_proj [128, 128] (second scale) those two heads feed
           float* osc = sl + 642;
-          if ((rc = absmax(lb + L.layer.in_w, (int64_t)384 * 128, up, lsc + 0))) return rc;
-          for (int h = 0; h < d.n_heads; ++h)
-            for (int part = 0; part < 3; ++part) {
-              char* a = st + (int64_t)((h / 2) * 8 + (h % 2) * 3 + part) * H3_STAGE_BYTES;
-              if ((rc = block(lb + L.layer.in_w, 128, 384, 128, part * 128 + 16 * h, 0, 1, 4, up, a))) return rc;
+          // stage order = consumption order of the attention section (tools/gen_h3_dense_attn_asm.py): q_0 k_0, then per
+          // head h: v_h, q_{h+1} k_{h+1} (while the softmax of head h runs), and after an odd h the out_proj k-step of its pair
+          std::vector<std::pair<int, int>> order;  // (kind 0 q / 1 k / 2 v / 3 out_proj, head or 2 * pair + half)
+          order.push_back({0, 0});
+          order.push_back({1, 0});
+          for (int h = 0; h < d.n_heads; ++h) {
+            order.push_back({2, h});
+            if (h + 1 < d.n_heads) {
+              order.push_back({0, h + 1});
+              order.push_back({1, h + 1});
             }
-          if ((rc = absmax(lb + L.layer.out_w, (int64_t)128 * 128, up, osc))) return rc;
-          for (int hp = 0; hp < d.n_heads / 2; ++hp)
-            for (int hf = 0; hf < 2; ++hf) {
-              char* b = st + (int64_t)(hp * 8 + 6 + hf) * H3_STAGE_BYTES;
-              if ((rc = block(lb + L.layer.out_w, 128, 128, 128, 64 * hf, 32 * hp, 4, 1, up, b))) return rc;
+            if (h % 2 == 1) {
+              order.push_back({3, 2 * (h / 2)});
+              order.push_back({3, 2 * (h / 2) + 1});
             }
+          }
+          for (int pass = 0; pass < 2; ++pass) {  // pass 0: in_proj stages (scale of in_proj in `up`), pass 1: out_proj stages
+            if (pass == 0) {
+              if ((rc = absmax(lb + L.layer.in_w, (int64_t)384 * 128, up, lsc + 0))) return rc;
+            } else {
+              if ((rc = absmax(lb + L.layer.out_w, (int64_t)128 * 128, up, osc))) return rc;
+            }
+            for (size_t i = 0; i < order.size(); ++i) {
+              char* a = st + (int64_t)i * H3_STAGE_BYTES;
+              const int kind = order[i].first, idx = order[i].second;
+              if (pass == 0 && kind < 3) {
+                if ((rc = block(lb + L.layer.in_w, 128, 384, 128, kind * 128 + 16 * idx, 0, 1, 4, up, a))) return rc;
+              } else if (pass == 1 && kind == 3) {
+                if ((rc = block(lb + L.layer.out_w, 128, 128, 128, 64 * (idx % 2), 32 * (idx / 2), 4, 1, up, a))) return rc;
+              }
+            }
+          }
           st += (int64_t)4 * d.n_heads * H3_STAGE_BYTES;
           if ((rc = copy(lb + L.layer.in_b, 384, sl + H3D_INB, 384))) return rc;
           if ((rc = copy(lb + L.layer.out_b, 128, sl + H3D_OUTB, 128))) return rc;
@@ -1348,57 +1368,89 @@ netblock_h3_kernel(const H3Params p) {
       for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
 
     stamp(40 + 4 * l + 0);
-    if constexpr (DENSE) {
+    if constexpr (DENSE && ASM) {
+      // Hand-scheduled dense-softmax attention block (tools/gen_h3_dense_attn_asm.py): the split activations in through the
+      // wave-private LDS block, y back the same way; biases and the in_proj scale from the layer's side block in LDS
+      // (landed: the first stage hand-off inside the block lies between its DMA and the first read).
+      static_assert(NT == 3, "key tiles 0, 1 form the K = 32 part of P.V, tile 2 the K = 16 part");
+      BOp<NT> xb[4];
+      to_bop<NT, 4>(x, xb);
+      char* priv = (char*)xt_hi;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          *(h8*)(priv + ((ks * NT + jt) * 2) * 1024 + lane * 16) = xb[ks].h[jt];
+          *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = xb[ks].l[jt];
+        }
+      int cur = __builtin_amdgcn_readfirstlane(pipe.cur);
+      const char* gn = pipe.gnext;
+      const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+      const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
+      const unsigned sl_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(lds + SIDE_LDS_OFFSET);
+      const unsigned m0l = (unsigned)kvalid[0], m0h = (unsigned)(kvalid[0] >> 32), m1l = (unsigned)kvalid[1],
+                     m1h = (unsigned)(kvalid[1] >> 32), m2l = (unsigned)kvalid[2], m2h = (unsigned)(kvalid[2] >> 32);
+      asm volatile(
+#include "tw_h3_attnd_asm.inc"
+          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [sl] "s"(sl_lds), [m0l] "v"(m0l), [m0h] "v"(m0h),
+            [m1l] "v"(m1l), [m1h] "v"(m1h), [m2l] "v"(m2l), [m2h] "v"(m2h)
+          :
+#include "tw_h3_attnd_clobbers.inc"
+      );
+      pipe.cur = cur;
+      pipe.gnext = gn;
+      stamp(40 + 4 * l + 1);
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) y[ot][jt] = *(const f4*)(priv + (ot * NT + jt) * 1024 + lane * 16);
+    } else if constexpr (DENSE) {
+      // compiled-C++ statement of the same block (tw_debug_set_flags bit 3), same stage order:
+      //   q_0 k_0 | per head h: v_h, [head h], q_{h+1} k_{h+1}, after an odd h the out_proj k-step of the pair
       static_assert(NT == 3, "key tiles 0, 1 form the K = 32 part of P.V, tile 2 the K = 16 part");
       BOp<NT> xb[4];
       to_bop<NT, 4>(x, xb);
       constexpr float LOG2E = 1.44269504088896340736f;
-      for (int hp = 0; hp < p.H / 2; ++hp) {
-        f4 oh[2][NT];
+      f4 qa[NT], ka[NT], va[NT];
+      f4 oh[2][NT];
+      auto stage_qk = [&](f4 (&acc)[NT]) {  // acc = W[16-row tile of the stage] . x^T
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int h = 2 * hp + hh;
-          f4 qa[NT], ka[NT], va[NT];
+        for (int jt = 0; jt < NT; ++jt) acc[jt] = (f4){0.f, 0.f, 0.f, 0.f};
+        H3Tiles w;
+        w.load(pipe.stage(), lane);
 #pragma unroll
-          for (int jt = 0; jt < NT; ++jt) qa[jt] = ka[jt] = va[jt] = (f4){0.f, 0.f, 0.f, 0.f};
-          {  // q_h = W_q[16 h ..] . x^T
-            H3Tiles w;
-            w.load(pipe.stage(), lane);
+        for (int ks = 0; ks < 4; ++ks) {
+          w.ready(ks);
+          mma3<NT>(w.hi(ks), w.lo(ks), xb[ks], acc);
+          w.done(ks);
+        }
+        pipe.advance();
+      };
+      auto stage_v = [&]() {  // operands swapped: va[jt] = x[tokens of tile jt] . W_v[16 h ..]^T  (lane = feature, registers = tokens)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              w.ready(ks);
-              mma3<NT>(w.hi(ks), w.lo(ks), xb[ks], qa);
-              w.done(ks);
-            }
-            pipe.advance();
-          }
-          {  // k_h
-            H3Tiles w;
-            w.load(pipe.stage(), lane);
+        for (int jt = 0; jt < NT; ++jt) va[jt] = (f4){0.f, 0.f, 0.f, 0.f};
+        H3Tiles w;
+        w.load(pipe.stage(), lane);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              w.ready(ks);
-              mma3<NT>(w.hi(ks), w.lo(ks), xb[ks], ka);
-              w.done(ks);
-            }
-            pipe.advance();
-          }
-          {  // v_h, operands swapped: va[jt] = x[tokens of tile jt] . W_v[16 h ..]^T  (lane = feature, registers = tokens)
-            H3Tiles w;
-            w.load(pipe.stage(), lane);
+        for (int ks = 0; ks < 4; ++ks) {
+          w.ready(ks);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              w.ready(ks);
+          for (int jt = 0; jt < NT; ++jt) va[jt] = mfma32(xb[ks].h[jt], w.hi(ks), va[jt]);
 #pragma unroll
-              for (int jt = 0; jt < NT; ++jt) va[jt] = mfma32(xb[ks].h[jt], w.hi(ks), va[jt]);
+          for (int jt = 0; jt < NT; ++jt) va[jt] = mfma32(xb[ks].l[jt], w.hi(ks), va[jt]);
 #pragma unroll
-              for (int jt = 0; jt < NT; ++jt) va[jt] = mfma32(xb[ks].l[jt], w.hi(ks), va[jt]);
-#pragma unroll
-              for (int jt = 0; jt < NT; ++jt) va[jt] = mfma32(xb[ks].h[jt], w.lo(ks), va[jt]);
-              w.done(ks);
-            }
-            pipe.advance();
-          }
+          for (int jt = 0; jt < NT; ++jt) va[jt] = mfma32(xb[ks].h[jt], w.lo(ks), va[jt]);
+          w.done(ks);
+        }
+        pipe.advance();
+      };
+      stage_qk(qa);
+      stage_qk(ka);
+      for (int h = 0; h < p.H; ++h) {
+        const int hh = h & 1;
+        stage_v();
+        {
           // scale, bias, 1 / sqrt(16) on q; fp16 hi / lo operands
           h4 qh[NT], ql[NT], kh[NT], kl[NT], vh2, vl2;
           h8 vh01, vl01;
@@ -1416,6 +1468,10 @@ netblock_h3_kernel(const H3Params p) {
             split8(va[0], va[1], vh01, vl01);
             split4(va[2], vh2, vl2);
           }
+          if (p.debug & 2048) {  // timing experiment (results WRONG): no scores / softmax / P.V - what the GEMM stages alone cost
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) oh[hh][jt] = qa[jt] + ka[jt] + va[jt];
+          } else
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt) {
             // S^T[key tile mt][query tile jt]: this lane holds keys 16 mt + 4 g + r of its query 16 jt + i16
@@ -1462,21 +1518,27 @@ netblock_h3_kernel(const H3Params p) {
             oh[hh][jt] = (o32 + o16) * __builtin_amdgcn_rcpf(sum);
           }
         }
-        // y += W_o[:, 32 hp .. 32 hp + 31] . O(heads 2 hp, 2 hp + 1)
-        BOp<NT> ob;
+        if (h + 1 < p.H) {
+          stage_qk(qa);
+          stage_qk(ka);
+        }
+        if (hh == 1) {
+          // y += W_o[:, 32 hp .. 32 hp + 31] . O(heads 2 hp, 2 hp + 1)
+          BOp<NT> ob;
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) split8(oh[0][jt], oh[1][jt], ob.h[jt], ob.l[jt]);
+          for (int jt = 0; jt < NT; ++jt) split8(oh[0][jt], oh[1][jt], ob.h[jt], ob.l[jt]);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          H3Tiles w;
-          w.load(pipe.stage(), lane);
+          for (int half = 0; half < 2; ++half) {
+            H3Tiles w;
+            w.load(pipe.stage(), lane);
 #pragma unroll
-          for (int oo = 0; oo < 4; ++oo) {
-            w.ready(oo);
-            mma3<NT>(w.hi(oo), w.lo(oo), ob, y[4 * half + oo]);
-            w.done(oo);
+            for (int oo = 0; oo < 4; ++oo) {
+              w.ready(oo);
+              mma3<NT>(w.hi(oo), w.lo(oo), ob, y[4 * half + oo]);
+              w.done(oo);
+            }
+            pipe.advance();
           }
-          pipe.advance();
         }
       }
       stamp(40 + 4 * l + 1);
