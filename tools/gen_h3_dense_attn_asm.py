@@ -112,6 +112,8 @@ def handoff(next_reads, label, aux):
                f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off",
                f".Lh3atd_noaux_{label}_%=:"]]
     h += [f"v_lshl_add_u64 {vr(V_GN, 2)}, {vr(V_GN, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]"]
+    if "nodma" in EXPERIMENT:  # timing experiment (results wrong): no weight DMA inside the section
+        h = [x for x in h if isinstance(x, str) and not x.startswith("global_load_lds")]
     return h
 
 
