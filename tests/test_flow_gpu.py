@@ -222,19 +222,21 @@ def test_full_dense_ad_golden(path):
         assert m._dev_weights["f32"] is not None  # the fused kernel's weight stream was built and used
 
 
-@pytest.mark.parametrize("path", [SIMPLE, FUSED, 0, None])
+@pytest.mark.parametrize("path", [SIMPLE, FUSED, 0, H3, None])
 def test_full_dense_posenc_golden(path):
     """transformer_nvp_posenc.yaml at full size (128 random Fourier features of the conditioning positions appended to
     the in-MLP's input, rff_position_encoder.py:57-62): per-op path, the fused f32 dense kernel (cos / sin in its
-    prologue, eleven input tiles), TW_PATH_AUTO and the constructor's default - which must both land on the fused f32
-    kernel: the split-fp16 in-MLP section takes 64 input features."""
+    prologue, eleven input tiles), TW_PATH_AUTO, the split-fp16 dense kernel (six input k-steps) and the constructor's
+    default, which must land on the latter."""
     d, _ = H.load("dense_posenc_full_ad")
     m = H.tw_dense_model(H.full_dense_posenc_sd(), rff_dim=128, path=path)
     if path is None:
-        assert m._path_for(22) == 0
+        assert m._path_for(22) == H3
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
-    if path in (0, None):
+    if path == 0:
         assert m._dev_weights["f32"] is not None
+    if path in (H3, None):
+        assert m._dev_weights["h3"] is not None and m._dev_weights["f32"] is None
 
 
 @pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])

@@ -85,6 +85,7 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 //                      scales: in0, in2, per layer (wc, w1, w2), out0, out2  (as 2^-s multipliers)
 struct H3Geom {
   int hid_chunks, ff_chunks, H, L;
+  int in_a_stages;  // A stages per chunk of the in-MLP: 1 (64 input columns) or 3 (192: dense model with 128 RFF features)
   int64_t stages;
   int64_t side_in2b, side_layers, side_layer_size, side_out2b, side_scales, side_size;
   int64_t net_stride_bytes;
@@ -97,7 +98,8 @@ static H3Geom h3_geom(const tw_flow_desc& d) {
   g.H = d.n_heads;
   g.L = d.n_layers;
   const int64_t att_stages = d.variant == 1 ? 4LL * g.H : 8LL * g.H;
-  g.stages = 3LL * g.hid_chunks + (int64_t)g.L * (att_stages + 4LL * g.ff_chunks) + 3LL * g.hid_chunks;
+  g.in_a_stages = (d.variant == 1 && d.d_rff > 0) ? 3 : 1;
+  g.stages = (int64_t)(g.in_a_stages + 2) * g.hid_chunks + (int64_t)g.L * (att_stages + 4LL * g.ff_chunks) + 3LL * g.hid_chunks;
   int64_t o = 0;
   g.side_in2b = o; o += 128;
   g.side_layers = o;
@@ -160,9 +162,10 @@ bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   if (d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
       h3_wide_geom(n_atoms, &wd))
     return h3w_sf_lds_bytes(n_atoms, wd.mpwg) <= H3_SF_LDS_MAX;
-  if (d.variant == 1)  // dense softmax attention: 8 heads of 16 = one MFMA tile each; no RFF features (input width <= 64)
-    return d.d_model == 128 && d.n_heads == 8 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_rff == 0 &&
-           d.d_emb + 9 <= 64 && fused_geom_nt(n_atoms, H3_NT, &fg);
+  if (d.variant == 1)  // dense softmax attention: 8 heads of 16 = one MFMA tile each; input width <= 64, or 32 + 9 + 128
+                       // random Fourier position features (192 columns: the in-MLP then runs as compiled C++)
+    return d.d_model == 128 && d.n_heads == 8 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 &&
+           ((d.d_rff == 0 && d.d_emb + 9 <= 64) || (d.d_rff == 128 && d.d_emb == 32)) && fused_geom_nt(n_atoms, H3_NT, &fg);
   return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
          fused_geom_nt(n_atoms, H3_NT, &fg) &&
          h3_sf_lds_bytes(d.n_heads, n_atoms, fg.mpw) <= H3_SF_LDS_MAX;
@@ -296,19 +299,27 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
       char* st = pn;
       // ---- IN
       if ((rc = absmax(nb + L.net.in0_w, (int64_t)d.d_hidden * L.d_in, up, scales + 0))) return rc;
-      for (int ch = 0; ch < g.hid_chunks; ++ch) {
-        char* a = st + a_off(ch, g.hid_chunks, 1, 2) * H3_STAGE_BYTES;
-        if ((rc = block(nb + L.net.in0_w, L.d_in, d.d_hidden, L.d_in, 32 * ch, 0, 2, 2, up, a))) return rc;
-        if ((rc = copy(nb + L.net.in0_b + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
-        if ((rc = copy(scales + 0, 1, (float*)(a + H3_STAGE_TILE_BYTES) + 32, 1))) return rc;
-      }
+      const int ia = g.in_a_stages, ks_in = 2 * ia;  // k-steps of the first GEMM: 2 or 6
+      for (int ch = 0; ch < g.hid_chunks; ++ch)
+        for (int a_ = 0; a_ < ia; ++a_) {
+          char* a = st + (a_off(ch, g.hid_chunks, ia, 2) + a_) * H3_STAGE_BYTES;
+          for (int pp = 0; pp < H3_STAGE_PAIRS; ++pp) {  // pair q = (o, ks), four to a stage (h3_mlp_chain)
+            const int q = a_ * H3_STAGE_PAIRS + pp, o = q / ks_in, ks = q % ks_in;
+            if ((rc = block(nb + L.net.in0_w, L.d_in, d.d_hidden, L.d_in, 32 * ch + 16 * o, 32 * ks, 1, 1, up, a + pp * H3_PAIR_BYTES)))
+              return rc;
+          }
+          if (a_ == 0) {
+            if ((rc = copy(nb + L.net.in0_b + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
+            if ((rc = copy(scales + 0, 1, (float*)(a + H3_STAGE_TILE_BYTES) + 32, 1))) return rc;
+          }
+        }
       if ((rc = absmax(nb + L.net.in2_w, (int64_t)128 * d.d_hidden, up, scales + 1))) return rc;
       for (int ch = 0; ch < g.hid_chunks; ++ch)
         for (int hf = 0; hf < 2; ++hf) {
-          char* b = st + (b_off(ch, g.hid_chunks, 1, 2) + hf) * H3_STAGE_BYTES;
+          char* b = st + (b_off(ch, g.hid_chunks, ia, 2) + hf) * H3_STAGE_BYTES;
           if ((rc = block(nb + L.net.in2_w, d.d_hidden, 128, d.d_hidden, 64 * hf, 32 * ch, 4, 1, up, b))) return rc;
         }
-      st += (int64_t)3 * g.hid_chunks * H3_STAGE_BYTES;
+      st += (int64_t)(ia + 2) * g.hid_chunks * H3_STAGE_BYTES;
       if ((rc = copy(nb + L.net.in2_b, 128, side + g.side_in2b, 128))) return rc;
       // ---- layers
       for (int l = 0; l < d.n_layers; ++l) {
@@ -637,6 +648,8 @@ struct H3Params {
   int sfrag_shared;
   int64_t sf_variant_bytes;  // chebyshev_kernel: bytes between the fragment sets of (net, layer) variants; else 0
   int windowed;              // block-diagonal mixing with per-tile key windows (h3_windowed); asm variant only
+  const float* rff;          // dense model with position features: [3, d_rff / 2] Gaussian vectors of this coupling layer
+  int d_rff;
   int win[4];                // wide layout: byte offset of each wave's key window in a row of the shared X^T tile
   float* out[2];
   float* dump;
@@ -907,8 +920,10 @@ template <int NT, int KS_IN, int OT_OUT, bool SILU>
 __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&yacc)[OT_OUT][NT], H3Pipe& pipe,
                                              int n_chunks, int lane) {
   const int g = lane >> 4;
-  constexpr int O_PER_STAGE = H3_STAGE_PAIRS / KS_IN;  // 1 (KS_IN = 4) or 2 (KS_IN = 2)
-  constexpr int A_STAGES = 2 / O_PER_STAGE;
+  // the 2 KS_IN tile pairs of a chunk's first GEMM, pair q = (o = q / KS_IN, ks = q % KS_IN), four to a stage:
+  // KS_IN = 2: one stage, 4: two, 6 (dense model with RFF position features, 192 input columns): three
+  static_assert((2 * KS_IN) % H3_STAGE_PAIRS == 0, "whole stages");
+  constexpr int A_STAGES = 2 * KS_IN / H3_STAGE_PAIRS;
   constexpr int B_STAGES = (OT_OUT + 3) / 4;
   constexpr int UNITS = 2 * NT;  // epilogue units: (o, jt), four hidden values of one token column each
   f4 hacc[2][NT];
@@ -928,17 +943,15 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
       H3Tiles w;
       w.load(st, lane);
 #pragma unroll
-      for (int oo = 0; oo < O_PER_STAGE; ++oo) {
-        const int o = a * O_PER_STAGE + oo;
+      for (int pr = 0; pr < H3_STAGE_PAIRS; ++pr) {
+        const int q = a * H3_STAGE_PAIRS + pr, o = q / KS_IN, ks = q % KS_IN;
+        if (ks == 0) {
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) hacc[o][jt] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS_IN; ++ks) {
-          const int pr = oo * KS_IN + ks;
-          w.ready(pr);
-          mma3<NT>(w.hi(pr), w.lo(pr), xin[ks], hacc[o]);
-          w.done(pr);
+          for (int jt = 0; jt < NT; ++jt) hacc[o][jt] = (f4){0.f, 0.f, 0.f, 0.f};
         }
+        w.ready(pr);
+        mma3<NT>(w.hi(pr), w.lo(pr), xin[ks], hacc[o]);
+        w.done(pr);
       }
       pipe.advance();
     }
@@ -1035,11 +1048,15 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
 // Nothing is transposed through memory and nothing leaves the registers.
 // WIDE = true (kernel attention, asm sections only): molecules of 49 .. 160 atoms, packed back to back over the workgroup's
 // 192 token slots; token-local sections unchanged, attention through the shared X^T tile (tw_h3_attns_asm.inc).
-template <int NT, bool ASM, bool DENSE = false, bool WIDE = false>
+// RFF = true (dense only): 128 random Fourier features of the conditioning positions appended to the in-MLP's input
+// (transformer_nvp_posenc.yaml); six input k-steps, the in-MLP as compiled C++ (the asm section takes two).
+template <int NT, bool ASM, bool DENSE = false, bool WIDE = false, bool RFF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_h3_kernel(const H3Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   static_assert(!WIDE || (ASM && !DENSE), "the wide layout exists for the asm build of the kernel-attention variant");
+  static_assert(!RFF || DENSE, "position features belong to the dense model");
+  constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
   constexpr int WAVE_LDS = DENSE ? H3D_WAVE_LDS : (WIDE ? H3W_WAVE_LDS : H3_WAVE_LDS);
   constexpr int SIDE_LDS_OFFSET = DENSE ? H3D_SIDE_LDS_OFFSET : (WIDE ? H3W_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET);
   constexpr int SIDE_CHUNKS = DENSE ? 5 : 3;
@@ -1163,7 +1180,7 @@ netblock_h3_kernel(const H3Params p) {
     }
   }
   // u in B-operand element order: k-step ks, element e  <->  feature 32 ks + 16 (e/4) + 4 g + e%4
-  BOp<NT> u[2];
+  BOp<NT> u[KIN];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     const int64_t n = tok_row[jt];
@@ -1171,7 +1188,7 @@ netblock_h3_kernel(const H3Params p) {
     const int a = tok_atom[jt];
     const int ty = n < 0 ? 0 : p.types[c * p.V + a];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KIN; ++ks)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int f = 32 * ks + 16 * (e / 4) + 4 * g + (e % 4);
@@ -1181,6 +1198,15 @@ netblock_h3_kernel(const H3Params p) {
           else if (f < p.d_emb + 3) val = p.xc[(c * p.V + a) * 3 + (f - p.d_emb)];
           else if (f < p.d_emb + 6) val = p.xv[(c * p.V + a) * 3 + (f - p.d_emb - 3)];
           else if (f < p.d_emb + 9) val = zo[jt][f - p.d_emb - 6];
+          else if (RFF && f < p.d_emb + 9 + p.d_rff) {
+            // rff_position_encoder.py:57-62: sqrt(1/n) * [cos(x G), sin(x G)]; same arithmetic as build_input_kernel
+            const float* px = p.xc + (c * p.V + a) * 3;
+            const int nvec = p.d_rff / 2;
+            const int j = f - p.d_emb - 9;
+            const int col = j % nvec;
+            const float ip = px[0] * p.rff[0 * nvec + col] + px[1] * p.rff[1 * nvec + col] + px[2] * p.rff[2 * nvec + col];
+            val = sqrtf(1.0f / nvec) * (j < nvec ? cosf(ip) : sinf(ip));
+          }
         }
         const _Float16 hi = (_Float16)val;
         u[ks].h[jt][e] = hi;
@@ -1226,7 +1252,7 @@ netblock_h3_kernel(const H3Params p) {
     for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) x[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (ASM) {
+    if constexpr (ASM && !RFF) {
       // generated asm (tools/gen_h3_ffn_asm.py --shape=in): u in, x out through the wave-private LDS block
       char* priv = (char*)xt_hi;
 #pragma unroll
@@ -1255,7 +1281,7 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) x[ot][jt] = *(const f4*)(priv + (ot * NT + jt) * 1024 + lane * 16);
     } else {
-      h3_mlp_chain<NT, 2, 8, true>(u, x, pipe, p.hid_chunks, lane);
+      h3_mlp_chain<NT, KIN, 8, true>(u, x, pipe, p.hid_chunks, lane);
     }
     const float sc = h3_load_f1(scales + 1);
     f4 bb[8];
@@ -1897,6 +1923,8 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.sf_variant_bytes = sf_variant_bytes;
   H3Wide wd{};
   const bool wide = d.variant == 0 && h3_wide_geom(a.n_atoms, &wd);
+  p.d_rff = d.variant == 1 ? d.d_rff : 0;
+  p.rff = p.d_rff > 0 ? a.raw + L.chain + (int64_t)c * L.coupling_size + L.rff : nullptr;
   p.windowed = (!wide && h3_windowed(fg, a.n_atoms)) ? 1 : 0;
   for (int i = 0; i < 4; ++i) p.win[i] = wide ? wd.win[i] : 0;
   p.out[0] = s_out;
@@ -1929,6 +1957,14 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   if ((prc = profile_mark(a.stream, true))) return prc;
   if (wide) {
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+  } else if (d.variant == 1 && d.d_rff > 0) {
+    static LdsLimit lim_rff, lim_rff_cpp;
+    if ((prc = lim_rff.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, true>, (int)H3D_LDS_BYTES))) return prc;
+    if ((prc = lim_rff_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false, true, false, true>, (int)H3D_LDS_BYTES))) return prc;
+    if (g_debug_flags & 8)
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false, true, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
+    else
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
   } else if (d.variant == 1) {
     if (g_debug_flags & 8)
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
