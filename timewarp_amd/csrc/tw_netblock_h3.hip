@@ -38,7 +38,8 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 #define H3_NT 3
 #define H3_TOK (16 * H3_NT)
-#define H3_XT 48
+#define H3_XT 48      // tokens of a wave
+#define H3_XT_IMG 1536  // transposed copy: bytes per (feature tile, hi | lo) = [T0 | T1] 1024 + T2 512
 // ^ halfs per feature row of the transposed X tile: the 48 tokens, no padding.  Row stride 24 dwords is conflict-free for
 //   the ds_read_b128 lane groups of gfx950; 56 halfs (the r01/r02 value) was 2-way (tools/gen_h3_attn_asm.py)
 #define H3_PAIR_BYTES 2048          // one (hi, lo) tile pair: 16 out x 32 k
@@ -532,12 +533,15 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
     const float* row = E + h * MVV + ((mq == 255 ? 0 : mq) * V + tatm[tq]) * V;
     // windowed (h3_windowed): query tile 2 only has keys in [16, 48) - its K = 32 block covers those, its K = 16 block
     // is not used (nor is tile 0's, whose keys all lie in [0, 32))
-    const int k0 = ((windowed && jt == 2) ? 16 : 0) + 8 * g, k1 = 32 + 4 * g;
+    // K = 32 block: the K index runs over two key tiles, element e of lane group g = key 16 Ta + 4 g + e (e < 4),
+    // 16 Tb + 4 g + e - 4 (e >= 4) - the order the transposed copy of x comes out of the matrix pipe in (kernel, "x ->
+    // transposed"); (Ta, Tb) = (0, 1), windowed tile 2: (1, 2)
+    const int k0 = ((windowed && jt == 2) ? 16 : 0) + 4 * g, k1 = 32 + 4 * g;
     h8 hi0, lo0;
     h4 hi1, lo1;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int tk = k0 + e;
+      const int tk = k0 + (e < 4 ? e : e + 12);
       const float val = (mq != 255 && tmol[tk] == mq) ? row[tatm[tk]] : 0.f;
       const _Float16 hi = (_Float16)val;
       hi0[e] = hi;
@@ -682,27 +686,38 @@ __device__ __forceinline__ void mma3(const h8 ah, const h8 al, const BOp<NT>& b,
   for (int jt = 0; jt < NT; ++jt) acc[jt] = mfma32(al, b.h[jt], acc[jt]);
 }
 
+// fp32 pair -> packed fp16 hi pair + packed fp16 lo pair (lo = fp16(v - hi)), four VALU ops: v_cvt_pk_f16_f32 (RNE),
+// two v_fma_mix_f32 (hi as an fp16 source: no conversion back) and a second pack - the sequence the generated asm
+// sections use.  hipcc's translation of the plain C++ form costs eight (cvt, cvt back, sub, and hi packed a second
+// time); the values are the same (v - hi is exact in fp32 either way).
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  float ta, tb;
+  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+      "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_cvt_pk_f16_f32 %1, %2, %3"
+      : "=&v"(hi), "=&v"(lo), "=&v"(ta), "=&v"(tb)
+      : "v"(a), "v"(b));
+}
+
 // two D tiles (features 16t..16t+15, 16t+16..16t+31 of one token) -> split B-operand element vector
 __device__ __forceinline__ void split8(const f4 a, const f4 b, h8& hi, h8& lo) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const _Float16 ha = (_Float16)a[e];
-    const _Float16 hb = (_Float16)b[e];
-    hi[e] = ha;
-    hi[e + 4] = hb;
-    lo[e] = (_Float16)(a[e] - (float)ha);
-    lo[e + 4] = (_Float16)(b[e] - (float)hb);
-  }
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  split_pair(a[0], a[1], h0, l0);
+  split_pair(a[2], a[3], h1, l1);
+  split_pair(b[0], b[1], h2, l2);
+  split_pair(b[2], b[3], h3, l3);
+  hi = __builtin_bit_cast(h8, (u4){h0, h1, h2, h3});
+  lo = __builtin_bit_cast(h8, (u4){l0, l1, l2, l3});
 }
 
 // one D tile -> split K = 16 operand
 __device__ __forceinline__ void split4(const f4 a, h4& hi, h4& lo) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const _Float16 ha = (_Float16)a[e];
-    hi[e] = ha;
-    lo[e] = (_Float16)(a[e] - (float)ha);
-  }
+  unsigned h0, h1, l0, l1;
+  split_pair(a[0], a[1], h0, l0);
+  split_pair(a[2], a[3], h1, l1);
+  hi = __builtin_bit_cast(h4, (u2){h0, h1});
+  lo = __builtin_bit_cast(h4, (u2){l0, l1});
 }
 
 // max / sum over the four lanes that share (lane & 15): v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16- and
@@ -1085,7 +1100,6 @@ netblock_h3_kernel(const H3Params p) {
   const float* side = (const float*)(net_base + p.stages * H3_STAGE_BYTES);
   const float* scales = side + p.side_scales;
   _Float16* xt_hi = (_Float16*)(lds + H3_RING * H3_STAGE_BYTES + wave * WAVE_LDS);
-  _Float16* xt_lo = xt_hi + 128 * H3_XT;
 
   // ---- token bookkeeping and input features (ordinary loads: before the DMA pipeline starts) ----
   int64_t tok_row[NT];
@@ -1300,9 +1314,15 @@ netblock_h3_kernel(const H3Params p) {
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) padmask |= (tok_row[jt] < 0 ? 1u : 0u) << jt;
   if (p.debug & 1024) padmask = 0;
+  unsigned pad_tiles = 0;  // wave-uniform: token tiles that hold a padding token at all (V = 22: the last one only)
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt)
+    if (__builtin_amdgcn_ballot_w64((padmask >> jt) & 1u) != 0ull) pad_tiles |= 1u << jt;
+  pad_tiles = __builtin_amdgcn_readfirstlane(pad_tiles);
   auto zero_pad = [&]() {
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
+      if (!((pad_tiles >> jt) & 1u)) continue;
       const bool pad = (padmask >> jt) & 1u;
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft)
@@ -1371,20 +1391,39 @@ netblock_h3_kernel(const H3Params p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     } else if constexpr (!DENSE) {
-      // (pairing two tokens per store through DPP - half the LDS stores - was built and measured: 5.0 k -> 8.4 k cycles per
-      // layer, the extra VALU and exec masking cost more than the store port saves; profiles/r03_ab_glue.txt)
+      // Transposed through the matrix pipe, not through 192 two-byte LDS stores per lane: the lane holds token i16's
+      // features 16 ft + 4 g + r - as fp16 that is the A operand (row = token, k = 4 g + r) of a K = 16 MFMA; against the
+      // identity as B the result D[4 g + r][i16] = X[token 16 jt + 4 g + r][feature 16 ft + i16] comes back with the
+      // FEATURE on the lane and four TOKENS in its registers, exactly (products with 1.0, sums with zeros), i.e. as the A
+      // operand of the mixing MFMA.  Images per (feature tile ft, part): [T0 | T1] 16 B per lane (K = 32 operand: tokens
+      // 4 g + e and 16 + 4 g + e - the key order of the K index is free as long as the score fragments use the same one,
+      // h3_score_frag_kernel), then T2 8 B per lane (K = 16 operand, tokens 32 + 4 g + e): 1536 B, hi at
+      // (2 ft) * 1536, lo at (2 ft + 1) * 1536.  Every lane reads and writes its own 16 / 8 bytes: no bank conflicts.
+      // (r01-r03: rows of 48 halfs per feature, 4.9 k cycles per layer for this block; pairing tokens per store
+      // through DPP measured worse, profiles/r03_ab_glue.txt)
+      static_assert(NT == 3, "token tiles 0, 1 form the K = 32 operand, tile 2 the K = 16 operand");
+      char* xt = (char*)xt_hi;
+      h4 idb;
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
+      for (int e = 0; e < 4; ++e) idb[e] = (i16 == 4 * g + e) ? (_Float16)1.f : (_Float16)0.f;
 #pragma unroll
-        for (int ft = 0; ft < 8; ++ft)
+      for (int ft = 0; ft < 8; ++ft) {
+        u2 ph[NT], pl[NT];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = x[ft][jt][r];
-            const _Float16 hi = (_Float16)v;
-            const int idx = (16 * ft + 4 * g + r) * H3_XT + 16 * jt + i16;
-            xt_hi[idx] = hi;
-            xt_lo[idx] = (_Float16)(v - (float)hi);
-          }
+        for (int jt = 0; jt < NT; ++jt) {
+          h4 xh, xl;
+          split4(x[ft][jt], xh, xl);
+          const f4 th = mfma16(xh, idb, (f4){0.f, 0.f, 0.f, 0.f});
+          const f4 tl = mfma16(xl, idb, (f4){0.f, 0.f, 0.f, 0.f});
+          ph[jt] = __builtin_bit_cast(u2, __builtin_convertvector(th, h4));
+          pl[jt] = __builtin_bit_cast(u2, __builtin_convertvector(tl, h4));
+        }
+        char* img = xt + ft * (2 * H3_XT_IMG);
+        *(u4*)(img + lane * 16) = (u4){ph[0][0], ph[0][1], ph[1][0], ph[1][1]};
+        *(u2*)(img + 1024 + lane * 8) = ph[2];
+        *(u4*)(img + H3_XT_IMG + lane * 16) = (u4){pl[0][0], pl[0][1], pl[1][0], pl[1][1]};
+        *(u2*)(img + H3_XT_IMG + 1024 + lane * 8) = pl[2];
+      }
     }
 
     f4 y[8][NT];
@@ -1646,11 +1685,11 @@ netblock_h3_kernel(const H3Params p) {
         f4 acc[2][NT], tail[2][NT];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const int row = (16 * (2 * ks + t) + i16) * H3_XT;
-          const h8 a0h = *(const h8*)(xt_hi + row + 8 * g);
-          const h8 a0l = *(const h8*)(xt_lo + row + 8 * g);
-          const h4 a1h = *(const h4*)(xt_hi + row + 32 + 4 * g);
-          const h4 a1l = *(const h4*)(xt_lo + row + 32 + 4 * g);
+          const char* img = (const char*)xt_hi + (2 * ks + t) * (2 * H3_XT_IMG);
+          const h8 a0h = *(const h8*)(img + lane * 16);
+          const h8 a0l = *(const h8*)(img + H3_XT_IMG + lane * 16);
+          const h4 a1h = *(const h4*)(img + 1024 + lane * 8);
+          const h4 a1l = *(const h4*)(img + H3_XT_IMG + 1024 + lane * 8);
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a0h, s0h[jt], (f4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll

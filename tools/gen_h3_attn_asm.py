@@ -14,11 +14,11 @@ head h and waited for one k-step later.  Stage hand-off as in the FFN block (gen
 
 Register map (private to the asm statement):
   v0..v35     score fragments  SF[jt] = {s0h 4, s0l 4, s1h 2, s1l 2}
-  v36..v59    X^T operands, two buffers (t = 0, 1) of {a0h 4, a0l 4, a1h 2, a1l 2}
+  v36..v59    X^T operands, two buffers (t = 0, 1) of {a0h 4, a1h 2, a0l 4, a1l 2}
   v60..v83    acc[t][jt] (one chain per accumulator, K=32 and K=16 MFMAs alternating five MFMAs apart)
   v108..v155  xm[buf][jt] = {h 4, l 4}
   v156..v187  weight tile slots p=0..3: hi v[156+8p..], lo v[160+8p..]
-  v188..v195  temporaries;  v196 tile address; v197/v198 X^T row addresses (8g / 4g column groups)
+  v188..v195  temporaries;  v196 tile address; v197/v198 X^T image addresses (16 B / 8 B per lane)
   v200:201 DMA source; v202:203 temp; v204 lane*16; v206:207 / v208:209 score-fragment addresses (16 B / 8 B lanes)
   v210:211 temp
   a0..a95     y[ot][jt]"""
@@ -27,15 +27,14 @@ import sys
 
 NT = 3
 STAGE, TILES = 9216, 8192
-# 48 = no padding columns: with ds_read_b128's lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... MI355X_MICROARCH.md)
-# a row stride of 24 dwords is conflict-free, the former 28 (56 halfs) was 2-way: -3.7 % attention-section cycles, -0.6 % per
-# pass (profiles/r03_ab_xt_stride.txt)
-XT_HALFS = int(os.environ.get("H3_XT_HALFS", "48"))   # halfs per feature row of the transposed tile (csrc: H3_XT)
-XT_ROW = XT_HALFS * 2            # bytes per feature row of the transposed tile
-XT_LO = 128 * XT_HALFS * 2       # offset of the lo half
+# Transposed copy of x in the wave-private block (csrc: "x -> transposed", H3_XT_IMG): per feature tile ft and part
+# (hi, lo) one 1536-byte image = [T0 | T1] 16 B per lane (K = 32 operand) + T2 8 B per lane (K = 16 operand); every lane
+# reads its own bytes (conflict-free).  r03 before: rows of 48 halfs per feature (24-dword stride; 28 in r01 / r02 was 2-way).
+XT_IMG = 1536
 SF_BYTES = 3072
 SF = lambda jt, name: 12 * jt + {"s0h": 0, "s0l": 4, "s1h": 8, "s1l": 10}[name]
-XA = lambda buf, name: 36 + 12 * buf + {"a0h": 0, "a0l": 4, "a1h": 8, "a1l": 10}[name]
+# a1 (token tile 2) directly behind a0 (tiles 0 | 1): registers +2..+5 of a part are the (T1 | T2) operand of windowed tile 2
+XA = lambda buf, name: 36 + 12 * buf + {"a0h": 0, "a1h": 4, "a0l": 6, "a1l": 10}[name]
 ACC = lambda t, jt: 60 + 4 * (3 * t + jt)
 TAIL = lambda t, jt: 84 + 4 * (3 * t + jt)
 XM = lambda buf, jt, part: 108 + 24 * buf + 8 * jt + (0 if part == "h" else 4)
@@ -46,12 +45,12 @@ S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT, S_K3072, S_K6144 = 84, 
 N_V, N_A = 212, 96
 EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(",")))
 # --mode=windowed: waves that hold two or more molecules.  The score matrix is block diagonal, so query tile 0 only has
-# keys in [0, 32) and query tile 2 only in [16, 48): each takes ONE K=32 mixing MFMA per term (tile 2 with its X^T
-# operand read 16 tokens further in, into a96..a111) and only tile 1 keeps the K=16 tail - 24 instead of 36 mixing
+# keys in [0, 32) and query tile 2 only in [16, 48): each takes ONE K=32 mixing MFMA per term (tile 2 with the
+# (T1 | T2) registers of the operand buffer) and only tile 1 keeps the K=16 tail - 24 instead of 36 mixing
 # MFMAs per k-step (the K=16 shape costs a full slot).  The fragment producer lays tile 2's K=32 block over keys 16..47
 # for this mode (csrc: h3_score_frag_kernel `windowed`).  Single-molecule waves keep the full 48 keys (--mode=full).
 WINDOWED = "--mode=windowed" in sys.argv
-A2 = lambda t, part: 96 + 8 * t + (0 if part == "h" else 4)   # AGPRs
+A2 = lambda t, part: XA(t, "a0h" if part == "h" else "a0l") + 2
 
 
 def vr(base, n=4):
@@ -73,15 +72,11 @@ def mfma16(d, a, b, zero=False):
 
 
 def xt_reads(ks, t, buf):
-    off = XT_ROW * 16 * (2 * ks + t)
-    out = [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
-           f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_LO}",
-           f"ds_read_b64 {vr(XA(buf, 'a1h'), 2)}, v{V_XT1} offset:{off}",
-           f"ds_read_b64 {vr(XA(buf, 'a1l'), 2)}, v{V_XT1} offset:{off + XT_LO}"]
-    if WINDOWED:   # keys 16..47 for query tile 2: the same rows, 16 tokens (32 bytes) further in
-        out += [f"ds_read_b128 {ar(A2(buf, 'h'))}, v{V_XT0} offset:{off + 32}",
-                f"ds_read_b128 {ar(A2(buf, 'l'))}, v{V_XT0} offset:{off + XT_LO + 32}"]
-    return out
+    off = 2 * XT_IMG * (2 * ks + t)
+    return [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
+            f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_IMG}",
+            f"ds_read_b64 {vr(XA(buf, 'a1h'), 2)}, v{V_XT1} offset:{off + 1024}",
+            f"ds_read_b64 {vr(XA(buf, 'a1l'), 2)}, v{V_XT1} offset:{off + XT_IMG + 1024}"]
 
 
 def mixing_mfmas():
@@ -95,7 +90,7 @@ def mixing_mfmas():
         for t in range(2):
             for jt in range(NT):
                 if WINDOWED and jt == 2:
-                    out.append(mfma32(ACC(t, jt), A2(t, a32[2]), SF(jt, b32), zero=first, areg="a"))
+                    out.append(mfma32(ACC(t, jt), A2(t, a32[2]), SF(jt, b32), zero=first))
                 else:
                     out.append(mfma32(ACC(t, jt), XA(t, a32), SF(jt, b32), zero=first))
         for t in range(2):
@@ -249,15 +244,11 @@ def generate():
     A = L.append
     A(f"v_mbcnt_lo_u32_b32 v{V_LANE16}, -1, 0")
     A(f"v_mbcnt_hi_u32_b32 v{V_LANE16}, -1, v{V_LANE16}")
-    # X^T row addresses: row (lane & 15), column group 8 g (16 B) / 32 + 4 g (8 B)
-    A(f"v_and_b32 v{V_T}, 15, v{V_LANE16}")
-    A(f"v_mul_u32_u24 v{V_T}, {XT_ROW}, v{V_T}")
-    A(f"v_lshrrev_b32 v{V_T + 1}, 4, v{V_LANE16}")
-    A(f"v_lshlrev_b32 v{V_T + 2}, 4, v{V_T + 1}")          # 16 g bytes
-    A(f"v_lshlrev_b32 v{V_T + 3}, 3, v{V_T + 1}")          # 8 g bytes
-    A(f"v_add3_u32 v{V_XT0}, v{V_T}, v{V_T + 2}, %[priv]")
-    A(f"v_add3_u32 v{V_XT1}, v{V_T}, v{V_T + 3}, %[priv]")
-    A(f"v_add_u32 v{V_XT1}, 64, v{V_XT1}")
+    # transposed copy: this lane's 16 B / 8 B of every image
+    A(f"v_lshlrev_b32 v{V_T}, 4, v{V_LANE16}")
+    A(f"v_lshlrev_b32 v{V_T + 1}, 3, v{V_LANE16}")
+    A(f"v_add_u32 v{V_XT0}, %[priv], v{V_T}")
+    A(f"v_add_u32 v{V_XT1}, %[priv], v{V_T + 1}")
     # score-fragment lane addresses: sf + 16 lane (128-bit loads), sf + 8 lane (64-bit loads)
     A(f"v_lshlrev_b32 v{V_TMP2}, 3, v{V_LANE16}")
     A(f"v_mov_b32 v{V_TMP2 + 1}, 0")
@@ -355,7 +346,7 @@ def main():
     out = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''} - do not edit.  Body of the attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")
-    clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A + (16 if WINDOWED else 0))] + [f'"s{i}"' for i in range(84, 98)] + \
+    clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A)] + [f'"s{i}"' for i in range(84, 98)] + \
            ['"vcc"', '"scc"', '"memory"']
     cl = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''} - clobber list of the attention asm statement."]
     for i in range(0, len(clob), 12):
