@@ -294,11 +294,11 @@ def test_generated_asm_includes_are_current(tmp_path):
     for args in (["tools/gen_h3_ffn_asm.py", "--shape=ffn"], ["tools/gen_h3_ffn_asm.py", "--shape=in"],
                  ["tools/gen_h3_ffn_asm.py", "--shape=out"], ["tools/gen_h3_attn_asm.py"],
                  ["tools/gen_h3_attn_asm.py", "--mode=windowed"], ["tools/gen_h3_attn_wide_asm.py"],
-                 ["tools/gen_h3_dense_attn_asm.py"]):
+                 ["tools/gen_h3_dense_attn_asm.py"], ["tools/gen_h3_enc_asm.py"], ["tools/gen_h3_enc_asm.py", "--mode=windowed"]):
         subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
                        stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 14
+    assert len(names) == 17
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n

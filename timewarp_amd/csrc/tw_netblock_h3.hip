@@ -1065,12 +1065,13 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
 // 192 token slots; token-local sections unchanged, attention through the shared X^T tile (tw_h3_attns_asm.inc).
 // RFF = true (dense only): 128 random Fourier features of the conditioning positions appended to the in-MLP's input
 // (transformer_nvp_posenc.yaml); six input k-steps, the in-MLP as compiled C++ (the asm section takes two).
-template <int NT, bool ASM, bool DENSE = false, bool WIDE = false, bool RFF = false>
+template <int NT, bool ASM, bool DENSE = false, bool WIDE = false, bool RFF = false, bool ENC = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_h3_kernel(const H3Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   static_assert(!WIDE || (ASM && !DENSE), "the wide layout exists for the asm build of the kernel-attention variant");
   static_assert(!RFF || DENSE, "position features belong to the dense model");
+  static_assert(!ENC || (ASM && !DENSE && !WIDE && NT == 3), "the encoder-stack statement is the 48-token kernel-attention build");
   constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
   constexpr int WAVE_LDS = DENSE ? H3D_WAVE_LDS : (WIDE ? H3W_WAVE_LDS : H3_WAVE_LDS);
   constexpr int SIDE_LDS_OFFSET = DENSE ? H3D_SIDE_LDS_OFFSET : (WIDE ? H3W_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET);
@@ -1355,6 +1356,62 @@ netblock_h3_kernel(const H3Params p) {
       kvalid[jt] = m >> (4 * g);
     }
   }
+  if constexpr (ENC) {
+    // The whole encoder stack as ONE generated statement (tools/gen_h3_enc_asm.py): attention and FFN blocks as below,
+    // and the residual / LayerNorm / split / transpose glue between them hand-scheduled too, with the residual folded
+    // into the accumulators' start values.  x goes in as 24 register images through the wave-private block; what comes
+    // back there are the split operand images of the out-MLP statement.  No activation dumps, no section stamps: the
+    // launch code takes the per-section build for those.
+    static_assert(SIDE_CHUNKS == 3, "gen_h3_enc_asm.py SIDE_CHUNKS");
+    char* priv = (char*)xt_hi;
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) *(f4*)(priv + (ft * NT + jt) * 1024 + lane * 16) = x[ft][jt];
+    int cur = __builtin_amdgcn_readfirstlane(pipe.cur);
+    const char* gn = pipe.gnext;
+    const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
+    const unsigned sl_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(lds + SIDE_LDS_OFFSET);
+    const int heads = __builtin_amdgcn_readfirstlane(p.H);
+    const int chunks = __builtin_amdgcn_readfirstlane(p.ff_chunks);
+    const int layers = __builtin_amdgcn_readfirstlane(p.n_layers);
+    const char* sfp = sf_net;
+    const int64_t sfstride = p.sf_variant_bytes;
+    const char* sidep = (const char*)(side + p.side_layers) + lane * 16;
+    const int64_t sidestride = (int64_t)p.side_layer_size * 4;
+    const float* scp = scales + 2;
+    const float eps = p.eps;
+    // (only read by the H3_ENC_EXPERIMENT=stamps build of the statement, tools/profile_h3_sections.py)
+    const float* stamp_base = p.dump;
+    const int stampen = __builtin_amdgcn_readfirstlane(((p.debug & 16) && p.dump && blockIdx.x == 0 && wave == 0) ? 1 : 0);
+    if (p.windowed) {
+      asm volatile(
+#include "tw_h3_encw_asm.inc"
+          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+            [layers] "s"(layers), [sf] "v"(sfp), [sfstride] "s"(sfstride), [side] "v"(sidep), [sidestride] "s"(sidestride),
+            [sl] "s"(sl_lds), [scales] "s"(scp), [eps] "s"(eps), [padm] "v"(padmask), [padt] "s"(pad_tiles),
+            [dump] "v"(stamp_base), [stampen] "s"(stampen)
+          :
+#include "tw_h3_enc_clobbers.inc"
+      );
+    } else {
+      asm volatile(
+#include "tw_h3_enc_asm.inc"
+          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+            [layers] "s"(layers), [sf] "v"(sfp), [sfstride] "s"(sfstride), [side] "v"(sidep), [sidestride] "s"(sidestride),
+            [sl] "s"(sl_lds), [scales] "s"(scp), [eps] "s"(eps), [padm] "v"(padmask), [padt] "s"(pad_tiles),
+            [dump] "v"(stamp_base), [stampen] "s"(stampen)
+          :
+#include "tw_h3_enc_clobbers.inc"
+      );
+    }
+    pipe.cur = cur;
+    pipe.gnext = gn;
+    stamp(2 + 4 * (p.n_layers - 1) + 3);
+  } else
   for (int l = 0; l < p.n_layers; ++l) {
     const char* sf_base = sf_net + l * p.sf_variant_bytes;  // the layer's own score fragments (chebyshev_kernel), else shared
     // Stage the layer's LayerNorm parameters, FFN output bias and the two output scales (2.6 KB) in LDS: wave 0
@@ -1812,19 +1869,21 @@ netblock_h3_kernel(const H3Params p) {
   f4 o[1][NT];
   {
     BOp<NT> xb[4];
-    to_bop<NT, 4>(x, xb);
+    if constexpr (!ENC) to_bop<NT, 4>(x, xb);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) o[0][jt] = (f4){0.f, 0.f, 0.f, 0.f};
     if constexpr (ASM) {
       // generated asm (tools/gen_h3_ffn_asm.py --shape=out)
       char* priv = (char*)xt_hi;
+      if constexpr (!ENC) {  // (ENC: the encoder-stack statement left the split operand images there)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-          *(h8*)(priv + ((ks * NT + jt) * 2) * 1024 + lane * 16) = xb[ks].h[jt];
-          *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = xb[ks].l[jt];
-        }
+          for (int jt = 0; jt < NT; ++jt) {
+            *(h8*)(priv + ((ks * NT + jt) * 2) * 1024 + lane * 16) = xb[ks].h[jt];
+            *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = xb[ks].l[jt];
+          }
+      }
       int cur = __builtin_amdgcn_readfirstlane(pipe.cur);
       const char* gn = pipe.gnext;
       const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
@@ -2011,8 +2070,15 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
   } else if (g_debug_flags & 8)
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
-  else
+  else if ((dump != nullptr || (g_debug_flags & (4 | 16 | 4096))) && !(g_debug_flags & 8192))
+    // activation dumps / section stamps live between the sections; bit 12 (4096): A/B switch for the encoder-stack build;
+    // bit 13 (8192): the encoder-stack build even with a dump buffer (only the stamps / dumps outside the stack are written)
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
+  else {
+    static LdsLimit lim_enc;
+    if ((prc = lim_enc.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, false, false, true>, (int)H3_LDS_BYTES))) return prc;
+    hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, false, false, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
+  }
   TW_LAUNCH_CHECK();
   if ((prc = profile_mark(a.stream, false))) return prc;
   return TW_OK;

@@ -50,6 +50,11 @@ EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(","
 # MFMAs per k-step (the K=16 shape costs a full slot).  The fragment producer lays tile 2's K=32 block over keys 16..47
 # for this mode (csrc: h3_score_frag_kernel `windowed`).  Single-molecule waves keep the full 48 keys (--mode=full).
 WINDOWED = "--mode=windowed" in sys.argv
+# Set by tools/gen_h3_enc_asm.py, which embeds this block in the asm statement of the whole encoder stack: the accumulators
+# arrive holding the residual (x / scale) instead of zeros, y stays in a0..a95 (no trip through the LDS), and the score
+# fragments of the layer are addressed through SF_BASE (a VGPR pair that statement advances per layer).
+FUSED = False
+SF_BASE = "%[sf]"
 A2 = lambda t, part: XA(t, "a0h" if part == "h" else "a0l") + 2
 
 
@@ -254,8 +259,8 @@ def generate():
     A(f"v_mov_b32 v{V_TMP2 + 1}, 0")
     A(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_LANE16}")
     A(f"v_mov_b32 v{V_LANE16 + 1}, 0")
-    A(f"v_lshl_add_u64 {vr(V_SF16, 2)}, %[sf], 0, {vr(V_LANE16, 2)}")
-    A(f"v_lshl_add_u64 {vr(V_SF8, 2)}, %[sf], 0, {vr(V_TMP2, 2)}")
+    A(f"v_lshl_add_u64 {vr(V_SF16, 2)}, {SF_BASE}, 0, {vr(V_LANE16, 2)}")
+    A(f"v_lshl_add_u64 {vr(V_SF8, 2)}, {SF_BASE}, 0, {vr(V_TMP2, 2)}")
     A(f"s_lshl_b32 s{S_W2048}, %[wave], 11")
     A(f"s_mov_b32 s{S_W2048 + 1}, 0")
     A(f"s_mov_b32 s{S_STRIDE}, {STAGE}")
@@ -271,8 +276,9 @@ def generate():
     A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
     A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
     A(f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}")
-    for i in range(N_A):
-        A(f"v_accvgpr_write_b32 a{i}, 0")
+    if not FUSED:
+        for i in range(N_A):
+            A(f"v_accvgpr_write_b32 a{i}, 0")
     # ---- prologue: score fragments of head 0, mixing of (0, 0) and its split in the open
     L += sf_loads()
     A("s_waitcnt vmcnt(0)")
@@ -324,12 +330,13 @@ def generate():
     A("s_waitcnt lgkmcnt(0)")
     A("s_nop 15")
     A("s_nop 15")
-    A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-    for i in range(24):
-        for r in range(4):
-            A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
-        A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
-    A("s_waitcnt lgkmcnt(0)")
+    if not FUSED:
+        A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
+        for i in range(24):
+            for r in range(4):
+                A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
+            A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
+        A("s_waitcnt lgkmcnt(0)")
     A(f"s_sub_u32 s{S_AUXOFF}, 0, s{S_W2048}")
     A(f"s_subb_u32 s{S_AUXOFF + 1}, 0, 0")
     A(f"v_lshl_add_u64 %[gn], {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]")
@@ -355,4 +362,5 @@ def main():
     print(f"{len(lines)} instructions, {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs")
 
 
-main()
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,466 @@
+#!/usr/bin/env python3
+"""Generate timewarp_amd/csrc/tw_h3_enc_asm.inc (and tw_h3_encw_asm.inc, --mode=windowed): the WHOLE encoder stack of
+the split-fp16 net-block kernel (gfx950) as the body of one `asm volatile` statement - per layer the kernel-attention
+block (gen_h3_attn_asm.py) and the FFN (gen_h3_ffn_asm.py), embedded unchanged, and between them what r01-r03 left to
+hipcc: residual add, LayerNorm, padding select, fp32 -> fp16 hi/lo split, the transposed copy of x.
+
+Why: the section profile put 15.6 k of a layer's 240 k cycles into that compiled glue (1.4 k instructions at ~6 cycles,
+96 AGPR <-> VGPR moves of the residual per section, two trips of y and of the split operands through the LDS).  Here
+  * the residual never exists beside the accumulators: they START at x / scale (attention) or (x + b2) / scale (FFN) -
+    scales are powers of two, so y * scale = x + output with nothing else to add - and the fp32 residual registers of the
+    compiled version (96 per lane, kept in AGPRs across the GEMM blocks) are gone;
+  * y is read once from a0..a95, normalised in registers, split straight into the FFN's operand registers / through the
+    matrix pipe into the transposed tile of the next attention block, and the next accumulators are seeded in the same pass;
+  * every phase runs over 24 independent (feature tile, token tile) register tiles, so VALU latencies overlap.
+
+One LayerNorm (token = lane & 15, its 128 features spread over 8 tiles x 4 lane groups x 4 registers):
+  P1  t = acc * scale                                   sums per token tile
+  P2  mean  (v_permlane16/32_swap across the four lane groups)
+  P3  d = t - mean, squares summed
+  P4  rstd = rsq(var + eps)                              (v_rsq_f32, 1 ulp; the compiled version divided by an IEEE sqrt)
+  P5  x' = d * rstd * w + b, padding tokens -> 0, then  G1: split -> FFN operands, acc <- (x' + b2) / s_w2
+                                                        G2: split -> K=16 MFMAs against the identity -> X^T images,
+                                                            acc <- x' / s_wc(next layer);  last layer: split -> LDS for
+                                                            the out-MLP statement
+Register map of the glue (the embedded blocks own v0..v211 / a0..a119 while they run):
+  v72..v167   T[ft][jt]: y -> t -> d -> x'  (same index as the accumulators: T = 72 + a)
+  v0..v71     G1: the FFN's xb operands (k-steps 0-2; k-step 3 goes to a96..a119).  G2: transposer - D tiles v0..v47
+              (two buffers x 3 token tiles x hi/lo), split halves v48..v71 (two buffers)
+  v168..v191  LayerNorm weight / bias / FFN output bias of a feature tile (two buffers; streamed from the side block)
+  v192..v211  temporaries, X^T image staging (G2: v176..v179, v188..v191, v208..v211)
+  v212..v223  sums, -mean / rstd pairs
+  v224..v237  persistent: LDS addresses, padding mask, score-fragment base, side-block DMA source, identity operand,
+              broadcast constants
+  s74..s82, s98, s99  layer counter, scales and their inverses, eps
+Operands: see the asm statement in csrc/tw_netblock_h3.hip (kernel, `ENC`)."""
+import importlib.util
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(HERE, name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+WINDOWED = "--mode=windowed" in sys.argv
+EXPERIMENT = set(filter(None, os.environ.get("H3_ENC_EXPERIMENT", "").split(",")))
+attn = load("gen_h3_attn_asm")
+ffn = load("gen_h3_ffn_asm")
+attn.WINDOWED = WINDOWED
+attn.FUSED = True
+ffn.FUSED = True
+ffn.SHAPE = ffn.SHAPES["ffn"]
+
+NT = 3
+SIDE_CHUNKS = 3
+XT_IMG = attn.XT_IMG
+# side block of a layer (floats): LN1 w, LN1 b, FFN b2, LN2 w, LN2 b (128 each)
+SIDE_LN1W, SIDE_LN1B, SIDE_B2, SIDE_LN2W, SIDE_LN2B = 0, 128, 256, 384, 512
+
+T = lambda ft, jt: 72 + 4 * (3 * ft + jt)
+ACC = lambda ft, jt: 4 * (3 * ft + jt)
+PRM = lambda buf, which: 168 + 12 * buf + 4 * which        # which: 0 = w, 1 = b, 2 = b2 / s_w2
+TMP = lambda k: 192 + 4 * (k % 2)
+U = lambda k: 200 + 4 * (k % 2)
+V_ACC0 = 208                                               # G1: seed of an accumulator tile
+D = lambda buf, jt, part: 4 * (6 * buf + 2 * jt + part)    # part: 0 = hi, 1 = lo
+H = lambda buf, jt, part: 48 + 12 * buf + 4 * jt + 2 * part
+IMG01 = lambda part: (176, 188)[part]                      # G2 streams two parameters per buffer: 176..179, 188..191 are free
+IMG2 = lambda part: 208 + 2 * part
+S2 = lambda jt: 212 + 2 * jt
+NM = lambda jt: 218 + 2 * jt
+V_PRIV8, V_PRIV16, V_SLG, V_PAD, V_SFB, V_SIDE, V_IDB, V_C, V_C2 = 224, 225, 226, 227, 228, 230, 232, 234, 236
+N_V = 244
+S_LAYER, S_PADT, S_SCPTR, S_SCA, S_SCF, S_IA, S_IF, S_EPS, S_NA, S_NF = 76, 77, 78, 80, 81, 82, 98, 99, 74, 75
+attn.SF_BASE = f"v[{V_SFB}:{V_SFB + 1}]"
+S_MASK = lambda jt: 84 + 2 * jt                            # scratch of the embedded blocks, free in the glue
+XBX = lambda ks, jt, part: (8 * (3 * ks + jt) if ks < 3 else 72 + 8 * jt) + (0 if part == 0 else 4)   # exit: all VGPRs
+
+
+def vr(base, n=2):
+    return f"v[{base}:{base + n - 1}]"
+
+
+def interleave(*streams):
+    """Round-robin merge of instruction streams (independent register tiles): hides VALU latencies."""
+    out, streams = [], [list(s) for s in streams]
+    while any(streams):
+        for s in streams:
+            if s:
+                out.append(s.pop(0))
+    return out
+
+
+def quad_sums(regs):
+    """regs: list of (value VGPR, scratch VGPR).  value <- sum over the four lanes sharing (lane & 15); same association
+    as csrc h3_quad_sum."""
+    out = []
+    out += [f"v_mov_b32 v{b}, v{a}" for a, b in regs]
+    out += ["s_nop 1"]
+    out += [f"v_permlane16_swap_b32 v{a}, v{b}" for a, b in regs]
+    out += [f"v_add_f32 v{a}, v{a}, v{b}" for a, b in regs]
+    out += [f"v_mov_b32 v{b}, v{a}" for a, b in regs]
+    out += ["s_nop 1"]
+    out += [f"v_permlane32_swap_b32 v{a}, v{b}" for a, b in regs]
+    out += [f"v_add_f32 v{a}, v{a}, v{b}" for a, b in regs]
+    return out
+
+
+V_ONE = 240   # pair [1.0, 1.0]: a + b as fma(a, 1, b) - v_pk_add_f32 costs twice a v_pk_fma_f32 (tools/probe/valu_cost_probe.hip)
+
+
+def layer_norm(inv_sgpr, w_off, b_off, label):
+    """T <- LayerNorm(acc * scale) * w + b, padding tokens -> 0.  The scale (a power of two) never touches the data:
+    with t = acc, x = scale * t:  (x - mean_x) * rsq(var_x + eps) = (t - mean_t) * rsq(var_t + eps / scale^2)."""
+    L = []
+    A = L.append
+    for jt in range(NT):
+        A(f"v_mov_b32 v{S2(jt)}, 0")
+        A(f"v_mov_b32 v{S2(jt) + 1}, 0")
+    # P1: t = acc, sums
+    for ft in range(8):
+        for jt in range(NT):
+            for r in range(4):
+                A(f"v_accvgpr_read_b32 v{T(ft, jt) + r}, a{ACC(ft, jt) + r}")
+        for h in range(2):
+            for jt in range(NT):
+                A(f"v_pk_fma_f32 {vr(S2(jt))}, {vr(T(ft, jt) + 2 * h)}, {vr(V_ONE)}, {vr(S2(jt))}")
+    # P2: -mean
+    for jt in range(NT):
+        A(f"v_add_f32 v{S2(jt)}, v{S2(jt)}, v{S2(jt) + 1}")
+    L += quad_sums([(S2(jt), S2(jt) + 1) for jt in range(NT)])
+    for jt in range(NT):
+        A(f"v_mul_f32 v{NM(jt)}, 0xbc000000, v{S2(jt)}")
+    for jt in range(NT):
+        A(f"v_mov_b32 v{NM(jt) + 1}, v{NM(jt)}")
+        A(f"v_mov_b32 v{S2(jt)}, 0")
+        A(f"v_mov_b32 v{S2(jt) + 1}, 0")
+    # P3: d = t - mean, squares
+    for ft in range(8):
+        for h in range(2):
+            for jt in range(NT):
+                A(f"v_pk_fma_f32 {vr(T(ft, jt) + 2 * h)}, {vr(T(ft, jt) + 2 * h)}, {vr(V_ONE)}, {vr(NM(jt))}")
+        for h in range(2):
+            for jt in range(NT):
+                A(f"v_pk_fma_f32 {vr(S2(jt))}, {vr(T(ft, jt) + 2 * h)}, {vr(T(ft, jt) + 2 * h)}, {vr(S2(jt))}")
+    # P4: rstd = rsq(var + eps / scale^2)
+    for jt in range(NT):
+        A(f"v_add_f32 v{S2(jt)}, v{S2(jt)}, v{S2(jt) + 1}")
+    A(f"v_mov_b32 v{TMP(0)}, s{S_EPS}")
+    A(f"v_mul_f32 v{TMP(0)}, s{inv_sgpr}, v{TMP(0)}")
+    A(f"v_mul_f32 v{TMP(0)}, s{inv_sgpr}, v{TMP(0)}")
+    L += quad_sums([(S2(jt), S2(jt) + 1) for jt in range(NT)])
+    for jt in range(NT):
+        A(f"v_fmamk_f32 v{S2(jt)}, v{S2(jt)}, 0x3c000000, v{TMP(0)}")
+    for jt in range(NT):
+        A(f"v_rsq_f32 v{NM(jt)}, v{S2(jt)}")
+    A("s_nop 1")
+    for jt in range(NT):
+        A(f"v_mov_b32 v{NM(jt) + 1}, v{NM(jt)}")
+    # P5a: x' = d * rstd * w + b  (w, b of a feature tile streamed from the side block, two buffers)
+    L += [f"ds_read_b128 {vr(PRM(0, 0), 4)}, v{V_SLG} offset:{4 * w_off}", f"ds_read_b128 {vr(PRM(0, 1), 4)}, v{V_SLG} offset:{4 * b_off}"]
+    for ft in range(8):
+        buf = ft % 2
+        if ft + 1 < 8:
+            L += [f"ds_read_b128 {vr(PRM(1 - buf, 0), 4)}, v{V_SLG} offset:{4 * w_off + 64 * (ft + 1)}",
+                  f"ds_read_b128 {vr(PRM(1 - buf, 1), 4)}, v{V_SLG} offset:{4 * b_off + 64 * (ft + 1)}"]
+            A("s_waitcnt lgkmcnt(2)")
+        else:
+            A("s_waitcnt lgkmcnt(0)")
+        for h in range(2):
+            for jt in range(NT):
+                A(f"v_pk_mul_f32 {vr(T(ft, jt) + 2 * h)}, {vr(T(ft, jt) + 2 * h)}, {vr(NM(jt))}")
+        for h in range(2):
+            for jt in range(NT):
+                A(f"v_pk_fma_f32 {vr(T(ft, jt) + 2 * h)}, {vr(T(ft, jt) + 2 * h)}, {vr(PRM(buf, 0) + 2 * h)}, {vr(PRM(buf, 1) + 2 * h)}")
+    # padding tokens -> 0: per token tile, only tiles that hold any (S_PADT) - three branches per LayerNorm
+    for jt in range(NT):
+        A(f"s_bitcmp0_b32 s{S_PADT}, {jt}")
+        A(f"s_cbranch_scc1 .Lenc_nopad_{label}_{jt}_%=")
+        A(f"v_and_b32 v{TMP(0)}, {1 << jt}, v{V_PAD}")
+        A(f"v_cmp_eq_u32 vcc, 0, v{TMP(0)}")
+        for ft in range(8):
+            for r in range(4):
+                A(f"v_cndmask_b32 v{T(ft, jt) + r}, 0, v{T(ft, jt) + r}, vcc")
+        A(f".Lenc_nopad_{label}_{jt}_%=:")
+    return L
+
+
+def split_tile(t, hi, lo, tmp):
+    """T tile (4 fp32) -> hi pair regs (2), lo pair regs (2): the eight VALU ops of csrc split_pair x 2."""
+    ops = [f"v_cvt_pk_f16_f32 v{hi}, v{t}, v{t + 1}", f"v_cvt_pk_f16_f32 v{hi + 1}, v{t + 2}, v{t + 3}"]
+    for r in range(4):
+        sel = "op_sel:[1,0,0] " if r % 2 else ""
+        ops.append(f"v_fma_mix_f32 v{tmp + r}, v{hi + r // 2}, -1.0, v{t + r} {sel}op_sel_hi:[1,0,0]")
+    ops += [f"v_cvt_pk_f16_f32 v{lo}, v{tmp}, v{tmp + 1}", f"v_cvt_pk_f16_f32 v{lo + 1}, v{tmp + 2}, v{tmp + 3}"]
+    return ops
+
+
+def g1():
+    """After the attention block: LayerNorm 1, FFN operands, FFN accumulator seeds (x' + b2) / s_w2."""
+    L = layer_norm(S_IA, SIDE_LN1W, SIDE_LN1B, "g1")
+    A = L.append
+    A(f"v_mov_b32 v{V_C}, s{S_IF}")
+    A(f"v_mov_b32 v{V_C + 1}, s{S_IF}")
+    b2 = lambda buf: PRM(buf, 2)
+    A(f"ds_read_b128 {vr(b2(0), 4)}, v{V_SLG} offset:{4 * SIDE_B2}")
+    for ft in range(8):
+        buf = ft % 2
+        if ft + 1 < 8:
+            A(f"ds_read_b128 {vr(b2(1 - buf), 4)}, v{V_SLG} offset:{4 * SIDE_B2 + 64 * (ft + 1)}")
+            A("s_waitcnt lgkmcnt(1)")
+        else:
+            A("s_waitcnt lgkmcnt(0)")
+        for h in range(2):   # b2 / s_w2
+            A(f"v_pk_mul_f32 {vr(b2(buf) + 2 * h)}, {vr(b2(buf) + 2 * h)}, {vr(V_C)}")
+        ks, odd = ft // 2, ft % 2
+        streams = []
+        for jt in range(NT):
+            s = []
+            if ks < 3:
+                hi, lo = ffn.XB(ks, jt, "h") + 2 * odd, ffn.XB(ks, jt, "l") + 2 * odd
+                s += split_tile(T(ft, jt), hi, lo, TMP(jt))
+            else:
+                # k-step 3 lives in AGPRs: split into temporaries, then move
+                hi, lo = U(jt), U(jt) + 2
+                s += split_tile(T(ft, jt), hi, lo, TMP(jt))
+                s += [f"v_accvgpr_write_b32 a{ffn.XB(3, jt, 'h') + 2 * odd + k}, v{hi + k}" for k in range(2)]
+                s += [f"v_accvgpr_write_b32 a{ffn.XB(3, jt, 'l') + 2 * odd + k}, v{lo + k}" for k in range(2)]
+            streams.append(s)
+        # three tiles share TMP / U (two sets): tiles 0 and 1 interleaved, tile 2 behind them
+        L += interleave(streams[0], streams[1]) + streams[2]
+        for jt in range(NT):
+            t = T(ft, jt)
+            for h in range(2):
+                A(f"v_pk_fma_f32 {vr(V_ACC0 + 2 * h)}, {vr(t + 2 * h)}, {vr(V_C)}, {vr(b2(buf) + 2 * h)}")
+            for r in range(4):
+                A(f"v_accvgpr_write_b32 a{ACC(ft, jt) + r}, v{V_ACC0 + r}")
+    return L
+
+
+def transposer_issue(ft, buf):
+    """Split the three tiles of feature tile ft and send them through the matrix pipe (K = 16 against the identity)."""
+    L = []
+    L += interleave(split_tile(T(ft, 0), H(buf, 0, 0), H(buf, 0, 1), TMP(0)),
+                    split_tile(T(ft, 1), H(buf, 1, 0), H(buf, 1, 1), TMP(1)))
+    L += split_tile(T(ft, 2), H(buf, 2, 0), H(buf, 2, 1), TMP(0))
+    L.append("s_nop 1")
+    for jt in range(NT):
+        for part in range(2):
+            L.append(f"v_mfma_f32_16x16x16_f16 {vr(D(buf, jt, part), 4)}, {vr(H(buf, jt, part))}, {vr(V_IDB)}, 0")
+    return L
+
+
+def transposer_drain(ft, buf):
+    """D tiles of feature tile ft (issued a whole tile of work ago) -> packed images -> LDS."""
+    L = []
+    for part in range(2):
+        for jt in range(2):
+            d = D(buf, jt, part)
+            L += [f"v_cvt_pk_f16_f32 v{IMG01(part) + 2 * jt}, v{d}, v{d + 1}",
+                  f"v_cvt_pk_f16_f32 v{IMG01(part) + 2 * jt + 1}, v{d + 2}, v{d + 3}"]
+        d = D(buf, 2, part)
+        L += [f"v_cvt_pk_f16_f32 v{IMG2(part)}, v{d}, v{d + 1}", f"v_cvt_pk_f16_f32 v{IMG2(part) + 1}, v{d + 2}, v{d + 3}"]
+    for part in range(2):
+        off = 2 * XT_IMG * ft + XT_IMG * part
+        L += [f"ds_write_b128 v{V_PRIV16}, {vr(IMG01(part), 4)} offset:{off}",
+              f"ds_write_b64 v{V_PRIV8}, {vr(IMG2(part))} offset:{off + 1024}"]
+    return L
+
+
+def seed_attention(ft):
+    """acc <- x' / s_wc for the three tiles of feature tile ft (V_C2 = 1 / s_wc of the layer that follows)."""
+    L = []
+    for jt in range(NT):
+        t = T(ft, jt)
+        L += [f"v_pk_mul_f32 {vr(U(jt) + 2 * h)}, {vr(t + 2 * h)}, {vr(V_C2)}" for h in range(2)]
+        L += [f"v_accvgpr_write_b32 a{ACC(ft, jt) + r}, v{U(jt) + r}" for r in range(4)]
+    return L
+
+
+def entry_transposer():
+    """Layer 0: x (in T) -> X^T images + accumulator seeds."""
+    L = []
+    for ft in range(8):
+        L += transposer_issue(ft, ft % 2)
+        L += seed_attention(ft)
+        if ft > 0:
+            L += transposer_drain(ft - 1, (ft - 1) % 2)
+    L += ["s_nop 7", "s_nop 7"]
+    L += transposer_drain(7, 1)
+    return L
+
+
+def g2(last):
+    """After the FFN: LayerNorm 2, then the next layer's transposed tile and accumulator seeds (or, last layer, the
+    split operand images of the out-MLP)."""
+    L = layer_norm(S_IF, SIDE_LN2W, SIDE_LN2B, "g2x" if last else "g2")
+    A = L.append
+    for ft in range(8):
+        buf = ft % 2
+        if last:
+            ks, odd = ft // 2, ft % 2
+            L += interleave(split_tile(T(ft, 0), XBX(ks, 0, 0) + 2 * odd, XBX(ks, 0, 1) + 2 * odd, TMP(0)),
+                            split_tile(T(ft, 1), XBX(ks, 1, 0) + 2 * odd, XBX(ks, 1, 1) + 2 * odd, TMP(1)))
+            L += split_tile(T(ft, 2), XBX(ks, 2, 0) + 2 * odd, XBX(ks, 2, 1) + 2 * odd, TMP(0))
+            if odd:
+                for jt in range(NT):
+                    for part in range(2):
+                        A(f"ds_write_b128 v{V_PRIV16}, {vr(XBX(ks, jt, part), 4)} offset:{1024 * ((ks * NT + jt) * 2 + part)}")
+        else:
+            L += transposer_issue(ft, buf)
+            L += seed_attention(ft)
+            if ft > 0:
+                L += transposer_drain(ft - 1, 1 - buf)
+    if not last:
+        L += ["s_nop 7", "s_nop 7"]
+        L += transposer_drain(7, 1)
+    return L
+
+
+V_STAMP = 242   # stamps build only: dump address of the current layer's stamp block
+N_STAMP = [0]
+
+
+def stamp(k):
+    """H3_ENC_EXPERIMENT=stamps: s_memtime -> dump[40 + 4 l + k] (k = 0..3: attention start / end, FFN start / end) or,
+    k = 4, dump[2 + 4 l + 3] (end of the layer), by the wave the caller enabled (%[stampen])."""
+    if "stamps" not in EXPERIMENT:
+        return []
+    N_STAMP[0] += 1
+    off = 8 * (40 + k) if k < 4 else 8 * (2 + 3)
+    return ["s_cmp_eq_u32 %[stampen], 0", f"s_cbranch_scc1 .Lenc_nostamp_{N_STAMP[0]}_%=",
+            "s_memtime s[70:71]", "s_waitcnt lgkmcnt(0)",
+            f"v_mov_b32 v{NM(2)}, s70", f"v_mov_b32 v{NM(2) + 1}, s71",
+            f"global_store_dwordx2 {vr(V_STAMP)}, {vr(NM(2))}, off offset:{off}",
+            f".Lenc_nostamp_{N_STAMP[0]}_%=:"]
+
+
+def layer_top():
+    """All waves are done with the previous layer's side block: wave 0 fetches this layer's (LDS-DMA, nobody waits here:
+    it is older than every weight stage of the layer, the first hand-off inside the attention block covers it)."""
+    L = ["s_waitcnt lgkmcnt(0)", "s_barrier",
+         "s_cmp_lg_u32 %[wave], 0", "s_cbranch_scc1 .Lenc_noside_%=",
+         "s_mov_b32 m0, %[sl]", "s_nop 0"]
+    for i in range(SIDE_CHUNKS):
+        L.append(f"global_load_lds_dwordx4 {vr(V_SIDE)}, off" + (f" offset:{1024 * i}" if i else ""))
+    L += [f"v_lshl_add_u64 {vr(V_SIDE)}, {vr(V_SIDE)}, 0, %[sidestride]", ".Lenc_noside_%=:"]
+    return L
+
+
+def generate():
+    L = []
+    A = L.append
+    # ---- persistent registers
+    A(f"v_mbcnt_lo_u32_b32 v{TMP(0)}, -1, 0")
+    A(f"v_mbcnt_hi_u32_b32 v{TMP(0)}, -1, v{TMP(0)}")                 # lane
+    A(f"v_lshlrev_b32 v{V_PRIV8}, 3, v{TMP(0)}")
+    A(f"v_add_u32 v{V_PRIV8}, %[priv], v{V_PRIV8}")
+    A(f"v_lshlrev_b32 v{V_PRIV16}, 4, v{TMP(0)}")
+    A(f"v_add_u32 v{V_PRIV16}, %[priv], v{V_PRIV16}")
+    A(f"v_lshrrev_b32 v{TMP(0) + 1}, 4, v{TMP(0)}")                   # g
+    A(f"v_lshlrev_b32 v{V_SLG}, 4, v{TMP(0) + 1}")
+    A(f"v_add_u32 v{V_SLG}, %[sl], v{V_SLG}")                        # side block + 16 g bytes
+    A(f"v_mov_b32 v{V_PAD}, %[padm]")
+    A(f"v_mov_b64 {vr(V_SFB)}, %[sf]")
+    A(f"v_mov_b64 {vr(V_SIDE)}, %[side]")
+    # identity operand of the transposing MFMA: element e of lane (i16, g) = (i16 == 4 g + e)
+    A(f"v_and_b32 v{TMP(0) + 2}, 15, v{TMP(0)}")                      # i16
+    A(f"v_lshlrev_b32 v{TMP(0) + 3}, 2, v{TMP(0) + 1}")               # 4 g
+    A(f"v_sub_u32 v{TMP(0) + 2}, v{TMP(0) + 2}, v{TMP(0) + 3}")       # i16 - 4 g  (0..3 -> a one in that element)
+    A(f"v_mov_b32 v{V_IDB}, 0")
+    A(f"v_mov_b32 v{V_IDB + 1}, 0")
+    A(f"v_mov_b32 v{TMP(1) + 2}, 0x3c00")
+    A(f"v_mov_b32 v{TMP(1) + 3}, 0x3c000000")
+    for e, (reg, src) in enumerate(((V_IDB, TMP(1) + 2), (V_IDB, TMP(1) + 3), (V_IDB + 1, TMP(1) + 2), (V_IDB + 1, TMP(1) + 3))):
+        A(f"v_cmp_eq_u32 vcc, {e}, v{TMP(0) + 2}")
+        A(f"v_cndmask_b32 v{reg}, v{reg}, v{src}, vcc")
+    A(f"v_mov_b32 v{V_ONE}, 1.0")
+    A(f"v_mov_b32 v{V_ONE + 1}, 1.0")
+    A(f"s_mov_b32 s{S_LAYER}, %[layers]")
+    A(f"s_mov_b32 s{S_PADT}, %[padt]")
+    A(f"s_mov_b64 s[{S_SCPTR}:{S_SCPTR + 1}], %[scales]")
+    A(f"s_mov_b32 s{S_EPS}, %[eps]")
+    A(f"s_load_dword s{S_SCA}, s[{S_SCPTR}:{S_SCPTR + 1}], 0x0")
+    A(f"s_load_dword s{S_SCF}, s[{S_SCPTR}:{S_SCPTR + 1}], 0x8")
+    # ---- x in: 24 register images from the wave-private block
+    for ft in range(8):
+        for jt in range(NT):
+            A(f"ds_read_b128 {vr(T(ft, jt), 4)}, v{V_PRIV16} offset:{1024 * (ft * NT + jt)}")
+    A("s_waitcnt lgkmcnt(0)")
+    A(f"s_sub_u32 s{S_IA}, 0x7f000000, s{S_SCA}")                    # scales are powers of two: 1 / s by exponent
+    A(f"s_sub_u32 s{S_IF}, 0x7f000000, s{S_SCF}")
+    A(f"v_mov_b32 v{V_C2}, s{S_IA}")
+    A(f"v_mov_b32 v{V_C2 + 1}, s{S_IA}")
+    L += entry_transposer()
+    # ---- layer loop
+    if "stamps" in EXPERIMENT:
+        A(f"v_mov_b64 {vr(V_STAMP)}, %[dump]")
+        A("s_mov_b32 s72, 32")
+        A("s_mov_b32 s73, 0")
+    A(".Lenc_layer_%=:")
+    L += stamp(0)
+    L += layer_top()
+    L += attn.generate()
+    L += stamp(1)
+    L += g1()
+    L += stamp(2)
+    L += ffn.generate()
+    L += stamp(3)
+    A(f"s_sub_u32 s{S_LAYER}, s{S_LAYER}, 1")
+    A(f"s_cmp_eq_u32 s{S_LAYER}, 0")
+    A("s_cbranch_scc1 .Lenc_last_%=")
+    # next layer's scales (12 bytes further), fragments
+    A(f"s_add_u32 s{S_SCPTR}, s{S_SCPTR}, 12")
+    A(f"s_addc_u32 s{S_SCPTR + 1}, s{S_SCPTR + 1}, 0")
+    A(f"s_load_dword s{S_NA}, s[{S_SCPTR}:{S_SCPTR + 1}], 0x0")
+    A(f"s_load_dword s{S_NF}, s[{S_SCPTR}:{S_SCPTR + 1}], 0x8")
+    A(f"v_lshl_add_u64 {vr(V_SFB)}, {vr(V_SFB)}, 0, %[sfstride]")
+    A("s_waitcnt lgkmcnt(0)")
+    A(f"s_sub_u32 s{S_IA}, 0x7f000000, s{S_NA}")
+    A(f"v_mov_b32 v{V_C2}, s{S_IA}")
+    A(f"v_mov_b32 v{V_C2 + 1}, s{S_IA}")
+    L += g2(False)
+    L += stamp(4)
+    if "stamps" in EXPERIMENT:
+        A(f"v_lshl_add_u64 {vr(V_STAMP)}, {vr(V_STAMP)}, 0, s[72:73]")
+    A(f"s_mov_b32 s{S_SCA}, s{S_NA}")
+    A(f"s_mov_b32 s{S_SCF}, s{S_NF}")
+    A(f"s_sub_u32 s{S_IF}, 0x7f000000, s{S_SCF}")
+    A("s_branch .Lenc_layer_%=")
+    A(".Lenc_last_%=:")
+    L += g2(True)
+    A("s_waitcnt lgkmcnt(0)")
+    L += stamp(4)
+    return L
+
+
+def main():
+    lines = generate()
+    out_dir = "timewarp_amd/csrc"
+    for a in sys.argv[1:]:
+        if a.startswith("--out-dir="):
+            out_dir = a.split("=", 1)[1]
+    mode = " --mode=windowed" if WINDOWED else ""
+    base = os.path.join(out_dir, "tw_h3_encw_asm.inc" if WINDOWED else "tw_h3_enc_asm.inc")
+    out = [f"// GENERATED by tools/gen_h3_enc_asm.py{mode} - do not edit.  Body of the encoder-stack asm statement."]
+    out += ['"' + l + '\\n\\t"' for l in lines]
+    open(base, "w").write("\n".join(out) + "\n")
+    if not WINDOWED:
+        clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(120)] + [f'"s{i}"' for i in range(70, 100)] + \
+               ['"vcc"', '"scc"', '"memory"']
+        cl = ["// GENERATED by tools/gen_h3_enc_asm.py - clobber list of the encoder-stack asm statement."]
+        for i in range(0, len(clob), 12):
+            cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
+        open(os.path.join(out_dir, "tw_h3_enc_clobbers.inc"), "w").write("\n".join(cl) + "\n")
+    n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
+    print(f"enc{mode}: {len(lines)} instructions, {n_mfma} MFMAs")
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,10 @@ SPREAD = "nospread" not in EXPERIMENT
 # beside the 9 MFMAs of its single B stage; in: three tails under the next A stage
 IOTAIL = "iotail" in EXPERIMENT
 
+# Set by tools/gen_h3_enc_asm.py (the FFN embedded in the asm statement of the whole encoder stack): the split input is
+# already in the xb registers, the accumulators hold the residual ((x + b2) / scale) and y stays in a0..a95.
+FUSED = False
+
 NT = 3
 # Shapes of the three chunked MLPs (same schedule, one generated file each):
 #   ffn : 128 -> 32-unit chunk (ReLU) -> 128     A = 2 stages (o = 0, 1; 4 k-steps),  B = 2 stages (ot 0-3, 4-7)
@@ -356,13 +360,14 @@ def generate():
     ffn = SHAPE["tag"] == "ffn"
     n_a, n_b = (2 if ks_in == 4 else 1), (ot_out + 3) // 4
     # input operand (split activations) from the wave-private LDS block: 2 images per (ks, jt)
-    A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-    for i in range(2 * NT * ks_in):
-        dst = vr(4 * i) if i < 18 else ar(96 + 4 * (i - 18))
-        A(f"ds_read_b128 {dst}, v{V_TMP} offset:{1024 * i}")
-    for i in range(4 * NT * ot_out):
-        A(f"v_accvgpr_write_b32 a{i}, 0")
-    A("s_waitcnt lgkmcnt(0)")
+    if not FUSED:
+        A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
+        for i in range(2 * NT * ks_in):
+            dst = vr(4 * i) if i < 18 else ar(96 + 4 * (i - 18))
+            A(f"ds_read_b128 {dst}, v{V_TMP} offset:{1024 * i}")
+        for i in range(4 * NT * ot_out):
+            A(f"v_accvgpr_write_b32 a{i}, 0")
+        A("s_waitcnt lgkmcnt(0)")
     # first stage's reads
     for r in tile_reads(0) + tile_reads(1):
         A(r)
@@ -471,12 +476,13 @@ def generate():
     # ---- y out through the wave-private LDS block
     A("s_nop 15")
     A("s_nop 15")
-    A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-    for i in range(NT * ot_out):
-        for r in range(4):
-            A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
-        A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
-    A("s_waitcnt lgkmcnt(0)")
+    if not FUSED:
+        A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
+        for i in range(NT * ot_out):
+            for r in range(4):
+                A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
+            A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
+        A("s_waitcnt lgkmcnt(0)")
     # gnext back (without the wave term)
     A(f"s_sub_u32 s{S_AUXOFF}, 0, s{S_W2048}")
     A(f"s_subb_u32 s{S_AUXOFF + 1}, 0, 0")
@@ -511,4 +517,5 @@ def main():
     print(f"{shape}: {len(lines)} instructions, {n_mfma} MFMAs")
 
 
-main()
+if __name__ == "__main__":
+    main()

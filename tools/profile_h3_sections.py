@@ -32,6 +32,17 @@ names += ["out_mlp"]
 t = ts[: len(names)]
 total = t[-1] - t[0]
 print(f"total {total} cycles")
+if extra & 8192:   # encoder-stack build (tools/gen_h3_enc_asm.py); inner stamps only from its H3_ENC_EXPERIMENT=stamps build
+    print(f"  in_mlp {t[1] - t[0]}, encoder stack {t[-2] - t[1]} ({(t[-2] - t[1]) // L} per layer), out_mlp {t[-1] - t[-2]}")
+    prev = t[1]
+    for l in range(L):
+        a0, a1, f0, f1 = ts[40 + 4 * l: 44 + 4 * l]
+        end = ts[2 + 4 * l + 3]
+        if a0 and a1 > a0:
+            print(f"  layer {l}: before the layer {a0 - prev}, barrier + side DMA + attention {a1 - a0}, LN1 glue {f0 - a1}, FFN {f1 - f0}, "
+                  f"LN2 glue (+ transposer) {end - f1}")
+        prev = end
+    sys.exit(0)
 agg = {}
 for i in range(1, len(names)):
     d = t[i] - t[i - 1]
