@@ -33,10 +33,15 @@ FLOP_PER_SAMPLE_PASS = 1.612e9  # 16 * V * F_blk(V), V = 22
 N_COUPLING = 8
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (~2.5 PF)
+# What the chip sustains (reported beside the roofline, never instead of it): tools/probe/mfma_stream_probe on all 256 CUs with
+# random fp16 operands runs at 1.74 GHz (profiles/r03_mfma_stream_probe.txt); the dominant kernel keeps a wave's matrix pipe
+# busy for 579.5 k clocks per launch (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_h3_sq_counters.md)
+SUSTAINED_MFMA_CLOCK_GHZ = 1.74
+H3_MFMA_BUSY_CLOCKS_PER_LAUNCH = 579.5e3
 # execution paths of the flow (include/timewarp_hip.h): both hold the 1e-5 parity bar
 PATHS = {
     "h3": dict(path=3, dtype="f16x3 (split-fp16 operands, 3 MFMAs per fp32 product, fp32 accumulate)",
-               kernel="tw::netblock_h3_kernel<3, true>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=3),
+               kernel="tw::netblock_h3_kernel<3, true, false, false, false, true>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=3),
     "f32": dict(path=1, dtype="f32", kernel="tw::netblock_kernel<3>", peak=F32_MFMA_PEAK_TFLOPS, mfma_per_product=1),
 }
 # Synthetic-weight calibration (SURVEY section 8d idea, tuned so acceptance is non-degenerate against
@@ -127,7 +132,10 @@ def attention_block(model, device, proposals, avg_launch_ms):
         "share_of_launch": share, "algorithmic_flop_per_launch": float(flop_launch),
         "executed_over_algorithmic": "2.26 (3-term fp16 split x 1/2 from folding out_proj into values_proj per head "
                                      "+ the K=48 block-diagonal mixing on K=32+16 MFMAs)",
-        "method": "s_memtime section stamps of one untimed launch (tw_debug_set_flags 16) x live average launch time",
+        "method": "s_memtime section stamps of one untimed launch (tw_debug_set_flags 16: the per-section build of the kernel, "
+                  "whose stamps sit between the sections) x live average launch time of the encoder-stack build; that build "
+                  "spends 3 x 52.4 k of 758 k cycles in the attention blocks (profiles/r03_enc_stack_ab.txt), so the share "
+                  "used here is slightly high and the rate slightly low",
     }
 
 
@@ -500,6 +508,18 @@ def main():
         }
         if args.path == "h3" and args.proposals == S_PROPOSALS:
             out["roofline"]["attention_block"] = attention_block(model, device, args.proposals, avg_ms)
+            floor_ms = H3_MFMA_BUSY_CLOCKS_PER_LAUNCH / (SUSTAINED_MFMA_CLOCK_GHZ * 1e6)
+            out["roofline"]["power_bound"] = {
+                "what": "launch time if the matrix pipe never idled, at the clock the chip sustains with every matrix pipe busy on "
+                        "random fp16 operands (tools/probe/mfma_stream_probe: 2.40 GHz on one CU, 1.74 GHz on 256); frac = that "
+                        "floor / the live launch time.  Context for `frac` above, not a replacement of it",
+                "matrix_pipe_busy_clocks_per_wave": H3_MFMA_BUSY_CLOCKS_PER_LAUNCH,
+                "sustained_clock_ghz": SUSTAINED_MFMA_CLOCK_GHZ,
+                "sustained_f16_mfma_tflops": SUSTAINED_MFMA_CLOCK_GHZ * 1e9 * 1024 * 1024 / 1e12,
+                "floor_ms": floor_ms,
+                "frac": floor_ms / avg_ms,
+                "source": "profiles/r03_mfma_stream_probe.txt, profiles/r03_h3_sq_counters.md",
+            }
         if world == 1 and args.path != "f32":
             out["alt_path"] = alt_path_record(device, distributed.chain_seed(args.seed, rank), args.proposals,
                                               max(4, args.steps // 4), args.sync_every)

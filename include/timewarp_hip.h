@@ -305,7 +305,11 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *              launch's prologue (A/B switch; same results up to the summation order of the log-determinant)
  *   bit 6 (64), bit 7 (128) fused dense kernel, timing experiments (results WRONG): no softmax section / also no LDS round
  *              trip of q, k, v - what the attention block costs beyond its MFMAs (0.8 of 11.4 ms per 1000-proposal pass)
- *   bit 10 (1024) split-fp16 kernel: do not zero the padding tokens of a wave between sections (A/B switch; results equal) */
+ *   bit 10 (1024) split-fp16 kernel: do not zero the padding tokens of a wave between sections (A/B switch; results equal)
+ *   bit 12 (4096) split-fp16 kernel-attention kernel, <= 48 atoms: run the per-section build (attention / FFN asm blocks with
+ *              compiled glue between them) instead of the encoder-stack statement (tools/gen_h3_enc_asm.py); same results
+ *              up to the last bits.  Activation dumps (tw_debug_netblock) and bits 2 / 4 take that build anyway.
+ *   bit 13 (8192) ... the encoder-stack build even with a dump buffer (profiling: only stamps outside the stack) */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every
