@@ -283,6 +283,45 @@ def test_sample_trajectory_segments_and_resume(tmp_path):
     assert len(os.listdir(out)) == 4
 
 
+def test_recorded_draws_replay_in_order():
+    """The split-fp16 range guard redoes the iterations since the last read-back on the f32 kernels with the SAME random
+    numbers: RecordingNoise keeps every draw in order (latents written into caller buffers are kept as copies - the
+    buffers become the proposals), `mark()` starts a new window, ReplayDraws hands the window back draw by draw, also
+    through the other latents entry point."""
+    from timewarp_amd.utils.evaluation_utils import DeviceNoise, RecordingNoise, ReplayDraws
+
+    S, V = 5, 4
+    rec = RecordingNoise(DeviceNoise("cpu", seed=3))
+    rec.uniform(S)                                   # an iteration before the read-back: forgotten by mark()
+    rec.mark()
+    zc, zv = torch.zeros(S + 1, V, 3), torch.zeros(S + 1, V, 3)
+    rec.latents_into(zc, zv, S, 0.5, 2.0)
+    kept_c, kept_v = zc[:S].clone(), zv[:S].clone()
+    zc[:S] += 7.0                                    # the kernel overwrites the buffers with the proposals
+    u = rec.uniform(S)
+    r = rec.randn_like(torch.zeros(1, V, 3))
+    a, b = rec.latents(S, 1, V, 0.5, 2.0)
+    q = rec.rotation()
+    assert len(rec.log) == 5
+
+    rep = RecordingNoise(ReplayDraws(rec.log))       # the redo records again (a second overflow would replay the replay)
+    zc2, zv2 = torch.zeros(S + 1, V, 3), torch.zeros(S + 1, V, 3)
+    rep.latents_into(zc2, zv2, S, 0.5, 2.0, scale_c=0.5, scale_v=2.0)
+    assert torch.equal(zc2[:S], kept_c) and torch.equal(zv2[:S], kept_v) and float(zc2[S].abs().max()) == 0.0
+    assert torch.equal(rep.uniform(S), u)
+    assert torch.equal(rep.randn_like(torch.zeros(1, V, 3)), r)
+    a2, b2 = rep.latents(S, 1, V, 0.5, 2.0)
+    assert torch.equal(a2, a) and torch.equal(b2, b) and a2.shape == (S, 1, V, 3)
+    assert torch.equal(rep.rotation(), q)
+    assert len(rep.log) == 5 and not rep.inner.log
+    # the draws themselves are the seeded stream of the wrapped source
+    ref = DeviceNoise("cpu", seed=3)
+    ref.uniform(S)
+    zr, zs = torch.zeros(S + 1, V, 3), torch.zeros(S + 1, V, 3)
+    ref.latents_into(zr, zs, S, 0.5, 2.0)
+    assert torch.equal(zr[:S], kept_c) and torch.equal(ref.uniform(S), u)
+
+
 def test_generated_asm_includes_are_current(tmp_path):
     """The committed tw_h3_*_asm.inc / *_clobbers.inc files are exactly what the generators in tools/ emit (a build
     needs hipcc only; this keeps the committed text from going stale)."""

@@ -2070,7 +2070,7 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
   } else if (g_debug_flags & 8)
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
-  else if ((dump != nullptr || (g_debug_flags & (4 | 16 | 4096))) && !(g_debug_flags & 8192))
+  else if (((dump != nullptr || (g_debug_flags & (4 | 16 | 4096))) && !(g_debug_flags & 8192)) || d.n_layers < 1)
     // activation dumps / section stamps live between the sections; bit 12 (4096): A/B switch for the encoder-stack build;
     // bit 13 (8192): the encoder-stack build even with a dump buffer (only the stamps / dumps outside the stack are written)
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
