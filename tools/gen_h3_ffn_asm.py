@@ -101,7 +101,10 @@ def epi_unit(o, jt, buf, relu=True, tset=None):
     if tset is None:
         tset = (o * NT + jt) % 2
     t = [(V_T, V_T + 4, V_T3)[tset] + i for i in range(4)]
-    ops = [f"v_fma_f32 v{t[r]}, v{HACC(o, jt) + r}, s{S_SC}, v{BIAS(o) + r}" for r in range(4)]
+    # timing experiments (results WRONG): `episrc` reads the bias registers instead of the MFMA results, `epidst` writes
+    # scratch registers instead of the B operands of the second GEMM - is it the op count or the MFMA <-> VALU register traffic?
+    src = (lambda r: BIAS(o) + r) if "episrc" in EXPERIMENT else (lambda r: HACC(o, jt) + r)
+    ops = [f"v_fma_f32 v{t[r]}, v{src(r)}, s{S_SC}, v{BIAS(o) + r}" for r in range(4)]
     if SHAPE["silu"]:
         # v * 1 / (1 + 2^(-v log2 e)) with the hardware exp2 / rcp
         u = [V_U + r for r in range(4)]
@@ -114,6 +117,8 @@ def epi_unit(o, jt, buf, relu=True, tset=None):
         ops += [f"v_max_f32 v{t[r]}, v{t[r]}, 0" for r in range(4)]
     hh = HB(buf, jt, "h") + 2 * o
     ll = HB(buf, jt, "l") + 2 * o
+    if "epidst" in EXPERIMENT:
+        hh, ll = V_T3, V_T3 + 2
     ops += [f"v_cvt_pk_f16_f32 v{hh}, v{t[0]}, v{t[1]}", f"v_cvt_pk_f16_f32 v{hh + 1}, v{t[2]}, v{t[3]}"]
     for r in range(4):
         sel = "op_sel:[1,0,0] " if r % 2 else ""
