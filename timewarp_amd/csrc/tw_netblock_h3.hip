@@ -558,8 +558,8 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
     char* base = out + (int64_t)hj * H3_SF_BYTES;
     *(h8*)(base + lane * 16) = hi0;
     *(h8*)(base + 1024 + lane * 16) = lo0;
-    *(h4*)(base + 2048 + lane * 8) = hi1;
-    *(h4*)(base + 2560 + lane * 8) = lo1;
+    *(h4*)(base + 2048 + lane * 16) = hi1;  // [hi | lo] of the K = 16 block side by side: one 16-byte load per lane
+    *(h4*)(base + 2048 + lane * 16 + 8) = lo1;
   }
 }
 
@@ -796,15 +796,15 @@ __device__ __forceinline__ void h3_load_sf3(const char* p16, const char* p8, u4 
       "global_load_dwordx4 %0, %12, off\n\t"
       "global_load_dwordx4 %1, %12, off offset:1024\n\t"
       "global_load_dwordx2 %2, %13, off offset:2048\n\t"
-      "global_load_dwordx2 %3, %13, off offset:2560\n\t"
+      "global_load_dwordx2 %3, %13, off offset:2056\n\t"
       "global_load_dwordx4 %4, %14, off\n\t"
       "global_load_dwordx4 %5, %14, off offset:1024\n\t"
       "global_load_dwordx2 %6, %15, off offset:2048\n\t"
-      "global_load_dwordx2 %7, %15, off offset:2560\n\t"
+      "global_load_dwordx2 %7, %15, off offset:2056\n\t"
       "global_load_dwordx4 %8, %16, off\n\t"
       "global_load_dwordx4 %9, %16, off offset:1024\n\t"
       "global_load_dwordx2 %10, %17, off offset:2048\n\t"
-      "global_load_dwordx2 %11, %17, off offset:2560\n\t"
+      "global_load_dwordx2 %11, %17, off offset:2056\n\t"
       "s_waitcnt vmcnt(0)"
       : "=&v"(a[0]), "=&v"(b[0]), "=&v"(c[0]), "=&v"(d[0]), "=&v"(a[1]), "=&v"(b[1]), "=&v"(c[1]), "=&v"(d[1]),
         "=&v"(a[2]), "=&v"(b[2]), "=&v"(c[2]), "=&v"(d[2])
@@ -1719,7 +1719,7 @@ netblock_h3_kernel(const H3Params p) {
       u2 r1h[3], r1l[3];
       {
         const char* sp = sf_base + (int64_t)(h * NT) * H3_SF_BYTES;
-        h3_load_sf3(sp + lane * 16, sp + lane * 8, r0h, r0l, r1h, r1l);
+        h3_load_sf3(sp + lane * 16, sp + lane * 16, r0h, r0l, r1h, r1l);
       }
       h8 s0h[NT], s0l[NT];
       h4 s1h[NT], s1l[NT];

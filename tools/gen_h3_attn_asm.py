@@ -9,7 +9,7 @@ Per head h and k-step ks (32 features):
   GEMM     y[ot] += Wc_h[ot][ks] . xm[ks]       two weight stages (ot 0-3, 4-7) of 36 MFMAs each
 Software pipeline (one step = one ks):  the mixing MFMAs of the NEXT k-step run first, then the two GEMM stages
 of the current k-step with the fp32 -> fp16 hi/lo split of the new mixing result (72 VALU ops) issued in the
-shadow of their MFMAs.  The score fragments of head h+1 are loaded (12 global loads) right after the last mixing of
+shadow of their MFMAs.  The score fragments of head h+1 are loaded (9 global loads, windowed 7) right after the last mixing of
 head h and waited for one k-step later.  Stage hand-off as in the FFN block (gen_h3_ffn_asm.py).
 
 Register map (private to the asm statement):
@@ -221,25 +221,30 @@ def gemm_stage(half, xm_buf, valu, next_reads, label, vm_allow=6, skip=0, tail_m
     return out
 
 
+def sf_tiles():
+    """(jt, with_tail): the K = 16 block of a query tile is only loaded where the mixing uses it (windowed: tile 1 only)."""
+    return [(jt, not WINDOWED or jt == 1) for jt in range(NT)]
+
+
 def sf_loads():
-    """Score fragments of the head at V_SF16 / V_SF8 (12 loads), then both addresses advance to the next head."""
+    """Score fragments of the head at V_SF16 (per query tile: K = 32 hi, K = 32 lo, [K = 16 hi | lo] - 16 bytes per lane
+    each), then the address advances to the next head.  Every load costs ~60 cycles of issue beside the LDS-DMA stream
+    (profiles/r03_attn_deletion_matrix_cycles.txt), so nothing is fetched that the mixing does not read."""
     out = []
     if "nosf" in EXPERIMENT:
         return ["s_nop 0"]
-    for jt in range(NT):
+    for jt, tail in sf_tiles():
         if jt == 0:
-            a16, a8 = V_SF16, V_SF8
+            a16 = V_SF16
         else:
             k = S_K3072 if jt == 1 else S_K6144
-            out += [f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_SF16, 2)}, 0, s[{k}:{k + 1}]",
-                    f"v_lshl_add_u64 {vr(V_TMP2, 2)}, {vr(V_SF8, 2)}, 0, s[{k}:{k + 1}]"]
-            a16, a8 = V_TMP, V_TMP2
+            out += [f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_SF16, 2)}, 0, s[{k}:{k + 1}]"]
+            a16 = V_TMP
         out += [f"global_load_dwordx4 {vr(SF(jt, 's0h'))}, {vr(a16, 2)}, off",
-                f"global_load_dwordx4 {vr(SF(jt, 's0l'))}, {vr(a16, 2)}, off offset:1024",
-                f"global_load_dwordx2 {vr(SF(jt, 's1h'), 2)}, {vr(a8, 2)}, off offset:2048",
-                f"global_load_dwordx2 {vr(SF(jt, 's1l'), 2)}, {vr(a8, 2)}, off offset:2560"]
-    out += [f"v_lshl_add_u64 {vr(V_SF16, 2)}, {vr(V_SF16, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]",   # NT * SF_BYTES == STAGE
-            f"v_lshl_add_u64 {vr(V_SF8, 2)}, {vr(V_SF8, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]"]
+                f"global_load_dwordx4 {vr(SF(jt, 's0l'))}, {vr(a16, 2)}, off offset:1024"]
+        if tail:
+            out += [f"global_load_dwordx4 {vr(SF(jt, 's1h'))}, {vr(a16, 2)}, off offset:2048"]
+    out += [f"v_lshl_add_u64 {vr(V_SF16, 2)}, {vr(V_SF16, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]"]   # NT * SF_BYTES == STAGE
     return out
 
 
@@ -255,12 +260,9 @@ def generate():
     A(f"v_add_u32 v{V_XT0}, %[priv], v{V_T}")
     A(f"v_add_u32 v{V_XT1}, %[priv], v{V_T + 1}")
     # score-fragment lane addresses: sf + 16 lane (128-bit loads), sf + 8 lane (64-bit loads)
-    A(f"v_lshlrev_b32 v{V_TMP2}, 3, v{V_LANE16}")
-    A(f"v_mov_b32 v{V_TMP2 + 1}, 0")
     A(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_LANE16}")
     A(f"v_mov_b32 v{V_LANE16 + 1}, 0")
     A(f"v_lshl_add_u64 {vr(V_SF16, 2)}, {SF_BASE}, 0, {vr(V_LANE16, 2)}")
-    A(f"v_lshl_add_u64 {vr(V_SF8, 2)}, {SF_BASE}, 0, {vr(V_TMP2, 2)}")
     A(f"s_lshl_b32 s{S_W2048}, %[wave], 11")
     A(f"s_mov_b32 s{S_W2048 + 1}, 0")
     A(f"s_mov_b32 s{S_STRIDE}, {STAGE}")
@@ -300,11 +302,12 @@ def generate():
             L += mixing_part(ks + 1, True)
             if ks == 2:
                 # last use of this head's score fragments is issued: fetch the next head's.  Also after the last
-                # head (the buffer has one head of slack): the s_waitcnt vmcnt counts below assume the 12 loads.
+                # head (the buffer has one head of slack): the s_waitcnt vmcnt counts below assume these loads.
                 L += sf_loads()
-            vm = 18 if ks == 2 else 6   # the 12 fragment loads sit in the same queue behind the stage DMAs
+            n_sf = sum(3 if tail else 2 for _, tail in sf_tiles())
+            vm = n_sf + 6 if ks == 2 else 6   # the fragment loads (full: 9, windowed: 7) sit in the same queue behind the stage DMAs
         else:
-            # mixing of (h + 1, 0): needs the new score fragments; skipped after the last head.  Newer than the 12
+            # mixing of (h + 1, 0): needs the new score fragments; skipped after the last head.  Newer than the
             # fragment loads are the DMAs of two hand-offs: 4 for every wave (aux blocks move in the last head only,
             # where this block is skipped).
             A(f"s_cmp_eq_u32 s{S_CNT}, 1")
