@@ -55,6 +55,9 @@ WINDOWED = "--mode=windowed" in sys.argv
 # fragments of the layer are addressed through SF_BASE (a VGPR pair that statement advances per layer).
 FUSED = False
 SF_BASE = "%[sf]"
+# FUSED only: the transposed copy of x does not go through the LDS at all - the statement's transposer leaves it in AGPRs
+# (MFMA A operands may be AGPRs), 12 per feature tile: [T0 | T1] hi 4, T2 hi 2, [T0 | T1] lo 4, T2 lo 2
+XT_AGPR = None   # first AGPR (gen_h3_enc_asm.py: 96), or None: operand buffers v36..v59 filled by ds_reads
 A2 = lambda t, part: XA(t, "a0h" if part == "h" else "a0l") + 2
 
 
@@ -72,8 +75,19 @@ def mfma32(d, a, b, zero=False, dreg="v", areg="v"):
     return f"v_mfma_f32_16x16x32_f16 {dd}, {aa}, {vr(b)}, {'0' if zero else dd}"
 
 
-def mfma16(d, a, b, zero=False):
-    return f"v_mfma_f32_16x16x16_f16 {vr(d)}, {vr(a, 2)}, {vr(b, 2)}, {'0' if zero else vr(d)}"
+def mfma16(d, a, b, zero=False, areg="v"):
+    aa = vr(a, 2) if areg == "v" else ar(a, 2)
+    return f"v_mfma_f32_16x16x16_f16 {vr(d)}, {aa}, {vr(b, 2)}, {'0' if zero else vr(d)}"
+
+
+XT_OFF = {"a0h": 0, "a1h": 4, "a0l": 6, "a1l": 10}
+
+
+def xt_operand(ks, t, name):
+    """(register, file) of a mixing A operand of feature tile 2 ks + t."""
+    if XT_AGPR is not None:
+        return XT_AGPR + 12 * (2 * ks + t) + XT_OFF[name], "a"
+    return XA(t, name), "v"
 
 
 def xt_reads(ks, t, buf):
@@ -84,7 +98,7 @@ def xt_reads(ks, t, buf):
             f"ds_read_b64 {vr(XA(buf, 'a1l'), 2)}, v{V_XT1} offset:{off + XT_IMG + 1024}"]
 
 
-def mixing_mfmas():
+def mixing_mfmas(ks):
     """36 MFMAs of one k-step: six accumulators acc[t][jt], each a chain  K32 hh -> K16 hh -> K32 hl -> K16 hl ->
     K32 lh -> K16 lh.  Alternating the two MFMA shapes on ONE accumulator needs >= 5 wait states between them
     (tools/probe/mfma_chain_probe.hip); the six chains are issued round-robin, so two MFMAs of one chain are always
@@ -94,20 +108,21 @@ def mixing_mfmas():
     for a32, b32, a16, b16 in (("a0h", "s0h", "a1h", "s1h"), ("a0h", "s0l", "a1h", "s1l"), ("a0l", "s0h", "a1l", "s1h")):
         for t in range(2):
             for jt in range(NT):
+                reg, file = xt_operand(ks, t, a32)
                 if WINDOWED and jt == 2:
-                    out.append(mfma32(ACC(t, jt), A2(t, a32[2]), SF(jt, b32), zero=first))
-                else:
-                    out.append(mfma32(ACC(t, jt), XA(t, a32), SF(jt, b32), zero=first))
+                    reg += 2   # the (T1 | T2) registers
+                out.append(mfma32(ACC(t, jt), reg, SF(jt, b32), zero=first, areg=file))
         for t in range(2):
             for jt in ((1,) if WINDOWED else range(NT)):
                 # windowed: the chain of (t, 1) still has four other MFMAs between its K=32 and its K=16 member
-                out.append(mfma16(ACC(t, jt), XA(t, a16), SF(jt, b16)))
+                reg, file = xt_operand(ks, t, a16)
+                out.append(mfma16(ACC(t, jt), reg, SF(jt, b16), areg=file))
         first = False
     return out
 
 
 def xt_reads_step(ks):
-    return [] if "noxt" in EXPERIMENT else xt_reads(ks, 0, 0) + xt_reads(ks, 1, 1)
+    return [] if "noxt" in EXPERIMENT or XT_AGPR is not None else xt_reads(ks, 0, 0) + xt_reads(ks, 1, 1)
 
 
 def mixing_part(ks, reads_issued):
@@ -116,7 +131,7 @@ def mixing_part(ks, reads_issued):
     out = [] if reads_issued else xt_reads_step(ks)
     out.append("s_waitcnt lgkmcnt(0)")
     if "nomix" not in EXPERIMENT:
-        out += mixing_mfmas()
+        out += mixing_mfmas(ks)
     return out
 
 

@@ -26,6 +26,8 @@ Register map of the glue (the embedded blocks own v0..v211 / a0..a119 while they
   v72..v167   T[ft][jt]: y -> t -> d -> x'  (same index as the accumulators: T = 72 + a)
   v0..v71     G1: the FFN's xb operands (k-steps 0-2; k-step 3 goes to a96..a119).  G2: transposer - D tiles v0..v47
               (two buffers x 3 token tiles x hi/lo), split halves v48..v71 (two buffers)
+  a96..a191   the transposed copy of x (fp16 hi / lo, 12 per feature tile) from the transposer to the end of the
+              attention block: the mixing MFMAs take their A operands there, nothing goes through the LDS
   v168..v191  LayerNorm weight / bias / FFN output bias of a feature tile (two buffers; streamed from the side block)
   v192..v211  temporaries, X^T image staging (G2: v176..v179, v188..v191, v208..v211)
   v212..v223  sums, -mean / rstd pairs
@@ -53,6 +55,7 @@ attn = load("gen_h3_attn_asm")
 ffn = load("gen_h3_ffn_asm")
 attn.WINDOWED = WINDOWED
 attn.FUSED = True
+attn.XT_AGPR = 96   # the transposed copy of x lives in a96..a191 from the transposer to the end of the attention block
 ffn.FUSED = True
 ffn.SHAPE = ffn.SHAPES["ffn"]
 
@@ -257,8 +260,10 @@ def transposer_issue(ft, buf):
 
 
 def transposer_drain(ft, buf):
-    """D tiles of feature tile ft (issued a whole tile of work ago) -> packed images -> LDS."""
+    """D tiles of feature tile ft (issued a whole tile of work ago) -> packed fp16 -> the attention block's operand AGPRs
+    (no LDS in between: MFMA A operands may be AGPRs, and 192 ds_reads per layer disappear with the 32 ds_writes)."""
     L = []
+    base = attn.XT_AGPR + 12 * ft
     for part in range(2):
         for jt in range(2):
             d = D(buf, jt, part)
@@ -266,10 +271,9 @@ def transposer_drain(ft, buf):
                   f"v_cvt_pk_f16_f32 v{IMG01(part) + 2 * jt + 1}, v{d + 2}, v{d + 3}"]
         d = D(buf, 2, part)
         L += [f"v_cvt_pk_f16_f32 v{IMG2(part)}, v{d}, v{d + 1}", f"v_cvt_pk_f16_f32 v{IMG2(part) + 1}, v{d + 2}, v{d + 3}"]
-    for part in range(2):
-        off = 2 * XT_IMG * ft + XT_IMG * part
-        L += [f"ds_write_b128 v{V_PRIV16}, {vr(IMG01(part), 4)} offset:{off}",
-              f"ds_write_b64 v{V_PRIV8}, {vr(IMG2(part))} offset:{off + 1024}"]
+    for part, (n01, n2) in enumerate((("a0h", "a1h"), ("a0l", "a1l"))):
+        L += [f"v_accvgpr_write_b32 a{base + attn.XT_OFF[n01] + k}, v{IMG01(part) + k}" for k in range(4)]
+        L += [f"v_accvgpr_write_b32 a{base + attn.XT_OFF[n2] + k}, v{IMG2(part) + k}" for k in range(2)]
     return L
 
 
@@ -452,7 +456,7 @@ def main():
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")
     if not WINDOWED:
-        clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(120)] + [f'"s{i}"' for i in range(70, 100)] + \
+        clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(192)] + [f'"s{i}"' for i in range(70, 100)] + \
                ['"vcc"', '"scc"', '"memory"']
         cl = ["// GENERATED by tools/gen_h3_enc_asm.py - clobber list of the encoder-stack asm statement."]
         for i in range(0, len(clob), 12):
