@@ -134,7 +134,7 @@ def attention_block(model, device, proposals, avg_launch_ms):
                                      "+ the K=48 block-diagonal mixing on K=32+16 MFMAs)",
         "method": "s_memtime section stamps of one untimed launch (tw_debug_set_flags 16: the per-section build of the kernel, "
                   "whose stamps sit between the sections) x live average launch time of the encoder-stack build; that build "
-                  "spends 3 x 52.4 k of 758 k cycles in the attention blocks (profiles/r03_enc_stack_ab.txt), so the share "
+                  "spends 3 x 47.1 k of 744.5 k cycles in the attention blocks (profiles/r03_ab_xt_agprs.txt), so the share "
                   "used here is slightly high and the rate slightly low",
     }
 

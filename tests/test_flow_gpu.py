@@ -125,8 +125,9 @@ def test_full_chebyshev_attention_all_paths(path):
     # Chebyshev coefficients make the L1-normalised scores cancellation-prone.  The exact-f32 fused kernel stays below
     # 1e-5; the split-fp16 kernel sits AT it on log p(x~|y~) - 0.97e-5, 1.01e-5 or 0.81e-5 depending on the order the mixing
     # MFMA walks the keys in and on the build (profiles/r03_mfma_transpose_tests.txt, r03_enc_accuracy_ab.txt), everything
-    # else 3e-7 - hence 1.5e-5 for that path here
-    H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5 if path == SIMPLE else (1.5e-5 if path == H3 else TOL))
+    # else 3e-7.  The build the kernel runs by default (the encoder-stack statement) is the 0.81e-5 one, so the bar
+    # stays at 1e-5; the per-section build (tw_debug_set_flags 4096) would need 1.1e-5 on this one case
+    H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5 if path == SIMPLE else TOL)
 
 
 def test_chebyshev_scores_kernel_vs_oracle():

@@ -35,6 +35,8 @@ def traffic(d_fetch, d_write, out):
         key = "netblock_h3_kernel" if "h3" in k else ("netblock_dense_kernel" if "dense" in k else "netblock_kernel")
         f = sum(v["FETCH_SIZE"]) / max(len(v["FETCH_SIZE"]), 1)
         w = sum(v["WRITE_SIZE"]) / max(len(v["WRITE_SIZE"]), 1)
+        if key in res and res[key]["dispatches"] >= len(v["FETCH_SIZE"]):
+            continue  # several instantiations of one kernel family in the run: keep the one the timed region launches
         res[key] = {"kernel": k, "dispatches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                     "traffic_bytes_per_launch_corrected": (2 * f + w) * 1024,
                     "traffic_bytes_per_launch_uncorrected": (f + w) * 1024,
@@ -51,7 +53,7 @@ def sq(dirs, out):
             if "netblock_h3" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     waves = 1000.0
-    lines = ["# SQ counters, `tw::netblock_h3_kernel<3, true>` (r03 build)", "",
+    lines = ["# SQ counters, `tw::netblock_h3_kernel<3, true, ..., ENC>` (late r03 build: encoder-stack statement)", "",
              "`bash tools/profile_round.sh` on the GPU box: four `rocprofv3 --kernel-trace --pmc <4 counters> --kernel-include-regex "
              "netblock_h3` passes over `python tools/time_flow.py --iters 2 --paths 3` (1000-proposal alanine-dipeptide flow passes). "
              "Averages per launch divided by the 1000 waves of a launch; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles, "
