@@ -23,6 +23,10 @@ def regen(ffn_flags, attn_flags):
     subprocess.run([sys.executable, "tools/gen_h3_attn_asm.py"], cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL)
     subprocess.run([sys.executable, "tools/gen_h3_attn_asm.py", "--mode=windowed"], cwd=ROOT, env=env, check=True,
                    stdout=subprocess.DEVNULL)
+    # the encoder-stack statement (what the kernel runs by default) embeds both blocks: regenerate it with the same flags
+    subprocess.run([sys.executable, "tools/gen_h3_enc_asm.py"], cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([sys.executable, "tools/gen_h3_enc_asm.py", "--mode=windowed"], cwd=ROOT, env=env, check=True,
+                   stdout=subprocess.DEVNULL)
     subprocess.run([sys.executable, "-m", "timewarp_amd.build"], cwd=ROOT, check=True, stdout=subprocess.DEVNULL,
                    stderr=subprocess.DEVNULL)
 

@@ -89,6 +89,35 @@ def vr(base, n=2):
     return f"v[{base}:{base + n - 1}]"
 
 
+def _check_register_map():
+    """The glue's register sets must not overlap where they are live together (a typo here is silent corruption)."""
+    def span(lo, n):
+        return set(range(lo, lo + n))
+    t = span(T(0, 0), 96)
+    xb = span(0, 72)
+    transposer = span(D(0, 0, 0), 48) | span(H(0, 0, 0), 24)
+    prm = span(PRM(0, 0), 24)
+    tmp = span(TMP(0), 8) | span(U(0), 8) | span(V_ACC0, 4)
+    img = span(IMG01(0), 4) | span(IMG01(1), 4) | span(IMG2(0), 2) | span(IMG2(1), 2)
+    stats = span(S2(0), 6) | span(NM(0), 6)
+    persistent = span(V_PRIV8, 1) | span(V_PRIV16, 1) | span(V_SLG, 1) | span(V_PAD, 1) | span(V_SFB, 2) | span(V_SIDE, 2) | \
+        span(V_IDB, 2) | span(V_C, 2) | span(V_C2, 2) | span(V_ONE, 2) | span(V_STAMP, 2)
+    assert transposer == xb                                    # G2 reuses the FFN operand registers of G1
+    for a, b in ((t, xb), (t, prm), (t, tmp), (t, stats), (t, persistent), (xb, prm), (xb, tmp), (xb, stats), (prm, tmp),
+                 (prm, stats), (tmp, stats), (stats, persistent), (tmp, persistent), (prm, persistent), (xb, persistent)):
+        assert not (a & b), sorted(a & b)
+    # the image staging registers of G2 sit in the b2 columns of the parameter buffers (G2 streams w and b only) and
+    # behind the temporaries G1's seeds use
+    assert img <= span(PRM(0, 2), 4) | span(PRM(1, 2), 4) | span(V_ACC0, 4)
+    assert max(persistent) < N_V and min(persistent) >= 212  # the embedded blocks own v0..v211
+    xbx = set()
+    for ks in range(4):
+        for jt in range(NT):
+            for part in range(2):
+                xbx |= span(XBX(ks, jt, part), 4)
+    assert len(xbx) == 96 and max(xbx) < T(2, 0)               # exit images: only T tiles that are dead by then
+
+
 def interleave(*streams):
     """Round-robin merge of instruction streams (independent register tiles): hides VALU latencies."""
     out, streams = [], [list(s) for s in streams]
@@ -445,6 +474,7 @@ def generate():
 
 
 def main():
+    _check_register_map()
     lines = generate()
     out_dir = "timewarp_amd/csrc"
     for a in sys.argv[1:]:
