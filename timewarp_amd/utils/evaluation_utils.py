@@ -169,6 +169,13 @@ class RecordingNoise:
         return zc, zv
 
     def latents_into(self, zc, zv, S, std_c, std_v, scale_c=None, scale_v=None):
+        if isinstance(self.inner, DeviceNoise):
+            # Two device copies per iteration would be the price of keeping the values (the caller's buffers become the
+            # proposals): keep the generator state in front of the draw instead and draw again on replay.
+            gen = self.inner.gen if self.inner.gen is not None else _default_generator(zc.device)
+            self.log.append(_RegenLatents(gen.get_state(), zc.device, S, tuple(zc.shape[1:]), float(std_c), float(std_v)))
+            self.inner.latents_into(zc, zv, S, std_c, std_v)
+            return
         if hasattr(self.inner, "latents_into"):
             self.inner.latents_into(zc, zv, S, std_c, std_v)
         else:  # replayed / host-drawn noise
@@ -188,6 +195,27 @@ class RecordingNoise:
         return q
 
 
+def _default_generator(device):
+    device = torch.device(device)
+    if device.type == "cuda":
+        return torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    return torch.default_generator
+
+
+class _RegenLatents:
+    """A `DeviceNoise.latents_into` draw, kept as the generator state in front of it."""
+
+    def __init__(self, state, device, S, row_shape, std_c, std_v):
+        self.state, self.device, self.S, self.row_shape, self.std_c, self.std_v = state, device, S, row_shape, std_c, std_v
+
+    def draw(self):
+        g = torch.Generator(device=self.device)
+        g.set_state(self.state)
+        zc = torch.empty((self.S, *self.row_shape), device=self.device).normal_(0.0, self.std_c, generator=g)
+        zv = torch.empty((self.S, *self.row_shape), device=self.device).normal_(0.0, self.std_v, generator=g)
+        return zc, zv
+
+
 class ReplayDraws:
     """Hands a RecordingNoise log back, draw by draw."""
 
@@ -195,7 +223,8 @@ class ReplayDraws:
         self.log = list(log)
 
     def _pop(self):
-        return self.log.pop(0)
+        e = self.log.pop(0)
+        return e.draw() if isinstance(e, _RegenLatents) else e
 
     def randn_like(self, t):
         return self._pop()
