@@ -760,36 +760,11 @@ __device__ __forceinline__ void to_bop(const f4 (&x)[2 * KS][NT], BOp<NT> (&b)[K
     for (int jt = 0; jt < NT; ++jt) split8(x[2 * ks][jt], x[2 * ks + 1][jt], b[ks].h[jt], b[ks].l[jt]);
 }
 
-// hipcc's s_waitcnt insertion cannot be trusted for ordinary global loads while LDS-DMA is in flight
-// (a missing wait was observed once control flow was added around the score-fragment loads).  Every
-// global load inside the pipelined part of the kernel is therefore issued from inline asm together
-// with its own s_waitcnt vmcnt(0) in ONE statement (early-clobber outputs): the compiler neither
-// counts nor schedules around these loads, and the wait also drains the LDS-DMA queue.
-__device__ __forceinline__ void h3_load8_f4(const float* p, f4 (&v)[8]) {  // v[i] = *(f4*)(p + 16 i)
-  asm volatile(
-      "global_load_dwordx4 %0, %8, off\n\t"
-      "global_load_dwordx4 %1, %8, off offset:64\n\t"
-      "global_load_dwordx4 %2, %8, off offset:128\n\t"
-      "global_load_dwordx4 %3, %8, off offset:192\n\t"
-      "global_load_dwordx4 %4, %8, off offset:256\n\t"
-      "global_load_dwordx4 %5, %8, off offset:320\n\t"
-      "global_load_dwordx4 %6, %8, off offset:384\n\t"
-      "global_load_dwordx4 %7, %8, off offset:448\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-      : "v"(p)
-      : "memory");
-}
-__device__ __forceinline__ f4 h3_load_f4(const float* p) {
-  f4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ float h3_load_f1(const float* p) {
-  float v;
-  asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-  return v;
-}
+// hipcc's s_waitcnt insertion cannot be trusted for ordinary global loads issued while YOUNGER LDS-DMAs join the queue
+// (a missing wait was observed once control flow was added around the score-fragment loads).  Global loads inside the
+// pipelined part of the kernel are therefore issued from inline asm together with their own s_waitcnt vmcnt(0) in ONE
+// statement (early-clobber outputs): the compiler neither counts nor schedules around them, and the wait also drains
+// the LDS-DMA queue.  (Loads in the prologue are plain C++: the only LDS-DMAs in flight there are older than they are.)
 // score fragments of one head for three token tiles (H3_SF_BYTES apart): 16-B and 8-B parts
 __device__ __forceinline__ void h3_load_sf3(const char* p16, const char* p8, u4 (&a)[3], u4 (&b)[3], u2 (&c)[3], u2 (&d)[3]) {
   asm volatile(
@@ -875,10 +850,17 @@ struct H3Pipe {
                                        (__attribute__((address_space(3))) void*)(dst + H3_STAGE_TILE_BYTES), 16, 0, 0);
     gnext += H3_STAGE_BYTES;
   }
-  __device__ __forceinline__ void start() {
+  // The first H3_RING stages are requested at the very top of the kernel and waited for only when the in-MLP is about to
+  // read them: their latency (L2 / Infinity Cache, ~1-2 us) runs under the prologue's own dependent loads (token
+  // bookkeeping, embedding gather, the previous coupling layer's update) instead of behind them.  The compiler's vmcnt
+  // waits for those loads stay correct with LDS-DMAs OLDER than the loads in the queue (returns are in order; the waits
+  // only become conservative).
+  __device__ __forceinline__ void start_issue() {
 #pragma unroll
     for (int i = 0; i < H3_RING; ++i) fetch(i);
     cur = 0;
+  }
+  __device__ __forceinline__ void start_wait() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1102,16 +1084,41 @@ netblock_h3_kernel(const H3Params p) {
   const float* scales = side + p.side_scales;
   _Float16* xt_hi = (_Float16*)(lds + H3_RING * H3_STAGE_BYTES + wave * WAVE_LDS);
 
-  // ---- token bookkeeping and input features (ordinary loads: before the DMA pipeline starts) ----
+  const unsigned long long t_kernel_top = (p.debug & 16) ? __builtin_readcyclecounter() : 0ull;  // section profile only
+  // ---- request the first stages of the weight stream ----
+  H3Pipe pipe;
+  pipe.gnext = net_base + lane * 16;
+  pipe.lds = lds;
+  pipe.cur = 0;
+  pipe.wave = wave;
+  pipe.debug = p.debug;
+  pipe.start_issue();
+
+  // Second-layer bias and output scale of the in and out MLPs: plain loads at the very top, so that they are back long
+  // before the first use (behind the asm statements each of them was a global round trip of its own, with the pipe idle)
+  const float sc_in2 = scales[1], sc_out2 = scales[2 + 3 * p.n_layers + 1];
+  f4 bb_in2[8];
+#pragma unroll
+  for (int ot = 0; ot < 8; ++ot) bb_in2[ot] = *(const f4*)(side + p.side_in2b + 4 * g + 16 * ot);
+  const f4 bb_out2 = *(const f4*)(side + p.side_out2b + 4 * g);
+
+  // ---- token bookkeeping and input features (ordinary loads, compiler-scheduled: the only LDS-DMAs in flight are older) ----
   int64_t tok_row[NT];
+  int64_t tok_cond[NT];  // the conditioning state (row of atom_types / x / masked) of the token's conformation: row % n_cond
   int tok_atom[NT];
+  // token slot -> (molecule, atom) without an integer division per token: floor(t / V) = (t * ceil(2^16 / V)) >> 16 for
+  // t < 192, V <= 160 (t * (ceil(2^16 / V) * V - 2^16) < 2^16); the row's conditioning state without a 64-bit modulo in the
+  // two layouts the flow uses (one shared state: the reverse pass of an MH iteration; one per row: the forward pass)
+  const unsigned inv_v = (65536u + (unsigned)p.V - 1u) / (unsigned)p.V;
+  const bool cond_shared = p.n_cond == 1, cond_per_row = p.n_cond >= p.n_rows;
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     const int t = slot0 + 16 * jt + i16;
-    const int q = t / p.V;
+    const int q = (int)(((unsigned)t * inv_v) >> 16);
     const int64_t n = row0 + q;
     const bool ok = active && q < p.mpw && n < p.n_rows;
     tok_row[jt] = ok ? n : -1;
+    tok_cond[jt] = !ok || cond_shared ? 0 : (cond_per_row ? n : n % p.n_cond);
     tok_atom[jt] = t - q * p.V;
   }
   // z_other of this lane's tokens: from memory, or - when the previous coupling layer's update is still pending - that
@@ -1139,7 +1146,7 @@ netblock_h3_kernel(const H3Params p) {
           zo[jt][k] = p.prev.reverse ? (z - shift) / scale : z * scale + shift;
           ld += logf(scale);
         }
-        part[jt] = p.masked[(n % p.n_cond) * p.V + tok_atom[jt]] ? 0.f : ld;
+        part[jt] = p.masked[tok_cond[jt] * p.V + tok_atom[jt]] ? 0.f : ld;
         if (net == 0 && g == 0) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) p.prev.z_out[idx + k] = zo[jt][k];
@@ -1194,12 +1201,39 @@ netblock_h3_kernel(const H3Params p) {
       }
     }
   }
+  const unsigned long long t_pro1 = (p.debug & 16) ? __builtin_readcyclecounter() : 0ull;
   // u in B-operand element order: k-step ks, element e  <->  feature 32 ks + 16 (e/4) + 4 g + e%4
   BOp<NT> u[KIN];
+  const bool std_input = !RFF && p.d_emb == 32;  // (uniform) 32 embedding columns + 9 of the second k-step's 32
+  if (std_input) {
+    // The configured shape (atom_embedding_dim 32): lane group g holds embedding columns 4 g.., 16 + 4 g.. - two 16-byte
+    // loads of the row - and columns 32 + 4 g.. = [xc 3 | xv 3 | z 3 | 0...] picked by g; columns 48.. are padding.  The
+    // general loop below walks the 16 elements through runtime comparisons and a dynamically indexed register array: 27 k
+    // cycles of prologue per launch (tools/profile_h3_sections.py) were mostly that.
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const int64_t n = tok_row[jt];
+      const int64_t ca = n < 0 ? 0 : tok_cond[jt] * p.V + tok_atom[jt];
+      const int ty = n < 0 ? 0 : p.types[ca];
+      const float* er = p.emb + ty * 32 + 4 * g;
+      f4 e0, e1, m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { e0[r] = er[r]; e1[r] = er[16 + r]; }
+      const float c0 = p.xc[ca * 3], c1 = p.xc[ca * 3 + 1], c2 = p.xc[ca * 3 + 2];
+      const float v0 = p.xv[ca * 3], v1 = p.xv[ca * 3 + 1], v2 = p.xv[ca * 3 + 2];
+      m[0] = g == 0 ? c0 : g == 1 ? v1 : g == 2 ? zo[jt][2] : 0.f;
+      m[1] = g == 0 ? c1 : g == 1 ? v2 : 0.f;
+      m[2] = g == 0 ? c2 : g == 1 ? zo[jt][0] : 0.f;
+      m[3] = g == 0 ? v0 : g == 1 ? zo[jt][1] : 0.f;
+      if (n < 0) e0 = e1 = m = (f4){0.f, 0.f, 0.f, 0.f};
+      split8(e0, e1, u[0].h[jt], u[0].l[jt]);
+      split8(m, (f4){0.f, 0.f, 0.f, 0.f}, u[1].h[jt], u[1].l[jt]);
+    }
+  } else
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     const int64_t n = tok_row[jt];
-    const int64_t c = n < 0 ? 0 : n % p.n_cond;
+    const int64_t c = tok_cond[jt];
     const int a = tok_atom[jt];
     const int ty = n < 0 ? 0 : p.types[c * p.V + a];
 #pragma unroll
@@ -1228,17 +1262,16 @@ netblock_h3_kernel(const H3Params p) {
         u[ks].l[jt][e] = (_Float16)(val - (float)hi);
       }
   }
-  // zero the transposed tile once: its pad columns are multiplied by zero scores and must be finite
-  for (int i = lane; i < WAVE_LDS / 16; i += 64) ((f4*)xt_hi)[i] = (f4){0.f, 0.f, 0.f, 0.f};
+  asm volatile("" : "+v"(u[0].h[0]), "+v"(u[1].h[0]));
+  const unsigned long long t_pro2 = (p.debug & 16) ? __builtin_readcyclecounter() : 0ull;
+  // zero the transposed tile once: its pad columns are multiplied by zero scores and must be finite (the encoder-stack
+  // statement keeps the transposed copy in registers and writes all of it)
+  if constexpr (!ENC)
+    for (int i = lane; i < WAVE_LDS / 16; i += 64) ((f4*)xt_hi)[i] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- start the weight pipeline ----
-  H3Pipe pipe;
-  pipe.gnext = net_base + lane * 16;
-  pipe.lds = lds;
-  pipe.cur = 0;
-  pipe.wave = wave;
-  pipe.debug = p.debug;
-  pipe.start();
+  const unsigned long long t_pro3 = (p.debug & 16) ? __builtin_readcyclecounter() : 0ull;
+  // ---- the weight pipeline (requested at the top of the kernel) must have its first stages in the LDS now ----
+  pipe.start_wait();
 
   auto dump_x = [&](const f4 (&x)[8][NT], int stage) {
     if (!p.dump) return;
@@ -1259,6 +1292,12 @@ netblock_h3_kernel(const H3Params p) {
       ((unsigned long long*)p.dump)[idx] = __builtin_readcyclecounter();
   };
   stamp(0);
+  if ((p.debug & 16) && p.dump && blockIdx.x == 0 && wave == 0 && lane == 0) {
+    ((unsigned long long*)p.dump)[60] = t_kernel_top;
+    ((unsigned long long*)p.dump)[61] = t_pro1;
+    ((unsigned long long*)p.dump)[62] = t_pro2;
+    ((unsigned long long*)p.dump)[63] = t_pro3;
+  }
 
   // ---- IN stage ----
   f4 x[8][NT];
@@ -1298,13 +1337,10 @@ netblock_h3_kernel(const H3Params p) {
     } else {
       h3_mlp_chain<NT, KIN, 8, true>(u, x, pipe, p.hid_chunks, lane);
     }
-    const float sc = h3_load_f1(scales + 1);
-    f4 bb[8];
-    h3_load8_f4(side + p.side_in2b + 4 * g, bb);
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) {
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) x[ot][jt] = x[ot][jt] * sc + bb[ot];
+      for (int jt = 0; jt < NT; ++jt) x[ot][jt] = x[ot][jt] * sc_in2 + bb_in2[ot];
     }
   }
   // Padding tokens (4 of a wave's 48 with 22-atom molecules) carry zeros instead of whatever the biases and LayerNorms
@@ -1350,7 +1386,7 @@ netblock_h3_kernel(const H3Params p) {
       unsigned long long m = 0ull;
       if (tok_row[jt] >= 0) {
         const int q = (16 * jt + i16) / p.V;
-        const uint8_t* mk = p.masked + (tok_row[jt] % p.n_cond) * p.V;
+        const uint8_t* mk = p.masked + tok_cond[jt] * p.V;
         for (int a = 0; a < p.V; ++a) m |= mk[a] ? 0ull : (1ull << (q * p.V + a));
       }
       kvalid[jt] = m >> (4 * g);
@@ -1903,10 +1939,8 @@ netblock_h3_kernel(const H3Params p) {
     } else {
       h3_mlp_chain<NT, 4, 1, true>(xb, o, pipe, p.hid_chunks, lane);
     }
-    const float sc = h3_load_f1(scales + 2 + 3 * p.n_layers + 1);
-    const f4 bb = h3_load_f4(side + p.side_out2b + 4 * g);
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt) o[0][jt] = o[0][jt] * sc + bb;
+    for (int jt = 0; jt < NT; ++jt) o[0][jt] = o[0][jt] * sc_out2 + bb_out2;
   }
   stamp(2 + 4 * p.n_layers);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // drain the over-fetched stages before the workgroup retires its LDS

@@ -32,6 +32,12 @@ names += ["out_mlp"]
 t = ts[: len(names)]
 total = t[-1] - t[0]
 print(f"total {total} cycles")
+if ts[60]:
+    print(f"  prologue in front of the first stamp (token bookkeeping, embedding gather, previous coupling update, first weight "
+          f"stages): {t[0] - ts[60]} cycles")
+    if ts[61]:
+        print(f"    token bookkeeping + z loads {ts[61] - ts[60]}, input features {ts[62] - ts[61]}, LDS zeroing + bias loads {ts[63] - ts[62]}, "
+              f"wait for the first stages {t[0] - ts[63]}")
 if extra & 8192:   # encoder-stack build (tools/gen_h3_enc_asm.py); inner stamps only from its H3_ENC_EXPERIMENT=stamps build
     print(f"  in_mlp {t[1] - t[0]}, encoder stack {t[-2] - t[1]} ({(t[-2] - t[1]) // L} per layer), out_mlp {t[-1] - t[-2]}")
     prev = t[1]
