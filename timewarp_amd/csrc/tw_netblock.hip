@@ -332,6 +332,35 @@ netblock_kernel(const NBParams p) {
 
   // ---- input features u = [emb(type), x_coords, x_velocs, z_other] padded to 48 -------------
   f4 u[3][NT];
+  if (p.d_emb == 32) {
+    // the configured shape: two 16-byte loads of the embedding row, columns 32 + 4 g.. = [xc 3 | xv 3 | z 3 | 0...] picked
+    // by lane group (same path as the split-fp16 kernel's prologue, tw_netblock_h3.hip; the general loop below walks every
+    // element through runtime comparisons)
+    const bool cond_shared = p.n_cond == 1, cond_per_row = p.n_cond >= p.n_rows;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const int64_t n = tok_row[jt];
+      const int64_t c = n < 0 || cond_shared ? 0 : (cond_per_row ? n : n % p.n_cond);
+      const int64_t ca = c * p.V + (n < 0 ? 0 : tok_atom[jt]);
+      const int ty = n < 0 ? 0 : p.types[ca];
+      const float* er = p.emb + ty * 32 + 4 * g;
+      const int64_t zi = n < 0 ? 0 : (n * p.V + tok_atom[jt]) * 3;
+      const float c0 = p.xc[ca * 3], c1 = p.xc[ca * 3 + 1], c2 = p.xc[ca * 3 + 2];
+      const float v0 = p.xv[ca * 3], v1 = p.xv[ca * 3 + 1], v2 = p.xv[ca * 3 + 2];
+      const float z0 = p.z_other[zi], z1 = p.z_other[zi + 1], z2 = p.z_other[zi + 2];
+      f4 e0, e1, m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { e0[r] = er[r]; e1[r] = er[16 + r]; }
+      m[0] = g == 0 ? c0 : g == 1 ? v1 : g == 2 ? z2 : 0.f;
+      m[1] = g == 0 ? c1 : g == 1 ? v2 : 0.f;
+      m[2] = g == 0 ? c2 : g == 1 ? z0 : 0.f;
+      m[3] = g == 0 ? v0 : g == 1 ? z1 : 0.f;
+      if (n < 0) e0 = e1 = m = (f4){0.f, 0.f, 0.f, 0.f};
+      u[0][jt] = e0;
+      u[1][jt] = e1;
+      u[2][jt] = m;
+    }
+  } else
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     const int64_t n = tok_row[jt];
