@@ -389,6 +389,33 @@ def test_encoder_stack_statement_vs_per_section_build(V, lens):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("emb", [16, 24])
+def test_other_embedding_widths_take_the_general_input_path(emb):
+    """atom_embedding_dim 32 (every config of the reference) has a straight-line input-feature path in the fused kernels'
+    prologues; any other width that fits the 64-column input tile goes through the general element-by-element loop.  Both
+    fused kernels on 16 and 24 embedding columns against the oracle (the f32 kernel takes up to 39: 48-column input tile)."""
+    spec = fo.FlowSpec(variant="kernel", num_transformer_layers=1, num_coupling_layers=2)
+    sd = fo.synth_state_dict(fo.make_template(spec, atom_embedding_dim=emb), 0)
+    g = torch.Generator().manual_seed(700 + emb)
+    V, lens = 22, [22, 18, 22, 22, 21]
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.3
+    x_v = torch.randn(B, V, 3, generator=g) * 0.5
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+    y_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    ref = fo.log_likelihood(sd, spec, at, x_c, x_v, y_c, y_v, mask)
+    for path in (FUSED, H3):
+        m = H.tw_kernel_model(sd, emb=emb, path=path, n_coupling=2, n_layers=1)
+        out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                               y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
+        H.assert_not_demoted(m)
+        assert H.rel_err(out, ref) < TOL, (path, H.rel_err(out, ref))
+
+
 @pytest.mark.parametrize("n_layers", [1, 2, 5])
 def test_encoder_stack_statement_layer_counts_vs_oracle(n_layers):
     """The layer loop lives inside the statement (scales, side blocks and, for chebyshev_kernel, score fragments advance
