@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 4
+#define TW_ABI_VERSION 5
 
 typedef enum {
   TW_OK = 0,
@@ -92,6 +92,9 @@ int tw_flow_pack(const tw_flow_desc* desc, const float* raw, float* packed, void
  * (per-matrix power-of-two scaling, fp16 hi/lo tile pairs in LDS-DMA stage order). */
 int64_t tw_flow_packed_h3_bytes(const tw_flow_desc* desc);
 int tw_flow_pack_h3(const tw_flow_desc* desc, const float* raw, void* packed_h3, void* stream);
+/* The same for TW_PATH_FUSED_H1 (fp16 hi tiles only: 8 tiles per 9 KiB stage, half as many stages). */
+int64_t tw_flow_packed_h1_bytes(const tw_flow_desc* desc);
+int tw_flow_pack_h1(const tw_flow_desc* desc, const float* raw, void* packed_h1, void* stream);
 
 /* Bytes of scratch the flow entry points need for n_rows conformations of n_atoms atoms. */
 int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_t n_atoms);
@@ -105,6 +108,12 @@ int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_
                               (48-token waves holding floor(48 / n_atoms) molecules); needs |activations| < 65504.
                               `packed` must then point at the tw_flow_pack_h3 stream.  Never chosen by
                               TW_PATH_AUTO. */
+#define TW_PATH_FUSED_H1 4 /* "fast" mode, NOT a parity path: the same fused kernel with ONE half-precision MFMA per
+                              product (fp16 operands, 11 significand bits, fp32 accumulation) and half the weight stream.
+                              Kernel variant, n_atoms <= 48.  Results deviate from the reference's fp32 arithmetic by
+                              ~1e-4 relative (measured per case in tests/test_flow_h1_gpu.py); proposal and reverse-move
+                              densities of an MH iteration are evaluated by the same arithmetic.  `packed` must point at
+                              the tw_flow_pack_h1 stream.  Only ever chosen by name. */
 
 /* 1 if `path` can run this configuration on molecules of n_atoms atoms (TW_PATH_AUTO / TW_PATH_SIMPLE: always), else 0.
  * What a caller asks before it requests TW_PATH_FUSED / TW_PATH_FUSED_H3 by name (those fail with TW_ERR_INVALID on an

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/timewarp_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_raw_layout_matches_library_and_oracle_template():
@@ -333,11 +333,14 @@ def test_generated_asm_includes_are_current(tmp_path):
     for args in (["tools/gen_h3_ffn_asm.py", "--shape=ffn"], ["tools/gen_h3_ffn_asm.py", "--shape=in"],
                  ["tools/gen_h3_ffn_asm.py", "--shape=out"], ["tools/gen_h3_attn_asm.py"],
                  ["tools/gen_h3_attn_asm.py", "--mode=windowed"], ["tools/gen_h3_attn_wide_asm.py"],
-                 ["tools/gen_h3_dense_attn_asm.py"], ["tools/gen_h3_enc_asm.py"], ["tools/gen_h3_enc_asm.py", "--mode=windowed"]):
+                 ["tools/gen_h3_dense_attn_asm.py"], ["tools/gen_h3_enc_asm.py"], ["tools/gen_h3_enc_asm.py", "--mode=windowed"],
+                 # the single-MFMA variant (TW_PATH_FUSED_H1): tw_h1_*
+                 ["tools/gen_h3_ffn_asm.py", "--shape=in", "--h1"], ["tools/gen_h3_ffn_asm.py", "--shape=out", "--h1"],
+                 ["tools/gen_h3_enc_asm.py", "--h1"], ["tools/gen_h3_enc_asm.py", "--mode=windowed", "--h1"]):
         subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
                        stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 17
+    assert len(names) == 24
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n

@@ -16,7 +16,7 @@ from . import build as _build
 
 _LIB: Optional[C.CDLL] = None
 
-TW_PATH_AUTO, TW_PATH_FUSED, TW_PATH_SIMPLE, TW_PATH_FUSED_H3 = 0, 1, 2, 3
+TW_PATH_AUTO, TW_PATH_FUSED, TW_PATH_SIMPLE, TW_PATH_FUSED_H3, TW_PATH_FUSED_H1 = 0, 1, 2, 3, 4
 
 
 class FlowDesc(C.Structure):
@@ -83,7 +83,7 @@ class MHOptions(C.Structure):
     ]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 _DESC = C.POINTER(FlowDesc)
@@ -98,6 +98,8 @@ SIGNATURES = {
     "tw_flow_pack": (C.c_int, [_DESC, _P, _P, _P]),
     "tw_flow_packed_h3_bytes": (_I64, [_DESC]),
     "tw_flow_pack_h3": (C.c_int, [_DESC, _P, _P, _P]),
+    "tw_flow_packed_h1_bytes": (_I64, [_DESC]),
+    "tw_flow_pack_h1": (C.c_int, [_DESC, _P, _P, _P]),
     "tw_flow_path_supported": (C.c_int, [_DESC, _I32, _I32]),
     "tw_flow_workspace_bytes": (_I64, [_DESC, _I64, _I32]),
     "tw_flow_pass": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I64, _P]),

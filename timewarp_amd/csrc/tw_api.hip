@@ -45,6 +45,10 @@ static int resolve_path(const tw_flow_desc& d, int n_atoms, int path, const floa
     TW_REQUIRE(h3_supported(d, n_atoms), "split-fp16 path unsupported for this config (variant=%d d_model=%d n_atoms=%d)",
                d.variant, d.d_model, n_atoms);
     TW_REQUIRE(packed != nullptr, "split-fp16 path needs its packed weight stream (tw_flow_pack_h3)");
+  } else if (path == TW_PATH_FUSED_H1) {
+    TW_REQUIRE(h1_supported(d, n_atoms), "single-MFMA path unsupported for this config (variant=%d d_model=%d n_atoms=%d)",
+               d.variant, d.d_model, n_atoms);
+    TW_REQUIRE(packed != nullptr, "single-MFMA path needs its packed weight stream (tw_flow_pack_h1)");
   } else if (path == TW_PATH_FUSED) {
     TW_REQUIRE(fused_supported(d, n_atoms), "fused path unsupported for this config (variant=%d d_model=%d n_atoms=%d)",
                d.variant, d.d_model, n_atoms);
@@ -99,6 +103,7 @@ int tw_flow_path_supported(const tw_flow_desc* desc, int32_t n_atoms, int32_t pa
     case TW_PATH_SIMPLE: return 1;
     case TW_PATH_FUSED: return fused_supported(*desc, n_atoms) ? 1 : 0;
     case TW_PATH_FUSED_H3: return h3_supported(*desc, n_atoms) ? 1 : 0;
+    case TW_PATH_FUSED_H1: return h1_supported(*desc, n_atoms) ? 1 : 0;
     default: return 0;
   }
 }
@@ -111,6 +116,21 @@ int tw_flow_pack_h3(const tw_flow_desc* desc, const float* raw, void* packed_h3,
   // the last 256 bytes of the over-fetch slack double as scratch for the per-matrix scale search
   float* scratch = (float*)((char*)packed_h3 + h3_packed_bytes(*desc) - 256);
   return h3_pack_weights(*desc, raw, (char*)packed_h3, scratch, (hipStream_t)stream);
+}
+
+int64_t tw_flow_packed_h1_bytes(const tw_flow_desc* desc) {
+  if (check_desc(desc)) return -1;
+  if (!h1_supported(*desc, 22)) return 0;
+  return h3_packed_bytes(*desc, true);
+}
+
+int tw_flow_pack_h1(const tw_flow_desc* desc, const float* raw, void* packed_h1, void* stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  TW_REQUIRE(h1_supported(*desc, 22), "single-MFMA path unsupported for this config");
+  TW_REQUIRE(raw && packed_h1, "NULL buffer");
+  float* scratch = (float*)((char*)packed_h1 + h3_packed_bytes(*desc, true) - 256);  // as tw_flow_pack_h3
+  return h3_pack_weights(*desc, raw, (char*)packed_h1, scratch, (hipStream_t)stream, true);
 }
 
 int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_t n_atoms) {
@@ -143,7 +163,10 @@ int tw_flow_pass(const tw_flow_desc* desc, const float* raw, const float* packed
   if ((rc = resolve_path(*desc, n_atoms, path, packed, &p))) return rc;
   FlowArgs a{desc, raw, packed, atom_types, x_coords, x_velocs, masked, n_cond, z_coords, z_velocs,
              delta_logp, n_rows, n_atoms, reverse, workspace, workspace_bytes, (hipStream_t)stream};
-  if (p == TW_PATH_FUSED_H3) return flow_pass_h3(a);
+  if (p == TW_PATH_FUSED_H3 || p == TW_PATH_FUSED_H1) {
+    a.h1 = p == TW_PATH_FUSED_H1 ? 1 : 0;
+    return flow_pass_h3(a);
+  }
   return p == TW_PATH_FUSED ? flow_pass_fused(a) : flow_pass_simple(a);
 }
 
@@ -357,7 +380,10 @@ int tw_debug_netblock(const tw_flow_desc* desc, const float* raw, const float* p
   if ((rc = resolve_path(*desc, n_atoms, path, packed, &p))) return rc;
   FlowArgs a{desc, raw, packed, atom_types, x_coords, x_velocs, masked, n_cond, nullptr, nullptr,
              nullptr, n_rows, n_atoms, 0, workspace, workspace_bytes, (hipStream_t)stream};
-  if (p == TW_PATH_FUSED_H3) return debug_netblock_h3(a, coupling, net, z_other, dump);
+  if (p == TW_PATH_FUSED_H3 || p == TW_PATH_FUSED_H1) {
+    a.h1 = p == TW_PATH_FUSED_H1 ? 1 : 0;
+    return debug_netblock_h3(a, coupling, net, z_other, dump);
+  }
   return p == TW_PATH_FUSED ? debug_netblock_fused(a, coupling, net, z_other, dump)
                             : debug_netblock_simple(a, coupling, net, z_other, dump);
 }

@@ -131,6 +131,7 @@ struct FlowArgs {
   void* ws;
   int64_t ws_bytes;
   hipStream_t stream;
+  int h1 = 0;  // split-fp16 translation unit only: the single-MFMA variant (TW_PATH_FUSED_H1); `packed` is then its stream
 };
 // basis value for scaled distance sc: Gaussian exp(-sc^2), or sum_c coeff[c] R_c(sc^2) with the three-term recursion
 // of chebyshev_expansion (kernel_attention.py:37-66), evaluated in the same order as the reference's stacked terms
@@ -207,9 +208,10 @@ int flow_pass_fused_dense(const FlowArgs& a);
 int debug_netblock_fused_dense(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
 // split-fp16 fused path (tw_netblock_h3.hip); FlowArgs::packed points at the h3 stream (bytes)
 bool h3_supported(const tw_flow_desc& d, int n_atoms);
-int64_t h3_packed_bytes(const tw_flow_desc& d);
+bool h1_supported(const tw_flow_desc& d, int n_atoms);  // single-MFMA variant of the same kernel (TW_PATH_FUSED_H1)
+int64_t h3_packed_bytes(const tw_flow_desc& d, bool h1 = false);
 int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms);
-int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float* scratch, hipStream_t s);
+int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float* scratch, hipStream_t s, bool h1 = false);
 int flow_pass_h3(const FlowArgs& a);
 int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
 extern int g_debug_flags;

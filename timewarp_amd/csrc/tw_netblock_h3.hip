@@ -92,7 +92,14 @@ struct H3Geom {
   int64_t net_stride_bytes;
 };
 
-static H3Geom h3_geom(const tw_flow_desc& d) {
+// h1: the single-MFMA stream (TW_PATH_FUSED_H1, kernel attention only).  A stage's four 2 KiB pair slots hold EIGHT fp16 hi
+// tiles (tile t at 1 KiB t) instead of four hi / lo pairs, so every chunked MLP is one A stage + one B stage per chunk and
+// the attention GEMM one stage per (head, k-step):
+//   IN   : hid_chunks x { A: [W0 chunk: tile 2 o + ks (4 tiles) + aux]          B: [W2 chunk: tile ot] }
+//   layer: H heads x 4 ks x [Wc_h k-step ks: tile ot]
+//          ff_chunks x { A: [W1 chunk: tile 4 o + ks + aux]                     B: [W2 chunk: tile ot] }
+//   OUT  : hid_chunks x { A: [W0 chunk: tile 4 o + ks + aux]                    B: [W2 chunk: tile 0] }
+static H3Geom h3_geom(const tw_flow_desc& d, bool h1 = false) {
   H3Geom g;
   g.hid_chunks = d.d_hidden / 32;
   g.ff_chunks = d.d_ff / 32;
@@ -101,6 +108,7 @@ static H3Geom h3_geom(const tw_flow_desc& d) {
   const int64_t att_stages = d.variant == 1 ? 4LL * g.H : 8LL * g.H;
   g.in_a_stages = (d.variant == 1 && d.d_rff > 0) ? 3 : 1;
   g.stages = (int64_t)(g.in_a_stages + 2) * g.hid_chunks + (int64_t)g.L * (att_stages + 4LL * g.ff_chunks) + 3LL * g.hid_chunks;
+  if (h1) g.stages = 2LL * g.hid_chunks + (int64_t)g.L * (4LL * g.H + 2LL * g.ff_chunks) + 2LL * g.hid_chunks;
   int64_t o = 0;
   g.side_in2b = o; o += 128;
   g.side_layers = o;
@@ -113,8 +121,8 @@ static H3Geom h3_geom(const tw_flow_desc& d) {
   return g;
 }
 
-int64_t h3_packed_bytes(const tw_flow_desc& d) {
-  H3Geom g = h3_geom(d);
+int64_t h3_packed_bytes(const tw_flow_desc& d, bool h1) {
+  H3Geom g = h3_geom(d, h1);
   return g.net_stride_bytes * 2 * d.n_coupling + (H3_RING + 1) * H3_STAGE_BYTES;  // DMA prefetch overrun slack
 }
 
@@ -170,6 +178,12 @@ bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
          fused_geom_nt(n_atoms, H3_NT, &fg) &&
          h3_sf_lds_bytes(d.n_heads, n_atoms, fg.mpw) <= H3_SF_LDS_MAX;
+}
+
+// the single-MFMA variant exists for the 48-token kernel-attention build (every molecule of up to 48 atoms)
+bool h1_supported(const tw_flow_desc& d, int n_atoms) {
+  H3Wide wd;
+  return d.variant == 0 && !h3_wide_geom(n_atoms, &wd) && h3_supported(d, n_atoms);
 }
 
 // ================================================================================================
@@ -228,31 +242,36 @@ __device__ __forceinline__ void store_pair(char* pair, int lane, int e, float v)
 }
 
 // tile pairs ordered ot-major over (n_ot, n_ks); src row-major [rows, cols] (ld)
+// h1: hi tiles only, 1 KiB each, in the same (ot, ks) order
 __global__ void h3_pack_block_kernel(const float* __restrict__ src, int ld, int rows_valid, int cols_valid, int row0,
-                                     int col0, int n_ks, const float* __restrict__ scale_up, char* __restrict__ dst) {
+                                     int col0, int n_ks, const float* __restrict__ scale_up, char* __restrict__ dst, int h1) {
   const int ot = blockIdx.x, ks = blockIdx.y, lane = threadIdx.x;
   const float sc = scale_up[0];
   const int row = row0 + 16 * ot + (lane & 15);
-  char* pair = dst + (int64_t)(ot * n_ks + ks) * H3_PAIR_BYTES;
+  char* pair = dst + (int64_t)(ot * n_ks + ks) * (h1 ? 1024 : H3_PAIR_BYTES);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int col = col0 + 32 * ks + 16 * (e / 4) + 4 * (lane >> 4) + (e % 4);
     const float v = (row < rows_valid && col < cols_valid) ? src[(int64_t)row * ld + col] * sc : 0.f;
-    store_pair(pair, lane, e, v);
+    if (h1) ((_Float16*)(pair + lane * 16))[e] = (_Float16)v;
+    else store_pair(pair, lane, e, v);
   }
 }
 
 // one Wc stage = k-step ks of four output tiles (ot = 4 half + oo): tile pair oo
+// h1: the grid runs over all eight output tiles of the k-step (half = 0), hi tiles of 1 KiB
 __global__ void h3_pack_fold_kernel(const float* __restrict__ wv, const float* __restrict__ wo, int H, int h, int ks,
-                                    int half, const float* __restrict__ scale_up, char* __restrict__ dst) {
+                                    int half, const float* __restrict__ scale_up, char* __restrict__ dst, int h1) {
   const int oo = blockIdx.x, lane = threadIdx.x;
   const float sc = scale_up[0];
   const int row = 16 * (4 * half + oo) + (lane & 15);
-  char* pair = dst + (int64_t)oo * H3_PAIR_BYTES;
+  char* pair = dst + (int64_t)oo * (h1 ? 1024 : H3_PAIR_BYTES);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int col = 32 * ks + 16 * (e / 4) + 4 * (lane >> 4) + (e % 4);
-    store_pair(pair, lane, e, (float)(fold_elem(wv, wo, H, h, row, col) * (double)sc));
+    const float v = (float)(fold_elem(wv, wo, H, h, row, col) * (double)sc);
+    if (h1) ((_Float16*)(pair + lane * 16))[e] = (_Float16)v;
+    else store_pair(pair, lane, e, v);
   }
 }
 
@@ -262,10 +281,11 @@ __global__ void h3_copy_kernel(const float* __restrict__ src, int n, float* __re
 }
 
 int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float* scratch /* >= 64 floats */,
-                    hipStream_t s) {
+                    hipStream_t s, bool h1) {
   const RawLayout L = raw_layout(d);
-  const H3Geom g = h3_geom(d);
-  TW_HIP_CHECK(hipMemsetAsync(packed, 0, h3_packed_bytes(d), s));
+  const H3Geom g = h3_geom(d, h1);
+  TW_REQUIRE(!h1 || d.variant == 0, "the single-MFMA stream exists for the kernel-attention variant");
+  TW_HIP_CHECK(hipMemsetAsync(packed, 0, h3_packed_bytes(d, h1), s));
   auto absmax = [&](const float* src, int64_t n, float* up, float* down) -> int {
     TW_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float), s));
     hipLaunchKernelGGL(h3_absmax_kernel, dim3(64), dim3(256), 0, s, src, n, scratch);
@@ -277,7 +297,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
   auto block = [&](const float* src, int ld, int rows_valid, int cols_valid, int row0, int col0, int n_ot, int n_ks,
                    const float* up, char* dst) -> int {
     hipLaunchKernelGGL(h3_pack_block_kernel, dim3(n_ot, n_ks), dim3(64), 0, s, src, ld, rows_valid, cols_valid, row0,
-                       col0, n_ks, up, dst);
+                       col0, n_ks, up, dst, h1 ? 1 : 0);
     TW_LAUNCH_CHECK();
     return TW_OK;
   };
@@ -301,6 +321,15 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
       // ---- IN
       if ((rc = absmax(nb + L.net.in0_w, (int64_t)d.d_hidden * L.d_in, up, scales + 0))) return rc;
       const int ia = g.in_a_stages, ks_in = 2 * ia;  // k-steps of the first GEMM: 2 or 6
+      const int ib = h1 ? 1 : 2;                      // B stages per chunk of the in-MLP / FFN
+      if (h1) {
+        for (int ch = 0; ch < g.hid_chunks; ++ch) {
+          char* a = st + a_off(ch, g.hid_chunks, 1, 1) * H3_STAGE_BYTES;
+          if ((rc = block(nb + L.net.in0_w, L.d_in, d.d_hidden, L.d_in, 32 * ch, 0, 2, 2, up, a))) return rc;  // tile 2 o + ks
+          if ((rc = copy(nb + L.net.in0_b + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
+          if ((rc = copy(scales + 0, 1, (float*)(a + H3_STAGE_TILE_BYTES) + 32, 1))) return rc;
+        }
+      } else
       for (int ch = 0; ch < g.hid_chunks; ++ch)
         for (int a_ = 0; a_ < ia; ++a_) {
           char* a = st + (a_off(ch, g.hid_chunks, ia, 2) + a_) * H3_STAGE_BYTES;
@@ -316,11 +345,11 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         }
       if ((rc = absmax(nb + L.net.in2_w, (int64_t)128 * d.d_hidden, up, scales + 1))) return rc;
       for (int ch = 0; ch < g.hid_chunks; ++ch)
-        for (int hf = 0; hf < 2; ++hf) {
-          char* b = st + (b_off(ch, g.hid_chunks, ia, 2) + hf) * H3_STAGE_BYTES;
-          if ((rc = block(nb + L.net.in2_w, d.d_hidden, 128, d.d_hidden, 64 * hf, 32 * ch, 4, 1, up, b))) return rc;
+        for (int hf = 0; hf < ib; ++hf) {
+          char* b = st + (b_off(ch, g.hid_chunks, ia, ib) + hf) * H3_STAGE_BYTES;
+          if ((rc = block(nb + L.net.in2_w, d.d_hidden, 128, d.d_hidden, 64 * hf, 32 * ch, h1 ? 8 : 4, 1, up, b))) return rc;
         }
-      st += (int64_t)(ia + 2) * g.hid_chunks * H3_STAGE_BYTES;
+      st += (int64_t)(ia + ib) * g.hid_chunks * H3_STAGE_BYTES;
       if ((rc = copy(nb + L.net.in2_b, 128, side + g.side_in2b, 128))) return rc;
       // ---- layers
       for (int l = 0; l < d.n_layers; ++l) {
@@ -376,18 +405,19 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         TW_LAUNCH_CHECK();
         for (int h = 0; h < d.n_heads; ++h)
           for (int ks = 0; ks < 4; ++ks)
-            for (int half = 0; half < 2; ++half) {
-              hipLaunchKernelGGL(h3_pack_fold_kernel, dim3(4), dim3(64), 0, s, lb + L.layer.wv, lb + L.layer.wo, d.n_heads, h,
-                                 ks, half, up, st + (int64_t)(8 * h + 2 * ks + half) * H3_STAGE_BYTES);
+            for (int half = 0; half < (h1 ? 1 : 2); ++half) {
+              hipLaunchKernelGGL(h3_pack_fold_kernel, dim3(h1 ? 8 : 4), dim3(64), 0, s, lb + L.layer.wv, lb + L.layer.wo, d.n_heads, h,
+                                 ks, half, up, st + (int64_t)(h1 ? 4 * h + ks : 8 * h + 2 * ks + half) * H3_STAGE_BYTES, h1 ? 1 : 0);
               TW_LAUNCH_CHECK();
             }
-        st += (int64_t)8 * d.n_heads * H3_STAGE_BYTES;
+        st += (int64_t)(h1 ? 4 : 8) * d.n_heads * H3_STAGE_BYTES;
         }
         if ((rc = absmax(lb + L.layer.w1, (int64_t)d.d_ff * 128, up, lsc + 1))) return rc;
+        const int fa = h1 ? 1 : 2;  // A stages per chunk of the FFN / out-MLP (h1: both o in one stage, tile 4 o + ks)
         for (int ch = 0; ch < g.ff_chunks; ++ch)
-          for (int o = 0; o < 2; ++o) {
-            char* a = st + (a_off(ch, g.ff_chunks, 2, 2) + o) * H3_STAGE_BYTES;
-            if ((rc = block(lb + L.layer.w1, 128, d.d_ff, 128, 32 * ch + 16 * o, 0, 1, 4, up, a))) return rc;
+          for (int o = 0; o < fa; ++o) {
+            char* a = st + (a_off(ch, g.ff_chunks, fa, ib) + o) * H3_STAGE_BYTES;
+            if ((rc = block(lb + L.layer.w1, 128, d.d_ff, 128, 32 * ch + 16 * o, 0, h1 ? 2 : 1, 4, up, a))) return rc;
             if (o == 0) {
               if ((rc = copy(lb + L.layer.b1 + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
               if ((rc = copy(lsc + 1, 1, (float*)(a + H3_STAGE_TILE_BYTES) + 32, 1))) return rc;
@@ -395,11 +425,11 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
           }
         if ((rc = absmax(lb + L.layer.w2, (int64_t)128 * d.d_ff, up, lsc + 2))) return rc;
         for (int ch = 0; ch < g.ff_chunks; ++ch)
-          for (int hf = 0; hf < 2; ++hf) {
-            char* b = st + (b_off(ch, g.ff_chunks, 2, 2) + hf) * H3_STAGE_BYTES;
-            if ((rc = block(lb + L.layer.w2, d.d_ff, 128, d.d_ff, 64 * hf, 32 * ch, 4, 1, up, b))) return rc;
+          for (int hf = 0; hf < ib; ++hf) {
+            char* b = st + (b_off(ch, g.ff_chunks, fa, ib) + hf) * H3_STAGE_BYTES;
+            if ((rc = block(lb + L.layer.w2, d.d_ff, 128, d.d_ff, 64 * hf, 32 * ch, h1 ? 8 : 4, 1, up, b))) return rc;
           }
-        st += (int64_t)4 * g.ff_chunks * H3_STAGE_BYTES;
+        st += (int64_t)(fa + ib) * g.ff_chunks * H3_STAGE_BYTES;
         if ((rc = copy(lb + L.layer.n1w, 128, sl, 128))) return rc;
         if ((rc = copy(lb + L.layer.n1b, 128, sl + 128, 128))) return rc;
         if ((rc = copy(lb + L.layer.b2, 128, sl + 256, 128))) return rc;
@@ -411,10 +441,11 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
       // ---- OUT
       float* osc = scales + 2 + 3 * d.n_layers;
       if ((rc = absmax(nb + L.net.out0_w, (int64_t)d.d_hidden * 128, up, osc + 0))) return rc;
+      const int oa = h1 ? 1 : 2;
       for (int ch = 0; ch < g.hid_chunks; ++ch)
-        for (int o = 0; o < 2; ++o) {
-          char* a = st + (a_off(ch, g.hid_chunks, 2, 1) + o) * H3_STAGE_BYTES;
-          if ((rc = block(nb + L.net.out0_w, 128, d.d_hidden, 128, 32 * ch + 16 * o, 0, 1, 4, up, a))) return rc;
+        for (int o = 0; o < oa; ++o) {
+          char* a = st + (a_off(ch, g.hid_chunks, oa, 1) + o) * H3_STAGE_BYTES;
+          if ((rc = block(nb + L.net.out0_w, 128, d.d_hidden, 128, 32 * ch + 16 * o, 0, h1 ? 2 : 1, 4, up, a))) return rc;
           if (o == 0) {
             if ((rc = copy(nb + L.net.out0_b + 32 * ch, 32, (float*)(a + H3_STAGE_TILE_BYTES), 32))) return rc;
             if ((rc = copy(osc + 0, 1, (float*)(a + H3_STAGE_TILE_BYTES) + 32, 1))) return rc;
@@ -422,7 +453,7 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         }
       if ((rc = absmax(nb + L.net.out2_w, (int64_t)3 * d.d_hidden, up, osc + 1))) return rc;
       for (int ch = 0; ch < g.hid_chunks; ++ch) {
-        char* b = st + b_off(ch, g.hid_chunks, 2, 1) * H3_STAGE_BYTES;
+        char* b = st + b_off(ch, g.hid_chunks, oa, 1) * H3_STAGE_BYTES;
         if ((rc = block(nb + L.net.out2_w, d.d_hidden, 3, d.d_hidden, 0, 32 * ch, 1, 1, up, b))) return rc;
       }
       if ((rc = copy(nb + L.net.out2_b, 3, side + g.side_out2b, 16))) return rc;
@@ -1047,10 +1078,14 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
 // 192 token slots; token-local sections unchanged, attention through the shared X^T tile (tw_h3_attns_asm.inc).
 // RFF = true (dense only): 128 random Fourier features of the conditioning positions appended to the in-MLP's input
 // (transformer_nvp_posenc.yaml); six input k-steps, the in-MLP as compiled C++ (the asm section takes two).
-template <int NT, bool ASM, bool DENSE = false, bool WIDE = false, bool RFF = false, bool ENC = false>
+// H1 = true (encoder-stack build only): the single-MFMA "fast" variant, TW_PATH_FUSED_H1 - one half-precision MFMA per
+// product (fp16 hi halves only), the weight stream of h3_geom(d, true); tools/gen_h3_*_asm.py --h1 -> tw_h1_*_asm.inc.
+// Not a parity path: operands carry 11 significand bits.
+template <int NT, bool ASM, bool DENSE = false, bool WIDE = false, bool RFF = false, bool ENC = false, bool H1 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_h3_kernel(const H3Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  static_assert(!H1 || ENC, "the single-MFMA variant exists as the encoder-stack build");
   static_assert(!WIDE || (ASM && !DENSE), "the wide layout exists for the asm build of the kernel-attention variant");
   static_assert(!RFF || DENSE, "position features belong to the dense model");
   static_assert(!ENC || (ASM && !DENSE && !WIDE && NT == 3), "the encoder-stack statement is the 48-token kernel-attention build");
@@ -1321,6 +1356,15 @@ netblock_h3_kernel(const H3Params p) {
       const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
       const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
       const int chunks = __builtin_amdgcn_readfirstlane(p.hid_chunks);
+      if constexpr (H1) {
+        asm volatile(
+#include "tw_h1_in_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+            :
+#include "tw_h1_in_clobbers.inc"
+        );
+      } else
       asm volatile(
 #include "tw_h3_in_asm.inc"
           : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -1421,6 +1465,31 @@ netblock_h3_kernel(const H3Params p) {
     // (only read by the H3_ENC_EXPERIMENT=stamps build of the statement, tools/profile_h3_sections.py)
     const float* stamp_base = p.dump;
     const int stampen = __builtin_amdgcn_readfirstlane(((p.debug & 16) && p.dump && blockIdx.x == 0 && wave == 0) ? 1 : 0);
+    if constexpr (H1) {
+    if (p.windowed) {
+      asm volatile(
+#include "tw_h1_encw_asm.inc"
+          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+            [layers] "s"(layers), [sf] "v"(sfp), [sfstride] "s"(sfstride), [side] "v"(sidep), [sidestride] "s"(sidestride),
+            [sl] "s"(sl_lds), [scales] "s"(scp), [eps] "s"(eps), [padm] "v"(padmask), [padt] "s"(pad_tiles),
+            [dump] "v"(stamp_base), [stampen] "s"(stampen)
+          :
+#include "tw_h1_enc_clobbers.inc"
+      );
+    } else {
+      asm volatile(
+#include "tw_h1_enc_asm.inc"
+          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+            [layers] "s"(layers), [sf] "v"(sfp), [sfstride] "s"(sfstride), [side] "v"(sidep), [sidestride] "s"(sidestride),
+            [sl] "s"(sl_lds), [scales] "s"(scp), [eps] "s"(eps), [padm] "v"(padmask), [padt] "s"(pad_tiles),
+            [dump] "v"(stamp_base), [stampen] "s"(stampen)
+          :
+#include "tw_h1_enc_clobbers.inc"
+      );
+    }
+    } else {
     if (p.windowed) {
       asm volatile(
 #include "tw_h3_encw_asm.inc"
@@ -1443,6 +1512,7 @@ netblock_h3_kernel(const H3Params p) {
           :
 #include "tw_h3_enc_clobbers.inc"
       );
+    }
     }
     pipe.cur = cur;
     pipe.gnext = gn;
@@ -1925,6 +1995,15 @@ netblock_h3_kernel(const H3Params p) {
       const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
       const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
       const int chunks = __builtin_amdgcn_readfirstlane(p.hid_chunks);
+      if constexpr (H1) {
+        asm volatile(
+#include "tw_h1_out_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+            :
+#include "tw_h1_out_clobbers.inc"
+        );
+      } else
       asm volatile(
 #include "tw_h3_out_asm.inc"
           : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -2035,7 +2114,8 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
                      const char* sfrag, int64_t sf_variant_bytes, bool shared, float* s_out, float* t_out, float* dump,
                      const PrevCoupling& prev = PrevCoupling{}) {
   const tw_flow_desc& d = *a.desc;
-  const H3Geom g = h3_geom(d);
+  const bool h1 = a.h1 != 0;
+  const H3Geom g = h3_geom(d, h1);
   H3Params p;
   p.packed = (const char*)a.packed + (int64_t)(c * 2) * g.net_stride_bytes;
   p.net_stride_bytes = g.net_stride_bytes;
@@ -2087,7 +2167,14 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   if ((prc = lim_dense_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false, true>, (int)H3D_LDS_BYTES))) return prc;
   if ((prc = lim_wide.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
-  if (wide) {
+  if (h1) {
+    // single-MFMA build: encoder-stack statement only (section stamps are compiled into it; no activation dumps)
+    TW_REQUIRE(!wide && d.variant == 0 && d.n_layers >= 1, "single-MFMA path: unsupported configuration");
+    TW_REQUIRE(dump == nullptr || (g_debug_flags & 16), "single-MFMA path: no activation dumps (section stamps only)");
+    static LdsLimit lim_h1;
+    if ((prc = lim_h1.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, false, false, true, true>, (int)H3_LDS_BYTES))) return prc;
+    hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, false, false, true, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
+  } else if (wide) {
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
   } else if (d.variant == 1 && d.d_rff > 0) {
     static LdsLimit lim_rff, lim_rff_cpp;

@@ -15,7 +15,7 @@ from . import _lib
 from .model_configs import duck_get as g
 from .modules import layers as L
 from .modules.baselines import EulerMaruyamaGaussian
-from .modules.flow import PREFER_SPLIT_FP16, ConditionalFlowDensityModel
+from .modules.flow import PREFER_SINGLE_FP16, PREFER_SPLIT_FP16, ConditionalFlowDensityModel
 from .weights import DENSE, KERNEL, FlowDims
 
 ELEMENT_VOCAB = ("C", "H", "N", "O", "S")  # dataloader.py:24-25
@@ -37,7 +37,9 @@ def model_constructor(config) -> nn.Module:
 
 
 _PATH_NAMES = {"auto": _lib.TW_PATH_AUTO, "f32": _lib.TW_PATH_FUSED, "simple": _lib.TW_PATH_SIMPLE,
-               "h3": PREFER_SPLIT_FP16, "split_fp16": PREFER_SPLIT_FP16}
+               "h3": PREFER_SPLIT_FP16, "split_fp16": PREFER_SPLIT_FP16,
+               # opt-in fast mode: one fp16 MFMA per product (~1e-4 relative deviation from the reference; not a parity path)
+               "h1": PREFER_SINGLE_FP16, "fast": PREFER_SINGLE_FP16}
 
 
 def default_execution_path() -> int:

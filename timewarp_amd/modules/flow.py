@@ -23,6 +23,11 @@ from .density_model_base import ConditionalDensityModel
 # library supports it for the call's molecule size (tw_flow_path_supported: kernel attention, d_model 128, up to 48
 # atoms), else AUTO.
 PREFER_SPLIT_FP16 = -1
+# Opt-in "fast" mode (TW_EXECUTION_PATH=h1): the single-MFMA kernel (TW_PATH_FUSED_H1: fp16 operands, one MFMA per product)
+# wherever it applies, the split-fp16 kernel or AUTO for the rest.  NOT a parity mode: results deviate from the reference's
+# fp32 arithmetic by ~1e-4 relative; never the default.
+PREFER_SINGLE_FP16 = -2
+_HALF_PATHS = (_lib.TW_PATH_FUSED_H3, _lib.TW_PATH_FUSED_H1)
 
 
 class ConditionalFlowDensityModel(ConditionalDensityModel):
@@ -59,11 +64,15 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
     def _path_for(self, n_atoms: int) -> int:
         """The C-ABI execution path of a call on molecules of `n_atoms` atoms."""
         path = self.execution_path
-        if path == PREFER_SPLIT_FP16:
+        if path in (PREFER_SPLIT_FP16, PREFER_SINGLE_FP16):
             desc = self.dims.to_desc()
-            ok = _lib.load().tw_flow_path_supported(C.byref(desc), int(n_atoms), _lib.TW_PATH_FUSED_H3) == 1
-            path = _lib.TW_PATH_FUSED_H3 if ok else _lib.TW_PATH_AUTO
-        if path == _lib.TW_PATH_FUSED_H3:
+            sup = _lib.load().tw_flow_path_supported
+            if path == PREFER_SINGLE_FP16 and sup(C.byref(desc), int(n_atoms), _lib.TW_PATH_FUSED_H1) == 1:
+                path = _lib.TW_PATH_FUSED_H1
+            else:
+                ok = sup(C.byref(desc), int(n_atoms), _lib.TW_PATH_FUSED_H3) == 1
+                path = _lib.TW_PATH_FUSED_H3 if ok else _lib.TW_PATH_AUTO
+        if path in _HALF_PATHS:
             self.used_split_fp16 = True
         return path
 
@@ -86,7 +95,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
 
     def demote_to_f32(self) -> None:
         """Leave the split-fp16 kernel for good: every later call runs on the exact-f32 kernels."""
-        if self.execution_path in (PREFER_SPLIT_FP16, _lib.TW_PATH_FUSED_H3):
+        if self.execution_path in (PREFER_SPLIT_FP16, PREFER_SINGLE_FP16) + _HALF_PATHS:
             warnings.warn(
                 "timewarp_amd: this checkpoint's activations leave the fp16 range (+-65504) on the split-fp16 kernel; "
                 "switching this model to the exact-f32 kernels and redoing the affected calls there "
@@ -114,7 +123,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         """run(path) on the call's execution path; on a split-fp16 range overflow, demote and run again."""
         path = self._path_for(n_atoms)
         out = run(path)
-        if path == _lib.TW_PATH_FUSED_H3 and self._defer_range_check == 0 and self.split_fp16_overflowed(device):
+        if path in _HALF_PATHS and self._defer_range_check == 0 and self.split_fp16_overflowed(device):
             self.demote_to_f32()
             out = run(self._path_for(n_atoms))
         return out
@@ -140,12 +149,23 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
             expect = lib.tw_flow_raw_floats(C.byref(desc))
             if expect != raw_cpu.numel():
                 raise RuntimeError(f"raw weight layout mismatch: host packed {raw_cpu.numel()} floats, library expects {expect}")
-            self._dev_weights = {"device": device, "raw": raw_cpu.to(device), "f32": None, "h3": None}
+            self._dev_weights = {"device": device, "raw": raw_cpu.to(device), "f32": None, "h3": None, "h1": None}
             self._dirty = False
         w = self._dev_weights
         lib = _lib.load()
         desc = self.dims.to_desc()
         path = self.execution_path if path is None else path
+        if path == _lib.TW_PATH_FUSED_H1:
+            if w["h1"] is None:
+                n = lib.tw_flow_packed_h1_bytes(C.byref(desc))
+                if n <= 0:
+                    raise RuntimeError("the single-MFMA path does not support this model configuration")
+                buf = torch.empty(n, dtype=torch.uint8, device=device)
+                with torch.cuda.device(device):
+                    _lib.check(lib.tw_flow_pack_h1(C.byref(desc), w["raw"].data_ptr(), buf.data_ptr(),
+                                                   _lib.stream_ptr(device)), "tw_flow_pack_h1")
+                w["h1"] = buf
+            return w["raw"], w["h1"]
         if path == _lib.TW_PATH_FUSED_H3:
             if w["h3"] is None:
                 n = lib.tw_flow_packed_h3_bytes(C.byref(desc))

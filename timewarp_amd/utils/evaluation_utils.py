@@ -248,7 +248,7 @@ class ReplayDraws:
 def _range_guarded(model) -> bool:
     """The model may run on the split-fp16 kernel (and so needs the range guard's recorded draws)."""
     return hasattr(model, "split_fp16_overflowed") and not getattr(model, "demoted", False) and \
-        getattr(model, "execution_path", 0) in (-1, _lib.TW_PATH_FUSED_H3)
+        getattr(model, "execution_path", 0) in (-1, -2, _lib.TW_PATH_FUSED_H3, _lib.TW_PATH_FUSED_H1)
 
 
 class _no_defer:
@@ -542,8 +542,11 @@ class MetropolisHastingsChain:
             ("dpot", e_pot), ("dkin", e_kin))
 
     def _overflowed(self) -> bool:
-        """Split-fp16 range guard, asked right after a host read-back (which has synchronised)."""
-        return self._guard and self.model.split_fp16_overflowed(self.device)
+        """Split-fp16 range guard, asked right after a host read-back (which has synchronised).  The device flag is ONE
+        sticky bit per device, read and cleared by whoever looks first: if somebody else (another chain's flush, a public
+        call on the shared model) has seen it and demoted the model while this chain still has iterations recorded, those
+        iterations may be the ones that overflowed - `model.demoted` therefore counts as an overflow for an open window."""
+        return self._guard and (bool(getattr(self.model, "demoted", False)) or self.model.split_fp16_overflowed(self.device))
 
     def _redo_on_f32(self, start_c, start_v, n_iterations: int):
         """The model's activations left the fp16 range somewhere in the last `n_iterations` iterations: demote the model

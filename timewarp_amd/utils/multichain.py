@@ -129,7 +129,8 @@ class MetropolisHastingsChains:
         if not self._pending:
             return
         results = torch.stack([p[0] for p in self._pending]).cpu().tolist()  # [iterations][C][4]
-        if self._guard and self.model.split_fp16_overflowed(self.device):
+        # (`demoted`: someone else read - and cleared - the device's sticky flag while these iterations were parked)
+        if self._guard and (bool(getattr(self.model, "demoted", False)) or self.model.split_fp16_overflowed(self.device)):
             # the model's activations left the fp16 range: the parked iterations again, on the exact-f32 kernels, from
             # their starting states and with the recorded draws; the chains then continue there
             self.model.demote_to_f32()

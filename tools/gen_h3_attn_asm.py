@@ -54,6 +54,10 @@ WINDOWED = "--mode=windowed" in sys.argv
 # arrive holding the residual (x / scale) instead of zeros, y stays in a0..a95 (no trip through the LDS), and the score
 # fragments of the layer are addressed through SF_BASE (a VGPR pair that statement advances per layer).
 FUSED = False
+# --h1 (or set by tools/gen_h3_enc_asm.py): the single-MFMA "fast" variant (TW_PATH_FUSED_H1, see gen_h3_ffn_asm.py).  One MFMA
+# per product on the fp16 hi halves: 8 (windowed) / 12 mixing MFMAs per k-step, ONE weight stage of 8 hi tiles per k-step
+# (pair p = output tiles 2 p, 2 p + 1, the second in the place of the lo tile), the split of a mixing result is a pack.
+H1 = "--h1" in sys.argv
 SF_BASE = "%[sf]"
 # FUSED only: the transposed copy of x does not go through the LDS at all - the statement's transposer leaves it in AGPRs
 # (MFMA A operands may be AGPRs), 12 per feature tile: [T0 | T1] hi 4, T2 hi 2, [T0 | T1] lo 4, T2 lo 2
@@ -92,10 +96,11 @@ def xt_operand(ks, t, name):
 
 def xt_reads(ks, t, buf):
     off = 2 * XT_IMG * (2 * ks + t)
-    return [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
-            f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_IMG}",
-            f"ds_read_b64 {vr(XA(buf, 'a1h'), 2)}, v{V_XT1} offset:{off + 1024}",
-            f"ds_read_b64 {vr(XA(buf, 'a1l'), 2)}, v{V_XT1} offset:{off + XT_IMG + 1024}"]
+    r = [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
+         f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_IMG}",
+         f"ds_read_b64 {vr(XA(buf, 'a1h'), 2)}, v{V_XT1} offset:{off + 1024}",
+         f"ds_read_b64 {vr(XA(buf, 'a1l'), 2)}, v{V_XT1} offset:{off + XT_IMG + 1024}"]
+    return r[0::2] if H1 else r
 
 
 def mixing_mfmas(ks):
@@ -105,13 +110,19 @@ def mixing_mfmas(ks):
     five MFMAs (>= 40 cycles) apart."""
     out = []
     first = True
-    for a32, b32, a16, b16 in (("a0h", "s0h", "a1h", "s1h"), ("a0h", "s0l", "a1h", "s1l"), ("a0l", "s0h", "a1l", "s1h")):
-        for t in range(2):
-            for jt in range(NT):
-                reg, file = xt_operand(ks, t, a32)
-                if WINDOWED and jt == 2:
-                    reg += 2   # the (T1 | T2) registers
-                out.append(mfma32(ACC(t, jt), reg, SF(jt, b32), zero=first, areg=file))
+    terms = (("a0h", "s0h", "a1h", "s1h"), ("a0h", "s0l", "a1h", "s1l"), ("a0l", "s0h", "a1l", "s1h"))
+    # H1: the hi x hi term only.  Windowed: a chain's K = 16 member follows its K = 32 member with >= 2 other MFMAs between
+    for a32, b32, a16, b16 in (terms[:1] if H1 else terms):
+        order = [(t, jt) for t in range(2) for jt in range(NT)]
+        if H1 and WINDOWED:
+            # the two chains that get a K = 16 member first: five MFMAs between the two shapes on one accumulator, as in the
+            # three-term schedule (tools/probe/mfma_chain_probe.hip)
+            order = [(0, 1), (1, 1), (0, 0), (0, 2), (1, 0), (1, 2)]
+        for t, jt in order:
+            reg, file = xt_operand(ks, t, a32)
+            if WINDOWED and jt == 2:
+                reg += 2   # the (T1 | T2) registers
+            out.append(mfma32(ACC(t, jt), reg, SF(jt, b32), zero=first, areg=file))
         for t in range(2):
             for jt in ((1,) if WINDOWED else range(NT)):
                 # windowed: the chain of (t, 1) still has four other MFMAs between its K=32 and its K=16 member
@@ -147,6 +158,8 @@ def split_ops(buf):
             hh = XM(buf, jt, "h") + 2 * t
             ll = XM(buf, jt, "l") + 2 * t
             ops += [f"v_cvt_pk_f16_f32 v{hh}, v{a}, v{a + 1}", f"v_cvt_pk_f16_f32 v{hh + 1}, v{a + 2}, v{a + 3}"]
+            if H1:
+                continue
             for r in range(4):
                 sel = "op_sel:[1,0,0] " if r % 2 else ""
                 ops.append(f"v_fma_mix_f32 v{tt[r]}, v{hh + r // 2}, -1.0, v{a + r} {sel}op_sel_hi:[1,0,0]")
@@ -159,7 +172,8 @@ def tile_reads(pair):
             f"ds_read_b128 {vr(SLOT(pair, 'l'))}, v{V_TILE} offset:{2048 * pair + 1024}"]
 
 
-def handoff(next_reads, label):
+def handoff(next_reads, label, aux_cnt=1):
+    """`aux_cnt`: wave 0 also moves the 1 KiB bias / scale block while the head counter is <= aux_cnt (see below)."""
     h = [
         f"s_mov_b32 s{S_REL}, s{S_OFF}",
         f"s_add_u32 s{S_OFF}, s{S_OFF}, {STAGE}",
@@ -176,7 +190,7 @@ def handoff(next_reads, label):
         # layer's LAST head, so wave 0 moves the aux block there only and is not the straggler at every barrier.
         ["s_cmp_lg_u32 %[wave], 0",
          f"s_cbranch_scc1 .Lh3att_noaux_{label}_%=",
-         f"s_cmp_lg_u32 s{S_CNT}, 1",
+         f"s_cmp_lg_u32 s{S_CNT}, 1" if aux_cnt == 1 else f"s_cmp_gt_u32 s{S_CNT}, {aux_cnt}",
          f"s_cbranch_scc1 .Lh3att_noaux_{label}_%=",
          f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
          f"s_add_u32 m0, s{S_REL}, {TILES}",
@@ -212,11 +226,18 @@ def weave(mfmas, valu, misc, valu_per=1, misc_per=3, skip=0):
     return out
 
 
-def gemm_stage(half, xm_buf, valu, next_reads, label, vm_allow=6, skip=0, tail_misc=()):
-    """One Wc stage: y[4 half + p] += tile pair p . xm[xm_buf], with `valu` woven under the MFMAs."""
+def gemm_stage(half, xm_buf, valu, next_reads, label, vm_allow=6, skip=0, tail_misc=(), aux_cnt=1):
+    """One Wc stage: y[4 half + p] += tile pair p . xm[xm_buf], with `valu` woven under the MFMAs.
+    H1: the stage holds all eight output tiles of the k-step (`half` unused): y[2 p + j] += tile j of pair p . xm.h."""
     groups = []
     for p in range(4):
         g = []
+        if H1:
+            for j, part in enumerate(("h", "l")):
+                for jt in range(NT):
+                    g.append(mfma32(YACC(2 * p + j, jt), SLOT(p, part), XM(xm_buf, jt, "h"), dreg="a"))
+            groups.append(g)
+            continue
         for a_part, b_part in (("h", "h"), ("h", "l"), ("l", "h")):
             for jt in range(NT):
                 g.append(mfma32(YACC(4 * half + p, jt), SLOT(p, a_part), XM(xm_buf, jt, b_part), dreg="a"))
@@ -231,7 +252,7 @@ def gemm_stage(half, xm_buf, valu, next_reads, label, vm_allow=6, skip=0, tail_m
     out.append(f"s_waitcnt vmcnt({vm_allow}) lgkmcnt(0)")
     if "nobarrier" not in EXPERIMENT:
         out.append("s_barrier")
-    out += weave(groups[2], parts[2], handoff(next_reads, label))
+    out += weave(groups[2], parts[2], handoff(next_reads, label, aux_cnt))
     out += weave(groups[3], parts[3], list(tail_misc))
     return out
 
@@ -255,8 +276,9 @@ def sf_loads():
             k = S_K3072 if jt == 1 else S_K6144
             out += [f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_SF16, 2)}, 0, s[{k}:{k + 1}]"]
             a16 = V_TMP
-        out += [f"global_load_dwordx4 {vr(SF(jt, 's0h'))}, {vr(a16, 2)}, off",
-                f"global_load_dwordx4 {vr(SF(jt, 's0l'))}, {vr(a16, 2)}, off offset:1024"]
+        out += [f"global_load_dwordx4 {vr(SF(jt, 's0h'))}, {vr(a16, 2)}, off"]
+        if not H1:
+            out += [f"global_load_dwordx4 {vr(SF(jt, 's0l'))}, {vr(a16, 2)}, off offset:1024"]
         if tail:
             out += [f"global_load_dwordx4 {vr(SF(jt, 's1h'))}, {vr(a16, 2)}, off offset:2048"]
     out += [f"v_lshl_add_u64 {vr(V_SF16, 2)}, {vr(V_SF16, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]"]   # NT * SF_BYTES == STAGE
@@ -319,7 +341,7 @@ def generate():
                 # last use of this head's score fragments is issued: fetch the next head's.  Also after the last
                 # head (the buffer has one head of slack): the s_waitcnt vmcnt counts below assume these loads.
                 L += sf_loads()
-            n_sf = sum(3 if tail else 2 for _, tail in sf_tiles())
+            n_sf = sum((3 if tail else 2) - (1 if H1 else 0) for _, tail in sf_tiles())
             vm = n_sf + 6 if ks == 2 else 6   # the fragment loads (full: 9, windowed: 7) sit in the same queue behind the stage DMAs
         else:
             # mixing of (h + 1, 0): needs the new score fragments; skipped after the last head.  Newer than the
@@ -327,14 +349,20 @@ def generate():
             # where this block is skipped).
             A(f"s_cmp_eq_u32 s{S_CNT}, 1")
             A("s_cbranch_scc1 .Lh3att_nomix_%=")
-            A("s_waitcnt vmcnt(4)")
+            A("s_waitcnt vmcnt(2)" if H1 else "s_waitcnt vmcnt(4)")   # H1: one hand-off (2 DMAs) is newer than the fragment loads
             L += mixing_part(0, True)
             A(".Lh3att_nomix_%=:")
             vm = 6
         split = split_ops(nbuf)
         nxt = (ks + 2) % 4   # k-step whose mixing runs at the start of the next step
-        L += gemm_stage(0, buf, split[:24], True, f"k{ks}a", vm_allow=vm, skip=3)
-        L += gemm_stage(1, buf, split[24:], True, f"k{ks}b", vm_allow=vm, tail_misc=xt_reads_step(nxt))
+        if H1:
+            # the hand-off of a stage fetches the stage five ahead: FFN A stages (which carry a bias / scale block) for the
+            # last head's four stages and for the last stage of the head before
+            L += gemm_stage(0, buf, split, True, f"k{ks}", vm_allow=vm, skip=3, tail_misc=xt_reads_step(nxt),
+                            aux_cnt=2 if ks == 3 else 1)
+        else:
+            L += gemm_stage(0, buf, split[:24], True, f"k{ks}a", vm_allow=vm, skip=3)
+            L += gemm_stage(1, buf, split[24:], True, f"k{ks}b", vm_allow=vm, tail_misc=xt_reads_step(nxt))
         A("s_nop 1")
     A(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     A(f"s_cmp_eq_u32 s{S_CNT}, 0")

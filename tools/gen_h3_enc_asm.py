@@ -50,9 +50,17 @@ def load(name):
 
 
 WINDOWED = "--mode=windowed" in sys.argv
+# --h1: the single-MFMA "fast" variant (TW_PATH_FUSED_H1; gen_h3_ffn_asm.py / gen_h3_attn_asm.py H1).  The glue only ever
+# produces the fp16 hi halves: a split is one pack per register pair, the transposer sends three tiles per feature tile
+# through the matrix pipe instead of six.  The section stamps are always compiled in (one scalar compare per stamp when
+# off): bench.py reads the attention block's cycles from them.
+H1 = "--h1" in sys.argv
 EXPERIMENT = set(filter(None, os.environ.get("H3_ENC_EXPERIMENT", "").split(",")))
+if H1:
+    EXPERIMENT.add("stamps")
 attn = load("gen_h3_attn_asm")
 ffn = load("gen_h3_ffn_asm")
+attn.H1 = ffn.H1 = H1
 attn.WINDOWED = WINDOWED
 attn.FUSED = True
 attn.XT_AGPR = 96   # the transposed copy of x lives in a96..a191 from the transposer to the end of the attention block
@@ -226,6 +234,8 @@ def layer_norm(inv_sgpr, w_off, b_off, label):
 def split_tile(t, hi, lo, tmp):
     """T tile (4 fp32) -> hi pair regs (2), lo pair regs (2): the eight VALU ops of csrc split_pair x 2."""
     ops = [f"v_cvt_pk_f16_f32 v{hi}, v{t}, v{t + 1}", f"v_cvt_pk_f16_f32 v{hi + 1}, v{t + 2}, v{t + 3}"]
+    if H1:
+        return ops
     for r in range(4):
         sel = "op_sel:[1,0,0] " if r % 2 else ""
         ops.append(f"v_fma_mix_f32 v{tmp + r}, v{hi + r // 2}, -1.0, v{t + r} {sel}op_sel_hi:[1,0,0]")
@@ -262,7 +272,8 @@ def g1():
                 hi, lo = U(jt), U(jt) + 2
                 s += split_tile(T(ft, jt), hi, lo, TMP(jt))
                 s += [f"v_accvgpr_write_b32 a{ffn.XB(3, jt, 'h') + 2 * odd + k}, v{hi + k}" for k in range(2)]
-                s += [f"v_accvgpr_write_b32 a{ffn.XB(3, jt, 'l') + 2 * odd + k}, v{lo + k}" for k in range(2)]
+                if not H1:
+                    s += [f"v_accvgpr_write_b32 a{ffn.XB(3, jt, 'l') + 2 * odd + k}, v{lo + k}" for k in range(2)]
             streams.append(s)
         # three tiles share TMP / U (two sets): tiles 0 and 1 interleaved, tile 2 behind them
         L += interleave(streams[0], streams[1]) + streams[2]
@@ -283,7 +294,7 @@ def transposer_issue(ft, buf):
     L += split_tile(T(ft, 2), H(buf, 2, 0), H(buf, 2, 1), TMP(0))
     L.append("s_nop 1")
     for jt in range(NT):
-        for part in range(2):
+        for part in range(1 if H1 else 2):
             L.append(f"v_mfma_f32_16x16x16_f16 {vr(D(buf, jt, part), 4)}, {vr(H(buf, jt, part))}, {vr(V_IDB)}, 0")
     return L
 
@@ -293,14 +304,15 @@ def transposer_drain(ft, buf):
     (no LDS in between: MFMA A operands may be AGPRs, and 192 ds_reads per layer disappear with the 32 ds_writes)."""
     L = []
     base = attn.XT_AGPR + 12 * ft
-    for part in range(2):
+    parts = 1 if H1 else 2
+    for part in range(parts):
         for jt in range(2):
             d = D(buf, jt, part)
             L += [f"v_cvt_pk_f16_f32 v{IMG01(part) + 2 * jt}, v{d}, v{d + 1}",
                   f"v_cvt_pk_f16_f32 v{IMG01(part) + 2 * jt + 1}, v{d + 2}, v{d + 3}"]
         d = D(buf, 2, part)
         L += [f"v_cvt_pk_f16_f32 v{IMG2(part)}, v{d}, v{d + 1}", f"v_cvt_pk_f16_f32 v{IMG2(part) + 1}, v{d + 2}, v{d + 3}"]
-    for part, (n01, n2) in enumerate((("a0h", "a1h"), ("a0l", "a1l"))):
+    for part, (n01, n2) in enumerate((("a0h", "a1h"), ("a0l", "a1l"))[:parts]):
         L += [f"v_accvgpr_write_b32 a{base + attn.XT_OFF[n01] + k}, v{IMG01(part) + k}" for k in range(4)]
         L += [f"v_accvgpr_write_b32 a{base + attn.XT_OFF[n2] + k}, v{IMG2(part) + k}" for k in range(2)]
     return L
@@ -343,7 +355,7 @@ def g2(last):
             L += split_tile(T(ft, 2), XBX(ks, 2, 0) + 2 * odd, XBX(ks, 2, 1) + 2 * odd, TMP(0))
             if odd:
                 for jt in range(NT):
-                    for part in range(2):
+                    for part in range(1 if H1 else 2):
                         A(f"ds_write_b128 v{V_PRIV16}, {vr(XBX(ks, jt, part), 4)} offset:{1024 * ((ks * NT + jt) * 2 + part)}")
         else:
             L += transposer_issue(ft, buf)
@@ -480,18 +492,19 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--out-dir="):
             out_dir = a.split("=", 1)[1]
-    mode = " --mode=windowed" if WINDOWED else ""
-    base = os.path.join(out_dir, "tw_h3_encw_asm.inc" if WINDOWED else "tw_h3_enc_asm.inc")
+    mode = (" --mode=windowed" if WINDOWED else "") + (" --h1" if H1 else "")
+    fam = "h1" if H1 else "h3"
+    base = os.path.join(out_dir, f"tw_{fam}_encw_asm.inc" if WINDOWED else f"tw_{fam}_enc_asm.inc")
     out = [f"// GENERATED by tools/gen_h3_enc_asm.py{mode} - do not edit.  Body of the encoder-stack asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")
     if not WINDOWED:
         clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(192)] + [f'"s{i}"' for i in range(70, 100)] + \
                ['"vcc"', '"scc"', '"memory"']
-        cl = ["// GENERATED by tools/gen_h3_enc_asm.py - clobber list of the encoder-stack asm statement."]
+        cl = [f"// GENERATED by tools/gen_h3_enc_asm.py{mode} - clobber list of the encoder-stack asm statement."]
         for i in range(0, len(clob), 12):
             cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
-        open(os.path.join(out_dir, "tw_h3_enc_clobbers.inc"), "w").write("\n".join(cl) + "\n")
+        open(os.path.join(out_dir, f"tw_{fam}_enc_clobbers.inc"), "w").write("\n".join(cl) + "\n")
     n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
     print(f"enc{mode}: {len(lines)} instructions, {n_mfma} MFMAs")
 

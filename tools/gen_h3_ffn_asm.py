@@ -38,6 +38,11 @@ IOTAIL = "iotail" in EXPERIMENT
 # Set by tools/gen_h3_enc_asm.py (the FFN embedded in the asm statement of the whole encoder stack): the split input is
 # already in the xb registers, the accumulators hold the residual ((x + b2) / scale) and y stays in a0..a95.
 FUSED = False
+# --h1 (or set by tools/gen_h3_enc_asm.py): the single-MFMA "fast" variant (TW_PATH_FUSED_H1).  Every product is ONE
+# v_mfma_f32_16x16x32_f16 on the fp16 hi halves; a stage's four 2 KiB "pairs" then hold TWO hi tiles each (the second in
+# the place of the lo tile: SLOT(p, 'l')), so a stage is 8 tiles = 24 MFMAs and a chunk is ONE A stage (tile 4 o + ks)
+# and ONE B stage (tile ot).  Ring, DMA and hand-off are unchanged; the lo operand registers stay unused.
+H1 = "--h1" in sys.argv
 
 NT = 3
 # Shapes of the three chunked MLPs (same schedule, one generated file each):
@@ -117,6 +122,14 @@ def epi_unit(o, jt, buf, relu=True, tset=None):
         ops += [f"v_max_f32 v{t[r]}, v{t[r]}, 0" for r in range(4)]
     hh = HB(buf, jt, "h") + 2 * o
     ll = HB(buf, jt, "l") + 2 * o
+    if H1:
+        # no lo half; ReLU after the rounding (max(rne(v), 0) == rne(max(v, 0))) on the packed pair: 8 ops per unit
+        if not SHAPE["silu"]:
+            ops = ops[:4]
+        ops += [f"v_cvt_pk_f16_f32 v{hh}, v{t[0]}, v{t[1]}", f"v_cvt_pk_f16_f32 v{hh + 1}, v{t[2]}, v{t[3]}"]
+        if not SHAPE["silu"]:
+            ops += [f"v_pk_max_f16 v{hh}, v{hh}, 0", f"v_pk_max_f16 v{hh + 1}, v{hh + 1}, 0"]
+        return ops
     if "epidst" in EXPERIMENT:
         hh, ll = V_T3, V_T3 + 2
     ops += [f"v_cvt_pk_f16_f32 v{hh}, v{t[0]}, v{t[1]}", f"v_cvt_pk_f16_f32 v{hh + 1}, v{t[2]}, v{t[3]}"]
@@ -240,7 +253,7 @@ def weave(mfmas, valu, misc, valu_per=2, misc_per=2):
     return out
 
 
-def place_valu(lines, valu, cap_empty=2):
+def place_valu(lines, valu, cap_empty=2, skip_gaps=0):
     """`lines`: a stage's instructions with the MFMAs and everything that has a fixed place (LDS reads, waits, the
     barrier, the hand-off).  Distribute `valu` (order kept) over the gaps behind the MFMAs, preferring gaps that hold
     nothing else: an MFMA issues every 16 cycles and the wave issues about one instruction per 4, so a gap takes two or
@@ -254,10 +267,10 @@ def place_valu(lines, valu, cap_empty=2):
     heavy = lambda l: not (l.endswith(":") or l.startswith("s_")) or l.startswith("s_waitcnt") or l.startswith("s_barrier")
     for k, i in enumerate(idx):
         end = idx[k + 1] if k + 1 < len(idx) else len(lines)
-        gaps.append((i, sum(1 for l in lines[i + 1:end] if heavy(l))))
+        gaps.append((i, 99 if k < skip_gaps else sum(1 for l in lines[i + 1:end] if heavy(l))))
     cap = cap_empty
     while True:
-        caps = [max(0, cap - n) for _, n in gaps]
+        caps = [0 if n == 99 else max(0, cap - n) for _, n in gaps]
         if sum(caps) >= len(valu):
             break
         cap += 1
@@ -282,6 +295,8 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     the single A stage holds both o, pair = 2 o + ks);  kind 'B': yacc[4b+p] += W2tile(p) . hb (pairs beyond ot_out
     do not exist: no MFMAs, no tile reads)."""
     ks_in, ot_out = SHAPE["ks_in"], SHAPE["ot_out"]
+    if H1:
+        return stage_h1(kind, hb_cur, epi_ops, next_reads, with_aux, label)
     groups = []
     for p in range(4):
         if kind == "A":
@@ -334,6 +349,54 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     return out
 
 
+def stage_h1(kind, hb_cur, epi_ops, next_reads, with_aux, label):
+    """One 8-tile stage of the single-MFMA variant.  kind 'A' (always carries the chunk's bias / scale block):
+    ks_in = 4: pair p = tiles (o = p // 2, ks = 2 (p % 2) + j), so hacc[0] is complete after pair 1 and its epilogue units
+    (`epi_ops`) run under pairs 2, 3; ks_in = 2: pairs 0, 1 = tiles (o = p, ks = j), pairs 2, 3 do not exist.
+    kind 'B': pair p = tiles ot = 2 p + j (beyond ot_out: none); `epi_ops` spread over the whole stage."""
+    ks_in, ot_out = SHAPE["ks_in"], SHAPE["ot_out"]
+    groups = []
+    for p in range(4):
+        g = []
+        for j, part in enumerate(("h", "l")):
+            if kind == "A":
+                if ks_in == 4:
+                    o, ks = p // 2, 2 * (p % 2) + j
+                elif p < 2:
+                    o, ks = p, j
+                else:
+                    continue
+                g += [mfma(HACC(o, jt), SLOT(p, part), XB(ks, jt, "h"), zero=(ks == 0), dst="v", bsrc=XB_SRC(ks)) for jt in range(NT)]
+            else:
+                ot = 2 * p + j
+                if ot < ot_out:
+                    g += [mfma(YACC(ot, jt), SLOT(p, part), HB(hb_cur, jt, "h")) for jt in range(NT)]
+        groups.append(g)
+    live = [bool(g) for g in groups]
+    is_a0 = kind == "A"
+    aux = 3 if is_a0 else 0
+    epi = [] if "noepi" in EXPERIMENT else list(epi_ops)
+    first = ["s_waitcnt lgkmcnt(2)"]
+    first_misc = tile_reads(2) if live[2] else []
+    if is_a0:
+        first_misc = [f"v_add_u32 v{V_AUX}, s{S_OFF}, v{V_G16}", f"v_mov_b32 v{V_SCADDR}, s{S_OFF}"] + aux_reads() + first_misc
+    first += weave(groups[0], [], first_misc, misc_per=3)
+    first.append(f"s_waitcnt lgkmcnt({(2 if live[2] else 0) + aux})")
+    first += weave(groups[1], [], tile_reads(3) if live[3] else [])
+    first.append("s_waitcnt vmcnt(6) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
+    if "nobarrier" not in EXPERIMENT:
+        first.append("s_barrier")
+    h = handoff(next_reads, with_aux, label)
+    if is_a0:
+        h = [f"v_readfirstlane_b32 s{S_SC}, v{V_SC}"] + h   # aux block landed (lgkmcnt(0) above)
+    second = weave(groups[2], [], h, misc_per=3)
+    second += weave(groups[3], [], [])
+    if kind == "A" and ks_in == 4:
+        # epilogue of hacc[0] (complete after pair 1) under pairs 2, 3; two MFMAs of distance to its last writer
+        return first + place_valu(second, epi, skip_gaps=2)
+    return place_valu(first + second, epi, skip_gaps=2)
+
+
 def generate():
     L = []
     A = L.append
@@ -364,10 +427,14 @@ def generate():
     ks_in, ot_out = SHAPE["ks_in"], SHAPE["ot_out"]
     ffn = SHAPE["tag"] == "ffn"
     n_a, n_b = (2 if ks_in == 4 else 1), (ot_out + 3) // 4
+    if H1:
+        n_a = n_b = 1
     # input operand (split activations) from the wave-private LDS block: 2 images per (ks, jt)
     if not FUSED:
         A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
         for i in range(2 * NT * ks_in):
+            if H1 and i % 2:
+                continue   # lo images: not used
             dst = vr(4 * i) if i < 18 else ar(96 + 4 * (i - 18))
             A(f"ds_read_b128 {dst}, v{V_TMP} offset:{1024 * i}")
         for i in range(4 * NT * ot_out):
@@ -396,6 +463,11 @@ def generate():
     # bias/scale block, so B1 fetches one.  A1 keeps the aux DMA as well: in the last trips its hand-off fetches the
     # first stage AFTER the FFN (an A0 of out_mlp in the last layer).  The short in/out MLPs always move it.
     steady = (lambda kind, idx: (kind, idx) in (("A", 1), ("B", 1))) if ffn else always
+    if H1:
+        # two stages per chunk: a B stage's hand-off (five ahead) fetches an A stage, which carries a bias / scale block;
+        # an A stage's fetches a B stage - except in the last trips, where it is the first stage BEHIND this MLP (the
+        # out-MLP's first A stage after the last layer).  Same code for all trips, so both move the block.
+        steady = always
 
     iotail = IOTAIL and SPREAD and not ffn
     UNITS = [(o, jt) for o in range(2) for jt in range(NT)]
@@ -427,7 +499,15 @@ def generate():
     A(".Lh3mlp_loop_%=:")
     for half, (cur_buf, nxt_buf) in enumerate(((0, 1), (1, 0))):
         units = [epi_unit(o, jt, nxt_buf) for o in range(2) for jt in range(NT)]
-        if ffn and SPREAD:
+        if H1 and ks_in == 4:
+            # hacc[0] is complete after the first half of the A stage: its three units under the second half, hacc[1]'s
+            # under the B stage of the chunk before (stage_h1)
+            a_epi = {0: units[0] + units[1] + units[2]}
+            epi = units[3] + units[4] + units[5]
+        elif H1:
+            a_epi = None
+            epi = [op for u_ in units for op in u_]
+        elif ffn and SPREAD:
             # hacc[0] is complete after stage A0: two of its three units run under A1, the rest under B0 and B1
             # (B0 starts with the last hacc[0] unit, so hacc[1] - finished by A1's last MFMAs - is read well after it)
             a_epi = {0: [], 1: units[0] + units[1]}
@@ -505,8 +585,9 @@ def main():
             out_dir = a.split("=", 1)[1]
     SHAPE = SHAPES[shape]
     lines = generate()
-    base = os.path.join(out_dir, f"tw_h3_{SHAPE['tag']}_asm.inc")
-    out = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape} - do not edit.  Body of the {shape} MLP asm statement",
+    fam, flag = ("h1", " --h1") if H1 else ("h3", "")
+    base = os.path.join(out_dir, f"tw_{fam}_{SHAPE['tag']}_asm.inc")
+    out = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape}{flag} - do not edit.  Body of the {shape} MLP asm statement",
            "// (see the generator for the register map and the schedule)."]
     for l in lines:
         out.append('"' + l + '\\n\\t"')
@@ -514,7 +595,7 @@ def main():
     n_v = (212 if IOTAIL else 208) if SHAPE["silu"] else 204
     clob = [f'"v{i}"' for i in range(n_v)] + [f'"a{i}"' for i in range(120)] + [f'"s{i}"' for i in range(83 if "auxrot" in EXPERIMENT else 84, 96)] + \
            ['"vcc"', '"scc"', '"memory"']
-    cl = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape} - clobber list of the {shape} MLP asm statement."]
+    cl = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape}{flag} - clobber list of the {shape} MLP asm statement."]
     for i in range(0, len(clob), 12):
         cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
     open(base.replace("_asm.inc", "_clobbers.inc"), "w").write("\n".join(cl) + "\n")
