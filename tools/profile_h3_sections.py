@@ -8,6 +8,7 @@ from timewarp_amd import _lib
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 extra = int(args[0]) if args else 0
+H1 = "--h1" in sys.argv         # the single-MFMA build (TW_PATH_FUSED_H1): encoder-stack statement with its stamps always compiled in
 DENSE = "--dense" in sys.argv   # the split-fp16 dense-softmax kernel (transformer_nvp) instead of the kernel-attention one
 sd = H.full_dense_sd() if DENSE else H.full_kernel_sd()
 N, V = 1000, 22
@@ -18,10 +19,13 @@ x_v = torch.randn(1, V, 3, generator=g) * 0.5
 zo = torch.randn(N, V, 3, generator=g) * 0.5
 mask = torch.zeros(1, V, dtype=torch.bool)
 xc = x_c - fo.centre_of_mass(x_c, mask)
-m = H.tw_dense_model(sd, path=3) if DENSE else H.tw_kernel_model(sd, path=3)
+PATH = 4 if H1 else 3
+if H1:
+    extra |= 8192
+m = H.tw_dense_model(sd, path=3) if DENSE else H.tw_kernel_model(sd, path=PATH)
 _lib.load().tw_debug_set_flags(16 | extra)
 for rep in range(3):
-    acts, out = m.debug_netblock(0, 0, at.cuda(), xc.cuda(), x_v.cuda(), mask.cuda(), zo.cuda(), 3)
+    acts, out = m.debug_netblock(0, 0, at.cuda(), xc.cuda(), x_v.cuda(), mask.cuda(), zo.cuda(), PATH)
 torch.cuda.synchronize()
 ts = acts.reshape(-1)[:128].contiguous().view(torch.int64).cpu().tolist()
 L = 3
