@@ -38,11 +38,15 @@ F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (
 # busy for 579.5 k clocks per launch (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_h3_sq_counters.md)
 SUSTAINED_MFMA_CLOCK_GHZ = 1.74
 H3_MFMA_BUSY_CLOCKS_PER_LAUNCH = 579.5e3
-# execution paths of the flow (include/timewarp_hip.h): both hold the 1e-5 parity bar
+# execution paths of the flow (include/timewarp_hip.h): h3 and f32 hold the 1e-5 parity bar
 PATHS = {
     "h3": dict(path=3, dtype="f16x3 (split-fp16 operands, 3 MFMAs per fp32 product, fp32 accumulate)",
                kernel="tw::netblock_h3_kernel<3, true, false, false, false, true>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=3),
     "f32": dict(path=1, dtype="f32", kernel="tw::netblock_kernel<3>", peak=F32_MFMA_PEAK_TFLOPS, mfma_per_product=1),
+    # opt-in fast mode, NOT a parity path and never the headline: fp16 operands (11 significand bits), one MFMA per product
+    "h1": dict(path=4, dtype="f16 (fp16 operands, ONE MFMA per product, fp32 accumulate; ~1e-4 relative deviation from the "
+                             "reference's fp32 arithmetic - tests/test_flow_h1_gpu.py; opt-in fast mode, not a parity path)",
+               kernel="tw::netblock_h3_kernel<3, true, false, false, false, true, true>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=1),
 }
 # Synthetic-weight calibration (SURVEY section 8d idea, tuned so acceptance is non-degenerate against
 # the stiff bonded terms): identity flow (last out_mlp layer zeroed), coordinate prior std e^-7 nm,
@@ -93,7 +97,7 @@ def prewarm(model, types, coords, device, proposals):
     torch.cuda.synchronize(device)
 
 
-def attention_block(model, device, proposals, avg_launch_ms):
+def attention_block(model, device, proposals, avg_launch_ms, path_name="h3"):
     """The north-star's second figure: algorithmic FLOP rate of the attention block (values_proj + A.V + out_proj,
     SURVEY 8d) against the bf16/f16 dense MFMA peak.  Measured on one extra, untimed launch of the dominant kernel with
     its s_memtime section stamps switched on (tw_debug_set_flags bit 4; wave 0 of workgroup 0 stamps the shader clock at
@@ -111,15 +115,20 @@ def attention_block(model, device, proposals, avg_launch_ms):
     lib.tw_debug_set_flags(16)
     try:
         for _ in range(2):
-            acts, _ = model.debug_netblock(0, 0, at, xc, xv, mask, zo, _lib.TW_PATH_FUSED_H3)
+            acts, _ = model.debug_netblock(0, 0, at, xc, xv, mask, zo, PATHS[path_name]["path"])
         torch.cuda.synchronize()
     finally:
         lib.tw_debug_set_flags(0)
     n_layers = model.dims.n_layers
-    ts = acts.reshape(-1)[:64].contiguous().view(torch.int64).cpu().tolist()
-    # stamps: 0 start, 1 in_mlp, then per layer (attention, add+LN1, FFN, add+LN2), out_mlp
-    total = ts[2 + 4 * n_layers] - ts[0]
-    att = sum(ts[2 + 4 * l] - ts[1 + 4 * l] for l in range(n_layers))
+    ts = acts.reshape(-1)[:128].contiguous().view(torch.int64).cpu().tolist()
+    # stamps: 0 start, 1 in_mlp, then per layer (attention, add+LN1, FFN, add+LN2), out_mlp; 60: top of the kernel
+    total = ts[2 + 4 * n_layers] - (ts[60] or ts[0])
+    if path_name == "h1":
+        # the single-MFMA build is the encoder-stack statement with its stamps compiled in: 40 + 4 l + {0, 1} = start /
+        # end of layer l's attention block (side-block DMA + all heads: mixing and folded out_proj . values_proj GEMM)
+        att = sum(ts[40 + 4 * l + 1] - ts[40 + 4 * l] for l in range(n_layers))
+    else:
+        att = sum(ts[2 + 4 * l] - ts[1 + 4 * l] for l in range(n_layers))
     share = att / total
     d = model.dims
     flop_token_layer = 2 * d.d_model * d.n_heads * d.d_model * 2 + 2 * d.n_heads * V_ATOMS * d.d_model
@@ -130,12 +139,17 @@ def attention_block(model, device, proposals, avg_launch_ms):
                 "sections of the dominant kernel",
         "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F16_MFMA_PEAK_TFLOPS,
         "share_of_launch": share, "algorithmic_flop_per_launch": float(flop_launch),
-        "executed_over_algorithmic": "2.26 (3-term fp16 split x 1/2 from folding out_proj into values_proj per head "
-                                     "+ the K=48 block-diagonal mixing on K=32+16 MFMAs)",
-        "method": "s_memtime section stamps of one untimed launch (tw_debug_set_flags 16: the per-section build of the kernel, "
-                  "whose stamps sit between the sections) x live average launch time of the encoder-stack build; that build "
-                  "spends 3 x 47.1 k of 744.5 k cycles in the attention blocks (profiles/r03_ab_xt_agprs.txt), so the share "
-                  "used here is slightly high and the rate slightly low",
+        "attention_cycles_per_launch": att, "stamped_cycles_per_launch": total,
+        "executed_over_algorithmic": ("0.75 (one fp16 MFMA per product x 1/2 from folding out_proj into values_proj per head + the "
+                                      "block-diagonal mixing on K=32+16 MFMAs)" if path_name == "h1" else
+                                      "2.26 (3-term fp16 split x 1/2 from folding out_proj into values_proj per head "
+                                      "+ the K=48 block-diagonal mixing on K=32+16 MFMAs)"),
+        "method": ("s_memtime section stamps of one untimed launch (tw_debug_set_flags 16; the stamps are compiled into the "
+                   "encoder-stack statement of this build) x live average launch time" if path_name == "h1" else
+                   "s_memtime section stamps of one untimed launch (tw_debug_set_flags 16: the per-section build of the kernel, "
+                   "whose stamps sit between the sections) x live average launch time of the encoder-stack build; that build "
+                   "spends 3 x 47.1 k of 744.5 k cycles in the attention blocks (profiles/r03_ab_xt_agprs.txt), so the share "
+                   "used here is slightly high and the rate slightly low"),
     }
 
 
@@ -305,14 +319,15 @@ def cpu_baseline(proposals):
     }
 
 
-def alt_path_record(device, seed, proposals, steps, sync_every):
-    """The same workload on the exact-f32 fused kernel (TW_EXECUTION_PATH=f32; the C ABI's TW_PATH_AUTO), timed after the
-    main region on a second chain so the driver's record carries both kernel families."""
+def alt_path_record(device, seed, proposals, steps, sync_every, name="f32"):
+    """The same workload on another kernel family, timed after the main region on a second chain so the driver's record
+    carries them all: "f32" = the exact-f32 fused kernel (TW_EXECUTION_PATH=f32; the C ABI's TW_PATH_AUTO); "h1" = the
+    opt-in single-MFMA fast mode (TW_EXECUTION_PATH=h1), with the north star's attention-block figure."""
     from timewarp_amd import _lib
 
-    pinfo = PATHS["f32"]
+    pinfo = PATHS[name]
     lib = _lib.load()
-    chain, _ = build_chain(device, seed, proposals, _lib.TW_PATH_AUTO)
+    chain, model = build_chain(device, seed, proposals, _lib.TW_PATH_AUTO if name == "f32" else pinfo["path"])
     with torch.no_grad():
         chain.step_deferred()
         chain.flush()
@@ -332,14 +347,24 @@ def alt_path_record(device, seed, proposals, steps, sync_every):
     lib.tw_profile_end(C.byref(k_ms), C.byref(k_launches))
     avg_ms = k_ms.value / max(int(k_launches.value), 1)
     achieved = FLOP_PER_SAMPLE_PASS * proposals / N_COUPLING / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    return {
-        "execution_path": "f32 (exact-f32 fused kernel: TW_EXECUTION_PATH=f32 / the C ABI's TW_PATH_AUTO; model_constructor's default is h3)",
+    rec = {
+        "execution_path": {"f32": "f32 (exact-f32 fused kernel: TW_EXECUTION_PATH=f32 / the C ABI's TW_PATH_AUTO; model_constructor's default is h3)",
+                           "h1": "h1 (opt-in fast mode: TW_EXECUTION_PATH=h1 / TW_PATH_FUSED_H1; one fp16 MFMA per product; NOT a "
+                                 "parity path - never the default, never the headline)"}[name],
         "dtype": pinfo["dtype"], "value": (chain.accepted - acc0) / elapsed, "unit": "MH-accepted samples/s",
         "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+        "range_guard_fired": bool(getattr(model, "demoted", False)),
         "roofline": {"bound": "mfma", "kernel": pinfo["kernel"], "achieved": achieved, "peak": pinfo["peak"],
                      "unit": "TFLOP/s", "frac": achieved / pinfo["peak"], "avg_launch_ms": avg_ms,
-                     "launches": int(k_launches.value)},
+                     "launches": int(k_launches.value), "mfma_per_fp32_product": pinfo["mfma_per_product"]},
     }
+    if name == "h1" and proposals == S_PROPOSALS and not rec["range_guard_fired"]:
+        rec["roofline"]["attention_block"] = attention_block(model, device, proposals, avg_ms, "h1")
+        rec["measured_deviation"] = ("un-calibrated full-size weights vs the reference's vectors: 1.6e-3 (coordinates), 2.0e-4 "
+                                     "(log p) relative; forward/reverse round trip of log p: 0.043 max of ~228; accept indicators of "
+                                     "whole MH iterations vs the fp32 oracle 384/384 (profiles/r04_h1_accuracy.txt).  This bench's "
+                                     "identity-flow calibration makes scale = 1, shift = 0 exactly on every path")
+    return rec
 
 
 def end_timed_region(traj, t0, device, world):
@@ -385,7 +410,8 @@ def main():
                     help="MH iterations queued per host read-back of the accept results (sample_with_model's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", choices=sorted(PATHS), default="h3",
-                    help="flow execution path: split-fp16 fused kernel (default) or exact-f32 fused kernel")
+                    help="flow execution path: split-fp16 fused kernel (default, the headline), exact-f32 fused kernel, or the "
+                         "opt-in single-MFMA fast mode h1 (not a parity path)")
     args = ap.parse_args()
 
     from timewarp_amd import _lib, distributed
@@ -506,6 +532,14 @@ def main():
                 "algorithmic_flop_per_launch": flop_per_launch,
             },
         }
+        # a run whose range guard fired has been (partly) timed on the f32 kernels - say so instead of
+        # reporting an f16 roofline computed from f32 launch times
+        out["range_guard_fired"] = bool(getattr(model, "demoted", False))
+        if out["range_guard_fired"]:
+            raise RuntimeError("bench.py: the fp16 range guard demoted the model to the exact-f32 kernels during the run; "
+                               "the line would mislabel the measured path.  Re-run with --path f32")
+        if args.path == "h1" and args.proposals == S_PROPOSALS:
+            out["roofline"]["attention_block"] = attention_block(model, device, args.proposals, avg_ms, "h1")
         if args.path == "h3" and args.proposals == S_PROPOSALS:
             out["roofline"]["attention_block"] = attention_block(model, device, args.proposals, avg_ms)
             floor_ms = H3_MFMA_BUSY_CLOCKS_PER_LAUNCH / (SUSTAINED_MFMA_CLOCK_GHZ * 1e6)
@@ -523,6 +557,11 @@ def main():
         if world == 1 and args.path != "f32":
             out["alt_path"] = alt_path_record(device, distributed.chain_seed(args.seed, rank), args.proposals,
                                               max(4, args.steps // 4), args.sync_every)
+        if world == 1 and args.path == "h3":
+            # the north star's second figure (>= 40 % of the half-precision MFMA roofline on the attention block) belongs to
+            # the fast mode (SURVEY section 7 "precision contract"): reported here, beside the headline
+            out["alt_path_h1"] = alt_path_record(device, distributed.chain_seed(args.seed, rank), args.proposals,
+                                                 max(8, args.steps // 2), args.sync_every, "h1")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.proposals)
         print(json.dumps(out), flush=True)
