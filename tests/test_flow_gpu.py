@@ -472,6 +472,83 @@ def test_large_molecules_vs_oracle(V, lens, paths):
                 adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
 
 
+@pytest.mark.parametrize("V,lens", [(25, [25, 25, 20, 25, 25, 25, 25, 11, 25]), (30, [30, 28, 30, 30, 25, 30, 30, 30]),
+                                    (32, [32, 32, 17, 32, 32, 32, 32]), (38, [38, 38, 38, 30, 38, 38]), (48, [48, 40, 48, 48, 48])])
+def test_wide_layout_on_25_to_48_atoms_vs_oracle(V, lens):
+    """r04: the wide layout (floor(192 / V) molecules back to back over a workgroup's four waves) also takes molecules of
+    25 - 48 atoms, for which a 48-token wave holds only one.  Forced here (tw_debug_set_flags 32768) on ragged batches of more
+    than one workgroup, against the oracle and against the narrow layout (flag 16384) - the launch code picks between the
+    two by rounds of the chip (next test)."""
+    from timewarp_amd import _lib
+
+    sd = H.full_kernel_sd()
+    g = torch.Generator().manual_seed(700 + V)
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.4
+    x_v = torch.randn(B, V, 3, generator=g) * 0.5
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+    y_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    args = dict(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(), y_velocs=y_v.cuda(),
+                adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+    lib = _lib.load()
+    outs = {}
+    try:
+        for flag in (32768, 16384):
+            lib.tw_debug_set_flags(flag)
+            m = H.tw_kernel_model(sd, path=H3)
+            outs[flag] = m.log_likelihood(**args).cpu()
+            H.assert_not_demoted(m)
+    finally:
+        lib.tw_debug_set_flags(0)
+    tol = 2e-5 if V > 25 else TOL  # above 25 atoms the scores follow torch.cdist's matmul branch
+    assert H.rel_err(outs[32768], ref) < tol, H.rel_err(outs[32768], ref)
+    assert H.rel_err(outs[16384], ref) < tol
+
+
+def test_layout_choice_by_rounds_of_the_chip():
+    """Which layout a launch takes between 25 and 48 atoms follows from its row count (h3_wide_choice): 768 proposals of a
+    30-atom molecule are one round of workgroups wide (2 x 128) against two narrow (2 x 192); 1000 proposals are two rounds
+    either way and stay narrow.  Both must give the oracle's numbers; that the choice is really made shows in the workspace
+    the library asks for and in the two results differing in the last bits."""
+    from timewarp_amd import _lib
+
+    sd = H.full_kernel_sd()
+    V = 30
+    g = torch.Generator().manual_seed(31)
+    at = torch.randint(0, 5, (1, V), generator=g)
+    x_c = torch.randn(1, V, 3, generator=g) * 0.4
+    x_v = torch.randn(1, V, 3, generator=g) * 0.5
+    mk = torch.zeros(1, V, dtype=torch.bool)
+    lib = _lib.load()
+    for S in (768, 1000):
+        zc, zv = fo.draw_latents(sd, S, (1, V, 3), g)
+        res = {}
+        try:
+            for flag in (0, 16384, 32768):
+                lib.tw_debug_set_flags(flag)
+                m = H.tw_kernel_model(sd, path=H3)
+                yc, yv, lp = m.conditional_sample_with_logp(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(),
+                                                            adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda(),
+                                                            num_samples=S, z_coords=zc.cuda(), z_velocs=zv.cuda())
+                res[flag] = (yc.cpu(), lp.cpu())
+                H.assert_not_demoted(m)
+        finally:
+            lib.tw_debug_set_flags(0)
+        chosen = 32768 if S == 768 else 16384
+        other = 16384 if S == 768 else 32768
+        assert torch.equal(res[0][0], res[chosen][0]) and torch.equal(res[0][1], res[chosen][1]), S
+        assert not torch.equal(res[0][1], res[other][1]), S
+        rows = torch.tensor([0, 1, 5, 6, S // 2, S - 7, S - 1])
+        ryc, _, rlp = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, mk, zc[rows], zv[rows])
+        for flag in (16384, 32768):
+            assert H.rel_err(res[flag][0][rows], ryc) < 2e-5 and H.rel_err(res[flag][1][rows], rlp) < 2e-5, (S, flag)
+
+
 def test_per_op_path_lds_limit():
     """150 atoms: the per-op kernels' V x V score tile needs > 64 KiB of LDS (raised limit) and still matches the
     oracle; 256 atoms exceed the CU's 160 KiB and are refused with a message instead of failing at launch."""

@@ -112,7 +112,26 @@ def test_execution_path_from_environment(monkeypatch):
     many.custom_transformer_nvp_config.encoder_layer_config.lengthscales = [0.1 * (i + 1) for i in range(18)]
     many.custom_transformer_nvp_config.encoder_layer_config.num_heads = 18
     mm = tw.model_constructor(many)
-    assert mm._path_for(22) == 3 and mm._path_for(48) == 0 and mm._path_for(60) == 3  # (wide: one head at a time)
+    # (the wide layout's producer works one head at a time, so 25 .. 160 atoms stay on the split-fp16 kernel; 24 atoms and
+    # fewer need the per-wave producer, whose tile would be 2 x 18 x 24 x 24 floats + ... and fits)
+    assert mm._path_for(22) == 3 and mm._path_for(48) == 3 and mm._path_for(60) == 3
+
+
+def test_path_supported_sweep():
+    """tw_flow_path_supported over 1 .. 200 atoms: the split-fp16 kernel takes 1 .. 48 (48-token waves), the wide
+    layout 25 .. 160 except 81 .. 95 (wave 1 would span two molecules over eleven key tiles = six key groups, the statement
+    has five); the single-MFMA fast path 1 .. 48; the f32 kernel 1 .. 64."""
+    import ctypes as C
+    from timewarp_amd import _lib, synthetic
+    import timewarp_amd as tw
+
+    lib = _lib.load()
+    desc = tw.model_constructor(synthetic.kernel_transformer_nvp_config()).dims.to_desc()
+    sup = lambda path: [v for v in range(1, 201) if lib.tw_flow_path_supported(C.byref(desc), v, path) == 1]
+    assert sup(3) == list(range(1, 81)) + list(range(96, 161))
+    assert sup(4) == list(range(1, 49))
+    assert sup(1) == list(range(1, 65))
+    assert sup(2) == list(range(1, 201)) and sup(0) == list(range(1, 201))
 
 
 def test_holder_modules_refuse_to_compute():

@@ -143,8 +143,11 @@ struct H3Wide {
   int mpwg;
   int win[4];  // bytes: 32 * K0
 };
+// Geometrically possible from 25 atoms on (below that a 48-token wave already holds two or more whole molecules and its
+// windowed mixing is cheaper); 81 .. 95 atoms would need a sixth key group for wave 1 and are refused (h3_wide_choice).
+#define H3W_MIN_ATOMS 25
 static bool h3_wide_geom(int V, H3Wide* w) {
-  if (V <= 16 * H3_NT || V > 64 * H3_NT) return false;
+  if (V < H3W_MIN_ATOMS || V > 64 * H3_NT) return false;
   w->mpwg = (64 * H3_NT) / V;
   for (int wave = 0; wave < 4; ++wave) {
     const int lo = 16 * H3_NT * wave, hi = lo + 16 * H3_NT - 1;
@@ -165,25 +168,55 @@ static size_t h3w_sf_lds_bytes(int V, int mpwg) {
   return (MV * 3 + MV * V) * 4 + MV + 16;
 }
 
-bool h3_supported(const tw_flow_desc& d, int n_atoms) {
+extern int g_debug_flags;
+static bool h3_narrow_ok(const tw_flow_desc& d, int V) {
+  FusedGeom fg;
+  return fused_geom_nt(V, H3_NT, &fg) && h3_sf_lds_bytes(d.n_heads, V, fg.mpw) <= H3_SF_LDS_MAX;
+}
+static bool h3_wide_ok(int V) {
+  H3Wide wd;
+  return h3_wide_geom(V, &wd) && h3w_sf_lds_bytes(V, wd.mpwg) <= H3_SF_LDS_MAX;
+}
+// Which layout a kernel-attention launch of n_rows conformations of V atoms takes.  Above 48 atoms only the wide one
+// exists.  From 25 to 48 atoms both do: a 48-token wave holds ONE such molecule (4 per workgroup, 52-100 % of the token
+// slots), the wide packing floor(192 / V) (V = 30: 6, 94 %) - fewer workgroups, but each pays the wide mixing (90 instead
+// of 36 MFMAs per head and k-step on the shared X^T tile, two more workgroup barriers per layer: measured 1.12-1.24x per
+// workgroup).  One workgroup occupies a CU, so what counts is ROUNDS of the chip: the wide layout is taken when
+// rounds x cost is lower (V = 30: 768 proposals -> 1 round instead of 2; 1000 proposals -> 2 rounds either way, narrow).
+// tw_debug_set_flags bit 14 (16384): never wide below 49 atoms; bit 15 (32768): always wide where it exists (A/B, tests).
+#define H3_CUS 256
+static bool h3_wide_choice(const tw_flow_desc& d, int V, int64_t n_rows, bool h1) {
+  if (d.variant != 0 || h1 || !h3_wide_ok(V)) return false;
+  if (!h3_narrow_ok(d, V)) return true;
+  if (g_debug_flags & 16384) return false;
+  if (g_debug_flags & 32768) return true;
   FusedGeom fg;
   H3Wide wd;
-  if (d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
-      h3_wide_geom(n_atoms, &wd))
-    return h3w_sf_lds_bytes(n_atoms, wd.mpwg) <= H3_SF_LDS_MAX;
+  fused_geom_nt(V, H3_NT, &fg);
+  h3_wide_geom(V, &wd);
+  if (wd.mpwg <= 4 * fg.mpw) return false;  // no denser than the narrow layout
+  const int64_t rows = n_rows > 0 ? n_rows : 1;
+  const int64_t wg_n = ((rows + fg.mpw - 1) / fg.mpw + 3) / 4, wg_w = (rows + wd.mpwg - 1) / wd.mpwg;
+  auto rounds = [](int64_t wgs_per_net) { return (8 * ((wgs_per_net + 3) / 4) + H3_CUS - 1) / H3_CUS; };
+  return 1.2 * (double)rounds(wg_w) < (double)rounds(wg_n);  // measured 1.12 (26-30 atoms) .. 1.24 (36-44): profiles/r04_layout_choice.txt
+}
+
+bool h3_supported(const tw_flow_desc& d, int n_atoms) {
+  FusedGeom fg;
+  if (d.variant == 0)
+    return d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
+           (h3_narrow_ok(d, n_atoms) || h3_wide_ok(n_atoms));
   if (d.variant == 1)  // dense softmax attention: 8 heads of 16 = one MFMA tile each; input width <= 64, or 32 + 9 + 128
                        // random Fourier position features (192 columns: the in-MLP then runs as compiled C++)
     return d.d_model == 128 && d.n_heads == 8 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 &&
            ((d.d_rff == 0 && d.d_emb + 9 <= 64) || (d.d_rff == 128 && d.d_emb == 32)) && fused_geom_nt(n_atoms, H3_NT, &fg);
-  return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
-         fused_geom_nt(n_atoms, H3_NT, &fg) &&
-         h3_sf_lds_bytes(d.n_heads, n_atoms, fg.mpw) <= H3_SF_LDS_MAX;
+  return false;
 }
 
 // the single-MFMA variant exists for the 48-token kernel-attention build (every molecule of up to 48 atoms)
 bool h1_supported(const tw_flow_desc& d, int n_atoms) {
-  H3Wide wd;
-  return d.variant == 0 && !h3_wide_geom(n_atoms, &wd) && h3_supported(d, n_atoms);
+  return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
+         h3_narrow_ok(d, n_atoms);
 }
 
 // ================================================================================================
@@ -2052,9 +2085,10 @@ struct H3Ws {
 };
 
 // molecules per block and number of blocks for n_rows conformations: wave-blocks (<= 48 atoms) or workgroup blocks (wide)
-static bool h3_layout(int V, FusedGeom* fg, H3Wide* wd, bool* wide) {
-  *wide = h3_wide_geom(V, wd);
+static bool h3_layout(const tw_flow_desc& d, int V, int64_t n_rows, bool h1, FusedGeom* fg, H3Wide* wd, bool* wide) {
+  *wide = h3_wide_choice(d, V, n_rows, h1);
   if (*wide) {
+    h3_wide_geom(V, wd);
     fg->nt = H3_NT;
     fg->mpw = wd->mpwg;
     fg->tile_mask = 0;
@@ -2063,11 +2097,20 @@ static bool h3_layout(int V, FusedGeom* fg, H3Wide* wd, bool* wide) {
   return fused_geom_nt(V, H3_NT, fg);
 }
 
-static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base) {
+static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool h1 = false, int force_layout = -1) {
   FusedGeom g;
   H3Wide wd;
   bool wide = false;
-  h3_layout(V, &g, &wd, &wide);
+  h3_layout(d, V, n_rows, h1, &g, &wd, &wide);
+  if (force_layout >= 0 && (force_layout != 0) != wide) {  // (sizing only: the other layout, where it exists)
+    wide = force_layout != 0;
+    if (wide) {
+      if (!h3_wide_geom(V, &wd)) return H3Ws{};
+      g.mpw = wd.mpwg;
+    } else if (!fused_geom_nt(V, H3_NT, &g)) {
+      return H3Ws{};
+    }
+  }
   H3Ws w;
   char* p = (char*)base;
   auto take = [&](int64_t bytes) {
@@ -2107,7 +2150,15 @@ static bool h3_windowed(const FusedGeom& fg, int V) {
 
 
 int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms) {
-  return h3_ws(d, n_rows, n_atoms, nullptr).bytes;
+  // the larger of the two layouts: which one a call takes depends on its own row count (h3_wide_choice), and callers size
+  // one workspace for calls of up to n_rows rows
+  int64_t b = 0;
+  for (int layout = 0; layout < 2; ++layout)
+    if (d.variant == 0 ? (layout ? h3_wide_ok(n_atoms) : h3_narrow_ok(d, n_atoms)) : layout == 0) {
+      const int64_t x = h3_ws(d, n_rows, n_atoms, nullptr, false, layout).bytes;
+      if (x > b) b = x;
+    }
+  return b;
 }
 
 static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg, int c, int net_sel, const float* z_other,
@@ -2134,7 +2185,8 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.sfrag_shared = shared ? 1 : 0;
   p.sf_variant_bytes = sf_variant_bytes;
   H3Wide wd{};
-  const bool wide = d.variant == 0 && h3_wide_geom(a.n_atoms, &wd);
+  const bool wide = h3_wide_choice(d, a.n_atoms, a.n_rows, h1);
+  if (wide) h3_wide_geom(a.n_atoms, &wd);
   p.d_rff = d.variant == 1 ? d.d_rff : 0;
   p.rff = p.d_rff > 0 ? a.raw + L.chain + (int64_t)c * L.coupling_size + L.rff : nullptr;
   p.windowed = (!wide && h3_windowed(fg, a.n_atoms)) ? 1 : 0;
@@ -2214,7 +2266,8 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
   const int64_t nblocks = shared ? 1 : (a.n_rows + fg.mpw - 1) / fg.mpw;
   const ScoreBasis basis = score_basis(d, L, a.raw, c);
   H3Wide wd;
-  if (h3_wide_geom(V, &wd)) {
+  if (h3_wide_choice(d, V, a.n_rows, a.h1 != 0)) {
+    h3_wide_geom(V, &wd);
     const int64_t vbw = basis.n_variants > 1 ? nblocks * 4 * d.n_heads * H3W_FRAG_HEAD : 0;
     const float* lsw = a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0);
     const size_t shmw = h3w_sf_lds_bytes(V, wd.mpwg);
@@ -2257,10 +2310,10 @@ int flow_pass_h3(const FlowArgs& a) {
   FusedGeom fg;
   H3Wide wdg;
   bool wide_layout = false;
-  TW_REQUIRE(h3_layout(a.n_atoms, &fg, &wdg, &wide_layout) && !(wide_layout && d.variant != 0),
+  TW_REQUIRE(h3_layout(d, a.n_atoms, a.n_rows, a.h1 != 0, &fg, &wdg, &wide_layout) && !(wide_layout && d.variant != 0),
              "split-fp16 path: unsupported atom count %d", a.n_atoms);
   const RawLayout L = raw_layout(d);
-  const H3Ws w = h3_ws(d, a.n_rows, a.n_atoms, a.ws);
+  const H3Ws w = h3_ws(d, a.n_rows, a.n_atoms, a.ws, a.h1 != 0);
   if (w.bytes > a.ws_bytes) {
     set_error("workspace too small: need %lld bytes, have %lld", (long long)w.bytes, (long long)a.ws_bytes);
     return TW_ERR_WORKSPACE;
@@ -2325,10 +2378,10 @@ int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, f
   FusedGeom fg;
   H3Wide wdg;
   bool wide_layout = false;
-  TW_REQUIRE(h3_layout(a.n_atoms, &fg, &wdg, &wide_layout) && !(wide_layout && d.variant != 0),
+  TW_REQUIRE(h3_layout(d, a.n_atoms, a.n_rows, a.h1 != 0, &fg, &wdg, &wide_layout) && !(wide_layout && d.variant != 0),
              "split-fp16 path: unsupported atom count %d", a.n_atoms);
   const RawLayout L = raw_layout(d);
-  const H3Ws w = h3_ws(d, a.n_rows, a.n_atoms, a.ws);
+  const H3Ws w = h3_ws(d, a.n_rows, a.n_atoms, a.ws, a.h1 != 0);
   if (w.bytes > a.ws_bytes) {
     set_error("workspace too small: need %lld bytes, have %lld", (long long)w.bytes, (long long)a.ws_bytes);
     return TW_ERR_WORKSPACE;
