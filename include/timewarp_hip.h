@@ -13,8 +13,11 @@
  *   - return value: 0 on success, a negative tw_status otherwise; tw_last_error() gives the
  *     message of the last failure on the calling thread.  No entry point allocates or frees
  *     caller memory; workspaces are caller-provided (tw_flow_workspace_bytes);
- *   - thread-safety: re-entrant across streams; no global state except the error string (tw_mh_iteration keeps
- *     one helper stream and two events per device and calling thread, created on first use).
+ *   - thread-safety: the compute entry points are re-entrant across streams.  Process-wide state: the per-thread error
+ *     string; the debug / measurement word of tw_debug_set_flags (one atomic int, read once per launch: set it while no
+ *     other thread launches); the profile hooks (tw_profile_begin / tw_profile_end, not thread-safe); the sticky
+ *     per-device non-finite flag of tw_flow_nonfinite; tw_mh_iteration keeps one helper stream and two events per device
+ *     and calling thread, created on first use.
  */
 #ifndef TIMEWARP_HIP_H
 #define TIMEWARP_HIP_H
@@ -302,7 +305,10 @@ int tw_profile_end(double* total_ms, int64_t* launches);
  * `reset` != 0 clears the flag. */
 int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
 
-/* Debug / measurement switches of the split-fp16 kernel.  0 restores normal operation.
+/* Debug / measurement switches of the split-fp16 kernel.  0 restores normal operation.  Process-wide (see the
+ * thread-safety note at the top).  Bits 0, 1, 6, 7, 11 are timing experiments that make results WRONG: the product
+ * library refuses them (TW_ERR_INVALID) and compiles their branches out; they exist in a -DTW_EXPERIMENTS build only
+ * (TW_EXPERIMENTS=1 python -m timewarp_amd.build).
  *   bit 0 (1)  no weight LDS-DMA after the prologue   } timing experiments on the compiled-C++ sections only:
  *   bit 1 (2)  no workgroup barriers                  } results become WRONG
  *   bit 2 (4)  tw_debug_netblock dumps the attention output (before the first LayerNorm) instead of the layer output
@@ -315,10 +321,14 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *   bit 6 (64), bit 7 (128) fused dense kernel, timing experiments (results WRONG): no softmax section / also no LDS round
  *              trip of q, k, v - what the attention block costs beyond its MFMAs (0.8 of 11.4 ms per 1000-proposal pass)
  *   bit 10 (1024) split-fp16 kernel: do not zero the padding tokens of a wave between sections (A/B switch; results equal)
+ *   bit 11 (2048) split-fp16 dense kernel, compiled-C++ attention: no scores / softmax / P.V (timing experiment, results WRONG)
  *   bit 12 (4096) split-fp16 kernel-attention kernel, <= 48 atoms: run the per-section build (attention / FFN asm blocks with
  *              compiled glue between them) instead of the encoder-stack statement (tools/gen_h3_enc_asm.py); same results
  *              up to the last bits.  Activation dumps (tw_debug_netblock) and bits 2 / 4 take that build anyway.
- *   bit 13 (8192) ... the encoder-stack build even with a dump buffer (profiling: only stamps outside the stack) */
+ *   bit 13 (8192) ... the encoder-stack build even with a dump buffer (profiling: only stamps outside the stack)
+ *   bit 14 (16384) molecules of 25 .. 48 atoms: never the wide layout; bit 15 (32768): the wide layout wherever it exists
+ *              (the launch code otherwise picks the layout that needs fewer rounds of the chip; same results up to the last
+ *              bits; A/B switch and tests) */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

@@ -136,3 +136,76 @@ def test_single_process_is_a_no_op():
     all_c, all_s = distributed.gather_trajectories(c, {"a": torch.arange(4.0)})
     assert len(all_c) == 1 and torch.equal(all_c[0], c) and torch.equal(all_s["a"][0], torch.arange(4.0))
     assert distributed.chain_seed(7, 3, 1, 4) == 7 + 13
+
+
+def _eight_rank_worker(rank, world, port, q, lengths, tmp):
+    """What an 8-GPU node does at start-up and at collection time, on CPU: every rank finds the library missing at the
+    same moment (one must build, seven must wait and then load the finished file), then bench.py's N > 1 leg with ragged
+    trajectory lengths, including ranks that hold nothing."""
+    import ctypes
+    import shutil
+    import sys
+    import time
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from timewarp_amd import build as B
+    from timewarp_amd import distributed
+
+    # a private copy of the build state: library and stamp absent -> stale for everybody
+    real_lib = B.LIB_PATH
+    B.LIB_DIR = tmp
+    B.LIB_PATH = os.path.join(tmp, "libtimewarp_hip.so")
+    B.STAMP_PATH = os.path.join(tmp, ".build_stamp")
+    log = os.path.join(tmp, "builders.log")
+
+    def fake_build(hipcc, verbose):  # stands in for the 45 s of hipcc: slow, and NOT atomic unless the lock works
+        with open(log, "a") as f:
+            f.write(f"{rank}\n")
+        time.sleep(0.8)
+        part = B.LIB_PATH + ".part"
+        shutil.copyfile(real_lib, part)
+        os.replace(part, B.LIB_PATH)
+        with open(B.STAMP_PATH, "w") as f:
+            f.write(B._source_digest())
+        return B.LIB_PATH
+
+    B._build_locked = fake_build
+    B.hipcc_path = lambda: "/bin/true"
+    distributed.init_from_env("gloo")
+    dist.barrier()                      # all ranks reach the build together
+    path = B.build_library()
+    lib = ctypes.CDLL(path)             # complete file, whoever built it
+    ok = lib.tw_abi_version() > 0 and not B.stale()
+    dist.barrier()
+    with open(log) as f:
+        ok = ok and len(f.read().split()) == 1   # exactly one builder
+
+    import bench
+
+    traj = torch.full((lengths[rank], 22, 3), float(rank))
+    t0 = time.perf_counter() - 0.05 * (rank + 1)
+    gathered, elapsed = bench.end_timed_region(traj, t0, "cpu", world)
+    ok = ok and len(gathered) == world and all(g.shape == (lengths[r], 22, 3) and bool((g == r).all()) for r, g in enumerate(gathered))
+    value, _, _, accepted = bench.whole_job_rates(float(rank), 1000.0, float(lengths[rank]), elapsed, "cpu")
+    ok = ok and accepted == sum(range(world)) and elapsed >= 0.05 * world
+    ok = ok and len(bench.end_timed_region.per_rank_seconds) == world
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_library_race_and_ragged_collection_gloo(tmp_path):
+    """r03 review: nothing had ever run the N = 8 shape.  Eight gloo ranks: the `.so` build race (flock in
+    timewarp_amd/build.py) and bench.end_timed_region with trajectory lengths 9 / 0 / 4 / 17 / 1 / 0 / 30 / 2."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    lengths = [9, 0, 4, 17, 1, 0, 30, 2]
+    procs = [ctx.Process(target=_eight_rank_worker, args=(r, 8, port, q, lengths, str(tmp_path))) for r in range(8)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {r: True for r in range(8)}

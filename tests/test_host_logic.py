@@ -593,3 +593,19 @@ def test_openmm_step_drives_the_callers_simulation():
     assert torch.isfinite(w[0]).all() and w[1].shape == c.shape
     with pytest.raises(ValueError):
         openmm_step(FakeSimulation(), c, None)
+
+
+def test_wrong_result_debug_switches_are_not_in_the_product_library():
+    """r03 review: tw_debug_set_flags bits 0, 1, 6, 7 (and 11) are timing experiments that make results wrong.  The
+    product build refuses them; only a -DTW_EXPERIMENTS developer build has them."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    try:
+        for bit in (1, 2, 64, 128, 2048, 1 | 8):
+            assert lib.tw_debug_set_flags(bit) != 0
+            assert b"TW_EXPERIMENTS" in lib.tw_last_error()
+        for bit in (4, 8, 16, 32, 1024, 4096, 8192, 16384, 32768):
+            assert lib.tw_debug_set_flags(bit) == 0
+    finally:
+        assert lib.tw_debug_set_flags(0) == 0

@@ -1,0 +1,53 @@
+"""RCCL self-test on one GPU (r03 review: the "nccl" backend had never executed anywhere).  A single-rank process group
+with backend "nccl" (= RCCL on ROCm) on cuda:0, and the path's two collectives forced through it: the all-gather of
+variable-length trajectories and the all-reduce of the counters (timewarp_amd/distributed.py, `force_collective=True`
+bypasses the world-of-one early return), then bench.py's timed-region epilogue.  Runs in a subprocess so the process
+group does not outlive the test.  What stays unmeasured without an 8-GPU node: xGMI transfers, per-rank device
+selection with 8 visible devices."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_SCRIPT = r'''
+import os, sys, time
+sys.path.insert(0, {root!r})
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+from timewarp_amd import distributed
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+dev = torch.device("cuda", 0)
+g = torch.Generator().manual_seed(3)
+coords = torch.randn(37, 22, 3, generator=g).to(dev)
+stats = {{"acceptance": torch.rand(37, generator=g).to(dev), "p_xy": torch.randn(37, generator=g).to(dev)}}
+all_c, all_s = distributed.gather_trajectories(coords, stats, force_collective=True)
+assert len(all_c) == 1 and torch.equal(all_c[0], coords) and all_c[0].data_ptr() != coords.data_ptr()   # went through the collective
+assert torch.equal(all_s["p_xy"][0], stats["p_xy"]) and torch.equal(all_s["acceptance"][0], stats["acceptance"])
+empty_c, _ = distributed.gather_trajectories(torch.zeros(0, 22, 3, device=dev), {{}}, force_collective=True)
+assert empty_c[0].shape == (0, 22, 3)
+assert distributed.all_reduce_counters([3.0, 1000.0, 41.0], dev, force_collective=True) == [3.0, 1000.0, 41.0]
+t = torch.ones(1 << 20, device=dev)
+dist.all_reduce(t); dist.barrier(); torch.cuda.synchronize()
+assert float(t.sum()) == float(1 << 20)
+import bench
+gathered, elapsed = bench.end_timed_region(coords, time.perf_counter() - 0.01, dev, 1)
+assert len(gathered) == 1 and elapsed >= 0.01
+dist.destroy_process_group()
+import ctypes
+maps = open("/proc/self/maps").read()
+print("RCCL_OK", "librccl" in maps)
+'''
+
+
+def test_single_rank_nccl_group_runs_the_paths_collectives():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 36500 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, "-c", _SCRIPT.format(root=root, port=port)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "RCCL_OK True" in r.stdout, r.stdout

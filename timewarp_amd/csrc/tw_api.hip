@@ -360,7 +360,12 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag) {
 }
 
 int tw_debug_set_flags(int flags) {
-  tw::g_debug_flags = flags;
+#ifndef TW_EXPERIMENTS
+  TW_REQUIRE((flags & TW_WRONG_RESULT_BITS) == 0,
+             "tw_debug_set_flags: bits %d are timing experiments that make results wrong; they exist only in a "
+             "-DTW_EXPERIMENTS build of the library", flags & TW_WRONG_RESULT_BITS);
+#endif
+  tw::g_debug_flags.store(flags, std::memory_order_relaxed);
   return TW_OK;
 }
 

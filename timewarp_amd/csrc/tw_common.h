@@ -214,7 +214,16 @@ int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms);
 int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float* scratch, hipStream_t s, bool h1 = false);
 int flow_pass_h3(const FlowArgs& a);
 int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, float* dump);
-extern int g_debug_flags;
+// tw_debug_set_flags: one process-wide word, read once per launch.  The bits that make results WRONG on purpose (timing
+// experiments: 1, 2, 64, 128, 2048) exist only in a -DTW_EXPERIMENTS build (TW_EXPERIMENTS=1 python -m timewarp_amd.build);
+// the product library refuses to set them and compiles the branches out.
+extern std::atomic<int> g_debug_flags;
+#define TW_WRONG_RESULT_BITS (1 | 2 | 64 | 128 | 2048)
+#ifdef TW_EXPERIMENTS
+#define TW_EXPERIMENT(x) (x)
+#else
+#define TW_EXPERIMENT(x) (false)
+#endif
 int nonfinite_flag(int reset, int* out);
 int profile_mark(hipStream_t s, bool begin);
 int profile_begin();

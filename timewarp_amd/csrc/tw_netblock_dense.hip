@@ -325,7 +325,7 @@ netblock_dense_kernel(const DNParams p) {
           TW_PIN();
         }
       // to the wave-private LDS tiles, [token][feature]
-      if (!(p.debug & 128))
+      if (!TW_EXPERIMENT(p.debug & 128))
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
         const int row = (16 * jt + i16) * QS + 4 * g;
@@ -339,7 +339,7 @@ netblock_dense_kernel(const DNParams p) {
       // wrote what it reads: LDS operations of a wave complete in order.  Padded keys get -inf (nn.MultiheadAttention).
       f4 oh[NT];
       float mx[NT];
-      if (p.debug & 64) {
+      if (TW_EXPERIMENT(p.debug & 64)) {
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) oh[jt] = qkv[2][jt] + qkv[0][jt] * qkv[1][jt];
       } else {

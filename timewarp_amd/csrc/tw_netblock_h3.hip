@@ -168,7 +168,6 @@ static size_t h3w_sf_lds_bytes(int V, int mpwg) {
   return (MV * 3 + MV * V) * 4 + MV + 16;
 }
 
-extern int g_debug_flags;
 static bool h3_narrow_ok(const tw_flow_desc& d, int V) {
   FusedGeom fg;
   return fused_geom_nt(V, H3_NT, &fg) && h3_sf_lds_bytes(d.n_heads, V, fg.mpw) <= H3_SF_LDS_MAX;
@@ -932,11 +931,11 @@ struct H3Pipe {
   __device__ __forceinline__ const char* stage() const { return lds + cur * H3_STAGE_BYTES; }
   __device__ __forceinline__ void advance() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (!(debug & 2)) __builtin_amdgcn_s_barrier();
+    if (!TW_EXPERIMENT(debug & 2)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const int released = cur;
     cur = (cur + 1 == H3_RING) ? 0 : cur + 1;
-    if (!(debug & 1)) fetch(released);
+    if (!TW_EXPERIMENT(debug & 1)) fetch(released);
   }
 };
 
@@ -1729,7 +1728,7 @@ netblock_h3_kernel(const H3Params p) {
             split8(va[0], va[1], vh01, vl01);
             split4(va[2], vh2, vl2);
           }
-          if (p.debug & 2048) {  // timing experiment (results WRONG): no scores / softmax / P.V - what the GEMM stages alone cost
+          if (TW_EXPERIMENT(p.debug & 2048)) {  // timing experiment (results WRONG): no scores / softmax / P.V - what the GEMM stages alone cost
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) oh[hh][jt] = qa[jt] + ka[jt] + va[jt];
           } else
@@ -2136,7 +2135,7 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool
   return w;
 }
 
-int g_debug_flags = 0;
+std::atomic<int> g_debug_flags{0};
 
 // Per-tile key windows for the mixing (gen_h3_attn_asm.py --mode=windowed): every molecule that has a token in query
 // tile 0 ends before token 32, and every molecule with a token in tile 2 starts at token 16 or later.  True for all

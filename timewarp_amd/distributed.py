@@ -30,14 +30,15 @@ def chain_seed(base_seed: int, rank: int, chain: int = 0, chains_per_rank: int =
     return base_seed + rank * chains_per_rank + chain
 
 
-def gather_trajectories(coords: torch.Tensor, extras: Dict[str, torch.Tensor] = None):
+def gather_trajectories(coords: torch.Tensor, extras: Dict[str, torch.Tensor] = None, force_collective: bool = False):
     """All-gather variable-length per-rank trajectories.
 
     coords [n_r, V, 3] on this rank's device -> list over ranks of [n_r, V, 3] (same on every rank).
     `extras`: per-state vectors [n_r] (ChainStats fields) gathered alongside.  One all_gather of the
-    lengths (8 bytes/rank) and one of the zero-padded payload."""
+    lengths (8 bytes/rank) and one of the zero-padded payload.  A world of one returns at once unless
+    `force_collective` (the RCCL self-test: the real collectives on a single-rank group)."""
     extras = extras or {}
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return [coords], {k: [v] for k, v in extras.items()}
     world = dist.get_world_size()
     dev = coords.device
@@ -63,9 +64,9 @@ def gather_trajectories(coords: torch.Tensor, extras: Dict[str, torch.Tensor] = 
     return coords_all, extras_all
 
 
-def all_reduce_counters(values: List[float], device) -> List[float]:
+def all_reduce_counters(values: List[float], device, force_collective: bool = False) -> List[float]:
     """Sum small counters (proposals, accepted, states) over ranks."""
     t = torch.tensor(values, dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.tolist()
