@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 5
+#define TW_ABI_VERSION 6
 
 typedef enum {
   TW_OK = 0,
@@ -226,6 +226,25 @@ typedef struct {
  * (the decomposition of simulation/md.py:288-413). */
 int tw_amber_energy(const tw_forcefield* ff, const float* coords, double* out_energy,
                     double* out_terms, int64_t n_rows, void* stream);
+
+/* Forces of the same potential (kJ/mol/nm, fp64): out_forces [n_rows,n_atoms,3] = -dE/dx, analytic for all five terms
+ * (the Born-radius chain rule of GBSA-OBC included); out_energy [n_rows] may be NULL.  What OpenMM's
+ * Context.getState(getForces=True) returns for the Systems of simulation/md.py:128-187; pinned against the forces of the
+ * reference's own known-answer file (simulation/testdata/implicit-2olx-traj-cpu-arrays.npz, simulation/tests/test_md.py:35-47). */
+int tw_amber_energy_forces(const tw_forcefield* ff, const float* coords, double* out_energy, double* out_forces,
+                           int64_t n_rows, void* stream);
+
+/* `n_steps` integration steps of every conformation on the device - what `openmm_step` (utils/evaluation_utils.py:439-466)
+ * does through the caller's openmm.app.Simulation, for the two integrators simulation/md.py:213-231 builds:
+ *   scheme 0  LangevinMiddleIntegrator (v += dt F/m; x += dt/2 v; v <- a v + sqrt(1 - a^2) sqrt(kT/m) N(0,1); x += dt/2 v)
+ *   scheme 1  LangevinIntegrator       (v <- a v + (1 - a)/friction F/m + sqrt(kT (1 - a^2)/m) N(0,1); x += dt v),  a = exp(-friction dt)
+ * coords (nm) / velocs (nm/ps) [n_rows,n_atoms,3] are updated in place; masses [n_atoms] in dalton; kbT in kJ/mol;
+ * friction 0 = plain leapfrog.  The Gaussian noise is counter-based on (seed, conformation, first_step + step, atom): a
+ * trajectory is reproducible for a seed but NOT the trajectory OpenMM would produce (its generator is its own).
+ * out_energy [n_rows] (may be NULL): potential energy at the positions of the last force evaluation. */
+int tw_langevin_steps(const tw_forcefield* ff, const float* masses, float* coords, float* velocs, int32_t n_steps,
+                      double timestep_ps, double friction_per_ps, double kbT, int32_t scheme, uint64_t seed, int64_t first_step,
+                      double* out_energy, int64_t n_rows, void* stream);
 
 /* The accept step of sample_with_model (utils/evaluation_utils.py:659-713) for one chain:
  *   exp_ = e_pot_y/kbT(scaled by caller) ...: exponent[s] = energy[s] + p_xy[s] - p_yx[s];

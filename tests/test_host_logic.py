@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/timewarp_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_raw_layout_matches_library_and_oracle_template():

@@ -83,7 +83,7 @@ class MHOptions(C.Structure):
     ]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 _DESC = C.POINTER(FlowDesc)
@@ -117,6 +117,9 @@ SIGNATURES = {
     "tw_centre": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
     "tw_kinetic_energy": (C.c_int, [_P, _P, _I32, _F, _P, _I64, _I32, _P]),
     "tw_amber_energy": (C.c_int, [C.POINTER(ForceField), _P, _P, _P, _I64, _P]),
+    "tw_amber_energy_forces": (C.c_int, [C.POINTER(ForceField), _P, _P, _P, _I64, _P]),
+    "tw_langevin_steps": (C.c_int, [C.POINTER(ForceField), _P, _P, _P, _I32, C.c_double, C.c_double, C.c_double, _I32,
+                                    C.c_uint64, _I64, _P, _I64, _P]),
     "tw_mh_accept": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "tw_mh_accept_chains": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _P]),
     "tw_chirality_changed": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _I32, _P]),

@@ -16,6 +16,10 @@ int launch_mh_accept(const float* energy, const float* p_xy, const float* p_yx, 
 int launch_chirality(const float* coords, const int32_t* centres, const float* ref, int n_centres, uint8_t* changed,
                      int64_t n_rows, int V, hipStream_t s);
 int amber_energy(const tw_forcefield* ff, const float* coords, double* out, double* terms, int64_t n, hipStream_t s);
+int amber_energy_forces(const tw_forcefield* ff, const float* coords, double* out_energy, double* out_forces, int64_t n, hipStream_t s);
+int langevin_steps(const tw_forcefield* ff, const float* masses, float* coords, float* velocs, int n_steps, double dt,
+                   double friction, double kbT, int scheme, unsigned long long seed, long long step0, double* out_energy,
+                   int64_t n, hipStream_t s);
 }  // namespace tw
 
 using namespace tw;
@@ -319,6 +323,24 @@ int tw_amber_energy(const tw_forcefield* ff, const float* coords, double* out_en
   TW_REQUIRE(ff && coords && out_energy, "NULL pointer argument");
   TW_REQUIRE(ff->n_atoms > 0 && ff->n_atoms <= 256, "n_atoms must be in 1..256");
   return amber_energy(ff, coords, out_energy, out_terms, n_rows, (hipStream_t)stream);
+}
+
+int tw_amber_energy_forces(const tw_forcefield* ff, const float* coords, double* out_energy, double* out_forces,
+                           int64_t n_rows, void* stream) {
+  TW_REQUIRE(ff && coords && out_forces, "NULL pointer argument");
+  TW_REQUIRE(ff->n_atoms > 0 && ff->n_atoms <= 256, "n_atoms must be in 1..256");
+  return amber_energy_forces(ff, coords, out_energy, out_forces, n_rows, (hipStream_t)stream);
+}
+
+int tw_langevin_steps(const tw_forcefield* ff, const float* masses, float* coords, float* velocs, int32_t n_steps,
+                      double timestep_ps, double friction_per_ps, double kbT, int32_t scheme, uint64_t seed, int64_t first_step,
+                      double* out_energy, int64_t n_rows, void* stream) {
+  TW_REQUIRE(ff && masses && coords && velocs, "NULL pointer argument");
+  TW_REQUIRE(ff->n_atoms > 0 && ff->n_atoms <= 256, "n_atoms must be in 1..256");
+  TW_REQUIRE(n_steps >= 0 && timestep_ps > 0.0 && friction_per_ps >= 0.0 && kbT >= 0.0 && (scheme == 0 || scheme == 1),
+             "bad integrator parameters");
+  return langevin_steps(ff, masses, coords, velocs, n_steps, timestep_ps, friction_per_ps, kbT, scheme, seed, first_step,
+                        out_energy, n_rows, (hipStream_t)stream);
 }
 
 int tw_mh_accept(const float* energy, const float* p_xy, const float* p_yx, const float* u, const float* y_coords,

@@ -82,6 +82,23 @@ class AmberPotentialEnergyTorch:
                                            _lib.stream_ptr(dev)), "tw_amber_energy")
         return out, terms
 
+    @torch.no_grad()
+    def energy_and_forces(self, coords: torch.Tensor):
+        """(E [N] kJ/mol, F [N, V, 3] kJ/mol/nm), both float64: what `Context.getState(getEnergy=True, getForces=True)` gives
+        for the System (simulation/md.py:292-298 sums the same forces per term).  Analytic forces of all five terms from the
+        HIP kernel behind `tw_amber_energy_forces`."""
+        V = self.tables.n_atoms
+        assert coords.size(-1) == 3 and coords.size(-2) == V, f"size {coords.size()} does not align with {V} particles"
+        x = _lib.require_gpu_tensor(coords.reshape(-1, V, 3), torch.float32, "coords")
+        n, dev = x.shape[0], x.device
+        ff = self._device_ff(dev)
+        e = torch.empty(n, dtype=torch.float64, device=dev)
+        f = torch.empty((n, V, 3), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().tw_amber_energy_forces(C.byref(ff.struct), x.data_ptr(), e.data_ptr(), f.data_ptr(), n,
+                                                          _lib.stream_ptr(dev)), "tw_amber_energy_forces")
+        return e, f
+
     def __call__(self, coords: torch.Tensor) -> torch.Tensor:
         e, _ = self.energy_and_terms(coords)
         return e.to(coords.dtype)[:, None]

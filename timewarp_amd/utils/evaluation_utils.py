@@ -286,7 +286,18 @@ def _mh_accept(energy, p_xy, p_yx, u, y_c=None, y_v=None, x_c=None, x_v=None):
 def openmm_step(sim, coords: torch.Tensor, velocs: Optional[torch.Tensor] = None, num_steps: int = 1, integrator=None):
     """`num_steps` integration steps of the caller's `openmm.app.Simulation` from (coords, velocs); returns the new
     (coords, velocs) as tensors like `coords`.  Same calls, in the same order, as the reference's function
-    (evaluation_utils.py:439-466) - nothing here imports OpenMM, the Simulation object is the caller's."""
+    (evaluation_utils.py:439-466) - nothing here imports OpenMM, the Simulation object is the caller's.
+    r04: a `timewarp_amd.md.LangevinDynamics` in the Simulation's place integrates on the device (analytic AMBER forces,
+    OpenMM's integration schemes, its own noise stream): no host round trip."""
+    from ..md import LangevinDynamics
+
+    if isinstance(sim, LangevinDynamics):
+        if velocs is None:
+            if integrator is None:
+                raise ValueError("either `velocs` or `integrator` needs to be specified")
+            m = sim.masses.to(coords.device)
+            velocs = torch.randn_like(coords) * (sim.kbT / m).sqrt()[None, :, None]   # setVelocitiesToTemperature
+        return sim.step(coords, velocs, num_steps)
     sim.context.setPositions(coords.detach().cpu().numpy().squeeze(0))
     if velocs is not None:
         sim.context.setVelocities(velocs.detach().cpu().numpy().squeeze(0))
@@ -345,6 +356,13 @@ class MetropolisHastingsChain:
         # OpenMM steps on the current state / on the proposal (evaluation_utils.py:556-565, 594-602, 623-626): a host
         # round trip through the caller's Simulation per iteration, so these chains take the op-by-op route
         self.sim, self.n_omm = sim, int(num_openmm_steps)
+        if sim is None and self.n_omm > 0 and (openmm_on_current or openmm_on_proposal):
+            # the reference needs the caller's Simulation for these options; with the HIP energy the chain can integrate by
+            # itself, on the device, with the reference's preset integrator (simulation/md.py:75-93, 213-231)
+            from ..energy import AmberPotentialEnergyTorch
+            from ..md import LangevinDynamics
+            if isinstance(energy_fn, AmberPotentialEnergyTorch):
+                self.sim = sim = LangevinDynamics.from_preset(energy_fn, masses)
         self.omm_current = bool(openmm_on_current) and self.n_omm > 0 and sim is not None
         self.omm_proposal = bool(openmm_on_proposal) and self.n_omm > 0 and sim is not None
         self.velocs_std = (self.kbT / self.masses.unsqueeze(0).unsqueeze(-1)).sqrt()
