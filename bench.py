@@ -55,23 +55,64 @@ PATHS = {
 CALIBRATION = dict(coords_log_scale=-7.0, velocs_log_scale=0.0)
 MH_MODE = dict(accept=True, random_velocs=True, resample_velocs=True)
 
+# --config: the default "ad" is BASELINE.json configs[1] (the headline, what the driver runs); "4aa" and "dense" are
+# configs[3] and configs[4], benched by hand for their roofline lines (profiles/r04_bench_{4aa,dense}.json).
+F_BLK_KERNEL = lambda V: 4478976 + 4608 * V     # FLOP per token per net-block, kernel attention
+F_BLK_DENSE = 3726336                           # dense softmax variant, V = 22
+CONFIGS = {
+    "ad": dict(V=22, S=1000, model="kernel", flop_sample_pass=FLOP_PER_SAMPLE_PASS, calibration=CALIBRATION,
+               workload="kernel_transformer_nvp.yaml, alanine-dipeptide (22 atoms), 1000-proposal parallel MH, "
+                        "1 chain per GPU (BASELINE.json configs[1]; configs[2] when n_gpus=8)"),
+    "4aa": dict(V=65, S=512, model="kernel", flop_sample_pass=16 * 65 * F_BLK_KERNEL(65),
+                calibration=dict(coords_log_scale=-7.5, velocs_log_scale=0.0),
+                kernel="tw::netblock_h3_kernel<3, true, false, true> (wide layout: 2 molecules per workgroup)",
+                workload="kernel_transformer_nvp.yaml, 4AA tetrapeptide NNQQ (65 atoms: the reference's own OpenMM test molecule, "
+                         "simulation/testdata/implicit-2olx-*; amber99sb-ildn + OBC tables pinned by that file), 512-proposal "
+                         "parallel MH, 1 chain per GPU (BASELINE.json configs[3], '~60 atoms'; SURVEY 8d's 4.675 TFLOP per iteration "
+                         "is the same formula at V = 60)"),
+    "dense": dict(V=22, S=1000, model="dense", flop_sample_pass=16 * 22 * F_BLK_DENSE, calibration=CALIBRATION,
+                  kernel="tw::netblock_h3_kernel<3, true, true> (split-fp16 dense-softmax kernel)",
+                  workload="transformer_nvp.yaml (dense softmax attention variant), alanine-dipeptide (22 atoms), 1000-proposal "
+                           "parallel MH, 1 chain per GPU (BASELINE.json configs[4])"),
+}
 
-def build_chain(device, seed, proposals, path):
+
+def molecule(config):
+    """(name, atom types, coordinates nm, masses, energy) of a bench configuration."""
+    from timewarp_amd import synthetic
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+
+    if CONFIGS[config]["V"] == 22:
+        types, coords, masses = synthetic.alanine_dipeptide_state()
+        return "alanine-dipeptide", types, coords, masses, AmberPotentialEnergyTorch.alanine_dipeptide()
+    # NNQQ: topology, a frame of coordinates and the elements from the reference's known-answer file (data fixture)
+    import numpy as np
+    from timewarp_amd.forcefield import ELEMENT_MASSES, amber99sbildn_obc_tables
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "energy_kat_2olx.npz"))
+    tables = amber99sbildn_obc_tables(list(z["atom_names"]), list(z["residue_names"]), list(z["residue_ids"]))
+    els = [str(e) for e in z["elements"]]
+    vocab = {"C": 0, "H": 1, "N": 2, "O": 3, "S": 4}
+    types = torch.tensor([vocab[e] for e in els])
+    masses = torch.tensor([ELEMENT_MASSES[e] for e in els], dtype=torch.float32)
+    return "NNQQ", types, torch.from_numpy(z["positions"][0]).float(), masses, AmberPotentialEnergyTorch(tables)
+
+
+def build_chain(device, seed, proposals, path, config="ad"):
     import timewarp_amd as tw
     from timewarp_amd import synthetic
     from timewarp_amd.dataloader import single_state_batch
-    from timewarp_amd.energy import AmberPotentialEnergyTorch
     from timewarp_amd.utils.evaluation_utils import MetropolisHastingsChain
 
-    model = tw.model_constructor(synthetic.kernel_transformer_nvp_config())
-    model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), base_seed=0, calibrated=True, **CALIBRATION))
+    cfg = CONFIGS[config]
+    model = tw.model_constructor(synthetic.transformer_nvp_config() if cfg["model"] == "dense" else synthetic.kernel_transformer_nvp_config())
+    model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), base_seed=0, calibrated=True, **cfg["calibration"]))
     model.execution_path = path
     model = model.to(device).eval()
-    types, coords, masses = synthetic.alanine_dipeptide_state()
+    name, types, coords, masses, energy = molecule(config)
     torch.manual_seed(seed)
     torch.cuda.manual_seed(seed)
-    energy = AmberPotentialEnergyTorch.alanine_dipeptide()
-    batch = single_state_batch("alanine-dipeptide", types, coords, torch.zeros(V_ATOMS, 3))
+    batch = single_state_batch(name, types, coords, torch.zeros(cfg["V"], 3))
     chain = MetropolisHastingsChain(batch, model, device, energy, masses, num_proposal_steps=proposals, **MH_MODE)
     prewarm(model, types, coords, device, proposals)
     return chain, model
@@ -86,11 +127,12 @@ def prewarm(model, types, coords, device, proposals):
     launches of the dominant kernel run 465-560 us before settling at ~415 us (per-dispatch trace of this bench under
     rocprofv3, profiles/README.md).  The chain's state and random streams are not touched."""
     with torch.no_grad():
+        V = coords.shape[0]
         at = types[None].to(device)
         xc = coords[None].to(device)
-        xv = torch.zeros(1, V_ATOMS, 3, device=device)
-        mk = torch.zeros(1, V_ATOMS, dtype=torch.bool, device=device)
-        z = torch.zeros(proposals, 1, V_ATOMS, 3, device=device)
+        xv = torch.zeros(1, V, 3, device=device)
+        mk = torch.zeros(1, V, dtype=torch.bool, device=device)
+        z = torch.zeros(proposals, 1, V, 3, device=device)
         for _ in range(PREWARM_PASSES):
             model.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None, edge_batch_idx=None,
                                                masked_elements=mk, num_samples=proposals, z_coords=z, z_velocs=z)
@@ -404,7 +446,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--proposals", type=int, default=S_PROPOSALS)
+    ap.add_argument("--proposals", type=int, default=None, help="proposals per MH iteration (default: the configuration's)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="ad",
+                    help="ad: BASELINE.json configs[1], the headline (default); 4aa: configs[3]; dense: configs[4]")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--sync-every", type=int, default=8,
                     help="MH iterations queued per host read-back of the accept results (sample_with_model's default)")
@@ -413,6 +457,11 @@ def main():
                     help="flow execution path: split-fp16 fused kernel (default, the headline), exact-f32 fused kernel, or the "
                          "opt-in single-MFMA fast mode h1 (not a parity path)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.proposals is None:
+        args.proposals = cfg["S"]
+    if args.config != "ad" and args.path != "h3":
+        ap.error("--config 4aa / dense are measured on the default (split-fp16) path")
 
     from timewarp_amd import _lib, distributed
 
@@ -434,7 +483,7 @@ def main():
     lib = _lib.load()
 
     pinfo = PATHS[args.path]
-    chain, model = build_chain(device, distributed.chain_seed(args.seed, rank), args.proposals, pinfo["path"])
+    chain, model = build_chain(device, distributed.chain_seed(args.seed, rank), args.proposals, pinfo["path"], args.config)
     with torch.no_grad():
         for _ in range(args.warmup):
             chain.step_deferred()
@@ -470,13 +519,13 @@ def main():
     if rank == 0:
         launches = max(int(k_launches.value), 1)
         avg_ms = k_ms.value / launches
-        flop_per_launch = FLOP_PER_SAMPLE_PASS * args.proposals / N_COUPLING
+        flop_per_launch = cfg["flop_sample_pass"] * args.proposals / N_COUPLING
         # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied), summarised in profiles/
         traffic, traffic_src = None, None
         for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest committed PMC summary
             pmc = os.path.join(ROOT, "profiles", name)
-            if args.proposals != S_PROPOSALS or traffic is not None or not os.path.exists(pmc):
+            if args.config != "ad" or args.proposals != S_PROPOSALS or traffic is not None or not os.path.exists(pmc):
                 continue
             with open(pmc) as f:
                 rec = json.load(f).get("netblock_h3_kernel" if args.path == "h3" else "netblock_kernel")
@@ -485,7 +534,9 @@ def main():
                 traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
-            "metric": "MH-accepted samples/sec (whole node), alanine-dipeptide kernel_transformer_nvp",
+            "metric": "MH-accepted samples/sec (whole node), alanine-dipeptide kernel_transformer_nvp" if args.config == "ad" else
+                      "MH-accepted samples/sec (whole node), " + ("4AA tetrapeptide kernel_transformer_nvp" if args.config == "4aa"
+                                                                   else "alanine-dipeptide transformer_nvp (dense softmax)"),
             "value": value,
             "unit": "MH-accepted samples/s",
             "n_gpus": world,
@@ -498,13 +549,13 @@ def main():
             "dtype": pinfo["dtype"],
             "data": "synthetic",
             "config": {
-                "workload": "kernel_transformer_nvp.yaml, alanine-dipeptide (22 atoms), 1000-proposal parallel MH, "
-                            "1 chain per GPU (BASELINE.json configs[1]; configs[2] when n_gpus=8)",
+                "workload": cfg["workload"],
+                "bench_config": args.config,
                 "proposals_per_step": args.proposals,
                 "chains_per_gpu": 1,
                 "weights": "name-seeded synthetic N(0,1)/sqrt(fan_in); identity flow (last out_mlp layer of every coupling net "
-                           "zeroed, SURVEY 8d's idea) with coordinate prior log-scale -7 and velocity prior log-scale 0 (NOT "
-                           "8d's -5 / -5: tuned so acceptance is non-degenerate against the stiff bonded terms)",
+                           "zeroed, SURVEY 8d's idea) with coordinate prior log-scale %g and velocity prior log-scale 0 (NOT "
+                           "8d's -5 / -5: tuned so acceptance is non-degenerate against the stiff bonded terms)" % cfg["calibration"]["coords_log_scale"],
                 "mh_mode": "accept=True, random_velocs=True, resample_velocs=True (velocity terms of the exponent cancel)",
                 "setup_prewarm": f"{PREWARM_PASSES} untimed flow passes on throw-away inputs before the warm-up steps (GPU clock ramp)",
                 "execution_path": args.path,
@@ -515,7 +566,7 @@ def main():
             "per_rank_ms": [t / args.steps * 1e3 for t in getattr(end_timed_region, "per_rank_seconds", [elapsed])],
             "roofline": {
                 "bound": "mfma",
-                "kernel": pinfo["kernel"] + " (both coupling nets of one coupling layer, all proposals)",
+                "kernel": cfg.get("kernel", pinfo["kernel"]) + " (both coupling nets of one coupling layer, all proposals)",
                 "achieved": achieved,
                 "peak": pinfo["peak"],
                 "unit": "TFLOP/s",
@@ -538,6 +589,14 @@ def main():
         if out["range_guard_fired"]:
             raise RuntimeError("bench.py: the fp16 range guard demoted the model to the exact-f32 kernels during the run; "
                                "the line would mislabel the measured path.  Re-run with --path f32")
+        if args.config != "ad":
+            # one line per extra configuration: roofline from the live HIP events; the headline's companions (attention block,
+            # other paths, CPU baseline) belong to --config ad
+            out["roofline"]["algorithmic_tflop_per_iteration"] = 2 * cfg["flop_sample_pass"] * args.proposals / 1e12
+            print(json.dumps(out), flush=True)
+            if world > 1:
+                torch.distributed.destroy_process_group()
+            return
         if args.path == "h1" and args.proposals == S_PROPOSALS:
             out["roofline"]["attention_block"] = attention_block(model, device, args.proposals, avg_ms, "h1")
         if args.path == "h3" and args.proposals == S_PROPOSALS:

@@ -86,3 +86,17 @@ def kernel_transformer_nvp_config():
                                      "normalise_kernel_values": True},
         },
     })
+
+
+def transformer_nvp_config():
+    """configs/transformer_nvp.yaml:14-25 (dense softmax attention) as a ModelConfig."""
+    from .model_configs import model_config_from_dict
+
+    return model_config_from_dict({
+        "model_type": "transformer_nvp",
+        "transformer_nvp_config": {
+            "atom_embedding_dim": 32, "transformer_hidden_dim": 128, "latent_mlp_hidden_dims": [256],
+            "num_coupling_layers": 8, "num_transformer_layers": 3,
+            "transformer_config": {"n_head": 8, "dim_feedforward": 2048, "dropout": 0},
+        },
+    })
