@@ -133,6 +133,24 @@ struct FlowArgs {
   hipStream_t stream;
   int h1 = 0;  // split-fp16 translation unit only: the single-MFMA variant (TW_PATH_FUSED_H1); `packed` is then its stream
 };
+// torch.cdist's matmul formulation (what the reference gets above 25 atoms): the row [-2 x, |x|^2, 1] times
+// the column [y, 1, |y|^2], clamp_min(0), sqrt.  The result is dominated by fp32 cancellation (|x|^2 + |y|^2 - 2 x.y with
+// terms of O(1) for distances of O(0.1)), so it is only reproducible with the SAME sequence of roundings: torch's CPU sgemm
+// accumulates the five products in k order with fused multiply-adds from zero, and the norms are x*x + y*y + z*z with every
+// product and sum rounded separately (pow(2).sum(-1)) - checked bit for bit against torch.cdist on the 60-atom golden
+// geometry (99.4 % of the 3600 entries identical, the rest one ulp).  __fmul_rn / __fadd_rn keep hipcc from contracting the
+// norm into FMAs (which alone moved a fifth of the entries, by up to 7e-4 nm).
+__device__ __forceinline__ float tw_cdist_mm(float qx, float qy, float qz, float mx, float my, float mz) {
+  const float qn = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
+  const float mn = __fadd_rn(__fadd_rn(__fmul_rn(mx, mx), __fmul_rn(my, my)), __fmul_rn(mz, mz));
+  float acc = __fmul_rn(-2.f * qx, mx);
+  acc = fmaf(-2.f * qy, my, acc);
+  acc = fmaf(-2.f * qz, mz, acc);
+  acc = __fadd_rn(acc, qn);   // fma(qn, 1, acc)
+  acc = __fadd_rn(acc, mn);   // fma(1, mn, acc)
+  return sqrtf(fmaxf(acc, 0.f));
+}
+
 // basis value for scaled distance sc: Gaussian exp(-sc^2), or sum_c coeff[c] R_c(sc^2) with the three-term recursion
 // of chebyshev_expansion (kernel_attention.py:37-66), evaluated in the same order as the reference's stacked terms
 __device__ __forceinline__ float basis_value(float sc, const float* __restrict__ coeff, int order, float coeff_mean) {

@@ -98,15 +98,7 @@ __device__ __forceinline__ float pair_distance(const float* x, int q, int m, int
     float dx = qx - mx, dy = qy - my, dz = qz - mz;
     return sqrtf(dx * dx + dy * dy + dz * dz);
   }
-  // torch.cdist matmul formulation: [-2x, |x|^2, 1] . [y, 1, |y|^2], clamp_min(0), sqrt
-  float qn = qx * qx + qy * qy + qz * qz;
-  float mn = mx * mx + my * my + mz * mz;
-  float acc = (-2.f * qx) * mx;
-  acc = fmaf(-2.f * qy, my, acc);
-  acc = fmaf(-2.f * qz, mz, acc);
-  acc = acc + qn;
-  acc = acc + mn;
-  return sqrtf(fmaxf(acc, 0.f));
+  return tw_cdist_mm(qx, qy, qz, mx, my, mz);
 }
 
 __global__ void scores_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,

@@ -187,14 +187,7 @@ __device__ __forceinline__ float pair_dist(const float* x, int q, int m, int use
     float dx = qx - mx, dy = qy - my, dz = qz - mz;
     return sqrtf(dx * dx + dy * dy + dz * dz);
   }
-  float qn = qx * qx + qy * qy + qz * qz;
-  float mn = mx * mx + my * my + mz * mz;
-  float acc = (-2.f * qx) * mx;
-  acc = fmaf(-2.f * qy, my, acc);
-  acc = fmaf(-2.f * qz, mz, acc);
-  acc = acc + qn;
-  acc = acc + mn;
-  return sqrtf(fmaxf(acc, 0.f));
+  return tw_cdist_mm(qx, qy, qz, mx, my, mz);
 }
 
 __global__ void score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,

@@ -510,14 +510,7 @@ __device__ __forceinline__ float h3_pair_dist(const float* x, int q, int m, int 
     float dx = qx - mx, dy = qy - my, dz = qz - mz;
     return sqrtf(dx * dx + dy * dy + dz * dz);
   }
-  const float qn = qx * qx + qy * qy + qz * qz;
-  const float mn = mx * mx + my * my + mz * mz;
-  float acc = (-2.f * qx) * mx;
-  acc = fmaf(-2.f * qy, my, acc);
-  acc = fmaf(-2.f * qz, mz, acc);
-  acc = acc + qn;
-  acc = acc + mn;
-  return sqrtf(fmaxf(acc, 0.f));
+  return tw_cdist_mm(qx, qy, qz, mx, my, mz);
 }
 
 // One workgroup per wave-block (all heads): distances and basis values once per (pair, head), rows normalised in LDS, then
