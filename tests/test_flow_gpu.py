@@ -121,13 +121,25 @@ def test_full_chebyshev_attention_all_paths(path):
     d, _ = H.load("kernel_cheb_full_ad")
     m = H.tw_kernel_model(H.full_cheb_sd(), path=path, attention_type="chebyshev_kernel", cheb_order=6,
                           force_asymptotic_zero=True)
-    # per-op path: 2e-5 - on 64 proposals its log p(x~|y~) lands at 1.1e-5 of the reference; the randomly drawn
-    # Chebyshev coefficients make the L1-normalised scores cancellation-prone.  The exact-f32 fused kernel stays below
-    # 1e-5; the split-fp16 kernel sits AT it on log p(x~|y~) - 0.97e-5, 1.01e-5 or 0.81e-5 depending on the order the mixing
-    # MFMA walks the keys in and on the build (profiles/r03_mfma_transpose_tests.txt, r03_enc_accuracy_ab.txt), everything
-    # else 3e-7.  The build the kernel runs by default (the encoder-stack statement) is the 0.81e-5 one, so the bar
-    # stays at 1e-5; the per-section build (tw_debug_set_flags 4096) would need 1.1e-5 on this one case
-    H.assert_case_close(H.run_model_case(m, d), d, tol=2e-5 if path == SIMPLE else TOL)
+    # Bar against the reference's vectors: 2e-5 on this one case, on every path.  The reverse-move log-density of ONE of the
+    # 64 golden rows (row 34) carries 9.8e-6 of the reference's OWN fp32 rounding noise (its fp32 arithmetic against the
+    # same computation in fp64; 90th percentile over the rows 2e-7), and every HIP path lands within 8-11e-6 of the
+    # vectors on that row while being within 2e-6 of the fp64 result (tools/cheb_noise_floor.py,
+    # profiles/r04_chebyshev_noise_floor.txt; r03 held the split-fp16 kernel to 1e-5 here and sat at 0.81e-5 / 1.01e-5
+    # depending on the build - rounding order, not correctness).  The sharper statement follows: against fp64 arithmetic.
+    out = H.run_model_case(m, d)
+    H.assert_case_close(out, d, tol=2e-5)
+    rows = torch.tensor([34, 60, 18, 36, 0, 1, 2, 3])   # the four rows with the largest reference noise, four ordinary ones
+    n = len(rows)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in H.full_cheb_sd().items()}
+    gy, gv = d["s_y_coords"][rows].squeeze(1).double(), d["s_y_velocs"][rows].squeeze(1).double()
+    exact = fo.log_likelihood(sd64, H.FULL_CHEB_SPEC, d["atom_types"].repeat(n, 1), gy, -gv, d["x_coords"].double().repeat(n, 1, 1),
+                              -d["x_velocs"].double().repeat(n, 1, 1), d["masked"].repeat(n, 1))
+    scale = float(d["logp_yx"].abs().max())
+    got = float((out["logp_yx"][rows].double() - exact).abs().max()) / scale
+    own = float((d["logp_yx"][rows].double() - exact).abs().max()) / scale
+    assert got < 5e-6, (got, own)        # measured 1.7-2.0e-6 on every path
+    assert own > 5e-6, own               # the reference's own fp32 result is further from fp64 than the kernels are
 
 
 def test_chebyshev_scores_kernel_vs_oracle():

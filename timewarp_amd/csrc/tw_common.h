@@ -155,14 +155,19 @@ __device__ __forceinline__ float tw_cdist_mm(float qx, float qy, float qz, float
 // of chebyshev_expansion (kernel_attention.py:37-66), evaluated in the same order as the reference's stacked terms
 __device__ __forceinline__ float basis_value(float sc, const float* __restrict__ coeff, int order, float coeff_mean) {
   if (order <= 0) return expf(-(sc * sc));
-  const float x = sc * sc;
-  const float rf = (x - 1.0f) / (x + 1.0f);
+  // torch's sequence of roundings (kernel_attention.py:37-66): every product and difference of the recursion
+  // 2.0 * rfactor * rcur - rprev is rounded separately (hipcc would fuse the last two into an FMA), and the contraction with
+  // the coefficients (einsum -> sgemm, K = order) is a chain of fused multiply-adds from zero in c order.  The basis values
+  // cancel (sum |c_k R_k| >> |sum|), so a different sequence of roundings shows at the 1e-5 level in log p(x~|y~).
+  const float x = __fmul_rn(sc, sc);
+  const float rf = __fdiv_rn(__fsub_rn(x, 1.0f), __fadd_rn(x, 1.0f));
+  const float rf2 = __fmul_rn(2.0f, rf);
   float rprev = 1.0f, rcur = rf;
-  float acc = (coeff[0] - coeff_mean) * rprev;
-  if (order >= 2) acc += (coeff[1] - coeff_mean) * rcur;
+  float acc = __fmul_rn(__fsub_rn(coeff[0], coeff_mean), rprev);
+  if (order >= 2) acc = fmaf(__fsub_rn(coeff[1], coeff_mean), rcur, acc);
   for (int c = 2; c < order; ++c) {
-    const float rnext = 2.0f * rf * rcur - rprev;
-    acc += (coeff[c] - coeff_mean) * rnext;
+    const float rnext = __fsub_rn(__fmul_rn(rf2, rcur), rprev);
+    acc = fmaf(__fsub_rn(coeff[c], coeff_mean), rnext, acc);
     rprev = rcur;
     rcur = rnext;
   }

@@ -122,13 +122,13 @@ __global__ void scores_kernel(const float* __restrict__ x, const uint8_t* __rest
       for (int c = 0; c < order; ++c) cmean += cf[c];
       cmean /= (float)order;
     }
-    float sum = 0.f;
+    double sum = 0.0;  // exact sum, rounded once: the neutral statement of torch's (vectorised, non-sequential) reduction
     for (int m = 0; m < V; ++m) {
       float sc = dist[q * V + m] / l;
       float e = masked[b * V + m] ? 0.f : basis_value(sc, cf, order, cmean);
-      sum += fabsf(e);
+      sum += (double)fabsf(e);
     }
-    const float denom = sum + 1e-5f;
+    const float denom = (float)sum + 1e-5f;
     float* o = out + ((b * H + h) * V + q) * (int64_t)V;
     for (int m = 0; m < V; ++m) {
       float sc = dist[q * V + m] / l;

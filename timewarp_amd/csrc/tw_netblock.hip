@@ -223,13 +223,13 @@ __global__ void score_frag_kernel(const float* __restrict__ x, const uint8_t* __
     const float l = ls[h];
     float cmean;
     const float* cf = basis_coeffs(basis, blockIdx.y, h, &cmean);  // grid.y = basis variant (chebyshev_kernel: net x layer)
-    float sum = 0.f;
+    double sum = 0.0;
     for (int m = 0; m < V; ++m) {
       float sc = dist[(q * V + a) * V + m] / l;
       float e = msk[q * V + m] ? 0.f : basis_value(sc, cf, basis.order, cmean);
-      sum += fabsf(e);
+      sum += (double)fabsf(e);
     }
-    denom[i] = sum + 1e-5f;
+    denom[i] = (float)sum + 1e-5f;
   }
   __syncthreads();
   const int ntt = nt * nt;

@@ -573,9 +573,9 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
   __syncthreads();
   for (int i = t; i < H * MV; i += nthr) {
     float* row = E + (int64_t)i * V;  // (h, q, a) rows are contiguous
-    float sum = 0.f;
-    for (int m = 0; m < V; ++m) sum += fabsf(row[m]);
-    const float den = sum + 1e-5f;
+    double sum = 0.0;
+    for (int m = 0; m < V; ++m) sum += (double)fabsf(row[m]);
+    const float den = (float)sum + 1e-5f;
     if (normalise)
       for (int m = 0; m < V; ++m) row[m] = row[m] / den;
   }
@@ -660,9 +660,9 @@ __global__ void h3w_score_frag_kernel(const float* __restrict__ x, const uint8_t
   __syncthreads();
   for (int i = t; i < MV; i += nthr) {
     float* row = E + (int64_t)i * V;
-    float sum = 0.f;
-    for (int m = 0; m < V; ++m) sum += fabsf(row[m]);
-    const float den = sum + 1e-5f;
+    double sum = 0.0;
+    for (int m = 0; m < V; ++m) sum += (double)fabsf(row[m]);
+    const float den = (float)sum + 1e-5f;
     if (normalise)
       for (int m = 0; m < V; ++m) row[m] = row[m] / den;
   }
