@@ -182,6 +182,9 @@ def attention_block(model, device, proposals, avg_launch_ms, path_name="h3"):
         "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F16_MFMA_PEAK_TFLOPS,
         "share_of_launch": share, "algorithmic_flop_per_launch": float(flop_launch),
         "attention_cycles_per_launch": att, "stamped_cycles_per_launch": total,
+        # shader clock the launch actually ran at: stamped cycles of the launch / live average launch time (the per-section
+        # build's cycle count for h3, the product build's own for h1)
+        "effective_clock_ghz": total / (avg_launch_ms * 1e6),
         "executed_over_algorithmic": ("0.75 (one fp16 MFMA per product x 1/2 from folding out_proj into values_proj per head + the "
                                       "block-diagonal mixing on K=32+16 MFMAs)" if path_name == "h1" else
                                       "2.26 (3-term fp16 split x 1/2 from folding out_proj into values_proj per head "
@@ -611,6 +614,9 @@ def main():
                 "sustained_f16_mfma_tflops": SUSTAINED_MFMA_CLOCK_GHZ * 1e9 * 1024 * 1024 / 1e12,
                 "floor_ms": floor_ms,
                 "frac": floor_ms / avg_ms,
+                "constants": "matrix_pipe_busy_clocks_per_wave (36.1 k MFMAs x 16 clocks, a property of the kernel's instruction "
+                             "stream, confirmed by SQ_VALU_MFMA_BUSY_CYCLES) and sustained_clock_ghz (a probe result) are NOT measured "
+                             "by this run; what this run measures is avg_launch_ms and attention_block.effective_clock_ghz",
                 "source": "profiles/r03_mfma_stream_probe.txt, profiles/r03_h3_sq_counters.md",
             }
         if world == 1 and args.path != "f32":

@@ -52,11 +52,14 @@ def sq(dirs, out):
         for r in counters(d):
             if "netblock_h3" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    waves = 1000.0
-    lines = ["# SQ counters, `tw::netblock_h3_kernel<3, true, ..., ENC>` (late r03 build: encoder-stack statement)", "",
-             "`bash tools/profile_round.sh` on the GPU box: four `rocprofv3 --kernel-trace --pmc <4 counters> --kernel-include-regex "
-             "netblock_h3` passes over `python tools/time_flow.py --iters 2 --paths 3` (1000-proposal alanine-dipeptide flow passes). "
-             "Averages per launch divided by the 1000 waves of a launch; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles, "
+    # waves per launch: 2 nets x ceil(rows / molecules per workgroup) workgroups x 4 waves - 1000 for the 1000-proposal
+    # alanine-dipeptide launches (250 workgroups), 2048 for NNQQ x 512 proposals on the wide layout (2 molecules per workgroup)
+    waves = 2048.0 if "4aa" in dirs[0] else 1000.0
+    names = sorted({r["Kernel_Name"] for d in dirs for r in counters(d) if "netblock_h3" in r["Kernel_Name"]})
+    lines = [f"# SQ counters, {', '.join('`' + n.split('(')[0].replace('void ', '') + '`' for n in names)}", "",
+             f"`bash tools/pmc_h3.sh` on the GPU box ({os.path.basename(dirs[0])[:-2]}): four `rocprofv3 --kernel-trace --pmc <4 counters> "
+             "--kernel-include-regex netblock_h3` passes (command in tools/pmc_h3.sh). "
+             f"Averages per launch divided by the {waves:.0f} waves of a launch; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles, "
              "SQ_VALU_MFMA_BUSY_CYCLES counts clocks.", "", "| counter | per wave |", "|---|---|"]
     vals = {k: sum(v) / len(v) / waves for k, v in acc.items()}
     for k in sorted(vals):
