@@ -526,7 +526,7 @@ def main():
         # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied), summarised in profiles/
         traffic, traffic_src = None, None
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest committed PMC summary
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest committed PMC summary
             pmc = os.path.join(ROOT, "profiles", name)
             if args.config != "ad" or args.proposals != S_PROPOSALS or traffic is not None or not os.path.exists(pmc):
                 continue

@@ -18,3 +18,5 @@ python $R/tools/summarize_profiles.py --sq $O/pmc_4aa_1 $O/pmc_4aa_2 $O/pmc_4aa_
 bash $R/tools/pmc_h3.sh dense
 python $R/tools/summarize_profiles.py --sq $O/pmc_dense_1 $O/pmc_dense_2 $O/pmc_dense_3 $O/pmc_dense_4 $O/r04_dense_sq_counters.md
 python $R/tools/profile_h3_sections.py --h1 > $O/r04_h1_sections.txt 2>&1; tail -8 $O/r04_h1_sections.txt
+# raw counter dumps are scratch: only the summaries travel back (gpurun merges at most 64 MiB)
+rm -rf $O/prof_r04_stats $O/pmc_*_[1-4] $O/pmc_traffic_fetch $O/pmc_traffic_write
