@@ -126,7 +126,7 @@ def prewarm(model, types, coords, device, proposals):
     starts with the GPU at idle clocks and the packed weights not yet resident in the Infinity Cache: the first ~80
     launches of the dominant kernel run 465-560 us before settling at ~415 us (per-dispatch trace of this bench under
     rocprofv3, profiles/README.md).  The chain's state and random streams are not touched."""
-    with torch.no_grad():
+    with torch.no_grad(), model.deferred_range_check():  # no range-flag read-back (a device sync) per pass; the chain looks at its flushes
         V = coords.shape[0]
         at = types[None].to(device)
         xc = coords[None].to(device)

@@ -107,8 +107,11 @@ int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_
 #define TW_PATH_FUSED 1  /* fused f32-MFMA net-block kernel (kernel variant, n_atoms <= 64) */
 #define TW_PATH_SIMPLE 2 /* one plain HIP kernel per reference op (all variants) */
 #define TW_PATH_FUSED_H3 3 /* fused split-fp16 kernel: every fp32 product as 3 half-precision MFMAs with fp32
-                              accumulation (2^-22 operand representation); kernel variant, n_atoms <= 48
-                              (48-token waves holding floor(48 / n_atoms) molecules); needs |activations| < 65504.
+                              accumulation (2^-22 operand representation); needs |activations| < 65504.  Kernel
+                              attention: n_atoms <= 48 in 48-token waves holding floor(48 / n_atoms) molecules, and
+                              25 .. 160 atoms (except 81 .. 95) in the "wide" layout - floor(192 / n_atoms) molecules
+                              packed over a workgroup's four waves - chosen per launch where both exist (fewer rounds of
+                              the chip); dense softmax attention: n_atoms <= 48.  tw_flow_path_supported answers per size.
                               `packed` must then point at the tw_flow_pack_h3 stream.  Never chosen by
                               TW_PATH_AUTO. */
 #define TW_PATH_FUSED_H1 4 /* "fast" mode, NOT a parity path: the same fused kernel with ONE half-precision MFMA per

@@ -783,22 +783,35 @@ def sample_on_batches(batches, model, device, openmm_potential_energy_torch, dat
             sv = torch.exp(model.velocs_prior_log_scale.detach()).to(device)
             z_c, z_v = noise.latents(1, B, V, sc, sv)
             kw = dict(atom_types=at, adj_list=adj, edge_batch_idx=ebi, masked_elements=mk)
-            y_c, y_v, _ = model.conditional_sample_with_logp(x_coords=x_c, x_velocs=x_v, num_samples=1, z_coords=z_c,
-                                                             z_velocs=z_v, **kw)
-            y_c, y_v = y_c.squeeze(0).contiguous(), y_v.squeeze(0).contiguous()
-            p_xy = model.log_likelihood(x_coords=x_c, x_velocs=x_v, y_coords=y_c, y_velocs=y_v, **kw)
-            e_kin = (compute_kinetic_energy(y_v, masses, random_velocs=random_velocs, kbT=kbT)
-                     - compute_kinetic_energy(x_v, masses, random_velocs=random_velocs, kbT=kbT))
-            e_pot = ((openmm_potential_energy_torch(y_c) - openmm_potential_energy_torch(x_c)) / kbT).view(-1)
-            assert e_kin.shape == e_pot.shape
-            energy = e_pot + e_kin
-            p_yx = model.log_likelihood(x_coords=y_c, x_velocs=(sgn * y_v).contiguous(), y_coords=x_c,
-                                        y_velocs=(sgn * x_v).contiguous(), **kw)
-            assert energy.shape == p_xy.shape and p_yx.shape == p_xy.shape
-            p_acc = torch.clamp(torch.exp(-(energy + p_xy - p_yx)), max=1.0)
-            p_xy_tr = model.log_likelihood(x_coords=x_c, x_velocs=x_v, y_coords=y_t, y_velocs=w_t, **kw)
-            p_yx_tr = model.log_likelihood(x_coords=y_t, x_velocs=(sgn * w_t).contiguous(), y_coords=x_c,
-                                           y_velocs=(sgn * x_v).contiguous(), **kw)
+
+            def model_calls():
+                y_c, y_v, _ = model.conditional_sample_with_logp(x_coords=x_c, x_velocs=x_v, num_samples=1, z_coords=z_c,
+                                                                 z_velocs=z_v, **kw)
+                y_c, y_v = y_c.squeeze(0).contiguous(), y_v.squeeze(0).contiguous()
+                p_xy = model.log_likelihood(x_coords=x_c, x_velocs=x_v, y_coords=y_c, y_velocs=y_v, **kw)
+                e_kin = (compute_kinetic_energy(y_v, masses, random_velocs=random_velocs, kbT=kbT)
+                         - compute_kinetic_energy(x_v, masses, random_velocs=random_velocs, kbT=kbT))
+                e_pot = ((openmm_potential_energy_torch(y_c) - openmm_potential_energy_torch(x_c)) / kbT).view(-1)
+                assert e_kin.shape == e_pot.shape
+                energy = e_pot + e_kin
+                p_yx = model.log_likelihood(x_coords=y_c, x_velocs=(sgn * y_v).contiguous(), y_coords=x_c,
+                                            y_velocs=(sgn * x_v).contiguous(), **kw)
+                assert energy.shape == p_xy.shape and p_yx.shape == p_xy.shape
+                p_acc = torch.clamp(torch.exp(-(energy + p_xy - p_yx)), max=1.0)
+                p_xy_tr = model.log_likelihood(x_coords=x_c, x_velocs=x_v, y_coords=y_t, y_velocs=w_t, **kw)
+                p_yx_tr = model.log_likelihood(x_coords=y_t, x_velocs=(sgn * w_t).contiguous(), y_coords=x_c,
+                                               y_velocs=(sgn * x_v).contiguous(), **kw)
+                return y_c, y_v, p_xy, p_yx, p_acc, p_xy_tr, p_yx_tr
+
+            # five model calls per batch: no range-flag read-back (a device synchronisation) after each of them - one look
+            # where the results are copied to the host anyway; on an fp16 range overflow the model is demoted and this
+            # batch's calls run again on the exact-f32 kernels with the same draws
+            with _deferred(model):
+                out = model_calls()
+            if hasattr(model, "split_fp16_overflowed") and model.split_fp16_overflowed(device):
+                model.demote_to_f32()
+                out = model_calls()
+            y_c, y_v, p_xy, p_yx, p_acc, p_xy_tr, p_yx_tr = out
             for k, t in (("acc", p_acc), ("p_xy", p_xy), ("p_yx", p_yx), ("p_xy_tr", p_xy_tr), ("p_yx_tr", p_yx_tr),
                          ("y_c", y_c), ("y_v", y_v), ("c_c", x_c), ("c_v", x_v)):
                 cols[k].append(t.cpu().numpy())
@@ -830,8 +843,11 @@ def sample_on_single_conditional(batch, model, num_samples, sim, step_width, ran
             if random_velocs:
                 sim.context.setVelocitiesToTemperature(sim.integrator.getTemperature())
                 sim.context.getState(getPositions=True, getVelocities=True)
-                x_v = (noise.randn_like(batch.atom_velocs) if noise is not None
-                       else torch.randn(batch.atom_velocs.shape, device=device)).to(device, torch.float32)
+                # drawn ON THE DEVICE (x_c has the shape and lives there): a seeded DeviceNoise owns a device generator, which
+                # cannot fill the CPU tensor batch.atom_velocs.  The reference draws torch.randn_like on the
+                # host here (evaluation_utils.py:384): seeded runs reproduce this library's stream, not the reference's
+                x_v = (noise.randn_like(x_c) if noise is not None
+                       else torch.randn(x_c.shape, device=device)).to(device, torch.float32)
             else:
                 sim.context.setVelocities(batch.atom_velocs.numpy().squeeze(0))
                 x_v = batch.atom_velocs.to(device, torch.float32)
