@@ -182,8 +182,9 @@ def handoff(next_reads, with_aux, label):
         who = f"s{S_ROT}" if "auxrot" in EXPERIMENT else "0"
         if "auxrot" in EXPERIMENT:
             h += [f"s_add_u32 s{S_ROT}, s{S_ROT}, 1", f"s_and_b32 s{S_ROT}, s{S_ROT}, 3"]
+        tail_only = [f"s_cmp_gt_u32 s{S_CNT}, 2", f"s_cbranch_scc1 .Lh3mlp_noaux_{label}_%="] if with_aux == "tail" else []
         h += [[f"s_cmp_lg_u32 %[wave], {who}",
-               f"s_cbranch_scc1 .Lh3mlp_noaux_{label}_%=",
+               f"s_cbranch_scc1 .Lh3mlp_noaux_{label}_%="] + tail_only + [
                f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
                f"s_add_u32 m0, s{S_REL}, {TILES}",
                "s_nop 0",
@@ -465,9 +466,10 @@ def generate():
     steady = (lambda kind, idx: (kind, idx) in (("A", 1), ("B", 1))) if ffn else always
     if H1:
         # two stages per chunk: a B stage's hand-off (five ahead) fetches an A stage, which carries a bias / scale block;
-        # an A stage's fetches a B stage - except in the last trips, where it is the first stage BEHIND this MLP (the
-        # out-MLP's first A stage after the last layer).  Same code for all trips, so both move the block.
-        steady = always
+        # an A stage's fetches a B stage - except in the last two trips (chunk counter <= 2), where it is a stage BEHIND this
+        # MLP (the out-MLP's first A stage after the last layer): wave 0 moves the block there only, instead of being the
+        # straggler of every barrier
+        steady = (lambda kind, idx: True if kind == "B" else "tail") if "auxalways" not in EXPERIMENT else always
 
     iotail = IOTAIL and SPREAD and not ffn
     UNITS = [(o, jt) for o in range(2) for jt in range(NT)]
