@@ -463,8 +463,8 @@ def main():
     cfg = CONFIGS[args.config]
     if args.proposals is None:
         args.proposals = cfg["S"]
-    if args.config != "ad" and args.path != "h3":
-        ap.error("--config 4aa / dense are measured on the default (split-fp16) path")
+    if (args.config == "dense" and args.path != "h3") or (args.config == "4aa" and args.path == "f32"):
+        ap.error("--config dense is measured on the default (split-fp16) path, --config 4aa on h3 or the opt-in fast mode h1")
 
     from timewarp_amd import _lib, distributed
 
@@ -569,7 +569,9 @@ def main():
             "per_rank_ms": [t / args.steps * 1e3 for t in getattr(end_timed_region, "per_rank_seconds", [elapsed])],
             "roofline": {
                 "bound": "mfma",
-                "kernel": cfg.get("kernel", pinfo["kernel"]) + " (both coupling nets of one coupling layer, all proposals)",
+                "kernel": (cfg.get("kernel", pinfo["kernel"]) if args.path == "h3" else
+                           pinfo["kernel"].replace("false, false, false, true, true>", "false, true, false, false, true>") if args.config == "4aa"
+                           else pinfo["kernel"]) + " (both coupling nets of one coupling layer, all proposals)",
                 "achieved": achieved,
                 "peak": pinfo["peak"],
                 "unit": "TFLOP/s",

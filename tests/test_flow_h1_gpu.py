@@ -93,9 +93,11 @@ def test_full_size_S1000_rows_and_round_trip():
     assert e["coords"] < BARS["s_y_coords"] and e["velocs"] < BARS["s_y_velocs"] and e["logp"] < BARS["s_logp"]
 
 
-@pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25]), (48, [48, 40])])
+@pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25]), (48, [48, 40]),
+                                    (60, [60, 51, 60, 60, 44]), (100, [100, 87, 100]), (160, [160, 131])])
 def test_ragged_batches_vs_split_fp16_kernel(V, lens):
-    """Padded atoms, several molecules per wave (windowed mixing) and one per wave (full mixing): log_likelihood of a
+    """Padded atoms, several molecules per wave (windowed mixing), one per wave (full mixing), and the wide layout (49 - 160
+    atoms: molecules packed over a workgroup's four waves, tw_h1_attns_asm.inc + the per-section in / FFN / out statements): log_likelihood of a
     ragged batch on the fast path against the split-fp16 kernel (itself held to the oracle at 1e-5) at the measured
     error; padded atoms contribute nothing (their inputs are overwritten with garbage and the result must not move)."""
     sd = H.full_kernel_sd()
@@ -118,7 +120,7 @@ def test_ragged_batches_vs_split_fp16_kernel(V, lens):
     H.assert_not_demoted(fast)
     e = H.rel_err(a, b)
     print(f"h1 vs h3, V={V}: {e:.2e}")
-    assert 0 < e < 2e-3
+    assert 0 < e < 3e-3
     yc2, yv2 = yc.clone(), yv.clone()
     yc2[mk] = 7.0
     yv2[mk] = -3.0
@@ -139,16 +141,35 @@ def test_path_selection_by_name(monkeypatch):
     monkeypatch.setenv("TW_EXECUTION_PATH", "h1")
     m = tw.model_constructor(cfg)
     assert m.execution_path == flow.PREFER_SINGLE_FP16
-    assert [m._path_for(v) for v in (1, 22, 48, 49, 60, 160, 161)] == [H1, H1, H1, H3, H3, H3, 0]
+    assert [m._path_for(v) for v in (1, 22, 48, 49, 60, 80, 90, 160, 161)] == [H1, H1, H1, H1, H1, H1, 0, H1, 0]
     desc = m.dims.to_desc()
     lib = _lib.load()
-    assert lib.tw_flow_path_supported(C.byref(desc), 22, H1) == 1 and lib.tw_flow_path_supported(C.byref(desc), 60, H1) == 0
+    assert lib.tw_flow_path_supported(C.byref(desc), 22, H1) == 1 and lib.tw_flow_path_supported(C.byref(desc), 60, H1) == 1
     assert 0 < lib.tw_flow_packed_h1_bytes(C.byref(desc)) < lib.tw_flow_packed_h3_bytes(C.byref(desc)) * 0.6
+    # the dense softmax variant has no fast kernel: the preference falls back to its split-fp16 kernel
+    monkeypatch.setenv("TW_EXECUTION_PATH", "h1")
+    md = tw.model_constructor(synthetic.transformer_nvp_config())
+    assert md._path_for(22) == H3
     # by name on an unsupported shape: an error, not a silent other kernel
     mm = H.tw_kernel_model(H.full_kernel_sd(), path=H1)
-    d, _ = H.load("kernel_full_v60")
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(1, 170, 3, generator=g) * 0.8).cuda()
     with pytest.raises(RuntimeError, match="single-MFMA path unsupported"):
-        H.run_model_case(mm, d)
+        mm.log_likelihood(atom_types=torch.zeros(1, 170, dtype=torch.long).cuda(), x_coords=x, x_velocs=x, y_coords=x, y_velocs=x,
+                          adj_list=None, edge_batch_idx=None, masked_elements=torch.zeros(1, 170, dtype=torch.bool).cuda())
+
+
+def test_wide_layout_v60_golden_measured_error():
+    """BASELINE config 3's molecule size on the fast path: the 60-atom vectors from the reference (three molecules per
+    workgroup, cross-wave mixing) at the measured error - the same class as on alanine dipeptide."""
+    d, _ = H.load("kernel_full_v60")
+    m = H.tw_kernel_model(H.full_kernel_sd(), path=H1)
+    out = H.run_model_case(m, d)
+    e = _errors(out, d)
+    print("h1 (wide layout) vs the 60-atom reference vectors:", {k: f"{v:.2e}" for k, v in e.items()})
+    for k, bar in BARS.items():
+        assert e[k] < (4e-4 if k == "loglik" else bar), (k, e[k], bar)   # measured: loglik 1.4e-4, the rest as on alanine dipeptide
+    assert e["s_y_coords"] > 1e-5
 
 
 class _Rec:

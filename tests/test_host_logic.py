@@ -120,7 +120,7 @@ def test_execution_path_from_environment(monkeypatch):
 def test_path_supported_sweep():
     """tw_flow_path_supported over 1 .. 200 atoms: the split-fp16 kernel takes 1 .. 48 (48-token waves), the wide
     layout 25 .. 160 except 81 .. 95 (wave 1 would span two molecules over eleven key tiles = six key groups, the statement
-    has five); the single-MFMA fast path 1 .. 48; the f32 kernel 1 .. 64."""
+    has five); the single-MFMA fast path the same set; the f32 kernel 1 .. 64."""
     import ctypes as C
     from timewarp_amd import _lib, synthetic
     import timewarp_amd as tw
@@ -129,7 +129,7 @@ def test_path_supported_sweep():
     desc = tw.model_constructor(synthetic.kernel_transformer_nvp_config()).dims.to_desc()
     sup = lambda path: [v for v in range(1, 201) if lib.tw_flow_path_supported(C.byref(desc), v, path) == 1]
     assert sup(3) == list(range(1, 81)) + list(range(96, 161))
-    assert sup(4) == list(range(1, 49))
+    assert sup(4) == sup(3)   # the single-MFMA fast path: wherever the split-fp16 kernel runs kernel attention
     assert sup(1) == list(range(1, 65))
     assert sup(2) == list(range(1, 201)) and sup(0) == list(range(1, 201))
 
@@ -355,11 +355,12 @@ def test_generated_asm_includes_are_current(tmp_path):
                  ["tools/gen_h3_dense_attn_asm.py"], ["tools/gen_h3_enc_asm.py"], ["tools/gen_h3_enc_asm.py", "--mode=windowed"],
                  # the single-MFMA variant (TW_PATH_FUSED_H1): tw_h1_*
                  ["tools/gen_h3_ffn_asm.py", "--shape=in", "--h1"], ["tools/gen_h3_ffn_asm.py", "--shape=out", "--h1"],
-                 ["tools/gen_h3_enc_asm.py", "--h1"], ["tools/gen_h3_enc_asm.py", "--mode=windowed", "--h1"]):
+                 ["tools/gen_h3_enc_asm.py", "--h1"], ["tools/gen_h3_enc_asm.py", "--mode=windowed", "--h1"],
+                 ["tools/gen_h3_ffn_asm.py", "--shape=ffn", "--h1"], ["tools/gen_h3_attn_wide_asm.py", "--h1"]):
         subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
                        stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 24
+    assert len(names) == 28
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n

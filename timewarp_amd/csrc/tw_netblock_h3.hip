@@ -184,8 +184,8 @@ static bool h3_wide_ok(int V) {
 // rounds x cost is lower (V = 30: 768 proposals -> 1 round instead of 2; 1000 proposals -> 2 rounds either way, narrow).
 // tw_debug_set_flags bit 14 (16384): never wide below 49 atoms; bit 15 (32768): always wide where it exists (A/B, tests).
 #define H3_CUS 256
-static bool h3_wide_choice(const tw_flow_desc& d, int V, int64_t n_rows, bool h1) {
-  if (d.variant != 0 || h1 || !h3_wide_ok(V)) return false;
+static bool h3_wide_choice(const tw_flow_desc& d, int V, int64_t n_rows, bool /*h1: both layouts exist for it too*/) {
+  if (d.variant != 0 || !h3_wide_ok(V)) return false;
   if (!h3_narrow_ok(d, V)) return true;
   if (g_debug_flags & 16384) return false;
   if (g_debug_flags & 32768) return true;
@@ -212,11 +212,8 @@ bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   return false;
 }
 
-// the single-MFMA variant exists for the 48-token kernel-attention build (every molecule of up to 48 atoms)
-bool h1_supported(const tw_flow_desc& d, int n_atoms) {
-  return d.variant == 0 && d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
-         h3_narrow_ok(d, n_atoms);
-}
+// the single-MFMA variant exists for kernel attention: the 48-token encoder-stack build and the wide layout
+bool h1_supported(const tw_flow_desc& d, int n_atoms) { return d.variant == 0 && h3_supported(d, n_atoms); }
 
 // ================================================================================================
 // packing: fp32 raw weights -> scaled fp16 hi/lo tile pairs
@@ -1110,7 +1107,7 @@ template <int NT, bool ASM, bool DENSE = false, bool WIDE = false, bool RFF = fa
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_h3_kernel(const H3Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  static_assert(!H1 || ENC, "the single-MFMA variant exists as the encoder-stack build");
+  static_assert(!H1 || ENC || WIDE, "the single-MFMA variant exists as the encoder-stack build (<= 48 atoms) and for the wide layout");
   static_assert(!WIDE || (ASM && !DENSE), "the wide layout exists for the asm build of the kernel-attention variant");
   static_assert(!RFF || DENSE, "position features belong to the dense model");
   static_assert(!ENC || (ASM && !DENSE && !WIDE && NT == 3), "the encoder-stack statement is the 48-token kernel-attention build");
@@ -1809,6 +1806,16 @@ netblock_h3_kernel(const H3Params p) {
         // wide layout (tools/gen_h3_attn_wide_asm.py): mixing against the wave's key window of the shared X^T tile
         const unsigned xt_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(lds + H3_RING * H3_STAGE_BYTES);
         const int win = __builtin_amdgcn_readfirstlane(wave == 0 ? p.win[0] : wave == 1 ? p.win[1] : wave == 2 ? p.win[2] : p.win[3]);
+        if constexpr (H1) {
+          asm volatile(
+#include "tw_h1_attns_asm.inc"
+              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
+                [win] "s"(win)
+              :
+#include "tw_h1_attns_clobbers.inc"
+          );
+        } else
         asm volatile(
 #include "tw_h3_attns_asm.inc"
             : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -1962,6 +1969,15 @@ netblock_h3_kernel(const H3Params p) {
         const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
         const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
         const int chunks = __builtin_amdgcn_readfirstlane(p.ff_chunks);
+        if constexpr (H1) {
+          asm volatile(
+#include "tw_h1_ffn_asm.inc"
+              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+              :
+#include "tw_h1_ffn_clobbers.inc"
+          );
+        } else
         asm volatile(
 #include "tw_h3_ffn_asm.inc"
             : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -2212,12 +2228,19 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   if ((prc = lim_wide.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
   if (h1) {
-    // single-MFMA build: encoder-stack statement only (section stamps are compiled into it; no activation dumps)
-    TW_REQUIRE(!wide && d.variant == 0 && d.n_layers >= 1, "single-MFMA path: unsupported configuration");
-    TW_REQUIRE(dump == nullptr || (g_debug_flags & 16), "single-MFMA path: no activation dumps (section stamps only)");
-    static LdsLimit lim_h1;
-    if ((prc = lim_h1.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, false, false, true, true>, (int)H3_LDS_BYTES))) return prc;
-    hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, false, false, true, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
+    // single-MFMA build: the encoder-stack statement (section stamps compiled in; no activation dumps), or the wide layout's
+    // per-section build
+    TW_REQUIRE(d.variant == 0 && d.n_layers >= 1, "single-MFMA path: unsupported configuration");
+    if (wide) {
+      static LdsLimit lim_h1w;
+      if ((prc = lim_h1w.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, true>, (int)H3W_LDS_BYTES))) return prc;
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+    } else {
+      TW_REQUIRE(dump == nullptr || (g_debug_flags & 16), "single-MFMA path: no activation dumps (section stamps only)");
+      static LdsLimit lim_h1;
+      if ((prc = lim_h1.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, false, false, true, true>, (int)H3_LDS_BYTES))) return prc;
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, false, false, true, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
+    }
   } else if (wide) {
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
   } else if (d.variant == 1 && d.d_rff > 0) {

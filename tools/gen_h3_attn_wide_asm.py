@@ -45,7 +45,10 @@ V_T, V_TILE, V_XTH, V_XTL, V_GN, V_TMP, V_LANE16, V_SF = 136, 144, 145, 146, 148
 YACC = lambda ot, jt: 4 * (3 * ot + jt)
 S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT, S_K2048 = 84, 85, 86, 88, 90, 92, 93, 94
 N_V, N_A = 212, 160
-N_SF_LOADS = 2 * NT * NG    # global loads per head
+# --h1: the single-MFMA "fast" variant (TW_PATH_FUSED_H1; see gen_h3_ffn_asm.py / gen_h3_attn_asm.py): hi halves only - 30
+# mixing MFMAs per k-step, ONE weight stage of eight hi tiles per k-step, a split is a pack, half the fragment loads
+H1 = "--h1" in sys.argv
+N_SF_LOADS = (1 if H1 else 2) * NT * NG    # global loads per head
 EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(",")))
 
 
@@ -76,8 +79,9 @@ def xt_reads(ks, gi):
     out = []
     for t in range(2):
         off = XT_ROW * 16 * (2 * ks + t) + GROUP_BYTES * gi
-        out += [f"ds_read_b128 {vr(XA(buf, t, 'h'))}, v{V_XTH} offset:{off}",
-                f"ds_read_b128 {vr(XA(buf, t, 'l'))}, v{V_XTL} offset:{off}"]
+        out += [f"ds_read_b128 {vr(XA(buf, t, 'h'))}, v{V_XTH} offset:{off}"]
+        if not H1:
+            out += [f"ds_read_b128 {vr(XA(buf, t, 'l'))}, v{V_XTL} offset:{off}"]
     return out
 
 
@@ -85,7 +89,8 @@ def group_mfmas(gi):
     """18 MFMAs: hi x hi, hi x lo, lo x hi for (t, jt); the six accumulator chains are issued round-robin."""
     out = []
     buf = gi % 2
-    for k, (ap, bp) in enumerate((("h", "h"), ("h", "l"), ("l", "h"))):
+    terms = (("h", "h"), ("h", "l"), ("l", "h"))
+    for k, (ap, bp) in enumerate(terms[:1] if H1 else terms):
         for t in range(2):
             for jt in range(NT):
                 out.append(mfma_mix(ACC(t, jt), XA(buf, t, ap), SF(gi, jt, bp), zero=(gi == 0 and k == 0)))
@@ -138,6 +143,8 @@ def split_ops(buf):
             hh = XM(buf, jt, "h") + 2 * t
             ll = XM(buf, jt, "l") + 2 * t
             ops += [f"v_cvt_pk_f16_f32 v{hh}, v{a}, v{a + 1}", f"v_cvt_pk_f16_f32 v{hh + 1}, v{a + 2}, v{a + 3}"]
+            if H1:
+                continue
             for r in range(4):
                 sel = "op_sel:[1,0,0] " if r % 2 else ""
                 ops.append(f"v_fma_mix_f32 v{tt[r]}, v{hh + r // 2}, -1.0, v{a + r} {sel}op_sel_hi:[1,0,0]")
@@ -150,7 +157,7 @@ def tile_reads(pair):
             f"ds_read_b128 {vr(SLOT(pair, 'l'))}, v{V_TILE} offset:{2048 * pair + 1024}"]
 
 
-def handoff(next_reads, label):
+def handoff(next_reads, label, aux_cnt=1):
     h = [
         f"s_mov_b32 s{S_REL}, s{S_OFF}",
         f"s_add_u32 s{S_OFF}, s{S_OFF}, {STAGE}",
@@ -167,7 +174,7 @@ def handoff(next_reads, label):
         # LAST head, so wave 0 moves the aux block there only
         ["s_cmp_lg_u32 %[wave], 0",
          f"s_cbranch_scc1 .Lh3atw_noaux_{label}_%=",
-         f"s_cmp_lg_u32 s{S_CNT}, 1",
+         f"s_cmp_lg_u32 s{S_CNT}, 1" if aux_cnt == 1 else f"s_cmp_gt_u32 s{S_CNT}, {aux_cnt}",
          f"s_cbranch_scc1 .Lh3atw_noaux_{label}_%=",
          f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
          f"s_add_u32 m0, s{S_REL}, {TILES}",
@@ -179,11 +186,18 @@ def handoff(next_reads, label):
     return h
 
 
-def gemm_stage(half, xm_buf, valu, next_reads, label, vm_allow=6, skip=0, tail_misc=()):
-    """One Wc stage: y[4 half + p] += tile pair p . xm[xm_buf], with `valu` woven under the MFMAs."""
+def gemm_stage(half, xm_buf, valu, next_reads, label, vm_allow=6, skip=0, tail_misc=(), aux_cnt=1):
+    """One Wc stage: y[4 half + p] += tile pair p . xm[xm_buf], with `valu` woven under the MFMAs.
+    H1: all eight output tiles of the k-step in one stage: y[2 p + j] += tile j of pair p . xm.h"""
     groups = []
     for p in range(4):
         g = []
+        if H1:
+            for j, part in enumerate(("h", "l")):
+                for jt in range(NT):
+                    g.append(mfma_gemm(YACC(2 * p + j, jt), SLOT(p, part), XM(xm_buf, jt, "h")))
+            groups.append(g)
+            continue
         for a_part, b_part in (("h", "h"), ("h", "l"), ("l", "h")):
             for jt in range(NT):
                 g.append(mfma_gemm(YACC(4 * half + p, jt), SLOT(p, a_part), XM(xm_buf, jt, b_part)))
@@ -198,7 +212,7 @@ def gemm_stage(half, xm_buf, valu, next_reads, label, vm_allow=6, skip=0, tail_m
     out.append(f"s_waitcnt vmcnt({vm_allow}) lgkmcnt(0)")
     if "nobarrier" not in EXPERIMENT:
         out.append("s_barrier")
-    out += weave(groups[2], parts[2], handoff(next_reads, label))
+    out += weave(groups[2], parts[2], handoff(next_reads, label, aux_cnt))
     out += weave(groups[3], parts[3], list(tail_misc))
     return out
 
@@ -209,9 +223,10 @@ def sf_loads():
     out = []
     for gi in range(NG):
         for jt in range(NT):
-            out += [f"global_load_dwordx4 {reg(SF(gi, jt, 'h'))}, {vr(V_SF, 2)}, off",
-                    f"global_load_dwordx4 {reg(SF(gi, jt, 'l'))}, {vr(V_SF, 2)}, off offset:1024",
-                    f"v_lshl_add_u64 {vr(V_SF, 2)}, {vr(V_SF, 2)}, 0, s[{S_K2048}:{S_K2048 + 1}]"]
+            out += [f"global_load_dwordx4 {reg(SF(gi, jt, 'h'))}, {vr(V_SF, 2)}, off"]
+            if not H1:
+                out += [f"global_load_dwordx4 {reg(SF(gi, jt, 'l'))}, {vr(V_SF, 2)}, off offset:1024"]
+            out += [f"v_lshl_add_u64 {vr(V_SF, 2)}, {vr(V_SF, 2)}, 0, s[{S_K2048}:{S_K2048 + 1}]"]
     return out
 
 
@@ -274,14 +289,18 @@ def generate():
             # are the DMAs of two hand-offs: 4 for every wave (aux blocks move in the last head only, where this is skipped)
             A(f"s_cmp_eq_u32 s{S_CNT}, 1")
             A("s_cbranch_scc1 .Lh3atw_nomix_%=")
-            A("s_waitcnt vmcnt(4)")
+            A("s_waitcnt vmcnt(2)" if H1 else "s_waitcnt vmcnt(4)")   # H1: one hand-off is newer than the fragment loads
             L += mixing_part(0)
             A(".Lh3atw_nomix_%=:")
             vm = 6
         split = split_ops(nbuf)
         nxt = (ks + 2) % 4   # k-step whose mixing runs at the start of the next step
-        L += gemm_stage(0, buf, split[:24], True, f"k{ks}a", vm_allow=vm, skip=3)
-        L += gemm_stage(1, buf, split[24:], True, f"k{ks}b", vm_allow=vm, tail_misc=xt_reads(nxt, 0))
+        if H1:
+            L += gemm_stage(0, buf, split, True, f"k{ks}", vm_allow=vm, skip=3, tail_misc=xt_reads(nxt, 0),
+                            aux_cnt=2 if ks == 3 else 1)
+        else:
+            L += gemm_stage(0, buf, split[:24], True, f"k{ks}a", vm_allow=vm, skip=3)
+            L += gemm_stage(1, buf, split[24:], True, f"k{ks}b", vm_allow=vm, tail_misc=xt_reads(nxt, 0))
         A("s_nop 1")
     A(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     A(f"s_cmp_eq_u32 s{S_CNT}, 0")
@@ -314,13 +333,13 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--out-dir="):
             out_dir = a.split("=", 1)[1]
-    base = os.path.join(out_dir, "tw_h3_attns_asm.inc")
-    out = ["// GENERATED by tools/gen_h3_attn_wide_asm.py - do not edit.  Body of the wide-layout attention asm statement."]
+    base = os.path.join(out_dir, "tw_h1_attns_asm.inc" if H1 else "tw_h3_attns_asm.inc")
+    out = [f"// GENERATED by tools/gen_h3_attn_wide_asm.py{' --h1' if H1 else ''} - do not edit.  Body of the wide-layout attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")
     clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A)] + [f'"s{i}"' for i in range(84, 96)] + \
            ['"vcc"', '"scc"', '"memory"']
-    cl = ["// GENERATED by tools/gen_h3_attn_wide_asm.py - clobber list of the wide-layout attention asm statement."]
+    cl = [f"// GENERATED by tools/gen_h3_attn_wide_asm.py{' --h1' if H1 else ''} - clobber list of the wide-layout attention asm statement."]
     for i in range(0, len(clob), 12):
         cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
     open(base.replace("_asm.inc", "_clobbers.inc"), "w").write("\n".join(cl) + "\n")

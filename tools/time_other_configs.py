@@ -24,7 +24,8 @@ xv = (torch.randn(1, V, 3, generator=g) * 0.5).cuda()
 mk = torch.zeros(1, V, dtype=torch.bool).cuda()
 flop = 16 * V * (4478976 + 4608 * V) * S
 res3 = {}
-for path, name in ((1, "fused-f32 (64-token waves)"), (3, "split-fp16, wide layout (3 molecules per workgroup)")):
+for path, name in ((1, "fused-f32 (64-token waves)"), (3, "split-fp16, wide layout (3 molecules per workgroup)"),
+                   (4, "FAST MODE (single fp16 MFMA, not a parity path), wide layout")):
     m = H.tw_kernel_model(H.full_kernel_sd(), path=path)
     res3[path] = timed(lambda: m.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None, edge_batch_idx=None,
                                                               masked_elements=mk, num_samples=S))
