@@ -403,6 +403,14 @@ def alt_path_record(device, seed, proposals, steps, sync_every, name="f32"):
                      "unit": "TFLOP/s", "frac": achieved / pinfo["peak"], "avg_launch_ms": avg_ms,
                      "launches": int(k_launches.value), "mfma_per_fp32_product": pinfo["mfma_per_product"]},
     }
+    if name == "h1":
+        pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+        if proposals == S_PROPOSALS and os.path.exists(pmc):
+            with open(pmc) as f:
+                t = json.load(f).get("netblock_h1_kernel")
+            if t:
+                rec["roofline"]["traffic"] = t["traffic_bytes_per_launch_corrected"]
+                rec["roofline"]["traffic_source"] = "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     if name == "h1" and proposals == S_PROPOSALS and not rec["range_guard_fired"]:
         rec["roofline"]["attention_block"] = attention_block(model, device, proposals, avg_ms, "h1")
         rec["measured_deviation"] = ("un-calibrated full-size weights vs the reference's vectors: 1.6e-3 (coordinates), 2.0e-4 "
@@ -531,7 +539,9 @@ def main():
             if args.config != "ad" or args.proposals != S_PROPOSALS or traffic is not None or not os.path.exists(pmc):
                 continue
             with open(pmc) as f:
-                rec = json.load(f).get("netblock_h3_kernel" if args.path == "h3" else "netblock_kernel")
+                rec = json.load(f).get({"h3": "netblock_h3_kernel", "h1": "netblock_h1_kernel"}.get(args.path, "netblock_kernel"))
+                if rec and args.path == "h3" and rec["kernel"].rstrip(")").endswith("true, true>(tw::H3Params"):
+                    rec = None  # (a summary written before the fast mode had its own key)
             if rec:
                 traffic = rec["traffic_bytes_per_launch_corrected"]
                 traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"

@@ -32,7 +32,14 @@ def traffic(d_fetch, d_write, out):
     for k, v in per.items():
         if "netblock" not in k:
             continue
-        key = "netblock_h3_kernel" if "h3" in k else ("netblock_dense_kernel" if "dense" in k else "netblock_kernel")
+        # the split-fp16 family by instantiation: <NT, ASM, DENSE, WIDE, RFF, ENC, H1> - the fast mode (H1) streams half the bytes
+        args = [a.strip() for a in k[k.index("<") + 1:k.index(">")].split(",")] if "<" in k else []
+        if "h3" in k and len(args) >= 7 and args[6] == "true":
+            key = "netblock_h1_kernel"
+        elif "h3" in k:
+            key = "netblock_h3_kernel"
+        else:
+            key = "netblock_dense_kernel" if "dense" in k else "netblock_kernel"
         f = sum(v["FETCH_SIZE"]) / max(len(v["FETCH_SIZE"]), 1)
         w = sum(v["WRITE_SIZE"]) / max(len(v["WRITE_SIZE"]), 1)
         if key in res and res[key]["dispatches"] >= len(v["FETCH_SIZE"]):
