@@ -471,8 +471,8 @@ def main():
     cfg = CONFIGS[args.config]
     if args.proposals is None:
         args.proposals = cfg["S"]
-    if (args.config == "dense" and args.path != "h3") or (args.config == "4aa" and args.path == "f32"):
-        ap.error("--config dense is measured on the default (split-fp16) path, --config 4aa on h3 or the opt-in fast mode h1")
+    if args.config in ("dense", "4aa") and args.path == "f32":
+        ap.error("--config dense / 4aa are measured on the default (split-fp16) path h3 or the opt-in fast mode h1")
 
     from timewarp_amd import _lib, distributed
 
@@ -581,6 +581,8 @@ def main():
                 "bound": "mfma",
                 "kernel": (cfg.get("kernel", pinfo["kernel"]) if args.path == "h3" else
                            pinfo["kernel"].replace("false, false, false, true, true>", "false, true, false, false, true>") if args.config == "4aa"
+                           else pinfo["kernel"].replace("true, false, false, false, true, true>", "true, true, false, false, false, true> (MLP "
+                                                        "sections single-MFMA, the softmax attention block split-fp16)") if args.config == "dense"
                            else pinfo["kernel"]) + " (both coupling nets of one coupling layer, all proposals)",
                 "achieved": achieved,
                 "peak": pinfo["peak"],

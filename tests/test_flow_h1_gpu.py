@@ -146,10 +146,12 @@ def test_path_selection_by_name(monkeypatch):
     lib = _lib.load()
     assert lib.tw_flow_path_supported(C.byref(desc), 22, H1) == 1 and lib.tw_flow_path_supported(C.byref(desc), 60, H1) == 1
     assert 0 < lib.tw_flow_packed_h1_bytes(C.byref(desc)) < lib.tw_flow_packed_h3_bytes(C.byref(desc)) * 0.6
-    # the dense softmax variant has no fast kernel: the preference falls back to its split-fp16 kernel
+    # the dense softmax variant has one too (its MLP sections; the attention block stays in split form) - but not with
+    # position features, where the preference falls back to the split-fp16 kernel
     monkeypatch.setenv("TW_EXECUTION_PATH", "h1")
     md = tw.model_constructor(synthetic.transformer_nvp_config())
-    assert md._path_for(22) == H3
+    assert md._path_for(22) == H1
+    assert H.tw_dense_model(H.full_dense_posenc_sd(), rff_dim=128, path=None)._path_for(22) == H3
     # by name on an unsupported shape: an error, not a silent other kernel
     mm = H.tw_kernel_model(H.full_kernel_sd(), path=H1)
     g = torch.Generator().manual_seed(0)
@@ -157,6 +159,52 @@ def test_path_selection_by_name(monkeypatch):
     with pytest.raises(RuntimeError, match="single-MFMA path unsupported"):
         mm.log_likelihood(atom_types=torch.zeros(1, 170, dtype=torch.long).cuda(), x_coords=x, x_velocs=x, y_coords=x, y_velocs=x,
                           adj_list=None, edge_batch_idx=None, masked_elements=torch.zeros(1, 170, dtype=torch.bool).cuda())
+
+
+@pytest.mark.parametrize("name", ["dense_full_ad", "dense_full_padded"])
+def test_dense_model_fast_mode_measured_error(name):
+    """transformer_nvp (BASELINE config 4) on the fast path: in / FFN / out sections with one fp16 MFMA per product, the
+    softmax attention block unchanged (split-fp16).  Measured against the reference's vectors: log-likelihood 5.6e-4 /
+    6.5e-4 (plain / padded), proposals 1.0-1.4e-3, log-densities 1.4e-4 / 2.0e-3 - the class of the kernel-attention fast
+    mode; and clearly not the parity kernel (> 1e-5)."""
+    d, _ = H.load(name)
+    m = H.tw_dense_model(H.full_dense_sd(), path=H1)
+    out = H.run_model_case(m, d)
+    keep = ~d["masked"][0]
+    e = {}
+    for k in BARS:
+        if k in out:
+            a, b = (out[k][:, :, keep], d[k][:, :, keep]) if k.startswith("s_y") else (out[k], d[k])
+            e[k] = H.rel_err(a, b)
+    print("h1 dense vs the reference vectors:", name, {k: f"{v:.2e}" for k, v in e.items()})
+    for k, v in e.items():
+        assert v < (2e-3 if k == "loglik" else BARS[k]), (k, v)
+    assert e["loglik"] > 1e-5
+    assert not m.demoted
+
+
+def test_dense_model_fast_mode_round_trip_and_determinism():
+    """1000 proposals of the dense flow on the fast path: the forward pass returns the latents of the reverse pass to the
+    fast mode's own error (both passes use the same arithmetic), and two calls agree bit for bit."""
+    d, _ = H.load("dense_full_ad")
+    S = 1000
+    g = torch.Generator().manual_seed(3)
+    m = H.tw_dense_model(H.full_dense_sd(), path=H1)
+    a = {k: d[k].cuda() for k in ("atom_types", "x_coords", "x_velocs", "masked")}
+    zc, zv = torch.randn(S, 1, 22, 3, generator=g).cuda(), torch.randn(S, 1, 22, 3, generator=g).cuda()
+    call = lambda: m.conditional_sample_with_logp(atom_types=a["atom_types"], x_coords=a["x_coords"], x_velocs=a["x_velocs"],
+                                                  adj_list=None, edge_batch_idx=None, masked_elements=a["masked"],
+                                                  num_samples=S, z_coords=zc, z_velocs=zv)
+    yc, yv, lp = call()
+    yc2, yv2, lp2 = call()
+    assert torch.equal(yc, yc2) and torch.equal(yv, yv2) and torch.equal(lp, lp2)
+    assert torch.isfinite(yc).all() and torch.isfinite(lp).all()
+    rep = lambda t: t.expand(S, *t.shape[1:]).contiguous()
+    ll = m.log_likelihood(atom_types=rep(a["atom_types"]), x_coords=rep(a["x_coords"]), x_velocs=rep(a["x_velocs"]),
+                          y_coords=yc[:, 0], y_velocs=yv[:, 0], adj_list=None, edge_batch_idx=None, masked_elements=rep(a["masked"]))
+    err = float((ll - lp[:, 0]).abs().max() / lp.abs().max())
+    print("dense fast mode: |log p(forward) - log p(reverse)| / max |log p| =", f"{err:.2e}")
+    assert err < 5e-3
 
 
 def test_wide_layout_v60_golden_measured_error():

@@ -92,7 +92,7 @@ struct H3Geom {
   int64_t net_stride_bytes;
 };
 
-// h1: the single-MFMA stream (TW_PATH_FUSED_H1, kernel attention only).  A stage's four 2 KiB pair slots hold EIGHT fp16 hi
+// h1: the single-MFMA stream (TW_PATH_FUSED_H1).  A stage's four 2 KiB pair slots hold EIGHT fp16 hi
 // tiles (tile t at 1 KiB t) instead of four hi / lo pairs, so every chunked MLP is one A stage + one B stage per chunk and
 // the attention GEMM one stage per (head, k-step):
 //   IN   : hid_chunks x { A: [W0 chunk: tile 2 o + ks (4 tiles) + aux]          B: [W2 chunk: tile ot] }
@@ -108,6 +108,8 @@ static H3Geom h3_geom(const tw_flow_desc& d, bool h1 = false) {
   const int64_t att_stages = d.variant == 1 ? 4LL * g.H : 8LL * g.H;
   g.in_a_stages = (d.variant == 1 && d.d_rff > 0) ? 3 : 1;
   g.stages = (int64_t)(g.in_a_stages + 2) * g.hid_chunks + (int64_t)g.L * (att_stages + 4LL * g.ff_chunks) + 3LL * g.hid_chunks;
+  // (dense model: its attention stages keep the split form - q_h k_h v_h and the out_proj half-steps, 4 H stages per layer,
+  //  which happens to be the count of the single-MFMA folded attention too; only the MLP sections change)
   if (h1) g.stages = 2LL * g.hid_chunks + (int64_t)g.L * (4LL * g.H + 2LL * g.ff_chunks) + 2LL * g.hid_chunks;
   int64_t o = 0;
   g.side_in2b = o; o += 128;
@@ -212,8 +214,11 @@ bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   return false;
 }
 
-// the single-MFMA variant exists for kernel attention: the 48-token encoder-stack build and the wide layout
-bool h1_supported(const tw_flow_desc& d, int n_atoms) { return d.variant == 0 && h3_supported(d, n_atoms); }
+// the single-MFMA variant exists for kernel attention (the 48-token encoder-stack build and the wide layout) and for the dense
+// model without position features (in / FFN / out sections single-MFMA, the softmax attention block in split form)
+bool h1_supported(const tw_flow_desc& d, int n_atoms) {
+  return (d.variant == 0 || (d.variant == 1 && d.d_rff == 0)) && h3_supported(d, n_atoms);
+}
 
 // ================================================================================================
 // packing: fp32 raw weights -> scaled fp16 hi/lo tile pairs
@@ -313,7 +318,8 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
                     hipStream_t s, bool h1) {
   const RawLayout L = raw_layout(d);
   const H3Geom g = h3_geom(d, h1);
-  TW_REQUIRE(!h1 || d.variant == 0, "the single-MFMA stream exists for the kernel-attention variant");
+  TW_REQUIRE(!h1 || d.variant == 0 || (d.variant == 1 && d.d_rff == 0),
+             "the single-MFMA stream exists for kernel attention and for the dense model without position features");
   TW_HIP_CHECK(hipMemsetAsync(packed, 0, h3_packed_bytes(d, h1), s));
   auto absmax = [&](const float* src, int64_t n, float* up, float* down) -> int {
     TW_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float), s));
@@ -323,12 +329,16 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
     TW_LAUNCH_CHECK();
     return TW_OK;
   };
-  auto block = [&](const float* src, int ld, int rows_valid, int cols_valid, int row0, int col0, int n_ot, int n_ks,
-                   const float* up, char* dst) -> int {
+  auto block_fmt = [&](const float* src, int ld, int rows_valid, int cols_valid, int row0, int col0, int n_ot, int n_ks,
+                       const float* up, char* dst, int hi_only) -> int {
     hipLaunchKernelGGL(h3_pack_block_kernel, dim3(n_ot, n_ks), dim3(64), 0, s, src, ld, rows_valid, cols_valid, row0,
-                       col0, n_ks, up, dst, h1 ? 1 : 0);
+                       col0, n_ks, up, dst, hi_only);
     TW_LAUNCH_CHECK();
     return TW_OK;
+  };
+  auto block = [&](const float* src, int ld, int rows_valid, int cols_valid, int row0, int col0, int n_ot, int n_ks,
+                   const float* up, char* dst) -> int {
+    return block_fmt(src, ld, rows_valid, cols_valid, row0, col0, n_ot, n_ks, up, dst, h1 ? 1 : 0);
   };
   auto copy = [&](const float* src, int n, float* dst, int n_pad) -> int {
     hipLaunchKernelGGL(h3_copy_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, s, src, n, dst, n_pad);
@@ -414,10 +424,11 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
             for (size_t i = 0; i < order.size(); ++i) {
               char* a = st + (int64_t)i * H3_STAGE_BYTES;
               const int kind = order[i].first, idx = order[i].second;
+              // (hi / lo pairs also in the single-MFMA stream: the softmax attention block stays in split form there)
               if (pass == 0 && kind < 3) {
-                if ((rc = block(lb + L.layer.in_w, 128, 384, 128, kind * 128 + 16 * idx, 0, 1, 4, up, a))) return rc;
+                if ((rc = block_fmt(lb + L.layer.in_w, 128, 384, 128, kind * 128 + 16 * idx, 0, 1, 4, up, a, 0))) return rc;
               } else if (pass == 1 && kind == 3) {
-                if ((rc = block(lb + L.layer.out_w, 128, 128, 128, 64 * (idx % 2), 32 * (idx / 2), 4, 1, up, a))) return rc;
+                if ((rc = block_fmt(lb + L.layer.out_w, 128, 128, 128, 64 * (idx % 2), 32 * (idx / 2), 4, 1, up, a, 0))) return rc;
               }
             }
           }
@@ -1107,7 +1118,9 @@ template <int NT, bool ASM, bool DENSE = false, bool WIDE = false, bool RFF = fa
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_h3_kernel(const H3Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  static_assert(!H1 || ENC || WIDE, "the single-MFMA variant exists as the encoder-stack build (<= 48 atoms) and for the wide layout");
+  static_assert(!H1 || ENC || WIDE || (DENSE && ASM && !RFF),
+                "the single-MFMA variant exists as the encoder-stack build (<= 48 atoms), for the wide layout, and - MLP sections "
+                "only, the softmax attention block stays in split form - for the dense model");
   static_assert(!WIDE || (ASM && !DENSE), "the wide layout exists for the asm build of the kernel-attention variant");
   static_assert(!RFF || DENSE, "position features belong to the dense model");
   static_assert(!ENC || (ASM && !DENSE && !WIDE && NT == 3), "the encoder-stack statement is the 48-token kernel-attention build");
@@ -2230,8 +2243,12 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   if (h1) {
     // single-MFMA build: the encoder-stack statement (section stamps compiled in; no activation dumps), or the wide layout's
     // per-section build
-    TW_REQUIRE(d.variant == 0 && d.n_layers >= 1, "single-MFMA path: unsupported configuration");
-    if (wide) {
+    TW_REQUIRE(h1_supported(d, a.n_atoms) && d.n_layers >= 1, "single-MFMA path: unsupported configuration");
+    if (d.variant == 1) {
+      static LdsLimit lim_h1d;
+      if ((prc = lim_h1d.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, false, false, true>, (int)H3D_LDS_BYTES))) return prc;
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, false, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
+    } else if (wide) {
       static LdsLimit lim_h1w;
       if ((prc = lim_h1w.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, true>, (int)H3W_LDS_BYTES))) return prc;
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
