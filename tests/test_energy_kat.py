@@ -39,27 +39,29 @@ def more():
 
 def old_openmm_improper(t, z):
     """Two of the extra files (testdata/output, testdata/smallest_molecule) were written by OpenMM 7.4.1 (their PDB headers),
-    which places the C-terminal carboxylate improper X-O2-C-O2 as (CA, OXT, C, O); 7.6 - which wrote the simulation/testdata
-    files - and the 7.7 the reference pins give (CA, O, C, OXT), the ordering of the tables.  Each file is compared with the
-    ordering of the OpenMM that wrote it (with the other one its carboxylate forces are off by up to 220 kJ/mol/nm; with
-    its own, k = 10.5000 kcal/mol comes out of either group of files: tools/pin_energy/refit_asn.py)."""
-    import dataclasses
+    which walks an sp2 centre's neighbours in the iteration order of a Python SET of atom indices (by index mod 8 for three
+    neighbours) when it places the AMBER impropers; 7.6 - which wrote the simulation/testdata files - and the 7.7 the
+    reference pins walk them sorted, the ordering of the tables.  On this peptide the only improper that changes is the
+    C-terminal carboxylate, (CA, OXT, C, O) instead of (CA, O, C, OXT).  Each file is compared with the ordering of the OpenMM
+    that wrote it (with the other one its carboxylate forces are off by up to 220 kJ/mol/nm).  r04: the set-order rule
+    (forcefield._improper, `improper_neighbour_order="pyset"`) replaces the hand-written swap - the protein file below, 691
+    atoms with 62 impropers of eight kinds, is what shows that it IS the rule."""
+    from timewarp_amd.forcefield import amber99sbildn_obc_tables
 
     names, rid = list(z["atom_names"]), list(z["residue_ids"])
+    told = amber99sbildn_obc_tables(names, list(z["residue_names"]), rid, improper_neighbour_order="pyset")
     idx = {(r, n): i for i, (n, r) in enumerate(zip(names, rid))}
     C, CA, O, OXT = (idx[(4, n)] for n in ("C", "CA", "O", "OXT"))
-    ti = t.torsion_idx.copy()
-    hit = [i for i, q in enumerate(ti.tolist()) if q[2] == C and set(q) == {C, CA, O, OXT}]
-    assert len(hit) == 1 and tuple(ti[hit[0]]) == (CA, O, C, OXT)
-    ti[hit[0]] = (CA, OXT, C, O)
-    return dataclasses.replace(t, torsion_idx=ti)
+    changed = [(tuple(a), tuple(b)) for a, b in zip(t.torsion_idx.tolist(), told.torsion_idx.tolist()) if a != b]
+    assert changed == [((CA, O, C, OXT), (CA, OXT, C, O))] and np.array_equal(t.torsion_par, told.torsion_par)
+    return told
 
 
-def numerical_forces(tables, x, h=1e-4):
-    """central differences of the C oracle in float64-accurate coordinates: x [F,V,3] -> [F,V,3]"""
+def numerical_forces(tables, x, h=1e-4, atoms=None):
+    """central differences of the C oracle in float64-accurate coordinates: x [F,V,3] -> [F,V,3] (rows of `atoms` only)"""
     F, V, _ = x.shape
     out = np.zeros((F, V, 3))
-    for a in range(V):
+    for a in (range(V) if atoms is None else atoms):
         for c in range(3):
             xp, xm = x.copy(), x.copy()
             xp[:, a, c] += h
@@ -137,6 +139,81 @@ def test_everything_but_the_fitted_torsions_is_pinned():
     untouched = [a for a in range(65) if a not in touched]
     assert np.sqrt(((f - ref)[:, untouched] ** 2).mean()) < FORCE_RMS_TOL
     assert np.sqrt(((f - ref)[:, touched] ** 2).mean()) > 10 * FORCE_RMS_TOL  # the fitted terms do matter there
+
+
+def protein():
+    return np.load(H.GOLDEN + "/energy_kat_1hgv.npz")
+
+
+def protein_tables(z, order="pyset"):
+    from timewarp_amd.forcefield import amber99sbildn_obc_tables
+
+    return amber99sbildn_obc_tables(list(z["atom_names"]), list(z["residue_names"]), list(z["residue_ids"]),
+                                    improper_neighbour_order=order)
+
+
+def test_protein_with_18_residue_types_known_answers():
+    """The reference's SECOND OpenMM known-answer file (testdata/output/1hgv-traj-arrays.npz: a 46-residue, 691-atom protein;
+    NMET ... CGLY with ALA ARG ASN ASP GLN GLU GLY ILE LEU LYS PHE PRO SER THR TRP TYR VAL in between; positions, energies
+    and forces of 140 frames, 12 of the odd ones committed as tests/golden/energy_kat_1hgv.npz by tools/pin_energy/pin_1hgv.py).
+    The ff94 charges, parm99 / ff99SB parameters, the improper placement and the OBC radii of all these residues were written
+    down and met this file at its float32 noise as they stood; the ILDN side-chain series of ILE / LEU / ASP were fitted to the
+    EVEN frames (fit_ildn_1hgv.py), the asparagine series come from the other molecule.  Here: ABSOLUTE energies of the
+    held-out frames to 6e-3 kJ/mol of -2490 (measured -0.0014 +- 0.0016 in float64; the oracle reads the float32 positions),
+    forces on one residue of every type by central differences."""
+    z = protein()
+    t = protein_tables(z)
+    assert t.n_atoms == 691 and abs(t.atom_par[:, 0].sum() - 2.0) < 1e-9   # net charge +2: NMET, 3 LYS, ARG / ASP, GLU, CGLY
+    e, _ = H.oracle_energy(t, z["positions"])
+    d = e - z["energies"]
+    assert np.abs(d).max() < 6e-3 and d.std() < 2.5e-3, (np.abs(d).max(), d.std())
+    names, res, rid = list(z["atom_names"]), list(z["residue_names"]), list(z["residue_ids"])
+    first = {}
+    for r, i in zip(res, rid):
+        first.setdefault(("N" if i == rid[0] else "C" if i == rid[-1] else "") + r, i)
+    assert len(first) == 19   # 17 residue types inside the chain + the NH3+ methionine + the COO- glycine
+    # (central differences step over the 2 nm cutoff when a partner sits within h of it: such atoms are left out - 5 of 156)
+    x5, h = z["positions"][5].astype(np.float64), 2e-5
+    near_cutoff = lambda a: np.abs(np.linalg.norm(x5 - x5[a], axis=1) - t.cutoff).min() < 3 * h
+    atoms = [a for a in range(691) if rid[a] in set(first.values()) and not names[a].startswith("H") and not near_cutoff(a)]
+    assert len(atoms) > 145 and {res[a] for a in atoms} == set(res)
+    f = numerical_forces(t, x5[None], h=h, atoms=atoms)[:, atoms]
+    ref = z["forces"][[5]].astype(np.float64)[:, atoms]
+    assert np.sqrt(((f - ref) ** 2).mean()) < FORCE_RMS_TOL, np.sqrt(((f - ref) ** 2).mean())
+    assert np.allclose(f, ref, rtol=0.05, atol=1e-2)
+    # not vacuous: with the neighbour order of the later OpenMM versions this 7.4.1 file is missed (19 impropers move)
+    e76, _ = H.oracle_energy(protein_tables(z, "sorted"), z["positions"])
+    assert np.abs(e76 - z["energies"]).max() > 0.1
+
+
+@pytest.mark.gpu
+def test_hip_kernels_on_segments_of_the_protein():
+    """The HIP energy / force kernels hold one conformation per wave in LDS (molecules up to ~240 atoms), so the 691-atom file
+    cannot run through them whole.  Their arithmetic is pinned on the peptide files; what the protein adds is parameter
+    TABLES of sixteen more residue types.  This test runs the kernels on those tables: five overlapping segments of the chain
+    (cut at peptide bonds, 10 residues each, every residue type in at least one), energies and analytic forces against the C
+    oracle on the same tables and coordinates."""
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.forcefield import amber99sbildn_obc_tables
+
+    z = protein()
+    names, res, rid = list(z["atom_names"]), list(z["residue_names"]), list(z["residue_ids"])
+    order = list(dict.fromkeys(rid))
+    seen = set()
+    for start in (0, 9, 18, 27, 36):
+        keep_res = set(order[start:start + 10])
+        sel = [a for a in range(691) if rid[a] in keep_res]
+        assert len(sel) < 240
+        seen |= {res[a] for a in sel}
+        t = amber99sbildn_obc_tables([names[a] for a in sel], [res[a] for a in sel], [rid[a] for a in sel])
+        x = z["positions"][:, sel]
+        e_ref, _ = H.oracle_energy(t, x)
+        en, f = AmberPotentialEnergyTorch(t).energy_and_forces(torch.from_numpy(x).cuda())
+        assert np.allclose(en.cpu().numpy(), e_ref, rtol=0, atol=1e-6 * np.abs(e_ref).max())
+        atoms = list(range(0, len(sel), 7))
+        fn = numerical_forces(t, x[[3]].astype(np.float64), atoms=atoms)[:, atoms]
+        assert np.allclose(f.cpu().numpy()[[3]][:, atoms], fn, rtol=1e-4, atol=2e-2), np.abs(f.cpu().numpy()[[3]][:, atoms] - fn).max()
+    assert len(seen) == 18
 
 
 @pytest.mark.gpu

@@ -6,10 +6,11 @@ The reference never holds these numbers itself: `simulation/md.py:150-173` asks 
 * `tables_from_openmm_system(system)` -- reads the tables out of an `openmm.System` exactly as the
   scripts build it (the drop-in route; needs OpenMM importable, which it is not in this image);
 * `amber99sbildn_obc_tables(...)` / `tables_from_pdb(path)` / `alanine_dipeptide_amber99sb()` -- the published
-  parm99 / ff99SB / ff94-charge / OBC numbers for a small residue set (ACE, ALA, NME, ASN, GLN), written out here so
-  the whole MH path runs without OpenMM.  Pinned against the reference's own OpenMM known-answer file (40 frames of
-  NNQQ with energies and forces, simulation/tests/test_md.py:35-83); see the section comment below for what that
-  covers and for the two asparagine torsion series that had to be fitted.
+  parm99 / ff99SB / ff94-charge / OBC numbers for ACE, NME and 18 of the 20 amino acids (not HIS, CYS), written out here so
+  the whole MH path runs without OpenMM.  Pinned against the reference's own OpenMM known-answer files: 40 (+ 342) frames
+  of the peptide NNQQ (simulation/tests/test_md.py:35-83) and 140 frames of a 691-atom protein, energies and forces; see
+  the section comments below for what they cover and for the side-chain torsion series of ASN / ILE / LEU / ASP
+  (ff99SB-ILDN's) that had to be fitted.
 
 Units: nm, kJ/mol, elementary charge, radians.
 """
@@ -96,12 +97,22 @@ class DeviceForceField:
 # parm99: Rmin/2 (Angstrom), eps (kcal/mol)
 _LJ = {"H": (0.6000, 0.0157), "HC": (1.4870, 0.0157), "H1": (1.3870, 0.0157), "HP": (1.1000, 0.0157),
        "CT": (1.9080, 0.1094), "C": (1.9080, 0.0860), "N": (1.8240, 0.1700), "N3": (1.8240, 0.1700),
-       "O": (1.6612, 0.2100), "O2": (1.6612, 0.2100)}
+       "O": (1.6612, 0.2100), "O2": (1.6612, 0.2100),
+       # r04: the types of the other residues (pinned by the 691-atom protein file, see RESIDUES below)
+       "HO": (0.0000, 0.0000), "HA": (1.4590, 0.0150), "H4": (1.4090, 0.0150), "CA": (1.9080, 0.0860), "C*": (1.9080, 0.0860),
+       "CW": (1.9080, 0.0860), "CB": (1.9080, 0.0860), "CN": (1.9080, 0.0860), "N2": (1.8240, 0.1700), "NA": (1.8240, 0.1700),
+       "OH": (1.7210, 0.2104), "S": (2.0000, 0.2500)}
 # parm99 bonds: k (kcal/mol/A^2, E = k (r-r0)^2), r0 (A)
 _BOND = {("CT", "HC"): (340.0, 1.090), ("CT", "H1"): (340.0, 1.090), ("CT", "HP"): (340.0, 1.090),
          ("C", "CT"): (317.0, 1.522), ("C", "O"): (570.0, 1.229), ("C", "N"): (490.0, 1.335),
          ("H", "N"): (434.0, 1.010), ("CT", "N"): (337.0, 1.449), ("CT", "CT"): (310.0, 1.526),
-         ("H", "N3"): (434.0, 1.010), ("CT", "N3"): (367.0, 1.471), ("C", "O2"): (656.0, 1.250)}
+         ("H", "N3"): (434.0, 1.010), ("CT", "N3"): (367.0, 1.471), ("C", "O2"): (656.0, 1.250),
+         ("C", "CA"): (469.0, 1.409), ("C", "OH"): (450.0, 1.364), ("CA", "CA"): (469.0, 1.400), ("CA", "CB"): (469.0, 1.404),
+         ("CA", "CN"): (469.0, 1.400), ("CA", "CT"): (317.0, 1.510), ("CA", "HA"): (367.0, 1.080), ("CA", "N2"): (481.0, 1.340),
+         ("C*", "CB"): (388.0, 1.459), ("CB", "CN"): (447.0, 1.419), ("C*", "CW"): (546.0, 1.352), ("C*", "CT"): (317.0, 1.495),
+         ("CN", "NA"): (428.0, 1.380), ("CW", "H4"): (367.0, 1.080), ("CW", "NA"): (427.0, 1.381), ("CT", "N2"): (337.0, 1.463),
+         ("CT", "OH"): (320.0, 1.410), ("CT", "S"): (227.0, 1.810), ("H", "N2"): (434.0, 1.010), ("H", "NA"): (434.0, 1.010),
+         ("HO", "OH"): (553.0, 0.960)}
 # parm99 angles: k (kcal/mol/rad^2, E = k (t-t0)^2), theta0 (deg); keyed (a, centre, c) with a <= c
 _ANGLE = {("HC", "CT", "HC"): (35.0, 109.50), ("H1", "CT", "H1"): (35.0, 109.50), ("HP", "CT", "HP"): (35.0, 109.50),
           ("CT", "CT", "HC"): (50.0, 109.50), ("CT", "CT", "H1"): (50.0, 109.50), ("CT", "CT", "HP"): (50.0, 109.50),
@@ -113,7 +124,26 @@ _ANGLE = {("HC", "CT", "HC"): (35.0, 109.50), ("H1", "CT", "H1"): (35.0, 109.50)
           ("H", "N", "H"): (35.0, 120.00),
           ("H1", "CT", "N"): (50.0, 109.50), ("CT", "CT", "N"): (80.0, 109.70), ("C", "CT", "N"): (63.0, 110.10),
           ("H", "N3", "H"): (35.0, 109.50), ("CT", "N3", "H"): (50.0, 109.50), ("CT", "CT", "N3"): (80.0, 111.20),
-          ("C", "CT", "N3"): (80.0, 111.20), ("HP", "CT", "N3"): (50.0, 109.50)}
+          ("C", "CT", "N3"): (80.0, 111.20), ("HP", "CT", "N3"): (50.0, 109.50),
+          # aromatic side chains
+          ("CA", "CT", "CT"): (63.0, 114.00), ("CA", "CT", "HC"): (50.0, 109.50), ("CA", "CA", "CT"): (70.0, 120.00),
+          ("CA", "CA", "CA"): (63.0, 120.00), ("CA", "CA", "HA"): (50.0, 120.00), ("C", "CA", "CA"): (63.0, 120.00),
+          ("CA", "C", "CA"): (63.0, 120.00), ("CA", "C", "OH"): (70.0, 120.00), ("C", "OH", "HO"): (50.0, 113.00),
+          ("C", "CA", "HA"): (50.0, 120.00),
+          ("C*", "CT", "CT"): (63.0, 115.60), ("C*", "CT", "HC"): (50.0, 109.50), ("CT", "C*", "CW"): (70.0, 125.00),
+          ("CB", "C*", "CT"): (70.0, 128.60), ("CB", "C*", "CW"): (63.0, 106.40), ("C*", "CW", "H4"): (50.0, 120.00),
+          ("C*", "CW", "NA"): (70.0, 108.70), ("H4", "CW", "NA"): (50.0, 120.00), ("CW", "NA", "H"): (50.0, 120.00),
+          ("CN", "NA", "CW"): (70.0, 111.60), ("CN", "NA", "H"): (50.0, 123.10), ("CA", "CN", "NA"): (70.0, 132.80),
+          ("CB", "CN", "NA"): (70.0, 104.40), ("CA", "CN", "CB"): (63.0, 122.70), ("CA", "CA", "CN"): (63.0, 120.00),
+          ("CN", "CA", "HA"): (50.0, 120.00), ("CA", "CA", "CB"): (63.0, 120.00), ("CB", "CA", "HA"): (50.0, 120.00),
+          ("CA", "CB", "CN"): (63.0, 116.20), ("C*", "CB", "CA"): (63.0, 134.90), ("C*", "CB", "CN"): (63.0, 108.80),
+          # arginine, lysine, methionine, serine / threonine, proline
+          ("CT", "CT", "N2"): (80.0, 111.20), ("H1", "CT", "N2"): (50.0, 109.50), ("CT", "N2", "H"): (50.0, 118.40),
+          ("CA", "N2", "CT"): (50.0, 123.20), ("CA", "N2", "H"): (50.0, 120.00), ("H", "N2", "H"): (35.0, 120.00),
+          ("N2", "CA", "N2"): (70.0, 120.00),
+          ("CT", "CT", "S"): (50.0, 114.70), ("H1", "CT", "S"): (50.0, 109.50), ("CT", "S", "CT"): (62.0, 98.90),
+          ("CT", "CT", "OH"): (50.0, 109.50), ("H1", "CT", "OH"): (50.0, 109.50), ("CT", "OH", "HO"): (55.0, 108.50),
+          ("CT", "N", "CT"): (50.0, 118.00)}
 # parm99 + ff99SB propers: list of (k kcal/mol, phase deg, n); generic entries are keyed by the central pair
 _TORSION_SPECIFIC = {
     ("C", "N", "CT", "C"): [(0.42, 0.0, 3), (0.27, 0.0, 2)],                        # phi
@@ -126,6 +156,9 @@ _TORSION_SPECIFIC = {
     ("CT", "CT", "CT", "CT"): [(0.18, 0.0, 3), (0.25, 180.0, 2), (0.20, 180.0, 1)],
     ("HC", "CT", "CT", "HC"): [(0.15, 0.0, 3)],
     ("CT", "CT", "CT", "HC"): [(0.16, 0.0, 3)],
+    ("HO", "OH", "CT", "CT"): [(0.16, 0.0, 3), (0.25, 0.0, 1)],
+    ("H1", "CT", "CT", "OH"): [(0.25, 0.0, 1)],
+    ("HC", "CT", "CT", "OH"): [(0.25, 0.0, 1)],
 }
 _TORSION_GENERIC = {
     ("C", "N"): [(2.50, 180.0, 2)],            # X-C-N-X   10.0 / 4 paths
@@ -133,6 +166,12 @@ _TORSION_GENERIC = {
     ("C", "CT"): [],                           # X-C-CT-X  0.0
     ("CT", "N"): [],                           # X-CT-N-X  0.0
     ("CT", "N3"): [(1.40 / 9.0, 0.0, 3)],      # X-CT-N3-X
+    ("C", "CA"): [(14.5 / 4.0, 180.0, 2)], ("CA", "CA"): [(14.5 / 4.0, 180.0, 2)], ("CA", "CB"): [(14.0 / 4.0, 180.0, 2)],
+    ("CA", "CN"): [(14.5 / 4.0, 180.0, 2)], ("CA", "CT"): [], ("CA", "N2"): [(9.6 / 4.0, 180.0, 2)],
+    ("CB", "CN"): [(12.0 / 4.0, 180.0, 2)], ("C*", "CB"): [(6.7 / 4.0, 180.0, 2)], ("C*", "CT"): [],
+    ("C*", "CW"): [(26.1 / 4.0, 180.0, 2)], ("CN", "NA"): [(6.1 / 4.0, 180.0, 2)], ("CW", "NA"): [(6.0 / 4.0, 180.0, 2)],
+    ("CT", "N2"): [], ("CT", "OH"): [(0.5 / 3.0, 0.0, 3)], ("CT", "S"): [(1.0 / 3.0, 0.0, 3)],
+    ("C", "OH"): [(4.6 / 2.0, 180.0, 2)],
 }
 # Side-chain torsions of asparagine that ff99SB-ILDN replaces, by atom names.  FITTED to the reference's OpenMM data (the
 # published ILDN series are not available offline).  r02 fitted them to the 40-frame known-answer file alone, where
@@ -151,19 +190,46 @@ _ASN_FITTED_TORSIONS = {
     ("CA", "CB", "CG", "ND2"): [(1.04630, 180.0, 1), (0.18100, 180.0, 2), (0.03540, 179.997, 3), (0.10030, 0.0, 4),
                                 (0.12980, 0.0, 5), (0.10605, 180.0, 6)],
 }
+# The other three residues ff99SB-ILDN touches, FITTED the same way (r04, tools/pin_energy/fit_ildn_1hgv.py) to the forces of
+# the reference's second OpenMM file - 140 frames of a 46-residue protein (3 ILE, 4 LEU, 1 ASP; testdata/output/1hgv-traj-
+# arrays.npz).  Every other entry of this file meets that data at its float32 noise without any fitting, so the residual
+# force there IS the difference between ILDN's series and the parm99 terms on those bonds.  Least squares over cos + sin
+# coefficients up to n = 6 on ten candidate carrier dihedrals, every second frame: one carrier per bond comes out non-zero, all
+# phases within 0.004 degrees of 0 / 180 (written as such), the generic X-CT-CT-X term on the carrier cancels exactly (ILE) -
+# and the held-out frames are met to 0.0016 kJ/mol/nm rms (forces) and 0.0011 kJ/mol (energies, ABSOLUTE: in
+# PeriodicTorsionForce's form k (1 + cos(n phi - phase)) no additive constant is needed).  The two asparagines of that protein
+# meet the asparagine series above at the same level: an independent check of the r02 / r04 fit on another molecule.
+# What the data cannot say: terms whose dihedral the protein's frames never move (none seen: the held-out residual is noise).
+_ILDN_FITTED_TORSIONS = {
+    "ASN": _ASN_FITTED_TORSIONS,
+    "ILE": {("N", "CA", "CB", "CG2"): [(0.19510, 0.0, 1), (0.84590, 180.0, 2)]},
+    "LEU": {("C", "CA", "CB", "CG"): [(0.57143, 0.0, 1), (0.35831, 180.0, 2), (0.13480, 0.0, 3)]},
+    "ASP": {("N", "CA", "CB", "CG"): [(2.63493, 180.0, 1), (1.19037, 180.0, 2), (0.00687, 180.0, 3), (0.42274, 0.0, 4),
+                                      (0.23170, 0.0, 5), (0.21276, 180.0, 6)],
+            ("CA", "CB", "CG", "OD1"): [(0.44320, 180.0, 2), (0.13760, 180.0, 4), (0.01325, 180.0, 6)],
+            ("CA", "CB", "CG", "OD2"): [(0.44320, 180.0, 2), (0.13760, 180.0, 4), (0.01325, 180.0, 6)]},
+}
 # GBSAOBCForce parameters of amber99_obc.xml: radius (nm) by element and number of bonded atoms, scale by element
-_GB_SCALE = {"H": 0.85, "C": 0.72, "N": 0.79, "O": 0.85}
-ELEMENT_MASSES = {"C": 12.01, "H": 1.008, "N": 14.01, "O": 16.0}
+_GB_SCALE = {"H": 0.85, "C": 0.72, "N": 0.79, "O": 0.85, "S": 0.96}
+ELEMENT_MASSES = {"C": 12.01, "H": 1.008, "N": 14.01, "O": 16.0, "S": 32.06}
 AD_MASSES = ELEMENT_MASSES
 
 
 def _gb_radius(element: str, n_bonds: int, partner_element: str) -> float:
+    """GBSAOBCForce radius (nm) as amber99_obc.xml assigns it: the rule of TINKER's OBC set by element, number of bonded atoms
+    and - for hydrogen - the element it sits on.  Pinned by the two known-answer files for every case a complete standard
+    residue produces (H on C / N / O, sp3 / sp2 carbon, 3- and 4-bonded nitrogen, carbonyl / hydroxyl oxygen, sulfur)."""
     if element == "H":
-        return 0.115 if partner_element == "N" else 0.125
-    table = {("C", 4): 0.190, ("C", 3): 0.1875, ("N", 3): 0.1706, ("N", 4): 0.1625, ("O", 1): 0.148}
-    if (element, n_bonds) not in table:
-        raise NotImplementedError(f"GBSA-OBC radius of {element} with {n_bonds} bonds is not in the verified table")
-    return table[(element, n_bonds)]
+        return {"N": 0.115, "O": 0.105}.get(partner_element, 0.125)
+    if element == "C":
+        return {3: 0.1875, 2: 0.1825}.get(n_bonds, 0.190)
+    if element == "N":
+        return {4: 0.1625, 1: 0.160}.get(n_bonds, 0.1706)
+    if element == "O":
+        return 0.148 if n_bonds == 1 else 0.1535
+    if element == "S":
+        return 0.1775
+    raise NotImplementedError(f"GBSA-OBC radius of element {element}")
 
 
 def _res(types: str, charges: Sequence[float], names: str, bonds: str):
@@ -202,6 +268,84 @@ RESIDUES = {
                  "N H CA HA CB HB2 HB3 CG HG2 HG3 CD OE1 NE2 HE21 HE22 C O OXT", _BB + "C-OXT " + _GLN_SIDE),
 }
 
+# r04: the other residues of the ff94 library (charges as published; every template sums to its formal charge to 1e-4).
+# Pinned by a second OpenMM known-answer file the reference holds: testdata/output/1hgv-traj-arrays.npz, 140 frames of a
+# 46-residue, 691-atom protein written by the same run as the NNQQ file next to it (energies and forces;
+# tools/pin_energy/pin_1hgv.py, tests/test_energy_kat.py).  HIS and CYS do not occur in it and are not offered.
+_PHE_RING = "CB-HB2 CB-HB3 CB-CG CG-CD1 CD1-HD1 CD1-CE1 CE1-HE1 CE1-CZ CZ-CE2 CE2-HE2 CE2-CD2 CD2-HD2 CD2-CG "
+_MET_SIDE = "CB-HB2 CB-HB3 CB-CG CG-HG2 CG-HG3 CG-SD SD-CE CE-HE1 CE-HE2 CE-HE3"
+RESIDUES.update({
+    "GLY": _res("N H CT H1 H1 C O", [-0.4157, 0.2719, -0.0252, 0.0698, 0.0698, 0.5973, -0.5679],
+                "N H CA HA2 HA3 C O", "N-H N-CA CA-HA2 CA-HA3 CA-C C-O"),
+    "CGLY": _res("N H CT H1 H1 C O2 O2", [-0.3821, 0.2681, -0.2493, 0.1056, 0.1056, 0.7231, -0.7855, -0.7855],
+                 "N H CA HA2 HA3 C O OXT", "N-H N-CA CA-HA2 CA-HA3 CA-C C-O C-OXT"),
+    "SER": _res("N H CT H1 CT H1 H1 OH HO C O",
+                [-0.4157, 0.2719, -0.0249, 0.0843, 0.2117, 0.0352, 0.0352, -0.6546, 0.4275, 0.5973, -0.5679],
+                "N H CA HA CB HB2 HB3 OG HG C O", _BB + "CB-HB2 CB-HB3 CB-OG OG-HG"),
+    "THR": _res("N H CT H1 CT H1 CT HC HC HC OH HO C O",
+                [-0.4157, 0.2719, -0.0389, 0.1007, 0.3654, 0.0043, -0.2438, 0.0642, 0.0642, 0.0642, -0.6761, 0.4102, 0.5973, -0.5679],
+                "N H CA HA CB HB CG2 HG21 HG22 HG23 OG1 HG1 C O", _BB + "CB-HB CB-CG2 CG2-HG21 CG2-HG22 CG2-HG23 CB-OG1 OG1-HG1"),
+    "VAL": _res("N H CT H1 CT HC CT HC HC HC CT HC HC HC C O",
+                [-0.4157, 0.2719, -0.0875, 0.0969, 0.2985, -0.0297, -0.3192, 0.0791, 0.0791, 0.0791, -0.3192, 0.0791, 0.0791, 0.0791,
+                 0.5973, -0.5679],
+                "N H CA HA CB HB CG1 HG11 HG12 HG13 CG2 HG21 HG22 HG23 C O",
+                _BB + "CB-HB CB-CG1 CG1-HG11 CG1-HG12 CG1-HG13 CB-CG2 CG2-HG21 CG2-HG22 CG2-HG23"),
+    "LEU": _res("N H CT H1 CT HC HC CT HC CT HC HC HC CT HC HC HC C O",
+                [-0.4157, 0.2719, -0.0518, 0.0922, -0.1102, 0.0457, 0.0457, 0.3531, -0.0361, -0.4121, 0.1000, 0.1000, 0.1000,
+                 -0.4121, 0.1000, 0.1000, 0.1000, 0.5973, -0.5679],
+                "N H CA HA CB HB2 HB3 CG HG CD1 HD11 HD12 HD13 CD2 HD21 HD22 HD23 C O",
+                _BB + "CB-HB2 CB-HB3 CB-CG CG-HG CG-CD1 CD1-HD11 CD1-HD12 CD1-HD13 CG-CD2 CD2-HD21 CD2-HD22 CD2-HD23"),
+    "ILE": _res("N H CT H1 CT HC CT HC HC HC CT HC HC CT HC HC HC C O",
+                [-0.4157, 0.2719, -0.0597, 0.0869, 0.1303, 0.0187, -0.3204, 0.0882, 0.0882, 0.0882, -0.0430, 0.0236, 0.0236,
+                 -0.0660, 0.0186, 0.0186, 0.0186, 0.5973, -0.5679],
+                "N H CA HA CB HB CG2 HG21 HG22 HG23 CG1 HG12 HG13 CD1 HD11 HD12 HD13 C O",
+                _BB + "CB-HB CB-CG2 CG2-HG21 CG2-HG22 CG2-HG23 CB-CG1 CG1-HG12 CG1-HG13 CG1-CD1 CD1-HD11 CD1-HD12 CD1-HD13"),
+    "MET": _res("N H CT H1 CT HC HC CT H1 H1 S CT H1 H1 H1 C O",
+                [-0.4157, 0.2719, -0.0237, 0.0880, 0.0342, 0.0241, 0.0241, 0.0018, 0.0440, 0.0440, -0.2737, -0.0536, 0.0684, 0.0684,
+                 0.0684, 0.5973, -0.5679],
+                "N H CA HA CB HB2 HB3 CG HG2 HG3 SD CE HE1 HE2 HE3 C O", _BB + _MET_SIDE),
+    "NMET": _res("N3 H H H CT HP CT HC HC CT H1 H1 S CT H1 H1 H1 C O",
+                 [0.1592, 0.1984, 0.1984, 0.1984, 0.0221, 0.1116, 0.0865, 0.0125, 0.0125, 0.0334, 0.0292, 0.0292, -0.2774, -0.0341,
+                  0.0597, 0.0597, 0.0597, 0.6123, -0.5713],
+                 "N H H2 H3 CA HA CB HB2 HB3 CG HG2 HG3 SD CE HE1 HE2 HE3 C O", _BB + "N-H2 N-H3 " + _MET_SIDE),
+    "PRO": _res("N CT H1 H1 CT HC HC CT HC HC CT H1 C O",
+                [-0.2548, 0.0192, 0.0391, 0.0391, 0.0189, 0.0213, 0.0213, -0.0070, 0.0253, 0.0253, -0.0266, 0.0641, 0.5896, -0.5748],
+                "N CD HD2 HD3 CG HG2 HG3 CB HB2 HB3 CA HA C O",
+                "N-CD CD-HD2 CD-HD3 CD-CG CG-HG2 CG-HG3 CG-CB CB-HB2 CB-HB3 CB-CA N-CA CA-HA CA-C C-O"),
+    "PHE": _res("N H CT H1 CT HC HC CA CA HA CA HA CA HA CA HA CA HA C O",
+                [-0.4157, 0.2719, -0.0024, 0.0978, -0.0343, 0.0295, 0.0295, 0.0118, -0.1256, 0.1330, -0.1704, 0.1430, -0.1072, 0.1297,
+                 -0.1704, 0.1430, -0.1256, 0.1330, 0.5973, -0.5679],
+                "N H CA HA CB HB2 HB3 CG CD1 HD1 CE1 HE1 CZ HZ CE2 HE2 CD2 HD2 C O", _BB + _PHE_RING + "CZ-HZ"),
+    "TYR": _res("N H CT H1 CT HC HC CA CA HA CA HA C OH HO CA HA CA HA C O",
+                [-0.4157, 0.2719, -0.0014, 0.0876, -0.0152, 0.0295, 0.0295, -0.0011, -0.1906, 0.1699, -0.2341, 0.1656, 0.3226, -0.5579,
+                 0.3992, -0.2341, 0.1656, -0.1906, 0.1699, 0.5973, -0.5679],
+                "N H CA HA CB HB2 HB3 CG CD1 HD1 CE1 HE1 CZ OH HH CE2 HE2 CD2 HD2 C O", _BB + _PHE_RING + "CZ-OH OH-HH"),
+    "TRP": _res("N H CT H1 CT HC HC C* CW H4 NA H CN CA HA CA HA CA HA CA HA CB C O",
+                [-0.4157, 0.2719, -0.0275, 0.1123, -0.0050, 0.0339, 0.0339, -0.1415, -0.1638, 0.2062, -0.3418, 0.3412, 0.1380, -0.2601,
+                 0.1572, -0.1134, 0.1417, -0.1972, 0.1447, -0.2387, 0.1700, 0.1243, 0.5973, -0.5679],
+                "N H CA HA CB HB2 HB3 CG CD1 HD1 NE1 HE1 CE2 CZ2 HZ2 CH2 HH2 CZ3 HZ3 CE3 HE3 CD2 C O",
+                _BB + "CB-HB2 CB-HB3 CB-CG CG-CD1 CD1-HD1 CD1-NE1 NE1-HE1 NE1-CE2 CE2-CZ2 CZ2-HZ2 CZ2-CH2 CH2-HH2 CH2-CZ3 CZ3-HZ3 "
+                      "CZ3-CE3 CE3-HE3 CE3-CD2 CD2-CE2 CD2-CG"),
+    "ASP": _res("N H CT H1 CT HC HC C O2 O2 C O",
+                [-0.5163, 0.2936, 0.0381, 0.0880, -0.0303, -0.0122, -0.0122, 0.7994, -0.8014, -0.8014, 0.5366, -0.5819],
+                "N H CA HA CB HB2 HB3 CG OD1 OD2 C O", _BB + "CB-HB2 CB-HB3 CB-CG CG-OD1 CG-OD2"),
+    "GLU": _res("N H CT H1 CT HC HC CT HC HC C O2 O2 C O",
+                [-0.5163, 0.2936, 0.0397, 0.1105, 0.0560, -0.0173, -0.0173, 0.0136, -0.0425, -0.0425, 0.8054, -0.8188, -0.8188,
+                 0.5366, -0.5819],
+                "N H CA HA CB HB2 HB3 CG HG2 HG3 CD OE1 OE2 C O", _BB + "CB-HB2 CB-HB3 CB-CG CG-HG2 CG-HG3 CG-CD CD-OE1 CD-OE2"),
+    "LYS": _res("N H CT H1 CT HC HC CT HC HC CT HC HC CT HP HP N3 H H H C O",
+                [-0.3479, 0.2747, -0.2400, 0.1426, -0.0094, 0.0362, 0.0362, 0.0187, 0.0103, 0.0103, -0.0479, 0.0621, 0.0621, -0.0143,
+                 0.1135, 0.1135, -0.3854, 0.3400, 0.3400, 0.3400, 0.7341, -0.5894],
+                "N H CA HA CB HB2 HB3 CG HG2 HG3 CD HD2 HD3 CE HE2 HE3 NZ HZ1 HZ2 HZ3 C O",
+                _BB + "CB-HB2 CB-HB3 CB-CG CG-HG2 CG-HG3 CG-CD CD-HD2 CD-HD3 CD-CE CE-HE2 CE-HE3 CE-NZ NZ-HZ1 NZ-HZ2 NZ-HZ3"),
+    "ARG": _res("N H CT H1 CT HC HC CT HC HC CT H1 H1 N2 H CA N2 H H N2 H H C O",
+                [-0.3479, 0.2747, -0.2637, 0.1560, -0.0007, 0.0327, 0.0327, 0.0390, 0.0285, 0.0285, 0.0486, 0.0687, 0.0687, -0.5295,
+                 0.3456, 0.8076, -0.8627, 0.4478, 0.4478, -0.8627, 0.4478, 0.4478, 0.7341, -0.5894],
+                "N H CA HA CB HB2 HB3 CG HG2 HG3 CD HD2 HD3 NE HE CZ NH1 HH11 HH12 NH2 HH21 HH22 C O",
+                _BB + "CB-HB2 CB-HB3 CB-CG CG-HG2 CG-HG3 CG-CD CD-HD2 CD-HD3 CD-NE NE-HE NE-CZ CZ-NH1 NH1-HH11 NH1-HH12 CZ-NH2 "
+                      "NH2-HH21 NH2-HH22"),
+})
+
 AD_ATOM_NAMES = "HH31 CH3 HH32 HH33 C O N H CA HA CB HB1 HB2 HB3 C O N H CH3 HH31 HH32 HH33".split()
 AD_RESIDUES = ["ACE"] * 6 + ["ALA"] * 10 + ["NME"] * 6
 
@@ -214,39 +358,53 @@ def _neighbours(n: int, bonds: Sequence[Tuple[int, int]]) -> List[List[int]]:
     return nb
 
 
-def _improper(centre: int, nb: List[int], ty: List[str], el: List[str]):
-    """OpenMM's placement of the AMBER wildcard impropers (X-X-C-O, X-O2-C-O2, X-X-N-H) for an sp2 centre with three
-    neighbours: (a1, a2, centre, a4) and k in kcal/mol, or None.  a4 is the atom the pattern names last; the other two
-    go carbon first, else heavier element first, same element by index (openmm/app/forcefield.py `_matchImproper`,
-    confirmed per class against the known-answer forces)."""
-    t = ty[centre]
-    if t == "C":
-        o2 = [a for a in nb if ty[a] == "O2"]
-        if len(o2) == 2:
-            other = [a for a in nb if ty[a] != "O2"][0]
-            return (other, min(o2), centre, max(o2)), 10.5
-        last = [a for a in nb if ty[a] == "O"]
-        k = 10.5
-    elif t == "N":
-        last = [a for a in nb if el[a] == "H"]
-        # 1.1 for the backbone pattern (C, CT, H); 1.0 for the generic X-X-N-H (amide NH2)
-        k = 1.1 if sorted(ty[a] for a in nb) == ["C", "CT", "H"] else 1.0
-    else:
+# parm99 impropers as OpenMM's amber99sb.xml holds them: centre type -> [(type2, type3, type4, k kcal/mol)], None = wildcard.
+# (AMBER writes the centre third: X-X-C-O, X-O2-C-O2, CA-CA-C-OH, X-X-N-H, C-CT-N-H (ff99SB backbone, 1.1), X-CT-N-CT,
+#  X-X-N2-H, X-X-NA-H, X-X-CA-HA, X-N2-CA-N2, CA-CA-CA-CT, X-X-CW-H4, CW-CB-C*-CT.)
+_IMPROPER_PATTERNS = {
+    "C": [(None, None, "O", 10.5), (None, "O2", "O2", 10.5), ("CA", "CA", "OH", 1.1)],
+    "N": [(None, None, "H", 1.0), ("C", "CT", "H", 1.1), (None, "CT", "CT", 1.0)],
+    "N2": [(None, None, "H", 1.0)], "NA": [(None, None, "H", 1.0)],
+    "CA": [(None, None, "HA", 1.1), (None, "N2", "N2", 10.5), ("CA", "CA", "CT", 1.1)],
+    "CW": [(None, None, "H4", 1.1)], "C*": [("CW", "CB", "CT", 1.1)],
+}
+_PERMUTATIONS3 = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
+
+
+def _improper(centre: int, nb: List[int], ty: List[str], el: List[str], neighbour_order: str = "sorted"):
+    """OpenMM's placement of the AMBER impropers for an sp2 centre with three neighbours: (a1, a2, centre, a4) and k in
+    kcal/mol, or None - a restatement of openmm/app/forcefield.py `_matchImproper`: the first permutation of the neighbours
+    that fits a pattern gives a4 (the atom in the pattern's last slot); the other two go carbon first, else heavier element
+    first, same element by index; a specific pattern beats a wildcard one.  Confirmed per class against the known-answer
+    forces of both files.  `neighbour_order`: the order OpenMM walks the neighbours in - "sorted" (by atom index: OpenMM 7.6
+    and later, what the 40-frame file pins) or "pyset" (iteration order of a Python set of the indices, i.e. by index mod 8
+    for three neighbours: OpenMM 7.4, what the reference's 2021 files were written with; tests only)."""
+    pats = _IMPROPER_PATTERNS.get(ty[centre])
+    if pats is None:
         return None
-    if not last:
-        return None
-    a4 = max(last)
-    a1, a2 = [a for a in nb if a != a4]
-    if el[a1] == el[a2]:
-        if a1 > a2:
-            a1, a2 = a2, a1
-    elif el[a1] != "C" and (el[a2] == "C" or ELEMENT_MASSES[el[a1]] < ELEMENT_MASSES[el[a2]]):
-        a1, a2 = a2, a1
-    return (a1, a2, centre, a4), k
+    order = sorted(nb) if neighbour_order == "sorted" else list(set(nb))
+    match = None
+    for t2, t3, t4, k in pats:
+        wild = t2 is None or t3 is None
+        if match is not None and wild:
+            continue
+        for perm in _PERMUTATIONS3:
+            x2, x3, x4 = (order[i] for i in perm)
+            if (t2 is None or ty[x2] == t2) and (t3 is None or ty[x3] == t3) and ty[x4] == t4:
+                a1, a2 = x2, x3
+                if el[a1] == el[a2]:
+                    if a1 > a2:
+                        a1, a2 = a2, a1
+                elif el[a1] != "C" and (el[a2] == "C" or ELEMENT_MASSES[el[a1]] < ELEMENT_MASSES[el[a2]]):
+                    a1, a2 = a2, a1
+                match = ((a1, a2, centre, x4), k)
+                break
+    return match
 
 
 def amber99sbildn_obc_tables(atom_names: Sequence[str], residue_names: Sequence[str],
-                             residue_ids: Sequence[int], family: str = "amber99") -> ForceFieldTables:
+                             residue_ids: Sequence[int], family: str = "amber99",
+                             improper_neighbour_order: str = "sorted") -> ForceFieldTables:
     """Tables of `ForceField("amber99sbildn.xml", "amber99_obc.xml").createSystem(topology, CutoffNonPeriodic, 2 nm,
     constraints=None)` (simulation/md.py:150-173) for a single chain made of the residues in `RESIDUES`, atoms in any
     order.  A first residue carrying H2/H3 selects the NH3+ variant, a last residue carrying OXT the COO- variant.
@@ -305,9 +463,11 @@ def amber99sbildn_obc_tables(atom_names: Sequence[str], residue_names: Sequence[
                     continue
                 pairs14.add((min(a, d), max(a, d)))
                 terms = None
-                if fam["asn_fitted"] and local[b] == "ASN" and residue_ids[a] == residue_ids[b] == residue_ids[c] == residue_ids[d]:
+                if fam["asn_fitted"] and local[b] in _ILDN_FITTED_TORSIONS and \
+                        residue_ids[a] == residue_ids[b] == residue_ids[c] == residue_ids[d]:
                     nm4 = (atom_names[a], atom_names[b], atom_names[c], atom_names[d])
-                    terms = _ASN_FITTED_TORSIONS.get(nm4) or _ASN_FITTED_TORSIONS.get(nm4[::-1])
+                    fitted = _ILDN_FITTED_TORSIONS[local[b]]
+                    terms = fitted.get(nm4) or fitted.get(nm4[::-1])
                 if terms is None:
                     key = (ty[a], ty[b], ty[c], ty[d])
                     terms = _TORSION_SPECIFIC.get(key) or _TORSION_SPECIFIC.get(key[::-1])
@@ -318,7 +478,7 @@ def amber99sbildn_obc_tables(atom_names: Sequence[str], residue_names: Sequence[
                     torsion_par.append((float(per), math.radians(phase), kk * KCAL))
     for c in range(n):
         if len(nb[c]) == 3:
-            imp = _improper(c, nb[c], [parent(t) for t in ty], el)
+            imp = _improper(c, nb[c], [parent(t) for t in ty], el, improper_neighbour_order)
             if imp is not None:
                 torsion_idx.append(imp[0])
                 torsion_par.append((2.0, math.pi, imp[1] * KCAL))
