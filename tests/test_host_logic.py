@@ -217,6 +217,35 @@ def test_alanine_dipeptide_charges_against_the_pinned_conventions():
     assert q["ALA"]["HB1"] == q["ALA"]["HB2"] == q["ALA"]["HB3"]
 
 
+def test_every_residue_template_builds_in_any_neighbourhood():
+    """The 18-residue amber99sb-ildn library (pinned on the protein file, tests/test_energy_kat.py): every template is neutral
+    or carries its formal charge; every capped single residue ACE-X-NME and every pair X-PRO / PRO-X resolves all of its bond,
+    angle, torsion, LJ and GB-radius types (the protein only holds some neighbour pairs); ILDN series attach where they should."""
+    from timewarp_amd import forcefield as ff
+
+    formal = {"ASP": -1, "GLU": -1, "LYS": 1, "ARG": 1, "NASN": 1, "NMET": 1, "CGLN": -1, "CGLY": -1}
+    for name, tpl in ff.RESIDUES.items():
+        assert abs(sum(tpl["charges"].values()) - formal.get(name, 0)) < 1e-9, name
+    mids = [r for r in ff.RESIDUES if r not in ("ACE", "NME") and not (len(r) == 4 and r[0] in "NC")]
+    assert len(mids) == 18 and "HIS" not in mids and "CYS" not in mids
+
+    def chain(seq):
+        names, res, rid = [], [], []
+        for i, r in enumerate(seq):
+            for a in ff.RESIDUES[r]["names"]:
+                names.append(a); res.append(r); rid.append(i + 1)
+        return ff.amber99sbildn_obc_tables(names, res, rid)
+
+    for r in mids:
+        t = chain(["ACE", r, "NME"])
+        assert abs(t.atom_par[:, 0].sum() - formal.get(r, 0)) < 1e-9
+        assert len(t.bond_idx) >= t.n_atoms - 1 and (t.atom_par[:, 3] > 0.1).all()
+        chain(["ACE", r, "PRO", "NME"]); chain(["ACE", "PRO", r, "NME"])
+    per = lambda t: sorted(t.torsion_par[:, 0].astype(int).tolist())
+    assert per(chain(["ACE", "ASP", "NME"])).count(6) == 3 and per(chain(["ACE", "ASN", "NME"])).count(6) == 2
+    assert per(chain(["ACE", "ALA", "NME"])).count(6) == 0
+
+
 def test_proposal_step_schedule_matches_oracle():
     from timewarp_amd.utils.evaluation_utils import ChainStats, compute_num_proposal_steps
 
