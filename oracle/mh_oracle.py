@@ -293,3 +293,35 @@ def sample_on_single_conditional(atom_types, x_coords, x_velocs, masked, model: 
         yv_all.append(y_v.numpy())
     return (np.array(yc_all).squeeze(1).squeeze(1), np.array(yv_all).squeeze(1).squeeze(1), np.array(positions),
             np.array(velocities), np.array(x_coords.numpy()))
+
+
+def explore(atom_types, x_coords, x_velocs, masked, model: OracleModel, energy, chirality_centres, num_steps: int,
+            num_parallel_steps: int, energy_threshold: float, noise):
+    """The exploration loop of the reference's exploration.py:229-257 (no MH correction: an explorer moves to the proposal
+    unless the potential energy rises by more than `energy_threshold`; a flipped chirality centre adds 10000), written after
+    the script line by line - the loop sits inline in its `main` and cannot be imported, so this restatement is pinned only
+    through the model / energy / chirality calls it is made of (parity unpinned as a whole).  Returns (positions
+    [num_steps * P, V, 3], energies [num_steps * P, 1])."""
+    P = num_parallel_steps
+    signs = compute_chirality_sign(x_coords, chirality_centres) if len(chirality_centres) else None   # :230
+    y_c, y_v = x_coords, x_velocs                                                                     # :232-233
+    energies = energy(y_c).repeat(P, 1)                                                               # :236-237
+    y_c, y_v = y_c.repeat(P, 1, 1), y_v.repeat(P, 1, 1)
+    at, mk = atom_types.repeat(P, 1), masked.repeat(P, 1)
+    sc, sv = model.scales()
+    traj, elog = [], []
+    for _ in range(num_steps):
+        z_c, z_v = noise.latents(1, P, y_c.shape[1], sc, sv)
+        y_new, _, _ = model.conditional_sample_with_logp(at, y_c, y_v, mk, z_c, z_v)                  # :122-134
+        y_new = y_new.squeeze(0)
+        e_new = energy(y_new)                                                                         # :242
+        if signs is not None:
+            e_new = e_new.clone()
+            e_new[check_symmetry_change(y_new, chirality_centres, signs)] += 10000                    # :243-245
+        stay = e_new - energies > energy_threshold
+        y_c = torch.where(stay.unsqueeze(-1), y_c, y_new)                                             # :246-248
+        energies = torch.where(stay, energies, e_new)                                                 # :249
+        traj.append(y_c)
+        elog.append(energies)
+        y_v = noise.randn_like(y_c)                                                                   # :253
+    return torch.cat(traj, 0), torch.cat(elog, 0)

@@ -692,3 +692,41 @@ def test_dense_flow_mh_iterations_vs_oracle(path):
     assert ref[2] >= 1
     H.assert_not_demoted(model)
     _assert_chain_matches_oracle(got, ref, tol=1e-5, stat_tol=2e-4)
+
+
+@pytest.mark.parametrize("path", [1, 3])
+def test_exploration_mode_vs_oracle(path):
+    """The exploration loop (timewarp_amd/exploration.py after the reference's exploration.py:229-257: P parallel explorers,
+    no MH correction, energy threshold, chirality guard) on the HIP flow / energy / chirality kernels against the oracle
+    loop with the same host-drawn noise: the same stay / move decisions, positions and energies at 1e-5.  Weights whose
+    nets act and a coordinate prior (e^-6 nm) for which, with a 60 kJ/mol threshold, both outcomes occur (23 moves of 40 after
+    the first step)."""
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.exploration import explore
+    from timewarp_amd.forcefield import alanine_dipeptide_amber99sb
+
+    sd = H.mh_state_dict("scaled", True, coords_log_scale=-6.0)
+    model = H.tw_kernel_model(sd, path=path)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    tables = alanine_dipeptide_amber99sb()
+    adj = torch.from_numpy(tables.bond_idx.astype(np.int64))
+    v0 = torch.randn(22, 3, generator=torch.Generator().manual_seed(4))
+    batch = single_state_batch("ad", types, coords, v0, adj_list=adj)
+    P, steps, thr = 8, 6, 60.0
+    pos, en = explore(batch, model, "cuda", AmberPotentialEnergyTorch(tables), steps, P, thr, noise=H.HostNoise(11, "cuda"))
+    from timewarp_amd.utils.chirality import find_chirality_centers
+
+    centres = find_chirality_centers(adj, types[None])
+    assert centres.tolist() == [[8, 6, 9, 14]]   # the alpha carbon with N, HA, C
+    om = mo.OracleModel(sd, H.FULL_KERNEL_SPEC)
+    rpos, ren = mo.explore(types[None], coords[None], v0[None], torch.zeros(1, 22, dtype=torch.bool), om,
+                           H.OracleAmberEnergy(tables), centres, steps, P, thr, H.HostNoise(11))
+    pos, en = pos.cpu(), en.cpu()
+    assert pos.shape == (steps * P, 22, 3) and en.shape == (steps * P, 1)
+    moved = (rpos[P:] != rpos[:-P]).any(-1).any(-1)
+    assert 0 < int(moved.sum()) < moved.numel()            # both outcomes occur after the first step
+    assert torch.equal((pos[P:] != pos[:-P]).any(-1).any(-1), moved)
+    assert H.rel_err(pos, rpos) < 1e-5
+    assert float((en - ren).abs().max()) < 2e-3            # kJ/mol, fp32 energies of ~ -50 .. +100

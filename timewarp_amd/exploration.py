@@ -1,0 +1,62 @@
+"""Exploration mode: `num_parallel_steps` independent explorers that always move to the model's proposal unless the potential
+energy rises by more than a threshold or a chirality centre flips - no Metropolis-Hastings correction (reference
+exploration.py:120-262, the loop at :236-252).
+
+`explore` is that loop on the device: one `conditional_sample` launch for all explorers (each is its own conditioning state,
+`num_samples = 1`), the AMBER energy kernel, the chirality kernel and two `torch.where` - nothing crosses to the host inside
+the loop; the caller copies the trajectory once at the end (the script's `np.savez(positions=..., time=...)`, :259-260).
+Like `sample_trajectory.py`, this is the loop without the script's argument parsing and checkpoint loading: the reference's
+own script runs unchanged on this package's model and energy after `integration.install()` (its loop is written inline in
+`main`, so it then drives the same kernels call by call).
+"""
+from __future__ import annotations
+
+import torch
+
+from .utils.chirality import compute_chirality_sign, find_chirality_centers
+from .utils.evaluation_utils import DeviceNoise, check_symmetry_change
+
+CHIRALITY_PENALTY = 10000.0  # exploration.py:243
+
+
+def explore(batch, model, device, openmm_potential_energy_torch, num_steps: int, num_parallel_steps: int = 1,
+            energy_threshold: float = 300.0, noise=None):
+    """exploration.py:219-257.  `batch`: one conditioning state (B = 1).  Returns (positions [num_steps * P, V, 3],
+    energies [num_steps * P, 1]) as device tensors: after every step the current state of all P explorers, in step order
+    (`torch.cat(trajectory_exploration, axis=0)`).  `noise` (extension, as in `sample_with_model`) supplies the latent and
+    velocity draws; by default they come from the device generator."""
+    device = torch.device(device)
+    noise = noise or DeviceNoise(device)
+    P = int(num_parallel_steps)
+    f32 = torch.float32
+    centers = find_chirality_centers(batch.adj_list, batch.atom_types)                  # :229
+    signs = compute_chirality_sign(batch.atom_coords, centers) if len(centers) else None  # :230
+    y_coords = batch.atom_coords.to(device, f32)                                          # :232
+    y_velocs = batch.atom_velocs.to(device, f32)
+    energies = openmm_potential_energy_torch(y_coords).repeat(P, 1)                       # :236-237
+    y_coords = y_coords.repeat(P, 1, 1).contiguous()
+    y_velocs = y_velocs.repeat(P, 1, 1).contiguous()
+    V = y_coords.shape[1]
+    kw = dict(atom_types=batch.atom_types.repeat(P, 1).to(device), adj_list=batch.adj_list,
+              edge_batch_idx=batch.edge_batch_idx.to(device) if batch.edge_batch_idx is not None else None,
+              masked_elements=batch.masked_elements.repeat(P, 1).to(device))              # :122-131
+    sc = torch.exp(model.coords_prior_log_scale.detach()).to(device)
+    sv = torch.exp(model.velocs_prior_log_scale.detach()).to(device)
+    trajectory, energy_log = [], []
+    with torch.no_grad():
+        for _ in range(num_steps):
+            z_c, z_v = noise.latents(1, P, V, sc, sv)
+            y_new, _, _ = model.conditional_sample_with_logp(x_coords=y_coords, x_velocs=y_velocs, num_samples=1,
+                                                             z_coords=z_c, z_velocs=z_v, **kw)
+            y_new = y_new.squeeze(0).contiguous()
+            e_new = openmm_potential_energy_torch(y_new)                                  # :242
+            if signs is not None:
+                changes = check_symmetry_change(y_new, centers.to(device), signs.to(device))
+                e_new = e_new + CHIRALITY_PENALTY * changes.to(e_new.dtype).unsqueeze(-1)  # :245 (reject if chirality changes)
+            stay = e_new - energies > energy_threshold                                    # [P,1]
+            y_coords = torch.where(stay.unsqueeze(-1), y_coords, y_new)                   # :246-248
+            energies = torch.where(stay, energies, e_new)                                 # :249
+            trajectory.append(y_coords)
+            energy_log.append(energies)
+            y_velocs = noise.randn_like(y_coords)                                         # :253
+    return torch.cat(trajectory, dim=0), torch.cat(energy_log, dim=0)
