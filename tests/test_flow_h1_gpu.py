@@ -260,8 +260,8 @@ class _Rec:
         return self.u
 
 
-@pytest.mark.parametrize("random_velocs", [True, False])
-def test_mh_iterations_vs_oracle_indicator_agreement(random_velocs):
+@pytest.mark.parametrize("random_velocs,kind", [(True, "kernel"), (False, "kernel"), (True, "dense")])
+def test_mh_iterations_vs_oracle_indicator_agreement(random_velocs, kind):
     """Whole MH iterations (tw_mh_iteration: fast flow kernel + AMBER energy kernel, 64 proposals) against the oracle loop
     on shared host noise, weights whose coupling nets move the proposals.  The oracle runs fp32: a proposal whose
     acceptance probability lies within the fast path's noise of the uniform draw may flip, and after the first flip the
@@ -275,20 +275,28 @@ def test_mh_iterations_vs_oracle_indicator_agreement(random_velocs):
     from timewarp_amd.utils.evaluation_utils import MetropolisHastingsChain
 
     S, n_iter = 64, 6
-    sd = H.mh_state_dict("scaled", random_velocs)
+    if kind == "dense":   # transformer_nvp on its fast path (MLP sections single-MFMA), same scaling of the output layers
+        sd = dict(H.full_dense_sd())
+        for k in sd:
+            if ".out_mlp._layers.2." in k:
+                sd[k] = sd[k] * 1e-4
+        sd["coords_prior_log_scale"], sd["velocs_prior_log_scale"] = torch.tensor(-7.0), torch.tensor(0.0)
+        spec = H.FULL_DENSE_SPEC
+    else:
+        sd, spec = H.mh_state_dict("scaled", random_velocs), H.FULL_KERNEL_SPEC
     types, coords, masses = synthetic.alanine_dipeptide_state()
     kw = dict(accept=True, num_proposal_steps=S)
     if random_velocs:
         kw.update(random_velocs=True, resample_velocs=True)
     energy = AmberPotentialEnergyTorch.alanine_dipeptide()
-    model = H.tw_kernel_model(sd, path=H1)
+    model = H.tw_dense_model(sd, path=H1) if kind == "dense" else H.tw_kernel_model(sd, path=H1)
     mask = torch.zeros(1, 22, dtype=torch.bool)
     x_c = coords[None].clone()
     x_v = torch.randn(1, 22, 3, generator=torch.Generator().manual_seed(9)) * 0.05
     agree = total = accepted_ref = 0
     worst = dict(p_xy=0.0, p_yx=0.0, exponent=0.0)
     for it in range(n_iter):
-        rec = _Rec(mo.OracleModel(sd, H.FULL_KERNEL_SPEC), H.OracleAmberEnergy(energy.tables), H.HostNoise(100 + it))
+        rec = _Rec(mo.OracleModel(sd, spec), H.OracleAmberEnergy(energy.tables), H.HostNoise(100 + it))
         rc, rv, racc, _ = mo.sample_with_model(types[None], x_c, x_v, mask, rec, rec, masses, 1, rec, **kw)
         kbT = rec.kbT
         e_x, e_y = (t.squeeze(-1) / kbT for t in rec.energies[:2])
@@ -309,7 +317,7 @@ def test_mh_iterations_vs_oracle_indicator_agreement(random_velocs):
         worst["p_yx"] = max(worst["p_yx"], float((per["pyx"].cpu() - rec.p_yx).abs().max()))
         worst["exponent"] = max(worst["exponent"], float((per["exp"].cpu() - ex_ref).abs().max()))
         x_c, x_v = torch.from_numpy(rc[-1:]), torch.from_numpy(rv[-1:])   # follow the ORACLE's chain
-    print(f"h1 MH iterations vs oracle (random_velocs={random_velocs}): indicator agreement {agree}/{total} over all proposals "
+    print(f"h1 MH iterations vs oracle ({kind}, random_velocs={random_velocs}): indicator agreement {agree}/{total} over all proposals "
           f"({accepted_ref} of {n_iter} reference iterations accepted), max abs deviation log p(y|x) {worst['p_xy']:.3e}, "
           f"log p(x|y) {worst['p_yx']:.3e}, exponent {worst['exponent']:.3e}")
     assert accepted_ref >= 1 and agree >= 0.98 * total
