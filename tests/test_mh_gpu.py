@@ -730,3 +730,34 @@ def test_exploration_mode_vs_oracle(path):
     assert torch.equal((pos[P:] != pos[:-P]).any(-1).any(-1), moved)
     assert H.rel_err(pos, rpos) < 1e-5
     assert float((en - ren).abs().max()) < 2e-3            # kJ/mol, fp32 energies of ~ -50 .. +100
+
+
+def test_exploration_mode_range_guard_replays_on_f32():
+    """Exploration with a checkpoint whose activations leave the fp16 range: one look at the range flag at the end of the loop
+    (no synchronisation per model call), then the whole exploration again on the f32 kernels with the recorded draws - bit
+    for bit what the f32 path gives from the start with the same device noise."""
+    from tests.test_flow_gpu import _overflowing_sd
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.exploration import explore
+    from timewarp_amd.forcefield import alanine_dipeptide_amber99sb
+    from timewarp_amd.utils.evaluation_utils import DeviceNoise
+
+    sd = _overflowing_sd()
+    for k in sd:
+        if ".out_mlp._layers.2." in k:
+            sd[k] = sd[k] * 1e-4
+    sd["coords_prior_log_scale"], sd["velocs_prior_log_scale"] = torch.tensor(-6.0), torch.tensor(0.0)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    tables = alanine_dipeptide_amber99sb()
+    batch = single_state_batch("ad", types, coords, adj_list=torch.from_numpy(tables.bond_idx.astype(np.int64)))
+    energy = AmberPotentialEnergyTorch(tables)
+    dev = torch.device("cuda")
+    m32 = H.tw_kernel_model(sd, path=1)
+    ref = explore(batch, m32, dev, energy, 5, 6, 60.0, noise=DeviceNoise(dev, seed=21))
+    m = H.tw_kernel_model(sd, path=3)
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        got = explore(batch, m, dev, energy, 5, 6, 60.0, noise=DeviceNoise(dev, seed=21))
+    assert m.demoted and not m32.demoted
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.isfinite(got[0]).all()

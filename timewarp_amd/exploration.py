@@ -14,7 +14,8 @@ from __future__ import annotations
 import torch
 
 from .utils.chirality import compute_chirality_sign, find_chirality_centers
-from .utils.evaluation_utils import DeviceNoise, check_symmetry_change
+from .utils.evaluation_utils import (DeviceNoise, RecordingNoise, ReplayDraws, _deferred, _range_guarded,
+                                     check_symmetry_change)
 
 CHIRALITY_PENALTY = 10000.0  # exploration.py:243
 
@@ -42,21 +43,35 @@ def explore(batch, model, device, openmm_potential_energy_torch, num_steps: int,
               masked_elements=batch.masked_elements.repeat(P, 1).to(device))              # :122-131
     sc = torch.exp(model.coords_prior_log_scale.detach()).to(device)
     sv = torch.exp(model.velocs_prior_log_scale.detach()).to(device)
-    trajectory, energy_log = [], []
-    with torch.no_grad():
+    def run(noise):
+        y_c, y_v, e = y_coords, y_velocs, energies
+        trajectory, energy_log = [], []
         for _ in range(num_steps):
             z_c, z_v = noise.latents(1, P, V, sc, sv)
-            y_new, _, _ = model.conditional_sample_with_logp(x_coords=y_coords, x_velocs=y_velocs, num_samples=1,
-                                                             z_coords=z_c, z_velocs=z_v, **kw)
+            y_new, _, _ = model.conditional_sample_with_logp(x_coords=y_c, x_velocs=y_v, num_samples=1, z_coords=z_c,
+                                                             z_velocs=z_v, **kw)
             y_new = y_new.squeeze(0).contiguous()
             e_new = openmm_potential_energy_torch(y_new)                                  # :242
             if signs is not None:
                 changes = check_symmetry_change(y_new, centers.to(device), signs.to(device))
                 e_new = e_new + CHIRALITY_PENALTY * changes.to(e_new.dtype).unsqueeze(-1)  # :245 (reject if chirality changes)
-            stay = e_new - energies > energy_threshold                                    # [P,1]
-            y_coords = torch.where(stay.unsqueeze(-1), y_coords, y_new)                   # :246-248
-            energies = torch.where(stay, energies, e_new)                                 # :249
-            trajectory.append(y_coords)
-            energy_log.append(energies)
-            y_velocs = noise.randn_like(y_coords)                                         # :253
-    return torch.cat(trajectory, dim=0), torch.cat(energy_log, dim=0)
+            stay = e_new - e > energy_threshold                                           # [P,1]
+            y_c = torch.where(stay.unsqueeze(-1), y_c, y_new)                             # :246-248
+            e = torch.where(stay, e, e_new)                                               # :249
+            trajectory.append(y_c)
+            energy_log.append(e)
+            y_v = noise.randn_like(y_c)                                                   # :253
+        return torch.cat(trajectory, dim=0), torch.cat(energy_log, dim=0)
+
+    with torch.no_grad():
+        if not _range_guarded(model):
+            return run(noise)
+        # split-fp16 kernels: no range-flag read-back (a device synchronisation) per model call - one look at the end; on an
+        # overflow the model is demoted and the whole exploration runs again on the exact-f32 kernels with the SAME draws
+        rec = RecordingNoise(noise)
+        with _deferred(model):
+            out = run(rec)
+        if model.demoted or model.split_fp16_overflowed(device):
+            model.demote_to_f32()
+            out = run(ReplayDraws(rec.log))
+        return out
