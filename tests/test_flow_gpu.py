@@ -794,3 +794,41 @@ def test_no_cpu_fallback():
         m.log_likelihood(atom_types=d["atom_types"], x_coords=d["x_coords"], x_velocs=d["x_velocs"],
                          y_coords=d["y_coords"], y_velocs=d["y_velocs"], adj_list=None, edge_batch_idx=None,
                          masked_elements=d["masked"])
+
+
+@pytest.mark.parametrize("ff,hidden", [(32, 32), (64, 64), (96, 32), (512, 128)])
+def test_small_feedforward_and_hidden_widths_vs_oracle(ff, hidden):
+    """The chunked MLP sections run a software pipeline over 32-unit chunks (A(0) | A(c+1) B(c) ... | B(n-1)); the reference's
+    configs have 64 (FFN) and 8 (in / out MLP) of them.  One, two and three chunks are the edge cases of that pipeline's
+    prologue and epilogue: every fused path that claims the shape (`tw_flow_path_supported`) against the oracle, the parity
+    paths at 1e-5, the fast mode at its own bar."""
+    import ctypes as C
+    from timewarp_amd import _lib
+
+    spec = fo.FlowSpec(variant="kernel", num_transformer_layers=2, num_coupling_layers=2)
+    sd = fo.synth_state_dict(fo.make_template(spec, dim_feedforward=ff, mlp_hidden=(hidden,)), 0)
+    g = torch.Generator().manual_seed(ff + hidden)
+    V, lens = 22, [22, 20, 22, 17, 22]
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.3
+    x_v = torch.randn(B, V, 3, generator=g) * 0.5
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+    y_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    ref = fo.log_likelihood(sd, spec, at, x_c, x_v, y_c, y_v, mask)
+    lib = _lib.load()
+    ran = []
+    for path, bar in ((FUSED, TOL), (H3, TOL), (4, 2e-3)):
+        m = H.tw_kernel_model(sd, ff=ff, hidden=hidden, path=path, n_coupling=2, n_layers=2)
+        desc = m.dims.to_desc()
+        if lib.tw_flow_path_supported(C.byref(desc), V, path) != 1:
+            continue
+        out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                               y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
+        H.assert_not_demoted(m)
+        assert H.rel_err(out, ref) < bar, (path, H.rel_err(out, ref))
+        ran.append(path)
+    assert H3 in ran and 4 in ran, ran
