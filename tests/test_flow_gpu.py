@@ -832,3 +832,50 @@ def test_small_feedforward_and_hidden_widths_vs_oracle(ff, hidden):
         assert H.rel_err(out, ref) < bar, (path, H.rel_err(out, ref))
         ran.append(path)
     assert H3 in ran and 4 in ran, ran
+
+
+def test_random_shapes_split_fp16_against_the_per_op_path():
+    """Sixteen seeded random shapes - atoms 1..160, 1..40 conformations, ragged padding, types at random - through the
+    split-fp16 kernel (48-token waves, windowed and wide layouts as the launch code picks them) and through the per-op path
+    (one plain kernel per reference op, any shape): log-likelihoods at 1e-5, and the fast mode within its bar of both.  Not an
+    oracle test (the per-op path is held to the oracle elsewhere): a net for layout bugs at sizes no fixture happens to have."""
+    import ctypes as C
+
+    import numpy as np
+    from timewarp_amd import _lib
+
+    sd = H.full_kernel_sd()
+    lib = _lib.load()
+    models = {p: H.tw_kernel_model(sd, path=p) for p in (SIMPLE, H3, 4)}
+    desc = models[H3].dims.to_desc()
+    rng = np.random.default_rng(2024)
+    done = 0
+    sizes = []
+    while done < 16:
+        V = int(rng.integers(1, 161))
+        if lib.tw_flow_path_supported(C.byref(desc), V, H3) != 1:
+            continue
+        B = int(rng.integers(1, 41 if V <= 64 else 9))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        at = torch.randint(0, 5, (B, V), generator=g)
+        x_c = torch.randn(B, V, 3, generator=g) * (0.2 + 0.004 * V)
+        x_v = torch.randn(B, V, 3, generator=g) * 0.5
+        y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+        y_v = torch.randn(B, V, 3, generator=g) * 0.5
+        mask = torch.zeros(B, V, dtype=torch.bool)
+        for b in range(B):
+            n = int(rng.integers(max(1, V - 12), V + 1))
+            mask[b, n:] = True
+        mask[0] = False   # one full-length row
+        out = {}
+        for p, m in models.items():
+            out[p] = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                                      y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
+            H.assert_not_demoted(m)
+        assert torch.isfinite(out[SIMPLE]).all()
+        e3, e1 = H.rel_err(out[H3], out[SIMPLE]), H.rel_err(out[4], out[SIMPLE])
+        assert e3 < TOL, (V, B, e3)
+        assert e1 < 1e-3, (V, B, e1)
+        sizes.append((V, B))
+        done += 1
+    assert min(v for v, _ in sizes) <= 24 and max(v for v, _ in sizes) >= 100, sizes
