@@ -51,7 +51,12 @@ def main():
     nf = int(os.environ.get("FRAMES", "14"))
     sel = np.linspace(0, len(z["positions"]) - 1, nf).astype(int)
     pos, eref, fref = z["positions"][sel].astype(np.float64), z["energies"][sel, 0], z["forces"][sel].astype(np.float64)
+    if os.environ.get("NO_ILDN"):   # the tables as first written down: parm99 terms on the ILE / LEU / ASP side-chain bonds
+        for r in ("ILE", "LEU", "ASP"):
+            ff._ILDN_FITTED_TORSIONS.pop(r, None)
     t = ff.amber99sbildn_obc_tables(names, res, rid, improper_neighbour_order=os.environ.get("ORDER", "pyset"))
+    print(f"improper neighbour order {os.environ.get('ORDER', 'pyset')}; ILDN series of ILE / LEU / ASP: "
+          f"{'parm99 terms (as first written)' if os.environ.get('NO_ILDN') else 'fitted on the even frames'}")
     torch.set_num_threads(8)
     e, f, parts = evaluate(t, pos)
     de = e - eref
