@@ -534,12 +534,14 @@ def main():
         # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied), summarised in profiles/
         traffic, traffic_src = None, None
+        family = {"h3": "netblock_h3", "h1": "netblock_h1"}.get(args.path)
+        key = "netblock_kernel" if family is None else family + {"ad": "_kernel", "4aa": "_wide_kernel", "dense": "_dense_kernel"}[args.config]
         for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest committed PMC summary
             pmc = os.path.join(ROOT, "profiles", name)
-            if args.config != "ad" or args.proposals != S_PROPOSALS or traffic is not None or not os.path.exists(pmc):
+            if args.proposals != cfg["S"] or traffic is not None or not os.path.exists(pmc):
                 continue
             with open(pmc) as f:
-                rec = json.load(f).get({"h3": "netblock_h3_kernel", "h1": "netblock_h1_kernel"}.get(args.path, "netblock_kernel"))
+                rec = json.load(f).get(key)
                 if rec and args.path == "h3" and rec["kernel"].rstrip(")").endswith("true, true>(tw::H3Params"):
                     rec = None  # (a summary written before the fast mode had its own key)
             if rec:

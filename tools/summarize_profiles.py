@@ -1,5 +1,5 @@
 """Summaries of the rocprofv3 outputs that tools/profile_round.sh leaves under gpurun_out/ (run on the GPU box):
-  --traffic  DIR_FETCH DIR_WRITE OUT.json   FETCH_SIZE / WRITE_SIZE per launch of the net-block kernels (gfx950 correction)
+  --traffic  DIR_FETCH DIR_WRITE OUT.json [MERGE.json]  FETCH_SIZE / WRITE_SIZE per launch of the net-block kernels (gfx950 correction)
   --sq       DIR1 DIR2 ... OUT.md           SQ counters of netblock_h3 per wave
   --stats    DIR OUT.csv                    copy of the kernel-stats CSV of a --kernel-trace --stats run"""
 import csv
@@ -19,11 +19,13 @@ def counters(d):
     return rows
 
 
-def traffic(d_fetch, d_write, out):
-    res = {"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 3 --warmup 1 "
+def traffic(d_fetch, d_write, out, merge=None):
+    res = json.load(open(merge)) if merge and os.path.exists(merge) else {}   # add this run's kernels to an earlier summary
+    res.update({"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 3 --warmup 1 "
                       "--no-cpu-baseline (one pass per counter: FETCH_SIZE, WRITE_SIZE)",
            "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (rocprofv3); bytes = value * 1024; FETCH_SIZE doubled for the "
-                    "16 B/lane coalesced streams of these kernels (MI355X_MICROARCH.md section HBM)"}
+                    "16 B/lane coalesced streams of these kernels (MI355X_MICROARCH.md section HBM)"})
+    fresh = set()
     per = defaultdict(lambda: defaultdict(list))
     for name, d in (("FETCH_SIZE", d_fetch), ("WRITE_SIZE", d_write)):
         for r in counters(d):
@@ -34,16 +36,19 @@ def traffic(d_fetch, d_write, out):
             continue
         # the split-fp16 family by instantiation: <NT, ASM, DENSE, WIDE, RFF, ENC, H1> - the fast mode (H1) streams half the bytes
         args = [a.strip() for a in k[k.index("<") + 1:k.index(">")].split(",")] if "<" in k else []
-        if "h3" in k and len(args) >= 7 and args[6] == "true":
-            key = "netblock_h1_kernel"
+        if "h3" in k and len(args) >= 7:
+            base = "h1" if args[6] == "true" else "h3"
+            key = f"netblock_{base}_dense_kernel" if args[2] == "true" else f"netblock_{base}_wide_kernel" if args[3] == "true" \
+                else f"netblock_{base}_kernel"
         elif "h3" in k:
             key = "netblock_h3_kernel"
         else:
             key = "netblock_dense_kernel" if "dense" in k else "netblock_kernel"
         f = sum(v["FETCH_SIZE"]) / max(len(v["FETCH_SIZE"]), 1)
         w = sum(v["WRITE_SIZE"]) / max(len(v["WRITE_SIZE"]), 1)
-        if key in res and res[key]["dispatches"] >= len(v["FETCH_SIZE"]):
+        if key in fresh and res[key]["dispatches"] >= len(v["FETCH_SIZE"]):
             continue  # several instantiations of one kernel family in the run: keep the one the timed region launches
+        fresh.add(key)
         res[key] = {"kernel": k, "dispatches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                     "traffic_bytes_per_launch_corrected": (2 * f + w) * 1024,
                     "traffic_bytes_per_launch_uncorrected": (f + w) * 1024,
@@ -89,7 +94,7 @@ def stats(d, out):
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "--traffic":
-        traffic(*sys.argv[2:5])
+        traffic(*sys.argv[2:6])   # optional 4th argument: an earlier summary to merge into
     elif mode == "--sq":
         sq(sys.argv[2:-1], sys.argv[-1])
     elif mode == "--stats":
