@@ -355,7 +355,9 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *   bit 13 (8192) ... the encoder-stack build even with a dump buffer (profiling: only stamps outside the stack)
  *   bit 14 (16384) molecules of 25 .. 48 atoms: never the wide layout; bit 15 (32768): the wide layout wherever it exists
  *              (the launch code otherwise picks the layout that needs fewer rounds of the chip; same results up to the last
- *              bits; A/B switch and tests) */
+ *              bits; A/B switch and tests)
+ *   bit 16 (65536) molecules of 49 .. 64 atoms: always 64-token waves (one molecule per wave); bit 17 (131072): never -
+ *              the wide layout instead (the launch code otherwise picks by rounds of the chip x cost per workgroup) */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

@@ -561,6 +561,82 @@ def test_layout_choice_by_rounds_of_the_chip():
             assert H.rel_err(res[flag][0][rows], ryc) < TOL and H.rel_err(res[flag][1][rows], rlp) < TOL, (S, flag)
 
 
+@pytest.mark.parametrize("V,lens", [(49, [49, 49, 40, 49, 49, 49, 49, 31, 49]), (52, [52, 52, 52, 45, 52]),
+                                    (60, [60, 60, 60, 60, 51, 60, 60, 60, 60, 60, 42]), (64, [64, 64, 50, 64, 64, 64])])
+def test_64_token_waves_on_49_to_64_atoms_vs_oracle(V, lens):
+    """r04: 64-token waves - ONE molecule of 49-64 atoms per wave (NT = 4, keys = two K = 32 groups, a three-slot weight ring
+    beside four 32 KiB wave blocks) - the geometry that runs BASELINE config 3 (60 atoms x 512 proposals) in one round of
+    the chip.  Forced here (tw_debug_set_flags 65536) on ragged batches of more than one workgroup, against the oracle and
+    against the wide layout (flag 131072); the launch code picks between the two (next test)."""
+    from timewarp_amd import _lib
+
+    sd = H.full_kernel_sd()
+    g = torch.Generator().manual_seed(900 + V)
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.5
+    x_v = torch.randn(B, V, 3, generator=g) * 0.5
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+    y_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    args = dict(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(), y_velocs=y_v.cuda(),
+                adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+    lib = _lib.load()
+    outs = {}
+    try:
+        for flag in (65536, 131072):
+            lib.tw_debug_set_flags(flag)
+            m = H.tw_kernel_model(sd, path=H3)
+            outs[flag] = m.log_likelihood(**args).cpu()
+            H.assert_not_demoted(m)
+    finally:
+        lib.tw_debug_set_flags(0)
+    assert H.rel_err(outs[65536], ref) < TOL, H.rel_err(outs[65536], ref)
+    assert H.rel_err(outs[131072], ref) < TOL
+    assert not torch.equal(outs[65536], outs[131072])   # two different kernels did run
+
+
+def test_64_token_layout_choice_and_config_3_size():
+    """BASELINE config 3's size, 60 atoms x 512 proposals: 128 workgroups per net in 64-token waves = one round of the chip,
+    171 in the wide layout = 1.34 - the launch code takes the 64-token build there (h3_nt4_choice) and the wide layout at 768
+    proposals (two rounds either way, the wide workgroup is cheaper).  Sample rows of both launches against the oracle; that
+    the choice is really made shows in the results being bit-identical to the forced layout."""
+    from timewarp_amd import _lib
+
+    sd = H.full_kernel_sd()
+    V = 60
+    g = torch.Generator().manual_seed(61)
+    at = torch.randint(0, 5, (1, V), generator=g)
+    x_c = torch.randn(1, V, 3, generator=g) * 0.5
+    x_v = torch.randn(1, V, 3, generator=g) * 0.5
+    mk = torch.zeros(1, V, dtype=torch.bool)
+    lib = _lib.load()
+    for S, chosen, other in ((512, 65536, 131072), (768, 131072, 65536)):
+        zc, zv = fo.draw_latents(sd, S, (1, V, 3), g)
+        res = {}
+        try:
+            for flag in (0, 65536, 131072):
+                lib.tw_debug_set_flags(flag)
+                m = H.tw_kernel_model(sd, path=H3)
+                yc, yv, lp = m.conditional_sample_with_logp(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(),
+                                                            adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda(),
+                                                            num_samples=S, z_coords=zc.cuda(), z_velocs=zv.cuda())
+                res[flag] = (yc.cpu(), yv.cpu(), lp.cpu())
+                H.assert_not_demoted(m)
+        finally:
+            lib.tw_debug_set_flags(0)
+        assert all(torch.equal(a, b) for a, b in zip(res[0], res[chosen])), S
+        assert not torch.equal(res[0][2], res[other][2]), S
+        rows = torch.tensor([0, 1, 3, 4, 7, S // 2, S // 2 + 1, S - 5, S - 1])
+        ryc, ryv, rlp = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, mk, zc[rows], zv[rows])
+        for flag in (65536, 131072):
+            assert H.rel_err(res[flag][0][rows], ryc) < TOL and H.rel_err(res[flag][1][rows], ryv) < TOL and \
+                H.rel_err(res[flag][2][rows], rlp) < TOL, (S, flag)
+
+
 def test_per_op_path_lds_limit():
     """150 atoms: the per-op kernels' V x V score tile needs > 64 KiB of LDS (raised limit) and still matches the
     oracle; 256 atoms exceed the CU's 160 KiB and are refused with a message instead of failing at launch."""

@@ -53,6 +53,17 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3_SIDE_LDS_OFFSET (H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS)
 #define H3_SIDE_LDS_BYTES 3072        // three 1 KiB LDS-DMA chunks (the block is 2624 B; the rest of LDS up to 160 KiB)
 #define H3_LDS_BYTES (H3_SIDE_LDS_OFFSET + H3_SIDE_LDS_BYTES)
+// 64-token waves (NT = 4): one molecule of 49 .. 64 atoms per wave, so BASELINE config 3 (60 atoms x 512 proposals) is 128
+// workgroups per net = ONE round of the chip instead of the wide layout's 1.34.  The wave-private block grows to 32 KiB (the
+// 128 x 64 transposed tile, hi + lo; equally the 32 register images the sections exchange), which leaves room for a ring of
+// three stage buffers (the r03 DMA probe: same stage time as five).
+#define H3N4_NT 4
+#define H3N4_RING 3
+#define H3N4_XT_IMG 2048              // transposed copy: bytes per (feature tile, hi | lo) = [T0 | T1] 1024 + [T2 | T3] 1024
+#define H3N4_WAVE_LDS (2 * 128 * 64 * 2)
+#define H3N4_SF_BYTES 4096            // score fragments per (head, query tile): two K = 32 k-steps x (hi, lo) KiB
+#define H3N4_SIDE_LDS_OFFSET (H3N4_RING * H3_STAGE_BYTES + 4 * H3N4_WAVE_LDS)
+#define H3N4_LDS_BYTES (H3N4_SIDE_LDS_OFFSET + H3_SIDE_LDS_BYTES)
 // dense softmax variant (transformer_nvp): no transposed X tile, so the wave-private block only carries the 24 register
 // images the asm sections exchange operands through; the layer's side block grows by the in_proj / out_proj biases
 #define H3D_WAVE_LDS (24 * 1024)
@@ -134,7 +145,7 @@ int64_t h3_packed_bytes(const tw_flow_desc& d, bool h1) {
 #define H3_SF_LDS_MAX ((size_t)160 * 1024)
 static size_t h3_sf_lds_bytes(int H, int V, int mpw) {
   const size_t MV = (size_t)mpw * V;
-  return (MV * 3 + (size_t)H * MV * V + H) * 4 + MV + 32 * H3_NT;
+  return (MV * 3 + (size_t)H * MV * V + H) * 4 + MV + 32 * H3N4_NT;
 }
 
 // Wide layout: molecules per workgroup and, per wave, the byte offset of its key window in a row of the shared X^T tile.
@@ -186,7 +197,27 @@ static bool h3_wide_ok(int V) {
 // rounds x cost is lower (V = 30: 768 proposals -> 1 round instead of 2; 1000 proposals -> 2 rounds either way, narrow).
 // tw_debug_set_flags bit 14 (16384): never wide below 49 atoms; bit 15 (32768): always wide where it exists (A/B, tests).
 #define H3_CUS 256
-static bool h3_wide_choice(const tw_flow_desc& d, int V, int64_t n_rows, bool /*h1: both layouts exist for it too*/) {
+// 64-token waves (NT = 4): ONE molecule of 49-64 atoms per wave, four per workgroup - against the wide layout's floor(192 / V)
+// = 3 per workgroup, but without its shared tile, its 160-key windows and its two extra barriers per layer.  What decides
+// is rounds of the chip x cost per workgroup, in units of the 48-token kernel's workgroup: wide 1.2 (measured), 64-token
+// H3N4_COST (r04: the compiled-C++ statement of the kernel, measured 0.68 ms per launch against the wide layout's 0.475 per
+// round).  BASELINE config 3 (60 atoms x 512 proposals): 128 workgroups per net = one round x 1.72 against two x 1.2.
+// tw_debug_set_flags bit 16 (65536): always where it exists; bit 17 (131072): never (A/B, tests).
+#define H3N4_COST 1.72
+static bool h3_nt4_ok(const tw_flow_desc& d, int V, bool h1) {
+  return d.variant == 0 && !h1 && V > 16 * H3_NT && V <= 16 * H3N4_NT && h3_sf_lds_bytes(d.n_heads, V, 1) <= H3_SF_LDS_MAX;
+}
+static int64_t h3_rounds(int64_t wgs_per_net) { return (8 * ((wgs_per_net + 3) / 4) + H3_CUS - 1) / H3_CUS; }
+static bool h3_nt4_choice(const tw_flow_desc& d, int V, int64_t n_rows, bool h1) {
+  if (!h3_nt4_ok(d, V, h1) || (g_debug_flags & 131072)) return false;
+  if (g_debug_flags & 65536) return true;
+  H3Wide wd;
+  if (!h3_wide_ok(V) || !h3_wide_geom(V, &wd)) return true;
+  const int64_t rows = n_rows > 0 ? n_rows : 1;
+  return H3N4_COST * (double)h3_rounds((rows + 3) / 4) < 1.2 * (double)h3_rounds((rows + wd.mpwg - 1) / wd.mpwg);
+}
+static bool h3_wide_choice(const tw_flow_desc& d, int V, int64_t n_rows, bool h1) {
+  if (h3_nt4_choice(d, V, n_rows, h1)) return false;
   if (d.variant != 0 || !h3_wide_ok(V)) return false;
   if (!h3_narrow_ok(d, V)) return true;
   if (g_debug_flags & 16384) return false;
@@ -529,15 +560,16 @@ __device__ __forceinline__ float h3_pair_dist(const float* x, int q, int m, int 
 __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
                                      const float* __restrict__ ls, int H, int V, int mpw, int64_t n_rows,
                                      int64_t n_cond, int normalise, char* __restrict__ sfrag, ScoreBasis basis,
-                                     int64_t variant_bytes, int windowed, int use_mm) {
+                                     int64_t variant_bytes, int windowed, int use_mm, int nt) {
   extern __shared__ float sm[];
   const int MV = mpw * V, MVV = MV * V;
+  const int sf_bytes = nt == 4 ? H3N4_SF_BYTES : H3_SF_BYTES;
   float* xs = sm;                // [MV][3]
   float* E = xs + MV * 3;        // [H][MV][V]: basis values, then normalised scores
   float* cmean_s = E + H * MVV;  // [H]
   uint8_t* msk = (uint8_t*)(cmean_s + H);  // [MV]
   uint8_t* tmol = msk + MV;                // [16 NT] token -> molecule of the block (255: padding token)
-  uint8_t* tatm = tmol + 16 * H3_NT;       // [16 NT] token -> atom
+  uint8_t* tatm = tmol + 16 * nt;          // [16 NT] token -> atom
   const int64_t blk = blockIdx.x;
   const int nthr = blockDim.x, t = threadIdx.x;
   for (int i = t; i < MV; i += nthr) {
@@ -550,7 +582,7 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
     xs[3 * i + 2] = x[3 * src + 2];
     msk[i] = masked[src];
   }
-  for (int i = t; i < 16 * H3_NT; i += nthr) {
+  for (int i = t; i < 16 * nt; i += nthr) {
     const int q = i / V;
     tmol[i] = q < mpw ? (uint8_t)q : (uint8_t)255;
     tatm[i] = (uint8_t)(i - q * V);
@@ -588,10 +620,10 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
       for (int m = 0; m < V; ++m) row[m] = row[m] / den;
   }
   __syncthreads();
-  char* out = sfrag + blockIdx.z * variant_bytes + blk * (int64_t)H * H3_NT * H3_SF_BYTES;
-  for (int i = t; i < H * H3_NT * 64; i += nthr) {
+  char* out = sfrag + blockIdx.z * variant_bytes + blk * (int64_t)H * nt * sf_bytes;
+  for (int i = t; i < H * nt * 64; i += nthr) {
     const int lane = i & 63, hj = i >> 6;
-    const int h = hj / H3_NT, jt = hj - h * H3_NT;
+    const int h = hj / nt, jt = hj - h * nt;
     const int tq = 16 * jt + (lane & 15), g = lane >> 4;
     const int mq = tmol[tq];
     const float* row = E + h * MVV + ((mq == 255 ? 0 : mq) * V + tatm[tq]) * V;
@@ -619,9 +651,24 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
       hi1[e] = hi;
       lo1[e] = (_Float16)(val - (float)hi);
     }
-    char* base = out + (int64_t)hj * H3_SF_BYTES;
+    char* base = out + (int64_t)hj * sf_bytes;
     *(h8*)(base + lane * 16) = hi0;
     *(h8*)(base + 1024 + lane * 16) = lo0;
+    if (nt == 4) {
+      // 64-token waves: the second k-step is a K = 32 block as well - keys 32 + 4 g + e (e < 4), 48 + 4 g + e - 4 (e >= 4)
+      h8 hi2, lo2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int tk = 32 + 4 * g + (e < 4 ? e : e + 12);
+        const float val = (mq != 255 && tmol[tk] == mq) ? row[tatm[tk]] : 0.f;
+        const _Float16 hi = (_Float16)val;
+        hi2[e] = hi;
+        lo2[e] = (_Float16)(val - (float)hi);
+      }
+      *(h8*)(base + 2048 + lane * 16) = hi2;
+      *(h8*)(base + 3072 + lane * 16) = lo2;
+      continue;
+    }
     *(h4*)(base + 2048 + lane * 16) = hi1;  // [hi | lo] of the K = 16 block side by side: one 16-byte load per lane
     *(h4*)(base + 2048 + lane * 16 + 8) = lo1;
   }
@@ -730,6 +777,31 @@ struct H3Params {
   const uint8_t* masked;
   PrevCoupling prev;  // the previous coupling layer's update, applied here (flow_pass_h3)
 };
+// 64-token waves: four query tiles x [k-step 0 hi | lo | k-step 1 hi | lo], 16 B per lane each
+__device__ __forceinline__ void h3_load_sf4(const char* p, u4 (&r)[16]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %16, off\n\t"
+      "global_load_dwordx4 %1, %16, off offset:1024\n\t"
+      "global_load_dwordx4 %2, %16, off offset:2048\n\t"
+      "global_load_dwordx4 %3, %16, off offset:3072\n\t"
+      "global_load_dwordx4 %4, %17, off\n\t"
+      "global_load_dwordx4 %5, %17, off offset:1024\n\t"
+      "global_load_dwordx4 %6, %17, off offset:2048\n\t"
+      "global_load_dwordx4 %7, %17, off offset:3072\n\t"
+      "global_load_dwordx4 %8, %18, off\n\t"
+      "global_load_dwordx4 %9, %18, off offset:1024\n\t"
+      "global_load_dwordx4 %10, %18, off offset:2048\n\t"
+      "global_load_dwordx4 %11, %18, off offset:3072\n\t"
+      "global_load_dwordx4 %12, %19, off\n\t"
+      "global_load_dwordx4 %13, %19, off offset:1024\n\t"
+      "global_load_dwordx4 %14, %19, off offset:2048\n\t"
+      "global_load_dwordx4 %15, %19, off offset:3072\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
+        "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+      : "v"(p), "v"(p + H3N4_SF_BYTES), "v"(p + 2 * H3N4_SF_BYTES), "v"(p + 3 * H3N4_SF_BYTES)
+      : "memory");
+}
 
 template <int NT>
 struct BOp {  // B operand of one 32-deep k-step for NT token tiles, split fp16
@@ -902,6 +974,7 @@ struct H3Pipe {
   int cur;            // ring slot of the current stage
   int wave;
   int debug;
+  int ring = H3_RING;  // stage buffers (H3N4_RING for the 64-token build)
 
   __device__ __forceinline__ void fetch(int slot) {
     char* dst = lds + slot * H3_STAGE_BYTES;
@@ -921,7 +994,8 @@ struct H3Pipe {
   // only become conservative).
   __device__ __forceinline__ void start_issue() {
 #pragma unroll
-    for (int i = 0; i < H3_RING; ++i) fetch(i);
+    for (int i = 0; i < H3_RING; ++i)
+      if (i < ring) fetch(i);
     cur = 0;
   }
   __device__ __forceinline__ void start_wait() {
@@ -935,7 +1009,7 @@ struct H3Pipe {
     if (!TW_EXPERIMENT(debug & 2)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const int released = cur;
-    cur = (cur + 1 == H3_RING) ? 0 : cur + 1;
+    cur = (cur + 1 == ring) ? 0 : cur + 1;
     if (!TW_EXPERIMENT(debug & 1)) fetch(released);
   }
 };
@@ -1124,9 +1198,15 @@ netblock_h3_kernel(const H3Params p) {
   static_assert(!WIDE || (ASM && !DENSE), "the wide layout exists for the asm build of the kernel-attention variant");
   static_assert(!RFF || DENSE, "position features belong to the dense model");
   static_assert(!ENC || (ASM && !DENSE && !WIDE && NT == 3), "the encoder-stack statement is the 48-token kernel-attention build");
+  static_assert(NT == 3 || (NT == 4 && !DENSE && !WIDE && !RFF && !ENC && !H1),
+                "64-token waves: the kernel-attention variant, one molecule of 49-64 atoms per wave, per-section build");
   constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
-  constexpr int WAVE_LDS = DENSE ? H3D_WAVE_LDS : (WIDE ? H3W_WAVE_LDS : H3_WAVE_LDS);
-  constexpr int SIDE_LDS_OFFSET = DENSE ? H3D_SIDE_LDS_OFFSET : (WIDE ? H3W_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET);
+  constexpr int RING = NT == 4 ? H3N4_RING : H3_RING;
+  constexpr int XT_IMG = NT == 4 ? H3N4_XT_IMG : H3_XT_IMG;
+  constexpr int SF_BYTES = NT == 4 ? H3N4_SF_BYTES : H3_SF_BYTES;
+  constexpr int WAVE_LDS = DENSE ? H3D_WAVE_LDS : (WIDE ? H3W_WAVE_LDS : (NT == 4 ? H3N4_WAVE_LDS : H3_WAVE_LDS));
+  constexpr int SIDE_LDS_OFFSET = DENSE ? H3D_SIDE_LDS_OFFSET
+                                        : (WIDE ? H3W_SIDE_LDS_OFFSET : (NT == 4 ? H3N4_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET));
   constexpr int SIDE_CHUNKS = DENSE ? 5 : 3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1152,7 +1232,7 @@ netblock_h3_kernel(const H3Params p) {
   const char* net_base = p.packed + (int64_t)net * p.net_stride_bytes;
   const float* side = (const float*)(net_base + p.stages * H3_STAGE_BYTES);
   const float* scales = side + p.side_scales;
-  _Float16* xt_hi = (_Float16*)(lds + H3_RING * H3_STAGE_BYTES + wave * WAVE_LDS);
+  _Float16* xt_hi = (_Float16*)(lds + RING * H3_STAGE_BYTES + wave * WAVE_LDS);
 
   const unsigned long long t_kernel_top = (p.debug & 16) ? __builtin_readcyclecounter() : 0ull;  // section profile only
   // ---- request the first stages of the weight stream ----
@@ -1162,6 +1242,7 @@ netblock_h3_kernel(const H3Params p) {
   pipe.cur = 0;
   pipe.wave = wave;
   pipe.debug = p.debug;
+  pipe.ring = RING;
   pipe.start_issue();
 
   // Second-layer bias and output scale of the in and out MLPs: plain loads at the very top, so that they are back long
@@ -1230,7 +1311,7 @@ netblock_h3_kernel(const H3Params p) {
       // molecules span waves: the tokens' partial sums meet in a workgroup-shared LDS array (192 floats at the start of
       // the wave-private blocks, which nothing uses yet); wave 0 adds them up in atom order.  Both nets take the barriers.
       if (p.prev.s_raw) {
-        float* scr = (float*)(lds + H3_RING * H3_STAGE_BYTES);
+        float* scr = (float*)(lds + RING * H3_STAGE_BYTES);
         if (net == 0) {
           if (bad) atomicOr(p.prev.nonfinite, 1);
           if (g == 0) {
@@ -1452,7 +1533,7 @@ netblock_h3_kernel(const H3Params p) {
 
   const char* sf_net = p.sfrag + (int64_t)(net * p.n_layers) * p.sf_variant_bytes +
                        (WIDE ? (int64_t)((p.sfrag_shared ? 0 : wg * 4) + wave) * p.H * H3W_FRAG_HEAD
-                             : (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * H3_SF_BYTES));
+                             : (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * SF_BYTES));
 
   const float* sl = (const float*)(lds + SIDE_LDS_OFFSET);  // this layer's side block, staged in LDS
   // dense: which key tokens of the wave each of this lane's query tokens may attend to - the unmasked atoms of the
@@ -1573,7 +1654,7 @@ netblock_h3_kernel(const H3Params p) {
     if constexpr (WIDE) {
       // the workgroup's shared tile [feature][192 tokens] over the four wave-private blocks (every wave has passed the
       // barrier above, so nobody still reads operands there); a barrier before anyone mixes against other waves' columns
-      char* xts = lds + H3_RING * H3_STAGE_BYTES;
+      char* xts = lds + RING * H3_STAGE_BYTES;
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -1599,7 +1680,7 @@ netblock_h3_kernel(const H3Params p) {
       // (2 ft) * 1536, lo at (2 ft + 1) * 1536.  Every lane reads and writes its own 16 / 8 bytes: no bank conflicts.
       // (r01-r03: rows of 48 halfs per feature, 4.9 k cycles per layer for this block; pairing tokens per store
       // through DPP measured worse, profiles/r03_ab_glue.txt)
-      static_assert(NT == 3, "token tiles 0, 1 form the K = 32 operand, tile 2 the K = 16 operand");
+      static_assert(NT == 3 || NT == 4, "token tiles 0, 1 form a K = 32 operand; tile 2 a K = 16 one, or tiles 2, 3 a second K = 32");
       char* xt = (char*)xt_hi;
       h4 idb;
 #pragma unroll
@@ -1616,11 +1697,16 @@ netblock_h3_kernel(const H3Params p) {
           ph[jt] = __builtin_bit_cast(u2, __builtin_convertvector(th, h4));
           pl[jt] = __builtin_bit_cast(u2, __builtin_convertvector(tl, h4));
         }
-        char* img = xt + ft * (2 * H3_XT_IMG);
+        char* img = xt + ft * (2 * XT_IMG);
         *(u4*)(img + lane * 16) = (u4){ph[0][0], ph[0][1], ph[1][0], ph[1][1]};
-        *(u2*)(img + 1024 + lane * 8) = ph[2];
-        *(u4*)(img + H3_XT_IMG + lane * 16) = (u4){pl[0][0], pl[0][1], pl[1][0], pl[1][1]};
-        *(u2*)(img + H3_XT_IMG + 1024 + lane * 8) = pl[2];
+        *(u4*)(img + XT_IMG + lane * 16) = (u4){pl[0][0], pl[0][1], pl[1][0], pl[1][1]};
+        if constexpr (NT == 4) {  // [T2 | T3]: the second K = 32 operand
+          *(u4*)(img + 1024 + lane * 16) = (u4){ph[2][0], ph[2][1], ph[3][0], ph[3][1]};
+          *(u4*)(img + XT_IMG + 1024 + lane * 16) = (u4){pl[2][0], pl[2][1], pl[3][0], pl[3][1]};
+        } else {
+          *(u2*)(img + 1024 + lane * 8) = ph[2];
+          *(u2*)(img + XT_IMG + 1024 + lane * 8) = pl[2];
+        }
       }
     }
 
@@ -1817,7 +1903,7 @@ netblock_h3_kernel(const H3Params p) {
       const int heads = __builtin_amdgcn_readfirstlane(p.H);
       if constexpr (WIDE) {
         // wide layout (tools/gen_h3_attn_wide_asm.py): mixing against the wave's key window of the shared X^T tile
-        const unsigned xt_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(lds + H3_RING * H3_STAGE_BYTES);
+        const unsigned xt_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(lds + RING * H3_STAGE_BYTES);
         const int win = __builtin_amdgcn_readfirstlane(wave == 0 ? p.win[0] : wave == 1 ? p.win[1] : wave == 2 ? p.win[2] : p.win[3]);
         if constexpr (H1) {
           asm volatile(
@@ -1865,24 +1951,54 @@ netblock_h3_kernel(const H3Params p) {
     } else
     for (int h = 0; h < p.H; ++h) {
       // score fragments of this head (B operand of the mixing MFMA)
-      static_assert(NT == 3, "h3_load_sf3 loads three token tiles");
+      // mixing: xm = (A_h X)^T, produced directly as the split B operand of the Wc GEMM
+      BOp<NT> xm[4];
+      if constexpr (NT == 4) {
+        // 64-token waves: keys 0-31 and 32-63 are two K = 32 operands of the same shape, one accumulation chain
+        u4 r[16];
+        h3_load_sf4(sf_base + (int64_t)(h * NT) * SF_BYTES + lane * 16, r);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          f4 acc[2][NT];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const char* img = (const char*)xt_hi + (2 * ks + t) * (2 * XT_IMG);
+            const h8 a0h = *(const h8*)(img + lane * 16);
+            const h8 a0l = *(const h8*)(img + XT_IMG + lane * 16);
+            const h8 a1h = *(const h8*)(img + 1024 + lane * 16);
+            const h8 a1l = *(const h8*)(img + XT_IMG + 1024 + lane * 16);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a0h, __builtin_bit_cast(h8, r[4 * jt]), (f4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a1h, __builtin_bit_cast(h8, r[4 * jt + 2]), acc[t][jt]);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a0h, __builtin_bit_cast(h8, r[4 * jt + 1]), acc[t][jt]);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a1h, __builtin_bit_cast(h8, r[4 * jt + 3]), acc[t][jt]);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a0l, __builtin_bit_cast(h8, r[4 * jt]), acc[t][jt]);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) acc[t][jt] = mfma32(a1l, __builtin_bit_cast(h8, r[4 * jt + 2]), acc[t][jt]);
+          }
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) split8(acc[0][jt], acc[1][jt], xm[ks].h[jt], xm[ks].l[jt]);
+        }
+      } else {
       u4 r0h[3], r0l[3];
       u2 r1h[3], r1l[3];
       {
         const char* sp = sf_base + (int64_t)(h * NT) * H3_SF_BYTES;
         h3_load_sf3(sp + lane * 16, sp + lane * 16, r0h, r0l, r1h, r1l);
       }
-      h8 s0h[NT], s0l[NT];
-      h4 s1h[NT], s1l[NT];
+      h8 s0h[3], s0l[3];
+      h4 s1h[3], s1l[3];
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
+      for (int jt = 0; jt < 3; ++jt) {
         s0h[jt] = __builtin_bit_cast(h8, r0h[jt]);
         s0l[jt] = __builtin_bit_cast(h8, r0l[jt]);
         s1h[jt] = __builtin_bit_cast(h4, r1h[jt]);
         s1l[jt] = __builtin_bit_cast(h4, r1l[jt]);
       }
-      // mixing: xm = (A_h X)^T, produced directly as the split B operand of the Wc GEMM
-      BOp<NT> xm[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         // The K=32 body and the K=16 tail accumulate in SEPARATE registers and are summed on the VALU.
@@ -1917,6 +2033,7 @@ netblock_h3_kernel(const H3Params p) {
           for (int jt = 0; jt < NT; ++jt) acc[t][jt] = acc[t][jt] + tail[t][jt];
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) split8(acc[0][jt], acc[1][jt], xm[ks].h[jt], xm[ks].l[jt]);
+      }
       }
       // y += Wc_h . xm : eight stages, ks-major (k-step ks, output tiles 4 half .. 4 half + 3)
 #pragma unroll
@@ -2115,7 +2232,7 @@ static bool h3_layout(const tw_flow_desc& d, int V, int64_t n_rows, bool h1, Fus
     fg->tile_mask = 0;
     return true;
   }
-  return fused_geom_nt(V, H3_NT, fg);
+  return fused_geom_nt(V, h3_nt4_choice(d, V, n_rows, h1) ? H3N4_NT : H3_NT, fg);
 }
 
 static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool h1 = false, int force_layout = -1) {
@@ -2151,8 +2268,8 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool
   const int64_t variants = d.cheb_order > 0 ? 2 * d.n_layers : 1;
   if (d.variant == 1) w.sf_variant_bytes = 0;  // dense: no score fragments
   else if (wide) w.sf_variant_bytes = nblocks * 4 * d.n_heads * H3W_FRAG_HEAD;
-  else w.sf_variant_bytes = nblocks * d.n_heads * H3_NT * H3_SF_BYTES;
-  w.sfrag = take(variants * w.sf_variant_bytes + (wide ? H3W_FRAG_HEAD : H3_NT * H3_SF_BYTES));
+  else w.sf_variant_bytes = nblocks * d.n_heads * g.nt * (g.nt == 4 ? H3N4_SF_BYTES : H3_SF_BYTES);
+  w.sfrag = take(variants * w.sf_variant_bytes + (wide ? H3W_FRAG_HEAD : g.nt * (g.nt == 4 ? H3N4_SF_BYTES : H3_SF_BYTES)));
   w.bytes = p - (char*)base;
   return w;
 }
@@ -2240,7 +2357,12 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   if ((prc = lim_dense_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false, true>, (int)H3D_LDS_BYTES))) return prc;
   if ((prc = lim_wide.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
-  if (h1) {
+  if (!wide && fg.nt == H3N4_NT) {
+    TW_REQUIRE(!h1 && d.variant == 0, "64-token waves: kernel attention on the split-fp16 path");
+    static LdsLimit lim_n4;
+    if ((prc = lim_n4.ensure((const void*)netblock_h3_kernel<H3N4_NT, false>, (int)H3N4_LDS_BYTES))) return prc;
+    hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, false>), dim3(grid), dim3(256), H3N4_LDS_BYTES, a.stream, p);
+  } else if (h1) {
     // single-MFMA build: the encoder-stack statement (section stamps compiled in; no activation dumps), or the wide layout's
     // per-section build
     TW_REQUIRE(h1_supported(d, a.n_atoms) && d.n_layers >= 1, "single-MFMA path: unsupported configuration");
@@ -2318,7 +2440,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
     *variant_bytes = vbw;
     return TW_OK;
   }
-  const int64_t vb = basis.n_variants > 1 ? nblocks * d.n_heads * H3_NT * H3_SF_BYTES : 0;
+  const int64_t vb = basis.n_variants > 1 ? nblocks * d.n_heads * fg.nt * (fg.nt == 4 ? H3N4_SF_BYTES : H3_SF_BYTES) : 0;
   const unsigned nv = (unsigned)basis.n_variants;
   const float* ls = a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0);
   const int win = h3_windowed(fg, V) ? 1 : 0;
@@ -2331,7 +2453,8 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
   }
   // a lone block (all proposals share x) is latency-bound: spread it over 16 waves
   hipLaunchKernelGGL(h3_score_frag_kernel, dim3((unsigned)nblocks, 1, nv), dim3(shared ? 1024 : 512), shm, a.stream, a.x_coords,
-                     a.masked, ls, d.n_heads, V, fg.mpw, a.n_rows, a.n_cond, d.normalise, w.sfrag, basis, vb, win, V > 25 ? 1 : 0);
+                     a.masked, ls, d.n_heads, V, fg.mpw, a.n_rows, a.n_cond, d.normalise, w.sfrag, basis, vb, win, V > 25 ? 1 : 0,
+                     fg.nt);
   TW_LAUNCH_CHECK();
   *variant_bytes = vb;
   return TW_OK;
