@@ -565,7 +565,7 @@ def test_layout_choice_by_rounds_of_the_chip():
                                     (60, [60, 60, 60, 60, 51, 60, 60, 60, 60, 60, 42]), (64, [64, 64, 50, 64, 64, 64])])
 def test_64_token_waves_on_49_to_64_atoms_vs_oracle(V, lens):
     """r04: 64-token waves - ONE molecule of 49-64 atoms per wave (NT = 4, keys = two K = 32 groups, a three-slot weight ring
-    beside four 32 KiB wave blocks) - the geometry that runs BASELINE config 3 (60 atoms x 512 proposals) in one round of
+    beside four 32 KiB wave blocks; the FFN as generated asm, tools/gen_h3_ffn_asm.py --nt=4, the rest compiled C++) - the geometry that runs BASELINE config 3 (60 atoms x 512 proposals) in one round of
     the chip.  Forced here (tw_debug_set_flags 65536) on ragged batches of more than one workgroup, against the oracle and
     against the wide layout (flag 131072); the launch code picks between the two (next test)."""
     from timewarp_amd import _lib
@@ -597,6 +597,14 @@ def test_64_token_waves_on_49_to_64_atoms_vs_oracle(V, lens):
     assert H.rel_err(outs[65536], ref) < TOL, H.rel_err(outs[65536], ref)
     assert H.rel_err(outs[131072], ref) < TOL
     assert not torch.equal(outs[65536], outs[131072])   # two different kernels did run
+    # the all-C++ statement of the 64-token kernel (bit 3) against the build with the generated FFN
+    try:
+        lib.tw_debug_set_flags(65536 | 8)
+        m = H.tw_kernel_model(sd, path=H3)
+        cpp = m.log_likelihood(**args).cpu()
+    finally:
+        lib.tw_debug_set_flags(0)
+    assert H.rel_err(cpp, ref) < TOL and H.rel_err(cpp, outs[65536]) < 2e-6
 
 
 def test_64_token_layout_choice_and_config_3_size():

@@ -200,10 +200,11 @@ static bool h3_wide_ok(int V) {
 // 64-token waves (NT = 4): ONE molecule of 49-64 atoms per wave, four per workgroup - against the wide layout's floor(192 / V)
 // = 3 per workgroup, but without its shared tile, its 160-key windows and its two extra barriers per layer.  What decides
 // is rounds of the chip x cost per workgroup, in units of the 48-token kernel's workgroup: wide 1.2 (measured), 64-token
-// H3N4_COST (r04: the compiled-C++ statement of the kernel, measured 0.68 ms per launch against the wide layout's 0.475 per
-// round).  BASELINE config 3 (60 atoms x 512 proposals): 128 workgroups per net = one round x 1.72 against two x 1.2.
+// H3N4_COST - measured 1.03-1.06x the wide workgroup with the FFN as generated asm and the rest compiled C++
+// (profiles/r04_nt4_layout_choice.txt: 60 atoms x 256 proposals 4.03 against 3.80 ms, x 768 8.37 against 8.10).  BASELINE
+// config 3 (60 atoms x 512 proposals): 128 workgroups per net = ONE round against the wide layout's two: 4.73 against 7.45 ms.
 // tw_debug_set_flags bit 16 (65536): always where it exists; bit 17 (131072): never (A/B, tests).
-#define H3N4_COST 1.72
+#define H3N4_COST 1.3
 static bool h3_nt4_ok(const tw_flow_desc& d, int V, bool h1) {
   return d.variant == 0 && !h1 && V > 16 * H3_NT && V <= 16 * H3N4_NT && h3_sf_lds_bytes(d.n_heads, V, 1) <= H3_SF_LDS_MAX;
 }
@@ -1201,6 +1202,9 @@ netblock_h3_kernel(const H3Params p) {
   static_assert(NT == 3 || (NT == 4 && !DENSE && !WIDE && !RFF && !ENC && !H1),
                 "64-token waves: the kernel-attention variant, one molecule of 49-64 atoms per wave, per-section build");
   constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
+  // 64-token build: the FFN (two thirds of the cycles) is generated asm (tools/gen_h3_ffn_asm.py --nt=4), the in / out MLPs
+  // and the attention block are the compiled-C++ statements
+  constexpr bool ASM_IO = ASM && NT == 3, ASM_ATT = ASM && NT == 3;
   constexpr int RING = NT == 4 ? H3N4_RING : H3_RING;
   constexpr int XT_IMG = NT == 4 ? H3N4_XT_IMG : H3_XT_IMG;
   constexpr int SF_BYTES = NT == 4 ? H3N4_SF_BYTES : H3_SF_BYTES;
@@ -1457,7 +1461,7 @@ netblock_h3_kernel(const H3Params p) {
     for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) x[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (ASM && !RFF) {
+    if constexpr (ASM_IO && !RFF) {
       // generated asm (tools/gen_h3_ffn_asm.py --shape=in): u in, x out through the wave-private LDS block
       char* priv = (char*)xt_hi;
 #pragma unroll
@@ -1891,7 +1895,7 @@ netblock_h3_kernel(const H3Params p) {
         }
       }
       stamp(40 + 4 * l + 1);
-    } else if constexpr (ASM) {
+    } else if constexpr (ASM_ATT) {
       // Hand-scheduled attention block (tools/gen_h3_attn_asm.py): all heads, mixing + Wc GEMM; reads the
       // transposed copy of x written above, returns y through the same wave-private LDS block.
       char* priv = (char*)xt_hi;
@@ -2099,7 +2103,15 @@ netblock_h3_kernel(const H3Params p) {
         const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
         const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
         const int chunks = __builtin_amdgcn_readfirstlane(p.ff_chunks);
-        if constexpr (H1) {
+        if constexpr (NT == 4) {
+          asm volatile(
+#include "tw_h3n4_ffn_asm.inc"
+              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+              :
+#include "tw_h3n4_ffn_clobbers.inc"
+          );
+        } else if constexpr (H1) {
           asm volatile(
 #include "tw_h1_ffn_asm.inc"
               : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -2149,7 +2161,7 @@ netblock_h3_kernel(const H3Params p) {
     if constexpr (!ENC) to_bop<NT, 4>(x, xb);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) o[0][jt] = (f4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (ASM) {
+    if constexpr (ASM_IO) {
       // generated asm (tools/gen_h3_ffn_asm.py --shape=out)
       char* priv = (char*)xt_hi;
       if constexpr (!ENC) {  // (ENC: the encoder-stack statement left the split operand images there)
@@ -2359,9 +2371,13 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   if ((prc = profile_mark(a.stream, true))) return prc;
   if (!wide && fg.nt == H3N4_NT) {
     TW_REQUIRE(!h1 && d.variant == 0, "64-token waves: kernel attention on the split-fp16 path");
-    static LdsLimit lim_n4;
-    if ((prc = lim_n4.ensure((const void*)netblock_h3_kernel<H3N4_NT, false>, (int)H3N4_LDS_BYTES))) return prc;
-    hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, false>), dim3(grid), dim3(256), H3N4_LDS_BYTES, a.stream, p);
+    static LdsLimit lim_n4, lim_n4_cpp;
+    if ((prc = lim_n4.ensure((const void*)netblock_h3_kernel<H3N4_NT, true>, (int)H3N4_LDS_BYTES))) return prc;
+    if ((prc = lim_n4_cpp.ensure((const void*)netblock_h3_kernel<H3N4_NT, false>, (int)H3N4_LDS_BYTES))) return prc;
+    if (g_debug_flags & 8)
+      hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, false>), dim3(grid), dim3(256), H3N4_LDS_BYTES, a.stream, p);
+    else
+      hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES, a.stream, p);
   } else if (h1) {
     // single-MFMA build: the encoder-stack statement (section stamps compiled in; no activation dumps), or the wide layout's
     // per-section build

@@ -43,8 +43,15 @@ FUSED = False
 # the place of the lo tile: SLOT(p, 'l')), so a stage is 8 tiles = 24 MFMAs and a chunk is ONE A stage (tile 4 o + ks)
 # and ONE B stage (tile ot).  Ring, DMA and hand-off are unchanged; the lo operand registers stay unused.
 H1 = "--h1" in sys.argv
+# --nt=4: 64-token waves (one molecule of 49-64 atoms per wave, csrc/tw_netblock_h3.hip H3N4_*): four token tiles, 48 MFMAs
+# per stage, a ring of THREE stage buffers (the four 32 KiB wave blocks leave room for no more).  Register map:
+#   v0..v63 xb k-steps 0, 1;  a128..a191 xb k-steps 2, 3;  a0..a127 yacc;  v64..v95 hacc;  v96..v127 tile slots;
+#   v128..v191 hb (two buffers);  v192..v199 bias;  v200 scale;  v202..v209 temporaries;  v210..v219 addresses
+NT4 = "--nt=4" in sys.argv
+assert not (NT4 and H1), "the 64-token build exists in split-fp16 form"
 
-NT = 3
+NT = 4 if NT4 else 3
+RING = 3 if NT4 else 5
 # Shapes of the three chunked MLPs (same schedule, one generated file each):
 #   ffn : 128 -> 32-unit chunk (ReLU) -> 128     A = 2 stages (o = 0, 1; 4 k-steps),  B = 2 stages (ot 0-3, 4-7)
 #   in  :  64 -> 32-unit chunk (SiLU) -> 128     A = 1 stage  (pairs = o x 2 k-steps), B = 2 stages
@@ -66,6 +73,17 @@ V_U = 204  # SiLU temporaries v204..v207 (clobbered only by the shapes that use 
 V_SC, V_T, V_TILE, V_AUX, V_SCADDR, V_GN, V_TMP, V_LANE16, V_G16 = 184, 186, 194, 195, 196, 198, 200, 202, 203  # tuples even-aligned
 YACC = lambda ot, jt: 4 * (3 * ot + jt)
 HACC = lambda o, jt: 72 + 4 * (3 * o + jt)   # VGPRs: the epilogue reads them without a v_accvgpr_read
+N_VGPR, N_AGPR = None, 120   # (N_VGPR: by shape, main())
+if NT4:
+    XB = lambda ks, jt, part: (8 * (4 * ks + jt) if ks < 2 else 128 + 8 * (4 * (ks - 2) + jt)) + (0 if part == "h" else 4)
+    XB_SRC = lambda ks: "v" if ks < 2 else "a"
+    HB = lambda buf, jt, part: 128 + 32 * buf + 8 * jt + (0 if part == "h" else 4)
+    BIAS = lambda o: 192 + 4 * o
+    V_SC, V_T, V_TILE, V_AUX, V_SCADDR, V_GN, V_TMP, V_LANE16, V_G16 = 200, 202, 210, 211, 212, 214, 216, 218, 219
+    V_U = 220  # SiLU temporaries v220..v223
+    YACC = lambda ot, jt: 4 * (4 * ot + jt)
+    HACC = lambda o, jt: 64 + 4 * (4 * o + jt)
+    N_VGPR, N_AGPR = 224, 192
 S_SC = 95
 S_PREV = 93   # pair-sync: slot of the first stage of a pair, released together with the second
 S_ROT = 83    # auxrot: the wave that moves the next bias/scale block (rotates 0..3 so no wave is always the slowest)
@@ -337,7 +355,7 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
                 f".Lh3mlp_w1_{label}_%=:", "s_barrier"]
         h = handoff_heavy(next_reads, label)
     else:
-        out.append("s_waitcnt vmcnt(6) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
+        out.append(f"s_waitcnt vmcnt({2 * (RING - 2)}) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
         if "nobarrier" not in EXPERIMENT:
             out.append("s_barrier")
         h = handoff(next_reads, with_aux, label)
@@ -417,7 +435,7 @@ def generate():
     else:
         A(f"s_mov_b32 s{S_AUXOFF}, {TILES}")
     A(f"s_mov_b32 s{S_AUXOFF + 1}, 0")
-    A(f"s_add_u32 s{S_END}, %[ring], {5 * STAGE}")
+    A(f"s_add_u32 s{S_END}, %[ring], {RING * STAGE}")
     if "auxrot" in EXPERIMENT:
         A(f"s_mov_b32 s{S_ROT}, 0")
     # DMA source of this wave = gnext + wave*2048
@@ -436,7 +454,10 @@ def generate():
         for i in range(2 * NT * ks_in):
             if H1 and i % 2:
                 continue   # lo images: not used
-            dst = vr(4 * i) if i < 18 else ar(96 + 4 * (i - 18))
+            if NT4:
+                dst = vr(4 * i) if i < 16 else ar(128 + 4 * (i - 16))
+            else:
+                dst = vr(4 * i) if i < 18 else ar(96 + 4 * (i - 18))
             A(f"ds_read_b128 {dst}, v{V_TMP} offset:{1024 * i}")
         for i in range(4 * NT * ot_out):
             A(f"v_accvgpr_write_b32 a{i}, 0")
@@ -512,8 +533,9 @@ def generate():
         elif ffn and SPREAD:
             # hacc[0] is complete after stage A0: two of its three units run under A1, the rest under B0 and B1
             # (B0 starts with the last hacc[0] unit, so hacc[1] - finished by A1's last MFMAs - is read well after it)
-            a_epi = {0: [], 1: units[0] + units[1]}
-            epi = units[2] + units[3] + units[4] + units[5]
+            n_a1 = NT - 1   # units of hacc[0] under A1
+            a_epi = {0: [], 1: [op for u_ in units[:n_a1] for op in u_]}
+            epi = [op for u_ in units[n_a1:] for op in u_]
             if "spread4" in EXPERIMENT:
                 # fourth window: the tail of the last unit (everything behind its bias/scale fma) runs under stage A0 of
                 # the NEXT chunk - hacc[1] is not rewritten before A1, the bias registers are only re-read by A0
@@ -557,7 +579,7 @@ def generate():
     # ring slot index back to the caller: cur = (S_OFF - ring) / STAGE, 0..4
     A(f"s_sub_u32 s{S_REL}, s{S_OFF}, %[ring]")
     A("s_mov_b32 %[cur], 0")
-    for k in range(1, 5):
+    for k in range(1, RING):
         A(f"s_cmp_eq_u32 s{S_REL}, {k * STAGE}")
         A(f"s_cselect_b32 %[cur], {k}, %[cur]")
     # ---- y out through the wave-private LDS block
@@ -587,7 +609,7 @@ def main():
             out_dir = a.split("=", 1)[1]
     SHAPE = SHAPES[shape]
     lines = generate()
-    fam, flag = ("h1", " --h1") if H1 else ("h3", "")
+    fam, flag = ("h1", " --h1") if H1 else ("h3n4", " --nt=4") if NT4 else ("h3", "")
     base = os.path.join(out_dir, f"tw_{fam}_{SHAPE['tag']}_asm.inc")
     out = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape}{flag} - do not edit.  Body of the {shape} MLP asm statement",
            "// (see the generator for the register map and the schedule)."]
@@ -595,7 +617,9 @@ def main():
         out.append('"' + l + '\\n\\t"')
     open(base, "w").write("\n".join(out) + "\n")
     n_v = (212 if IOTAIL else 208) if SHAPE["silu"] else 204
-    clob = [f'"v{i}"' for i in range(n_v)] + [f'"a{i}"' for i in range(120)] + [f'"s{i}"' for i in range(83 if "auxrot" in EXPERIMENT else 84, 96)] + \
+    if NT4:
+        n_v = N_VGPR
+    clob = [f'"v{i}"' for i in range(n_v)] + [f'"a{i}"' for i in range(N_AGPR)] + [f'"s{i}"' for i in range(83 if "auxrot" in EXPERIMENT else 84, 96)] + \
            ['"vcc"', '"scc"', '"memory"']
     cl = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape}{flag} - clobber list of the {shape} MLP asm statement."]
     for i in range(0, len(clob), 12):

@@ -12,6 +12,11 @@ H1 = "--h1" in sys.argv         # the single-MFMA build (TW_PATH_FUSED_H1): enco
 DENSE = "--dense" in sys.argv   # the split-fp16 dense-softmax kernel (transformer_nvp) instead of the kernel-attention one
 sd = H.full_dense_sd() if DENSE else H.full_kernel_sd()
 N, V = 1000, 22
+for a in sys.argv[1:]:          # --atoms=60 --rows=512: e.g. the 64-token build (flag 65536) at BASELINE config 3's size
+    if a.startswith("--atoms="):
+        V = int(a.split("=")[1])
+    if a.startswith("--rows="):
+        N = int(a.split("=")[1])
 g = torch.Generator().manual_seed(2)
 at = torch.randint(0, 5, (1, V), generator=g)
 x_c = torch.randn(1, V, 3, generator=g) * 0.3
