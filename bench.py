@@ -63,13 +63,20 @@ CONFIGS = {
     "ad": dict(V=22, S=1000, model="kernel", flop_sample_pass=FLOP_PER_SAMPLE_PASS, calibration=CALIBRATION,
                workload="kernel_transformer_nvp.yaml, alanine-dipeptide (22 atoms), 1000-proposal parallel MH, "
                         "1 chain per GPU (BASELINE.json configs[1]; configs[2] when n_gpus=8)"),
-    "4aa": dict(V=65, S=512, model="kernel", flop_sample_pass=16 * 65 * F_BLK_KERNEL(65),
+    "4aa": dict(V=61, S=512, model="kernel", flop_sample_pass=16 * 61 * F_BLK_KERNEL(61),
                 calibration=dict(coords_log_scale=-7.5, velocs_log_scale=0.0),
-                kernel="tw::netblock_h3_kernel<3, true, false, true> (wide layout: 2 molecules per workgroup)",
-                workload="kernel_transformer_nvp.yaml, 4AA tetrapeptide NNQQ (65 atoms: the reference's own OpenMM test molecule, "
-                         "simulation/testdata/implicit-2olx-*; amber99sb-ildn + OBC tables pinned by that file), 512-proposal "
-                         "parallel MH, 1 chain per GPU (BASELINE.json configs[3], '~60 atoms'; SURVEY 8d's 4.675 TFLOP per iteration "
-                         "is the same formula at V = 60)"),
+                kernel="tw::netblock_h3_kernel<4, true> (64-token waves: one molecule per wave, 128 workgroups per net = one round; FFN "
+                       "as generated asm, in / out MLPs and attention block compiled C++)",
+                workload="kernel_transformer_nvp.yaml, 4AA tetrapeptide NAQQ (61 atoms: the reference's OpenMM test peptide NNQQ, "
+                         "simulation/testdata/implicit-2olx-*, with its second asparagine cut back to alanine - CG becomes HB1 at "
+                         "1.09 A - so that the molecule has BASELINE's '~60 atoms'; amber99sb-ildn + OBC tables pinned by the "
+                         "reference's two OpenMM files), 512-proposal parallel MH, 1 chain per GPU (BASELINE.json configs[3]; "
+                         "SURVEY 8d's 4.675 TFLOP per iteration is the same formula at V = 60)"),
+    "4aa-nnqq": dict(V=65, S=512, model="kernel", flop_sample_pass=16 * 65 * F_BLK_KERNEL(65),
+                     calibration=dict(coords_log_scale=-7.5, velocs_log_scale=0.0),
+                     kernel="tw::netblock_h3_kernel<3, true, false, true> (wide layout: 2 molecules per workgroup)",
+                     workload="kernel_transformer_nvp.yaml, 4AA tetrapeptide NNQQ (65 atoms: the reference's own OpenMM test molecule, "
+                              "one atom above what a 64-token wave holds: the wide layout), 512-proposal parallel MH, 1 chain per GPU"),
     "dense": dict(V=22, S=1000, model="dense", flop_sample_pass=16 * 22 * F_BLK_DENSE, calibration=CALIBRATION,
                   kernel="tw::netblock_h3_kernel<3, true, true> (split-fp16 dense-softmax kernel)",
                   workload="transformer_nvp.yaml (dense softmax attention variant), alanine-dipeptide (22 atoms), 1000-proposal "
@@ -90,12 +97,28 @@ def molecule(config):
     from timewarp_amd.forcefield import ELEMENT_MASSES, amber99sbildn_obc_tables
 
     z = np.load(os.path.join(ROOT, "tests", "golden", "energy_kat_2olx.npz"))
-    tables = amber99sbildn_obc_tables(list(z["atom_names"]), list(z["residue_names"]), list(z["residue_ids"]))
+    names, res, rid = [str(n) for n in z["atom_names"]], [str(r) for r in z["residue_names"]], [int(i) for i in z["residue_ids"]]
     els = [str(e) for e in z["elements"]]
+    pos = z["positions"][0].astype(np.float64)
+    label = "NNQQ"
+    if config == "4aa":
+        # NAQQ: the second asparagine cut back to alanine (CG -> HB1 on the CB-CG axis at 0.109 nm; OD1 ND2 HD21 HD22 dropped)
+        at = {n: i for i, (n, r) in enumerate(zip(names, rid)) if r == 2}
+        cb, cg = at["CB"], at["CG"]
+        pos[cg] = pos[cb] + 0.109 * (pos[cg] - pos[cb]) / np.linalg.norm(pos[cg] - pos[cb])
+        names[cg], els[cg] = "HB1", "H"
+        drop = {at[n] for n in ("OD1", "ND2", "HD21", "HD22")}
+        keep = [i for i in range(len(names)) if i not in drop]
+        names, rid, els = [names[i] for i in keep], [rid[i] for i in keep], [els[i] for i in keep]
+        res = ["ALA" if r == 2 else res[i] for i, r in zip(keep, rid)]
+        pos = pos[keep]
+        label = "NAQQ"
+    tables = amber99sbildn_obc_tables(names, res, rid)
     vocab = {"C": 0, "H": 1, "N": 2, "O": 3, "S": 4}
     types = torch.tensor([vocab[e] for e in els])
     masses = torch.tensor([ELEMENT_MASSES[e] for e in els], dtype=torch.float32)
-    return "NNQQ", types, torch.from_numpy(z["positions"][0]).float(), masses, AmberPotentialEnergyTorch(tables)
+    assert len(names) == CONFIGS[config]["V"]
+    return label, types, torch.from_numpy(pos).float(), masses, AmberPotentialEnergyTorch(tables)
 
 
 def build_chain(device, seed, proposals, path, config="ad"):
@@ -471,7 +494,7 @@ def main():
     cfg = CONFIGS[args.config]
     if args.proposals is None:
         args.proposals = cfg["S"]
-    if args.config in ("dense", "4aa") and args.path == "f32":
+    if args.config in ("dense", "4aa", "4aa-nnqq") and args.path == "f32":
         ap.error("--config dense / 4aa are measured on the default (split-fp16) path h3 or the opt-in fast mode h1")
 
     from timewarp_amd import _lib, distributed
@@ -535,7 +558,7 @@ def main():
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied), summarised in profiles/
         traffic, traffic_src = None, None
         family = {"h3": "netblock_h3", "h1": "netblock_h1"}.get(args.path)
-        key = "netblock_kernel" if family is None else family + {"ad": "_kernel", "4aa": "_wide_kernel", "dense": "_dense_kernel"}[args.config]
+        key = "netblock_kernel" if family is None else family + {"ad": "_kernel", "4aa": "_n4_kernel", "4aa-nnqq": "_wide_kernel", "dense": "_dense_kernel"}[args.config]
         for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest committed PMC summary
             pmc = os.path.join(ROOT, "profiles", name)
             if args.proposals != cfg["S"] or traffic is not None or not os.path.exists(pmc):
@@ -550,7 +573,7 @@ def main():
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "MH-accepted samples/sec (whole node), alanine-dipeptide kernel_transformer_nvp" if args.config == "ad" else
-                      "MH-accepted samples/sec (whole node), " + ("4AA tetrapeptide kernel_transformer_nvp" if args.config == "4aa"
+                      "MH-accepted samples/sec (whole node), " + ("4AA tetrapeptide kernel_transformer_nvp" if args.config.startswith("4aa")
                                                                    else "alanine-dipeptide transformer_nvp (dense softmax)"),
             "value": value,
             "unit": "MH-accepted samples/s",
@@ -582,7 +605,7 @@ def main():
             "roofline": {
                 "bound": "mfma",
                 "kernel": (cfg.get("kernel", pinfo["kernel"]) if args.path == "h3" else
-                           pinfo["kernel"].replace("false, false, false, true, true>", "false, true, false, false, true>") if args.config == "4aa"
+                           pinfo["kernel"].replace("false, false, false, true, true>", "false, true, false, false, true>") if args.config.startswith("4aa")
                            else pinfo["kernel"].replace("true, false, false, false, true, true>", "true, true, false, false, false, true> (MLP "
                                                         "sections single-MFMA, the softmax attention block split-fp16)") if args.config == "dense"
                            else pinfo["kernel"]) + " (both coupling nets of one coupling layer, all proposals)",

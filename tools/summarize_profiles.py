@@ -39,9 +39,9 @@ def traffic(d_fetch, d_write, out, merge=None):
         if "h3" in k and len(args) >= 7:
             base = "h1" if args[6] == "true" else "h3"
             key = f"netblock_{base}_dense_kernel" if args[2] == "true" else f"netblock_{base}_wide_kernel" if args[3] == "true" \
-                else f"netblock_{base}_kernel"
+                else f"netblock_{base}_n4_kernel" if args[0] == "4" else f"netblock_{base}_kernel"
         elif "h3" in k:
-            key = "netblock_h3_kernel"
+            key = "netblock_h3_n4_kernel" if args[:1] == ["4"] else "netblock_h3_kernel"
         else:
             key = "netblock_dense_kernel" if "dense" in k else "netblock_kernel"
         f = sum(v["FETCH_SIZE"]) / max(len(v["FETCH_SIZE"]), 1)
