@@ -204,7 +204,7 @@ static bool h3_wide_ok(int V) {
 // (profiles/r04_nt4_layout_choice.txt: 60 atoms x 256 proposals 4.03 against 3.80 ms, x 768 8.37 against 8.10).  BASELINE
 // config 3 (60 atoms x 512 proposals): 128 workgroups per net = ONE round against the wide layout's two: 4.73 against 7.45 ms.
 // tw_debug_set_flags bit 16 (65536): always where it exists; bit 17 (131072): never (A/B, tests).
-#define H3N4_COST 1.3
+#define H3N4_COST 1.25
 static bool h3_nt4_ok(const tw_flow_desc& d, int V, bool h1) {
   return d.variant == 0 && !h1 && V > 16 * H3_NT && V <= 16 * H3N4_NT && h3_sf_lds_bytes(d.n_heads, V, 1) <= H3_SF_LDS_MAX;
 }
@@ -1202,9 +1202,9 @@ netblock_h3_kernel(const H3Params p) {
   static_assert(NT == 3 || (NT == 4 && !DENSE && !WIDE && !RFF && !ENC && !H1),
                 "64-token waves: the kernel-attention variant, one molecule of 49-64 atoms per wave, per-section build");
   constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
-  // 64-token build: the FFN (two thirds of the cycles) is generated asm (tools/gen_h3_ffn_asm.py --nt=4), the in / out MLPs
-  // and the attention block are the compiled-C++ statements
-  constexpr bool ASM_IO = ASM && NT == 3, ASM_ATT = ASM && NT == 3;
+  // 64-token build: all four GEMM sections are generated asm (tools/gen_h3_ffn_asm.py / gen_h3_attn_asm.py --nt=4), the glue
+  // between them compiled C++ (the per-section build)
+  constexpr bool ASM_IO = ASM, ASM_ATT = ASM;
   constexpr int RING = NT == 4 ? H3N4_RING : H3_RING;
   constexpr int XT_IMG = NT == 4 ? H3N4_XT_IMG : H3_XT_IMG;
   constexpr int SF_BYTES = NT == 4 ? H3N4_SF_BYTES : H3_SF_BYTES;
@@ -1476,7 +1476,15 @@ netblock_h3_kernel(const H3Params p) {
       const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
       const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
       const int chunks = __builtin_amdgcn_readfirstlane(p.hid_chunks);
-      if constexpr (H1) {
+      if constexpr (NT == 4) {
+        asm volatile(
+#include "tw_h3n4_in_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+            :
+#include "tw_h3n4_in_clobbers.inc"
+        );
+      } else if constexpr (H1) {
         asm volatile(
 #include "tw_h1_in_asm.inc"
             : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -1927,6 +1935,14 @@ netblock_h3_kernel(const H3Params p) {
             :
 #include "tw_h3_attns_clobbers.inc"
         );
+      } else if constexpr (NT == 4) {
+        asm volatile(
+#include "tw_h3n4_attn_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp)
+            :
+#include "tw_h3n4_attn_clobbers.inc"
+        );
       } else if (p.windowed) {
         // two or more molecules per wave: 24 instead of 36 mixing MFMAs per k-step (gen_h3_attn_asm.py --mode=windowed)
         asm volatile(
@@ -2178,7 +2194,15 @@ netblock_h3_kernel(const H3Params p) {
       const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
       const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
       const int chunks = __builtin_amdgcn_readfirstlane(p.hid_chunks);
-      if constexpr (H1) {
+      if constexpr (NT == 4) {
+        asm volatile(
+#include "tw_h3n4_out_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+            :
+#include "tw_h3n4_out_clobbers.inc"
+        );
+      } else if constexpr (H1) {
         asm volatile(
 #include "tw_h1_out_asm.inc"
             : [cur] "+s"(cur), [gn] "+v"(gn)

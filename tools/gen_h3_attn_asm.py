@@ -25,7 +25,15 @@ Register map (private to the asm statement):
 import os
 import sys
 
-NT = 3
+# --nt=4: 64-token waves (one molecule of 49-64 atoms per wave; csrc H3N4_*, gen_h3_ffn_asm.py --nt=4): keys = two K = 32 groups
+# (one accumulation chain of six same-shape MFMAs per tile: no K = 16 tail, no second accumulator), 48 mixing MFMAs per k-step,
+# 48 MFMAs per GEMM stage, a ring of three stage buffers.  Register map:
+#   v0..v63 score fragments SF[jt] = {s0h, s0l, s1h, s1l} x 4;  v64..v95 X^T operands, two buffers of {a0h, a1h, a0l, a1l} x 4;
+#   v96..v127 acc[t][jt];  v128..v191 xm[buf][jt] = {h 4, l 4};  v192..v223 weight tile slots;  v224..v231 temporaries;
+#   v232.. addresses;  a0..a127 y[ot][jt]
+NT4 = "--nt=4" in sys.argv
+NT = 4 if NT4 else 3
+RING = 3 if NT4 else 5
 STAGE, TILES = 9216, 8192
 # Transposed copy of x in the wave-private block (csrc: "x -> transposed", H3_XT_IMG): per feature tile ft and part
 # (hi, lo) one 1536-byte image = [T0 | T1] 16 B per lane (K = 32 operand) + T2 8 B per lane (K = 16 operand); every lane
@@ -43,6 +51,19 @@ V_T, V_TILE, V_XT0, V_XT1, V_GN, V_TMP, V_LANE16, V_SF16, V_SF8, V_TMP2 = 188, 1
 YACC = lambda ot, jt: 4 * (3 * ot + jt)
 S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT, S_K3072, S_K6144 = 84, 85, 86, 88, 90, 92, 93, 94, 96
 N_V, N_A = 212, 96
+N_S = 98
+if NT4:
+    XT_IMG, SF_BYTES = 2048, 4096
+    SF = lambda jt, name: 16 * jt + {"s0h": 0, "s0l": 4, "s1h": 8, "s1l": 12}[name]
+    XA = lambda buf, name: 64 + 16 * buf + {"a0h": 0, "a1h": 4, "a0l": 8, "a1l": 12}[name]
+    ACC = lambda t, jt: 96 + 4 * (4 * t + jt)
+    XM = lambda buf, jt, part: 128 + 32 * buf + 8 * jt + (0 if part == "h" else 4)
+    SLOT = lambda p, part: 192 + 8 * p + (0 if part == "h" else 4)
+    V_T, V_TILE, V_XT0, V_XT1, V_GN, V_TMP, V_LANE16, V_SF16, V_SF8, V_TMP2 = 224, 232, 233, 233, 234, 236, 238, 240, 242, 244
+    YACC = lambda ot, jt: 4 * (4 * ot + jt)
+    S_K3 = 98        # 3 * SF_BYTES; s100:101 = NT * SF_BYTES (fragment stride per head)
+    S_SFHEAD = 100
+    N_V, N_A, N_S = 246, 128, 102
 EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(",")))
 # --mode=windowed: waves that hold two or more molecules.  The score matrix is block diagonal, so query tile 0 only has
 # keys in [0, 32) and query tile 2 only in [16, 48): each takes ONE K=32 mixing MFMA per term (tile 2 with the
@@ -96,6 +117,11 @@ def xt_operand(ks, t, name):
 
 def xt_reads(ks, t, buf):
     off = 2 * XT_IMG * (2 * ks + t)
+    if NT4:   # four 16-byte operands per (feature tile, part pair): [T0 | T1], [T2 | T3], hi and lo
+        return [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
+                f"ds_read_b128 {vr(XA(buf, 'a1h'))}, v{V_XT0} offset:{off + 1024}",
+                f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_IMG}",
+                f"ds_read_b128 {vr(XA(buf, 'a1l'))}, v{V_XT0} offset:{off + XT_IMG + 1024}"]
     r = [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
          f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_IMG}",
          f"ds_read_b64 {vr(XA(buf, 'a1h'), 2)}, v{V_XT1} offset:{off + 1024}",
@@ -111,6 +137,16 @@ def mixing_mfmas(ks):
     out = []
     first = True
     terms = (("a0h", "s0h", "a1h", "s1h"), ("a0h", "s0l", "a1h", "s1l"), ("a0l", "s0h", "a1l", "s1h"))
+    if NT4:
+        # eight chains acc[t][jt] of six K = 32 MFMAs, issued round-robin: two MFMAs of a chain are eight apart
+        for a32, b32, a16, b16 in terms:
+            for a, b in ((a32, b32), (a16, b16)):
+                for t in range(2):
+                    for jt in range(NT):
+                        reg, file = xt_operand(ks, t, a)
+                        out.append(mfma32(ACC(t, jt), reg, SF(jt, b), zero=first, areg=file))
+                first = False
+        return out
     # H1: the hi x hi term only.  Windowed: a chain's K = 16 member follows its K = 32 member with >= 2 other MFMAs between
     for a32, b32, a16, b16 in (terms[:1] if H1 else terms):
         order = [(t, jt) for t in range(2) for jt in range(NT)]
@@ -269,6 +305,18 @@ def sf_loads():
     out = []
     if "nosf" in EXPERIMENT:
         return ["s_nop 0"]
+    if NT4:
+        for jt in range(NT):
+            if jt == 0:
+                a16 = V_SF16
+            else:
+                k = (S_K3072, S_K6144, S_K3)[jt - 1]
+                out += [f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_SF16, 2)}, 0, s[{k}:{k + 1}]"]
+                a16 = V_TMP
+            for i, name in enumerate(("s0h", "s0l", "s1h", "s1l")):
+                out += [f"global_load_dwordx4 {vr(SF(jt, name))}, {vr(a16, 2)}, off" + (f" offset:{1024 * i}" if i else "")]
+        out += [f"v_lshl_add_u64 {vr(V_SF16, 2)}, {vr(V_SF16, 2)}, 0, s[{S_SFHEAD}:{S_SFHEAD + 1}]"]
+        return out
     for jt, tail in sf_tiles():
         if jt == 0:
             a16 = V_SF16
@@ -286,7 +334,7 @@ def sf_loads():
 
 
 def generate():
-    assert NT * SF_BYTES == STAGE
+    assert NT4 or NT * SF_BYTES == STAGE
     L = []
     A = L.append
     A(f"v_mbcnt_lo_u32_b32 v{V_LANE16}, -1, 0")
@@ -295,7 +343,8 @@ def generate():
     A(f"v_lshlrev_b32 v{V_T}, 4, v{V_LANE16}")
     A(f"v_lshlrev_b32 v{V_T + 1}, 3, v{V_LANE16}")
     A(f"v_add_u32 v{V_XT0}, %[priv], v{V_T}")
-    A(f"v_add_u32 v{V_XT1}, %[priv], v{V_T + 1}")
+    if not NT4:   # (64-token build: every operand is 16 bytes per lane)
+        A(f"v_add_u32 v{V_XT1}, %[priv], v{V_T + 1}")
     # score-fragment lane addresses: sf + 16 lane (128-bit loads), sf + 8 lane (64-bit loads)
     A(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_LANE16}")
     A(f"v_mov_b32 v{V_LANE16 + 1}, 0")
@@ -310,7 +359,12 @@ def generate():
     A(f"s_mov_b32 s{S_K3072 + 1}, 0")
     A(f"s_mov_b32 s{S_K6144}, {2 * SF_BYTES}")
     A(f"s_mov_b32 s{S_K6144 + 1}, 0")
-    A(f"s_add_u32 s{S_END}, %[ring], {5 * STAGE}")
+    if NT4:
+        A(f"s_mov_b32 s{S_K3}, {3 * SF_BYTES}")
+        A(f"s_mov_b32 s{S_K3 + 1}, 0")
+        A(f"s_mov_b32 s{S_SFHEAD}, {NT * SF_BYTES}")
+        A(f"s_mov_b32 s{S_SFHEAD + 1}, 0")
+    A(f"s_add_u32 s{S_END}, %[ring], {RING * STAGE}")
     A(f"v_lshl_add_u64 {vr(V_GN, 2)}, %[gn], 0, s[{S_W2048}:{S_W2048 + 1}]")
     A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
     A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
@@ -341,8 +395,9 @@ def generate():
                 # last use of this head's score fragments is issued: fetch the next head's.  Also after the last
                 # head (the buffer has one head of slack): the s_waitcnt vmcnt counts below assume these loads.
                 L += sf_loads()
-            n_sf = sum((3 if tail else 2) - (1 if H1 else 0) for _, tail in sf_tiles())
-            vm = n_sf + 6 if ks == 2 else 6   # the fragment loads (full: 9, windowed: 7) sit in the same queue behind the stage DMAs
+            n_sf = 4 * NT if NT4 else sum((3 if tail else 2) - (1 if H1 else 0) for _, tail in sf_tiles())
+            base_vm = 2 * (RING - 2)          # stages s + 2 .. s + RING - 1 may stay in flight, two DMAs each
+            vm = n_sf + base_vm if ks == 2 else base_vm   # the fragment loads (full: 9, windowed: 7) sit in the same queue behind the stage DMAs
         else:
             # mixing of (h + 1, 0): needs the new score fragments; skipped after the last head.  Newer than the
             # fragment loads are the DMAs of two hand-offs: 4 for every wave (aux blocks move in the last head only,
@@ -352,7 +407,7 @@ def generate():
             A("s_waitcnt vmcnt(2)" if H1 else "s_waitcnt vmcnt(4)")   # H1: one hand-off (2 DMAs) is newer than the fragment loads
             L += mixing_part(0, True)
             A(".Lh3att_nomix_%=:")
-            vm = 6
+            vm = 2 * (RING - 2)
         split = split_ops(nbuf)
         nxt = (ks + 2) % 4   # k-step whose mixing runs at the start of the next step
         if H1:
@@ -361,8 +416,8 @@ def generate():
             L += gemm_stage(0, buf, split, True, f"k{ks}", vm_allow=vm, skip=3, tail_misc=xt_reads_step(nxt),
                             aux_cnt=2 if ks == 3 else 1)
         else:
-            L += gemm_stage(0, buf, split[:24], True, f"k{ks}a", vm_allow=vm, skip=3)
-            L += gemm_stage(1, buf, split[24:], True, f"k{ks}b", vm_allow=vm, tail_misc=xt_reads_step(nxt))
+            L += gemm_stage(0, buf, split[:8 * NT], True, f"k{ks}a", vm_allow=vm, skip=3)
+            L += gemm_stage(1, buf, split[8 * NT:], True, f"k{ks}b", vm_allow=vm, tail_misc=xt_reads_step(nxt))
         A("s_nop 1")
     A(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     A(f"s_cmp_eq_u32 s{S_CNT}, 0")
@@ -370,7 +425,7 @@ def generate():
     # ---- out: ring slot index, y through the wave-private block (X^T is dead now), DMA pointer
     A(f"s_sub_u32 s{S_REL}, s{S_OFF}, %[ring]")
     A("s_mov_b32 %[cur], 0")
-    for k in range(1, 5):
+    for k in range(1, RING):
         A(f"s_cmp_eq_u32 s{S_REL}, {k * STAGE}")
         A(f"s_cselect_b32 %[cur], {k}, %[cur]")
     A("s_waitcnt lgkmcnt(0)")
@@ -378,7 +433,7 @@ def generate():
     A("s_nop 15")
     if not FUSED:
         A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-        for i in range(24):
+        for i in range(8 * NT):
             for r in range(4):
                 A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
             A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
@@ -395,13 +450,14 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--out-dir="):
             out_dir = a.split("=", 1)[1]
-    base = os.path.join(out_dir, "tw_h3_attnw_asm.inc" if WINDOWED else "tw_h3_attn_asm.inc")
-    out = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''} - do not edit.  Body of the attention asm statement."]
+    base = os.path.join(out_dir, "tw_h3n4_attn_asm.inc" if NT4 else "tw_h3_attnw_asm.inc" if WINDOWED else "tw_h3_attn_asm.inc")
+    assert not (NT4 and (WINDOWED or H1))
+    out = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''}{' --nt=4' if NT4 else ''} - do not edit.  Body of the attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")
-    clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A)] + [f'"s{i}"' for i in range(84, 98)] + \
+    clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A)] + [f'"s{i}"' for i in range(84, N_S)] + \
            ['"vcc"', '"scc"', '"memory"']
-    cl = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''} - clobber list of the attention asm statement."]
+    cl = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''}{' --nt=4' if NT4 else ''} - clobber list of the attention asm statement."]
     for i in range(0, len(clob), 12):
         cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
     open(base.replace("_asm.inc", "_clobbers.inc"), "w").write("\n".join(cl) + "\n")
