@@ -605,7 +605,8 @@ def main():
             "roofline": {
                 "bound": "mfma",
                 "kernel": (cfg.get("kernel", pinfo["kernel"]) if args.path == "h3" else
-                           pinfo["kernel"].replace("false, false, false, true, true>", "false, true, false, false, true>") if args.config.startswith("4aa")
+                           "tw::netblock_h3_kernel<4, true, false, false, false, false, true> (64-token waves, single-MFMA sections)" if args.config == "4aa"
+                           else pinfo["kernel"].replace("false, false, false, true, true>", "false, true, false, false, true>") if args.config == "4aa-nnqq"
                            else pinfo["kernel"].replace("true, false, false, false, true, true>", "true, true, false, false, false, true> (MLP "
                                                         "sections single-MFMA, the softmax attention block split-fp16)") if args.config == "dense"
                            else pinfo["kernel"]) + " (both coupling nets of one coupling layer, all proposals)",

@@ -207,14 +207,23 @@ def test_dense_model_fast_mode_round_trip_and_determinism():
     assert err < 5e-3
 
 
-def test_wide_layout_v60_golden_measured_error():
-    """BASELINE config 3's molecule size on the fast path: the 60-atom vectors from the reference (three molecules per
-    workgroup, cross-wave mixing) at the measured error - the same class as on alanine dipeptide."""
+@pytest.mark.parametrize("flag,layout", [(131072, "wide"), (65536, "64-token")])
+def test_wide_layout_v60_golden_measured_error(flag, layout):
+    """BASELINE config 3's molecule size on the fast path: the 60-atom vectors from the reference on the wide layout (three
+    molecules per workgroup, cross-wave mixing) and on the 64-token build (one molecule per wave; tools/gen_h3_*_asm.py --h1
+    --nt=4), each forced by its debug bit, at the measured error - the same class as on alanine dipeptide."""
+    from timewarp_amd import _lib
+
     d, _ = H.load("kernel_full_v60")
-    m = H.tw_kernel_model(H.full_kernel_sd(), path=H1)
-    out = H.run_model_case(m, d)
+    lib = _lib.load()
+    try:
+        lib.tw_debug_set_flags(flag)
+        m = H.tw_kernel_model(H.full_kernel_sd(), path=H1)
+        out = H.run_model_case(m, d)
+    finally:
+        lib.tw_debug_set_flags(0)
     e = _errors(out, d)
-    print("h1 (wide layout) vs the 60-atom reference vectors:", {k: f"{v:.2e}" for k, v in e.items()})
+    print(f"h1 ({layout}) vs the 60-atom reference vectors:", {k: f"{v:.2e}" for k, v in e.items()})
     for k, bar in BARS.items():
         assert e[k] < (4e-4 if k == "loglik" else bar), (k, e[k], bar)   # measured: loglik 1.4e-4, the rest as on alanine dipeptide
     assert e["s_y_coords"] > 1e-5

@@ -206,7 +206,8 @@ static bool h3_wide_ok(int V) {
 // tw_debug_set_flags bit 16 (65536): always where it exists; bit 17 (131072): never (A/B, tests).
 #define H3N4_COST 1.25
 static bool h3_nt4_ok(const tw_flow_desc& d, int V, bool h1) {
-  return d.variant == 0 && !h1 && V > 16 * H3_NT && V <= 16 * H3N4_NT && h3_sf_lds_bytes(d.n_heads, V, 1) <= H3_SF_LDS_MAX;
+  (void)h1;  // both the split-fp16 and the single-MFMA stream have a 64-token build
+  return d.variant == 0 && V > 16 * H3_NT && V <= 16 * H3N4_NT && h3_sf_lds_bytes(d.n_heads, V, 1) <= H3_SF_LDS_MAX;
 }
 static int64_t h3_rounds(int64_t wgs_per_net) { return (8 * ((wgs_per_net + 3) / 4) + H3_CUS - 1) / H3_CUS; }
 static bool h3_nt4_choice(const tw_flow_desc& d, int V, int64_t n_rows, bool h1) {
@@ -1193,13 +1194,13 @@ template <int NT, bool ASM, bool DENSE = false, bool WIDE = false, bool RFF = fa
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_h3_kernel(const H3Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  static_assert(!H1 || ENC || WIDE || (DENSE && ASM && !RFF),
+  static_assert(!H1 || ENC || WIDE || (DENSE && ASM && !RFF) || (NT == 4 && ASM),
                 "the single-MFMA variant exists as the encoder-stack build (<= 48 atoms), for the wide layout, and - MLP sections "
                 "only, the softmax attention block stays in split form - for the dense model");
   static_assert(!WIDE || (ASM && !DENSE), "the wide layout exists for the asm build of the kernel-attention variant");
   static_assert(!RFF || DENSE, "position features belong to the dense model");
   static_assert(!ENC || (ASM && !DENSE && !WIDE && NT == 3), "the encoder-stack statement is the 48-token kernel-attention build");
-  static_assert(NT == 3 || (NT == 4 && !DENSE && !WIDE && !RFF && !ENC && !H1),
+  static_assert(NT == 3 || (NT == 4 && !DENSE && !WIDE && !RFF && !ENC),
                 "64-token waves: the kernel-attention variant, one molecule of 49-64 atoms per wave, per-section build");
   constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
   // 64-token build: all four GEMM sections are generated asm (tools/gen_h3_ffn_asm.py / gen_h3_attn_asm.py --nt=4), the glue
@@ -1476,7 +1477,15 @@ netblock_h3_kernel(const H3Params p) {
       const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
       const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
       const int chunks = __builtin_amdgcn_readfirstlane(p.hid_chunks);
-      if constexpr (NT == 4) {
+      if constexpr (NT == 4 && H1) {
+        asm volatile(
+#include "tw_h1n4_in_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+            :
+#include "tw_h1n4_in_clobbers.inc"
+        );
+      } else if constexpr (NT == 4) {
         asm volatile(
 #include "tw_h3n4_in_asm.inc"
             : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -1935,6 +1944,14 @@ netblock_h3_kernel(const H3Params p) {
             :
 #include "tw_h3_attns_clobbers.inc"
         );
+      } else if constexpr (NT == 4 && H1) {
+        asm volatile(
+#include "tw_h1n4_attn_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp)
+            :
+#include "tw_h1n4_attn_clobbers.inc"
+        );
       } else if constexpr (NT == 4) {
         asm volatile(
 #include "tw_h3n4_attn_asm.inc"
@@ -2119,7 +2136,15 @@ netblock_h3_kernel(const H3Params p) {
         const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
         const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
         const int chunks = __builtin_amdgcn_readfirstlane(p.ff_chunks);
-        if constexpr (NT == 4) {
+        if constexpr (NT == 4 && H1) {
+          asm volatile(
+#include "tw_h1n4_ffn_asm.inc"
+              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+              :
+#include "tw_h1n4_ffn_clobbers.inc"
+          );
+        } else if constexpr (NT == 4) {
           asm volatile(
 #include "tw_h3n4_ffn_asm.inc"
               : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -2194,7 +2219,15 @@ netblock_h3_kernel(const H3Params p) {
       const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
       const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
       const int chunks = __builtin_amdgcn_readfirstlane(p.hid_chunks);
-      if constexpr (NT == 4) {
+      if constexpr (NT == 4 && H1) {
+        asm volatile(
+#include "tw_h1n4_out_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+            :
+#include "tw_h1n4_out_clobbers.inc"
+        );
+      } else if constexpr (NT == 4) {
         asm volatile(
 #include "tw_h3n4_out_asm.inc"
             : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -2394,11 +2427,16 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   if ((prc = lim_wide.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
   if (!wide && fg.nt == H3N4_NT) {
-    TW_REQUIRE(!h1 && d.variant == 0, "64-token waves: kernel attention on the split-fp16 path");
-    static LdsLimit lim_n4, lim_n4_cpp;
+    TW_REQUIRE(d.variant == 0, "64-token waves: kernel attention");
+    static LdsLimit lim_n4, lim_n4_cpp, lim_n4_h1;
     if ((prc = lim_n4.ensure((const void*)netblock_h3_kernel<H3N4_NT, true>, (int)H3N4_LDS_BYTES))) return prc;
     if ((prc = lim_n4_cpp.ensure((const void*)netblock_h3_kernel<H3N4_NT, false>, (int)H3N4_LDS_BYTES))) return prc;
-    if (g_debug_flags & 8)
+    if ((prc = lim_n4_h1.ensure((const void*)netblock_h3_kernel<H3N4_NT, true, false, false, false, false, true>, (int)H3N4_LDS_BYTES)))
+      return prc;
+    if (h1)
+      hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true, false, false, false, false, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES,
+                         a.stream, p);
+    else if (g_debug_flags & 8)
       hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, false>), dim3(grid), dim3(256), H3N4_LDS_BYTES, a.stream, p);
     else
       hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES, a.stream, p);

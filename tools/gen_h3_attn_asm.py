@@ -118,10 +118,11 @@ def xt_operand(ks, t, name):
 def xt_reads(ks, t, buf):
     off = 2 * XT_IMG * (2 * ks + t)
     if NT4:   # four 16-byte operands per (feature tile, part pair): [T0 | T1], [T2 | T3], hi and lo
-        return [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
-                f"ds_read_b128 {vr(XA(buf, 'a1h'))}, v{V_XT0} offset:{off + 1024}",
-                f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_IMG}",
-                f"ds_read_b128 {vr(XA(buf, 'a1l'))}, v{V_XT0} offset:{off + XT_IMG + 1024}"]
+        r = [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
+             f"ds_read_b128 {vr(XA(buf, 'a1h'))}, v{V_XT0} offset:{off + 1024}",
+             f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_IMG}",
+             f"ds_read_b128 {vr(XA(buf, 'a1l'))}, v{V_XT0} offset:{off + XT_IMG + 1024}"]
+        return r[:2] if H1 else r
     r = [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
          f"ds_read_b128 {vr(XA(buf, 'a0l'))}, v{V_XT0} offset:{off + XT_IMG}",
          f"ds_read_b64 {vr(XA(buf, 'a1h'), 2)}, v{V_XT1} offset:{off + 1024}",
@@ -139,7 +140,7 @@ def mixing_mfmas(ks):
     terms = (("a0h", "s0h", "a1h", "s1h"), ("a0h", "s0l", "a1h", "s1l"), ("a0l", "s0h", "a1l", "s1h"))
     if NT4:
         # eight chains acc[t][jt] of six K = 32 MFMAs, issued round-robin: two MFMAs of a chain are eight apart
-        for a32, b32, a16, b16 in terms:
+        for a32, b32, a16, b16 in (terms[:1] if H1 else terms):
             for a, b in ((a32, b32), (a16, b16)):
                 for t in range(2):
                     for jt in range(NT):
@@ -314,6 +315,8 @@ def sf_loads():
                 out += [f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_SF16, 2)}, 0, s[{k}:{k + 1}]"]
                 a16 = V_TMP
             for i, name in enumerate(("s0h", "s0l", "s1h", "s1l")):
+                if H1 and name.endswith("l"):
+                    continue
                 out += [f"global_load_dwordx4 {vr(SF(jt, name))}, {vr(a16, 2)}, off" + (f" offset:{1024 * i}" if i else "")]
         out += [f"v_lshl_add_u64 {vr(V_SF16, 2)}, {vr(V_SF16, 2)}, 0, s[{S_SFHEAD}:{S_SFHEAD + 1}]"]
         return out
@@ -395,7 +398,7 @@ def generate():
                 # last use of this head's score fragments is issued: fetch the next head's.  Also after the last
                 # head (the buffer has one head of slack): the s_waitcnt vmcnt counts below assume these loads.
                 L += sf_loads()
-            n_sf = 4 * NT if NT4 else sum((3 if tail else 2) - (1 if H1 else 0) for _, tail in sf_tiles())
+            n_sf = (2 if H1 else 4) * NT if NT4 else sum((3 if tail else 2) - (1 if H1 else 0) for _, tail in sf_tiles())
             base_vm = 2 * (RING - 2)          # stages s + 2 .. s + RING - 1 may stay in flight, two DMAs each
             vm = n_sf + base_vm if ks == 2 else base_vm   # the fragment loads (full: 9, windowed: 7) sit in the same queue behind the stage DMAs
         else:
@@ -450,14 +453,15 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--out-dir="):
             out_dir = a.split("=", 1)[1]
-    base = os.path.join(out_dir, "tw_h3n4_attn_asm.inc" if NT4 else "tw_h3_attnw_asm.inc" if WINDOWED else "tw_h3_attn_asm.inc")
-    assert not (NT4 and (WINDOWED or H1))
-    out = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''}{' --nt=4' if NT4 else ''} - do not edit.  Body of the attention asm statement."]
+    base = os.path.join(out_dir, ("tw_h1n4_attn_asm.inc" if H1 else "tw_h3n4_attn_asm.inc") if NT4 else
+                        "tw_h3_attnw_asm.inc" if WINDOWED else "tw_h3_attn_asm.inc")
+    assert not (NT4 and WINDOWED) and (NT4 or not H1 or FUSED)
+    out = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''}{' --nt=4' if NT4 else ''}{' --h1' if H1 else ''} - do not edit.  Body of the attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")
     clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A)] + [f'"s{i}"' for i in range(84, N_S)] + \
            ['"vcc"', '"scc"', '"memory"']
-    cl = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''}{' --nt=4' if NT4 else ''} - clobber list of the attention asm statement."]
+    cl = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''}{' --nt=4' if NT4 else ''}{' --h1' if H1 else ''} - clobber list of the attention asm statement."]
     for i in range(0, len(clob), 12):
         cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
     open(base.replace("_asm.inc", "_clobbers.inc"), "w").write("\n".join(cl) + "\n")

@@ -48,7 +48,6 @@ H1 = "--h1" in sys.argv
 #   v0..v63 xb k-steps 0, 1;  a128..a191 xb k-steps 2, 3;  a0..a127 yacc;  v64..v95 hacc;  v96..v127 tile slots;
 #   v128..v191 hb (two buffers);  v192..v199 bias;  v200 scale;  v202..v209 temporaries;  v210..v219 addresses
 NT4 = "--nt=4" in sys.argv
-assert not (NT4 and H1), "the 64-token build exists in split-fp16 form"
 
 NT = 4 if NT4 else 3
 RING = 3 if NT4 else 5
@@ -402,7 +401,7 @@ def stage_h1(kind, hb_cur, epi_ops, next_reads, with_aux, label):
     first += weave(groups[0], [], first_misc, misc_per=3)
     first.append(f"s_waitcnt lgkmcnt({(2 if live[2] else 0) + aux})")
     first += weave(groups[1], [], tile_reads(3) if live[3] else [])
-    first.append("s_waitcnt vmcnt(6) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
+    first.append(f"s_waitcnt vmcnt({2 * (RING - 2)}) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
     if "nobarrier" not in EXPERIMENT:
         first.append("s_barrier")
     h = handoff(next_reads, with_aux, label)
@@ -525,8 +524,8 @@ def generate():
         if H1 and ks_in == 4:
             # hacc[0] is complete after the first half of the A stage: its three units under the second half, hacc[1]'s
             # under the B stage of the chunk before (stage_h1)
-            a_epi = {0: units[0] + units[1] + units[2]}
-            epi = units[3] + units[4] + units[5]
+            a_epi = {0: [op for u_ in units[:NT] for op in u_]}
+            epi = [op for u_ in units[NT:] for op in u_]
         elif H1:
             a_epi = None
             epi = [op for u_ in units for op in u_]
@@ -609,7 +608,7 @@ def main():
             out_dir = a.split("=", 1)[1]
     SHAPE = SHAPES[shape]
     lines = generate()
-    fam, flag = ("h1", " --h1") if H1 else ("h3n4", " --nt=4") if NT4 else ("h3", "")
+    fam, flag = ("h1n4", " --h1 --nt=4") if H1 and NT4 else ("h1", " --h1") if H1 else ("h3n4", " --nt=4") if NT4 else ("h3", "")
     base = os.path.join(out_dir, f"tw_{fam}_{SHAPE['tag']}_asm.inc")
     out = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape}{flag} - do not edit.  Body of the {shape} MLP asm statement",
            "// (see the generator for the register map and the schedule)."]

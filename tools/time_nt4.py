@@ -8,6 +8,7 @@ from tests import helpers as H
 from timewarp_amd import _lib
 
 lib = _lib.load()
+PATH = 4 if "--h1" in sys.argv else 3   # --h1: the fast mode (TW_PATH_FUSED_H1) on both layouts
 sd = H.full_kernel_sd()
 g = torch.Generator().manual_seed(0)
 for V, S in ((60, 256), (60, 512), (60, 768), (60, 1024), (64, 512), (49, 512), (52, 1000)):
@@ -18,7 +19,7 @@ for V, S in ((60, 256), (60, 512), (60, 768), (60, 1024), (64, 512), (49, 512), 
     res = {}
     for name, flags in (("wide", 131072), ("64-token", 65536), ("chosen", 0)):
         lib.tw_debug_set_flags(flags)
-        m = H.tw_kernel_model(sd, path=3); m._defer_range_check += 1
+        m = H.tw_kernel_model(sd, path=PATH); m._defer_range_check += 1
         f = lambda: m.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None, edge_batch_idx=None,
                                                    masked_elements=mk, num_samples=S, z_coords=zc, z_velocs=zv)
         for _ in range(2): f()
