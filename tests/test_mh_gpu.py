@@ -659,6 +659,41 @@ def test_mh_iterations_on_a_65_atom_peptide_vs_oracle(path):
     _assert_chain_matches_oracle(got, ref, tol=1e-5, stat_tol=2e-4)
 
 
+def test_mh_iterations_on_a_61_atom_peptide_in_64_token_waves_vs_oracle():
+    """bench.py --config 4aa's molecule (NAQQ: the reference's OpenMM test peptide with one asparagine cut back to alanine, 61
+    atoms) through tw_mh_iteration on the 64-token build of the split-fp16 kernel (forced: 16 proposals are one round of
+    workgroups in either layout, where the launch code would take the wide one), against the oracle loop and the C energy
+    oracle on shared host noise."""
+    import bench
+    from timewarp_amd import _lib
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.utils.evaluation_utils import MetropolisHastingsChain, sample_with_model
+
+    name, types, coords, masses, energy = bench.molecule("4aa")
+    assert name == "NAQQ" and len(types) == 61
+    sd = H.mh_state_dict("scaled", True, out_scale=3e-5, coords_log_scale=-7.5)
+    S, N = 16, 40
+    kw = dict(accept=True, num_proposal_steps=S, random_velocs=True, resample_velocs=True)
+    ref = mo.sample_with_model(types[None], coords[None], torch.zeros(1, 61, 3), torch.zeros(1, 61, dtype=torch.bool),
+                               mo.OracleModel(sd, H.FULL_KERNEL_SPEC), H.OracleAmberEnergy(energy.tables), masses, N,
+                               H.HostNoise(2), **kw)
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    try:
+        lib.tw_debug_set_flags(65536)
+        model = H.tw_kernel_model(sd, path=3)
+        chain = MetropolisHastingsChain(single_state_batch("naqq", types, coords), model, dev, energy, masses,
+                                        noise=H.HostNoise(2, "cuda"), **kw)
+        assert chain._fused
+        got = sample_with_model(single_state_batch("naqq", types, coords), model, dev, energy, masses, N, disable_tqdm=True,
+                                noise=H.HostNoise(2, "cuda"), **kw)
+    finally:
+        lib.tw_debug_set_flags(0)
+    assert ref[2] >= 1
+    H.assert_not_demoted(model)
+    _assert_chain_matches_oracle(got, ref, tol=1e-5, stat_tol=2e-4)
+
+
 @pytest.mark.parametrize("path", [1, 3])
 def test_dense_flow_mh_iterations_vs_oracle(path):
     """BASELINE config 4 as a sampler: whole MH iterations with the full-size dense-softmax flow (transformer_nvp) on the
