@@ -454,11 +454,15 @@ def test_encoder_stack_statement_layer_counts_vs_oracle(n_layers):
 
 
 @pytest.mark.parametrize("V,lens,paths", [(64, [64, 51], (FUSED, SIMPLE)), (70, [70, 44, 70], (0, SIMPLE, H3)),
-                                          (100, [100, 87], (0, H3)), (96, [96, 90, 96], (H3,)), (160, [160, 131], (H3,))])
+                                          (100, [100, 87], (0, H3)), (96, [96, 90, 96], (H3,)), (160, [160, 131], (H3,)),
+                                          (81, [81, 70, 81], (H3,)), (88, [88, 88, 61, 88, 88], (SIMPLE, H3)),
+                                          (95, [95, 95, 95], (H3,))])
 def test_large_molecules_vs_oracle(V, lens, paths):
     """Maximum sizes: 64 atoms is the largest molecule a fused f32 wave holds (4 tiles); beyond it TW_PATH_AUTO has to fall
     back to the per-op path, while the split-fp16 kernel's wide layout goes on to 160 atoms (two, then one molecule per
-    workgroup).  All above 25 atoms, so the scores follow torch.cdist's matmul branch."""
+    workgroup).  All above 25 atoms, so the scores follow torch.cdist's matmul branch.  81 .. 95 atoms (refused
+    until r04) take a slot stride of 96 instead of sitting back to back - molecule 0 on waves 0-1, molecule 1 on waves 2-3,
+    padding slots behind each - odd and even row counts, so that the last workgroup holds one molecule and two."""
     sd = H.full_kernel_sd()
     g = torch.Generator().manual_seed(300 + V)
     B = len(lens)
@@ -477,6 +481,18 @@ def test_large_molecules_vs_oracle(V, lens, paths):
                                y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
         H.assert_not_demoted(m)
         assert H.rel_err(out, ref) < TOL, (path, H.rel_err(out, ref))
+    if 81 <= V <= 95:
+        # the reverse pass as well (its coupling prologue reduces the log-determinant over the strided slots)
+        S = 5
+        zc, zv = torch.randn(S, 1, V, 3, generator=g), torch.randn(S, 1, V, 3, generator=g)
+        mk1 = mask[1:2]
+        ryc, ryv, rlp = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, at[1:2], x_c[1:2], x_v[1:2], mk1, zc, zv)
+        m = H.tw_kernel_model(sd, path=H3)
+        yc, yv, lp = m.conditional_sample_with_logp(atom_types=at[1:2].cuda(), x_coords=x_c[1:2].cuda(), x_velocs=x_v[1:2].cuda(),
+                                                    adj_list=None, edge_batch_idx=None, masked_elements=mk1.cuda(),
+                                                    num_samples=S, z_coords=zc.cuda(), z_velocs=zv.cuda())
+        H.assert_not_demoted(m)
+        assert H.rel_err(yc.cpu(), ryc) < TOL and H.rel_err(yv.cpu(), ryv) < TOL and H.rel_err(lp.cpu(), rlp) < TOL
     if V > 64:
         with pytest.raises(RuntimeError, match="unsupported"):
             H.tw_kernel_model(sd, path=FUSED).log_likelihood(

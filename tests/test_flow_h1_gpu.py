@@ -94,7 +94,7 @@ def test_full_size_S1000_rows_and_round_trip():
 
 
 @pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25]), (48, [48, 40]),
-                                    (60, [60, 51, 60, 60, 44]), (100, [100, 87, 100]), (160, [160, 131])])
+                                    (60, [60, 51, 60, 60, 44]), (100, [100, 87, 100]), (160, [160, 131]), (88, [88, 61, 88])])
 def test_ragged_batches_vs_split_fp16_kernel(V, lens):
     """Padded atoms, several molecules per wave (windowed mixing), one per wave (full mixing), and the wide layout (49 - 160
     atoms: molecules packed over a workgroup's four waves, tw_h1_attns_asm.inc + the per-section in / FFN / out statements): log_likelihood of a

@@ -119,8 +119,8 @@ def test_execution_path_from_environment(monkeypatch):
 
 def test_path_supported_sweep():
     """tw_flow_path_supported over 1 .. 200 atoms: the split-fp16 kernel takes 1 .. 48 (48-token waves), the wide
-    layout 25 .. 160 except 81 .. 95 (wave 1 would span two molecules over eleven key tiles = six key groups, the statement
-    has five); the single-MFMA fast path the same set; the f32 kernel 1 .. 64."""
+    layout 25 .. 160 (81 .. 95 with a slot stride of 96: back to back, wave 1 would span two molecules over eleven key tiles =
+    six key groups, the statement has five); the single-MFMA fast path the same set; the f32 kernel 1 .. 64."""
     import ctypes as C
     from timewarp_amd import _lib, synthetic
     import timewarp_amd as tw
@@ -128,7 +128,7 @@ def test_path_supported_sweep():
     lib = _lib.load()
     desc = tw.model_constructor(synthetic.kernel_transformer_nvp_config()).dims.to_desc()
     sup = lambda path: [v for v in range(1, 201) if lib.tw_flow_path_supported(C.byref(desc), v, path) == 1]
-    assert sup(3) == list(range(1, 81)) + list(range(96, 161))
+    assert sup(3) == list(range(1, 161))
     assert sup(4) == sup(3)   # the single-MFMA fast path: wherever the split-fp16 kernel runs kernel attention
     assert sup(1) == list(range(1, 65))
     assert sup(2) == list(range(1, 201)) and sup(0) == list(range(1, 201))

@@ -154,27 +154,36 @@ static size_t h3_sf_lds_bytes(int H, int V, int mpw) {
 // tokens).  false if a wave needs more than H3W_NG groups (V > 160) or the molecule does not fit a workgroup.
 struct H3Wide {
   int mpwg;
+  int stride;  // token slots per molecule: V (back to back), or 96 where that needs a sixth key group (81 .. 95 atoms)
   int win[4];  // bytes: 32 * K0
 };
 // Geometrically possible from 25 atoms on (below that a 48-token wave already holds two or more whole molecules and its
-// windowed mixing is cheaper); 81 .. 95 atoms would need a sixth key group for wave 1 and are refused (h3_wide_choice).
+// windowed mixing is cheaper).  Molecules sit back to back (slot stride V) - except 81 .. 95 atoms, where wave 1 would then
+// span the end of molecule 0 and most of molecule 1 and need a sixth key group: those take a stride of 96 slots (molecule 0
+// on waves 0-1, molecule 1 on waves 2-3, three key groups each; the slots between V and 96 are padding tokens).
 #define H3W_MIN_ATOMS 25
-static bool h3_wide_geom(int V, H3Wide* w) {
-  if (V < H3W_MIN_ATOMS || V > 64 * H3_NT) return false;
-  w->mpwg = (64 * H3_NT) / V;
+static bool h3_wide_geom_stride(int V, int P, H3Wide* w) {
+  w->mpwg = (64 * H3_NT) / P;
+  w->stride = P;
   for (int wave = 0; wave < 4; ++wave) {
     const int lo = 16 * H3_NT * wave, hi = lo + 16 * H3_NT - 1;
-    int m0 = lo / V, m1 = hi / V;
+    int m0 = lo / P, m1 = hi / P;
+    if (lo - m0 * P >= V) ++m0;  // the wave starts in the padding behind molecule m0
     if (m1 >= w->mpwg) m1 = w->mpwg - 1;
     int k0 = 0;
     if (m0 <= m1) {
-      const int first = (m0 * V) / 16, last = ((m1 + 1) * V - 1) / 16;
+      const int first = (m0 * P) / 16, last = (m1 * P + V - 1) / 16;
       if ((last - first + 2) / 2 > H3W_NG) return false;
       k0 = first < 12 - 2 * H3W_NG ? first : 12 - 2 * H3W_NG;
     }
     w->win[wave] = 32 * k0;
   }
   return true;
+}
+static bool h3_wide_geom(int V, H3Wide* w) {
+  if (V < H3W_MIN_ATOMS || V > 64 * H3_NT) return false;
+  if (h3_wide_geom_stride(V, V, w)) return true;
+  return V <= 96 && h3_wide_geom_stride(V, 96, w);
 }
 static size_t h3w_sf_lds_bytes(int V, int mpwg) {
   const size_t MV = (size_t)mpwg * V;
@@ -682,7 +691,7 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
 // with S the block-diagonal matrix of the block's molecules' normalised scores (zero outside a molecule / masked keys).
 struct H3WideWin { int w[4]; };
 __global__ void h3w_score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
-                                      const float* __restrict__ ls, int H, int V, int mpwg, int64_t n_rows,
+                                      const float* __restrict__ ls, int H, int V, int P, int mpwg, int64_t n_rows,
                                       int64_t n_cond, int normalise, char* __restrict__ sfrag, ScoreBasis basis,
                                       int64_t variant_bytes, int use_mm, H3WideWin win) {
   extern __shared__ float sm[];
@@ -729,15 +738,16 @@ __global__ void h3w_score_frag_kernel(const float* __restrict__ x, const uint8_t
     const int lane = i & 63, rest = i >> 6;
     const int jt = rest % H3_NT, gi = (rest / H3_NT) % H3W_NG, w = rest / (H3_NT * H3W_NG);
     const int tq = 16 * H3_NT * w + 16 * jt + (lane & 15);
-    const int mq = tq / V;
-    const bool qok = mq < mpwg;
-    const float* row = E + (int64_t)(qok ? tq : 0) * V;  // row of (molecule mq, atom tq - mq V): index mq V + (tq - mq V) = tq
+    const int mq = tq / P, aq = tq - mq * P;  // slot -> (molecule, atom); atoms >= V are the padding of a strided molecule
+    const bool qok = mq < mpwg && aq < V;
+    const float* row = E + (int64_t)(qok ? mq * V + aq : 0) * V;
     const int k0 = 16 * (win.w[w] / 32 + 2 * gi) + 8 * (lane >> 4);
     h8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int tk = k0 + e;
-      const float val = (qok && tk / V == mq) ? row[tk - mq * V] : 0.f;
+      const int ak = tk - mq * P;
+      const float val = (qok && ak >= 0 && ak < V) ? row[ak] : 0.f;
       const _Float16 hh = (_Float16)val;
       hi[e] = hh;
       lo[e] = (_Float16)(val - (float)hh);
@@ -772,6 +782,7 @@ struct H3Params {
   float* dump;
   int64_t n_rows, n_cond;
   int V, mpw, nblocks;
+  int P;  // token slots per molecule in the block: V, or the wide layout's padded stride (H3Wide::stride)
   int H, n_layers, ff_chunks, hid_chunks, d_emb;
   float eps;
   int net_sel;
@@ -1265,17 +1276,18 @@ netblock_h3_kernel(const H3Params p) {
   // token slot -> (molecule, atom) without an integer division per token: floor(t / V) = (t * ceil(2^16 / V)) >> 16 for
   // t < 192, V <= 160 (t * (ceil(2^16 / V) * V - 2^16) < 2^16); the row's conditioning state without a 64-bit modulo in the
   // two layouts the flow uses (one shared state: the reverse pass of an MH iteration; one per row: the forward pass)
-  const unsigned inv_v = (65536u + (unsigned)p.V - 1u) / (unsigned)p.V;
+  const unsigned inv_v = (65536u + (unsigned)p.P - 1u) / (unsigned)p.P;
   const bool cond_shared = p.n_cond == 1, cond_per_row = p.n_cond >= p.n_rows;
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     const int t = slot0 + 16 * jt + i16;
     const int q = (int)(((unsigned)t * inv_v) >> 16);
     const int64_t n = row0 + q;
-    const bool ok = active && q < p.mpw && n < p.n_rows;
+    const int atom = t - q * p.P;
+    const bool ok = active && q < p.mpw && n < p.n_rows && atom < p.V;  // (atom >= V: padding slots of a strided molecule)
     tok_row[jt] = ok ? n : -1;
     tok_cond[jt] = !ok || cond_shared ? 0 : (cond_per_row ? n : n % p.n_cond);
-    tok_atom[jt] = t - q * p.V;
+    tok_atom[jt] = ok ? atom : 0;
   }
   // z_other of this lane's tokens: from memory, or - when the previous coupling layer's update is still pending - that
   // update applied on the fly (PrevCoupling, tw_common.h; same arithmetic as coupling_kernel)
@@ -1330,7 +1342,7 @@ netblock_h3_kernel(const H3Params p) {
           const int64_t n = row0 + lane;
           if (n < p.n_rows) {
             float acc = 0.f;
-            for (int a = 0; a < p.V; ++a) acc += scr[lane * p.V + a];
+            for (int a = 0; a < p.V; ++a) acc += scr[lane * p.P + a];
             p.prev.delta_logp[n] -= p.prev.reverse ? -acc : acc;
           }
         }
@@ -2404,6 +2416,7 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.n_rows = a.n_rows;
   p.n_cond = a.n_cond;
   p.V = a.n_atoms;
+  p.P = wide ? wd.stride : a.n_atoms;
   p.mpw = fg.mpw;
   p.nblocks = (int)((a.n_rows + fg.mpw - 1) / fg.mpw);
   p.H = d.n_heads;
@@ -2512,7 +2525,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
     H3WideWin win;
     for (int i = 0; i < 4; ++i) win.w[i] = wd.win[i];
     hipLaunchKernelGGL(h3w_score_frag_kernel, dim3((unsigned)nblocks, (unsigned)d.n_heads, (unsigned)basis.n_variants), dim3(512),
-                       shmw, a.stream, a.x_coords, a.masked, lsw, d.n_heads, V, wd.mpwg, a.n_rows, a.n_cond, d.normalise, w.sfrag,
+                       shmw, a.stream, a.x_coords, a.masked, lsw, d.n_heads, V, wd.stride, wd.mpwg, a.n_rows, a.n_cond, d.normalise, w.sfrag,
                        basis, vbw, V > 25 ? 1 : 0, win);
     TW_LAUNCH_CHECK();
     *variant_bytes = vbw;
