@@ -357,7 +357,9 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *              (the launch code otherwise picks the layout that needs fewer rounds of the chip; same results up to the last
  *              bits; A/B switch and tests)
  *   bit 16 (65536) molecules of 49 .. 64 atoms: always 64-token waves (one molecule per wave); bit 17 (131072): never -
- *              the wide layout instead (the launch code otherwise picks by rounds of the chip x cost per workgroup) */
+ *              the wide layout instead (the launch code otherwise picks by rounds of the chip x cost per workgroup)
+ *   bit 18 (262144) wide layout, 65 .. 96 atoms: five-group key windows (molecules back to back where that fits) instead of
+ *              the 96-slot stride with three-group windows; same results up to the last bits (A/B switch and tests) */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

@@ -577,6 +577,57 @@ def test_layout_choice_by_rounds_of_the_chip():
             assert H.rel_err(res[flag][0][rows], ryc) < TOL and H.rel_err(res[flag][1][rows], rlp) < TOL, (S, flag)
 
 
+@pytest.mark.parametrize("V,lens", [(65, [65, 65, 50, 65, 65]), (70, [70, 44, 70]), (80, [80, 80, 80, 66]), (88, [88, 61, 88]),
+                                    (96, [96, 90, 96, 96])])
+def test_wide_layout_three_group_windows_vs_five(V, lens):
+    """r04: molecules of 65 .. 96 atoms sit at a slot stride of 96 in the wide layout (two per workgroup either way) - each on
+    its own pair of waves, so a wave's keys are its molecule's three K = 32 groups: tw_h3_attns3_asm.inc (54 mixing MFMAs per
+    head and k-step, 18 fragment loads per head) instead of the five-group statement (90 / 30; tw_debug_set_flags 262144,
+    molecules back to back where that fits).  Both against the oracle on ragged batches of odd and even row counts, on the
+    split-fp16 kernel; the fast mode's two statements against each other at its own error."""
+    from timewarp_amd import _lib
+
+    sd = H.full_kernel_sd()
+    g = torch.Generator().manual_seed(1200 + V)
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.55
+    x_v = torch.randn(B, V, 3, generator=g) * 0.5
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+    y_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    args = dict(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(), y_velocs=y_v.cuda(),
+                adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+    lib = _lib.load()
+    outs = {}
+    try:
+        for path in (H3, 4):
+            for flag in (0, 262144):
+                lib.tw_debug_set_flags(flag)
+                m = H.tw_kernel_model(sd, path=path)
+                outs[path, flag] = m.log_likelihood(**args).cpu()
+                H.assert_not_demoted(m)
+    finally:
+        lib.tw_debug_set_flags(0)
+    assert H.rel_err(outs[H3, 0], ref) < TOL, H.rel_err(outs[H3, 0], ref)
+    assert H.rel_err(outs[H3, 262144], ref) < TOL
+    assert H.rel_err(outs[H3, 0], outs[H3, 262144]) < 2e-6
+    assert 0 < H.rel_err(outs[4, 0], ref) < 3e-3 and H.rel_err(outs[4, 0], outs[4, 262144]) < 3e-3
+    # the reverse pass of one conditioning state (shared score fragments), five proposals
+    S = 5
+    zc, zv = torch.randn(S, 1, V, 3, generator=g), torch.randn(S, 1, V, 3, generator=g)
+    ryc, ryv, rlp = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, at[2:3], x_c[2:3], x_v[2:3], mask[2:3], zc, zv)
+    m = H.tw_kernel_model(sd, path=H3)
+    yc, yv, lp = m.conditional_sample_with_logp(atom_types=at[2:3].cuda(), x_coords=x_c[2:3].cuda(), x_velocs=x_v[2:3].cuda(),
+                                                adj_list=None, edge_batch_idx=None, masked_elements=mask[2:3].cuda(),
+                                                num_samples=S, z_coords=zc.cuda(), z_velocs=zv.cuda())
+    H.assert_not_demoted(m)
+    assert H.rel_err(yc.cpu(), ryc) < TOL and H.rel_err(yv.cpu(), ryv) < TOL and H.rel_err(lp.cpu(), rlp) < TOL
+
+
 @pytest.mark.parametrize("V,lens", [(49, [49, 49, 40, 49, 49, 49, 49, 31, 49]), (52, [52, 52, 52, 45, 52]),
                                     (60, [60, 60, 60, 60, 51, 60, 60, 60, 60, 60, 42]), (64, [64, 64, 50, 64, 64, 64])])
 def test_64_token_waves_on_49_to_64_atoms_vs_oracle(V, lens):

@@ -386,6 +386,8 @@ def test_generated_asm_includes_are_current(tmp_path):
                  ["tools/gen_h3_ffn_asm.py", "--shape=in", "--h1"], ["tools/gen_h3_ffn_asm.py", "--shape=out", "--h1"],
                  ["tools/gen_h3_enc_asm.py", "--h1"], ["tools/gen_h3_enc_asm.py", "--mode=windowed", "--h1"],
                  ["tools/gen_h3_ffn_asm.py", "--shape=ffn", "--h1"], ["tools/gen_h3_attn_wide_asm.py", "--h1"],
+                 # wide layout, 65-96 atoms at the 96-slot stride: three-group windows, tw_h?_attns3_*
+                 ["tools/gen_h3_attn_wide_asm.py", "--ng=3"], ["tools/gen_h3_attn_wide_asm.py", "--ng=3", "--h1"],
                  # 64-token waves (49-64 atoms): tw_h3n4_*
                  ["tools/gen_h3_ffn_asm.py", "--shape=ffn", "--nt=4"], ["tools/gen_h3_attn_asm.py", "--nt=4"],
                  ["tools/gen_h3_ffn_asm.py", "--shape=in", "--nt=4"], ["tools/gen_h3_ffn_asm.py", "--shape=out", "--nt=4"],
@@ -394,7 +396,7 @@ def test_generated_asm_includes_are_current(tmp_path):
         subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
                        stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 44
+    assert len(names) == 48
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n

@@ -78,8 +78,9 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3W_WAVE_LDS 28672
 #define H3W_XT_ROW 416                  // bytes per feature row: 192 tokens + 16 pad (104 dwords: conflict-free ds_read_b128)
 #define H3W_XT_LO (128 * H3W_XT_ROW)
-#define H3W_NG 5                        // K = 32 key groups in a wave's key window
-#define H3W_FRAG_HEAD (H3W_NG * H3_NT * 2048)  // score fragments of one (wave, head): [group][query tile][hi 1 KiB | lo 1 KiB]
+#define H3W_NG 5                        // K = 32 key groups in a wave's key window (tw_h3_attns_asm.inc) ...
+#define H3W_NG3 3                       // ... or three, for 65 .. 96 atoms at a slot stride of 96 (tw_h3_attns3_asm.inc)
+#define H3W_FRAG_HEAD(ng) ((ng) * H3_NT * 2048)  // score fragments of one (wave, head): [group][query tile][hi 1 KiB | lo 1 KiB]
 #define H3W_SIDE_LDS_OFFSET (H3_RING * H3_STAGE_BYTES + 4 * H3W_WAVE_LDS)
 #define H3W_LDS_BYTES (H3W_SIDE_LDS_OFFSET + H3_SIDE_LDS_BYTES)
 #define H3_TARGET_MAX 4096.0f       // |w| * 2^s is scaled up to just below this
@@ -154,17 +155,21 @@ static size_t h3_sf_lds_bytes(int H, int V, int mpw) {
 // tokens).  false if a wave needs more than H3W_NG groups (V > 160) or the molecule does not fit a workgroup.
 struct H3Wide {
   int mpwg;
-  int stride;  // token slots per molecule: V (back to back), or 96 where that needs a sixth key group (81 .. 95 atoms)
+  int stride;  // token slots per molecule: V (back to back), or 96 (65 .. 96 atoms: each molecule on its own pair of waves)
+  int ng;      // key groups of a wave's window: 5 (160 keys), or 3 with the 96-slot stride (a wave's keys = its molecule's 96 slots)
   int win[4];  // bytes: 32 * K0
 };
 // Geometrically possible from 25 atoms on (below that a 48-token wave already holds two or more whole molecules and its
-// windowed mixing is cheaper).  Molecules sit back to back (slot stride V) - except 81 .. 95 atoms, where wave 1 would then
-// span the end of molecule 0 and most of molecule 1 and need a sixth key group: those take a stride of 96 slots (molecule 0
-// on waves 0-1, molecule 1 on waves 2-3, three key groups each; the slots between V and 96 are padding tokens).
+// windowed mixing is cheaper).  Molecules sit back to back (slot stride V) with five-group windows - except 65 .. 96 atoms:
+// two molecules per workgroup either way, so each takes 96 slots (molecule 0 on waves 0-1, molecule 1 on waves 2-3, the
+// slots between V and 96 are padding tokens) and a wave's keys are its own molecule's three groups: 54 instead of 90 mixing
+// MFMAs per head and k-step, 18 instead of 30 fragment loads per head.  (Back to back, 81 .. 95 atoms would even need a SIXTH
+// group for wave 1 and were refused until r04.)  tw_debug_set_flags bit 18 (262144): five-group statement only (A/B, tests).
 #define H3W_MIN_ATOMS 25
-static bool h3_wide_geom_stride(int V, int P, H3Wide* w) {
+static bool h3_wide_geom_stride(int V, int P, int NG, H3Wide* w) {
   w->mpwg = (64 * H3_NT) / P;
   w->stride = P;
+  w->ng = NG;
   for (int wave = 0; wave < 4; ++wave) {
     const int lo = 16 * H3_NT * wave, hi = lo + 16 * H3_NT - 1;
     int m0 = lo / P, m1 = hi / P;
@@ -173,8 +178,8 @@ static bool h3_wide_geom_stride(int V, int P, H3Wide* w) {
     int k0 = 0;
     if (m0 <= m1) {
       const int first = (m0 * P) / 16, last = (m1 * P + V - 1) / 16;
-      if ((last - first + 2) / 2 > H3W_NG) return false;
-      k0 = first < 12 - 2 * H3W_NG ? first : 12 - 2 * H3W_NG;
+      if ((last - first + 2) / 2 > NG) return false;
+      k0 = first < 12 - 2 * NG ? first : 12 - 2 * NG;
     }
     w->win[wave] = 32 * k0;
   }
@@ -182,8 +187,9 @@ static bool h3_wide_geom_stride(int V, int P, H3Wide* w) {
 }
 static bool h3_wide_geom(int V, H3Wide* w) {
   if (V < H3W_MIN_ATOMS || V > 64 * H3_NT) return false;
-  if (h3_wide_geom_stride(V, V, w)) return true;
-  return V <= 96 && h3_wide_geom_stride(V, 96, w);
+  if (V > 64 && V <= 96 && !(g_debug_flags & 262144) && h3_wide_geom_stride(V, 96, H3W_NG3, w)) return true;
+  if (h3_wide_geom_stride(V, V, H3W_NG, w)) return true;
+  return V <= 96 && h3_wide_geom_stride(V, 96, H3W_NG, w);
 }
 static size_t h3w_sf_lds_bytes(int V, int mpwg) {
   const size_t MV = (size_t)mpwg * V;
@@ -686,12 +692,12 @@ __global__ void h3_score_frag_kernel(const float* __restrict__ x, const uint8_t*
 }
 
 // Wide layout: fragments of one head of one workgroup block.  grid (blocks, heads, basis variants).  Output per
-// (wave w, head h): H3W_NG groups x 3 query tiles x [hi | lo] KiB; element (lane, e) of (group gi, tile jt) =
+// (wave w, head h): NG groups x 3 query tiles x [hi | lo] KiB; element (lane, e) of (group gi, tile jt) =
 //   S[query token 48 w + 16 jt + (lane & 15)][key token 16 (K0_w + 2 gi) + 8 (lane >> 4) + e]
 // with S the block-diagonal matrix of the block's molecules' normalised scores (zero outside a molecule / masked keys).
 struct H3WideWin { int w[4]; };
 __global__ void h3w_score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
-                                      const float* __restrict__ ls, int H, int V, int P, int mpwg, int64_t n_rows,
+                                      const float* __restrict__ ls, int H, int V, int P, int NG, int mpwg, int64_t n_rows,
                                       int64_t n_cond, int normalise, char* __restrict__ sfrag, ScoreBasis basis,
                                       int64_t variant_bytes, int use_mm, H3WideWin win) {
   extern __shared__ float sm[];
@@ -733,10 +739,10 @@ __global__ void h3w_score_frag_kernel(const float* __restrict__ x, const uint8_t
       for (int m = 0; m < V; ++m) row[m] = row[m] / den;
   }
   __syncthreads();
-  char* out = sfrag + blockIdx.z * variant_bytes + blk * (int64_t)4 * H * H3W_FRAG_HEAD;
-  for (int i = t; i < 4 * H3W_NG * H3_NT * 64; i += nthr) {
+  char* out = sfrag + blockIdx.z * variant_bytes + blk * (int64_t)4 * H * H3W_FRAG_HEAD(NG);
+  for (int i = t; i < 4 * NG * H3_NT * 64; i += nthr) {
     const int lane = i & 63, rest = i >> 6;
-    const int jt = rest % H3_NT, gi = (rest / H3_NT) % H3W_NG, w = rest / (H3_NT * H3W_NG);
+    const int jt = rest % H3_NT, gi = (rest / H3_NT) % NG, w = rest / (H3_NT * NG);
     const int tq = 16 * H3_NT * w + 16 * jt + (lane & 15);
     const int mq = tq / P, aq = tq - mq * P;  // slot -> (molecule, atom); atoms >= V are the padding of a strided molecule
     const bool qok = mq < mpwg && aq < V;
@@ -752,7 +758,7 @@ __global__ void h3w_score_frag_kernel(const float* __restrict__ x, const uint8_t
       hi[e] = hh;
       lo[e] = (_Float16)(val - (float)hh);
     }
-    char* base = out + ((int64_t)(w * H + h) * (H3W_NG * H3_NT) + gi * H3_NT + jt) * 2048;
+    char* base = out + ((int64_t)(w * H + h) * (NG * H3_NT) + gi * H3_NT + jt) * 2048;
     *(h8*)(base + lane * 16) = hi;
     *(h8*)(base + 1024 + lane * 16) = lo;
   }
@@ -782,6 +788,7 @@ struct H3Params {
   float* dump;
   int64_t n_rows, n_cond;
   int V, mpw, nblocks;
+  int ng;  // wide layout: key groups of a wave's window (H3Wide::ng: 5, or 3 -> the tw_h?_attns3 statement)
   int P;  // token slots per molecule in the block: V, or the wide layout's padded stride (H3Wide::stride)
   int H, n_layers, ff_chunks, hid_chunks, d_emb;
   float eps;
@@ -1565,7 +1572,7 @@ netblock_h3_kernel(const H3Params p) {
   stamp(1);
 
   const char* sf_net = p.sfrag + (int64_t)(net * p.n_layers) * p.sf_variant_bytes +
-                       (WIDE ? (int64_t)((p.sfrag_shared ? 0 : wg * 4) + wave) * p.H * H3W_FRAG_HEAD
+                       (WIDE ? (int64_t)((p.sfrag_shared ? 0 : wg * 4) + wave) * p.H * H3W_FRAG_HEAD(p.ng)
                              : (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * SF_BYTES));
 
   const float* sl = (const float*)(lds + SIDE_LDS_OFFSET);  // this layer's side block, staged in LDS
@@ -1938,7 +1945,18 @@ netblock_h3_kernel(const H3Params p) {
         // wide layout (tools/gen_h3_attn_wide_asm.py): mixing against the wave's key window of the shared X^T tile
         const unsigned xt_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(lds + RING * H3_STAGE_BYTES);
         const int win = __builtin_amdgcn_readfirstlane(wave == 0 ? p.win[0] : wave == 1 ? p.win[1] : wave == 2 ? p.win[2] : p.win[3]);
+        // (p.ng is launch-uniform: three-group windows for 65 .. 96 atoms at the 96-slot stride, five otherwise)
         if constexpr (H1) {
+          if (p.ng == H3W_NG3) {
+          asm volatile(
+#include "tw_h1_attns3_asm.inc"
+              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
+                [win] "s"(win)
+              :
+#include "tw_h1_attns3_clobbers.inc"
+          );
+          } else {
           asm volatile(
 #include "tw_h1_attns_asm.inc"
               : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -1947,7 +1965,17 @@ netblock_h3_kernel(const H3Params p) {
               :
 #include "tw_h1_attns_clobbers.inc"
           );
-        } else
+          }
+        } else if (p.ng == H3W_NG3) {
+        asm volatile(
+#include "tw_h3_attns3_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
+              [win] "s"(win)
+            :
+#include "tw_h3_attns3_clobbers.inc"
+        );
+        } else {
         asm volatile(
 #include "tw_h3_attns_asm.inc"
             : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -1956,6 +1984,7 @@ netblock_h3_kernel(const H3Params p) {
             :
 #include "tw_h3_attns_clobbers.inc"
         );
+        }
       } else if constexpr (NT == 4 && H1) {
         asm volatile(
 #include "tw_h1n4_attn_asm.inc"
@@ -2348,9 +2377,12 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool
   // + one head of slack: the attention asm block prefetches the "next head" also after the last one
   const int64_t variants = d.cheb_order > 0 ? 2 * d.n_layers : 1;
   if (d.variant == 1) w.sf_variant_bytes = 0;  // dense: no score fragments
-  else if (wide) w.sf_variant_bytes = nblocks * 4 * d.n_heads * H3W_FRAG_HEAD;
+  else if (wide) w.sf_variant_bytes = nblocks * 4 * d.n_heads * H3W_FRAG_HEAD(wd.ng);
   else w.sf_variant_bytes = nblocks * d.n_heads * g.nt * (g.nt == 4 ? H3N4_SF_BYTES : H3_SF_BYTES);
-  w.sfrag = take(variants * w.sf_variant_bytes + (wide ? H3W_FRAG_HEAD : g.nt * (g.nt == 4 ? H3N4_SF_BYTES : H3_SF_BYTES)));
+  // (wide: sized for five-group windows whatever the launch takes - the workspace a caller allocated stays large enough when
+  // tw_debug_set_flags moves between the two statements)
+  w.sfrag = take(wide ? (variants * nblocks * 4 * d.n_heads + 1) * (int64_t)H3W_FRAG_HEAD(H3W_NG)
+                      : variants * w.sf_variant_bytes + g.nt * (g.nt == 4 ? H3N4_SF_BYTES : H3_SF_BYTES));
   w.bytes = p - (char*)base;
   return w;
 }
@@ -2417,6 +2449,7 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.n_cond = a.n_cond;
   p.V = a.n_atoms;
   p.P = wide ? wd.stride : a.n_atoms;
+  p.ng = wide ? wd.ng : 0;
   p.mpw = fg.mpw;
   p.nblocks = (int)((a.n_rows + fg.mpw - 1) / fg.mpw);
   p.H = d.n_heads;
@@ -2513,7 +2546,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
   H3Wide wd;
   if (h3_wide_choice(d, V, a.n_rows, a.h1 != 0)) {
     h3_wide_geom(V, &wd);
-    const int64_t vbw = basis.n_variants > 1 ? nblocks * 4 * d.n_heads * H3W_FRAG_HEAD : 0;
+    const int64_t vbw = basis.n_variants > 1 ? nblocks * 4 * d.n_heads * H3W_FRAG_HEAD(wd.ng) : 0;
     const float* lsw = a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0);
     const size_t shmw = h3w_sf_lds_bytes(V, wd.mpwg);
     TW_REQUIRE(shmw <= H3_SF_LDS_MAX, "score fragments: %zu bytes of LDS for %d atoms", shmw, V);
@@ -2525,7 +2558,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
     H3WideWin win;
     for (int i = 0; i < 4; ++i) win.w[i] = wd.win[i];
     hipLaunchKernelGGL(h3w_score_frag_kernel, dim3((unsigned)nblocks, (unsigned)d.n_heads, (unsigned)basis.n_variants), dim3(512),
-                       shmw, a.stream, a.x_coords, a.masked, lsw, d.n_heads, V, wd.stride, wd.mpwg, a.n_rows, a.n_cond, d.normalise, w.sfrag,
+                       shmw, a.stream, a.x_coords, a.masked, lsw, d.n_heads, V, wd.stride, wd.ng, wd.mpwg, a.n_rows, a.n_cond, d.normalise, w.sfrag,
                        basis, vbw, V > 25 ? 1 : 0, win);
     TW_LAUNCH_CHECK();
     *variant_bytes = vbw;

@@ -26,6 +26,13 @@ import sys
 
 NT = 3
 NG = 5                      # K = 32 key groups per wave window
+# --ng=3: molecules of 65 .. 96 atoms at a slot stride of 96 (two per workgroup, each on its own pair of waves): a wave's
+# keys are its molecule's <= 96 slots = three groups - 54 mixing MFMAs per head and k-step instead of 90, 18 fragment
+# loads per head instead of 30 (tw_h3_attns3_asm.inc; H3Wide::ng in csrc/tw_netblock_h3.hip)
+for _a in sys.argv[1:]:
+    if _a.startswith("--ng="):
+        NG = int(_a.split("=", 1)[1])
+assert NG in (3, 5)
 STAGE, TILES = 9216, 8192
 XT_ROW = 416                # bytes per feature row of the shared transposed tile (104 dwords = 192 tokens + 16 pad)
 XT_LO = 128 * XT_ROW        # offset of the lo half
@@ -333,17 +340,19 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--out-dir="):
             out_dir = a.split("=", 1)[1]
-    base = os.path.join(out_dir, "tw_h1_attns_asm.inc" if H1 else "tw_h3_attns_asm.inc")
-    out = [f"// GENERATED by tools/gen_h3_attn_wide_asm.py{' --h1' if H1 else ''} - do not edit.  Body of the wide-layout attention asm statement."]
+    sfx = "3" if NG == 3 else ""
+    flags = (" --ng=3" if NG == 3 else "") + (" --h1" if H1 else "")
+    base = os.path.join(out_dir, f"tw_h1_attns{sfx}_asm.inc" if H1 else f"tw_h3_attns{sfx}_asm.inc")
+    out = [f"// GENERATED by tools/gen_h3_attn_wide_asm.py{flags} - do not edit.  Body of the wide-layout attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")
     clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A)] + [f'"s{i}"' for i in range(84, 96)] + \
            ['"vcc"', '"scc"', '"memory"']
-    cl = [f"// GENERATED by tools/gen_h3_attn_wide_asm.py{' --h1' if H1 else ''} - clobber list of the wide-layout attention asm statement."]
+    cl = [f"// GENERATED by tools/gen_h3_attn_wide_asm.py{flags} - clobber list of the wide-layout attention asm statement."]
     for i in range(0, len(clob), 12):
         cl.append(", ".join(clob[i:i + 12]) + ("," if i + 12 < len(clob) else ""))
     open(base.replace("_asm.inc", "_clobbers.inc"), "w").write("\n".join(cl) + "\n")
-    print(f"wide: {len(lines)} instructions, {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs")
+    print(f"wide{flags}: {len(lines)} instructions, {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs")
 
 
 main()
