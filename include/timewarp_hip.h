@@ -359,7 +359,9 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *   bit 16 (65536) molecules of 49 .. 64 atoms: always 64-token waves (one molecule per wave); bit 17 (131072): never -
  *              the wide layout instead (the launch code otherwise picks by rounds of the chip x cost per workgroup)
  *   bit 18 (262144) wide layout, 65 .. 96 atoms: five-group key windows (molecules back to back where that fits) instead of
- *              the 96-slot stride with three-group windows; same results up to the last bits (A/B switch and tests) */
+ *              the 96-slot stride with three-group windows; same results up to the last bits (A/B switch and tests)
+ *   bit 19 (524288) wide layout: the transposed tile written with two-byte stores (r03's form) instead of through the matrix
+ *              pipe; bit-identical results (A/B switch and tests) */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

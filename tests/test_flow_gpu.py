@@ -577,6 +577,44 @@ def test_layout_choice_by_rounds_of_the_chip():
             assert H.rel_err(res[flag][0][rows], ryc) < TOL and H.rel_err(res[flag][1][rows], rlp) < TOL, (S, flag)
 
 
+@pytest.mark.parametrize("V,lens,layout", [(30, [30, 28, 25, 30, 30, 30, 30], 32768), (60, [60, 44, 60, 60], 131072),
+                                           (70, [70, 44, 70], 0), (100, [100, 87, 100], 0), (160, [160, 131], 0)])
+def test_wide_layout_transposed_tile_through_matrix_pipe(V, lens, layout):
+    """r04: the wide layout's shared transposed tile is written through the matrix pipe (K = 16 MFMAs against the identity, 48
+    eight-byte stores per lane and layer) instead of with 192 two-byte stores (tw_debug_set_flags bit 19 keeps r03's form: the
+    section profile had 46 k cycles per layer there).  The transposition is exact, so both builds must agree bit for bit -
+    on the split-fp16 kernel and on the fast path, whichever statement (three- or five-group windows) the size takes."""
+    from timewarp_amd import _lib
+
+    sd = H.full_kernel_sd()
+    g = torch.Generator().manual_seed(1700 + V)
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.5
+    x_v = torch.randn(B, V, 3, generator=g) * 0.5
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+    y_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    args = dict(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(), y_velocs=y_v.cuda(),
+                adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+    lib = _lib.load()
+    outs = {}
+    try:
+        for path in (H3, 4):
+            for flag in (0, 524288):
+                lib.tw_debug_set_flags(layout | flag)
+                m = H.tw_kernel_model(sd, path=path)
+                outs[path, flag] = m.log_likelihood(**args).cpu()
+                H.assert_not_demoted(m)
+    finally:
+        lib.tw_debug_set_flags(0)
+    assert H.rel_err(outs[H3, 0], ref) < TOL, H.rel_err(outs[H3, 0], ref)
+    assert torch.equal(outs[H3, 0], outs[H3, 524288]) and torch.equal(outs[4, 0], outs[4, 524288])
+
+
 @pytest.mark.parametrize("V,lens", [(65, [65, 65, 50, 65, 65]), (70, [70, 44, 70]), (80, [80, 80, 80, 66]), (88, [88, 61, 88]),
                                     (96, [96, 90, 96, 96])])
 def test_wide_layout_three_group_windows_vs_five(V, lens):

@@ -1695,18 +1695,45 @@ netblock_h3_kernel(const H3Params p) {
       // the workgroup's shared tile [feature][192 tokens] over the four wave-private blocks (every wave has passed the
       // barrier above, so nobody still reads operands there); a barrier before anyone mixes against other waves' columns
       char* xts = lds + RING * H3_STAGE_BYTES;
+      if (p.debug & 524288) {
+        // r03's form, kept as the A/B reference (tw_debug_set_flags bit 19): 192 two-byte stores per lane and layer - the
+        // section profile put 46 k cycles per layer here, 15 % of the launch (profiles/r04_wide_ng3_sections.txt)
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+          for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = x[ft][jt][r];
+              const _Float16 hi = (_Float16)v;
+              const int off = (16 * ft + 4 * g + r) * H3W_XT_ROW + 2 * (slot0 + 16 * jt + i16);
+              *(_Float16*)(xts + off) = hi;
+              *(_Float16*)(xts + H3W_XT_LO + off) = (_Float16)(v - (float)hi);
+            }
+      } else {
+        // Transposed through the matrix pipe like the 48-token kernel's tile (below): K = 16 MFMAs against the identity
+        // return X[token 16 jt + 4 g + r][feature 16 ft + i16] with the FEATURE on the lane and four consecutive TOKENS in
+        // its registers - exactly (products with 1.0, sums with zeros) - i.e. 8 contiguous bytes of the feature's row:
+        // 48 (fast mode: 24) eight-byte stores per lane and layer.  Rows 16 ft + i16 at a stride of 104 dwords + 2 g dwords
+        // cover all 64 banks twice per 64-lane store: conflict-free.
+        h4 idw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) idw[e] = (i16 == 4 * g + e) ? (_Float16)1.f : (_Float16)0.f;
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = x[ft][jt][r];
-            const _Float16 hi = (_Float16)v;
-            const int off = (16 * ft + 4 * g + r) * H3W_XT_ROW + 2 * (slot0 + 16 * jt + i16);
-            *(_Float16*)(xts + off) = hi;
-            *(_Float16*)(xts + H3W_XT_LO + off) = (_Float16)(v - (float)hi);
+          for (int jt = 0; jt < NT; ++jt) {
+            h4 xh, xl;
+            split4(x[ft][jt], xh, xl);
+            const int off = (16 * ft + i16) * H3W_XT_ROW + 2 * (slot0 + 16 * jt + 4 * g);
+            const f4 th = mfma16(xh, idw, (f4){0.f, 0.f, 0.f, 0.f});
+            *(u2*)(xts + off) = __builtin_bit_cast(u2, __builtin_convertvector(th, h4));
+            if constexpr (!H1) {
+              const f4 tl = mfma16(xl, idw, (f4){0.f, 0.f, 0.f, 0.f});
+              *(u2*)(xts + H3W_XT_LO + off) = __builtin_bit_cast(u2, __builtin_convertvector(tl, h4));
+            }
           }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     } else if constexpr (!DENSE) {
