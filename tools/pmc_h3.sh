@@ -2,6 +2,7 @@
 #   bash tools/pmc_h3.sh          the headline kernel: 1000-proposal alanine-dipeptide flow passes on path 3  -> gpurun_out/pmc_h3_{1..4}
 #   bash tools/pmc_h3.sh h1       the single-MFMA fast mode (path 4)                                       -> pmc_h1_*
 #   bash tools/pmc_h3.sh 4aa      BASELINE configs[3]: wide layout, NNQQ, 512 proposals (bench.py --config 4aa) -> pmc_4aa_*
+#   bash tools/pmc_h3.sh nnqq     the wide layout: NNQQ (65 atoms, 96-slot stride, three-group windows), 512 proposals  -> pmc_nnqq_*
 #   bash tools/pmc_h3.sh dense    BASELINE configs[4]: dense softmax flow (bench.py --config dense)        -> pmc_dense_*
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -11,6 +12,7 @@ case $W in
   h1) CMD="python $R/tools/time_flow.py --iters 2 --paths 4";;
   4aa) CMD="python $R/bench.py --config 4aa --steps 2 --warmup 1";;
   dense) CMD="python $R/bench.py --config dense --steps 2 --warmup 1";;
+  nnqq) CMD="python $R/bench.py --config 4aa-nnqq --steps 2 --warmup 1";;
 esac
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_RD"; do
