@@ -7,7 +7,6 @@ from __future__ import annotations
 import os
 from typing import Dict, List, Tuple
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -16,7 +16,6 @@ Units: nm, kJ/mol, elementary charge, radians.
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 from dataclasses import dataclass
 from itertools import combinations

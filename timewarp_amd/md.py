@@ -11,7 +11,7 @@ conservation without friction), not step for step.  There is no CPU path."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

@@ -5,7 +5,7 @@ the model families on the hot path.  A reference YAML's `model_config:` block ma
 (see `model_config_from_dict`)."""
 from __future__ import annotations
 
-from dataclasses import dataclass, field, fields, is_dataclass
+from dataclasses import dataclass, field, fields
 from typing import Any, Dict, List, Optional
 
 

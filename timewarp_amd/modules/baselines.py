@@ -5,8 +5,7 @@ writing -- it exists so that `sample.py`-style drivers (utils/sampling_utils.py)
 end to end.  Elementwise torch ops on whatever device the inputs live on."""
 from __future__ import annotations
 
-import math
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 import torch.nn as nn
