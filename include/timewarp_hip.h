@@ -109,7 +109,7 @@ int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_
 #define TW_PATH_FUSED_H3 3 /* fused split-fp16 kernel: every fp32 product as 3 half-precision MFMAs with fp32
                               accumulation (2^-22 operand representation); needs |activations| < 65504.  Kernel
                               attention: n_atoms <= 48 in 48-token waves holding floor(48 / n_atoms) molecules, and
-                              25 .. 160 atoms in the "wide" layout - floor(192 / n_atoms) molecules packed over a workgroup's
+                              25 .. 192 atoms in the "wide" layout - floor(192 / n_atoms) molecules packed over a workgroup's
                               four waves (81 .. 95 atoms: two, at a slot stride of 96) - chosen per launch where both exist (fewer rounds of
                               the chip); dense softmax attention: n_atoms <= 48.  tw_flow_path_supported answers per size.
                               `packed` must then point at the tw_flow_pack_h3 stream.  Never chosen by

@@ -215,7 +215,7 @@ def test_preferred_split_fp16_path_falls_back_per_call(monkeypatch):
     monkeypatch.setenv("TW_EXECUTION_PATH", "h3")
     m = H.tw_kernel_model(H.full_kernel_sd(), path=None)
     assert m.execution_path == flow.PREFER_SPLIT_FP16
-    assert m._path_for(22) == H3 and m._path_for(30) == H3 and m._path_for(60) == H3 and m._path_for(161) == 0
+    assert m._path_for(22) == H3 and m._path_for(30) == H3 and m._path_for(60) == H3 and m._path_for(161) == H3 and m._path_for(193) == 0
     d, _ = H.load("kernel_full_ad")
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
     assert m._dev_weights["h3"] is not None and m._dev_weights["f32"] is None  # the 22-atom calls ran on the h3 stream
@@ -456,13 +456,15 @@ def test_encoder_stack_statement_layer_counts_vs_oracle(n_layers):
 @pytest.mark.parametrize("V,lens,paths", [(64, [64, 51], (FUSED, SIMPLE)), (70, [70, 44, 70], (0, SIMPLE, H3)),
                                           (100, [100, 87], (0, H3)), (96, [96, 90, 96], (H3,)), (160, [160, 131], (H3,)),
                                           (81, [81, 70, 81], (H3,)), (88, [88, 88, 61, 88, 88], (SIMPLE, H3)),
-                                          (95, [95, 95, 95], (H3,))])
+                                          (95, [95, 95, 95], (H3,)), (161, [161, 140], (H3,)), (176, [176, 176, 133], (SIMPLE, H3)),
+                                          (192, [192, 161, 192], (H3,))])
 def test_large_molecules_vs_oracle(V, lens, paths):
     """Maximum sizes: 64 atoms is the largest molecule a fused f32 wave holds (4 tiles); beyond it TW_PATH_AUTO has to fall
     back to the per-op path, while the split-fp16 kernel's wide layout goes on to 160 atoms (two, then one molecule per
     workgroup).  All above 25 atoms, so the scores follow torch.cdist's matmul branch.  81 .. 95 atoms (refused
     until r04) take a slot stride of 96 instead of sitting back to back - molecule 0 on waves 0-1, molecule 1 on waves 2-3,
-    padding slots behind each - odd and even row counts, so that the last workgroup holds one molecule and two."""
+    padding slots behind each - odd and even row counts, so that the last workgroup holds one molecule and two.  161 .. 192
+    atoms (r04): one molecule over the workgroup's 192 slots, every wave mixing against all six key groups."""
     sd = H.full_kernel_sd()
     g = torch.Generator().manual_seed(300 + V)
     B = len(lens)
@@ -481,7 +483,7 @@ def test_large_molecules_vs_oracle(V, lens, paths):
                                y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
         H.assert_not_demoted(m)
         assert H.rel_err(out, ref) < TOL, (path, H.rel_err(out, ref))
-    if 81 <= V <= 95:
+    if 81 <= V <= 95 or V > 160:
         # the reverse pass as well (its coupling prologue reduces the log-determinant over the strided slots)
         S = 5
         zc, zv = torch.randn(S, 1, V, 3, generator=g), torch.randn(S, 1, V, 3, generator=g)
@@ -578,7 +580,7 @@ def test_layout_choice_by_rounds_of_the_chip():
 
 
 @pytest.mark.parametrize("V,lens,layout", [(30, [30, 28, 25, 30, 30, 30, 30], 32768), (60, [60, 44, 60, 60], 131072),
-                                           (70, [70, 44, 70], 0), (100, [100, 87, 100], 0), (160, [160, 131], 0)])
+                                           (70, [70, 44, 70], 0), (100, [100, 87, 100], 0), (160, [160, 131], 0), (180, [180, 171], 0)])
 def test_wide_layout_transposed_tile_through_matrix_pipe(V, lens, layout):
     """r04: the wide layout's shared transposed tile is written through the matrix pipe (K = 16 MFMAs against the identity, 48
     eight-byte stores per lane and layer) instead of with 192 two-byte stores (tw_debug_set_flags bit 19 keeps r03's form: the

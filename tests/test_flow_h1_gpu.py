@@ -94,7 +94,7 @@ def test_full_size_S1000_rows_and_round_trip():
 
 
 @pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25]), (48, [48, 40]),
-                                    (60, [60, 51, 60, 60, 44]), (100, [100, 87, 100]), (160, [160, 131]), (88, [88, 61, 88])])
+                                    (60, [60, 51, 60, 60, 44]), (100, [100, 87, 100]), (160, [160, 131]), (88, [88, 61, 88]), (176, [176, 150])])
 def test_ragged_batches_vs_split_fp16_kernel(V, lens):
     """Padded atoms, several molecules per wave (windowed mixing), one per wave (full mixing), and the wide layout (49 - 160
     atoms: molecules packed over a workgroup's four waves, tw_h1_attns_asm.inc + the per-section in / FFN / out statements): log_likelihood of a
@@ -141,7 +141,7 @@ def test_path_selection_by_name(monkeypatch):
     monkeypatch.setenv("TW_EXECUTION_PATH", "h1")
     m = tw.model_constructor(cfg)
     assert m.execution_path == flow.PREFER_SINGLE_FP16
-    assert [m._path_for(v) for v in (1, 22, 48, 49, 60, 80, 90, 160, 161)] == [H1, H1, H1, H1, H1, H1, H1, H1, 0]   # (90: since the 96-slot stride)
+    assert [m._path_for(v) for v in (1, 22, 48, 49, 60, 80, 90, 160, 192, 193)] == [H1] * 9 + [0]   # (90: since the 96-slot stride; 161 .. 192: six-group windows)
     desc = m.dims.to_desc()
     lib = _lib.load()
     assert lib.tw_flow_path_supported(C.byref(desc), 22, H1) == 1 and lib.tw_flow_path_supported(C.byref(desc), 60, H1) == 1
@@ -155,10 +155,10 @@ def test_path_selection_by_name(monkeypatch):
     # by name on an unsupported shape: an error, not a silent other kernel
     mm = H.tw_kernel_model(H.full_kernel_sd(), path=H1)
     g = torch.Generator().manual_seed(0)
-    x = (torch.randn(1, 170, 3, generator=g) * 0.8).cuda()
+    x = (torch.randn(1, 200, 3, generator=g) * 0.8).cuda()   # (193+: beyond the 192 slots of a workgroup)
     with pytest.raises(RuntimeError, match="single-MFMA path unsupported"):
-        mm.log_likelihood(atom_types=torch.zeros(1, 170, dtype=torch.long).cuda(), x_coords=x, x_velocs=x, y_coords=x, y_velocs=x,
-                          adj_list=None, edge_batch_idx=None, masked_elements=torch.zeros(1, 170, dtype=torch.bool).cuda())
+        mm.log_likelihood(atom_types=torch.zeros(1, 200, dtype=torch.long).cuda(), x_coords=x, x_velocs=x, y_coords=x, y_velocs=x,
+                          adj_list=None, edge_batch_idx=None, masked_elements=torch.zeros(1, 200, dtype=torch.bool).cuda())
 
 
 @pytest.mark.parametrize("name", ["dense_full_ad", "dense_full_padded"])

@@ -106,7 +106,7 @@ def test_execution_path_from_environment(monkeypatch):
         tw.model_constructor(cfg)
     # every molecule that fits a 48-token wave runs on the split-fp16 kernel (tw_flow_path_supported), the rest on AUTO
     monkeypatch.setenv("TW_EXECUTION_PATH", "h3")
-    assert [m._path_for(v) for v in (1, 7, 12, 17, 21, 30, 40, 48, 49, 64, 65, 160, 161, 200)] == [3] * 12 + [0] * 2
+    assert [m._path_for(v) for v in (1, 7, 12, 17, 21, 30, 40, 48, 49, 64, 65, 160, 192, 193, 200)] == [3] * 13 + [0] * 2
     # ... unless the score-fragment producer's LDS tile would not fit the CU: 48 atoms x 18 heads
     many = synthetic.kernel_transformer_nvp_config()
     many.custom_transformer_nvp_config.encoder_layer_config.lengthscales = [0.1 * (i + 1) for i in range(18)]
@@ -119,7 +119,7 @@ def test_execution_path_from_environment(monkeypatch):
 
 def test_path_supported_sweep():
     """tw_flow_path_supported over 1 .. 200 atoms: the split-fp16 kernel takes 1 .. 48 (48-token waves), the wide
-    layout 25 .. 160 (81 .. 95 with a slot stride of 96: back to back, wave 1 would span two molecules over eleven key tiles =
+    layout 25 .. 192 (161 .. 192: one molecule per workgroup, six-group windows; 81 .. 95 with a slot stride of 96: back to back, wave 1 would span two molecules over eleven key tiles =
     six key groups, the statement has five); the single-MFMA fast path the same set; the f32 kernel 1 .. 64."""
     import ctypes as C
     from timewarp_amd import _lib, synthetic
@@ -128,7 +128,7 @@ def test_path_supported_sweep():
     lib = _lib.load()
     desc = tw.model_constructor(synthetic.kernel_transformer_nvp_config()).dims.to_desc()
     sup = lambda path: [v for v in range(1, 201) if lib.tw_flow_path_supported(C.byref(desc), v, path) == 1]
-    assert sup(3) == list(range(1, 161))
+    assert sup(3) == list(range(1, 193))
     assert sup(4) == sup(3)   # the single-MFMA fast path: wherever the split-fp16 kernel runs kernel attention
     assert sup(1) == list(range(1, 65))
     assert sup(2) == list(range(1, 201)) and sup(0) == list(range(1, 201))
@@ -388,6 +388,8 @@ def test_generated_asm_includes_are_current(tmp_path):
                  ["tools/gen_h3_ffn_asm.py", "--shape=ffn", "--h1"], ["tools/gen_h3_attn_wide_asm.py", "--h1"],
                  # wide layout, 65-96 atoms at the 96-slot stride: three-group windows, tw_h?_attns3_*
                  ["tools/gen_h3_attn_wide_asm.py", "--ng=3"], ["tools/gen_h3_attn_wide_asm.py", "--ng=3", "--h1"],
+                 # ... 161-192 atoms, one molecule per workgroup: six-group windows, tw_h?_attns6_*
+                 ["tools/gen_h3_attn_wide_asm.py", "--ng=6"], ["tools/gen_h3_attn_wide_asm.py", "--ng=6", "--h1"],
                  # 64-token waves (49-64 atoms): tw_h3n4_*
                  ["tools/gen_h3_ffn_asm.py", "--shape=ffn", "--nt=4"], ["tools/gen_h3_attn_asm.py", "--nt=4"],
                  ["tools/gen_h3_ffn_asm.py", "--shape=in", "--nt=4"], ["tools/gen_h3_ffn_asm.py", "--shape=out", "--nt=4"],
@@ -396,7 +398,7 @@ def test_generated_asm_includes_are_current(tmp_path):
         subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
                        stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 48
+    assert len(names) == 52
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n

@@ -80,6 +80,7 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3W_XT_LO (128 * H3W_XT_ROW)
 #define H3W_NG 5                        // K = 32 key groups in a wave's key window (tw_h3_attns_asm.inc) ...
 #define H3W_NG3 3                       // ... or three, for 65 .. 96 atoms at a slot stride of 96 (tw_h3_attns3_asm.inc)
+#define H3W_NG6 6                       // ... or all six: one molecule of 161 .. 192 atoms per workgroup (tw_h3_attns6_asm.inc)
 #define H3W_FRAG_HEAD(ng) ((ng) * H3_NT * 2048)  // score fragments of one (wave, head): [group][query tile][hi 1 KiB | lo 1 KiB]
 #define H3W_SIDE_LDS_OFFSET (H3_RING * H3_STAGE_BYTES + 4 * H3W_WAVE_LDS)
 #define H3W_LDS_BYTES (H3W_SIDE_LDS_OFFSET + H3_SIDE_LDS_BYTES)
@@ -152,7 +153,7 @@ static size_t h3_sf_lds_bytes(int H, int V, int mpw) {
 // Wide layout: molecules per workgroup and, per wave, the byte offset of its key window in a row of the shared X^T tile.
 // Wave w's query tokens [48 w, 48 w + 48) touch the molecules overlapping that range; their keys span key tiles
 // first .. last; the window is H3W_NG groups of 32 keys from tile K0 = min(first, 12 - 2 NG) (it never leaves the 192
-// tokens).  false if a wave needs more than H3W_NG groups (V > 160) or the molecule does not fit a workgroup.
+// tokens).  false if the molecule does not fit a workgroup's 192 slots (161 .. 192 atoms: all six groups, H3W_NG6).
 struct H3Wide {
   int mpwg;
   int stride;  // token slots per molecule: V (back to back), or 96 (65 .. 96 atoms: each molecule on its own pair of waves)
@@ -189,7 +190,8 @@ static bool h3_wide_geom(int V, H3Wide* w) {
   if (V < H3W_MIN_ATOMS || V > 64 * H3_NT) return false;
   if (V > 64 && V <= 96 && !(g_debug_flags & 262144) && h3_wide_geom_stride(V, 96, H3W_NG3, w)) return true;
   if (h3_wide_geom_stride(V, V, H3W_NG, w)) return true;
-  return V <= 96 && h3_wide_geom_stride(V, 96, H3W_NG, w);
+  if (V <= 96) return h3_wide_geom_stride(V, 96, H3W_NG, w);
+  return h3_wide_geom_stride(V, V, H3W_NG6, w);  // 161 .. 192 atoms: the whole 192-key row
 }
 static size_t h3w_sf_lds_bytes(int V, int mpwg) {
   const size_t MV = (size_t)mpwg * V;
@@ -1974,7 +1976,16 @@ netblock_h3_kernel(const H3Params p) {
         const int win = __builtin_amdgcn_readfirstlane(wave == 0 ? p.win[0] : wave == 1 ? p.win[1] : wave == 2 ? p.win[2] : p.win[3]);
         // (p.ng is launch-uniform: three-group windows for 65 .. 96 atoms at the 96-slot stride, five otherwise)
         if constexpr (H1) {
-          if (p.ng == H3W_NG3) {
+          if (p.ng == H3W_NG6) {
+          asm volatile(
+#include "tw_h1_attns6_asm.inc"
+              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
+                [win] "s"(win)
+              :
+#include "tw_h1_attns6_clobbers.inc"
+          );
+          } else if (p.ng == H3W_NG3) {
           asm volatile(
 #include "tw_h1_attns3_asm.inc"
               : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -1993,6 +2004,15 @@ netblock_h3_kernel(const H3Params p) {
 #include "tw_h1_attns_clobbers.inc"
           );
           }
+        } else if (p.ng == H3W_NG6) {
+        asm volatile(
+#include "tw_h3_attns6_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
+              [win] "s"(win)
+            :
+#include "tw_h3_attns6_clobbers.inc"
+        );
         } else if (p.ng == H3W_NG3) {
         asm volatile(
 #include "tw_h3_attns3_asm.inc"
@@ -2406,9 +2426,9 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool
   if (d.variant == 1) w.sf_variant_bytes = 0;  // dense: no score fragments
   else if (wide) w.sf_variant_bytes = nblocks * 4 * d.n_heads * H3W_FRAG_HEAD(wd.ng);
   else w.sf_variant_bytes = nblocks * d.n_heads * g.nt * (g.nt == 4 ? H3N4_SF_BYTES : H3_SF_BYTES);
-  // (wide: sized for five-group windows whatever the launch takes - the workspace a caller allocated stays large enough when
+  // (wide: sized for six-group windows whatever the launch takes - the workspace a caller allocated stays large enough when
   // tw_debug_set_flags moves between the two statements)
-  w.sfrag = take(wide ? (variants * nblocks * 4 * d.n_heads + 1) * (int64_t)H3W_FRAG_HEAD(H3W_NG)
+  w.sfrag = take(wide ? (variants * nblocks * 4 * d.n_heads + 1) * (int64_t)H3W_FRAG_HEAD(H3W_NG6)
                       : variants * w.sf_variant_bytes + g.nt * (g.nt == 4 ? H3N4_SF_BYTES : H3_SF_BYTES));
   w.bytes = p - (char*)base;
   return w;

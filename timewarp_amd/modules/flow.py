@@ -20,7 +20,7 @@ from .density_model_base import ConditionalDensityModel
 
 
 # execution_path value of ConditionalFlowDensityModel only (not a C-ABI path): the split-fp16 kernel wherever the
-# library supports it for the call's molecule size (tw_flow_path_supported: d_model 128; kernel attention up to 160 atoms
+# library supports it for the call's molecule size (tw_flow_path_supported: d_model 128; kernel attention up to 192 atoms
 # - 48-token waves up to 48 atoms, 64-token waves for 49 .. 64, the wide layout from 25 - dense softmax attention up to 48), else AUTO.
 PREFER_SPLIT_FP16 = -1
 # Opt-in "fast" mode (TW_EXECUTION_PATH=h1): the single-MFMA kernel (TW_PATH_FUSED_H1: fp16 operands, one MFMA per product)

@@ -29,10 +29,13 @@ NG = 5                      # K = 32 key groups per wave window
 # --ng=3: molecules of 65 .. 96 atoms at a slot stride of 96 (two per workgroup, each on its own pair of waves): a wave's
 # keys are its molecule's <= 96 slots = three groups - 54 mixing MFMAs per head and k-step instead of 90, 18 fragment
 # loads per head instead of 30 (tw_h3_attns3_asm.inc; H3Wide::ng in csrc/tw_netblock_h3.hip)
+# --ng=6: ONE molecule of 161 .. 192 atoms over the workgroup's 192 slots - every wave mixes against all twelve key tiles
+# (tw_h3_attns6_asm.inc; the 144 fragment registers reach v239, so the compiler keeps less of its own state across this
+# statement than across the others - these sizes ran on the per-op path before)
 for _a in sys.argv[1:]:
     if _a.startswith("--ng="):
         NG = int(_a.split("=", 1)[1])
-assert NG in (3, 5)
+assert NG in (3, 5, 6)
 STAGE, TILES = 9216, 8192
 XT_ROW = 416                # bytes per feature row of the shared transposed tile (104 dwords = 192 tokens + 16 pad)
 XT_LO = 128 * XT_ROW        # offset of the lo half
@@ -51,7 +54,7 @@ def SF(gi, jt, part):
 V_T, V_TILE, V_XTH, V_XTL, V_GN, V_TMP, V_LANE16, V_SF = 136, 144, 145, 146, 148, 150, 152, 154
 YACC = lambda ot, jt: 4 * (3 * ot + jt)
 S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT, S_K2048 = 84, 85, 86, 88, 90, 92, 93, 94
-N_V, N_A = 212, 160
+N_V, N_A = (240 if NG == 6 else 212), 160
 # --h1: the single-MFMA "fast" variant (TW_PATH_FUSED_H1; see gen_h3_ffn_asm.py / gen_h3_attn_asm.py): hi halves only - 30
 # mixing MFMAs per k-step, ONE weight stage of eight hi tiles per k-step, a split is a pack, half the fragment loads
 H1 = "--h1" in sys.argv
@@ -340,8 +343,8 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--out-dir="):
             out_dir = a.split("=", 1)[1]
-    sfx = "3" if NG == 3 else ""
-    flags = (" --ng=3" if NG == 3 else "") + (" --h1" if H1 else "")
+    sfx = str(NG) if NG != 5 else ""
+    flags = (f" --ng={NG}" if NG != 5 else "") + (" --h1" if H1 else "")
     base = os.path.join(out_dir, f"tw_h1_attns{sfx}_asm.inc" if H1 else f"tw_h3_attns{sfx}_asm.inc")
     out = [f"// GENERATED by tools/gen_h3_attn_wide_asm.py{flags} - do not edit.  Body of the wide-layout attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
