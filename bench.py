@@ -657,7 +657,8 @@ def main():
                 "constants": "matrix_pipe_busy_clocks_per_wave (36.1 k MFMAs x 16 clocks, a property of the kernel's instruction "
                              "stream, confirmed by SQ_VALU_MFMA_BUSY_CYCLES) and sustained_clock_ghz (a probe result) are NOT measured "
                              "by this run; what this run measures is avg_launch_ms and attention_block.effective_clock_ghz",
-                "source": "profiles/r03_mfma_stream_probe.txt, profiles/r03_h3_sq_counters.md",
+                "source": "profiles/r03_mfma_stream_probe.txt, profiles/r04_mfma_shape_probe.txt (1.73-1.80 GHz on another box; a 32x32x16 "
+                          "stream sustains 1.50-1.57), profiles/r03_h3_sq_counters.md",
             }
         if world == 1 and args.path != "f32":
             out["alt_path"] = alt_path_record(device, distributed.chain_seed(args.seed, rank), args.proposals,
