@@ -332,3 +332,32 @@ def test_mh_iterations_vs_oracle_indicator_agreement(random_velocs, kind):
     assert accepted_ref >= 1 and agree >= 0.98 * total
     # measured (profiles/r04_h1_accuracy.txt): 9.2e-5, 4.7e-3, 4.6e-3 - the weights of these chains move a proposal by ~1e-4 nm
     assert worst["p_xy"] < 2e-3 and worst["p_yx"] < 0.03 and worst["exponent"] < 0.03
+
+
+@pytest.mark.parametrize("V,lens", [(70, [70, 44, 70] * 40), (176, [176, 150] * 30)])
+def test_fast_mode_wide_statements_repeat_bit_for_bit(V, lens):
+    """r04: the attention statements prefetch the score fragments of the "next head" also in the last head; until the statement
+    waited for those loads at its exit, one that returned late wrote into registers the code behind had taken over - ~0.5 % of
+    the fast mode's launches on the three- and six-group wide statements returned one corrupted workgroup (two 24-MFMA stages
+    behind the loads are ~800 cycles; tools/stress_wide.py, profiles/r04_stress_wide*.txt).  Forty repeats with the caches
+    flushed in between must return the first run's bits (a smoke alarm, not a proof: the stress tool runs thousands)."""
+    sd = H.full_kernel_sd()
+    g = torch.Generator().manual_seed(31 + V)
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    xc = torch.randn(B, V, 3, generator=g) * 0.5
+    xv = torch.randn(B, V, 3, generator=g) * 0.5
+    yc = xc + torch.randn(B, V, 3, generator=g) * 0.02
+    yv = torch.randn(B, V, 3, generator=g) * 0.5
+    mk = torch.zeros(B, V, dtype=torch.bool)
+    for i, n in enumerate(lens):
+        mk[i, n:] = True
+    args = dict(atom_types=at.cuda(), x_coords=xc.cuda(), x_velocs=xv.cuda(), y_coords=yc.cuda(), y_velocs=yv.cuda(),
+                adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda())
+    m = H.tw_kernel_model(sd, path=H1)
+    first = m.log_likelihood(**args).cpu()
+    assert torch.isfinite(first).all()
+    junk = torch.empty(1 << 28, dtype=torch.float32, device="cuda")   # 1 GiB: evicts L2 and the Infinity Cache
+    for it in range(40):
+        junk.fill_(float(it))
+        assert torch.equal(m.log_likelihood(**args).cpu(), first), it

@@ -425,6 +425,12 @@ def generate():
     A(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     A(f"s_cmp_eq_u32 s{S_CNT}, 0")
     A("s_cbranch_scc0 .Lh3att_head_%=")
+    # The fragment loads issued in the last head (the "next head" that does not exist) must have LANDED before the statement
+    # gives its registers back: a load that returns after the exit writes into whatever the code behind keeps there (r04,
+    # tools/stress_wide.py: ~0.5 % of the fast mode's launches on the new wide statements returned a corrupted workgroup - two
+    # 24-MFMA stages after the loads are only ~800 cycles).  Newer than those loads are the DMAs of the hand-offs of k-steps 2
+    # and 3: two per stage for every wave (wave 0's aux blocks only make the wait stricter).
+    A(f"s_waitcnt vmcnt({4 if H1 else 8})")
     # ---- out: ring slot index, y through the wave-private block (X^T is dead now), DMA pointer
     A(f"s_sub_u32 s{S_REL}, s{S_OFF}, %[ring]")
     A("s_mov_b32 %[cur], 0")

@@ -315,6 +315,9 @@ def generate():
     A(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     A(f"s_cmp_eq_u32 s{S_CNT}, 0")
     A("s_cbranch_scc0 .Lh3atw_head_%=")
+    # the last head's fragment prefetch (of a head that does not exist) must have landed before the statement returns its
+    # registers - see gen_h3_attn_asm.py; newer than those loads: two DMAs per hand-off of k-steps 2 and 3
+    A(f"s_waitcnt vmcnt({4 if H1 else 8})")
     # ---- out: ring slot index; every wave is done with the shared X^T tile before anyone writes y over it
     A(f"s_sub_u32 s{S_REL}, s{S_OFF}, %[ring]")
     A("s_mov_b32 %[cur], 0")
