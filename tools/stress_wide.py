@@ -43,11 +43,19 @@ for label, V, lens, flag in (("30 atoms, forced wide (five groups)", 30, [30, 28
     for path, name in ((3, "split-fp16"), (4, "fast mode")):
         lib.tw_debug_set_flags(flag)
         m = H.tw_kernel_model(sd, path=path)
-        first = ll(m, c)
-        bad = 0
-        for it in range(N):
-            junk.fill_(float(it))
-            ll(other, small)   # another kernel family leaves its bytes in LDS
-            bad += not torch.equal(ll(m, c), first)
+        S = 2 * len(lens) // 3
+        g = torch.Generator().manual_seed(V)
+        zc, zv = torch.randn(S, 1, V, 3, generator=g).cuda() * 0.1, torch.randn(S, 1, V, 3, generator=g).cuda()
+        rev = lambda: torch.cat([t.reshape(-1).cpu() for t in m.conditional_sample_with_logp(
+            atom_types=c[0][:1], x_coords=c[1][:1], x_velocs=c[2][:1], adj_list=None, edge_batch_idx=None,
+            masked_elements=c[5][:1] & False, num_samples=S, z_coords=zc, z_velocs=zv)])
+        for what, fn in (("forward", lambda: ll(m, c)), ("reverse", rev)):
+            first = fn()
+            bad = 0
+            for it in range(N):
+                junk.fill_(float(it))
+                ll(other, small)   # another kernel family leaves its bytes in LDS
+                bad += not torch.equal(fn(), first)
+            print(f"{label}, {len(lens) if what == 'forward' else S} rows, {name}, {what} pass: {bad}/{N} runs differ from the first; "
+                  f"finite: {bool(torch.isfinite(first).all())}", flush=True)
         lib.tw_debug_set_flags(0)
-        print(f"{label}, {len(lens)} rows, {name}: {bad}/{N} runs differ from the first; finite: {bool(torch.isfinite(first).all())}", flush=True)
