@@ -33,9 +33,10 @@ FLOP_PER_SAMPLE_PASS = 1.612e9  # 16 * V * F_blk(V), V = 22
 N_COUPLING = 8
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (~2.5 PF)
-# What the chip sustains (reported beside the roofline, never instead of it): tools/probe/mfma_stream_probe on all 256 CUs with
-# random fp16 operands runs at 1.74 GHz (profiles/r03_mfma_stream_probe.txt); the dominant kernel keeps a wave's matrix pipe
-# busy for 579.5 k clocks per launch (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_h3_sq_counters.md)
+# What the chip sustains (reported beside the roofline, never instead of it): a bare MFMA stream on all 256 CUs with random fp16
+# operands, measured by every run (tw_probe_mfma_clock; 1.74 GHz - r03's figure, taken 1.3 ms after idle and therefore low - is
+# only the fallback); the dominant kernel keeps a wave's matrix pipe busy for 579.5 k clocks per launch
+# (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_h3_sq_counters.md)
 SUSTAINED_MFMA_CLOCK_GHZ = 1.74
 H3_MFMA_BUSY_CLOCKS_PER_LAUNCH = 579.5e3
 # execution paths of the flow (include/timewarp_hip.h): h3 and f32 hold the 1e-5 parity bar
@@ -644,21 +645,35 @@ def main():
             out["roofline"]["attention_block"] = attention_block(model, device, args.proposals, avg_ms, "h1")
         if args.path == "h3" and args.proposals == S_PROPOSALS:
             out["roofline"]["attention_block"] = attention_block(model, device, args.proposals, avg_ms)
-            floor_ms = H3_MFMA_BUSY_CLOCKS_PER_LAUNCH / (SUSTAINED_MFMA_CLOCK_GHZ * 1e6)
+            # what the matrix pipes of THIS box sustain, measured now: a bare 16x16x32 MFMA stream on all 256 CUs (random
+            # operands; tw_probe_mfma_clock = tools/probe/mfma_stream_probe.hip as an entry point), two launches of ~10 ms: the first
+            # lets the clock settle (a 1.3 ms launch from idle reads 1.74-1.85 GHz where the settled chip runs 2.0-2.1: r03's constant)
+            probe_cyc, probe_ms = C.c_int64(0), C.c_double(0.0)
+            sustained_ghz, probe = SUSTAINED_MFMA_CLOCK_GHZ, None
+            if lib.tw_probe_mfma_clock(256, 32768, C.byref(probe_cyc), C.byref(probe_ms), None) == 0 and probe_ms.value > 0:
+                sustained_ghz = probe_cyc.value / (probe_ms.value * 1e6)
+                probe = {"workgroups": 256, "mfma_per_wave": 36 * 32768, "cycles": int(probe_cyc.value), "ms": probe_ms.value,
+                         "cycles_per_mfma": probe_cyc.value / (36.0 * 32768),
+                         "tflops": 256 * 4 * 36 * 32768 * 16384.0 / (probe_ms.value * 1e-3) / 1e12}
+            floor_ms = H3_MFMA_BUSY_CLOCKS_PER_LAUNCH / (sustained_ghz * 1e6)
             out["roofline"]["power_bound"] = {
-                "what": "launch time if the matrix pipe never idled, at the clock the chip sustains with every matrix pipe busy on "
-                        "random fp16 operands (tools/probe/mfma_stream_probe: 2.40 GHz on one CU, 1.74 GHz on 256); frac = that "
-                        "floor / the live launch time.  Context for `frac` above, not a replacement of it",
+                "what": "launch time if the matrix pipe never idled, at the clock THIS chip sustains with every matrix pipe busy on "
+                        "random fp16 operands (mfma_stream_probe below, measured right after the timed region; one CU alone runs "
+                        "2.40 GHz); frac = that floor / the live launch time.  Context for `frac` above, not a replacement of it",
                 "matrix_pipe_busy_clocks_per_wave": H3_MFMA_BUSY_CLOCKS_PER_LAUNCH,
-                "sustained_clock_ghz": SUSTAINED_MFMA_CLOCK_GHZ,
-                "sustained_f16_mfma_tflops": SUSTAINED_MFMA_CLOCK_GHZ * 1e9 * 1024 * 1024 / 1e12,
+                "sustained_clock_ghz": sustained_ghz,
+                "sustained_clock_measured_by_this_run": probe is not None,
+                "mfma_stream_probe": probe,
+                "sustained_f16_mfma_tflops": sustained_ghz * 1e9 * 1024 * 1024 / 1e12,
                 "floor_ms": floor_ms,
                 "frac": floor_ms / avg_ms,
-                "constants": "matrix_pipe_busy_clocks_per_wave (36.1 k MFMAs x 16 clocks, a property of the kernel's instruction "
-                             "stream, confirmed by SQ_VALU_MFMA_BUSY_CYCLES) and sustained_clock_ghz (a probe result) are NOT measured "
-                             "by this run; what this run measures is avg_launch_ms and attention_block.effective_clock_ghz",
-                "source": "profiles/r03_mfma_stream_probe.txt, profiles/r04_mfma_shape_probe.txt (1.73-1.80 GHz on another box; a 32x32x16 "
-                          "stream sustains 1.50-1.57), profiles/r03_h3_sq_counters.md",
+                "constants": "matrix_pipe_busy_clocks_per_wave (36.1 k MFMAs x 16 clocks) is a property of the kernel's instruction "
+                             "stream, confirmed by SQ_VALU_MFMA_BUSY_CYCLES, not a measurement of this run; sustained_clock_ghz, "
+                             "avg_launch_ms and attention_block.effective_clock_ghz are measured by this run (the clock by the "
+                             "bare MFMA stream of tw_probe_mfma_clock right after the timed region; 1.74 GHz, the r03 probe "
+                             "result, only if that call fails)",
+                "source": "tw_probe_mfma_clock (this run); profiles/r04_mfma_shape_probe_warm.txt (the same stream stand-alone: 1.99-2.02 GHz "
+                          "settled; a 32x32x16 stream sustains 1.65-1.69), profiles/r03_h3_sq_counters.md",
             }
         if world == 1 and args.path != "f32":
             out["alt_path"] = alt_path_record(device, distributed.chain_seed(args.seed, rank), args.proposals,

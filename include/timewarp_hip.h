@@ -325,6 +325,13 @@ int tw_chirality_changed(const float* coords, const int32_t* centres, const floa
 int tw_profile_begin(void);
 int tw_profile_end(double* total_ms, int64_t* launches);
 
+/* Measurement hook (bench.py roofline.power_bound): a bare stream of v_mfma_f32_16x16x32_f16 - 36 * iters instructions per
+ * wave, one wave per SIMD, `workgroups` workgroups of four waves (256 fills the chip), random fp16 operands of magnitude ~1 -
+ * i.e. what the matrix pipes of THIS device sustain when nothing else happens (tools/probe/mfma_stream_probe.hip as an entry
+ * point).  Returns (host pointers) the shader clocks one wave spent in the stream and the launch's duration from HIP events:
+ * clock = cycles / ms, sustained rate = workgroups * 4 * 36 * iters * 16384 FLOP / ms.  Synchronous; launches on `stream`. */
+int tw_probe_mfma_clock(int32_t workgroups, int32_t iters, int64_t* cycles, double* ms, void* stream);
+
 /* Safety net for TW_PATH_FUSED_H3 (no counterpart in the reference): *out_flag = 1 if, since the last reset, any
  * coupling net on the current device returned a non-finite scale or shift.  The split-fp16 kernel holds its operands in
  * fp16 (|value| < 65504); a checkpoint whose activations leave that range produces inf/NaN there, which the exact-f32

@@ -1118,3 +1118,25 @@ def test_64_token_waves_chebyshev_kernel_and_reverse_pass():
     floor_v = H.rel_err(ryv[0][keep], eyv[0][keep].float())
     assert H.rel_err(yc.cpu()[0][keep], eyc[0][keep].float()) < max(1.2 * floor_c, TOL), floor_c
     assert H.rel_err(yv.cpu()[0][keep], eyv[0][keep].float()) < max(1.2 * floor_v, TOL), floor_v
+
+
+def test_mfma_stream_probe_entry_point():
+    """tw_probe_mfma_clock (bench.py's roofline.power_bound): a bare v_mfma_f32_16x16x32_f16 stream costs ~16.8 cycles per
+    instruction whatever the load; the clock it reports for one workgroup / the whole chip is a plausible gfx950 clock and the
+    whole chip does not run faster than one CU."""
+    import ctypes as C
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    torch.zeros(1, device="cuda")
+    res = {}
+    for wgs in (1, 256):
+        cyc, ms = C.c_int64(0), C.c_double(0.0)
+        assert lib.tw_probe_mfma_clock(wgs, 2048, C.byref(cyc), C.byref(ms), None) == 0
+        per = cyc.value / (36.0 * 2048)
+        ghz = cyc.value / (ms.value * 1e6)
+        assert 16.0 <= per <= 18.0, per
+        assert 1.0 < ghz < 2.7, ghz
+        res[wgs] = ghz
+    assert res[256] <= res[1] * 1.05, res
+    assert lib.tw_probe_mfma_clock(0, 10, C.byref(cyc), C.byref(ms), None) != 0

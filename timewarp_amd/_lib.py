@@ -130,6 +130,7 @@ SIGNATURES = {
     "tw_debug_set_flags": (C.c_int, [C.c_int]),
     "tw_profile_begin": (C.c_int, []),
     "tw_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "tw_probe_mfma_clock": (C.c_int, [_I32, _I32, C.POINTER(C.c_int64), C.POINTER(C.c_double), _P]),
     "tw_debug_netblock": (
         C.c_int,
         [_DESC, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _P, _P, _I64, _P],

@@ -391,6 +391,76 @@ int tw_debug_set_flags(int flags) {
   return TW_OK;
 }
 
+// ---- tw_probe_mfma_clock: the bare MFMA stream of tools/probe/mfma_stream_probe.hip as a measurement hook
+namespace {
+__global__ void __launch_bounds__(256) mfma_stream_kernel(long long* out, int iters, unsigned seed) {
+  // operands: A = v[0:7] (two tiles), B = v[8:31] (six tiles): fp16 pairs of magnitude ~1 with random mantissas
+  unsigned r[32];
+  unsigned s = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    s = s * 1664525u + 1013904223u;
+    r[i] = (0x3800u + ((s >> 8) & 0x7ffu)) | ((0xb800u + ((s >> 20) & 0x7ffu)) << 16);
+  }
+  unsigned long long t0 = 0, t1 = 0;
+  asm volatile(
+      "v_mov_b32 v0, %[r0]\n\tv_mov_b32 v1, %[r1]\n\tv_mov_b32 v2, %[r2]\n\tv_mov_b32 v3, %[r3]\n\tv_mov_b32 v4, %[r4]\n\tv_mov_b32 v5, %[r5]\n\tv_mov_b32 v6, %[r6]\n\tv_mov_b32 v7, %[r7]\n\t"
+      "v_mov_b32 v8, %[r8]\n\tv_mov_b32 v9, %[r9]\n\tv_mov_b32 v10, %[r10]\n\tv_mov_b32 v11, %[r11]\n\tv_mov_b32 v12, %[r12]\n\tv_mov_b32 v13, %[r13]\n\tv_mov_b32 v14, %[r14]\n\tv_mov_b32 v15, %[r15]\n\t"
+      "v_mov_b32 v16, %[r16]\n\tv_mov_b32 v17, %[r17]\n\tv_mov_b32 v18, %[r18]\n\tv_mov_b32 v19, %[r19]\n\tv_mov_b32 v20, %[r20]\n\tv_mov_b32 v21, %[r21]\n\tv_mov_b32 v22, %[r22]\n\tv_mov_b32 v23, %[r23]\n\t"
+      "v_mov_b32 v24, %[r24]\n\tv_mov_b32 v25, %[r25]\n\tv_mov_b32 v26, %[r26]\n\tv_mov_b32 v27, %[r27]\n\tv_mov_b32 v28, %[r28]\n\tv_mov_b32 v29, %[r29]\n\tv_mov_b32 v30, %[r30]\n\tv_mov_b32 v31, %[r31]\n\t"
+      ".set i, 0\n\t.rept 12\n\tv_accvgpr_write_b32 a[i], 0\n\t.set i, i + 1\n\t.endr\n\t"
+      "s_memtime %[t0]\n\ts_waitcnt lgkmcnt(0)\n\t"
+      ".Ltw_probe_loop_%=:\n\t"
+      ".rept 4\n\t"
+      "v_mfma_f32_16x16x32_f16 a[0:3], v[0:3], v[8:11], a[0:3]\n\t"
+      "v_mfma_f32_16x16x32_f16 a[4:7], v[0:3], v[16:19], a[4:7]\n\t"
+      "v_mfma_f32_16x16x32_f16 a[8:11], v[0:3], v[24:27], a[8:11]\n\t"
+      "v_mfma_f32_16x16x32_f16 a[0:3], v[0:3], v[12:15], a[0:3]\n\t"
+      "v_mfma_f32_16x16x32_f16 a[4:7], v[0:3], v[20:23], a[4:7]\n\t"
+      "v_mfma_f32_16x16x32_f16 a[8:11], v[0:3], v[28:31], a[8:11]\n\t"
+      "v_mfma_f32_16x16x32_f16 a[0:3], v[4:7], v[8:11], a[0:3]\n\t"
+      "v_mfma_f32_16x16x32_f16 a[4:7], v[4:7], v[16:19], a[4:7]\n\t"
+      "v_mfma_f32_16x16x32_f16 a[8:11], v[4:7], v[24:27], a[8:11]\n\t"
+      ".endr\n\t"
+      "s_sub_u32 %[it], %[it], 1\n\t"
+      "s_cmp_lg_u32 %[it], 0\n\t"
+      "s_cbranch_scc1 .Ltw_probe_loop_%=\n\t"
+      "s_nop 15\n\t"
+      "s_memtime %[t1]\n\ts_waitcnt lgkmcnt(0)\n\t"
+      : [t0] "=&s"(t0), [t1] "=&s"(t1), [it] "+s"(iters)
+      : [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [r3] "v"(r[3]), [r4] "v"(r[4]), [r5] "v"(r[5]), [r6] "v"(r[6]), [r7] "v"(r[7]), [r8] "v"(r[8]), [r9] "v"(r[9]), [r10] "v"(r[10]), [r11] "v"(r[11]), [r12] "v"(r[12]), [r13] "v"(r[13]), [r14] "v"(r[14]), [r15] "v"(r[15]), [r16] "v"(r[16]), [r17] "v"(r[17]), [r18] "v"(r[18]), [r19] "v"(r[19]), [r20] "v"(r[20]), [r21] "v"(r[21]), [r22] "v"(r[22]), [r23] "v"(r[23]), [r24] "v"(r[24]), [r25] "v"(r[25]), [r26] "v"(r[26]), [r27] "v"(r[27]), [r28] "v"(r[28]), [r29] "v"(r[29]), [r30] "v"(r[30]), [r31] "v"(r[31])
+      : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
+        "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "a0", "a1", "a2", "a3", "a4",
+        "a5", "a6", "a7", "a8", "a9", "a10", "a11", "scc");
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (long long)(t1 - t0);
+}
+}  // namespace
+
+int tw_probe_mfma_clock(int32_t workgroups, int32_t iters, int64_t* cycles, double* ms, void* stream) {
+  TW_REQUIRE(workgroups > 0 && workgroups <= 65536 && iters > 0 && cycles && ms, "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  long long* dev = nullptr;
+  TW_HIP_CHECK(hipMalloc(&dev, sizeof(long long)));
+  hipEvent_t e0, e1;
+  TW_HIP_CHECK(hipEventCreate(&e0));
+  TW_HIP_CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(mfma_stream_kernel, dim3((unsigned)workgroups), dim3(256), 0, st, dev, iters, 12345u);  // clock ramp
+  TW_HIP_CHECK(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(mfma_stream_kernel, dim3((unsigned)workgroups), dim3(256), 0, st, dev, iters, 54321u);
+  TW_HIP_CHECK(hipEventRecord(e1, st));
+  TW_HIP_CHECK(hipEventSynchronize(e1));
+  float t = 0.f;
+  TW_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+  long long c = 0;
+  TW_HIP_CHECK(hipMemcpy(&c, dev, sizeof(c), hipMemcpyDeviceToHost));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(dev);
+  *cycles = (int64_t)c;
+  *ms = (double)t;
+  return TW_OK;
+}
+
 int tw_profile_begin(void) { return profile_begin(); }
 int tw_profile_end(double* total_ms, int64_t* launches) { return profile_end(total_ms, launches); }
 

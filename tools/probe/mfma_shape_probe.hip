@@ -1,8 +1,9 @@
 // Hardware probe (gfx950): the SAME FLOPs as a stream of v_mfma_f32_16x16x32_f16 (the shape every kernel here uses) and as a
 // stream of v_mfma_f32_32x32x16_f16, on one CU and on all 256, zero and random operands: cycles per instruction and the clock
 // the chip sustains.  Both shapes are 1024 FLOP per cycle and SIMD on paper; the 32x32 shape reads half as many operand
-// registers per FLOP, which is a power argument on a launch that is power-limited (profiles/r03_mfma_stream_probe.txt:
-// 16x16x32 sustains 1.74 GHz on 256 CUs with random operands, 2.40 on one CU).  Build: hipcc --offload-arch=gfx950 -O2.
+// registers per FLOP, which is a power argument on a launch that is power-limited.  Every measured launch follows ~70 ms of the
+// same stream: the clock takes tens of milliseconds to settle after idle (a 1.3 ms launch from idle reads 1.74-1.85 GHz where
+// the settled chip runs 2.0; profiles/r04_mfma_shape_probe_{cold,warm}.txt).  Build: hipcc --offload-arch=gfx950 -O2.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -69,7 +70,9 @@ template <int SHAPE>
 static void run(long long* dev, const unsigned* init, const char* what, int blocks, int iters) {
   hipMemset(dev, 0, 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<SHAPE>), dim3(blocks), dim3(256), 0, 0, dev, init, iters);   // warm
+  // warm-up: the clock ramps for tens of milliseconds after idle (r04: a 1.3 ms launch from idle reads 1.74-1.85 GHz where the
+  // settled chip runs 2.13) - so ~80 ms of the same stream first, then the measured launch back to back
+  hipLaunchKernelGGL((k<SHAPE>), dim3(blocks), dim3(256), 0, 0, dev, init, 8 * iters);
   hipEventRecord(e0);
   hipLaunchKernelGGL((k<SHAPE>), dim3(blocks), dim3(256), 0, 0, dev, init, iters);
   hipEventRecord(e1); hipEventSynchronize(e1);
@@ -89,10 +92,10 @@ int main() {
     srand(1);
     for (int i = 0; i < 4096; ++i) { unsigned a = 0x3800 + (rand() & 0x7ff), b = 0xb800 + (rand() & 0x7ff); h[i] = mode ? (a | (b << 16)) : 0u; }
     hipMemcpy(init, h, sizeof(h), hipMemcpyHostToDevice);
-    for (int rep = 0; rep < 2; ++rep)
+    for (int rep = 0; rep < 3; ++rep)
       for (int blocks : {1, 256}) {
-        run<16>(dev, init, mode ? "random" : "zero  ", blocks, 4096);
-        run<32>(dev, init, mode ? "random" : "zero  ", blocks, 4096);
+        run<16>(dev, init, mode ? "random" : "zero  ", blocks, 32768);
+        run<32>(dev, init, mode ? "random" : "zero  ", blocks, 32768);
       }
   }
   return 0;
