@@ -1210,7 +1210,7 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
 // H1 = true (encoder-stack build only): the single-MFMA "fast" variant, TW_PATH_FUSED_H1 - one half-precision MFMA per
 // product (fp16 hi halves only), the weight stream of h3_geom(d, true); tools/gen_h3_*_asm.py --h1 -> tw_h1_*_asm.inc.
 // Not a parity path: operands carry 11 significand bits.
-template <int NT, bool ASM, bool DENSE = false, bool WIDE = false, bool RFF = false, bool ENC = false, bool H1 = false>
+template <int NT, bool ASM, bool DENSE = false, bool WIDE = false, bool RFF = false, bool ENC = false, bool H1 = false, bool NG6 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 netblock_h3_kernel(const H3Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1218,6 +1218,9 @@ netblock_h3_kernel(const H3Params p) {
                 "the single-MFMA variant exists as the encoder-stack build (<= 48 atoms), for the wide layout, and - MLP sections "
                 "only, the softmax attention block stays in split form - for the dense model");
   static_assert(!WIDE || (ASM && !DENSE), "the wide layout exists for the asm build of the kernel-attention variant");
+  // NG6: the wide layout's six-group statement (161 .. 192 atoms) as an instantiation of its own - its clobber list reaches v239,
+  // and inside one kernel with the three- / five-group statements it cost every wide launch 30 more spilled registers
+  static_assert(!NG6 || WIDE, "six-group windows belong to the wide layout");
   static_assert(!RFF || DENSE, "position features belong to the dense model");
   static_assert(!ENC || (ASM && !DENSE && !WIDE && NT == 3), "the encoder-stack statement is the 48-token kernel-attention build");
   static_assert(NT == 3 || (NT == 4 && !DENSE && !WIDE && !RFF && !ENC),
@@ -1976,7 +1979,7 @@ netblock_h3_kernel(const H3Params p) {
         const int win = __builtin_amdgcn_readfirstlane(wave == 0 ? p.win[0] : wave == 1 ? p.win[1] : wave == 2 ? p.win[2] : p.win[3]);
         // (p.ng is launch-uniform: three-group windows for 65 .. 96 atoms at the 96-slot stride, five otherwise)
         if constexpr (H1) {
-          if (p.ng == H3W_NG6) {
+          if constexpr (NG6) {
           asm volatile(
 #include "tw_h1_attns6_asm.inc"
               : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -2004,7 +2007,7 @@ netblock_h3_kernel(const H3Params p) {
 #include "tw_h1_attns_clobbers.inc"
           );
           }
-        } else if (p.ng == H3W_NG6) {
+        } else if constexpr (NG6) {
         asm volatile(
 #include "tw_h3_attns6_asm.inc"
             : [cur] "+s"(cur), [gn] "+v"(gn)
@@ -2542,9 +2545,13 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
       if ((prc = lim_h1d.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, false, false, true>, (int)H3D_LDS_BYTES))) return prc;
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, false, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
     } else if (wide) {
-      static LdsLimit lim_h1w;
+      static LdsLimit lim_h1w, lim_h1w6;
       if ((prc = lim_h1w.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, true>, (int)H3W_LDS_BYTES))) return prc;
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+      if ((prc = lim_h1w6.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, true, true>, (int)H3W_LDS_BYTES))) return prc;
+      if (wd.ng == H3W_NG6)
+        hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, true, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+      else
+        hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
     } else {
       TW_REQUIRE(dump == nullptr || (g_debug_flags & 16), "single-MFMA path: no activation dumps (section stamps only)");
       static LdsLimit lim_h1;
@@ -2552,7 +2559,12 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, false, false, true, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
     }
   } else if (wide) {
-    hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+    static LdsLimit lim_wide6;
+    if ((prc = lim_wide6.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, false, true>, (int)H3W_LDS_BYTES))) return prc;
+    if (wd.ng == H3W_NG6)
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+    else
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
   } else if (d.variant == 1 && d.d_rff > 0) {
     static LdsLimit lim_rff, lim_rff_cpp;
     if ((prc = lim_rff.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, true>, (int)H3D_LDS_BYTES))) return prc;
