@@ -1,0 +1,148 @@
+"""r05: the encoder stack as ONE generated asm statement for the kernel families that still ran compiled glue between their
+asm sections (and spilled 200-528 bytes per lane around it): the 64-token build (49-64 atoms, BASELINE configs[3]), the wide
+layout, the dense softmax kernel.  Each statement against the oracle, against the per-section build of the same kernel
+(tw_debug_set_flags bit 12) and against itself (a repeated run must be bit-identical)."""
+import pytest
+import torch
+
+from oracle import flow_oracle as fo
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+H3, H1 = 3, 4
+NT4, PER_SECTION = 65536, 4096
+
+
+def _ragged(V, lens, seed):
+    g = torch.Generator().manual_seed(seed)
+    B = len(lens)
+    at = torch.randint(0, 5, (B, V), generator=g)
+    x_c = torch.randn(B, V, 3, generator=g) * 0.5
+    x_v = torch.randn(B, V, 3, generator=g) * 0.5
+    y_c = x_c + torch.randn(B, V, 3, generator=g) * 0.02
+    y_v = torch.randn(B, V, 3, generator=g) * 0.5
+    mask = torch.zeros(B, V, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    return g, at, x_c, x_v, y_c, y_v, mask
+
+
+def _loglik(m, at, x_c, x_v, y_c, y_v, mask):
+    return m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(), y_velocs=y_v.cuda(),
+                            adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()
+
+
+def _sample(m, at, x_c, x_v, mask, zc, zv):
+    yc, yv, lp = m.conditional_sample_with_logp(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), adj_list=None,
+                                                edge_batch_idx=None, masked_elements=mask.cuda(), num_samples=zc.shape[0],
+                                                z_coords=zc.cuda(), z_velocs=zv.cuda())
+    return yc.cpu(), yv.cpu(), lp.cpu()
+
+
+@pytest.mark.parametrize("V,lens", [(49, [49, 49, 40, 49, 49, 49, 49, 31, 49]), (60, [60, 60, 60, 60, 51, 60, 60, 60, 60, 60, 42]),
+                                    (64, [64, 64, 50, 64, 64, 64])])
+def test_64_token_encoder_stack_statement(V, lens):
+    """tools/gen_h3_enc_asm.py --nt=4: forward pass on a ragged batch of more than one workgroup (padding tokens in the last
+    one, two or three token tiles) and the reverse pass of one conditioning state, against the oracle and the per-section build."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_kernel_sd()
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 1500 + V)
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    S = 9
+    zc, zv = fo.draw_latents(sd, S, (1, V, 3), g)
+    rs = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, at[:1], x_c[:1], x_v[:1], mask[:1], zc, zv)
+    m = H.tw_kernel_model(sd, path=H3)
+
+    def run():
+        return (_loglik(m, at, x_c, x_v, y_c, y_v, mask),) + _sample(m, at[:1], x_c[:1], x_v[:1], mask[:1], zc, zv)
+
+    try:
+        lib.tw_debug_set_flags(NT4)
+        stack, again = run(), run()
+        lib.tw_debug_set_flags(NT4 | PER_SECTION)
+        sections = run()
+    finally:
+        lib.tw_debug_set_flags(0)
+    H.assert_not_demoted(m)
+    for a, b in zip(stack, again):
+        assert torch.equal(a, b)
+    assert not torch.equal(stack[0], sections[0])   # two different kernels did run
+    keep = ~mask[0]
+    for name, out in (("stack", stack), ("sections", sections)):
+        errs = (H.rel_err(out[0], ref), H.rel_err(out[1][:, :, keep], rs[0][:, :, keep]), H.rel_err(out[2][:, :, keep], rs[1][:, :, keep]),
+                H.rel_err(out[3], rs[2]))
+        print(f"64-token {name} vs oracle, V = {V}:", errs)
+        assert max(errs) < TOL, (name, errs)
+
+
+@pytest.mark.parametrize("n_layers", [1, 2, 4])
+def test_64_token_encoder_stack_layer_counts(n_layers):
+    """The layer loop (scales, side blocks, score fragments advancing per layer) lives inside the statement."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    spec = fo.FlowSpec(variant="kernel", num_transformer_layers=n_layers, num_coupling_layers=2)
+    sd = fo.synth_state_dict(fo.make_template(spec), 0)
+    V, lens = 52, [52, 52, 45, 52, 52]
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 1600 + n_layers)
+    ref = fo.log_likelihood(sd, spec, at, x_c, x_v, y_c, y_v, mask)
+    m = H.tw_kernel_model(sd, path=H3, n_coupling=2, n_layers=n_layers)
+    try:
+        lib.tw_debug_set_flags(NT4)
+        out = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+    finally:
+        lib.tw_debug_set_flags(0)
+    H.assert_not_demoted(m)
+    assert H.rel_err(out, ref) < TOL, H.rel_err(out, ref)
+
+
+def test_64_token_encoder_stack_chebyshev_fragments_per_layer():
+    """chebyshev_kernel: one score-fragment set per (net, layer) - the statement advances its fragment pointer (an SGPR pair
+    in this build) by the variant stride per layer."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_cheb_sd()
+    V, lens = 52, [52, 47, 52, 52, 52, 39]
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 1700)
+    ref = fo.log_likelihood(sd, H.FULL_CHEB_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    m = H.tw_kernel_model(sd, path=H3, attention_type="chebyshev_kernel", cheb_order=6, force_asymptotic_zero=True)
+    try:
+        lib.tw_debug_set_flags(NT4)
+        out = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+        lib.tw_debug_set_flags(NT4 | PER_SECTION)
+        sec = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+    finally:
+        lib.tw_debug_set_flags(0)
+    H.assert_not_demoted(m)
+    assert H.rel_err(out, ref) < 2e-5 and H.rel_err(sec, ref) < 2e-5, (H.rel_err(out, ref), H.rel_err(sec, ref))
+    assert H.rel_err(out, sec) < 5e-6, H.rel_err(out, sec)
+
+
+def test_64_token_encoder_stack_fast_mode():
+    """The single-MFMA form of the same statement (tw_h1n4_enc_asm.inc): NOT a parity path - held to the per-section fast
+    build at the fast mode's own noise and to the oracle at the measured deviation of that mode (tests/test_flow_h1_gpu.py)."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_kernel_sd()
+    V, lens = 60, [60, 60, 60, 60, 51, 60, 60, 60, 60]
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 1800)
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    m = H.tw_kernel_model(sd, path=H1)
+    try:
+        lib.tw_debug_set_flags(NT4)
+        stack, again = _loglik(m, at, x_c, x_v, y_c, y_v, mask), _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+        lib.tw_debug_set_flags(NT4 | PER_SECTION)
+        sections = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+    finally:
+        lib.tw_debug_set_flags(0)
+    assert torch.equal(stack, again)
+    e_ref, e_sec = H.rel_err(stack, ref), H.rel_err(stack, sections)
+    print("fast mode, 64-token statement: vs oracle", e_ref, "vs per-section build", e_sec, "per-section vs oracle", H.rel_err(sections, ref))
+    assert e_ref < 1.5e-3 and e_sec < 1.5e-3, (e_ref, e_sec)
+    assert e_ref > 1e-6   # it is the single-MFMA arithmetic

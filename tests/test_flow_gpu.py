@@ -925,9 +925,19 @@ def test_full_size_v60_S512_rows_vs_oracle(path):
     assert H.rel_err(yc.cpu()[rows], ryc) < tol and H.rel_err(yv.cpu()[rows], ryv) < tol
     assert H.rel_err(lp.cpu()[rows], rlp) < tol and H.elem_rel_err(lp.cpu()[rows], rlp) < tol
     n = len(rows)
+    # The reverse-move density as a FUNCTION: the oracle evaluated at the kernel's own proposals, element-wise at the bar.
+    g_yx = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, d["atom_types"].repeat(n, 1), yc.cpu()[rows].squeeze(1), -yv.cpu()[rows].squeeze(1),
+                             d["x_coords"].repeat(n, 1, 1), -d["x_velocs"].repeat(n, 1, 1), d["masked"].repeat(n, 1))
+    assert H.rel_err(p_yx[rows], g_yx) < tol and H.elem_rel_err(p_yx[rows], g_yx) < tol, H.elem_rel_err(p_yx[rows], g_yx)
+    # ... and as a CHAIN (kernel's proposals -> kernel's density against oracle's proposals -> oracle's density): relative to
+    # the tensor's scale at the bar; element-wise this is two evaluations at inputs that differ by the proposals' own
+    # 2-3e-6, and this un-calibrated 60-atom model turns a 1e-6 perturbation of y into 1.9e-5 of log p(x|y) in fp64
+    # arithmetic (tools/v60_conditioning.py, profiles/r05_v60_conditioning.txt: condition number ~19; the fp32 oracle's own
+    # chain is 2.9e-6 from the fp64 one) - so element-wise the chain is held to 2e-5 (r05: the encoder-stack statement of the
+    # 64-token build measured 1.02e-5, its per-section build passed at 1e-5; r04's 1e-5 here had no margin over that noise).
     r_yx = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, d["atom_types"].repeat(n, 1), ryc.squeeze(1), -ryv.squeeze(1),
                              d["x_coords"].repeat(n, 1, 1), -d["x_velocs"].repeat(n, 1, 1), d["masked"].repeat(n, 1))
-    assert H.rel_err(p_yx[rows], r_yx) < tol and H.elem_rel_err(p_yx[rows], r_yx) < tol
+    assert H.rel_err(p_yx[rows], r_yx) < tol and H.elem_rel_err(p_yx[rows], r_yx) < 2e-5, H.elem_rel_err(p_yx[rows], r_yx)
 
 
 @pytest.mark.parametrize("n_coupling,pos_mod2", [(2, 0), (2, 1), (4, 1), (6, 0)])

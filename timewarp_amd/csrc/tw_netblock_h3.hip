@@ -1222,9 +1222,9 @@ netblock_h3_kernel(const H3Params p) {
   // and inside one kernel with the three- / five-group statements it cost every wide launch 30 more spilled registers
   static_assert(!NG6 || WIDE, "six-group windows belong to the wide layout");
   static_assert(!RFF || DENSE, "position features belong to the dense model");
-  static_assert(!ENC || (ASM && !DENSE && !WIDE && NT == 3), "the encoder-stack statement is the 48-token kernel-attention build");
-  static_assert(NT == 3 || (NT == 4 && !DENSE && !WIDE && !RFF && !ENC),
-                "64-token waves: the kernel-attention variant, one molecule of 49-64 atoms per wave, per-section build");
+  static_assert(!ENC || (ASM && !DENSE && !WIDE), "the encoder-stack statement: the 48- and 64-token kernel-attention builds");
+  static_assert(NT == 3 || (NT == 4 && !DENSE && !WIDE && !RFF),
+                "64-token waves: the kernel-attention variant, one molecule of 49-64 atoms per wave");
   constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
   // 64-token build: all four GEMM sections are generated asm (tools/gen_h3_ffn_asm.py / gen_h3_attn_asm.py --nt=4), the glue
   // between them compiled C++ (the per-section build)
@@ -1626,6 +1626,43 @@ netblock_h3_kernel(const H3Params p) {
     // (only read by the H3_ENC_EXPERIMENT=stamps build of the statement, tools/profile_h3_sections.py)
     const float* stamp_base = p.dump;
     const int stampen = __builtin_amdgcn_readfirstlane(((p.debug & 16) && p.dump && blockIdx.x == 0 && wave == 0) ? 1 : 0);
+    if constexpr (NT == 4) {
+      // 64-token build (tools/gen_h3_enc_asm.py --nt=4): the statement owns v0..v245 and keeps nothing of its own in VGPRs
+      // across the embedded blocks, so its pointers arrive in SGPRs (all of them are wave-uniform)
+      auto uniform64 = [](const void* ptr) {
+        const uint64_t u = (uint64_t)(uintptr_t)ptr;
+        return (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u) |
+               ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32)) << 32);
+      };
+      const uint64_t sf_u = uniform64(sf_net), side_u = uniform64((const char*)(side + p.side_layers)), dump_u = uniform64(stamp_base);
+      const uint64_t scales_u = uniform64(scp);
+      const unsigned sfstride_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)sfstride);
+      const unsigned sfstride_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)sfstride >> 32));
+      const unsigned sidestride32 = (unsigned)__builtin_amdgcn_readfirstlane((int)sidestride);
+      if constexpr (H1) {
+        asm volatile(
+#include "tw_h1n4_enc_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+              [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
+              [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+              [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen)
+            :
+#include "tw_h1n4_enc_clobbers.inc"
+        );
+      } else {
+        asm volatile(
+#include "tw_h3n4_enc_asm.inc"
+            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+              [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
+              [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+              [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen)
+            :
+#include "tw_h3n4_enc_clobbers.inc"
+        );
+      }
+    } else
     if constexpr (H1) {
     if (p.windowed) {
       asm volatile(
@@ -2529,13 +2566,29 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
     if ((prc = lim_n4_cpp.ensure((const void*)netblock_h3_kernel<H3N4_NT, false>, (int)H3N4_LDS_BYTES))) return prc;
     if ((prc = lim_n4_h1.ensure((const void*)netblock_h3_kernel<H3N4_NT, true, false, false, false, false, true>, (int)H3N4_LDS_BYTES)))
       return prc;
-    if (h1)
+    // the encoder-stack statement (r05: no compiled glue, no scratch) unless activations / section stamps between the
+    // sections are asked for: same switches as the 48-token kernel (bit 12: per-section build, bit 13: encoder stack anyway)
+    const bool per_section = ((dump != nullptr || (g_debug_flags & (4 | 16 | 4096))) && !(g_debug_flags & 8192)) || d.n_layers < 1;
+    if (h1 && per_section)
       hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true, false, false, false, false, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES,
                          a.stream, p);
-    else if (g_debug_flags & 8)
+    else if (h1) {
+      static LdsLimit lim_n4_h1e;
+      if ((prc = lim_n4_h1e.ensure((const void*)netblock_h3_kernel<H3N4_NT, true, false, false, false, true, true>, (int)H3N4_LDS_BYTES)))
+        return prc;
+      hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true, false, false, false, true, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES,
+                         a.stream, p);
+    } else if (g_debug_flags & 8)
       hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, false>), dim3(grid), dim3(256), H3N4_LDS_BYTES, a.stream, p);
-    else
+    else if (per_section)
       hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES, a.stream, p);
+    else {
+      static LdsLimit lim_n4_enc;
+      if ((prc = lim_n4_enc.ensure((const void*)netblock_h3_kernel<H3N4_NT, true, false, false, false, true>, (int)H3N4_LDS_BYTES)))
+        return prc;
+      hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true, false, false, false, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES,
+                         a.stream, p);
+    }
   } else if (h1) {
     // single-MFMA build: the encoder-stack statement (section stamps compiled in; no activation dumps), or the wide layout's
     // per-section build

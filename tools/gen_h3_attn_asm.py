@@ -61,9 +61,9 @@ if NT4:
     SLOT = lambda p, part: 192 + 8 * p + (0 if part == "h" else 4)
     V_T, V_TILE, V_XT0, V_XT1, V_GN, V_TMP, V_LANE16, V_SF16, V_SF8, V_TMP2 = 224, 232, 233, 233, 234, 236, 238, 240, 242, 244
     YACC = lambda ot, jt: 4 * (4 * ot + jt)
-    S_K3 = 98        # 3 * SF_BYTES; s100:101 = NT * SF_BYTES (fragment stride per head)
-    S_SFHEAD = 100
-    N_V, N_A, N_S = 246, 128, 102
+    S_K3 = 98        # 3 * SF_BYTES; s82:83 = NT * SF_BYTES (fragment stride per head) - not s100:101, which hipcc reserves
+    S_SFHEAD = 82
+    N_V, N_A, N_S = 246, 128, 100
 EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(",")))
 # --mode=windowed: waves that hold two or more molecules.  The score matrix is block diagonal, so query tile 0 only has
 # keys in [0, 32) and query tile 2 only in [16, 48): each takes ONE K=32 mixing MFMA per term (tile 2 with the
@@ -465,7 +465,7 @@ def main():
     out = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''}{' --nt=4' if NT4 else ''}{' --h1' if H1 else ''} - do not edit.  Body of the attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")
-    clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A)] + [f'"s{i}"' for i in range(84, N_S)] + \
+    clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(N_A)] + [f'"s{i}"' for i in range(82 if NT4 else 84, N_S)] + \
            ['"vcc"', '"scc"', '"memory"']
     cl = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''}{' --nt=4' if NT4 else ''}{' --h1' if H1 else ''} - clobber list of the attention asm statement."]
     for i in range(0, len(clob), 12):

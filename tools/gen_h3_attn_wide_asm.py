@@ -60,6 +60,11 @@ N_V, N_A = (240 if NG == 6 else 212), 160
 H1 = "--h1" in sys.argv
 N_SF_LOADS = (1 if H1 else 2) * NT * NG    # global loads per head
 EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(",")))
+# Set by tools/gen_h3_enc_asm.py --wide, which embeds this block in the asm statement of the whole encoder stack: the
+# accumulators arrive holding the residual (x / scale) instead of zeros, y stays in a0..a95, and the score fragments of the
+# layer are addressed through SF_BASE (an SGPR pair that statement advances per layer).
+FUSED = False
+SF_BASE = "%[sf]"
 
 
 def vr(base, n=4):
@@ -255,7 +260,7 @@ def generate():
     A(f"v_add_u32 v{V_XTL}, {XT_LO}, v{V_XTH}")
     A(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_LANE16}")
     A(f"v_mov_b32 v{V_LANE16 + 1}, 0")
-    A(f"v_lshl_add_u64 {vr(V_SF, 2)}, %[sf], 0, {vr(V_LANE16, 2)}")
+    A(f"v_lshl_add_u64 {vr(V_SF, 2)}, {SF_BASE}, 0, {vr(V_LANE16, 2)}")
     A(f"s_lshl_b32 s{S_W2048}, %[wave], 11")
     A(f"s_mov_b32 s{S_W2048 + 1}, 0")
     A(f"s_mov_b32 s{S_STRIDE}, {STAGE}")
@@ -269,8 +274,9 @@ def generate():
     A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
     A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
     A(f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}")
-    for i in range(96):
-        A(f"v_accvgpr_write_b32 a{i}, 0")
+    if not FUSED:
+        for i in range(96):
+            A(f"v_accvgpr_write_b32 a{i}, 0")
     # ---- prologue: score fragments of head 0, mixing of (0, 0) and its split in the open
     L += sf_loads()
     A("s_waitcnt vmcnt(0)")
@@ -328,12 +334,13 @@ def generate():
     A("s_barrier")
     A("s_nop 15")
     A("s_nop 15")
-    A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-    for i in range(24):
-        for r in range(4):
-            A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
-        A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
-    A("s_waitcnt lgkmcnt(0)")
+    if not FUSED:
+        A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
+        for i in range(24):
+            for r in range(4):
+                A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
+            A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
+        A("s_waitcnt lgkmcnt(0)")
     A(f"s_sub_u32 s{S_AUXOFF}, 0, s{S_W2048}")
     A(f"s_subb_u32 s{S_AUXOFF + 1}, 0, 0")
     A(f"v_lshl_add_u64 %[gn], {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]")
@@ -361,4 +368,5 @@ def main():
     print(f"wide{flags}: {len(lines)} instructions, {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs")
 
 
-main()
+if __name__ == "__main__":
+    main()
