@@ -19,7 +19,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import asm_emu as E  # noqa: E402
 
 SL, PRIV = 120 * 1024, 32 * 1024   # LDS addresses of the side block and of the wave-private block in these tests
-OPERANDS = {"sl": "s10", "priv": "s11", "padm": "v250"}
+XT, WAVE = 8 * 1024, 2              # wide layout: the workgroup's shared X^T tile; the wave these tests play (token slots 96..143)
+OPERANDS = {"sl": "s10", "priv": "s11", "padm": "v250", "xt": "s12", "wave": "s13"}
 
 
 def load_gen(name, argv):
@@ -47,11 +48,13 @@ class Setup:
         rng = np.random.default_rng(seed)
         self.lds = np.zeros(160 * 1024, np.uint8)
         self.w = w = E.Wave(lds=self.lds)
-        self.side = rng.standard_normal(656).astype(np.float32)
-        self.lds[SL:SL + 656 * 4] = self.side.view(np.uint8)
+        self.side = rng.standard_normal(1280).astype(np.float32)   # (dense: in_proj / out_proj biases behind the 656)
+        self.lds[SL:SL + 1280 * 4] = self.side.view(np.uint8)
         lane = np.arange(64)
         self.g, self.i16 = lane // 16, lane % 16
-        w.s[10], w.s[11] = SL, PRIV
+        w.s[10], w.s[11], w.s[12], w.s[13] = SL, PRIV, XT, WAVE
+        if enc.DENSE:
+            w.s[enc.S_SLCUR], w.s[enc.S_SLOTHER] = SL, SL + 5120
         self.pad = np.zeros((self.NT, 16), bool)
         if pad_tile is not None:
             self.pad[pad_tile, 11:] = True           # tokens 11..15 of that tile are padding
@@ -64,7 +67,7 @@ class Setup:
         w.s[enc.S_EPS] = f32(1e-5)
         w.s[enc.S_IA] = f32(1 / self.sc_a)
         w.s[enc.S_IF] = f32(1 / self.sc_f)
-        if not enc.NT4:   # the 48-token statement keeps these in registers across the layer loop
+        if not enc.STATELESS:   # the 48-token statement keeps these in registers across the layer loop
             w.v[enc.V_SLG] = SL + 16 * self.g
             w.v[enc.V_PRIV16] = PRIV + 16 * lane
             w.v[enc.V_PRIV8] = PRIV + 8 * lane
@@ -89,8 +92,10 @@ class Setup:
                     X[jt, self.i16, 16 * ft + 4 * self.g + r] = regs[ft, jt, r]
         return X
 
-    def layer_norm(self, scale, w_off, b_off):
+    def layer_norm(self, scale, w_off, b_off, pre_bias=None):
         X = self.tokens(self.t) * np.float64(scale)
+        if pre_bias is not None:
+            X = X + self.side[pre_bias:pre_bias + 128]
         mean = X.mean(-1, keepdims=True)
         var = ((X - mean) ** 2).mean(-1, keepdims=True)
         Y = (X - mean) / np.sqrt(var + 1e-5) * self.side[w_off:w_off + 128] + self.side[b_off:b_off + 128]
@@ -127,7 +132,8 @@ def check_split(got_hi, got_lo, want, h1, what):
         assert np.abs(got_hi - want).max() / scale < 1.5e-3, what
 
 
-VARIANTS = [(), ("--mode=windowed",), ("--h1",), ("--nt=4",), ("--nt=4", "--h1")]
+VARIANTS = [(), ("--mode=windowed",), ("--h1",), ("--nt=4",), ("--nt=4", "--h1"), ("--wide",), ("--wide", "--h1"), ("--wide", "--ng=6"),
+            ("--dense",), ("--dense", "--h1")]
 
 
 @pytest.mark.parametrize("argv", VARIANTS, ids=lambda a: " ".join(a) or "nt3")
@@ -136,7 +142,7 @@ def test_g1_layernorm_ffn_operands_and_seeds(argv, pad_tile):
     enc = load_gen("gen_h3_enc_asm", argv)
     s = Setup(enc, 1, pad_tile)
     E.run(s.w, enc.g1(), OPERANDS)
-    Y = s.layer_norm(s.sc_a, 0, 128)
+    Y = s.layer_norm(s.sc_a, 0, 128, pre_bias=1040 if enc.DENSE else None)   # dense: + out_proj's bias (csrc H3D_OUTB)
     n_vg = 2 if enc.NT4 else 3
     for ks in range(4):
         for jt in range(s.NT):
@@ -156,9 +162,24 @@ def xt_images(s, enc):
     """The transposed copy the attention block will read: [part][jt][token 16][feature 128] from the AGPR images (48-token
     statement) or the wave-private LDS block (64-token statement)."""
     out = np.zeros((2, s.NT, 16, 128))
+    if enc.DENSE:
+        # no transposed copy: the attention block's operands are the split activations in a96..a191 (always hi and lo)
+        for ks in range(4):
+            for jt in range(s.NT):
+                for part, name in enumerate("hl"):
+                    h = halves(s.w.a[enc.attn.XB(ks, jt, name):enc.attn.XB(ks, jt, name) + 4])
+                    for e in range(8):
+                        out[part, jt, s.i16, 32 * ks + 16 * (e // 4) + 4 * s.g + e % 4] = h[:, e]
+        return out
     for ft in range(8):
         for part in range(1 if enc.H1 else 2):
-            if enc.NT4:
+            if enc.WIDE:
+                # the shared tile [feature][192 tokens + pad]: rows of XT_ROW bytes, the lo half XT_LO behind the hi half
+                for f in range(16):
+                    a = XT + part * enc.attn.XT_LO + (16 * ft + f) * enc.attn.XT_ROW + 2 * 48 * WAVE
+                    row = s.lds[a:a + 96].view(np.float16).astype(np.float64)   # this wave's 48 tokens
+                    out[part, :, :, 16 * ft + f] = row.reshape(s.NT, 16)
+            elif enc.NT4:
                 for pair in range(2):
                     a = PRIV + 2 * enc.XT_IMG * ft + enc.XT_IMG * part + 1024 * pair
                     h = s.lds[a:a + 1024].view(np.float16).reshape(64, 8).astype(np.float64)   # [lane][e]
@@ -181,14 +202,14 @@ def test_g2_layernorm_transposed_copy_and_seeds(argv):
     enc = load_gen("gen_h3_enc_asm", argv)
     s = Setup(enc, 2, pad_tile=s_pad(enc))
     s.w.s[enc.S_IA] = f32(1 / s.sc_next)      # (by then S_IA holds the NEXT layer's attention scale)
-    if not enc.NT4:
+    if not enc.STATELESS:
         s.w.v[enc.V_C2] = s.w.v[enc.V_C2 + 1] = f32(1 / s.sc_next)
     E.run(s.w, enc.g2(False), OPERANDS)
     Y = s.layer_norm(s.sc_f, 384, 512)
     xt = xt_images(s, enc)
     for jt in range(s.NT):
         hi, lo = xt[0, jt], xt[1, jt]
-        check_split(hi, lo, Y[jt], enc.H1, ("xt", jt))
+        check_split(hi, lo, Y[jt], enc.H1A, ("xt", jt))
     seeds = s.acc_tokens()
     want = Y / np.float64(s.sc_next)
     assert np.abs(seeds - want).max() / np.abs(want).max() < 1e-6
@@ -230,11 +251,13 @@ def test_entry_reads_x_and_builds_the_first_transposed_copy(argv):
     # the operands of the statement
     gm = np.zeros(4096, np.uint8)
     scales = np.array([s.sc_a, 0, s.sc_f], np.float32)
-    gm[256:268] = scales.view(np.uint8)
+    if enc.DENSE:   # [0] is the in_proj scale there; the residual scale (out_proj's) sits 2 + 3 L floats behind the pointer
+        scales = np.array([77.0, 0, s.sc_f] + [0] * 8 + [s.sc_a], np.float32)
+    gm[256:256 + 4 * len(scales)] = scales.view(np.uint8)
     s.w.gmem, s.w.gbase = gm, 0x1000
     s.w.s[20], s.w.s[21] = 0x1000 + 256, 0
     ops = dict(OPERANDS, layers="3", padt="0", scales="s[20:21]", eps="s22", sf="s[24:25]", side="s[26:27]", dump="s[28:29]",
-               stampen="0")
+               stampen="0", sidestride="5120")
     s.w.s[22] = f32(1e-5)
     lines = enc.generate()
     entry = lines[:lines.index(".Lenc_layer_%=:")]
@@ -242,25 +265,27 @@ def test_entry_reads_x_and_builds_the_first_transposed_copy(argv):
     X = s.tokens(x)
     xt = xt_images(s, enc)
     for jt in range(s.NT):
-        check_split(xt[0, jt], xt[1, jt], X[jt], enc.H1, ("xt", jt))
+        check_split(xt[0, jt], xt[1, jt], X[jt], enc.H1A, ("xt", jt))
     seeds = s.acc_tokens()
     want = X / np.float64(s.sc_a)
     assert np.abs(seeds - want).max() / np.abs(want).max() < 1e-6
     assert s.w.s[enc.S_IF].view(np.float32) == np.float32(1 / s.sc_f)
 
 
-@pytest.mark.parametrize("argv", [("--nt=4",), ("--nt=4", "--h1")], ids=lambda a: " ".join(a))
+@pytest.mark.parametrize("argv", [("--nt=4",), ("--nt=4", "--h1"), ("--wide",), ("--wide", "--ng=6", "--h1"), ("--dense",), ("--dense", "--h1")],
+                         ids=lambda a: " ".join(a))
 def test_the_64_token_glue_keeps_nothing_in_registers_across_the_embedded_blocks(argv):
-    """Every glue phase of the 64-token statement must work from a register file the embedded blocks have overwritten:
+    """Every glue phase of the 64-token statement (and of the wide / dense ones, which take the same form) must work from a
+    register file the embedded blocks have overwritten:
     poison all VGPRs and the AGPRs the blocks own for their operands, then run each phase."""
     enc = load_gen("gen_h3_enc_asm", argv)
     for phase, make in (("g1", enc.g1), ("g2", lambda: enc.g2(False)), ("g2 last", lambda: enc.g2(True))):
         s = Setup(enc, 7)
         s.w.v[:250] = 0x7FC12345   # NaN pattern
-        s.w.a[128:] = 0x7FC12345
+        s.w.a[128 if enc.NT4 else 96:] = 0x7FC12345
         E.run(s.w, make(), OPERANDS)
         assert np.isfinite(s.acc_tokens()).all() or phase == "g2 last", phase
         if phase == "g1":
-            Y = s.layer_norm(s.sc_a, 0, 128)
+            Y = s.layer_norm(s.sc_a, 0, 128, pre_bias=1040 if enc.DENSE else None)
             want = (Y + s.side[256:384]) / np.float64(s.sc_f)
             assert np.abs(s.acc_tokens() - want).max() / np.abs(want).max() < 1e-6

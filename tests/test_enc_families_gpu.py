@@ -146,3 +146,214 @@ def test_64_token_encoder_stack_fast_mode():
     print("fast mode, 64-token statement: vs oracle", e_ref, "vs per-section build", e_sec, "per-section vs oracle", H.rel_err(sections, ref))
     assert e_ref < 1.5e-3 and e_sec < 1.5e-3, (e_ref, e_sec)
     assert e_ref > 1e-6   # it is the single-MFMA arithmetic
+
+
+# ---- the wide layout (25-192 atoms: molecules packed over the workgroup's 192 token slots) ----
+ALWAYS_WIDE, FIVE_GROUPS_ONLY = 32768, 262144
+
+
+@pytest.mark.parametrize("V,lens,flags", [
+    (30, [30, 28, 30, 30, 25, 30, 30, 30], ALWAYS_WIDE),           # six molecules per workgroup, five-group windows
+    (48, [48, 40, 48, 48, 48], ALWAYS_WIDE),                        # four per workgroup: every molecule is one wave's tokens
+    (65, [65, 65, 50, 65, 65], 0),                                  # 96-slot stride, three-group windows (tw_h3w3_enc_asm.inc)
+    (88, [88, 88, 61, 88, 88], 0),
+    (70, [70, 44, 70], FIVE_GROUPS_ONLY),                           # the same sizes on the five-group statement
+    (100, [100, 87, 100], 0),                                       # one molecule per workgroup, padding waves
+    (150, [150, 131], 0),
+    (176, [176, 176, 133], 0),                                      # six-group windows (tw_h3w6_enc_asm.inc)
+    (192, [192, 161, 192], 0)])
+def test_wide_encoder_stack_statement(V, lens, flags):
+    """tools/gen_h3_enc_asm.py --wide [--ng=3|6]: forward pass on a ragged batch of more than one workgroup and the reverse pass of
+    one conditioning state, against the oracle, against the per-section build (bit 12) and against itself."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_kernel_sd()
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 2500 + V)
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    S = 7
+    zc, zv = fo.draw_latents(sd, S, (1, V, 3), g)
+    rs = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, at[:1], x_c[:1], x_v[:1], mask[:1], zc, zv)
+    m = H.tw_kernel_model(sd, path=H3)
+
+    def run():
+        return (_loglik(m, at, x_c, x_v, y_c, y_v, mask),) + _sample(m, at[:1], x_c[:1], x_v[:1], mask[:1], zc, zv)
+
+    try:
+        lib.tw_debug_set_flags(flags)
+        stack, again = run(), run()
+        lib.tw_debug_set_flags(flags | PER_SECTION)
+        sections = run()
+    finally:
+        lib.tw_debug_set_flags(0)
+    H.assert_not_demoted(m)
+    for a, b in zip(stack, again):
+        assert torch.equal(a, b)
+    assert not torch.equal(stack[0], sections[0])   # two different kernels did run
+    keep = ~mask[0]
+    for name, out in (("stack", stack), ("sections", sections)):
+        errs = (H.rel_err(out[0], ref), H.rel_err(out[1][:, :, keep], rs[0][:, :, keep]), H.rel_err(out[2][:, :, keep], rs[1][:, :, keep]),
+                H.rel_err(out[3], rs[2]))
+        print(f"wide {name} vs oracle, V = {V}:", errs)
+        assert max(errs) < TOL, (name, errs)
+
+
+@pytest.mark.parametrize("n_layers,V,lens", [(1, 72, [72, 72, 60]), (2, 110, [110, 95]), (4, 36, [36, 36, 36, 30, 36, 36, 36])])
+def test_wide_encoder_stack_layer_counts(n_layers, V, lens):
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    spec = fo.FlowSpec(variant="kernel", num_transformer_layers=n_layers, num_coupling_layers=2)
+    sd = fo.synth_state_dict(fo.make_template(spec), 0)
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 2600 + n_layers)
+    ref = fo.log_likelihood(sd, spec, at, x_c, x_v, y_c, y_v, mask)
+    m = H.tw_kernel_model(sd, path=H3, n_coupling=2, n_layers=n_layers)
+    try:
+        lib.tw_debug_set_flags(ALWAYS_WIDE)
+        out = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+    finally:
+        lib.tw_debug_set_flags(0)
+    H.assert_not_demoted(m)
+    assert H.rel_err(out, ref) < TOL, H.rel_err(out, ref)
+
+
+def test_wide_encoder_stack_chebyshev_fragments_per_layer():
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_cheb_sd()
+    V, lens = 90, [90, 77, 90]
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 2700)
+    ref = fo.log_likelihood(sd, H.FULL_CHEB_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    m = H.tw_kernel_model(sd, path=H3, attention_type="chebyshev_kernel", cheb_order=6, force_asymptotic_zero=True)
+    try:
+        out = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+        lib.tw_debug_set_flags(PER_SECTION)
+        sec = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+    finally:
+        lib.tw_debug_set_flags(0)
+    H.assert_not_demoted(m)
+    assert H.rel_err(out, ref) < 2e-5 and H.rel_err(sec, ref) < 2e-5, (H.rel_err(out, ref), H.rel_err(sec, ref))
+    assert H.rel_err(out, sec) < 5e-6, H.rel_err(out, sec)
+
+
+@pytest.mark.parametrize("V,lens,flags", [(40, [40, 40, 33, 40, 40, 40], ALWAYS_WIDE), (65, [65, 65, 50, 65, 65], 0), (120, [120, 99, 120], 0),
+                                          (180, [180, 150], 0)])
+def test_wide_encoder_stack_fast_mode(V, lens, flags):
+    """tw_h1w{,3,6}_enc_asm.inc: NOT a parity path - held to the per-section fast build and to the oracle at that mode's deviation."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_kernel_sd()
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 2800 + V)
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    m = H.tw_kernel_model(sd, path=H1)
+    try:
+        lib.tw_debug_set_flags(flags)
+        stack, again = _loglik(m, at, x_c, x_v, y_c, y_v, mask), _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+        lib.tw_debug_set_flags(flags | PER_SECTION)
+        sections = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+    finally:
+        lib.tw_debug_set_flags(0)
+    assert torch.equal(stack, again)
+    e_ref, e_sec = H.rel_err(stack, ref), H.rel_err(stack, sections)
+    print(f"fast mode, wide statement, V = {V}: vs oracle", e_ref, "vs per-section build", e_sec, "per-section vs oracle", H.rel_err(sections, ref))
+    assert e_ref < 1.5e-3 and e_sec < 1.5e-3, (e_ref, e_sec)
+    assert e_ref > 1e-6   # it is the single-MFMA arithmetic
+
+
+# ---- the dense softmax model (transformer_nvp; BASELINE configs[4]) ----
+def _dense_case(sd, spec, V, lens, seed, S=7):
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, seed)
+    ref = fo.log_likelihood(sd, spec, at, x_c, x_v, y_c, y_v, mask)
+    zc, zv = fo.draw_latents(sd, S, (1, V, 3), g)
+    rs = fo.conditional_sample_with_logp(sd, spec, at[:1], x_c[:1], x_v[:1], mask[:1], zc, zv)
+    return (at, x_c, x_v, y_c, y_v, mask, zc, zv), ref, rs
+
+
+@pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22, 22, 22, 22, 22]), (7, [7, 5, 6, 7, 7, 3, 7] * 5), (16, [16, 13, 16, 16, 16, 10, 16] * 2),
+                                    (30, [30, 28, 25, 30, 30]), (48, [48, 40, 33, 48, 48])])
+def test_dense_encoder_stack_statement(V, lens):
+    """tools/gen_h3_enc_asm.py --dense: ragged forward pass over more than one workgroup and the reverse pass of one conditioning
+    state, against the oracle, the per-section build (bit 12) and itself."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_dense_sd()
+    (at, x_c, x_v, y_c, y_v, mask, zc, zv), ref, rs = _dense_case(sd, H.FULL_DENSE_SPEC, V, lens, 3500 + V)
+    m = H.tw_dense_model(sd, path=H3)
+
+    def run():
+        return (_loglik(m, at, x_c, x_v, y_c, y_v, mask),) + _sample(m, at[:1], x_c[:1], x_v[:1], mask[:1], zc, zv)
+
+    try:
+        stack, again = run(), run()
+        lib.tw_debug_set_flags(PER_SECTION)
+        sections = run()
+    finally:
+        lib.tw_debug_set_flags(0)
+    H.assert_not_demoted(m)
+    for a, b in zip(stack, again):
+        assert torch.equal(a, b)
+    assert not torch.equal(stack[0], sections[0])   # two different kernels did run
+    keep = ~mask[0]
+    for name, out in (("stack", stack), ("sections", sections)):
+        errs = (H.rel_err(out[0], ref), H.rel_err(out[1][:, :, keep], rs[0][:, :, keep]), H.rel_err(out[2][:, :, keep], rs[1][:, :, keep]),
+                H.rel_err(out[3], rs[2]))
+        print(f"dense {name} vs oracle, V = {V}:", errs)
+        assert max(errs) < TOL, (name, errs)
+
+
+def test_dense_encoder_stack_position_features():
+    """transformer_nvp_posenc.yaml: the in-MLP of the 128 random Fourier features stays compiled C++ in front of the statement.
+    Against the reference's own vectors (tests/golden/dense_posenc_full_ad.npz), the statement and the per-section build."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    d, _ = H.load("dense_posenc_full_ad")
+    m = H.tw_dense_model(H.full_dense_posenc_sd(), rff_dim=128, path=H3)
+    try:
+        out = H.run_model_case(m, d)
+        lib.tw_debug_set_flags(PER_SECTION)
+        sec = H.run_model_case(m, d)
+    finally:
+        lib.tw_debug_set_flags(0)
+    H.assert_not_demoted(m)
+    H.assert_case_close(out, d, tol=TOL)
+    H.assert_case_close(sec, d, tol=TOL)
+    assert any(not torch.equal(torch.as_tensor(out[k]), torch.as_tensor(sec[k])) for k in out)   # two different kernels did run
+
+
+@pytest.mark.parametrize("n_layers", [1, 2, 4])
+def test_dense_encoder_stack_layer_counts(n_layers):
+    """The double-buffered side blocks and out_proj's scale a layer ahead: one, an even and more layers than buffers."""
+    spec = fo.FlowSpec(variant="dense", num_transformer_layers=n_layers, num_coupling_layers=2)
+    sd = fo.synth_state_dict(fo.make_template(spec), 0)
+    V, lens = 20, [20, 18, 20, 20, 20, 11, 20, 20, 20]
+    (at, x_c, x_v, y_c, y_v, mask, zc, zv), ref, rs = _dense_case(sd, spec, V, lens, 3700 + n_layers)
+    m = H.tw_dense_model(sd, path=H3, n_coupling=2, n_layers=n_layers)
+    out = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+    H.assert_not_demoted(m)
+    assert H.rel_err(out, ref) < TOL, H.rel_err(out, ref)
+
+
+def test_dense_encoder_stack_fast_mode():
+    """tw_h1d_enc_asm.inc (MLP sections single-MFMA, the softmax attention block in split form): NOT a parity path."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_dense_sd()
+    V, lens = 22, [22, 20, 22, 17, 22, 22, 22, 22, 22]
+    (at, x_c, x_v, y_c, y_v, mask, zc, zv), ref, rs = _dense_case(sd, H.FULL_DENSE_SPEC, V, lens, 3800)
+    m = H.tw_dense_model(sd, path=H1)
+    try:
+        stack, again = _loglik(m, at, x_c, x_v, y_c, y_v, mask), _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+        lib.tw_debug_set_flags(PER_SECTION)
+        sections = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+    finally:
+        lib.tw_debug_set_flags(0)
+    assert torch.equal(stack, again)
+    e_ref, e_sec = H.rel_err(stack, ref), H.rel_err(stack, sections)
+    print("fast mode, dense statement: vs oracle", e_ref, "vs per-section build", e_sec, "per-section vs oracle", H.rel_err(sections, ref))
+    assert e_ref < 1.5e-3 and e_sec < 1.5e-3, (e_ref, e_sec)
+    assert e_ref > 1e-6

@@ -396,11 +396,17 @@ def test_generated_asm_includes_are_current(tmp_path):
                  ["tools/gen_h3_ffn_asm.py", "--shape=ffn", "--nt=4", "--h1"], ["tools/gen_h3_attn_asm.py", "--nt=4", "--h1"],
                  ["tools/gen_h3_ffn_asm.py", "--shape=in", "--nt=4", "--h1"], ["tools/gen_h3_ffn_asm.py", "--shape=out", "--nt=4", "--h1"],
                  # r05: the encoder stack of the 64-token build as one statement, tw_h?n4_enc_*
-                 ["tools/gen_h3_enc_asm.py", "--nt=4"], ["tools/gen_h3_enc_asm.py", "--nt=4", "--h1"]):
+                 ["tools/gen_h3_enc_asm.py", "--nt=4"], ["tools/gen_h3_enc_asm.py", "--nt=4", "--h1"],
+                 # ... and of the wide layout (five- / three- / six-group key windows), tw_h?w{,3,6}_enc_*
+                 ["tools/gen_h3_enc_asm.py", "--wide"], ["tools/gen_h3_enc_asm.py", "--wide", "--h1"],
+                 ["tools/gen_h3_enc_asm.py", "--wide", "--ng=3"], ["tools/gen_h3_enc_asm.py", "--wide", "--ng=3", "--h1"],
+                 ["tools/gen_h3_enc_asm.py", "--wide", "--ng=6"], ["tools/gen_h3_enc_asm.py", "--wide", "--ng=6", "--h1"],
+                 # ... and of the dense softmax model, tw_h?d_enc_*
+                 ["tools/gen_h3_enc_asm.py", "--dense"], ["tools/gen_h3_enc_asm.py", "--dense", "--h1"]):
         subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
                        stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 56
+    assert len(names) == 72
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n

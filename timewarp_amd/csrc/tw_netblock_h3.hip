@@ -71,6 +71,7 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3D_SIDE_LDS_OFFSET (H3_RING * H3_STAGE_BYTES + 4 * H3D_WAVE_LDS)
 #define H3D_SIDE_LDS_BYTES 5120       // five 1 KiB LDS-DMA chunks
 #define H3D_LDS_BYTES (H3D_SIDE_LDS_OFFSET + H3D_SIDE_LDS_BYTES)
+#define H3D_ENC_LDS_BYTES (H3D_LDS_BYTES + H3D_SIDE_LDS_BYTES)  // encoder-stack statement: the side block double-buffered
 #define H3D_INB 656
 #define H3D_OUTB 1040
 // "wide" layout (49 .. 160 atoms): a workgroup's 4 x 48 token slots hold floor(192 / V) whole molecules back to back, the
@@ -130,7 +131,7 @@ static H3Geom h3_geom(const tw_flow_desc& d, bool h1 = false) {
   g.side_layer_size = d.variant == 1 ? H3D_SIDE_LAYER_FLOATS : H3_SIDE_LAYER_FLOATS;
   o += g.L * g.side_layer_size;
   g.side_out2b = o; o += 16;
-  g.side_scales = o; o += 4 + 3 * g.L;
+  g.side_scales = o; o += 4 + 4 * g.L;  // in-MLP 2, layers 3 each, out-MLP 2, then (dense) out_proj's scale per layer
   g.side_size = (o + 63) / 64 * 64 + 256;  // + slack: the per-layer block is fetched as three whole KiB
   g.net_stride_bytes = (g.stages * H3_STAGE_BYTES + g.side_size * 4 + 1023) / 1024 * 1024;
   return g;
@@ -485,6 +486,9 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
           st += (int64_t)4 * d.n_heads * H3_STAGE_BYTES;
           if ((rc = copy(lb + L.layer.in_b, 384, sl + H3D_INB, 384))) return rc;
           if ((rc = copy(lb + L.layer.out_b, 128, sl + H3D_OUTB, 128))) return rc;
+          // out_proj's scale once more where the encoder-stack statement can read it a layer AHEAD (it seeds the attention
+          // block's accumulators with x / s_o before that layer's side block is in the LDS): scales[4 + 3 L + l]
+          if ((rc = copy(osc, 1, scales + 4 + 3 * d.n_layers + l, 1))) return rc;
         } else {
         // folded attention: one scale for all heads of the layer
         TW_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float), s));
@@ -1222,7 +1226,8 @@ netblock_h3_kernel(const H3Params p) {
   // and inside one kernel with the three- / five-group statements it cost every wide launch 30 more spilled registers
   static_assert(!NG6 || WIDE, "six-group windows belong to the wide layout");
   static_assert(!RFF || DENSE, "position features belong to the dense model");
-  static_assert(!ENC || (ASM && !DENSE && !WIDE), "the encoder-stack statement: the 48- and 64-token kernel-attention builds");
+  static_assert(!ENC || ASM, "the encoder-stack statement embeds the generated asm sections");
+  static_assert(!(ENC && DENSE) || NT == 3, "dense encoder-stack statement: 48-token waves");
   static_assert(NT == 3 || (NT == 4 && !DENSE && !WIDE && !RFF),
                 "64-token waves: the kernel-attention variant, one molecule of 49-64 atoms per wave");
   constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
@@ -1271,6 +1276,19 @@ netblock_h3_kernel(const H3Params p) {
   pipe.wave = wave;
   pipe.debug = p.debug;
   pipe.ring = RING;
+  if constexpr (ENC && DENSE) {
+    // The dense encoder-stack statement double-buffers the layers' side blocks in the LDS (layer l in buffer l % 2, fetched
+    // a whole layer ahead: its attention block reads biases and the in_proj scale at its very entry).  Layer 0's goes first,
+    // older than every weight stage: start_wait()'s vmcnt(0) + barrier cover it.
+    if (wave == 0) {
+      const char* src = (const char*)(side + p.side_layers) + lane * 16;
+      char* dst = lds + SIDE_LDS_OFFSET;
+#pragma unroll
+      for (int i = 0; i < SIDE_CHUNKS; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
+  }
   pipe.start_issue();
 
   // Second-layer bias and output scale of the in and out MLPs: plain loads at the very top, so that they are back long
@@ -1504,7 +1522,7 @@ netblock_h3_kernel(const H3Params p) {
       if constexpr (NT == 4 && H1) {
         asm volatile(
 #include "tw_h1n4_in_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
             :
 #include "tw_h1n4_in_clobbers.inc"
@@ -1512,7 +1530,7 @@ netblock_h3_kernel(const H3Params p) {
       } else if constexpr (NT == 4) {
         asm volatile(
 #include "tw_h3n4_in_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
             :
 #include "tw_h3n4_in_clobbers.inc"
@@ -1520,7 +1538,7 @@ netblock_h3_kernel(const H3Params p) {
       } else if constexpr (H1) {
         asm volatile(
 #include "tw_h1_in_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
             :
 #include "tw_h1_in_clobbers.inc"
@@ -1528,7 +1546,7 @@ netblock_h3_kernel(const H3Params p) {
       } else
       asm volatile(
 #include "tw_h3_in_asm.inc"
-          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
           : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
           :
 #include "tw_h3_in_clobbers.inc"
@@ -1603,7 +1621,12 @@ netblock_h3_kernel(const H3Params p) {
     // into the accumulators' start values.  x goes in as 24 register images through the wave-private block; what comes
     // back there are the split operand images of the out-MLP statement.  No activation dumps, no section stamps: the
     // launch code takes the per-section build for those.
-    static_assert(SIDE_CHUNKS == 3, "gen_h3_enc_asm.py SIDE_CHUNKS");
+    static_assert(SIDE_CHUNKS == (DENSE ? 5 : 3), "gen_h3_enc_asm.py SIDE_CHUNKS");
+    // [cur] / [gn] are EARLY-CLOBBER read-write operands ("+&") in every statement of this file: the embedded blocks write
+    // %[cur] at each block's exit and the blocks behind it go on reading %[ring] and the other inputs.  Without the '&' hipcc
+    // may give an input of the same known value the same register - it did in the dense model's position-feature build
+    // (r05), where the compiled in-MLP leaves cur == 0 == ring: both in s24, the second block's ring wrap-around then
+    // selected slot `cur` instead of the ring base, and the nets returned garbage.
     char* priv = (char*)xt_hi;
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft)
@@ -1625,10 +1648,15 @@ netblock_h3_kernel(const H3Params p) {
     const float eps = p.eps;
     // (only read by the H3_ENC_EXPERIMENT=stamps build of the statement, tools/profile_h3_sections.py)
     const float* stamp_base = p.dump;
-    const int stampen = __builtin_amdgcn_readfirstlane(((p.debug & 16) && p.dump && blockIdx.x == 0 && wave == 0) ? 1 : 0);
-    if constexpr (NT == 4) {
+    int stampen = __builtin_amdgcn_readfirstlane(((p.debug & 16) && p.dump && blockIdx.x == 0 && wave == 0) ? 1 : 0);
+    // Opaque from here on: hipcc (ROCm 7.2) otherwise remembers that the value is a zero-extended i1, carries it to the
+    // statements below as a lane mask and re-materialises it with v_cndmask - into a VGPR, which it then hands to the "s"
+    // operand (seen with the wide layout's single-MFMA statements: "s_cmp_eq_u32 v252, 0", invalid operand)
+    asm volatile("" : "+s"(stampen));
+    if constexpr (NT == 4 || WIDE || DENSE) {
       // 64-token build (tools/gen_h3_enc_asm.py --nt=4): the statement owns v0..v245 and keeps nothing of its own in VGPRs
-      // across the embedded blocks, so its pointers arrive in SGPRs (all of them are wave-uniform)
+      // across the embedded blocks, so its pointers arrive in SGPRs (all of them are wave-uniform).  The wide layout's
+      // statements (--wide [--ng=3|6]: the six-group attention block owns v0..v239) take the same form.
       auto uniform64 = [](const void* ptr) {
         const uint64_t u = (uint64_t)(uintptr_t)ptr;
         return (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u) |
@@ -1639,10 +1667,112 @@ netblock_h3_kernel(const H3Params p) {
       const unsigned sfstride_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)sfstride);
       const unsigned sfstride_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)sfstride >> 32));
       const unsigned sidestride32 = (unsigned)__builtin_amdgcn_readfirstlane((int)sidestride);
+      if constexpr (DENSE) {
+        // dense softmax model (tools/gen_h3_enc_asm.py --dense [--h1]): no score fragments; the key masks of the softmax
+        const unsigned m0l = (unsigned)kvalid[0], m0h = (unsigned)(kvalid[0] >> 32), m1l = (unsigned)kvalid[1],
+                       m1h = (unsigned)(kvalid[1] >> 32), m2l = (unsigned)kvalid[2], m2h = (unsigned)(kvalid[2] >> 32);
+        if constexpr (H1) {
+          asm volatile(
+#include "tw_h1d_enc_asm.inc"
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks), [layers] "s"(layers), [side] "s"(side_u),
+                [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+                [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen), [m0l] "v"(m0l), [m0h] "v"(m0h), [m1l] "v"(m1l),
+                [m1h] "v"(m1h), [m2l] "v"(m2l), [m2h] "v"(m2h)
+              :
+#include "tw_h1d_enc_clobbers.inc"
+          );
+        } else {
+          asm volatile(
+#include "tw_h3d_enc_asm.inc"
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks), [layers] "s"(layers), [side] "s"(side_u),
+                [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+                [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen), [m0l] "v"(m0l), [m0h] "v"(m0h), [m1l] "v"(m1l),
+                [m1h] "v"(m1h), [m2l] "v"(m2l), [m2h] "v"(m2h)
+              :
+#include "tw_h3d_enc_clobbers.inc"
+          );
+        }
+      } else if constexpr (WIDE) {
+        // x went in through the wave-private blocks, which lie under the workgroup's shared X^T tile: the statement reads its
+        // images, takes a barrier, and only then writes the first transposed copy (tools/gen_h3_enc_asm.py generate())
+        const unsigned xt_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(lds + RING * H3_STAGE_BYTES);
+        const int win = __builtin_amdgcn_readfirstlane(wave == 0 ? p.win[0] : wave == 1 ? p.win[1] : wave == 2 ? p.win[2] : p.win[3]);
+        if constexpr (H1) {
+          if constexpr (NG6) {
+            asm volatile(
+#include "tw_h1w6_enc_asm.inc"
+                : [cur] "+&s"(cur), [gn] "+&v"(gn)
+                : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+                  [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
+                  [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+                  [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen), [xt] "s"(xt_lds), [win] "s"(win)
+                :
+#include "tw_h1w6_enc_clobbers.inc"
+            );
+          } else if (p.ng == H3W_NG3) {
+            asm volatile(
+#include "tw_h1w3_enc_asm.inc"
+                : [cur] "+&s"(cur), [gn] "+&v"(gn)
+                : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+                  [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
+                  [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+                  [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen), [xt] "s"(xt_lds), [win] "s"(win)
+                :
+#include "tw_h1w3_enc_clobbers.inc"
+            );
+          } else {
+            asm volatile(
+#include "tw_h1w_enc_asm.inc"
+                : [cur] "+&s"(cur), [gn] "+&v"(gn)
+                : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+                  [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
+                  [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+                  [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen), [xt] "s"(xt_lds), [win] "s"(win)
+                :
+#include "tw_h1w_enc_clobbers.inc"
+            );
+          }
+        } else if constexpr (NG6) {
+          asm volatile(
+#include "tw_h3w6_enc_asm.inc"
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+                [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
+                [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+                [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen), [xt] "s"(xt_lds), [win] "s"(win)
+              :
+#include "tw_h3w6_enc_clobbers.inc"
+          );
+        } else if (p.ng == H3W_NG3) {
+          asm volatile(
+#include "tw_h3w3_enc_asm.inc"
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+                [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
+                [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+                [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen), [xt] "s"(xt_lds), [win] "s"(win)
+              :
+#include "tw_h3w3_enc_clobbers.inc"
+          );
+        } else {
+          asm volatile(
+#include "tw_h3w_enc_asm.inc"
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+                [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
+                [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+                [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen), [xt] "s"(xt_lds), [win] "s"(win)
+              :
+#include "tw_h3w_enc_clobbers.inc"
+          );
+        }
+      } else
       if constexpr (H1) {
         asm volatile(
 #include "tw_h1n4_enc_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
               [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
               [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
@@ -1653,7 +1783,7 @@ netblock_h3_kernel(const H3Params p) {
       } else {
         asm volatile(
 #include "tw_h3n4_enc_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
               [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
               [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
@@ -1667,7 +1797,7 @@ netblock_h3_kernel(const H3Params p) {
     if (p.windowed) {
       asm volatile(
 #include "tw_h1_encw_asm.inc"
-          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
           : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
             [layers] "s"(layers), [sf] "v"(sfp), [sfstride] "s"(sfstride), [side] "v"(sidep), [sidestride] "s"(sidestride),
             [sl] "s"(sl_lds), [scales] "s"(scp), [eps] "s"(eps), [padm] "v"(padmask), [padt] "s"(pad_tiles),
@@ -1678,7 +1808,7 @@ netblock_h3_kernel(const H3Params p) {
     } else {
       asm volatile(
 #include "tw_h1_enc_asm.inc"
-          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
           : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
             [layers] "s"(layers), [sf] "v"(sfp), [sfstride] "s"(sfstride), [side] "v"(sidep), [sidestride] "s"(sidestride),
             [sl] "s"(sl_lds), [scales] "s"(scp), [eps] "s"(eps), [padm] "v"(padmask), [padt] "s"(pad_tiles),
@@ -1691,7 +1821,7 @@ netblock_h3_kernel(const H3Params p) {
     if (p.windowed) {
       asm volatile(
 #include "tw_h3_encw_asm.inc"
-          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
           : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
             [layers] "s"(layers), [sf] "v"(sfp), [sfstride] "s"(sfstride), [side] "v"(sidep), [sidestride] "s"(sidestride),
             [sl] "s"(sl_lds), [scales] "s"(scp), [eps] "s"(eps), [padm] "v"(padmask), [padt] "s"(pad_tiles),
@@ -1702,7 +1832,7 @@ netblock_h3_kernel(const H3Params p) {
     } else {
       asm volatile(
 #include "tw_h3_enc_asm.inc"
-          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
           : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
             [layers] "s"(layers), [sf] "v"(sfp), [sfstride] "s"(sfstride), [side] "v"(sidep), [sidestride] "s"(sidestride),
             [sl] "s"(sl_lds), [scales] "s"(scp), [eps] "s"(eps), [padm] "v"(padmask), [padt] "s"(pad_tiles),
@@ -1850,7 +1980,7 @@ netblock_h3_kernel(const H3Params p) {
                      m1h = (unsigned)(kvalid[1] >> 32), m2l = (unsigned)kvalid[2], m2h = (unsigned)(kvalid[2] >> 32);
       asm volatile(
 #include "tw_h3_attnd_asm.inc"
-          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
           : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [sl] "s"(sl_lds), [m0l] "v"(m0l), [m0h] "v"(m0h),
             [m1l] "v"(m1l), [m1h] "v"(m1h), [m2l] "v"(m2l), [m2h] "v"(m2h)
           :
@@ -2019,7 +2149,7 @@ netblock_h3_kernel(const H3Params p) {
           if constexpr (NG6) {
           asm volatile(
 #include "tw_h1_attns6_asm.inc"
-              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
               : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
                 [win] "s"(win)
               :
@@ -2028,7 +2158,7 @@ netblock_h3_kernel(const H3Params p) {
           } else if (p.ng == H3W_NG3) {
           asm volatile(
 #include "tw_h1_attns3_asm.inc"
-              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
               : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
                 [win] "s"(win)
               :
@@ -2037,7 +2167,7 @@ netblock_h3_kernel(const H3Params p) {
           } else {
           asm volatile(
 #include "tw_h1_attns_asm.inc"
-              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
               : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
                 [win] "s"(win)
               :
@@ -2047,7 +2177,7 @@ netblock_h3_kernel(const H3Params p) {
         } else if constexpr (NG6) {
         asm volatile(
 #include "tw_h3_attns6_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
               [win] "s"(win)
             :
@@ -2056,7 +2186,7 @@ netblock_h3_kernel(const H3Params p) {
         } else if (p.ng == H3W_NG3) {
         asm volatile(
 #include "tw_h3_attns3_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
               [win] "s"(win)
             :
@@ -2065,7 +2195,7 @@ netblock_h3_kernel(const H3Params p) {
         } else {
         asm volatile(
 #include "tw_h3_attns_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp), [xt] "s"(xt_lds),
               [win] "s"(win)
             :
@@ -2075,7 +2205,7 @@ netblock_h3_kernel(const H3Params p) {
       } else if constexpr (NT == 4 && H1) {
         asm volatile(
 #include "tw_h1n4_attn_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp)
             :
 #include "tw_h1n4_attn_clobbers.inc"
@@ -2083,7 +2213,7 @@ netblock_h3_kernel(const H3Params p) {
       } else if constexpr (NT == 4) {
         asm volatile(
 #include "tw_h3n4_attn_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp)
             :
 #include "tw_h3n4_attn_clobbers.inc"
@@ -2092,7 +2222,7 @@ netblock_h3_kernel(const H3Params p) {
         // two or more molecules per wave: 24 instead of 36 mixing MFMAs per k-step (gen_h3_attn_asm.py --mode=windowed)
         asm volatile(
 #include "tw_h3_attnw_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp)
             :
 #include "tw_h3_attnw_clobbers.inc"
@@ -2100,7 +2230,7 @@ netblock_h3_kernel(const H3Params p) {
       } else {
         asm volatile(
 #include "tw_h3_attn_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [sf] "v"(sfp)
             :
 #include "tw_h3_attn_clobbers.inc"
@@ -2267,7 +2397,7 @@ netblock_h3_kernel(const H3Params p) {
         if constexpr (NT == 4 && H1) {
           asm volatile(
 #include "tw_h1n4_ffn_asm.inc"
-              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
               : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
               :
 #include "tw_h1n4_ffn_clobbers.inc"
@@ -2275,7 +2405,7 @@ netblock_h3_kernel(const H3Params p) {
         } else if constexpr (NT == 4) {
           asm volatile(
 #include "tw_h3n4_ffn_asm.inc"
-              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
               : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
               :
 #include "tw_h3n4_ffn_clobbers.inc"
@@ -2283,7 +2413,7 @@ netblock_h3_kernel(const H3Params p) {
         } else if constexpr (H1) {
           asm volatile(
 #include "tw_h1_ffn_asm.inc"
-              : [cur] "+s"(cur), [gn] "+v"(gn)
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
               : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
               :
 #include "tw_h1_ffn_clobbers.inc"
@@ -2291,7 +2421,7 @@ netblock_h3_kernel(const H3Params p) {
         } else
         asm volatile(
 #include "tw_h3_ffn_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
             :
 #include "tw_h3_ffn_clobbers.inc"
@@ -2350,7 +2480,7 @@ netblock_h3_kernel(const H3Params p) {
       if constexpr (NT == 4 && H1) {
         asm volatile(
 #include "tw_h1n4_out_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
             :
 #include "tw_h1n4_out_clobbers.inc"
@@ -2358,7 +2488,7 @@ netblock_h3_kernel(const H3Params p) {
       } else if constexpr (NT == 4) {
         asm volatile(
 #include "tw_h3n4_out_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
             :
 #include "tw_h3n4_out_clobbers.inc"
@@ -2366,7 +2496,7 @@ netblock_h3_kernel(const H3Params p) {
       } else if constexpr (H1) {
         asm volatile(
 #include "tw_h1_out_asm.inc"
-            : [cur] "+s"(cur), [gn] "+v"(gn)
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
             : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
             :
 #include "tw_h1_out_clobbers.inc"
@@ -2374,7 +2504,7 @@ netblock_h3_kernel(const H3Params p) {
       } else
       asm volatile(
 #include "tw_h3_out_asm.inc"
-          : [cur] "+s"(cur), [gn] "+v"(gn)
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
           : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
           :
 #include "tw_h3_out_clobbers.inc"
@@ -2559,6 +2689,9 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   if ((prc = lim_dense_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false, true>, (int)H3D_LDS_BYTES))) return prc;
   if ((prc = lim_wide.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
+  // the encoder-stack statements (no compiled glue, no scratch) unless activations / section stamps between the sections are
+  // asked for (bit 12: per-section build, bit 13: encoder stack anyway)
+  const bool per_section = ((dump != nullptr || (g_debug_flags & (4 | 16 | 4096))) && !(g_debug_flags & 8192)) || d.n_layers < 1;
   if (!wide && fg.nt == H3N4_NT) {
     TW_REQUIRE(d.variant == 0, "64-token waves: kernel attention");
     static LdsLimit lim_n4, lim_n4_cpp, lim_n4_h1;
@@ -2566,9 +2699,6 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
     if ((prc = lim_n4_cpp.ensure((const void*)netblock_h3_kernel<H3N4_NT, false>, (int)H3N4_LDS_BYTES))) return prc;
     if ((prc = lim_n4_h1.ensure((const void*)netblock_h3_kernel<H3N4_NT, true, false, false, false, false, true>, (int)H3N4_LDS_BYTES)))
       return prc;
-    // the encoder-stack statement (r05: no compiled glue, no scratch) unless activations / section stamps between the
-    // sections are asked for: same switches as the 48-token kernel (bit 12: per-section build, bit 13: encoder stack anyway)
-    const bool per_section = ((dump != nullptr || (g_debug_flags & (4 | 16 | 4096))) && !(g_debug_flags & 8192)) || d.n_layers < 1;
     if (h1 && per_section)
       hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true, false, false, false, false, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES,
                          a.stream, p);
@@ -2593,11 +2723,15 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
     // single-MFMA build: the encoder-stack statement (section stamps compiled in; no activation dumps), or the wide layout's
     // per-section build
     TW_REQUIRE(h1_supported(d, a.n_atoms) && d.n_layers >= 1, "single-MFMA path: unsupported configuration");
-    if (d.variant == 1) {
+    if (d.variant == 1 && per_section) {
       static LdsLimit lim_h1d;
       if ((prc = lim_h1d.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, false, false, true>, (int)H3D_LDS_BYTES))) return prc;
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, false, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
-    } else if (wide) {
+    } else if (d.variant == 1) {
+      static LdsLimit lim_h1de;
+      if ((prc = lim_h1de.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, false, true, true>, (int)H3D_ENC_LDS_BYTES))) return prc;
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, false, true, true>), dim3(grid), dim3(256), H3D_ENC_LDS_BYTES, a.stream, p);
+    } else if (wide && per_section) {
       static LdsLimit lim_h1w, lim_h1w6;
       if ((prc = lim_h1w.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, true>, (int)H3W_LDS_BYTES))) return prc;
       if ((prc = lim_h1w6.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, true, true>, (int)H3W_LDS_BYTES))) return prc;
@@ -2605,35 +2739,65 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
         hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, true, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
       else
         hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+    } else if (wide) {
+      // r05: the wide layout's encoder stack as one statement (tools/gen_h3_enc_asm.py --wide [--ng=3|6] --h1)
+      static LdsLimit lim_h1we, lim_h1we6;
+      if ((prc = lim_h1we.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, true, true>, (int)H3W_LDS_BYTES))) return prc;
+      if ((prc = lim_h1we6.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, true, true, true>, (int)H3W_LDS_BYTES))) return prc;
+      if (wd.ng == H3W_NG6)
+        hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, true, true, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+      else
+        hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, true, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
     } else {
       TW_REQUIRE(dump == nullptr || (g_debug_flags & 16), "single-MFMA path: no activation dumps (section stamps only)");
       static LdsLimit lim_h1;
       if ((prc = lim_h1.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, false, false, true, true>, (int)H3_LDS_BYTES))) return prc;
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, false, false, true, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
     }
-  } else if (wide) {
+  } else if (wide && per_section) {
     static LdsLimit lim_wide6;
     if ((prc = lim_wide6.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, false, true>, (int)H3W_LDS_BYTES))) return prc;
     if (wd.ng == H3W_NG6)
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
     else
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+  } else if (wide) {
+    // r05: the wide layout's encoder stack as one statement (tools/gen_h3_enc_asm.py --wide [--ng=3|6]): no compiled glue, no scratch
+    static LdsLimit lim_wide_enc, lim_wide_enc6;
+    if ((prc = lim_wide_enc.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
+    if ((prc = lim_wide_enc6.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
+    if (wd.ng == H3W_NG6)
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+    else
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
   } else if (d.variant == 1 && d.d_rff > 0) {
     static LdsLimit lim_rff, lim_rff_cpp;
     if ((prc = lim_rff.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, true>, (int)H3D_LDS_BYTES))) return prc;
     if ((prc = lim_rff_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false, true, false, true>, (int)H3D_LDS_BYTES))) return prc;
     if (g_debug_flags & 8)
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false, true, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
-    else
+    else if (per_section)
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
+    else {
+      // r05: the dense model's encoder stack as one statement (tools/gen_h3_enc_asm.py --dense); the in-MLP of the position
+      // features stays compiled C++
+      static LdsLimit lim_rff_enc;
+      if ((prc = lim_rff_enc.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, true, true>, (int)H3D_ENC_LDS_BYTES))) return prc;
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, true, true>), dim3(grid), dim3(256), H3D_ENC_LDS_BYTES, a.stream, p);
+    }
   } else if (d.variant == 1) {
     if (g_debug_flags & 8)
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
-    else
+    else if (per_section)
       hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
+    else {
+      static LdsLimit lim_dense_enc;
+      if ((prc = lim_dense_enc.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, false, true>, (int)H3D_ENC_LDS_BYTES))) return prc;
+      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, false, true>), dim3(grid), dim3(256), H3D_ENC_LDS_BYTES, a.stream, p);
+    }
   } else if (g_debug_flags & 8)
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
-  else if (((dump != nullptr || (g_debug_flags & (4 | 16 | 4096))) && !(g_debug_flags & 8192)) || d.n_layers < 1)
+  else if (per_section)
     // activation dumps / section stamps live between the sections; bit 12 (4096): A/B switch for the encoder-stack build;
     // bit 13 (8192): the encoder-stack build even with a dump buffer (only the stamps / dumps outside the stack are written)
     hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);

@@ -61,6 +61,11 @@ XB = lambda ks, jt, part: 96 + 8 * (3 * ks + jt) + (0 if part == "h" else 4)
 S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_PAIR = 84, 85, 86, 88, 90, 92, 93
 S_SCIN, S_SCQ, S_LOG2E, S_MASKED = 94, 95, 96, 97
 EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(",")))
+# Set by tools/gen_h3_enc_asm.py --dense, which embeds this block in the asm statement of the whole encoder stack: the split
+# activations are already in a96..a191 (written there by the glue, no trip through the LDS), the accumulators arrive holding
+# the residual (x / s_o) instead of zeros, and y stays in a0..a95.
+FUSED = False
+SL = "%[sl]"               # LDS address of the layer's side block (the encoder-stack statement double-buffers it: an SGPR there)
 
 
 def vr(base, n=4):
@@ -356,10 +361,10 @@ def generate():
     # side-block lane addresses: f4 at feature 4 g (q, k biases), float at feature (lane & 15) (v bias)
     A(f"v_lshrrev_b32 v{V_T}, 4, v{V_LANE16}")
     A(f"v_lshlrev_b32 v{V_T}, 4, v{V_T}")
-    A(f"v_add_u32 v{V_SLQ}, %[sl], v{V_T}")
+    A(f"v_add_u32 v{V_SLQ}, {SL}, v{V_T}")
     A(f"v_and_b32 v{V_T}, 15, v{V_LANE16}")
     A(f"v_lshlrev_b32 v{V_T}, 2, v{V_T}")
-    A(f"v_add_u32 v{V_SLV}, %[sl], v{V_T}")
+    A(f"v_add_u32 v{V_SLV}, {SL}, v{V_T}")
     A(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_LANE16}")
     A(f"s_lshl_b32 s{S_W2048}, %[wave], 11")
     A(f"s_mov_b32 s{S_W2048 + 1}, 0")
@@ -375,14 +380,15 @@ def generate():
     A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
     A(f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}")
     # in_proj scale (side block slot 640) -> SGPRs (and a quarter of it for q)
-    A(f"v_mov_b32 v{V_T}, %[sl]")
+    A(f"v_mov_b32 v{V_T}, {SL}")
     A(f"ds_read_b32 v{V_T + 1}, v{V_T} offset:{4 * 640}")
-    # split activations from the wave-private block: 24 images -> a96..a191
-    A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-    for i in range(24):
-        A(f"ds_read_b128 {ar(96 + 4 * i)}, v{V_TMP} offset:{1024 * i}")
-    for i in range(96):
-        A(f"v_accvgpr_write_b32 a{i}, 0")
+    if not FUSED:
+        # split activations from the wave-private block: 24 images -> a96..a191
+        A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
+        for i in range(24):
+            A(f"ds_read_b128 {ar(96 + 4 * i)}, v{V_TMP} offset:{1024 * i}")
+        for i in range(96):
+            A(f"v_accvgpr_write_b32 a{i}, 0")
     A("s_waitcnt lgkmcnt(0)")
     A(f"v_mul_f32 v{V_T + 2}, 0.25, v{V_T + 1}")
     A("s_nop 1")
@@ -409,12 +415,13 @@ def generate():
     A("s_waitcnt lgkmcnt(0)")
     A("s_nop 15")
     A("s_nop 15")
-    A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-    for i in range(24):
-        for r in range(4):
-            A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
-        A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
-    A("s_waitcnt lgkmcnt(0)")
+    if not FUSED:
+        A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
+        for i in range(24):
+            for r in range(4):
+                A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
+            A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
+        A("s_waitcnt lgkmcnt(0)")
     A(f"s_sub_u32 s{S_AUXOFF}, 0, s{S_W2048}")
     A(f"s_subb_u32 s{S_AUXOFF + 1}, 0, 0")
     A(f"v_lshl_add_u64 %[gn], {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]")
@@ -440,4 +447,5 @@ def main():
     print(f"dense attention: {len(lines)} instructions, {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs")
 
 
-main()
+if __name__ == "__main__":
+    main()

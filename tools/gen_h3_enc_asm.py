@@ -76,26 +76,35 @@ NT4 = "--nt=4" in sys.argv      # 64-token waves (the embedded generators read t
 # --wide [--ng=3|6]: the wide layout (molecules packed over the workgroup's 192 token slots, 25-192 atoms): the attention block
 # is gen_h3_attn_wide_asm.py's, the transposed copy of x the workgroup's SHARED tile in the LDS
 WIDE = "--wide" in sys.argv
-STATELESS = NT4 or WIDE         # the glue keeps nothing in VGPRs across the embedded blocks; pointers in SGPRs
+# --dense: the dense softmax model (transformer_nvp; BASELINE configs[4]): the attention block is gen_h3_dense_attn_asm.py's,
+# whose operands are the split activations themselves (B operand of q / k, A operand of v) in a96..a191 - no transposed copy.
+# With --h1 the MLP sections are the single-MFMA ones, the attention block stays in split form (csrc: "MLP sections only").
+DENSE = "--dense" in sys.argv
+STATELESS = NT4 or WIDE or DENSE  # the glue keeps nothing in VGPRs across the embedded blocks; pointers in SGPRs
 EXPERIMENT = set(filter(None, os.environ.get("H3_ENC_EXPERIMENT", "").split(",")))
 if H1:
     EXPERIMENT.add("stamps")
-attn = load("gen_h3_attn_wide_asm" if WIDE else "gen_h3_attn_asm")
+attn = load("gen_h3_dense_attn_asm" if DENSE else ("gen_h3_attn_wide_asm" if WIDE else "gen_h3_attn_asm"))
 ffn = load("gen_h3_ffn_asm")
-attn.H1 = ffn.H1 = H1
+ffn.H1 = H1
+if not DENSE:
+    attn.H1 = H1
+H1A = H1 and not DENSE          # does the attention block take hi halves only?
 attn.FUSED = True
-if not WIDE:
+if not (WIDE or DENSE):
     attn.WINDOWED = WINDOWED
     assert attn.NT4 == NT4
 if not STATELESS:
     attn.XT_AGPR = 96   # the transposed copy of x lives in a96..a191 from the transposer to the end of the attention block
 ffn.FUSED = True
 ffn.SHAPE = ffn.SHAPES["ffn"]
-assert ffn.NT4 == NT4 and not (NT4 and WINDOWED) and not (WIDE and (NT4 or WINDOWED))
+assert ffn.NT4 == NT4 and not (NT4 and WINDOWED) and not (WIDE and (NT4 or WINDOWED)) and not (DENSE and (NT4 or WINDOWED or WIDE))
 
 NT = 4 if NT4 else 3
-SIDE_CHUNKS = 3
-XT_IMG = None if WIDE else attn.XT_IMG
+SIDE_CHUNKS = 5 if DENSE else 3
+XT_IMG = None if (WIDE or DENSE) else attn.XT_IMG
+SIDE_OUTB = 1040                # dense: out_proj bias [128] in the layer's side block (csrc H3D_OUTB)
+SIDE_LDS_BYTES = 1024 * SIDE_CHUNKS
 # side block of a layer (floats): LN1 w, LN1 b, FFN b2, LN2 w, LN2 b (128 each)
 SIDE_LN1W, SIDE_LN1B, SIDE_B2, SIDE_LN2W, SIDE_LN2B = 0, 128, 256, 384, 512
 
@@ -144,8 +153,9 @@ if NT4:
     PADM = "%[padm]"
     XBX = lambda ks, jt, part: 32 * (ks % 2) + 8 * jt + 4 * part        # exit staging: two k-steps of images in v0..v63
     attn.SF_BASE = f"s[{S_SFB}:{S_SFB + 1}]"
-elif WIDE:
-    # the 48-token map; v224.. are scratch here, rebuilt per phase (the six-group attention statement owns v0..v239)
+elif WIDE or DENSE:
+    # the 48-token map; v224.. are scratch here, rebuilt per phase (the six-group attention statement owns v0..v239, the
+    # dense one v0..v219)
     V_XTW, V_XTWL, V_ZERO = 228, 229, 242                  # this lane's 8 bytes of a shared-tile row, hi / lo half
     V_PRIV8 = V_PAD = V_SFB = V_SIDE = V_STAMP = None
     S_SFB, S_SIDE, S_DUMP = 56, 58, 60
@@ -153,7 +163,13 @@ elif WIDE:
     S_STAMP_T, S_STAMP_STEP, S_NF, S_SCPTR = 70, 72, 74, 78
     S_LO = 56
     PADM = "%[padm]"
-    attn.SF_BASE = f"s[{S_SFB}:{S_SFB + 1}]"
+    if DENSE:
+        # the side block is double-buffered in the LDS (layer l in buffer l % 2, fetched a whole layer ahead): the attention
+        # block reads its biases and the in_proj scale at its very entry, which one DMA latency behind layer_top() would race
+        S_SLCUR, S_SLOTHER, S_OSC, S_SWAP = 56, 57, 76, 75     # (S_SFB's pair: this model has no score fragments)
+        attn.SL = f"s{S_SLCUR}"
+    else:
+        attn.SF_BASE = f"s[{S_SFB}:{S_SFB + 1}]"
 else:
     attn.SF_BASE = f"v[{V_SFB}:{V_SFB + 1}]"
 
@@ -215,7 +231,7 @@ def _check_register_map():
     tmp = span(TMP(0), 8) | span(U(0), 8) | span(V_ACC0, 4)
     img = span(IMG01(0), 4) | span(IMG01(1), 4) | span(IMG2(0), 2) | span(IMG2(1), 2)
     stats = span(S2(0), 6) | span(NM(0), 6)
-    if WIDE:
+    if WIDE or DENSE:
         persistent = span(V_PRIV16, 1) | span(V_SLG, 1) | span(V_XTW, 2) | span(V_IDB, 2) | span(V_C, 2) | span(V_C2, 2) | \
             span(V_ONE, 2) | span(V_ZERO, 1)
     else:
@@ -228,7 +244,7 @@ def _check_register_map():
     # the image staging registers of G2 sit in the b2 columns of the parameter buffers (G2 streams w and b only) and
     # behind the temporaries G1's seeds use
     assert img <= span(PRM(0, 2), 4) | span(PRM(1, 2), 4) | span(V_ACC0, 4)
-    assert max(persistent) < N_V and min(persistent) >= 212  # the embedded blocks own v0..v211
+    assert max(persistent) < N_V and min(persistent) >= (220 if DENSE else 212)  # the embedded blocks own v0..v211 (dense: v219)
     xbx = set()
     for ks in range(4):
         for jt in range(NT):
@@ -267,7 +283,8 @@ def lane_addr(dst, base, shift, scratch, group=False):
     L = [f"v_mbcnt_lo_u32_b32 v{scratch}, -1, 0", f"v_mbcnt_hi_u32_b32 v{scratch}, -1, v{scratch}"]
     if group:
         L.append(f"v_lshrrev_b32 v{scratch}, 4, v{scratch}")
-    L += [f"v_lshlrev_b32 v{dst}, {shift}, v{scratch}", f"v_add_u32 v{dst}, %[{base}], v{dst}"]
+    src = base if base[0] in "sv" and base[1:].isdigit() else f"%[{base}]"   # a register of the statement's own, or an operand
+    L += [f"v_lshlrev_b32 v{dst}, {shift}, v{scratch}", f"v_add_u32 v{dst}, {src}, v{dst}"]
     return L
 
 
@@ -286,23 +303,41 @@ def identity_operand(t0, t1):
     return L
 
 
-def layer_norm(inv_sgpr, w_off, b_off, label):
+def layer_norm(inv_sgpr, w_off, b_off, label, pre_bias=None):
     """T <- LayerNorm(acc * scale) * w + b, padding tokens -> 0.  The scale (a power of two) never touches the data:
-    with t = acc, x = scale * t:  (x - mean_x) * rsq(var_x + eps) = (t - mean_t) * rsq(var_t + eps / scale^2)."""
+    with t = acc, x = scale * t:  (x - mean_x) * rsq(var_x + eps) = (t - mean_t) * rsq(var_t + eps / scale^2).
+    pre_bias (dense, LayerNorm 1): t = acc + bias / scale first - out_proj's bias, from the side block at that float offset
+    (the accumulators were seeded a layer earlier, before this layer's side block was in reach)."""
     L = []
     A = L.append
     if STATELESS:   # nothing survives the embedded blocks: the side-block lane address and the pair of ones are rebuilt here
-        L += lane_addr(V_SLG, "sl", 4, TMP(0), group=True)
+        L += lane_addr(V_SLG, f"s{S_SLCUR}" if DENSE else "sl", 4, TMP(0), group=True)
         A(f"v_mov_b32 v{V_ONE}, 1.0")
         A(f"v_mov_b32 v{V_ONE + 1}, 1.0")
     for jt in range(NT):
         A(f"v_mov_b32 v{S2(jt)}, 0")
         A(f"v_mov_b32 v{S2(jt) + 1}, 0")
+    if pre_bias is not None:
+        A(f"v_mov_b32 v{V_C2}, s{inv_sgpr}")
+        A(f"v_mov_b32 v{V_C2 + 1}, s{inv_sgpr}")
+        A(f"ds_read_b128 {vr(PRM(0, 0), 4)}, v{V_SLG} offset:{4 * pre_bias}")
     # P1: t = acc, sums
     for ft in range(8):
         for jt in range(NT):
             for r in range(4):
                 A(f"v_accvgpr_read_b32 v{T(ft, jt) + r}, a{ACC(ft, jt) + r}")
+        if pre_bias is not None:
+            buf = ft % 2
+            if ft + 1 < 8:
+                A(f"ds_read_b128 {vr(PRM(1 - buf, 0), 4)}, v{V_SLG} offset:{4 * pre_bias + 64 * (ft + 1)}")
+                A("s_waitcnt lgkmcnt(1)")
+            else:
+                A("s_waitcnt lgkmcnt(0)")
+            for h in range(2):
+                A(f"v_pk_mul_f32 {vr(PRM(buf, 0) + 2 * h)}, {vr(PRM(buf, 0) + 2 * h)}, {vr(V_C2)}")
+            for h in range(2):
+                for jt in range(NT):
+                    A(f"v_pk_fma_f32 {vr(T(ft, jt) + 2 * h)}, {vr(PRM(buf, 0) + 2 * h)}, {vr(V_ONE)}, {vr(T(ft, jt) + 2 * h)}")
         for h in range(2):
             for jt in range(NT):
                 A(f"v_pk_fma_f32 {vr(S2(jt))}, {vr(T(ft, jt) + 2 * h)}, {vr(V_ONE)}, {vr(S2(jt))}")
@@ -367,10 +402,10 @@ def layer_norm(inv_sgpr, w_off, b_off, label):
     return L
 
 
-def split_tile(t, hi, lo, tmp):
+def split_tile(t, hi, lo, tmp, h1=None):
     """T tile (4 fp32) -> hi pair regs (2), lo pair regs (2): the eight VALU ops of csrc split_pair x 2."""
     ops = [f"v_cvt_pk_f16_f32 v{hi}, v{t}, v{t + 1}", f"v_cvt_pk_f16_f32 v{hi + 1}, v{t + 2}, v{t + 3}"]
-    if H1:
+    if H1 if h1 is None else h1:
         return ops
     for r in range(4):
         sel = "op_sel:[1,0,0] " if r % 2 else ""
@@ -389,7 +424,7 @@ def by_pairs(streams):
 
 def g1():
     """After the attention block: LayerNorm 1, FFN operands, FFN accumulator seeds (x' + b2) / s_w2."""
-    L = layer_norm(S_IA, SIDE_LN1W, SIDE_LN1B, "g1")
+    L = layer_norm(S_IA, SIDE_LN1W, SIDE_LN1B, "g1", pre_bias=SIDE_OUTB if DENSE else None)
     A = L.append
     A(f"v_mov_b32 v{V_C}, s{S_IF}")
     A(f"v_mov_b32 v{V_C + 1}, s{S_IF}")
@@ -501,6 +536,24 @@ def seed_attention(ft):
     return L
 
 
+def dense_operands(seed_sgpr):
+    """Dense model: x' (in T) -> the attention block's split operands xb[ks][jt] = {hi, lo} in a96..a191 (element e of k-step
+    ks <-> feature 32 ks + 16 (e / 4) + 4 g + e % 4: the same images G1 builds for the FFN) + accumulator seeds x' / s_o."""
+    L = [f"v_mov_b32 v{V_C2}, s{seed_sgpr}", f"v_mov_b32 v{V_C2 + 1}, s{seed_sgpr}"]
+    for ft in range(8):
+        ks, odd = ft // 2, ft % 2
+        streams = []
+        for jt in range(NT):
+            hi, lo = U(jt), U(jt) + 2
+            s = split_tile(T(ft, jt), hi, lo, TMP(jt), h1=False)
+            s += [f"v_accvgpr_write_b32 a{attn.XB(ks, jt, 'h') + 2 * odd + k}, v{hi + k}" for k in range(2)]
+            s += [f"v_accvgpr_write_b32 a{attn.XB(ks, jt, 'l') + 2 * odd + k}, v{lo + k}" for k in range(2)]
+            streams.append(s)
+        L += interleave(streams[0], streams[1]) + streams[2]
+        L += seed_attention(ft)
+    return L
+
+
 def transposer(seed_sgpr=None):
     """x' (in T) -> the attention block's transposed copy + accumulator seeds: issue feature tile ft, drain ft - 1.
     64-token build: what the phase needs in registers is rebuilt first (`seed_sgpr`: 1 / s_wc of the layer that follows)."""
@@ -531,7 +584,7 @@ def transposer(seed_sgpr=None):
 
 def entry_transposer():
     """Layer 0: x (in T) -> X^T images + accumulator seeds."""
-    return transposer(S_IA)
+    return dense_operands(S_IA) if DENSE else transposer(S_IA)
 
 
 def g2(last):
@@ -541,6 +594,8 @@ def g2(last):
     A = L.append
     if last and STATELESS:
         L += lane_addr(V_PRIV16, "priv", 4, TMP(0))
+    if not last and DENSE:
+        return L + dense_operands(S_IA)
     if not last and STATELESS:
         return L + transposer(S_IA)
     for ft in range(8):
@@ -596,12 +651,20 @@ def layer_top():
     """All waves are done with the previous layer's side block: wave 0 fetches this layer's (LDS-DMA, nobody waits here:
     it is older than every weight stage of the layer, the first hand-off inside the attention block covers it)."""
     L = ["s_waitcnt lgkmcnt(0)", "s_barrier",
-         "s_cmp_lg_u32 %[wave], 0", "s_cbranch_scc1 .Lenc_noside_%=",
-         "s_mov_b32 m0, %[sl]", "s_nop 0"]
+         "s_cmp_lg_u32 %[wave], 0", "s_cbranch_scc1 .Lenc_noside_%="]
+    if DENSE:
+        # double-buffered: this layer's block arrived a layer ago (layer 0's: the kernel's prologue); fetch the NEXT layer's
+        # into the other buffer, which every wave has finished reading (LayerNorm 2 of the previous layer; the barrier above)
+        L += [f"s_cmp_eq_u32 s{S_LAYER}, 1", "s_cbranch_scc1 .Lenc_noside_%=", f"s_mov_b32 m0, s{S_SLOTHER}", "s_nop 0"]
+    else:
+        L += ["s_mov_b32 m0, %[sl]", "s_nop 0"]
     if STATELESS:   # SGPR base + lane offset
         L += [f"v_mbcnt_lo_u32_b32 v{TMP(0)}, -1, 0", f"v_mbcnt_hi_u32_b32 v{TMP(0)}, -1, v{TMP(0)}", f"v_lshlrev_b32 v{TMP(0)}, 4, v{TMP(0)}"]
-        for i in range(SIDE_CHUNKS):
+        for i in range(min(SIDE_CHUNKS, 4)):
             L.append(f"global_load_lds_dwordx4 v{TMP(0)}, {sr(S_SIDE)}" + (f" offset:{1024 * i}" if i else ""))
+        if SIDE_CHUNKS == 5:   # the instruction offset is 13 bits signed: the fifth KiB through the lane offset and m0
+            L += [f"s_add_u32 m0, s{S_SLOTHER}, 4096", f"v_add_u32 v{TMP(0) + 1}, 4096, v{TMP(0)}",
+                  f"global_load_lds_dwordx4 v{TMP(0) + 1}, {sr(S_SIDE)}"]
         L += [f"s_add_u32 s{S_SIDE}, s{S_SIDE}, %[sidestride]", f"s_addc_u32 s{S_SIDE + 1}, s{S_SIDE + 1}, 0", ".Lenc_noside_%=:"]
         return L
     for i in range(SIDE_CHUNKS):
@@ -614,7 +677,14 @@ def generate():
     L = []
     A = L.append
     # ---- persistent registers
-    if STATELESS:
+    if DENSE:
+        A(f"s_mov_b32 s{S_SLCUR}, %[sl]")
+        A(f"s_add_u32 s{S_SLOTHER}, %[sl], {SIDE_LDS_BYTES}")
+        A(f"s_mov_b64 {sr(S_SIDE)}, %[side]")                              # layer 0's block is in flight already:
+        A(f"s_add_u32 s{S_SIDE}, s{S_SIDE}, %[sidestride]")                # layer_top() fetches from layer 1 on
+        A(f"s_addc_u32 s{S_SIDE + 1}, s{S_SIDE + 1}, 0")
+        L += lane_addr(V_PRIV16, "priv", 4, TMP(0))
+    elif STATELESS:
         A(f"s_mov_b64 {sr(S_SFB)}, %[sf]")
         A(f"s_mov_b64 {sr(S_SIDE)}, %[side]")
         L += lane_addr(V_PRIV16, "priv", 4, TMP(0))
@@ -648,7 +718,15 @@ def generate():
     A(f"s_mov_b32 s{S_PADT}, %[padt]")
     A(f"s_mov_b64 s[{S_SCPTR}:{S_SCPTR + 1}], %[scales]")
     A(f"s_mov_b32 s{S_EPS}, %[eps]")
-    A(f"s_load_dword s{S_SCA}, s[{S_SCPTR}:{S_SCPTR + 1}], 0x0")
+    if DENSE:
+        # the residual scale of the attention block is out_proj's: floats 2 + 3 L + l behind %[scales] (h3_pack_weights)
+        A(f"s_mul_i32 s{S_OSC}, %[layers], 12")
+        A(f"s_add_u32 s{S_OSC}, s{S_OSC}, 8")
+        A(f"s_add_u32 s{S_OSC}, s{S_SCPTR}, s{S_OSC}")
+        A(f"s_addc_u32 s{S_OSC + 1}, s{S_SCPTR + 1}, 0")
+        A(f"s_load_dword s{S_SCA}, s[{S_OSC}:{S_OSC + 1}], 0x0")
+    else:
+        A(f"s_load_dword s{S_SCA}, s[{S_SCPTR}:{S_SCPTR + 1}], 0x0")
     A(f"s_load_dword s{S_SCF}, s[{S_SCPTR}:{S_SCPTR + 1}], 0x8")
     # ---- x in: 24 register images from the wave-private block
     for ft in range(8):
@@ -687,9 +765,16 @@ def generate():
     # next layer's scales (12 bytes further), fragments
     A(f"s_add_u32 s{S_SCPTR}, s{S_SCPTR}, 12")
     A(f"s_addc_u32 s{S_SCPTR + 1}, s{S_SCPTR + 1}, 0")
-    A(f"s_load_dword s{S_NA}, s[{S_SCPTR}:{S_SCPTR + 1}], 0x0")
+    if DENSE:
+        A(f"s_add_u32 s{S_OSC}, s{S_OSC}, 4")
+        A(f"s_addc_u32 s{S_OSC + 1}, s{S_OSC + 1}, 0")
+        A(f"s_load_dword s{S_NA}, s[{S_OSC}:{S_OSC + 1}], 0x0")
+    else:
+        A(f"s_load_dword s{S_NA}, s[{S_SCPTR}:{S_SCPTR + 1}], 0x0")
     A(f"s_load_dword s{S_NF}, s[{S_SCPTR}:{S_SCPTR + 1}], 0x8")
-    if STATELESS:
+    if DENSE:
+        pass
+    elif STATELESS:
         A(f"s_add_u32 s{S_SFB}, s{S_SFB}, %[sfstride]")
         A(f"s_addc_u32 s{S_SFB + 1}, s{S_SFB + 1}, %[sfstridehi]")
     else:
@@ -710,6 +795,10 @@ def generate():
     A(f"s_mov_b32 s{S_SCA}, s{S_NA}")
     A(f"s_mov_b32 s{S_SCF}, s{S_NF}")
     A(f"s_sub_u32 s{S_IF}, 0x7f000000, s{S_SCF}")
+    if DENSE:   # the next layer's side block is the other buffer
+        A(f"s_mov_b32 s{S_SWAP}, s{S_SLCUR}")
+        A(f"s_mov_b32 s{S_SLCUR}, s{S_SLOTHER}")
+        A(f"s_mov_b32 s{S_SLOTHER}, s{S_SWAP}")
     A("s_branch .Lenc_layer_%=")
     A(".Lenc_last_%=:")
     L += g2(True)
@@ -727,8 +816,8 @@ def main():
             out_dir = a.split("=", 1)[1]
     ng = getattr(attn, "NG", 5)
     mode = (" --mode=windowed" if WINDOWED else "") + (" --nt=4" if NT4 else "") + \
-        ((" --wide" + (f" --ng={ng}" if ng != 5 else "")) if WIDE else "") + (" --h1" if H1 else "")
-    fam = ("h1" if H1 else "h3") + ("n4" if NT4 else "") + ((f"w{ng}" if ng != 5 else "w") if WIDE else "")
+        ((" --wide" + (f" --ng={ng}" if ng != 5 else "")) if WIDE else "") + (" --dense" if DENSE else "") + (" --h1" if H1 else "")
+    fam = ("h1" if H1 else "h3") + ("n4" if NT4 else "") + ((f"w{ng}" if ng != 5 else "w") if WIDE else "") + ("d" if DENSE else "")
     base = os.path.join(out_dir, f"tw_{fam}_encw_asm.inc" if WINDOWED else f"tw_{fam}_enc_asm.inc")
     out = [f"// GENERATED by tools/gen_h3_enc_asm.py{mode} - do not edit.  Body of the encoder-stack asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
