@@ -16,7 +16,8 @@
  *   - thread-safety: the compute entry points are re-entrant across streams.  Process-wide state: the per-thread error
  *     string; the debug / measurement word of tw_debug_set_flags (one atomic int, read once per launch: set it while no
  *     other thread launches); the profile hooks (tw_profile_begin / tw_profile_end, not thread-safe); the sticky
- *     per-device non-finite flag of tw_flow_nonfinite; tw_mh_iteration keeps one helper stream and two events per device
+ *     per-device non-finite flag of tw_flow_nonfinite (used by descriptors whose range_flag is NULL; since ABI 7 a
+ *     descriptor can carry its caller's own word instead); tw_mh_iteration keeps one helper stream and two events per device
  *     and calling thread, created on first use.
  */
 #ifndef TIMEWARP_HIP_H
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 6
+#define TW_ABI_VERSION 7
 
 typedef enum {
   TW_OK = 0,
@@ -62,6 +63,10 @@ typedef struct {
                            with per-layer coefficients (kernel_attention.py:12-66, 255-339); all execution paths (the
                            fused kernels take one score-fragment set per (net, layer) of the coupling layer in flight) */
   int32_t cheb_force_zero; /* force_asymptotic_zero: subtract each head's mean coefficient */
+  int32_t* range_flag;  /* ABI 7 - split-fp16 range guard, per model / per call: DEVICE pointer to a caller-owned int32
+                           (zeroed by the caller) that the flow kernels OR to 1 when a coupling net returns a non-finite
+                           scale or shift; every entry point that takes this descriptor reports there.  NULL: the
+                           per-device word of tw_flow_nonfinite (two models on one device then share one flag). */
 } tw_flow_desc;
 
 const char* tw_last_error(void);

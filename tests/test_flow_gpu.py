@@ -847,6 +847,56 @@ def test_split_fp16_overflow_demotes_to_f32():
     good.check_finite()
 
 
+def test_range_guard_is_per_model_not_per_device():
+    """ABI 7 (tw_flow_desc.range_flag): two models on one device, only one of which overflows, both inside
+    `deferred_range_check()` so that nobody looks at a flag between the calls.  With the per-device word of ABI 6 whoever
+    asked first saw - and cleared - the other model's overflow: the good model was demoted and the bad one sampled on."""
+    import ctypes as C
+    import warnings
+
+    from timewarp_amd import _lib
+
+    d, _ = H.load("kernel_full_ad")
+    args = dict(atom_types=d["atom_types"].cuda(), x_coords=d["x_coords"].cuda(), x_velocs=d["x_velocs"].cuda(),
+                y_coords=d["y_coords"].cuda(), y_velocs=d["y_velocs"].cuda(), adj_list=None, edge_batch_idx=None,
+                masked_elements=d["masked"].cuda())
+    bad = H.tw_kernel_model(_overflowing_sd(), path=H3)
+    good = H.tw_kernel_model(H.full_kernel_sd(), path=H3)
+    with bad.deferred_range_check(), good.deferred_range_check():
+        bad.log_likelihood(**args)
+        good.log_likelihood(**args)
+    # the good model asks first
+    assert not good.split_fp16_overflowed(torch.device("cuda", 0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        good.check_finite()
+        good.log_likelihood(**args)
+    assert not good.demoted
+    assert bad.split_fp16_overflowed(torch.device("cuda", 0))          # ... and the bad one still finds its own overflow
+    assert not bad.split_fp16_overflowed(torch.device("cuda", 0))      # read and cleared
+    # the per-device word (descriptors without a flag: raw C-ABI callers) saw none of it
+    flag = C.c_int32(7)
+    _lib.check(_lib.load().tw_flow_nonfinite(1, C.byref(flag)), "tw_flow_nonfinite")
+    assert flag.value == 0
+    # ... and still works for them: the same call through a descriptor with range_flag = NULL
+    desc = bad.dims.to_desc()
+    assert not desc.range_flag
+    raw, packed = bad._weights(torch.device("cuda", 0), H3)
+    B, V = args["x_coords"].shape[:2]
+    ws = bad._ws(torch.device("cuda", 0), B, V)
+    out = torch.empty(B, dtype=torch.float32, device="cuda")
+    at, mk, xc, xv, yc, yv = bad._prep(args["atom_types"], args["masked_elements"], args["x_coords"], args["x_velocs"],
+                                       args["y_coords"], args["y_velocs"])
+    _lib.check(_lib.load().tw_flow_log_likelihood(C.byref(desc), raw.data_ptr(), _lib.ptr(packed), at.data_ptr(), xc.data_ptr(),
+                                                  xv.data_ptr(), yc.data_ptr(), yv.data_ptr(), mk.data_ptr(), out.data_ptr(), B, V, H3,
+                                                  ws.data_ptr(), ws.numel(), _lib.stream_ptr(torch.device("cuda", 0))),
+               "tw_flow_log_likelihood")
+    torch.cuda.synchronize()
+    _lib.check(_lib.load().tw_flow_nonfinite(1, C.byref(flag)), "tw_flow_nonfinite")
+    assert flag.value == 1
+    assert not bad.split_fp16_overflowed(torch.device("cuda", 0))      # the model's own word was not involved
+
+
 @pytest.mark.parametrize("path", [FUSED, H3])
 def test_full_size_S1000_rows_vs_oracle(path):
     """BASELINE size (S = 1000 proposals, 22 atoms, 125 workgroups per coupling net) on both fused kernels - the

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/timewarp_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_raw_layout_matches_library_and_oracle_template():
@@ -656,3 +656,28 @@ def test_wrong_result_debug_switches_are_not_in_the_product_library():
             assert lib.tw_debug_set_flags(bit) == 0
     finally:
         assert lib.tw_debug_set_flags(0) == 0
+
+
+def test_split_fp16_workspace_covers_every_layout_a_launch_can_take():
+    """the split-fp16 kernel picks its layout per launch (48-token waves, 64-token waves, wide) from the row
+    count and tw_debug_set_flags; a workspace sized once for up to n_rows rows must hold whichever is taken.  The sizing
+    takes the maximum over the layouts that exist for the size (the 64-token one explicitly since r05), so it must not
+    depend on the flags, must grow with the row count, and every size from 1 to 192 atoms must be supported."""
+    import timewarp_amd as tw
+    from timewarp_amd import _lib, synthetic
+
+    lib = _lib.load()
+    d = tw.model_constructor(synthetic.kernel_transformer_nvp_config()).dims.to_desc()
+    flags = (0, 16384, 32768, 65536, 131072, 262144, 32768 | 262144, 65536 | 4096)
+    try:
+        for V in list(range(1, 70)) + [80, 96, 97, 128, 160, 161, 192]:
+            assert lib.tw_flow_path_supported(C.byref(d), V, _lib.TW_PATH_FUSED_H3) == 1, V
+            sizes = []
+            for f in flags:
+                lib.tw_debug_set_flags(f)
+                sizes.append([lib.tw_flow_workspace_bytes(C.byref(d), n, V) for n in (1, 100, 512, 1000)])
+            assert all(s == sizes[0] for s in sizes), (V, sizes)
+            assert sizes[0] == sorted(sizes[0]) and sizes[0][0] > 0, (V, sizes[0])
+        assert lib.tw_flow_path_supported(C.byref(d), 193, _lib.TW_PATH_FUSED_H3) == 0
+    finally:
+        lib.tw_debug_set_flags(0)

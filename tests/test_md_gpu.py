@@ -132,10 +132,12 @@ def test_thermostat_reaches_the_target_temperature(scheme):
 
 @pytest.mark.parametrize("where", ["current", "proposal"])
 def test_hybrid_moves_run_on_the_device_without_a_simulation(where):
-    """sample_with_model's hybrid moves (evaluation_utils.py:558-565, 594-602, 623-626) with NO Simulation passed: the chain
-    integrates by itself on the HIP force kernel (LangevinDynamics.from_preset: LangevinMiddle, 310 K, 0.3 / ps, 0.5 fs).
-    The reference needs the caller's OpenMM objects for these options; here the states move on the device - no host copy
-    of coordinates happens inside `openmm_step`."""
+    """sample_with_model's hybrid moves (evaluation_utils.py:558-565, 594-602, 623-626) with sim="device" (opt-in): the chain
+    integrates by itself on the HIP force kernel (LangevinDynamics.from_preset with the integrator of the energy's dataset
+    preset - alanine dipeptide: amber99-implicit-old = LangevinIntegrator, 310 K, 0.3 / ps, 0.5 fs - and a seed drawn from
+    the chain's own noise source).  The reference needs the caller's OpenMM objects for these options; here the states move
+    on the device - no host copy of coordinates happens inside `openmm_step`.  sim=None keeps the reference's meaning: the
+    options are silently off."""
     from timewarp_amd import synthetic
     from timewarp_amd.dataloader import single_state_batch
     from timewarp_amd.energy import AmberPotentialEnergyTorch
@@ -149,9 +151,16 @@ def test_hybrid_moves_run_on_the_device_without_a_simulation(where):
     S = 1 if where == "proposal" else 16   # openmm_on_proposal handles one proposal per iteration, as the reference
     kw = dict(accept=True, num_proposal_steps=S, random_velocs=True, resample_velocs=True, num_openmm_steps=5,
               openmm_on_current=(where == "current"), openmm_on_proposal=(where == "proposal"))
+    off = eu.MetropolisHastingsChain(single_state_batch("ad", types, coords), model, torch.device("cuda"), energy, masses,
+                                     noise=H.HostNoise(3, "cuda"), **kw)
+    assert off.sim is None and not (off.omm_current or off.omm_proposal)   # as the reference: `... and sim is not None`
     chain = eu.MetropolisHastingsChain(single_state_batch("ad", types, coords), model, torch.device("cuda"), energy, masses,
-                                       noise=H.HostNoise(3, "cuda"), **kw)
+                                       noise=H.HostNoise(3, "cuda"), sim="device", **kw)
     assert isinstance(chain.sim, LangevinDynamics) and (chain.omm_current or chain.omm_proposal)
+    assert chain.sim.integrator == "LangevinIntegrator"   # alanine dipeptide's preset (simulation/md.py:31-37, 75-82)
+    other = eu.MetropolisHastingsChain(single_state_batch("ad", types, coords), model, torch.device("cuda"), energy, masses,
+                                       noise=H.HostNoise(4, "cuda"), sim="device", **kw)
+    assert other.sim.seed != chain.sim.seed    # another chain's noise -> another thermostat stream
     seen = []
     real = eu.openmm_step
 

@@ -40,6 +40,7 @@ class FlowDesc(C.Structure):
         ("ln_eps", C.c_float),
         ("cheb_order", C.c_int32),
         ("cheb_force_zero", C.c_int32),
+        ("range_flag", C.c_void_p),   # ABI 7: device int32 the flow kernels raise on a non-finite scale / shift (None: per device)
     ]
 
 
@@ -83,7 +84,7 @@ class MHOptions(C.Structure):
     ]
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 _DESC = C.POINTER(FlowDesc)

@@ -221,8 +221,10 @@ int64_t fused_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms
 // z_out = affine coupling of z_in (nullptr: in place on z_out)
 int launch_coupling(const float* s_raw, const float* t, const uint8_t* masked, int64_t n_cond,
                     float* z_out, float* delta_logp, int64_t n_rows, int V, int reverse, hipStream_t s,
-                    const float* z_in = nullptr);
-int* nonfinite_flag_device_ptr();  // address of the sticky non-finite flag (for kernels of other translation units)
+                    const float* z_in = nullptr, int* flag = nullptr);
+int* nonfinite_flag_device_ptr();  // address of the per-device sticky non-finite flag (for kernels of other translation units)
+// where the flow kernels of this call report a non-finite scale / shift: the descriptor's own word (ABI 7), else the device's
+inline int* flow_range_flag(const tw_flow_desc& d) { return d.range_flag ? d.range_flag : nonfinite_flag_device_ptr(); }
 
 // The affine coupling (layers/nvp.py:89-183) of the PREVIOUS coupling layer, applied by the next net-block launch in
 // its prologue instead of by a launch of its own: the variable it transforms is exactly the next layer's conditioning

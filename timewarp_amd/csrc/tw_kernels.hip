@@ -225,7 +225,7 @@ int* nonfinite_flag_device_ptr() {
 
 __global__ void coupling_kernel(const float* __restrict__ s_raw, const float* __restrict__ t,
                                 const uint8_t* __restrict__ masked, int64_t n_cond, const float* z_in, float* z,
-                                float* __restrict__ delta_logp, int V, int reverse) {
+                                float* __restrict__ delta_logp, int V, int reverse, int* __restrict__ flag) {
   const int64_t n = blockIdx.x;
   const int64_t c = n % n_cond;
   float acc = 0.f;
@@ -239,7 +239,7 @@ __global__ void coupling_kernel(const float* __restrict__ s_raw, const float* __
     acc += logf(scale) * keep;
     z[idx] = reverse ? (z_in[idx] - shift) / scale : z_in[idx] * scale + shift;
   }
-  if (bad) atomicOr(&g_nonfinite, 1);
+  if (bad) atomicOr(flag ? flag : &g_nonfinite, 1);
   acc = wave_sum(acc);
   if (threadIdx.x == 0) {
     const float logdet = reverse ? -acc : acc;
@@ -248,10 +248,10 @@ __global__ void coupling_kernel(const float* __restrict__ s_raw, const float* __
 }
 
 int launch_coupling(const float* s_raw, const float* t, const uint8_t* masked, int64_t n_cond, float* z,
-                    float* delta_logp, int64_t n_rows, int V, int reverse, hipStream_t s, const float* z_in) {
+                    float* delta_logp, int64_t n_rows, int V, int reverse, hipStream_t s, const float* z_in, int* flag) {
   if (n_rows == 0) return TW_OK;
   hipLaunchKernelGGL(coupling_kernel, dim3((unsigned)n_rows), dim3(64), 0, s, s_raw, t, masked, n_cond, z_in ? z_in : z, z,
-                     delta_logp, V, reverse);
+                     delta_logp, V, reverse, flag);
   TW_LAUNCH_CHECK();
   return TW_OK;
 }
@@ -740,7 +740,7 @@ int flow_pass_simple(const FlowArgs& a) {
     if ((rc = netblock_simple(a, L, w, c, 0, z_other, w.s_out, nullptr))) return rc;
     if ((rc = netblock_simple(a, L, w, c, 1, z_other, w.t_out, nullptr))) return rc;
     if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, z_t, a.delta_logp, a.n_rows, a.n_atoms,
-                              a.reverse, a.stream)))
+                              a.reverse, a.stream, nullptr, a.desc->range_flag)))
       return rc;
   }
   return TW_OK;

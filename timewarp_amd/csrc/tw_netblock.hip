@@ -698,7 +698,7 @@ int flow_pass_fused(const FlowArgs& a) {
     if (d.cheb_order > 0 && (rc = launch_score_frags(a, L, g, w.sfrag, shared, c, &vf))) return rc;
     if ((rc = launch_netblock(a, L, g, c, -1, z_other, w.sfrag, vf, shared, w.s_out, w.t_out, nullptr))) return rc;
     if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, z_t, a.delta_logp, a.n_rows, a.n_atoms, a.reverse,
-                              a.stream)))
+                              a.stream, nullptr, a.desc->range_flag)))
       return rc;
   }
   return TW_OK;

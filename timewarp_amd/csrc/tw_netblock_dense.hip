@@ -575,7 +575,7 @@ int flow_pass_fused_dense(const FlowArgs& a) {
     float* z_t = positions ? a.z_coords : a.z_velocs;
     if ((rc = dense_launch(a, L, g, c, -1, z_other, w.s_out, w.t_out, nullptr))) return rc;
     if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, z_t, a.delta_logp, a.n_rows, a.n_atoms, a.reverse,
-                              a.stream)))
+                              a.stream, nullptr, a.desc->range_flag)))
       return rc;
   }
   return TW_OK;

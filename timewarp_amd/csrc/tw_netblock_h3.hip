@@ -257,7 +257,7 @@ bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom fg;
   if (d.variant == 0)
     return d.d_model == 128 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 && d.d_emb + 9 <= 64 &&
-           (h3_narrow_ok(d, n_atoms) || h3_wide_ok(n_atoms));
+           (h3_narrow_ok(d, n_atoms) || h3_wide_ok(n_atoms) || h3_nt4_ok(d, n_atoms, false));
   if (d.variant == 1)  // dense softmax attention: 8 heads of 16 = one MFMA tile each; input width <= 64, or 32 + 9 + 128
                        // random Fourier position features (192 columns: the in-MLP then runs as compiled C++)
     return d.d_model == 128 && d.n_heads == 8 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 &&
@@ -2567,12 +2567,13 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool
   H3Wide wd;
   bool wide = false;
   h3_layout(d, V, n_rows, h1, &g, &wd, &wide);
-  if (force_layout >= 0 && (force_layout != 0) != wide) {  // (sizing only: the other layout, where it exists)
-    wide = force_layout != 0;
+  if (force_layout >= 0) {  // sizing only - 0: 48-token waves, 1: wide, 2: 64-token waves; an empty H3Ws where the layout does not exist
+    wide = force_layout == 1;
     if (wide) {
       if (!h3_wide_geom(V, &wd)) return H3Ws{};
+      g.nt = H3_NT;
       g.mpw = wd.mpwg;
-    } else if (!fused_geom_nt(V, H3_NT, &g)) {
+    } else if (!fused_geom_nt(V, force_layout == 2 ? H3N4_NT : H3_NT, &g)) {
       return H3Ws{};
     }
   }
@@ -2618,11 +2619,12 @@ static bool h3_windowed(const FusedGeom& fg, int V) {
 
 
 int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms) {
-  // the larger of the two layouts: which one a call takes depends on its own row count (h3_wide_choice), and callers size
-  // one workspace for calls of up to n_rows rows
+  // the largest of the layouts that exist for this size: which one a call takes depends on its own row count and on
+  // tw_debug_set_flags (h3_wide_choice, h3_nt4_choice), and callers size one workspace for calls of up to n_rows rows
   int64_t b = 0;
-  for (int layout = 0; layout < 2; ++layout)
-    if (d.variant == 0 ? (layout ? h3_wide_ok(n_atoms) : h3_narrow_ok(d, n_atoms)) : layout == 0) {
+  for (int layout = 0; layout < 3; ++layout)
+    if (d.variant == 0 ? (layout == 0 ? h3_narrow_ok(d, n_atoms) : layout == 1 ? h3_wide_ok(n_atoms) : h3_nt4_ok(d, n_atoms, false))
+                       : layout == 0) {
       const int64_t x = h3_ws(d, n_rows, n_atoms, nullptr, false, layout).bytes;
       if (x > b) b = x;
     }
@@ -2886,7 +2888,7 @@ int flow_pass_h3(const FlowArgs& a) {
   float* alt[2] = {w.zc_alt, w.zv_alt};
   float* sbuf[2] = {w.s_out, w.s_out2};
   float* tbuf[2] = {w.t_out, w.t_out2};
-  int* flag = nonfinite_flag_device_ptr();
+  int* flag = flow_range_flag(d);
   TW_REQUIRE(flag != nullptr, "hipGetSymbolAddress(g_nonfinite) failed");
   PrevCoupling prev{};
   int tv = 0;
@@ -2898,7 +2900,7 @@ int flow_pass_h3(const FlowArgs& a) {
       if ((rc = h3_launch(a, L, fg, c, -1, positions ? a.z_velocs : a.z_coords, w.sfrag, vb, shared, w.s_out, w.t_out, nullptr)))
         return rc;
       if ((rc = launch_coupling(w.s_out, w.t_out, a.masked, a.n_cond, positions ? a.z_coords : a.z_velocs, a.delta_logp,
-                                a.n_rows, a.n_atoms, a.reverse, a.stream)))
+                                a.n_rows, a.n_atoms, a.reverse, a.stream, nullptr, flag)))
         return rc;
     }
     return TW_OK;
@@ -2919,7 +2921,7 @@ int flow_pass_h3(const FlowArgs& a) {
   }
   // the last layer's update has no successor: its own small launch, straight into the caller's buffer
   if ((rc = launch_coupling(prev.s_raw, prev.t, a.masked, a.n_cond, caller[tv], a.delta_logp, a.n_rows, a.n_atoms, a.reverse,
-                            a.stream, cur[tv])))
+                            a.stream, cur[tv], flag)))
     return rc;
   const int ov = 1 - tv;
   if (cur[ov] != caller[ov])

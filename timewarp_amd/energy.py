@@ -15,8 +15,11 @@ GAS_CONSTANT = 8.314462618e-3  # kJ/(mol K), as openmm.unit.MOLAR_GAS_CONSTANT_R
 
 
 class AmberPotentialEnergyTorch:
-    def __init__(self, tables: ForceFieldTables, temperature: float = 310.0, integrator=None):
+    def __init__(self, tables: ForceFieldTables, temperature: float = 310.0, integrator=None, md_preset: str = None):
         self.tables = tables
+        # simulation preset the topology's dataset was made with (simulation/md.py:31-37): decides the integrator scheme of
+        # sample_with_model(sim="device").  Unknown origin: GBSA-OBC I is the amber14 preset's, anything else the older one's.
+        self.md_preset = md_preset or ("amber14-implicit" if tables.has_gbsa == 2 else "amber99-implicit-old")
         self.temperature = float(temperature)
         self.num_particles = tables.n_atoms  # openmm_bridge.py:279
         self._integrator = integrator
@@ -25,7 +28,7 @@ class AmberPotentialEnergyTorch:
     @classmethod
     def alanine_dipeptide(cls, temperature: float = 310.0) -> "AmberPotentialEnergyTorch":
         """Preset `alanine-dipeptide` of simulation/md.py:31-37,75-82 (310 K, 2 nm cutoff, OBC)."""
-        return cls(alanine_dipeptide_amber99sb(), temperature)
+        return cls(alanine_dipeptide_amber99sb(), temperature, md_preset="amber99-implicit-old")
 
     @classmethod
     def from_preset(cls, preset_or_dataset: str, atom_names, residue_names, residue_ids, temperature: float = 310.0):
@@ -35,7 +38,9 @@ class AmberPotentialEnergyTorch:
         ("T1B-peptides", the 4AA preset) is PARITY UNPINNED and limited to ACE / NME / ALA / GLY (forcefield.py)."""
         from .forcefield import tables_for_preset
 
-        return cls(tables_for_preset(preset_or_dataset, atom_names, residue_names, residue_ids), temperature)
+        md_preset = {"T1B-peptides": "amber14-implicit", "T1-peptides": "amber99-implicit-old", "HP-1400": "amber99-implicit-old",
+                     "HP-4000": "amber99-implicit-old", "alanine-dipeptide": "amber99-implicit-old"}.get(preset_or_dataset, preset_or_dataset)
+        return cls(tables_for_preset(preset_or_dataset, atom_names, residue_names, residue_ids), temperature, md_preset=md_preset)
 
     @classmethod
     def from_openmm(cls, system, integrator=None, platform_name=None, platform_properties=None, **_):

@@ -4,7 +4,8 @@ preset parameters of md.py:75-93: 310 K, friction 0.3 / ps, time step 0.5 fs, La
 for the oldest datasets).
 
 `sample_with_model(..., openmm_on_current / openmm_on_proposal, num_openmm_steps=n, sim=LangevinDynamics(...))` - or
-`sim=None` with an `AmberPotentialEnergyTorch` energy, for which the chain builds one - advances states on the GPU without
+`sim="device"` with an `AmberPotentialEnergyTorch` energy, for which the chain builds one (the preset's integrator, a seed
+drawn from the chain's noise; `sim=None` turns the options off, as in the reference) - advances states on the GPU without
 the host round trip an OpenMM Simulation costs per iteration.  The integration schemes are OpenMM's; the Gaussian noise is
 this library's own counter-based stream, so trajectories agree with OpenMM's statistically (temperature, energy
 conservation without friction), not step for step.  There is no CPU path."""
@@ -32,6 +33,7 @@ class LangevinDynamics:
         if self.masses.numel() != energy.tables.n_atoms:
             raise ValueError("one mass per atom")
         self.dt, self.friction, self.scheme = float(timestep_ps), float(friction_per_ps), SCHEMES[integrator]
+        self.integrator = integrator
         self.kbT = energy.kbT if temperature is None else 8.314462618e-3 * float(temperature)
         self.seed = int(seed) & (2 ** 64 - 1)
         self.steps_done = 0

@@ -47,6 +47,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         self.used_split_fp16 = False  # some call ran on the split-fp16 kernel since the last demotion (range guard)
         self.demoted = False          # the range guard has moved this model to the exact-f32 kernels
         self._defer_range_check = 0
+        self._range_flags = {}        # device -> int32[1]: THIS model's range-guard word (tw_flow_desc.range_flag, ABI 7)
 
     # ------------------------------------------------------------------ weight cache
     def _apply(self, fn, *a, **k):
@@ -83,15 +84,33 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
     # to the exact-f32 kernels (execution_path = TW_PATH_AUTO, one warning) and the affected work is redone there: a
     # public call re-runs itself, the MH loops replay the iterations since their last read-back from the recorded
     # draws (utils/evaluation_utils.py).  `check_finite` is the raising form for callers that drive the C ABI themselves.
+    def _desc(self, device):
+        """The C descriptor of a call on `device`, carrying this model's own range-guard word there (ABI 7): two models on
+        one device no longer see - or swallow - each other's overflow, as they did with the per-device word."""
+        d = self.dims.to_desc()
+        device = torch.device(device)
+        if device.type == "cuda":
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            if key not in self._range_flags:
+                self._range_flags[key] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key))
+            d.range_flag = self._range_flags[key].data_ptr()
+        return d
+
     def split_fp16_overflowed(self, device=None) -> bool:
-        """True if a split-fp16 launch produced non-finite coupling parameters since the last call (reads and clears
-        the device flag; synchronises).  Always False for a model that never ran on that kernel."""
+        """True if a split-fp16 launch of THIS model produced non-finite coupling parameters since the last call (reads and
+        clears the model's flag word on that device; synchronises).  Always False for a model that never ran on that kernel."""
         if not self.used_split_fp16:
             return False
-        flag = C.c_int32(0)
-        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
-            _lib.check(_lib.load().tw_flow_nonfinite(1, C.byref(flag)), "tw_flow_nonfinite")
-        return bool(flag.value)
+        key = torch.device(device).index if device is not None else None
+        if key is None:
+            key = torch.cuda.current_device()
+        flag = self._range_flags.get(key)
+        if flag is None:
+            return False
+        if int(flag.item()) == 0:
+            return False
+        flag.zero_()
+        return True
 
     def demote_to_f32(self) -> None:
         """Leave the split-fp16 kernel for good: every later call runs on the exact-f32 kernels."""
@@ -218,7 +237,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         ws = self._ws(dev, B, V)
         out = torch.empty(B, dtype=torch.float32, device=dev)
         lib = _lib.load()
-        desc = self.dims.to_desc()
+        desc = self._desc(dev)
 
         def run(path):
             raw, packed = self._weights(dev, path)
@@ -270,7 +289,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         y_v = torch.empty((S, B, V, 3), dtype=torch.float32, device=dev)
         logp = torch.empty((S, B), dtype=torch.float32, device=dev)
         lib = _lib.load()
-        desc = self.dims.to_desc()
+        desc = self._desc(dev)
 
         def run(path):
             raw, packed = self._weights(dev, path)
@@ -300,7 +319,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
         L, dm = self.dims.n_layers, self.dims.d_model
         dump = torch.zeros((L + 1) * N * V * dm + N * V * 3, dtype=torch.float32, device=dev)
         lib = _lib.load()
-        desc = self.dims.to_desc()
+        desc = self._desc(dev)
         with torch.cuda.device(dev):
             _lib.check(lib.tw_debug_netblock(
                 C.byref(desc), raw.data_ptr(), _lib.ptr(packed), coupling, net, at.data_ptr(), xc.data_ptr(),

@@ -356,13 +356,23 @@ class MetropolisHastingsChain:
         # OpenMM steps on the current state / on the proposal (evaluation_utils.py:556-565, 594-602, 623-626): a host
         # round trip through the caller's Simulation per iteration, so these chains take the op-by-op route
         self.sim, self.n_omm = sim, int(num_openmm_steps)
-        if sim is None and self.n_omm > 0 and (openmm_on_current or openmm_on_proposal):
-            # the reference needs the caller's Simulation for these options; with the HIP energy the chain can integrate by
-            # itself, on the device, with the reference's preset integrator (simulation/md.py:75-93, 213-231)
+        self._sim_steps_mark = None
+        if isinstance(sim, str):
+            # sim="device" (opt-in; the reference has no such value): the chain integrates by itself on the HIP force kernel
+            # with the reference's preset integrator for the energy's force-field family (simulation/md.py:75-93, 213-231).
+            # sim=None stays what it is in the reference - the hybrid-move options are silently off
+            # (`... and sim is not None`, evaluation_utils.py:556, 594, 623).
             from ..energy import AmberPotentialEnergyTorch
             from ..md import LangevinDynamics
-            if isinstance(energy_fn, AmberPotentialEnergyTorch):
-                self.sim = sim = LangevinDynamics.from_preset(energy_fn, masses)
+            if sim != "device":
+                raise ValueError(f"sim={sim!r}: pass an openmm.app.Simulation-like object, a LangevinDynamics, or 'device'")
+            if not isinstance(energy_fn, AmberPotentialEnergyTorch):
+                raise ValueError("sim='device' needs the HIP energy (AmberPotentialEnergyTorch) as energy_fn")
+            # the thermostat's Gaussian stream is keyed on (seed, step, atom): every chain draws its own seed from its own
+            # noise source, so independently seeded chains (distributed.chain_seed) stay independent
+            u = self.noise.uniform(2).double().cpu()
+            seed = (int(float(u[0]) * (1 << 26)) << 26) | int(float(u[1]) * (1 << 26))
+            self.sim = sim = LangevinDynamics.from_preset(energy_fn, masses, preset=energy_fn.md_preset, seed=seed)
         self.omm_current = bool(openmm_on_current) and self.n_omm > 0 and sim is not None
         self.omm_proposal = bool(openmm_on_proposal) and self.n_omm > 0 and sim is not None
         self.velocs_std = (self.kbT / self.masses.unsqueeze(0).unsqueeze(-1)).sqrt()
@@ -398,7 +408,7 @@ class MetropolisHastingsChain:
         if getattr(self, "_fconst", None) is None or self._fconst["S"] != S:
             dev = self.device
             lib = _lib.load()
-            desc = self.model.dims.to_desc()
+            desc = self.model._desc(dev)   # carries the model's own range-guard word (ABI 7)
             opt = _lib.MHOptions()
             opt.random_velocs = int(self.random_velocs)
             keep = {"masses": self.masses.contiguous()}
@@ -560,11 +570,17 @@ class MetropolisHastingsChain:
             ("dpot", e_pot), ("dkin", e_kin))
 
     def _overflowed(self) -> bool:
-        """Split-fp16 range guard, asked right after a host read-back (which has synchronised).  The device flag is ONE
-        sticky bit per device, read and cleared by whoever looks first: if somebody else (another chain's flush, a public
-        call on the shared model) has seen it and demoted the model while this chain still has iterations recorded, those
-        iterations may be the ones that overflowed - `model.demoted` therefore counts as an overflow for an open window."""
+        """Split-fp16 range guard, asked right after a host read-back (which has synchronised).  The flag word is the MODEL's
+        own (tw_flow_desc.range_flag, ABI 7), read and cleared by whoever of its users looks first: if another user of the
+        same model (another chain's flush, a public call) has seen it and demoted the model while this chain still has
+        iterations recorded, those iterations may be the ones that overflowed - `model.demoted` therefore counts as an
+        overflow for an open window.  Another model's overflow on the same device no longer shows up here."""
         return self._guard and (bool(getattr(self.model, "demoted", False)) or self.model.split_fp16_overflowed(self.device))
+
+    def _mark(self):
+        """Start of a range-guard window: forget the draws recorded so far, remember where the device integrator stands."""
+        self.noise.mark()
+        self._sim_steps_mark = getattr(self.sim, "steps_done", None)
 
     def _redo_on_f32(self, start_c, start_v, n_iterations: int):
         """The model's activations left the fp16 range somewhere in the last `n_iterations` iterations: demote the model
@@ -574,6 +590,8 @@ class MetropolisHastingsChain:
         recorder = self.noise
         self.noise = ReplayDraws(recorder.log)
         self.x_coords, self.x_velocs = start_c, start_v
+        if hasattr(self.sim, "steps_done") and self._sim_steps_mark is not None:
+            self.sim.steps_done = self._sim_steps_mark   # the device integrator's draws are keyed on the step count: same draws
         self.proposals -= n_iterations * self.S
         outs = []
         try:
@@ -593,7 +611,7 @@ class MetropolisHastingsChain:
         S, device = self.S, self.device
         start_c, start_v = self.x_coords, self.x_velocs
         if self._guard:
-            self.noise.mark()
+            self._mark()
         if self.accept:
             out = self._compute()
             k_true, any_acc = (int(v) for v in out[0][:2].tolist())  # the one host sync of the iteration
@@ -650,7 +668,7 @@ class MetropolisHastingsChain:
         if not self._pending:
             self._pending_start = (self.x_coords, self.x_velocs)
             if self._guard:
-                self.noise.mark()
+                self._mark()
         out = self._compute()
         self._pending.append(out)
         self.x_coords, self.x_velocs = out[3], out[4]
