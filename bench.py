@@ -66,8 +66,8 @@ CONFIGS = {
                         "1 chain per GPU (BASELINE.json configs[1]; configs[2] when n_gpus=8)"),
     "4aa": dict(V=61, S=512, model="kernel", flop_sample_pass=16 * 61 * F_BLK_KERNEL(61),
                 calibration=dict(coords_log_scale=-7.5, velocs_log_scale=0.0),
-                kernel="tw::netblock_h3_kernel<4, true> (64-token waves: one molecule per wave, 128 workgroups per net = one round; FFN "
-                       "as generated asm, in / out MLPs and attention block compiled C++)",
+                kernel_note="64-token waves: one molecule per wave, 128 workgroups per net = one round of the chip; both coupling "
+                            "nets of one coupling layer, all proposals",
                 workload="kernel_transformer_nvp.yaml, 4AA tetrapeptide NAQQ (61 atoms: the reference's OpenMM test peptide NNQQ, "
                          "simulation/testdata/implicit-2olx-*, with its second asparagine cut back to alanine - CG becomes HB1 at "
                          "1.09 A - so that the molecule has BASELINE's '~60 atoms'; amber99sb-ildn + OBC tables pinned by the "
@@ -75,11 +75,13 @@ CONFIGS = {
                          "SURVEY 8d's 4.675 TFLOP per iteration is the same formula at V = 60)"),
     "4aa-nnqq": dict(V=65, S=512, model="kernel", flop_sample_pass=16 * 65 * F_BLK_KERNEL(65),
                      calibration=dict(coords_log_scale=-7.5, velocs_log_scale=0.0),
-                     kernel="tw::netblock_h3_kernel<3, true, false, true> (wide layout: 2 molecules per workgroup)",
+                     kernel_note="wide layout: 2 molecules per workgroup at a slot stride of 96, three-group key windows; both "
+                                 "coupling nets of one coupling layer, all proposals",
                      workload="kernel_transformer_nvp.yaml, 4AA tetrapeptide NNQQ (65 atoms: the reference's own OpenMM test molecule, "
                               "one atom above what a 64-token wave holds: the wide layout), 512-proposal parallel MH, 1 chain per GPU"),
     "dense": dict(V=22, S=1000, model="dense", flop_sample_pass=16 * 22 * F_BLK_DENSE, calibration=CALIBRATION,
-                  kernel="tw::netblock_h3_kernel<3, true, true> (split-fp16 dense-softmax kernel)",
+                  kernel_note="dense-softmax kernel; with --path h1 the MLP sections are single-MFMA, the softmax attention "
+                              "block stays split-fp16; both coupling nets of one coupling layer, all proposals",
                   workload="transformer_nvp.yaml (dense softmax attention variant), alanine-dipeptide (22 atoms), 1000-proposal "
                            "parallel MH, 1 chain per GPU (BASELINE.json configs[4])"),
 }
@@ -122,11 +124,12 @@ def molecule(config):
     return label, types, torch.from_numpy(pos).float(), masses, AmberPotentialEnergyTorch(tables)
 
 
-def build_chain(device, seed, proposals, path, config="ad"):
+def build_chain(device, seed, proposals, path, config="ad", n_chains=1):
     import timewarp_amd as tw
     from timewarp_amd import synthetic
     from timewarp_amd.dataloader import single_state_batch
     from timewarp_amd.utils.evaluation_utils import MetropolisHastingsChain
+    from timewarp_amd.utils.multichain import MetropolisHastingsChains
 
     cfg = CONFIGS[config]
     model = tw.model_constructor(synthetic.transformer_nvp_config() if cfg["model"] == "dense" else synthetic.kernel_transformer_nvp_config())
@@ -137,9 +140,37 @@ def build_chain(device, seed, proposals, path, config="ad"):
     torch.manual_seed(seed)
     torch.cuda.manual_seed(seed)
     batch = single_state_batch(name, types, coords, torch.zeros(cfg["V"], 3))
+    if n_chains > 1:
+        # `proposals` rows per launch shared by the chains: S = proposals // C proposals per chain and iteration
+        chain = LockStepChains(MetropolisHastingsChains([batch] * n_chains, model, device, energy, masses, proposals // n_chains,
+                                                        random_velocs=MH_MODE["random_velocs"], resample_velocs=MH_MODE["resample_velocs"]))
+        prewarm(model, types, coords, device, (proposals // n_chains) * n_chains)
+        return chain, model
     chain = MetropolisHastingsChain(batch, model, device, energy, masses, num_proposal_steps=proposals, **MH_MODE)
     prewarm(model, types, coords, device, proposals)
     return chain, model
+
+
+class LockStepChains:
+    """--chains C (utils/multichain.py): C independent chains of the same molecule evaluated in lock-step - C x S
+    rows per flow launch, one accept scan per chain - behind the interface the timed loop drives a single chain through."""
+
+    def __init__(self, chains):
+        self.inner = chains
+
+    def step_deferred(self):
+        self.inner.step_deferred()
+
+    def flush(self):
+        self.inner.flush()
+
+    accepted = property(lambda self: sum(self.inner.accepted))
+    proposals = property(lambda self: self.inner.proposals)
+    chain_c = property(lambda self: [t for per_chain in self.inner.chain_c for t in per_chain])
+
+    def trajectory(self):
+        self.inner.flush()
+        return torch.cat(self.chain_c, dim=0), None
 
 
 PREWARM_PASSES = 40  # ~0.15 s
@@ -163,6 +194,33 @@ def prewarm(model, types, coords, device, proposals):
     torch.cuda.synchronize(device)
 
 
+def committed_traffic(kernel: str, bench_args: str):
+    """HBM / fabric bytes per launch from the newest committed rocprofv3 --pmc summary (profiles/r*_pmc_traffic.json, written by
+    tools/pmc_traffic.sh + tools/summarize_profiles.py --traffic) that measured EXACTLY this kernel instantiation under
+    exactly this bench configuration - else (None, None).  r04 read whatever the newest file held for the kernel family; a
+    rebuilt kernel then carried its predecessor's traffic."""
+    import glob
+
+    want = kernel.split(" (")[0].strip()
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        with open(pmc) as f:
+            recs = json.load(f)
+        for rec in recs.values():
+            if not isinstance(rec, dict) or "kernel" not in rec:
+                continue
+            name = rec["kernel"].replace("void ", "").split("(tw::")[0].strip()
+            if name == want and rec.get("bench_args") == bench_args:
+                return rec["traffic_bytes_per_launch_corrected"], (
+                    f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `bench.py "
+                    f"{bench_args}`: this instantiation, this configuration)")
+    return None, None
+
+
+def live_kernel(lib) -> str:
+    """The net-block instantiation the last flow call of this thread launched (tw_last_netblock_kernel, ABI 7)."""
+    return lib.tw_last_netblock_kernel().decode()
+
+
 def attention_block(model, device, proposals, avg_launch_ms, path_name="h3"):
     """The north-star's second figure: algorithmic FLOP rate of the attention block (values_proj + A.V + out_proj,
     SURVEY 8d) against the bf16/f16 dense MFMA peak.  Measured on one extra, untimed launch of the dominant kernel with
@@ -178,23 +236,23 @@ def attention_block(model, device, proposals, avg_launch_ms, path_name="h3"):
     zo = (torch.randn(proposals, V_ATOMS, 3, generator=g) * 0.5).to(device)
     mask = torch.zeros(1, V_ATOMS, dtype=torch.bool, device=device)
     lib = _lib.load()
-    lib.tw_debug_set_flags(16)
+    # bit 4: section stamps; bit 13: from the encoder-stack statement - the PRODUCT build, whose stamps are compiled in (r05:
+    # in every statement, five scalar compare-and-branch pairs per layer when off) - not from the per-section build
+    lib.tw_debug_set_flags(16 | 8192)
     try:
         for _ in range(2):
             acts, _ = model.debug_netblock(0, 0, at, xc, xv, mask, zo, PATHS[path_name]["path"])
         torch.cuda.synchronize()
+        stamped_kernel = live_kernel(lib)
     finally:
         lib.tw_debug_set_flags(0)
     n_layers = model.dims.n_layers
     ts = acts.reshape(-1)[:128].contiguous().view(torch.int64).cpu().tolist()
-    # stamps: 0 start, 1 in_mlp, then per layer (attention, add+LN1, FFN, add+LN2), out_mlp; 60: top of the kernel
+    # stamps: 0 start, 1 in_mlp, 2 + 4 l + 3 end of layer l, out_mlp; 60: top of the kernel; inside the statement
+    # 40 + 4 l + {0, 1} = start / end of layer l's attention block (side-block DMA + all heads: mixing and the folded
+    # out_proj . values_proj GEMM)
     total = ts[2 + 4 * n_layers] - (ts[60] or ts[0])
-    if path_name == "h1":
-        # the single-MFMA build is the encoder-stack statement with its stamps compiled in: 40 + 4 l + {0, 1} = start /
-        # end of layer l's attention block (side-block DMA + all heads: mixing and folded out_proj . values_proj GEMM)
-        att = sum(ts[40 + 4 * l + 1] - ts[40 + 4 * l] for l in range(n_layers))
-    else:
-        att = sum(ts[2 + 4 * l] - ts[1 + 4 * l] for l in range(n_layers))
+    att = sum(ts[40 + 4 * l + 1] - ts[40 + 4 * l] for l in range(n_layers))
     share = att / total
     d = model.dims
     flop_token_layer = 2 * d.d_model * d.n_heads * d.d_model * 2 + 2 * d.n_heads * V_ATOMS * d.d_model
@@ -213,12 +271,9 @@ def attention_block(model, device, proposals, avg_launch_ms, path_name="h3"):
                                       "block-diagonal mixing on K=32+16 MFMAs)" if path_name == "h1" else
                                       "2.26 (3-term fp16 split x 1/2 from folding out_proj into values_proj per head "
                                       "+ the K=48 block-diagonal mixing on K=32+16 MFMAs)"),
-        "method": ("s_memtime section stamps of one untimed launch (tw_debug_set_flags 16; the stamps are compiled into the "
-                   "encoder-stack statement of this build) x live average launch time" if path_name == "h1" else
-                   "s_memtime section stamps of one untimed launch (tw_debug_set_flags 16: the per-section build of the kernel, "
-                   "whose stamps sit between the sections) x live average launch time of the encoder-stack build; that build "
-                   "spends 3 x 47.1 k of 744.5 k cycles in the attention blocks (profiles/r03_ab_xt_agprs.txt), so the share "
-                   "used here is slightly high and the rate slightly low"),
+        "method": "s_memtime section stamps of one untimed launch of the timed build itself (tw_debug_set_flags 16 | 8192; the "
+                  "stamps are compiled into the encoder-stack statement) x live average launch time",
+        "stamped_kernel": stamped_kernel,
     }
 
 
@@ -416,6 +471,7 @@ def alt_path_record(device, seed, proposals, steps, sync_every, name="f32"):
     lib.tw_profile_end(C.byref(k_ms), C.byref(k_launches))
     avg_ms = k_ms.value / max(int(k_launches.value), 1)
     achieved = FLOP_PER_SAMPLE_PASS * proposals / N_COUPLING / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    kernel = live_kernel(lib) or pinfo["kernel"]
     rec = {
         "execution_path": {"f32": "f32 (exact-f32 fused kernel: TW_EXECUTION_PATH=f32 / the C ABI's TW_PATH_AUTO; model_constructor's default is h3)",
                            "h1": "h1 (opt-in fast mode: TW_EXECUTION_PATH=h1 / TW_PATH_FUSED_H1; one fp16 MFMA per product; NOT a "
@@ -423,18 +479,12 @@ def alt_path_record(device, seed, proposals, steps, sync_every, name="f32"):
         "dtype": pinfo["dtype"], "value": (chain.accepted - acc0) / elapsed, "unit": "MH-accepted samples/s",
         "steps": steps, "ms_per_step": elapsed / steps * 1e3,
         "range_guard_fired": bool(getattr(model, "demoted", False)),
-        "roofline": {"bound": "mfma", "kernel": pinfo["kernel"], "achieved": achieved, "peak": pinfo["peak"],
+        "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": pinfo["peak"],
                      "unit": "TFLOP/s", "frac": achieved / pinfo["peak"], "avg_launch_ms": avg_ms,
                      "launches": int(k_launches.value), "mfma_per_fp32_product": pinfo["mfma_per_product"]},
     }
-    if name == "h1":
-        pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-        if proposals == S_PROPOSALS and os.path.exists(pmc):
-            with open(pmc) as f:
-                t = json.load(f).get("netblock_h1_kernel")
-            if t:
-                rec["roofline"]["traffic"] = t["traffic_bytes_per_launch_corrected"]
-                rec["roofline"]["traffic_source"] = "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    if proposals == S_PROPOSALS:
+        rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = committed_traffic(kernel, f"--path {name}")
     if name == "h1" and proposals == S_PROPOSALS and not rec["range_guard_fired"]:
         rec["roofline"]["attention_block"] = attention_block(model, device, proposals, avg_ms, "h1")
         rec["measured_deviation"] = ("un-calibrated full-size weights vs the reference's vectors: 1.6e-3 (coordinates), 2.0e-4 "
@@ -488,6 +538,10 @@ def main():
     ap.add_argument("--sync-every", type=int, default=8,
                     help="MH iterations queued per host read-back of the accept results (sample_with_model's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chains", type=int, default=1,
+                    help="chains per GPU evaluated in lock-step (SURVEY 8f-1): the launch's rows (--proposals) are shared, "
+                         "proposals // chains per chain and iteration.  Default 1 = the BASELINE configuration; a line of its own "
+                         "otherwise (no alternative paths, no CPU baseline)")
     ap.add_argument("--path", choices=sorted(PATHS), default="h3",
                     help="flow execution path: split-fp16 fused kernel (default, the headline), exact-f32 fused kernel, or the "
                          "opt-in single-MFMA fast mode h1 (not a parity path)")
@@ -518,7 +572,10 @@ def main():
     lib = _lib.load()
 
     pinfo = PATHS[args.path]
-    chain, model = build_chain(device, distributed.chain_seed(args.seed, rank), args.proposals, pinfo["path"], args.config)
+    if args.chains < 1 or args.chains > args.proposals:
+        ap.error("--chains: 1 .. --proposals")
+    rows = (args.proposals // args.chains) * args.chains   # rows per flow launch
+    chain, model = build_chain(device, distributed.chain_seed(args.seed, rank), args.proposals, pinfo["path"], args.config, args.chains)
     with torch.no_grad():
         for _ in range(args.warmup):
             chain.step_deferred()
@@ -554,23 +611,13 @@ def main():
     if rank == 0:
         launches = max(int(k_launches.value), 1)
         avg_ms = k_ms.value / launches
-        flop_per_launch = cfg["flop_sample_pass"] * args.proposals / N_COUPLING
+        flop_per_launch = cfg["flop_sample_pass"] * rows / N_COUPLING
         # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied), summarised in profiles/
-        traffic, traffic_src = None, None
-        family = {"h3": "netblock_h3", "h1": "netblock_h1"}.get(args.path)
-        key = "netblock_kernel" if family is None else family + {"ad": "_kernel", "4aa": "_n4_kernel", "4aa-nnqq": "_wide_kernel", "dense": "_dense_kernel"}[args.config]
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest committed PMC summary
-            pmc = os.path.join(ROOT, "profiles", name)
-            if args.proposals != cfg["S"] or traffic is not None or not os.path.exists(pmc):
-                continue
-            with open(pmc) as f:
-                rec = json.load(f).get(key)
-                if rec and args.path == "h3" and rec["kernel"].rstrip(")").endswith("true, true>(tw::H3Params"):
-                    rec = None  # (a summary written before the fast mode had its own key)
-            if rec:
-                traffic = rec["traffic_bytes_per_launch_corrected"]
-                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        # ... of this kernel instantiation under this configuration - null when no committed summary measured exactly that
+        kernel_live = live_kernel(lib)
+        bench_args = " ".join(([] if args.config == "ad" else [f"--config {args.config}"]) + ([] if args.path == "h3" else [f"--path {args.path}"]))
+        traffic, traffic_src = committed_traffic(kernel_live, bench_args) if (args.proposals == cfg["S"] and args.chains == 1) else (None, None)
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "MH-accepted samples/sec (whole node), alanine-dipeptide kernel_transformer_nvp" if args.config == "ad" else
@@ -590,8 +637,9 @@ def main():
             "config": {
                 "workload": cfg["workload"],
                 "bench_config": args.config,
-                "proposals_per_step": args.proposals,
-                "chains_per_gpu": 1,
+                "proposals_per_step": rows,
+                "chains_per_gpu": args.chains,
+                "proposals_per_chain_and_step": rows // args.chains,
                 "weights": "name-seeded synthetic N(0,1)/sqrt(fan_in); identity flow (last out_mlp layer of every coupling net "
                            "zeroed, SURVEY 8d's idea) with coordinate prior log-scale %g and velocity prior log-scale 0 (NOT "
                            "8d's -5 / -5: tuned so acceptance is non-degenerate against the stiff bonded terms)" % cfg["calibration"]["coords_log_scale"],
@@ -605,12 +653,9 @@ def main():
             "per_rank_ms": [t / args.steps * 1e3 for t in getattr(end_timed_region, "per_rank_seconds", [elapsed])],
             "roofline": {
                 "bound": "mfma",
-                "kernel": (cfg.get("kernel", pinfo["kernel"]) if args.path == "h3" else
-                           "tw::netblock_h3_kernel<4, true, false, false, false, false, true> (64-token waves, single-MFMA sections)" if args.config == "4aa"
-                           else pinfo["kernel"].replace("false, false, false, true, true>", "false, true, false, false, true>") if args.config == "4aa-nnqq"
-                           else pinfo["kernel"].replace("true, false, false, false, true, true>", "true, true, false, false, false, true> (MLP "
-                                                        "sections single-MFMA, the softmax attention block split-fp16)") if args.config == "dense"
-                           else pinfo["kernel"]) + " (both coupling nets of one coupling layer, all proposals)",
+                # the instantiation the timed region's last flow pass launched, as the library reports it (tw_last_netblock_kernel:
+                # <NT, ASM, DENSE, WIDE, RFF, ENC, H1, NG6>) - the layout is chosen per launch
+                "kernel": kernel_live + " (" + cfg.get("kernel_note", "both coupling nets of one coupling layer, all proposals") + ")",
                 "achieved": achieved,
                 "peak": pinfo["peak"],
                 "unit": "TFLOP/s",
@@ -633,10 +678,10 @@ def main():
         if out["range_guard_fired"]:
             raise RuntimeError("bench.py: the fp16 range guard demoted the model to the exact-f32 kernels during the run; "
                                "the line would mislabel the measured path.  Re-run with --path f32")
-        if args.config != "ad":
+        if args.config != "ad" or args.chains > 1:
             # one line per extra configuration: roofline from the live HIP events; the headline's companions (attention block,
-            # other paths, CPU baseline) belong to --config ad
-            out["roofline"]["algorithmic_tflop_per_iteration"] = 2 * cfg["flop_sample_pass"] * args.proposals / 1e12
+            # other paths, CPU baseline) belong to --config ad with one chain
+            out["roofline"]["algorithmic_tflop_per_iteration"] = 2 * cfg["flop_sample_pass"] * rows / 1e12
             print(json.dumps(out), flush=True)
             if world > 1:
                 torch.distributed.destroy_process_group()

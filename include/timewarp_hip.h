@@ -337,6 +337,12 @@ int tw_profile_end(double* total_ms, int64_t* launches);
  * clock = cycles / ms, sustained rate = workgroups * 4 * 36 * iters * 16384 FLOP / ms.  Synchronous; launches on `stream`. */
 int tw_probe_mfma_clock(int32_t workgroups, int32_t iters, int64_t* cycles, double* ms, void* stream);
 
+/* Measurement hook (bench.py roofline.kernel, ABI 7): the template instantiation of the fused net-block kernel the calling
+ * thread launched last, spelled as rocprofv3 prints it ("tw::netblock_h3_kernel<3, true, false, false, false, true, false,
+ * false>": NT, ASM, DENSE, WIDE, RFF, ENC, H1, NG6) - which layout and build a flow call took is decided per launch (molecule
+ * size, row count, tw_debug_set_flags).  A static string ("" before the first launch); never NULL. */
+const char* tw_last_netblock_kernel(void);
+
 /* Safety net for TW_PATH_FUSED_H3 (no counterpart in the reference): *out_flag = 1 if, since the last reset, any
  * coupling net on the current device returned a non-finite scale or shift.  The split-fp16 kernel holds its operands in
  * fp16 (|value| < 65504); a checkpoint whose activations leave that range produces inf/NaN there, which the exact-f32

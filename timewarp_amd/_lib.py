@@ -128,6 +128,7 @@ SIGNATURES = {
     "tw_mh_iteration": (C.c_int, [_DESC, _P, _P, _I32, C.POINTER(ForceField), C.POINTER(MHOptions), _P, _P, _I32, _P, _P, _P, _P,
                                   _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P]),
     "tw_flow_nonfinite": (C.c_int, [_I32, C.POINTER(C.c_int32)]),
+    "tw_last_netblock_kernel": (C.c_char_p, []),
     "tw_debug_set_flags": (C.c_int, [C.c_int]),
     "tw_profile_begin": (C.c_int, []),
     "tw_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -373,6 +373,8 @@ int tw_chirality_changed(const float* coords, const int32_t* centres, const floa
                           (hipStream_t)stream);
 }
 
+const char* tw_last_netblock_kernel(void) { return last_netblock_kernel(); }
+
 int tw_flow_nonfinite(int32_t reset, int32_t* out_flag) {
   TW_REQUIRE(out_flag != nullptr, "NULL pointer argument");
   int v = 0;

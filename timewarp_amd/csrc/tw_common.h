@@ -270,6 +270,9 @@ extern std::atomic<int> g_debug_flags;
 #endif
 int nonfinite_flag(int reset, int* out);
 int profile_mark(hipStream_t s, bool begin);
+// the net-block kernel instantiation the calling thread launched last (a string literal; tw_last_netblock_kernel)
+void note_netblock_kernel(const char* name);
+const char* last_netblock_kernel();
 int profile_begin();
 int profile_end(double* total_ms, int64_t* launches);
 

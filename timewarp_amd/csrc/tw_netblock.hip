@@ -531,6 +531,10 @@ int profile_begin() {
   return TW_OK;
 }
 
+static thread_local const char* g_last_netblock = "";
+void note_netblock_kernel(const char* name) { g_last_netblock = name; }
+const char* last_netblock_kernel() { return g_last_netblock; }
+
 // begin=true records the start event of a new launch, begin=false the stop event of the last one
 int profile_mark(hipStream_t s, bool begin) {
   if (!g_profile) return TW_OK;
@@ -665,9 +669,11 @@ static int launch_netblock(const FlowArgs& a, const RawLayout& L, const FusedGeo
   static LdsLimit lim3, lim4;
   if (g.nt == 3) {
     if ((prc = lim3.ensure((const void*)netblock_kernel<3>, (int)shm))) return prc;
+    note_netblock_kernel("tw::netblock_kernel<3>");
     hipLaunchKernelGGL(netblock_kernel<3>, dim3(grid), dim3(256), shm, a.stream, p);
   } else {
     if ((prc = lim4.ensure((const void*)netblock_kernel<4>, (int)shm))) return prc;
+    note_netblock_kernel("tw::netblock_kernel<4>");
     hipLaunchKernelGGL(netblock_kernel<4>, dim3(grid), dim3(256), shm, a.stream, p);
   }
   TW_LAUNCH_CHECK();

@@ -541,15 +541,19 @@ static int dense_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& 
   const bool rff = dense_in_tiles(d) == 11;
   if (g.nt == 3 && !rff) {
     if ((prc = lim3.ensure((const void*)netblock_dense_kernel<3>, (int)shm))) return prc;
+    note_netblock_kernel("tw::netblock_dense_kernel<3, 3>");
     hipLaunchKernelGGL(netblock_dense_kernel<3>, dim3(grid), dim3(256), shm, a.stream, p);
   } else if (!rff) {
     if ((prc = lim4.ensure((const void*)netblock_dense_kernel<4>, (int)shm))) return prc;
+    note_netblock_kernel("tw::netblock_dense_kernel<4, 3>");
     hipLaunchKernelGGL(netblock_dense_kernel<4>, dim3(grid), dim3(256), shm, a.stream, p);
   } else if (g.nt == 3) {
     if ((prc = lim3r.ensure((const void*)netblock_dense_kernel<3, 11>, (int)shm))) return prc;
+    note_netblock_kernel("tw::netblock_dense_kernel<3, 11>");
     hipLaunchKernelGGL((netblock_dense_kernel<3, 11>), dim3(grid), dim3(256), shm, a.stream, p);
   } else {
     if ((prc = lim4r.ensure((const void*)netblock_dense_kernel<4, 11>, (int)shm))) return prc;
+    note_netblock_kernel("tw::netblock_dense_kernel<4, 11>");
     hipLaunchKernelGGL((netblock_dense_kernel<4, 11>), dim3(grid), dim3(256), shm, a.stream, p);
   }
   TW_LAUNCH_CHECK();

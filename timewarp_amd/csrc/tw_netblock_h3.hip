@@ -2683,131 +2683,75 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   p.prev = prev;
   const int wgs_per_net = wide ? p.nblocks : (p.nblocks + 3) / 4;  // wide: one block per workgroup
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
-  static LdsLimit lim_asm, lim_cpp, lim_dense, lim_dense_cpp, lim_wide;
   int prc;
-  if ((prc = lim_asm.ensure((const void*)netblock_h3_kernel<H3_NT, true>, (int)H3_LDS_BYTES))) return prc;
-  if ((prc = lim_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false>, (int)H3_LDS_BYTES))) return prc;
-  if ((prc = lim_dense.ensure((const void*)netblock_h3_kernel<H3_NT, true, true>, (int)H3D_LDS_BYTES))) return prc;
-  if ((prc = lim_dense_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false, true>, (int)H3D_LDS_BYTES))) return prc;
-  if ((prc = lim_wide.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
   if ((prc = profile_mark(a.stream, true))) return prc;
+  // One launch form for every instantiation: raise the kernel's dynamic-LDS limit once per device, note its name for
+  // tw_last_netblock_kernel (bench.py reports - and looks its PMC traffic up by - the instantiation that really ran), launch.
+  // Template arguments: <NT, ASM, DENSE, WIDE, RFF, ENC, H1, NG6>, all eight spelled out so that the name is rocprofv3's.
+#define H3_STR2(...) #__VA_ARGS__
+#define H3_STR(...) H3_STR2(__VA_ARGS__)
+#define H3_LAUNCH(LDS, ...)                                                                                        \
+  do {                                                                                                             \
+    static LdsLimit lim;                                                                                           \
+    if ((prc = lim.ensure((const void*)netblock_h3_kernel<__VA_ARGS__>, (int)(LDS)))) return prc;                  \
+    note_netblock_kernel("tw::netblock_h3_kernel<" H3_STR(__VA_ARGS__) ">");                                       \
+    hipLaunchKernelGGL((netblock_h3_kernel<__VA_ARGS__>), dim3(grid), dim3(256), (LDS), a.stream, p);              \
+  } while (0)
   // the encoder-stack statements (no compiled glue, no scratch) unless activations / section stamps between the sections are
-  // asked for (bit 12: per-section build, bit 13: encoder stack anyway)
+  // asked for (bit 12: per-section build, bit 13: encoder stack anyway; bit 3: the compiled-C++ statement of the kernel)
   const bool per_section = ((dump != nullptr || (g_debug_flags & (4 | 16 | 4096))) && !(g_debug_flags & 8192)) || d.n_layers < 1;
+  const bool cpp = (g_debug_flags & 8) != 0;
   if (!wide && fg.nt == H3N4_NT) {
     TW_REQUIRE(d.variant == 0, "64-token waves: kernel attention");
-    static LdsLimit lim_n4, lim_n4_cpp, lim_n4_h1;
-    if ((prc = lim_n4.ensure((const void*)netblock_h3_kernel<H3N4_NT, true>, (int)H3N4_LDS_BYTES))) return prc;
-    if ((prc = lim_n4_cpp.ensure((const void*)netblock_h3_kernel<H3N4_NT, false>, (int)H3N4_LDS_BYTES))) return prc;
-    if ((prc = lim_n4_h1.ensure((const void*)netblock_h3_kernel<H3N4_NT, true, false, false, false, false, true>, (int)H3N4_LDS_BYTES)))
-      return prc;
-    if (h1 && per_section)
-      hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true, false, false, false, false, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES,
-                         a.stream, p);
-    else if (h1) {
-      static LdsLimit lim_n4_h1e;
-      if ((prc = lim_n4_h1e.ensure((const void*)netblock_h3_kernel<H3N4_NT, true, false, false, false, true, true>, (int)H3N4_LDS_BYTES)))
-        return prc;
-      hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true, false, false, false, true, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES,
-                         a.stream, p);
-    } else if (g_debug_flags & 8)
-      hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, false>), dim3(grid), dim3(256), H3N4_LDS_BYTES, a.stream, p);
-    else if (per_section)
-      hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES, a.stream, p);
-    else {
-      static LdsLimit lim_n4_enc;
-      if ((prc = lim_n4_enc.ensure((const void*)netblock_h3_kernel<H3N4_NT, true, false, false, false, true>, (int)H3N4_LDS_BYTES)))
-        return prc;
-      hipLaunchKernelGGL((netblock_h3_kernel<H3N4_NT, true, false, false, false, true>), dim3(grid), dim3(256), H3N4_LDS_BYTES,
-                         a.stream, p);
-    }
+    if (h1 && per_section) H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, false, false, false, true, false);
+    else if (h1) H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, false, false, true, true, false);
+    else if (cpp) H3_LAUNCH(H3N4_LDS_BYTES, 4, false, false, false, false, false, false, false);
+    else if (per_section) H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, false, false, false, false, false);
+    else H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, false, false, true, false, false);
   } else if (h1) {
-    // single-MFMA build: the encoder-stack statement (section stamps compiled in; no activation dumps), or the wide layout's
-    // per-section build
+    // single-MFMA build: the encoder-stack statements (section stamps compiled in; no activation dumps), or the per-section builds
     TW_REQUIRE(h1_supported(d, a.n_atoms) && d.n_layers >= 1, "single-MFMA path: unsupported configuration");
-    if (d.variant == 1 && per_section) {
-      static LdsLimit lim_h1d;
-      if ((prc = lim_h1d.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, false, false, true>, (int)H3D_LDS_BYTES))) return prc;
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, false, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
-    } else if (d.variant == 1) {
-      static LdsLimit lim_h1de;
-      if ((prc = lim_h1de.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, false, true, true>, (int)H3D_ENC_LDS_BYTES))) return prc;
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, false, true, true>), dim3(grid), dim3(256), H3D_ENC_LDS_BYTES, a.stream, p);
-    } else if (wide && per_section) {
-      static LdsLimit lim_h1w, lim_h1w6;
-      if ((prc = lim_h1w.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, true>, (int)H3W_LDS_BYTES))) return prc;
-      if ((prc = lim_h1w6.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, true, true>, (int)H3W_LDS_BYTES))) return prc;
-      if (wd.ng == H3W_NG6)
-        hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, true, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
-      else
-        hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+    if (d.variant == 1) {
+      if (per_section) H3_LAUNCH(H3D_LDS_BYTES, 3, true, true, false, false, false, true, false);
+      else H3_LAUNCH(H3D_ENC_LDS_BYTES, 3, true, true, false, false, true, true, false);
     } else if (wide) {
       // r05: the wide layout's encoder stack as one statement (tools/gen_h3_enc_asm.py --wide [--ng=3|6] --h1)
-      static LdsLimit lim_h1we, lim_h1we6;
-      if ((prc = lim_h1we.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, true, true>, (int)H3W_LDS_BYTES))) return prc;
-      if ((prc = lim_h1we6.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, true, true, true>, (int)H3W_LDS_BYTES))) return prc;
-      if (wd.ng == H3W_NG6)
-        hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, true, true, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
-      else
-        hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, true, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+      if (per_section && wd.ng == H3W_NG6) H3_LAUNCH(H3W_LDS_BYTES, 3, true, false, true, false, false, true, true);
+      else if (per_section) H3_LAUNCH(H3W_LDS_BYTES, 3, true, false, true, false, false, true, false);
+      else if (wd.ng == H3W_NG6) H3_LAUNCH(H3W_LDS_BYTES, 3, true, false, true, false, true, true, true);
+      else H3_LAUNCH(H3W_LDS_BYTES, 3, true, false, true, false, true, true, false);
     } else {
       TW_REQUIRE(dump == nullptr || (g_debug_flags & 16), "single-MFMA path: no activation dumps (section stamps only)");
-      static LdsLimit lim_h1;
-      if ((prc = lim_h1.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, false, false, true, true>, (int)H3_LDS_BYTES))) return prc;
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, false, false, true, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
+      H3_LAUNCH(H3_LDS_BYTES, 3, true, false, false, false, true, true, false);
     }
-  } else if (wide && per_section) {
-    static LdsLimit lim_wide6;
-    if ((prc = lim_wide6.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, false, false, true>, (int)H3W_LDS_BYTES))) return prc;
-    if (wd.ng == H3W_NG6)
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, false, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
-    else
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
   } else if (wide) {
     // r05: the wide layout's encoder stack as one statement (tools/gen_h3_enc_asm.py --wide [--ng=3|6]): no compiled glue, no scratch
-    static LdsLimit lim_wide_enc, lim_wide_enc6;
-    if ((prc = lim_wide_enc.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
-    if ((prc = lim_wide_enc6.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, true, false, true, false, true>, (int)H3W_LDS_BYTES))) return prc;
-    if (wd.ng == H3W_NG6)
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
-    else
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, true, false, true>), dim3(grid), dim3(256), H3W_LDS_BYTES, a.stream, p);
+    if (per_section && wd.ng == H3W_NG6) H3_LAUNCH(H3W_LDS_BYTES, 3, true, false, true, false, false, false, true);
+    else if (per_section) H3_LAUNCH(H3W_LDS_BYTES, 3, true, false, true, false, false, false, false);
+    else if (wd.ng == H3W_NG6) H3_LAUNCH(H3W_LDS_BYTES, 3, true, false, true, false, true, false, true);
+    else H3_LAUNCH(H3W_LDS_BYTES, 3, true, false, true, false, true, false, false);
   } else if (d.variant == 1 && d.d_rff > 0) {
-    static LdsLimit lim_rff, lim_rff_cpp;
-    if ((prc = lim_rff.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, true>, (int)H3D_LDS_BYTES))) return prc;
-    if ((prc = lim_rff_cpp.ensure((const void*)netblock_h3_kernel<H3_NT, false, true, false, true>, (int)H3D_LDS_BYTES))) return prc;
-    if (g_debug_flags & 8)
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false, true, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
-    else if (per_section)
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
-    else {
-      // r05: the dense model's encoder stack as one statement (tools/gen_h3_enc_asm.py --dense); the in-MLP of the position
-      // features stays compiled C++
-      static LdsLimit lim_rff_enc;
-      if ((prc = lim_rff_enc.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, true, true>, (int)H3D_ENC_LDS_BYTES))) return prc;
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, true, true>), dim3(grid), dim3(256), H3D_ENC_LDS_BYTES, a.stream, p);
-    }
+    // the dense model's encoder stack as one statement (tools/gen_h3_enc_asm.py --dense); the in-MLP of the position features
+    // stays compiled C++
+    if (cpp) H3_LAUNCH(H3D_LDS_BYTES, 3, false, true, false, true, false, false, false);
+    else if (per_section) H3_LAUNCH(H3D_LDS_BYTES, 3, true, true, false, true, false, false, false);
+    else H3_LAUNCH(H3D_ENC_LDS_BYTES, 3, true, true, false, true, true, false, false);
   } else if (d.variant == 1) {
-    if (g_debug_flags & 8)
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
-    else if (per_section)
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true>), dim3(grid), dim3(256), H3D_LDS_BYTES, a.stream, p);
-    else {
-      static LdsLimit lim_dense_enc;
-      if ((prc = lim_dense_enc.ensure((const void*)netblock_h3_kernel<H3_NT, true, true, false, false, true>, (int)H3D_ENC_LDS_BYTES))) return prc;
-      hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, true, false, false, true>), dim3(grid), dim3(256), H3D_ENC_LDS_BYTES, a.stream, p);
-    }
-  } else if (g_debug_flags & 8)
-    hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, false>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
-  else if (per_section)
+    if (cpp) H3_LAUNCH(H3D_LDS_BYTES, 3, false, true, false, false, false, false, false);
+    else if (per_section) H3_LAUNCH(H3D_LDS_BYTES, 3, true, true, false, false, false, false, false);
+    else H3_LAUNCH(H3D_ENC_LDS_BYTES, 3, true, true, false, false, true, false, false);
+  } else if (cpp) {
+    H3_LAUNCH(H3_LDS_BYTES, 3, false, false, false, false, false, false, false);
+  } else if (per_section) {
     // activation dumps / section stamps live between the sections; bit 12 (4096): A/B switch for the encoder-stack build;
     // bit 13 (8192): the encoder-stack build even with a dump buffer (only the stamps / dumps outside the stack are written)
-    hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
-  else {
-    static LdsLimit lim_enc;
-    if ((prc = lim_enc.ensure((const void*)netblock_h3_kernel<H3_NT, true, false, false, false, true>, (int)H3_LDS_BYTES))) return prc;
-    hipLaunchKernelGGL((netblock_h3_kernel<H3_NT, true, false, false, false, true>), dim3(grid), dim3(256), H3_LDS_BYTES, a.stream, p);
+    H3_LAUNCH(H3_LDS_BYTES, 3, true, false, false, false, false, false, false);
+  } else {
+    H3_LAUNCH(H3_LDS_BYTES, 3, true, false, false, false, true, false, false);
   }
+#undef H3_LAUNCH
+#undef H3_STR
+#undef H3_STR2
   TW_LAUNCH_CHECK();
   if ((prc = profile_mark(a.stream, false))) return prc;
   return TW_OK;

@@ -32,6 +32,16 @@ import sys
 #   v96..v127 acc[t][jt];  v128..v191 xm[buf][jt] = {h 4, l 4};  v192..v223 weight tile slots;  v224..v231 temporaries;
 #   v232.. addresses;  a0..a127 y[ot][jt]
 NT4 = "--nt=4" in sys.argv
+# --nt=4 --pair (embedded in the encoder-stack statement only, gen_h3_enc_asm.py): ONE molecule of 97-128 atoms per PAIR of 64-token
+# waves, two molecules per workgroup (r04 ran these on the wide layout's 48-token waves: one molecule on three of four waves,
+# 52-67 % of the token slots).  A wave's queries are its own 64 tokens, its keys the molecule's 128: four K = 32 groups - the two
+# of its own X^T images and the two of its partner's, which are the lane-order images the 64-token statement already writes
+# (conflict-free as they are, no shared row-major tile, no padding: 4 x 32 KiB of images + the three-slot ring + the side block =
+# 158 KiB).  Per chain twelve same-shape MFMAs; the mixing of a k-step runs in four phases (feature tile t, key half) over the two
+# 16-register operand buffers, the second half's operands read while the other tile's phase runs.  Score fragments: groups 0, 1
+# in v0..v63 as before, groups 2, 3 in a128..a191 (MFMA B operands may be AGPRs) - 8 KiB per (head, query tile).
+PAIR = "--pair" in sys.argv
+assert not PAIR or NT4
 NT = 4 if NT4 else 3
 RING = 3 if NT4 else 5
 STAGE, TILES = 9216, 8192
@@ -64,6 +74,11 @@ if NT4:
     S_K3 = 98        # 3 * SF_BYTES; s82:83 = NT * SF_BYTES (fragment stride per head) - not s100:101, which hipcc reserves
     S_SFHEAD = 82
     N_V, N_A, N_S = 246, 128, 100
+    if PAIR:
+        SF_BYTES = 8192
+        PAIR_HALF = 32768           # bytes from a wave's X^T images to its partner's (csrc H3N4_WAVE_LDS)
+        SF_AGPR = 128               # groups 2, 3
+        N_A = 192
 EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(",")))
 # --mode=windowed: waves that hold two or more molecules.  The score matrix is block diagonal, so query tile 0 only has
 # keys in [0, 32) and query tile 2 only in [16, 48): each takes ONE K=32 mixing MFMA per term (tile 2 with the
@@ -94,10 +109,11 @@ def ar(base, n=4):
     return f"a[{base}:{base + n - 1}]"
 
 
-def mfma32(d, a, b, zero=False, dreg="v", areg="v"):
+def mfma32(d, a, b, zero=False, dreg="v", areg="v", breg="v"):
     dd = vr(d) if dreg == "v" else ar(d)
     aa = vr(a) if areg == "v" else ar(a)
-    return f"v_mfma_f32_16x16x32_f16 {dd}, {aa}, {vr(b)}, {'0' if zero else dd}"
+    bb = vr(b) if breg == "v" else ar(b)
+    return f"v_mfma_f32_16x16x32_f16 {dd}, {aa}, {bb}, {'0' if zero else dd}"
 
 
 def mfma16(d, a, b, zero=False, areg="v"):
@@ -115,8 +131,10 @@ def xt_operand(ks, t, name):
     return XA(t, name), "v"
 
 
-def xt_reads(ks, t, buf):
+def xt_reads(ks, t, buf, half=0):
     off = 2 * XT_IMG * (2 * ks + t)
+    if PAIR:
+        off += PAIR_HALF * half     # V_XT0 is the molecule's first wave's block: half 1 = the second wave's images
     if NT4:   # four 16-byte operands per (feature tile, part pair): [T0 | T1], [T2 | T3], hi and lo
         r = [f"ds_read_b128 {vr(XA(buf, 'a0h'))}, v{V_XT0} offset:{off}",
              f"ds_read_b128 {vr(XA(buf, 'a1h'))}, v{V_XT0} offset:{off + 1024}",
@@ -138,6 +156,8 @@ def mixing_mfmas(ks):
     out = []
     first = True
     terms = (("a0h", "s0h", "a1h", "s1h"), ("a0h", "s0l", "a1h", "s1l"), ("a0l", "s0h", "a1l", "s1h"))
+    if PAIR:
+        raise AssertionError("pair mode: mixing_part() issues the four phases itself")
     if NT4:
         # eight chains acc[t][jt] of six K = 32 MFMAs, issued round-robin: two MFMAs of a chain are eight apart
         for a32, b32, a16, b16 in (terms[:1] if H1 else terms):
@@ -173,13 +193,40 @@ def xt_reads_step(ks):
     return [] if "noxt" in EXPERIMENT or XT_AGPR is not None else xt_reads(ks, 0, 0) + xt_reads(ks, 1, 1)
 
 
+def pair_phase(t, half):
+    """Pair mode: the 24 (H1: 8) MFMAs of feature tile t against key groups 2 half, 2 half + 1 - four chains acc[t][jt], issued
+    round-robin (two MFMAs of a chain are four apart: 64 issue cycles against ~40 of latency)."""
+    out = []
+    terms = (("a0h", "s0h", "a1h", "s1h"), ("a0h", "s0l", "a1h", "s1l"), ("a0l", "s0h", "a1l", "s1h"))
+    first = half == 0
+    for a32, b32, a16, b16 in (terms[:1] if H1 else terms):
+        for a, b in ((a32, b32), (a16, b16)):
+            for jt in range(NT):
+                breg, base = ("v", 0) if half == 0 else ("a", SF_AGPR)
+                out.append(mfma32(ACC(t, jt), XA(t, a), base + SF(jt, b), zero=first, breg=breg))
+            first = False
+    return out
+
+
 def mixing_part(ks, reads_issued):
     """The 36 mixing MFMAs of k-step ks; the eight X^T operand reads are either issued here or were woven into
     the previous GEMM stage."""
     out = [] if reads_issued else xt_reads_step(ks)
     out.append("s_waitcnt lgkmcnt(0)")
-    if "nomix" not in EXPERIMENT:
-        out += mixing_mfmas(ks)
+    if "nomix" in EXPERIMENT:
+        return out
+    if PAIR:
+        # four phases over the two operand buffers (buffer t = feature tile t): the second key half of a tile is read into its
+        # buffer once every MFMA of that tile's first half has been issued AND the other tile's phase has started - a full
+        # phase (>= 130 issue cycles) lies between the last reader's issue and the overwrite, another before the first use
+        out += pair_phase(0, 0)
+        out += weave(pair_phase(1, 0), [], xt_reads(ks, 0, 0, half=1), misc_per=1, skip=2)
+        out.append("s_waitcnt lgkmcnt(0)")
+        out += weave(pair_phase(0, 1), [], xt_reads(ks, 1, 1, half=1), misc_per=1, skip=2)
+        out.append("s_waitcnt lgkmcnt(0)")
+        out += pair_phase(1, 1)
+        return out
+    out += mixing_mfmas(ks)
     return out
 
 
@@ -318,6 +365,11 @@ def sf_loads():
                 if H1 and name.endswith("l"):
                     continue
                 out += [f"global_load_dwordx4 {vr(SF(jt, name))}, {vr(a16, 2)}, off" + (f" offset:{1024 * i}" if i else "")]
+            if PAIR:   # key groups 2, 3 (the partner wave's half of the molecule) straight into AGPRs
+                for i, name in enumerate(("s0h", "s0l", "s1h", "s1l")):
+                    if H1 and name.endswith("l"):
+                        continue
+                    out += [f"global_load_dwordx4 {ar(SF_AGPR + SF(jt, name))}, {vr(a16, 2)}, off offset:{4096 + 1024 * i}"]
         out += [f"v_lshl_add_u64 {vr(V_SF16, 2)}, {vr(V_SF16, 2)}, 0, s[{S_SFHEAD}:{S_SFHEAD + 1}]"]
         return out
     for jt, tail in sf_tiles():
@@ -346,6 +398,10 @@ def generate():
     A(f"v_lshlrev_b32 v{V_T}, 4, v{V_LANE16}")
     A(f"v_lshlrev_b32 v{V_T + 1}, 3, v{V_LANE16}")
     A(f"v_add_u32 v{V_XT0}, %[priv], v{V_T}")
+    if PAIR:   # the molecule's first wave's block: an odd wave steps one block back
+        A(f"s_and_b32 s{S_OFF}, %[wave], 1")
+        A(f"s_mul_i32 s{S_OFF}, s{S_OFF}, {PAIR_HALF}")
+        A(f"v_subrev_u32 v{V_XT0}, s{S_OFF}, v{V_XT0}")
     if not NT4:   # (64-token build: every operand is 16 bytes per lane)
         A(f"v_add_u32 v{V_XT1}, %[priv], v{V_T + 1}")
     # score-fragment lane addresses: sf + 16 lane (128-bit loads), sf + 8 lane (64-bit loads)
@@ -398,7 +454,7 @@ def generate():
                 # last use of this head's score fragments is issued: fetch the next head's.  Also after the last
                 # head (the buffer has one head of slack): the s_waitcnt vmcnt counts below assume these loads.
                 L += sf_loads()
-            n_sf = (2 if H1 else 4) * NT if NT4 else sum((3 if tail else 2) - (1 if H1 else 0) for _, tail in sf_tiles())
+            n_sf = (2 if H1 else 4) * NT * (2 if PAIR else 1) if NT4 else sum((3 if tail else 2) - (1 if H1 else 0) for _, tail in sf_tiles())
             base_vm = 2 * (RING - 2)          # stages s + 2 .. s + RING - 1 may stay in flight, two DMAs each
             vm = n_sf + base_vm if ks == 2 else base_vm   # the fragment loads (full: 9, windowed: 7) sit in the same queue behind the stage DMAs
         else:
@@ -462,6 +518,7 @@ def main():
     base = os.path.join(out_dir, ("tw_h1n4_attn_asm.inc" if H1 else "tw_h3n4_attn_asm.inc") if NT4 else
                         "tw_h3_attnw_asm.inc" if WINDOWED else "tw_h3_attn_asm.inc")
     assert not (NT4 and WINDOWED) and (NT4 or not H1 or FUSED)
+    assert not PAIR, "--pair exists inside the encoder-stack statement only (tools/gen_h3_enc_asm.py --nt=4 --pair)"
     out = [f"// GENERATED by tools/gen_h3_attn_asm.py{' --mode=windowed' if WINDOWED else ''}{' --nt=4' if NT4 else ''}{' --h1' if H1 else ''} - do not edit.  Body of the attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]
     open(base, "w").write("\n".join(out) + "\n")

@@ -73,6 +73,11 @@ WINDOWED = "--mode=windowed" in sys.argv
 # off): bench.py reads the attention block's cycles from them.
 H1 = "--h1" in sys.argv
 NT4 = "--nt=4" in sys.argv      # 64-token waves (the embedded generators read the same flag)
+# --nt=4 --pair: one molecule of 97-128 atoms per pair of 64-token waves (gen_h3_attn_asm.py --pair: the attention block mixes
+# against both waves' X^T images).  The glue is the 64-token statement's unchanged - every wave still writes its own images
+# into its own block, and the barrier at the top of a layer (layer_top) stands between those writes and the partner's reads.
+PAIR = "--pair" in sys.argv
+assert not PAIR or NT4
 # --wide [--ng=3|6]: the wide layout (molecules packed over the workgroup's 192 token slots, 25-192 atoms): the attention block
 # is gen_h3_attn_wide_asm.py's, the transposed copy of x the workgroup's SHARED tile in the LDS
 WIDE = "--wide" in sys.argv
@@ -82,8 +87,10 @@ WIDE = "--wide" in sys.argv
 DENSE = "--dense" in sys.argv
 STATELESS = NT4 or WIDE or DENSE  # the glue keeps nothing in VGPRs across the embedded blocks; pointers in SGPRs
 EXPERIMENT = set(filter(None, os.environ.get("H3_ENC_EXPERIMENT", "").split(",")))
-if H1:
-    EXPERIMENT.add("stamps")
+# The section stamps are compiled into every statement (r05; r04: the fast-mode ones only): five scalar compare-and-branch
+# pairs per layer when off.  bench.py reads the attention block's share of a launch from the PRODUCT build that way
+# (tw_debug_set_flags 16 | 8192) instead of from the per-section build.
+EXPERIMENT.add("stamps")
 attn = load("gen_h3_dense_attn_asm" if DENSE else ("gen_h3_attn_wide_asm" if WIDE else "gen_h3_attn_asm"))
 ffn = load("gen_h3_ffn_asm")
 ffn.H1 = H1
@@ -815,9 +822,9 @@ def main():
         if a.startswith("--out-dir="):
             out_dir = a.split("=", 1)[1]
     ng = getattr(attn, "NG", 5)
-    mode = (" --mode=windowed" if WINDOWED else "") + (" --nt=4" if NT4 else "") + \
+    mode = (" --mode=windowed" if WINDOWED else "") + (" --nt=4" if NT4 else "") + (" --pair" if PAIR else "") + \
         ((" --wide" + (f" --ng={ng}" if ng != 5 else "")) if WIDE else "") + (" --dense" if DENSE else "") + (" --h1" if H1 else "")
-    fam = ("h1" if H1 else "h3") + ("n4" if NT4 else "") + ((f"w{ng}" if ng != 5 else "w") if WIDE else "") + ("d" if DENSE else "")
+    fam = ("h1" if H1 else "h3") + ("n4" if NT4 else "") + ("p" if PAIR else "") + ((f"w{ng}" if ng != 5 else "w") if WIDE else "") + ("d" if DENSE else "")
     base = os.path.join(out_dir, f"tw_{fam}_encw_asm.inc" if WINDOWED else f"tw_{fam}_enc_asm.inc")
     out = [f"// GENERATED by tools/gen_h3_enc_asm.py{mode} - do not edit.  Body of the encoder-stack asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]

@@ -19,7 +19,7 @@ def counters(d):
     return rows
 
 
-def traffic(d_fetch, d_write, out, merge=None):
+def traffic(d_fetch, d_write, out, merge=None, bench_args=""):
     res = json.load(open(merge)) if merge and os.path.exists(merge) else {}   # add this run's kernels to an earlier summary
     res.update({"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 3 --warmup 1 "
                       "--no-cpu-baseline (one pass per counter: FETCH_SIZE, WRITE_SIZE)",
@@ -46,10 +46,12 @@ def traffic(d_fetch, d_write, out, merge=None):
             key = "netblock_dense_kernel" if "dense" in k else "netblock_kernel"
         f = sum(v["FETCH_SIZE"]) / max(len(v["FETCH_SIZE"]), 1)
         w = sum(v["WRITE_SIZE"]) / max(len(v["WRITE_SIZE"]), 1)
+        # r05: one record per (instantiation family, bench configuration) - bench.py takes a figure only where both match
+        key += f" [{bench_args.strip()}]" if bench_args.strip() else ""
         if key in fresh and res[key]["dispatches"] >= len(v["FETCH_SIZE"]):
             continue  # several instantiations of one kernel family in the run: keep the one the timed region launches
         fresh.add(key)
-        res[key] = {"kernel": k, "dispatches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
+        res[key] = {"kernel": k, "bench_args": bench_args.strip(), "dispatches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                     "traffic_bytes_per_launch_corrected": (2 * f + w) * 1024,
                     "traffic_bytes_per_launch_uncorrected": (f + w) * 1024,
                     "note": "fabric-side L2 requests (Infinity-Cache hits are counted): the 8 XCD L2s each stream one net's "
@@ -94,7 +96,8 @@ def stats(d, out):
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "--traffic":
-        traffic(*sys.argv[2:6])   # optional 4th argument: an earlier summary to merge into
+        # optional 4th argument: an earlier summary to merge into; 5th: the bench.py arguments the passes ran with ("" = headline)
+        traffic(*sys.argv[2:6], **({"bench_args": sys.argv[6]} if len(sys.argv) > 6 else {}))
     elif mode == "--sq":
         sq(sys.argv[2:-1], sys.argv[-1])
     elif mode == "--stats":
