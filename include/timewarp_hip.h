@@ -379,7 +379,11 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *   bit 18 (262144) wide layout, 65 .. 96 atoms: five-group key windows (molecules back to back where that fits) instead of
  *              the 96-slot stride with three-group windows; same results up to the last bits (A/B switch and tests)
  *   bit 19 (524288) wide layout: the transposed tile written with two-byte stores (r03's form) instead of through the matrix
- *              pipe; bit-identical results (A/B switch and tests) */
+ *              pipe; bit-identical results (A/B switch and tests)
+ *   bit 20 (1048576) molecules of 97 .. 128 atoms: never the paired layout (one molecule per pair of 64-token waves, two per
+ *              workgroup; r05) - the wide layout's 48-token waves instead, one molecule per workgroup; same results up to the
+ *              last bits (A/B switch and tests).  The paired layout exists as the encoder-stack build only: bits 2 / 4 / 12
+ *              (without 13) and tw_debug_netblock take the 48-token wide layout as well */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

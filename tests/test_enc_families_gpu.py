@@ -357,3 +357,89 @@ def test_dense_encoder_stack_fast_mode():
     print("fast mode, dense statement: vs oracle", e_ref, "vs per-section build", e_sec, "per-section vs oracle", H.rel_err(sections, ref))
     assert e_ref < 1.5e-3 and e_sec < 1.5e-3, (e_ref, e_sec)
     assert e_ref > 1e-6
+
+
+# ---- the paired 64-token layout (97-128 atoms: one molecule per pair of waves, two per workgroup) ----
+NO_PAIR = 1048576
+
+
+@pytest.mark.parametrize("V,lens", [(97, [97, 97, 80, 97, 97]), (100, [100, 87, 100]), (112, [112, 112, 112, 99]), (128, [128, 128, 101, 128, 128])])
+def test_paired_64_token_layout_vs_oracle_and_wide_layout(V, lens):
+    """tools/gen_h3_enc_asm.py --nt=4 --pair: ragged forward pass (odd and even row counts: the last workgroup holds one molecule
+    or two) and the reverse pass of one conditioning state, against the oracle, against the 48-token wide layout (bit 20: one
+    molecule per workgroup, its own statement and fragment order) and against itself."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_kernel_sd()
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 4500 + V)
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    S = 7
+    zc, zv = fo.draw_latents(sd, S, (1, V, 3), g)
+    rs = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, at[:1], x_c[:1], x_v[:1], mask[:1], zc, zv)
+    m = H.tw_kernel_model(sd, path=H3)
+
+    def run():
+        out = (_loglik(m, at, x_c, x_v, y_c, y_v, mask),) + _sample(m, at[:1], x_c[:1], x_v[:1], mask[:1], zc, zv)
+        return out, lib.tw_last_netblock_kernel().decode()
+
+    try:
+        (paired, k_pair), (again, _) = run(), run()
+        lib.tw_debug_set_flags(NO_PAIR)
+        wide, k_wide = run()
+    finally:
+        lib.tw_debug_set_flags(0)
+    H.assert_not_demoted(m)
+    assert k_pair == "tw::netblock_h3_kernel<4, true, false, true, false, true, false, false>", k_pair
+    assert k_wide == "tw::netblock_h3_kernel<3, true, false, true, false, true, false, false>", k_wide
+    for a, b in zip(paired, again):
+        assert torch.equal(a, b)
+    keep = ~mask[0]
+    for name, out in (("paired", paired), ("wide", wide)):
+        errs = (H.rel_err(out[0], ref), H.rel_err(out[1][:, :, keep], rs[0][:, :, keep]), H.rel_err(out[2][:, :, keep], rs[1][:, :, keep]),
+                H.rel_err(out[3], rs[2]))
+        print(f"{name} vs oracle, V = {V}:", errs)
+        assert max(errs) < TOL, (name, errs)
+
+
+def test_paired_64_token_layout_chebyshev_fragments_per_layer():
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_cheb_sd()
+    V, lens = 104, [104, 91, 104]
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 4700)
+    ref = fo.log_likelihood(sd, H.FULL_CHEB_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    m = H.tw_kernel_model(sd, path=H3, attention_type="chebyshev_kernel", cheb_order=6, force_asymptotic_zero=True)
+    try:
+        out = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+        assert lib.tw_last_netblock_kernel().decode().startswith("tw::netblock_h3_kernel<4, true, false, true")
+        lib.tw_debug_set_flags(NO_PAIR)
+        wide = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+    finally:
+        lib.tw_debug_set_flags(0)
+    H.assert_not_demoted(m)
+    assert H.rel_err(out, ref) < 2e-5 and H.rel_err(wide, ref) < 2e-5, (H.rel_err(out, ref), H.rel_err(wide, ref))
+    assert H.rel_err(out, wide) < 5e-6, H.rel_err(out, wide)
+
+
+def test_paired_64_token_layout_fast_mode():
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_kernel_sd()
+    V, lens = 120, [120, 99, 120]
+    g, at, x_c, x_v, y_c, y_v, mask = _ragged(V, lens, 4800)
+    ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+    m = H.tw_kernel_model(sd, path=H1)
+    try:
+        paired, again = _loglik(m, at, x_c, x_v, y_c, y_v, mask), _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+        assert lib.tw_last_netblock_kernel().decode() == "tw::netblock_h3_kernel<4, true, false, true, false, true, true, false>"
+        lib.tw_debug_set_flags(NO_PAIR)
+        wide = _loglik(m, at, x_c, x_v, y_c, y_v, mask)
+    finally:
+        lib.tw_debug_set_flags(0)
+    assert torch.equal(paired, again)
+    e_ref, e_wide = H.rel_err(paired, ref), H.rel_err(paired, wide)
+    print("fast mode, paired layout: vs oracle", e_ref, "vs wide layout", e_wide)
+    assert e_ref < 1.5e-3 and e_wide < 1.5e-3 and e_ref > 1e-6, (e_ref, e_wide)

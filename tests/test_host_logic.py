@@ -402,11 +402,13 @@ def test_generated_asm_includes_are_current(tmp_path):
                  ["tools/gen_h3_enc_asm.py", "--wide", "--ng=3"], ["tools/gen_h3_enc_asm.py", "--wide", "--ng=3", "--h1"],
                  ["tools/gen_h3_enc_asm.py", "--wide", "--ng=6"], ["tools/gen_h3_enc_asm.py", "--wide", "--ng=6", "--h1"],
                  # ... and of the dense softmax model, tw_h?d_enc_*
-                 ["tools/gen_h3_enc_asm.py", "--dense"], ["tools/gen_h3_enc_asm.py", "--dense", "--h1"]):
+                 ["tools/gen_h3_enc_asm.py", "--dense"], ["tools/gen_h3_enc_asm.py", "--dense", "--h1"],
+                 # ... and of the paired 64-token layout (97-128 atoms), tw_h?n4p_enc_*
+                 ["tools/gen_h3_enc_asm.py", "--nt=4", "--pair"], ["tools/gen_h3_enc_asm.py", "--nt=4", "--pair", "--h1"]):
         subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
                        stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 72
+    assert len(names) == 76
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n
@@ -668,7 +670,7 @@ def test_split_fp16_workspace_covers_every_layout_a_launch_can_take():
 
     lib = _lib.load()
     d = tw.model_constructor(synthetic.kernel_transformer_nvp_config()).dims.to_desc()
-    flags = (0, 16384, 32768, 65536, 131072, 262144, 32768 | 262144, 65536 | 4096)
+    flags = (0, 16384, 32768, 65536, 131072, 262144, 32768 | 262144, 65536 | 4096, 1048576, 4096)
     try:
         for V in list(range(1, 70)) + [80, 96, 97, 128, 160, 161, 192]:
             assert lib.tw_flow_path_supported(C.byref(d), V, _lib.TW_PATH_FUSED_H3) == 1, V

@@ -160,7 +160,17 @@ struct H3Wide {
   int stride;  // token slots per molecule: V (back to back), or 96 (65 .. 96 atoms: each molecule on its own pair of waves)
   int ng;      // key groups of a wave's window: 5 (160 keys), or 3 with the 96-slot stride (a wave's keys = its molecule's 96 slots)
   int win[4];  // bytes: 32 * K0
+  int nt = H3_NT;  // token tiles per wave: 3, or 4 = the PAIRED layout (r05): one molecule of 97 .. 128 atoms per pair of 64-token
+                   // waves, two per workgroup (slot stride 128, four key groups = the molecule's 128 slots; tools/gen_h3_attn_asm.py --pair)
 };
+#define H3P_NG 4
+// bytes of the score fragments of one (wave, head): [group][query tile] (wide) or [query tile][group] (paired) x [hi 1 KiB | lo 1 KiB]
+static inline int64_t h3w_frag_head(const H3Wide& w) { return (int64_t)w.ng * w.nt * 2048; }
+// The paired layout exists as the encoder-stack statement only: a launch that asks for activation dumps / section stamps between
+// the sections (tw_debug_netblock, tw_debug_set_flags bits 2, 4, 12 without 13) takes the 48-token wide layout instead, and so
+// does tw_debug_set_flags bit 20 (1048576; A/B, tests).
+static thread_local bool t_no_pair = false;
+static bool h3_pair_enabled();
 // Geometrically possible from 25 atoms on (below that a 48-token wave already holds two or more whole molecules and its
 // windowed mixing is cheaper).  Molecules sit back to back (slot stride V) with five-group windows - except 65 .. 96 atoms:
 // two molecules per workgroup either way, so each takes 96 slots (molecule 0 on waves 0-1, molecule 1 on waves 2-3, the
@@ -187,8 +197,17 @@ static bool h3_wide_geom_stride(int V, int P, int NG, H3Wide* w) {
   }
   return true;
 }
-static bool h3_wide_geom(int V, H3Wide* w) {
+static bool h3_wide_geom(int V, H3Wide* w, bool allow_pair = true) {
   if (V < H3W_MIN_ATOMS || V > 64 * H3_NT) return false;
+  w->nt = H3_NT;
+  if (V > 96 && V <= 128 && allow_pair && h3_pair_enabled()) {
+    w->mpwg = 2;
+    w->stride = 128;
+    w->ng = H3P_NG;
+    w->nt = H3N4_NT;
+    for (int i = 0; i < 4; ++i) w->win[i] = 0;
+    return true;
+  }
   if (V > 64 && V <= 96 && !(g_debug_flags & 262144) && h3_wide_geom_stride(V, 96, H3W_NG3, w)) return true;
   if (h3_wide_geom_stride(V, V, H3W_NG, w)) return true;
   if (V <= 96) return h3_wide_geom_stride(V, 96, H3W_NG, w);
@@ -705,7 +724,7 @@ struct H3WideWin { int w[4]; };
 __global__ void h3w_score_frag_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
                                       const float* __restrict__ ls, int H, int V, int P, int NG, int mpwg, int64_t n_rows,
                                       int64_t n_cond, int normalise, char* __restrict__ sfrag, ScoreBasis basis,
-                                      int64_t variant_bytes, int use_mm, H3WideWin win) {
+                                      int64_t variant_bytes, int use_mm, H3WideWin win, int nt) {
   extern __shared__ float sm[];
   const int MV = mpwg * V;
   float* xs = sm;                         // [MV][3]
@@ -745,11 +764,12 @@ __global__ void h3w_score_frag_kernel(const float* __restrict__ x, const uint8_t
       for (int m = 0; m < V; ++m) row[m] = row[m] / den;
   }
   __syncthreads();
-  char* out = sfrag + blockIdx.z * variant_bytes + blk * (int64_t)4 * H * H3W_FRAG_HEAD(NG);
-  for (int i = t; i < 4 * NG * H3_NT * 64; i += nthr) {
+  char* out = sfrag + blockIdx.z * variant_bytes + blk * (int64_t)4 * H * ((int64_t)NG * nt * 2048);
+  const bool paired = nt == H3N4_NT;
+  for (int i = t; i < 4 * NG * nt * 64; i += nthr) {
     const int lane = i & 63, rest = i >> 6;
-    const int jt = rest % H3_NT, gi = (rest / H3_NT) % NG, w = rest / (H3_NT * NG);
-    const int tq = 16 * H3_NT * w + 16 * jt + (lane & 15);
+    const int jt = rest % nt, gi = (rest / nt) % NG, w = rest / (nt * NG);
+    const int tq = 16 * nt * w + 16 * jt + (lane & 15);
     const int mq = tq / P, aq = tq - mq * P;  // slot -> (molecule, atom); atoms >= V are the padding of a strided molecule
     const bool qok = mq < mpwg && aq < V;
     const float* row = E + (int64_t)(qok ? mq * V + aq : 0) * V;
@@ -757,14 +777,17 @@ __global__ void h3w_score_frag_kernel(const float* __restrict__ x, const uint8_t
     h8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int tk = k0 + e;
+      // paired layout: the keys of the molecule's 128 slots in the order its two waves' X^T images hold them (the 64-token
+      // statement's: element e of lane group g of group gi = slot 32 gi + 4 g + e, e < 4; 32 gi + 16 + 4 g + e - 4, e >= 4)
+      const int tk = paired ? mq * P + 32 * gi + 4 * (lane >> 4) + (e < 4 ? e : e + 12) : k0 + e;
       const int ak = tk - mq * P;
       const float val = (qok && ak >= 0 && ak < V) ? row[ak] : 0.f;
       const _Float16 hh = (_Float16)val;
       hi[e] = hh;
       lo[e] = (_Float16)(val - (float)hh);
     }
-    char* base = out + ((int64_t)(w * H + h) * (NG * H3_NT) + gi * H3_NT + jt) * 2048;
+    // wide: [group][query tile]; paired: [query tile][group] (8 KiB per query tile, as the statement's loads walk them)
+    char* base = out + ((int64_t)(w * H + h) * (NG * nt) + (paired ? jt * NG + gi : gi * nt + jt)) * 2048;
     *(h8*)(base + lane * 16) = hi;
     *(h8*)(base + 1024 + lane * 16) = lo;
   }
@@ -1228,8 +1251,9 @@ netblock_h3_kernel(const H3Params p) {
   static_assert(!RFF || DENSE, "position features belong to the dense model");
   static_assert(!ENC || ASM, "the encoder-stack statement embeds the generated asm sections");
   static_assert(!(ENC && DENSE) || NT == 3, "dense encoder-stack statement: 48-token waves");
-  static_assert(NT == 3 || (NT == 4 && !DENSE && !WIDE && !RFF),
-                "64-token waves: the kernel-attention variant, one molecule of 49-64 atoms per wave");
+  static_assert(NT == 3 || (NT == 4 && !DENSE && !RFF && (!WIDE || (ENC && !NG6))),
+                "64-token waves: the kernel-attention variant - one molecule of 49-64 atoms per wave, or (WIDE: the paired layout, "
+                "encoder-stack statement only) one of 97-128 atoms per pair of waves");
   constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
   // 64-token build: all four GEMM sections are generated asm (tools/gen_h3_ffn_asm.py / gen_h3_attn_asm.py --nt=4), the glue
   // between them compiled C++ (the per-section build)
@@ -1237,9 +1261,9 @@ netblock_h3_kernel(const H3Params p) {
   constexpr int RING = NT == 4 ? H3N4_RING : H3_RING;
   constexpr int XT_IMG = NT == 4 ? H3N4_XT_IMG : H3_XT_IMG;
   constexpr int SF_BYTES = NT == 4 ? H3N4_SF_BYTES : H3_SF_BYTES;
-  constexpr int WAVE_LDS = DENSE ? H3D_WAVE_LDS : (WIDE ? H3W_WAVE_LDS : (NT == 4 ? H3N4_WAVE_LDS : H3_WAVE_LDS));
+  constexpr int WAVE_LDS = DENSE ? H3D_WAVE_LDS : (NT == 4 ? H3N4_WAVE_LDS : (WIDE ? H3W_WAVE_LDS : H3_WAVE_LDS));
   constexpr int SIDE_LDS_OFFSET = DENSE ? H3D_SIDE_LDS_OFFSET
-                                        : (WIDE ? H3W_SIDE_LDS_OFFSET : (NT == 4 ? H3N4_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET));
+                                        : (NT == 4 ? H3N4_SIDE_LDS_OFFSET : (WIDE ? H3W_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET));
   constexpr int SIDE_CHUNKS = DENSE ? 5 : 3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1595,7 +1619,7 @@ netblock_h3_kernel(const H3Params p) {
   stamp(1);
 
   const char* sf_net = p.sfrag + (int64_t)(net * p.n_layers) * p.sf_variant_bytes +
-                       (WIDE ? (int64_t)((p.sfrag_shared ? 0 : wg * 4) + wave) * p.H * H3W_FRAG_HEAD(p.ng)
+                       (WIDE ? (int64_t)((p.sfrag_shared ? 0 : wg * 4) + wave) * p.H * ((int64_t)p.ng * NT * 2048)
                              : (p.sfrag_shared ? 0 : (int64_t)blk * p.H * NT * SF_BYTES));
 
   const float* sl = (const float*)(lds + SIDE_LDS_OFFSET);  // this layer's side block, staged in LDS
@@ -1667,7 +1691,32 @@ netblock_h3_kernel(const H3Params p) {
       const unsigned sfstride_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)sfstride);
       const unsigned sfstride_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)sfstride >> 32));
       const unsigned sidestride32 = (unsigned)__builtin_amdgcn_readfirstlane((int)sidestride);
-      if constexpr (DENSE) {
+      if constexpr (WIDE && NT == 4) {
+        // paired layout (tools/gen_h3_enc_asm.py --nt=4 --pair): the 64-token statement with a four-group attention block
+        if constexpr (H1) {
+          asm volatile(
+#include "tw_h1n4p_enc_asm.inc"
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+                [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
+                [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+                [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen)
+              :
+#include "tw_h1n4p_enc_clobbers.inc"
+          );
+        } else {
+          asm volatile(
+#include "tw_h3n4p_enc_asm.inc"
+              : [cur] "+&s"(cur), [gn] "+&v"(gn)
+              : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+                [layers] "s"(layers), [sf] "s"(sf_u), [sfstride] "s"(sfstride_lo), [sfstridehi] "s"(sfstride_hi), [side] "s"(side_u),
+                [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+                [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen)
+              :
+#include "tw_h3n4p_enc_clobbers.inc"
+          );
+        }
+      } else if constexpr (DENSE) {
         // dense softmax model (tools/gen_h3_enc_asm.py --dense [--h1]): no score fragments; the key masks of the softmax
         const unsigned m0l = (unsigned)kvalid[0], m0h = (unsigned)(kvalid[0] >> 32), m1l = (unsigned)kvalid[1],
                        m1h = (unsigned)(kvalid[1] >> 32), m2l = (unsigned)kvalid[2], m2h = (unsigned)(kvalid[2] >> 32);
@@ -2554,7 +2603,7 @@ static bool h3_layout(const tw_flow_desc& d, int V, int64_t n_rows, bool h1, Fus
   *wide = h3_wide_choice(d, V, n_rows, h1);
   if (*wide) {
     h3_wide_geom(V, wd);
-    fg->nt = H3_NT;
+    fg->nt = wd->nt;
     fg->mpw = wd->mpwg;
     fg->tile_mask = 0;
     return true;
@@ -2570,7 +2619,7 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool
   if (force_layout >= 0) {  // sizing only - 0: 48-token waves, 1: wide, 2: 64-token waves; an empty H3Ws where the layout does not exist
     wide = force_layout == 1;
     if (wide) {
-      if (!h3_wide_geom(V, &wd)) return H3Ws{};
+      if (!h3_wide_geom(V, &wd, false)) return H3Ws{};  // (97 .. 128 atoms: the paired layout holds two per workgroup and needs less)
       g.nt = H3_NT;
       g.mpw = wd.mpwg;
     } else if (!fused_geom_nt(V, force_layout == 2 ? H3N4_NT : H3_NT, &g)) {
@@ -2595,7 +2644,7 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool
   // + one head of slack: the attention asm block prefetches the "next head" also after the last one
   const int64_t variants = d.cheb_order > 0 ? 2 * d.n_layers : 1;
   if (d.variant == 1) w.sf_variant_bytes = 0;  // dense: no score fragments
-  else if (wide) w.sf_variant_bytes = nblocks * 4 * d.n_heads * H3W_FRAG_HEAD(wd.ng);
+  else if (wide) w.sf_variant_bytes = nblocks * 4 * d.n_heads * h3w_frag_head(wd);
   else w.sf_variant_bytes = nblocks * d.n_heads * g.nt * (g.nt == 4 ? H3N4_SF_BYTES : H3_SF_BYTES);
   // (wide: sized for six-group windows whatever the launch takes - the workspace a caller allocated stays large enough when
   // tw_debug_set_flags moves between the two statements)
@@ -2606,6 +2655,10 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool
 }
 
 std::atomic<int> g_debug_flags{0};
+static bool h3_pair_enabled() {
+  const int f = g_debug_flags;
+  return !t_no_pair && !(f & 1048576) && (!(f & (4 | 16 | 4096)) || (f & 8192));
+}
 
 // Per-tile key windows for the mixing (gen_h3_attn_asm.py --mode=windowed): every molecule that has a token in query
 // tile 0 ends before token 32, and every molecule with a token in tile 2 starts at token 16 or later.  True for all
@@ -2701,7 +2754,12 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   // asked for (bit 12: per-section build, bit 13: encoder stack anyway; bit 3: the compiled-C++ statement of the kernel)
   const bool per_section = ((dump != nullptr || (g_debug_flags & (4 | 16 | 4096))) && !(g_debug_flags & 8192)) || d.n_layers < 1;
   const bool cpp = (g_debug_flags & 8) != 0;
-  if (!wide && fg.nt == H3N4_NT) {
+  if (wide && wd.nt == H3N4_NT) {
+    // r05: the paired layout - one molecule of 97 .. 128 atoms per pair of 64-token waves (encoder-stack statement only)
+    TW_REQUIRE(d.variant == 0 && !per_section && !cpp, "paired 64-token layout: the encoder-stack statement only");
+    if (h1) H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, true, false, true, true, false);
+    else H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, true, false, true, false, false);
+  } else if (!wide && fg.nt == H3N4_NT) {
     TW_REQUIRE(d.variant == 0, "64-token waves: kernel attention");
     if (h1 && per_section) H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, false, false, false, true, false);
     else if (h1) H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, false, false, true, true, false);
@@ -2768,7 +2826,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
   H3Wide wd;
   if (h3_wide_choice(d, V, a.n_rows, a.h1 != 0)) {
     h3_wide_geom(V, &wd);
-    const int64_t vbw = basis.n_variants > 1 ? nblocks * 4 * d.n_heads * H3W_FRAG_HEAD(wd.ng) : 0;
+    const int64_t vbw = basis.n_variants > 1 ? nblocks * 4 * d.n_heads * h3w_frag_head(wd) : 0;
     const float* lsw = a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0);
     const size_t shmw = h3w_sf_lds_bytes(V, wd.mpwg);
     TW_REQUIRE(shmw <= H3_SF_LDS_MAX, "score fragments: %zu bytes of LDS for %d atoms", shmw, V);
@@ -2781,7 +2839,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
     for (int i = 0; i < 4; ++i) win.w[i] = wd.win[i];
     hipLaunchKernelGGL(h3w_score_frag_kernel, dim3((unsigned)nblocks, (unsigned)d.n_heads, (unsigned)basis.n_variants), dim3(512),
                        shmw, a.stream, a.x_coords, a.masked, lsw, d.n_heads, V, wd.stride, wd.ng, wd.mpwg, a.n_rows, a.n_cond, d.normalise, w.sfrag,
-                       basis, vbw, V > 25 ? 1 : 0, win);
+                       basis, vbw, V > 25 ? 1 : 0, win, wd.nt);
     TW_LAUNCH_CHECK();
     *variant_bytes = vbw;
     return TW_OK;
@@ -2874,8 +2932,15 @@ int flow_pass_h3(const FlowArgs& a) {
   return TW_OK;
 }
 
+struct NoPairScope {
+  bool prev;
+  NoPairScope() : prev(t_no_pair) { t_no_pair = true; }
+  ~NoPairScope() { t_no_pair = prev; }
+};
+
 int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, float* dump) {
   const tw_flow_desc& d = *a.desc;
+  NoPairScope no_pair;  // activation dumps / section stamps live in the per-section builds, which the paired layout has none of
   FusedGeom fg;
   H3Wide wdg;
   bool wide_layout = false;

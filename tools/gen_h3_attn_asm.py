@@ -364,12 +364,14 @@ def sf_loads():
             for i, name in enumerate(("s0h", "s0l", "s1h", "s1l")):
                 if H1 and name.endswith("l"):
                     continue
-                out += [f"global_load_dwordx4 {vr(SF(jt, name))}, {vr(a16, 2)}, off" + (f" offset:{1024 * i}" if i else "")]
-            if PAIR:   # key groups 2, 3 (the partner wave's half of the molecule) straight into AGPRs
+                # (pair mode: the fragment address is biased by + 4096 - the instruction offset is 13 bits, signed)
+                off = 1024 * i - (4096 if PAIR else 0)
+                out += [f"global_load_dwordx4 {vr(SF(jt, name))}, {vr(a16, 2)}, off" + (f" offset:{off}" if off else "")]
+            if PAIR:   # key groups 2, 3 (the molecule's second wave's half) straight into AGPRs
                 for i, name in enumerate(("s0h", "s0l", "s1h", "s1l")):
                     if H1 and name.endswith("l"):
                         continue
-                    out += [f"global_load_dwordx4 {ar(SF_AGPR + SF(jt, name))}, {vr(a16, 2)}, off offset:{4096 + 1024 * i}"]
+                    out += [f"global_load_dwordx4 {ar(SF_AGPR + SF(jt, name))}, {vr(a16, 2)}, off" + (f" offset:{1024 * i}" if i else "")]
         out += [f"v_lshl_add_u64 {vr(V_SF16, 2)}, {vr(V_SF16, 2)}, 0, s[{S_SFHEAD}:{S_SFHEAD + 1}]"]
         return out
     for jt, tail in sf_tiles():
@@ -408,6 +410,10 @@ def generate():
     A(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_LANE16}")
     A(f"v_mov_b32 v{V_LANE16 + 1}, 0")
     A(f"v_lshl_add_u64 {vr(V_SF16, 2)}, {SF_BASE}, 0, {vr(V_LANE16, 2)}")
+    if PAIR:
+        A(f"s_mov_b32 s{S_OFF}, 4096")
+        A(f"s_mov_b32 s{S_REL}, 0")
+        A(f"v_lshl_add_u64 {vr(V_SF16, 2)}, {vr(V_SF16, 2)}, 0, s[{S_OFF}:{S_REL}]")
     A(f"s_lshl_b32 s{S_W2048}, %[wave], 11")
     A(f"s_mov_b32 s{S_W2048 + 1}, 0")
     A(f"s_mov_b32 s{S_STRIDE}, {STAGE}")
