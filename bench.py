@@ -38,7 +38,17 @@ F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (
 # only the fallback); the dominant kernel keeps a wave's matrix pipe busy for 579.5 k clocks per launch
 # (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_h3_sq_counters.md)
 SUSTAINED_MFMA_CLOCK_GHZ = 1.74
-H3_MFMA_BUSY_CLOCKS_PER_LAUNCH = 579.5e3
+
+
+def h3_mfma_per_wave(dims) -> int:
+    """MFMA instructions one wave of the 48-token split-fp16 kernel issues per launch - a static property of the generated
+    statements, counted from their structure for the model's dimensions (three MFMAs per 16x16x32 product tile and token tile,
+    NT = 3): in-MLP 108 per 32-unit chunk, per encoder layer 4 k-steps x (24 windowed mixing + 72 GEMM) per head, 144 per FFN
+    chunk and 48 for the transposer, out-MLP 81 per chunk.  36 216 for kernel_transformer_nvp - SQ_INSTS_MFMA reads 36.2 k and
+    SQ_VALU_MFMA_BUSY_CYCLES 579.5 k = 16 clocks each (profiles/r05_ad_sq_counters.md)."""
+    hid, ff = dims.d_hidden // 32, dims.d_ff // 32
+    per_layer = dims.n_heads * 4 * (24 + 72) + 144 * ff + 48
+    return 108 * hid + dims.n_layers * per_layer + 81 * hid
 # execution paths of the flow (include/timewarp_hip.h): h3 and f32 hold the 1e-5 parity bar
 PATHS = {
     "h3": dict(path=3, dtype="f16x3 (split-fp16 operands, 3 MFMAs per fp32 product, fp32 accumulate)",
@@ -700,25 +710,27 @@ def main():
                 probe = {"workgroups": 256, "mfma_per_wave": 36 * 32768, "cycles": int(probe_cyc.value), "ms": probe_ms.value,
                          "cycles_per_mfma": probe_cyc.value / (36.0 * 32768),
                          "tflops": 256 * 4 * 36 * 32768 * 16384.0 / (probe_ms.value * 1e-3) / 1e12}
-            floor_ms = H3_MFMA_BUSY_CLOCKS_PER_LAUNCH / (sustained_ghz * 1e6)
+            busy_clocks = 16.0 * h3_mfma_per_wave(model.dims)
+            floor_ms = busy_clocks / (sustained_ghz * 1e6)
             out["roofline"]["power_bound"] = {
                 "what": "launch time if the matrix pipe never idled, at the clock THIS chip sustains with every matrix pipe busy on "
                         "random fp16 operands (mfma_stream_probe below, measured right after the timed region; one CU alone runs "
                         "2.40 GHz); frac = that floor / the live launch time.  Context for `frac` above, not a replacement of it",
-                "matrix_pipe_busy_clocks_per_wave": H3_MFMA_BUSY_CLOCKS_PER_LAUNCH,
+                "matrix_pipe_busy_clocks_per_wave": busy_clocks,
                 "sustained_clock_ghz": sustained_ghz,
                 "sustained_clock_measured_by_this_run": probe is not None,
                 "mfma_stream_probe": probe,
                 "sustained_f16_mfma_tflops": sustained_ghz * 1e9 * 1024 * 1024 / 1e12,
                 "floor_ms": floor_ms,
                 "frac": floor_ms / avg_ms,
-                "constants": "matrix_pipe_busy_clocks_per_wave (36.1 k MFMAs x 16 clocks) is a property of the kernel's instruction "
-                             "stream, confirmed by SQ_VALU_MFMA_BUSY_CYCLES, not a measurement of this run; sustained_clock_ghz, "
+                "constants": "matrix_pipe_busy_clocks_per_wave = 16 clocks x the MFMA count of the generated statements for this model's "
+                             "dimensions (h3_mfma_per_wave: 36 216; SQ_INSTS_MFMA 36.2 k, SQ_VALU_MFMA_BUSY_CYCLES 579.5 k in "
+                             "profiles/r05_ad_sq_counters.md) - a property of the instruction stream, not a measurement; sustained_clock_ghz, "
                              "avg_launch_ms and attention_block.effective_clock_ghz are measured by this run (the clock by the "
                              "bare MFMA stream of tw_probe_mfma_clock right after the timed region; 1.74 GHz, the r03 probe "
                              "result, only if that call fails)",
                 "source": "tw_probe_mfma_clock (this run); profiles/r04_mfma_shape_probe_warm.txt (the same stream stand-alone: 1.99-2.02 GHz "
-                          "settled; a 32x32x16 stream sustains 1.65-1.69), profiles/r03_h3_sq_counters.md",
+                          "settled; a 32x32x16 stream sustains 1.65-1.69), profiles/r05_ad_sq_counters.md",
             }
         if world == 1 and args.path != "f32":
             out["alt_path"] = alt_path_record(device, distributed.chain_seed(args.seed, rank), args.proposals,

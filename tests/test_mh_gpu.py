@@ -767,10 +767,16 @@ def test_exploration_mode_vs_oracle(path):
     assert float((en - ren).abs().max()) < 2e-3            # kJ/mol, fp32 energies of ~ -50 .. +100
 
 
-def test_exploration_mode_range_guard_replays_on_f32():
-    """Exploration with a checkpoint whose activations leave the fp16 range: one look at the range flag at the end of the loop
-    (no synchronisation per model call), then the whole exploration again on the f32 kernels with the recorded draws - bit
-    for bit what the f32 path gives from the start with the same device noise."""
+@pytest.mark.parametrize("window", [64, 2])
+def test_exploration_mode_range_guard_replays_on_f32(window, monkeypatch):
+    """Exploration with a checkpoint whose activations leave the fp16 range: one look at the range flag per WINDOW of steps (no
+    synchronisation per model call; r05: windows of 64 steps instead of the whole run, so that only one window's draws are
+    kept), then that window again on the f32 kernels with the recorded draws and the rest there too - bit for bit what the f32
+    path gives from the start with the same device noise.  With a window of 2 the five steps are three windows: the replay
+    starts from the window's own starting state and the later windows run unguarded."""
+    from timewarp_amd import exploration as ex_mod
+
+    monkeypatch.setattr(ex_mod, "RANGE_CHECK_WINDOW", window)
     from tests.test_flow_gpu import _overflowing_sd
     from timewarp_amd import synthetic
     from timewarp_amd.dataloader import single_state_batch

@@ -18,6 +18,7 @@ from .utils.evaluation_utils import (DeviceNoise, RecordingNoise, ReplayDraws, _
                                      check_symmetry_change)
 
 CHIRALITY_PENALTY = 10000.0  # exploration.py:243
+RANGE_CHECK_WINDOW = 64   # exploration steps per look at the split-fp16 range flag (and per recorded window of draws)
 
 
 def explore(batch, model, device, openmm_potential_energy_torch, num_steps: int, num_parallel_steps: int = 1,
@@ -43,10 +44,11 @@ def explore(batch, model, device, openmm_potential_energy_torch, num_steps: int,
               masked_elements=batch.masked_elements.repeat(P, 1).to(device))              # :122-131
     sc = torch.exp(model.coords_prior_log_scale.detach()).to(device)
     sv = torch.exp(model.velocs_prior_log_scale.detach()).to(device)
-    def run(noise):
-        y_c, y_v, e = y_coords, y_velocs, energies
+    def run_window(noise, state, n):
+        """n exploration steps from `state` = (y_c, y_v, e); returns the new state and the steps' trajectory / energy lists."""
+        y_c, y_v, e = state
         trajectory, energy_log = [], []
-        for _ in range(num_steps):
+        for _ in range(n):
             z_c, z_v = noise.latents(1, P, V, sc, sv)
             y_new, _, _ = model.conditional_sample_with_logp(x_coords=y_c, x_velocs=y_v, num_samples=1, z_coords=z_c,
                                                              z_velocs=z_v, **kw)
@@ -61,17 +63,32 @@ def explore(batch, model, device, openmm_potential_energy_torch, num_steps: int,
             trajectory.append(y_c)
             energy_log.append(e)
             y_v = noise.randn_like(y_c)                                                   # :253
-        return torch.cat(trajectory, dim=0), torch.cat(energy_log, dim=0)
+        return (y_c, y_v, e), trajectory, energy_log
 
     with torch.no_grad():
-        if not _range_guarded(model):
-            return run(noise)
-        # split-fp16 kernels: no range-flag read-back (a device synchronisation) per model call - one look at the end; on an
-        # overflow the model is demoted and the whole exploration runs again on the exact-f32 kernels with the SAME draws
-        rec = RecordingNoise(noise)
-        with _deferred(model):
-            out = run(rec)
-        if model.demoted or model.split_fp16_overflowed(device):
-            model.demote_to_f32()
-            out = run(ReplayDraws(rec.log))
-        return out
+        state = (y_coords, y_velocs, energies)
+        trajectory, energy_log = [], []
+        guarded = _range_guarded(model)
+        # split-fp16 kernels: no range-flag read-back (a device synchronisation) per model call.  The run goes in WINDOWS of
+        # RANGE_CHECK_WINDOW steps (r04 recorded the draws of the whole exploration - ~3x the trajectory's own memory
+        # for num_steps of 1e5 - and looked at the flag once, at the end): only the open window's draws are kept; one look at the
+        # flag per window; on an overflow the model is demoted and THAT window runs again from its starting state on the
+        # exact-f32 kernels with the same draws, the rest of the exploration continues there with the ordinary noise source.
+        done = 0
+        while done < num_steps:
+            n = min(RANGE_CHECK_WINDOW, num_steps - done)
+            if guarded:
+                rec = RecordingNoise(noise)
+                with _deferred(model):
+                    new_state, tr, el = run_window(rec, state, n)
+                if model.demoted or model.split_fp16_overflowed(device):
+                    model.demote_to_f32()
+                    new_state, tr, el = run_window(ReplayDraws(rec.log), state, n)
+                    guarded = False
+            else:
+                new_state, tr, el = run_window(noise, state, n)
+            state = new_state
+            trajectory += tr
+            energy_log += el
+            done += n
+        return torch.cat(trajectory, dim=0), torch.cat(energy_log, dim=0)
