@@ -683,3 +683,29 @@ def test_split_fp16_workspace_covers_every_layout_a_launch_can_take():
         assert lib.tw_flow_path_supported(C.byref(d), 193, _lib.TW_PATH_FUSED_H3) == 0
     finally:
         lib.tw_debug_set_flags(0)
+
+
+def test_product_kernels_do_not_spill():
+    """r05: every PRODUCT instantiation of the split-fp16 net-block kernel - the encoder-stack builds the launch code takes unless
+    a per-section build is asked for (tw_debug_set_flags bit 12, activation dumps) - compiles to ScratchSize 0 B/lane, and hipcc
+    has nothing to say about the inline asm (r04: 200-528 B/lane on the wide / dense / 64-token families, reserved s100 / s101 on
+    a clobber list).  Compiles csrc/tw_netblock_h3.hip once with -Rpass-analysis=kernel-resource-usage (~90 s, no GPU needed)."""
+    import shutil
+    import subprocess
+    import sys
+
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "resource_usage.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = {}
+    for line in out.stdout.splitlines():
+        m = re.match(r"\s*(\d+)\s+(\d+)\s+(-?\d+)\s+(\d+)\s+(tw::netblock_h3_kernel<[^>]*>)", line)
+        if m:
+            rows[m.group(5)] = int(m.group(4))
+    # <NT, ASM, DENSE, WIDE, RFF, ENC, H1, NG6>: every ENC = true instantiation
+    enc = {k: v for k, v in rows.items() if k.split(",")[5].strip() == "true"}
+    assert len(enc) >= 13, sorted(rows)          # 48-token x2, 64-token x2, paired x2, wide x4, dense x3 (one with position features)
+    assert all(v == 0 for v in enc.values()), {k: v for k, v in enc.items() if v}
+    assert "# warnings: 0" in out.stdout, out.stdout[-1500:]
