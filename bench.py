@@ -494,7 +494,8 @@ def alt_path_record(device, seed, proposals, steps, sync_every, name="f32"):
                      "launches": int(k_launches.value), "mfma_per_fp32_product": pinfo["mfma_per_product"]},
     }
     if proposals == S_PROPOSALS:
-        rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = committed_traffic(kernel, f"--path {name}")
+        # (the alternative paths run inside the default command, which is what the PMC passes profiled: bench args "")
+        rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = committed_traffic(kernel, "")
     if name == "h1" and proposals == S_PROPOSALS and not rec["range_guard_fired"]:
         rec["roofline"]["attention_block"] = attention_block(model, device, proposals, avg_ms, "h1")
         rec["measured_deviation"] = ("un-calibrated full-size weights vs the reference's vectors: 1.6e-3 (coordinates), 2.0e-4 "
