@@ -379,9 +379,22 @@ def generate():
     A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
     A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
     A(f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}")
-    # in_proj scale (side block slot 640) -> SGPRs (and a quarter of it for q)
-    A(f"v_mov_b32 v{V_T}, {SL}")
-    A(f"ds_read_b32 v{V_T + 1}, v{V_T} offset:{4 * 640}")
+    # in_proj scale (side block slot 640) -> SGPRs (and a quarter of it for q).  Per-section build: the layer's side block was
+    # requested by wave 0 only a few hundred cycles ago and nothing has waited for that DMA yet - the read sits behind the two
+    # bare prologue stages below (two hand-offs: vmcnt wait + barrier; the first use of the scale is in the stage after them).
+    # Encoder-stack build: the block arrived a whole layer ago (double-buffered), so the read can be the first thing.
+    def read_scale():
+        A(f"v_mov_b32 v{V_T}, {SL}")
+        A(f"ds_read_b32 v{V_T + 1}, v{V_T} offset:{4 * 640}")
+
+    def scale_to_sgprs():
+        A(f"v_mul_f32 v{V_T + 2}, 0.25, v{V_T + 1}")
+        A("s_nop 1")
+        A(f"v_readfirstlane_b32 s{S_SCIN}, v{V_T + 1}")
+        A(f"v_readfirstlane_b32 s{S_SCQ}, v{V_T + 2}")
+
+    if FUSED:
+        read_scale()
     if not FUSED:
         # split activations from the wave-private block: 24 images -> a96..a191
         A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
@@ -390,15 +403,21 @@ def generate():
         for i in range(96):
             A(f"v_accvgpr_write_b32 a{i}, 0")
     A("s_waitcnt lgkmcnt(0)")
-    A(f"v_mul_f32 v{V_T + 2}, 0.25, v{V_T + 1}")
-    A("s_nop 1")
-    A(f"v_readfirstlane_b32 s{S_SCIN}, v{V_T + 1}")
-    A(f"v_readfirstlane_b32 s{S_SCQ}, v{V_T + 2}")
+    if FUSED:
+        scale_to_sgprs()
     for r in tile_reads(0) + tile_reads(1):
         A(r)
     # ---- prologue: stages Q(0), K(0) bare; biases of head 0
     L += stage(qk_groups(QA), [], "pq", aux=False)
-    L += stage(qk_groups(KA), [], "pk", aux=False, pre_barrier=bias_reads())
+    if FUSED:
+        L += stage(qk_groups(KA), [], "pk", aux=False, pre_barrier=bias_reads())
+    else:
+        # (the head's biases come from the same side block: read behind both hand-offs as well)
+        L += stage(qk_groups(KA), [], "pk", aux=False)
+        read_scale()
+        L += bias_reads()
+        A("s_waitcnt lgkmcnt(0)")   # LDS reads return in order: the next stage's four tile reads (older) land with them
+        scale_to_sgprs()
     A(f"s_mov_b32 s{S_PAIR}, 4")
     A(".Lh3atd_pair_%=:")
     head_slot(0, L)
