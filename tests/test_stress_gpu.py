@@ -21,7 +21,8 @@ FAMILIES = [
     ("64-token waves", False, 60, 256, 65536),
     ("wide layout, five-group windows", False, 30, 384, ALWAYS_WIDE),
     ("wide layout, three-group windows", False, 65, 192, 0),
-    ("wide layout, one molecule per workgroup", False, 110, 128, 0),
+    ("paired 64-token waves (one molecule per pair of waves)", False, 110, 128, 0),
+    ("wide layout, one molecule per workgroup", False, 140, 96, 0),
     ("wide layout, six-group windows", False, 176, 96, 0),
     ("dense softmax model", True, 22, 600, 0),
 ]
