@@ -595,6 +595,10 @@ def main():
     acc0, prop0 = chain.accepted, chain.proposals
     states0 = sum(t.shape[0] for t in chain.chain_c)
     if world > 1:
+        # the collection's own collectives once, untimed (ragged lengths, as at collection): whatever RCCL sets up lazily at the
+        # first all_gather / all_reduce of a communicator - channels, kernels, staging buffers - is not part of the K timed steps
+        distributed.gather_trajectories(torch.zeros((1 + rank % 2, cfg["V"], 3), dtype=torch.float32, device=device))
+        distributed.all_reduce_counters([0.0, 0.0, 0.0], device)
         torch.distributed.barrier()
     torch.cuda.synchronize()
     # HIP events around every 5th launch of the dominant kernel (two event records per launch cost ~3 us of stream time

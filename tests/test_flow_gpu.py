@@ -752,28 +752,83 @@ def test_64_token_layout_choice_and_config_3_size():
                 H.rel_err(res[flag][2][rows], rlp) < TOL, (S, flag)
 
 
-def test_per_op_path_lds_limit():
-    """150 atoms: the per-op kernels' V x V score tile needs > 64 KiB of LDS (raised limit) and still matches the
-    oracle; 256 atoms exceed the CU's 160 KiB and are refused with a message instead of failing at launch."""
+def test_per_op_path_large_molecules():
+    """Above every fused layout (192 atoms) the flow runs on the per-op path.  r04 stopped at ~200 atoms there (one V x V score
+    tile per molecule in the LDS) and refused anything larger; r05: the scores are computed row-wise and the mixing is a tiled
+    f32-MFMA GEMM from 129 atoms on, so the reference's own 691-atom test protein size goes through - against the oracle at the
+    bar, ragged (masked tails), forward and reverse.  The row-wise scores kernel must equal the tile kernel bit for bit (150
+    atoms fit both).  The dense softmax variant keeps its limit and says so."""
+    import ctypes as C
+
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
     sd = H.full_kernel_sd()
     g = torch.Generator().manual_seed(77)
     m = H.tw_kernel_model(sd, path=0)
-    for V, ok in ((150, True), (256, False)):
+    for V in (150, 256, 691):
         at = torch.randint(0, 5, (2, V), generator=g)
-        x_c = torch.randn(2, V, 3, generator=g) * 0.8
+        x_c = torch.randn(2, V, 3, generator=g) * (0.8 if V < 300 else 1.5)
         x_v = torch.randn(2, V, 3, generator=g) * 0.5
         y_c = x_c + torch.randn(2, V, 3, generator=g) * 0.02
         y_v = torch.randn(2, V, 3, generator=g) * 0.5
         mask = torch.zeros(2, V, dtype=torch.bool)
         mask[1, V - 9:] = True
-        call = lambda: m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
-                                        y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
-        if ok:
-            ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
-            assert H.rel_err(call().cpu(), ref) < TOL
-        else:
-            with pytest.raises(RuntimeError, match="LDS"):
-                call()
+        out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                               y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+        ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, x_c, x_v, y_c, y_v, mask)
+        assert H.rel_err(out.cpu(), ref) < TOL, (V, H.rel_err(out.cpu(), ref))
+        if V == 256:
+            S = 3
+            zc, zv = fo.draw_latents(sd, S, (1, V, 3), g)
+            rs = fo.conditional_sample_with_logp(sd, H.FULL_KERNEL_SPEC, at[1:], x_c[1:], x_v[1:], mask[1:], zc, zv)
+            got = m.conditional_sample_with_logp(atom_types=at[1:].cuda(), x_coords=x_c[1:].cuda(), x_velocs=x_v[1:].cuda(), adj_list=None,
+                                                 edge_batch_idx=None, masked_elements=mask[1:].cuda(), num_samples=S,
+                                                 z_coords=zc.cuda(), z_velocs=zv.cuda())
+            keep = ~mask[1]
+            assert H.rel_err(got[0].cpu()[:, :, keep], rs[0][:, :, keep]) < TOL and H.rel_err(got[1].cpu()[:, :, keep], rs[1][:, :, keep]) < TOL
+            assert H.rel_err(got[2].cpu(), rs[2]) < TOL
+    # the two scores kernels on the same 150 atoms (bit 21 forces the row-wise one), both cdist branches, Gaussian and Chebyshev:
+    # bit-identical - the arithmetic of tw_cdist_mm / basis_value must not depend on the kernel it is inlined into
+    V = 150
+    x = torch.randn(1, V, 3, generator=g) * 0.8
+    ls = torch.tensor([0.1, 0.2, 0.5, 0.7, 1.0, 1.2])
+    coeffs = torch.randn(6, 7, generator=g) * 0.3
+    xd, md, ld, cd = x.cuda(), torch.zeros(1, V, dtype=torch.uint8).cuda(), ls.cuda(), coeffs.cuda()
+    try:
+        for use_mm in (1, 0):
+            outs = []
+            for flags in (0, 2097152):
+                lib.tw_debug_set_flags(flags)
+                a, b = torch.empty(1, 6, V, V, device="cuda"), torch.empty(1, 6, V, V, device="cuda")
+                _lib.check(lib.tw_kernel_scores(xd.data_ptr(), md.data_ptr(), ld.data_ptr(), 6, 1, V, 1, use_mm, a.data_ptr(), None), "tw_kernel_scores")
+                _lib.check(lib.tw_kernel_scores_cheb(xd.data_ptr(), md.data_ptr(), ld.data_ptr(), cd.data_ptr(), 7, 1, 6, 1, V, 1, use_mm,
+                                                     b.data_ptr(), None), "tw_kernel_scores_cheb")
+                outs.append((a, b))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), use_mm
+        # ... and the whole flow with the tiled kernels forced at a size the tile kernels take too
+        at = torch.randint(0, 5, (3, 100), generator=g)
+        xx = torch.randn(3, 100, 3, generator=g) * 0.7
+        yy = xx + torch.randn(3, 100, 3, generator=g) * 0.02
+        vv = torch.randn(3, 100, 3, generator=g) * 0.5
+        mk = torch.zeros(3, 100, dtype=torch.bool)
+        mk[2, 91:] = True
+        ref = fo.log_likelihood(sd, H.FULL_KERNEL_SPEC, at, xx, vv, yy, vv, mk)
+        for flags in (0, 2097152):
+            lib.tw_debug_set_flags(flags)
+            out = H.tw_kernel_model(sd, path=SIMPLE).log_likelihood(atom_types=at.cuda(), x_coords=xx.cuda(), x_velocs=vv.cuda(), y_coords=yy.cuda(),
+                                                                     y_velocs=vv.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda())
+            assert H.rel_err(out.cpu(), ref) < TOL, (flags, H.rel_err(out.cpu(), ref))
+    finally:
+        lib.tw_debug_set_flags(0)
+    # dense softmax variant: no tiled form of its attention
+    md_ = H.tw_dense_model(H.full_dense_sd(), path=0)
+    V = 256
+    at = torch.randint(0, 5, (1, V), generator=g)
+    xx = torch.randn(1, V, 3, generator=g)
+    with pytest.raises(RuntimeError, match="LDS"):
+        md_.log_likelihood(atom_types=at.cuda(), x_coords=xx.cuda(), x_velocs=xx.cuda(), y_coords=xx.cuda(), y_velocs=xx.cuda(),
+                           adj_list=None, edge_batch_idx=None, masked_elements=torch.zeros(1, V, dtype=torch.bool).cuda())
 
 
 @pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])

@@ -293,7 +293,7 @@ int tw_kernel_scores(const float* x_coords, const uint8_t* masked, const float* 
   TW_REQUIRE(x_coords && masked && lengthscales && out, "NULL pointer argument");
   TW_REQUIRE(n_heads > 0 && n_cond >= 0 && n_atoms > 0, "bad sizes");
   return launch_scores(x_coords, masked, lengthscales, n_heads, n_cond, n_atoms, normalise, use_mm, out,
-                       (hipStream_t)stream);  // refuses molecules whose V x V tile exceeds the CU's LDS (TW_LDS_LIMIT)
+                       (hipStream_t)stream);  // (molecules whose V x V tile exceeds the CU's LDS take the row-wise kernel)
 }
 
 int tw_kernel_scores_cheb(const float* x_coords, const uint8_t* masked, const float* lengthscales, const float* cheb_coeffs,

@@ -157,16 +157,20 @@ struct FlowArgs {
 // terms of O(1) for distances of O(0.1)), so it is only reproducible with the SAME sequence of roundings: torch's CPU sgemm
 // accumulates the five products in k order with fused multiply-adds from zero, and the norms are x*x + y*y + z*z with every
 // product and sum rounded separately (pow(2).sum(-1)) - checked bit for bit against torch.cdist on the 60-atom golden
-// geometry (99.4 % of the 3600 entries identical, the rest one ulp).  __fmul_rn / __fadd_rn keep hipcc from contracting the
-// norm into FMAs (which alone moved a fifth of the entries, by up to 7e-4 nm).
+// geometry (99.4 % of the 3600 entries identical, the rest one ulp).  Contraction is switched OFF for this function: hipcc's
+// default (-ffp-contract=fast) fuses a product into a following sum wherever it likes after inlining, which alone moved a
+// fifth of the entries by up to 7e-4 nm - and HIP's __fmul_rn / __fadd_rn are plain `*` / `+` (no OCML rounded operations in
+// this ROCm), so they do not prevent it: r05 found the same source giving two different sequences in two kernels (36 539 of
+// 135 000 scores of a 150-atom molecule differed between scores_kernel and scores_rows_kernel until the pragma went in).
 __device__ __forceinline__ float tw_cdist_mm(float qx, float qy, float qz, float mx, float my, float mz) {
-  const float qn = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
-  const float mn = __fadd_rn(__fadd_rn(__fmul_rn(mx, mx), __fmul_rn(my, my)), __fmul_rn(mz, mz));
-  float acc = __fmul_rn(-2.f * qx, mx);
-  acc = fmaf(-2.f * qy, my, acc);
-  acc = fmaf(-2.f * qz, mz, acc);
-  acc = __fadd_rn(acc, qn);   // fma(qn, 1, acc)
-  acc = __fadd_rn(acc, mn);   // fma(1, mn, acc)
+#pragma clang fp contract(off)
+  const float qn = (qx * qx + qy * qy) + qz * qz;
+  const float mn = (mx * mx + my * my) + mz * mz;
+  float acc = (-2.f * qx) * mx;
+  acc = __builtin_fmaf(-2.f * qy, my, acc);
+  acc = __builtin_fmaf(-2.f * qz, mz, acc);
+  acc = acc + qn;   // fma(qn, 1, acc)
+  acc = acc + mn;   // fma(1, mn, acc)
   return sqrtf(fmaxf(acc, 0.f));
 }
 
@@ -174,23 +178,27 @@ __device__ __forceinline__ float tw_cdist_mm(float qx, float qy, float qz, float
 // of chebyshev_expansion (kernel_attention.py:37-66), evaluated in the same order as the reference's stacked terms
 __device__ __forceinline__ float basis_value(float sc, const float* __restrict__ coeff, int order, float coeff_mean) {
   if (order <= 0) return expf(-(sc * sc));
+  {
   // torch's sequence of roundings (kernel_attention.py:37-66): every product and difference of the recursion
   // 2.0 * rfactor * rcur - rprev is rounded separately (hipcc would fuse the last two into an FMA), and the contraction with
   // the coefficients (einsum -> sgemm, K = order) is a chain of fused multiply-adds from zero in c order.  The basis values
   // cancel (sum |c_k R_k| >> |sum|), so a different sequence of roundings shows at the 1e-5 level in log p(x~|y~).
-  const float x = __fmul_rn(sc, sc);
-  const float rf = __fdiv_rn(__fsub_rn(x, 1.0f), __fadd_rn(x, 1.0f));
-  const float rf2 = __fmul_rn(2.0f, rf);
+  // (contraction off for the whole function, as in tw_cdist_mm: __fmul_rn / __fsub_rn are plain operators in this ROCm)
+#pragma clang fp contract(off)
+  const float x = sc * sc;
+  const float rf = (x - 1.0f) / (x + 1.0f);
+  const float rf2 = 2.0f * rf;
   float rprev = 1.0f, rcur = rf;
-  float acc = __fmul_rn(__fsub_rn(coeff[0], coeff_mean), rprev);
-  if (order >= 2) acc = fmaf(__fsub_rn(coeff[1], coeff_mean), rcur, acc);
+  float acc = (coeff[0] - coeff_mean) * rprev;
+  if (order >= 2) acc = __builtin_fmaf(coeff[1] - coeff_mean, rcur, acc);
   for (int c = 2; c < order; ++c) {
-    const float rnext = __fsub_rn(__fmul_rn(rf2, rcur), rprev);
-    acc = fmaf(__fsub_rn(coeff[c], coeff_mean), rnext, acc);
+    const float rnext = rf2 * rcur - rprev;
+    acc = __builtin_fmaf(coeff[c] - coeff_mean, rnext, acc);
     rprev = rcur;
     rcur = rnext;
   }
   return acc;
+  }
 }
 
 // Which basis the score-fragment producers of the fused paths evaluate.  order == 0: the Gaussian, one variant.

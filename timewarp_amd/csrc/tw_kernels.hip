@@ -1,7 +1,8 @@
 // Glue kernels (scores, centring, coupling, prior log-prob, kinetic energy, MH accept, chirality)
 // and the SIMPLE flow path: one plain HIP kernel per reference torch op.  The simple path is the
-// always-available HIP implementation (all variants; molecules up to ~180 atoms, whose V x V scores fit the CU's
-// LDS - larger ones are refused with a message, TW_LDS_LIMIT); the fused f32-MFMA path
+// always-available HIP implementation (all variants; kernel attention on molecules of any size since r05 - above ~128 atoms the
+// scores and the mixing take tiled kernels instead of one V x V tile in the LDS; the dense softmax variant up to ~190 atoms,
+// larger ones are refused with a message, TW_LDS_LIMIT); the fused f32-MFMA path
 // (tw_netblock.hip) is the fast one for the kernel variant.
 #include <stdarg.h>
 
@@ -138,9 +139,46 @@ __global__ void scores_kernel(const float* __restrict__ x, const uint8_t* __rest
   }
 }
 
-// The per-op kernels hold one molecule's V x V score / distance matrix in LDS.  Up to 64 KiB of dynamic LDS launches
-// as is; up to the CU's 160 KiB after raising the kernel's limit; beyond that (V > ~180) the call is refused with a
-// message instead of failing at launch.
+// Large molecules (r05): the same rows without the V x V distance tile - the coordinates (12 V bytes) are all the LDS a block
+// holds, every (head, query) row recomputes its V distances in both passes.  Same arithmetic, same order of operations per
+// row as scores_kernel: bit-identical output (tests/test_flow_gpu.py::test_per_op_path_large_molecules).  grid (B, row blocks).
+__global__ void scores_rows_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
+                                   const float* __restrict__ ls, int H, int V, int normalise, int use_mm,
+                                   float* __restrict__ out, const float* __restrict__ coeffs, int order, int force_zero) {
+  extern __shared__ float sm[];
+  float* xs = sm;  // [V*3]
+  const int64_t b = blockIdx.x;
+  for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) xs[i] = x[b * 3 * V + i];
+  __syncthreads();
+  const int r = blockIdx.y * blockDim.x + threadIdx.x;  // one thread per (h, q) row
+  if (r >= H * V) return;
+  const int h = r / V, q = r % V;
+  const float l = ls[h];
+  const float* cf = order > 0 ? coeffs + (int64_t)h * order : nullptr;
+  float cmean = 0.f;
+  if (order > 0 && force_zero) {
+    for (int c = 0; c < order; ++c) cmean += cf[c];
+    cmean /= (float)order;
+  }
+  double sum = 0.0;
+  for (int m = 0; m < V; ++m) {
+    const float sc = pair_distance(xs, q, m, use_mm) / l;
+    const float e = masked[b * V + m] ? 0.f : basis_value(sc, cf, order, cmean);
+    sum += (double)fabsf(e);
+  }
+  const float denom = (float)sum + 1e-5f;
+  float* o = out + ((b * H + h) * V + q) * (int64_t)V;
+  for (int m = 0; m < V; ++m) {
+    const float sc = pair_distance(xs, q, m, use_mm) / l;
+    const float e = masked[b * V + m] ? 0.f : basis_value(sc, cf, order, cmean);
+    o[m] = normalise ? e / denom : e;
+  }
+}
+
+// The small-molecule per-op kernels hold one molecule's V x V score / distance matrix in LDS.  Up to 64 KiB of dynamic LDS
+// launches as is; up to the CU's 160 KiB after raising the kernel's limit; beyond that the kernel-attention flow takes the
+// tiled kernels (scores_rows_kernel, attend_mfma_kernel: any V); the dense flow's sdpa_kernel has no tiled form and refuses
+// with a message instead of failing at launch.
 #define TW_LDS_LIMIT(kernel, bytes, V)                                                                        \
   do {                                                                                                        \
     TW_REQUIRE((bytes) <= (size_t)160 * 1024,                                                                 \
@@ -154,6 +192,12 @@ int launch_scores(const float* x, const uint8_t* masked, const float* ls, int H,
                   int normalise, int use_mm, float* out, hipStream_t s, const float* coeffs, int order, int force_zero) {
   if (B == 0) return TW_OK;
   size_t shm = (size_t)(3 * V + V * V) * sizeof(float);
+  if (shm > (size_t)160 * 1024 || (g_debug_flags & 2097152)) {  // no room for the distance tile (or bit 21): the row-wise kernel
+    hipLaunchKernelGGL(scores_rows_kernel, dim3((unsigned)B, (unsigned)((H * V + 255) / 256)), dim3(256), (size_t)3 * V * sizeof(float), s,
+                       x, masked, ls, H, V, normalise, use_mm, out, coeffs, order, force_zero);
+    TW_LAUNCH_CHECK();
+    return TW_OK;
+  }
   TW_LDS_LIMIT(scores_kernel, shm, V);
   hipLaunchKernelGGL(scores_kernel, dim3((unsigned)B), dim3(256), shm, s, x, masked, ls, H, V, normalise,
                      use_mm, out, coeffs, order, force_zero);
@@ -543,6 +587,71 @@ __global__ void attend_kernel(const float* __restrict__ scores, const float* __r
   }
 }
 
+// The same product for large molecules (r05: the V x V tile of attend_kernel stops at ~200 atoms): per (row n, head h) the GEMM
+//   att[q, d] = sum_m scores[q, m] * vals[m, d]      M = K = V, N = D
+// tiled like linear_kernel - 128 x 64 output tile per workgroup, k in steps of 16 through the LDS, v_mfma_f32_16x16x4_f32 (exact
+// fp32 products, fp32 accumulate).  1-D grid over (n, h, query tile, feature tile).
+__global__ void __launch_bounds__(256) attend_mfma_kernel(const float* __restrict__ scores, const float* __restrict__ vals,
+                                                           float* __restrict__ att, int64_t n_cond, int H, int V, int D) {
+  __shared__ float ss[16][LIN_BM + 4];   // scores tile, k-major: ss[k][q]
+  __shared__ float vs[16][LIN_BN + 4];   // values tile:          vs[k][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int tiles_n = (D + LIN_BN - 1) / LIN_BN, tiles_m = (V + LIN_BM - 1) / LIN_BM;
+  int64_t blk = blockIdx.x;
+  const int tn = (int)(blk % tiles_n); blk /= tiles_n;
+  const int tm = (int)(blk % tiles_m); blk /= tiles_m;
+  const int h = (int)(blk % H);
+  const int64_t n = blk / H;
+  const int64_t c = n % n_cond;
+  const int q0 = tm * LIN_BM, d0 = tn * LIN_BN;
+  const float* S = scores + ((c * H + h) * V) * (int64_t)V;                 // [V, V] row-major
+  const float* Vv = vals + (n * V * (int64_t)H + h) * D;                    // row m at + m * H * D
+  const int64_t vstride = (int64_t)H * D;
+  lin_f4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < V; k0 += 16) {
+    for (int i = threadIdx.x; i < LIN_BM * 16; i += 256) {   // scores: 16 consecutive k of a query row are contiguous
+      const int r = i / 16, k = i % 16;
+      ss[k][r] = (q0 + r < V && k0 + k < V) ? S[(int64_t)(q0 + r) * V + k0 + k] : 0.f;
+    }
+    for (int i = threadIdx.x; i < LIN_BN * 16; i += 256) {   // values: the feature index is contiguous
+      const int k = i / LIN_BN, dd = i % LIN_BN;
+      vs[k][dd] = (k0 + k < V && d0 + dd < D) ? Vv[(int64_t)(k0 + k) * vstride + d0 + dd] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float a[2], b[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = ss[4 * ks + g][32 * wave + 16 * i + i16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = vs[4 * ks + g][16 * j + i16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D layout: lane (i16, g) holds rows 4 g + r (r = 0..3) of column i16
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int dd = d0 + 16 * j + i16;
+    if (dd >= D) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = q0 + 32 * wave + 16 * i + 4 * g + r;
+        if (q < V) att[((n * V + q) * H + h) * (int64_t)D + dd] = acc[i][j][r];
+      }
+  }
+}
+
 // dense softmax attention for one (row, head): qkv [n, V, 3*d]; out [n, V, d]
 // (torch.nn.MultiheadAttention with key padding mask)
 __global__ void sdpa_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ masked, int64_t n_cond,
@@ -670,9 +779,16 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
           return rc;
       }
       if ((rc = launch_linear(w.h, lb + L.layer.wv, nullptr, w.vals, M, HD, d.d_model, ACT_NONE, s))) return rc;
-      TW_LDS_LIMIT(attend_kernel, (size_t)V * V * 4, V);
-      hipLaunchKernelGGL(attend_kernel, dim3((unsigned)a.n_rows, d.n_heads), dim3(128), (size_t)V * V * 4, s, w.scores,
-                         w.vals, w.att, a.n_cond, d.n_heads, V, d.d_model);
+      if ((size_t)V * V * 4 > (size_t)64 * 1024 || (g_debug_flags & 2097152)) {
+        // above 128 atoms: the tiled MFMA form (no V x V tile in the LDS: any molecule size; and faster from there on)
+        const int64_t blocks = a.n_rows * d.n_heads * ((V + LIN_BM - 1) / LIN_BM) * ((d.d_model + LIN_BN - 1) / LIN_BN);
+        TW_REQUIRE(blocks < (int64_t)1 << 31, "attend: %lld workgroups", (long long)blocks);
+        hipLaunchKernelGGL(attend_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w.scores, w.vals, w.att, a.n_cond, d.n_heads,
+                           V, d.d_model);
+      } else {
+        hipLaunchKernelGGL(attend_kernel, dim3((unsigned)a.n_rows, d.n_heads), dim3(128), (size_t)V * V * 4, s, w.scores,
+                           w.vals, w.att, a.n_cond, d.n_heads, V, d.d_model);
+      }
       TW_LAUNCH_CHECK();
       if ((rc = launch_linear(w.att, lb + L.layer.wo, nullptr, w.tmp, M, d.d_model, HD, ACT_NONE, s))) return rc;
     } else {

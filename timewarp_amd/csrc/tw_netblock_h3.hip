@@ -1230,8 +1230,13 @@ __device__ __forceinline__ void h3_mlp_chain(const BOp<NT> (&xin)[KS_IN], f4 (&y
 //                O^T[d][query] = V^T P^T on K = 32 (key tiles 0, 1) + K = 16 (tile 2) MFMAs -> standard orientation;
 //   per head pair: the two O tiles are one 32-deep k-step of out_proj:  y += W_o[:, 32 hp ..] . O
 // Nothing is transposed through memory and nothing leaves the registers.
-// WIDE = true (kernel attention, asm sections only): molecules of 49 .. 160 atoms, packed back to back over the workgroup's
-// 192 token slots; token-local sections unchanged, attention through the shared X^T tile (tw_h3_attns_asm.inc).
+// WIDE = true (kernel attention, asm sections only): molecules of 25 .. 192 atoms, packed over the workgroup's 192 token slots
+// (back to back, or at a slot stride of 96); token-local sections unchanged, attention through the shared X^T tile
+// (tw_h3_attns{,3,6}_asm.inc).  WIDE with NT = 4 (r05, ENC only): the PAIRED layout - one molecule of 97 .. 128 atoms per pair of
+// 64-token waves, no shared tile: a wave mixes against its own and its partner's X^T images (tw_h?n4p_enc_asm.inc).
+// ENC = true: the whole encoder stack is ONE generated asm statement (tools/gen_h3_enc_asm.py) - the product build of every
+// family since r05 (ScratchSize 0); ENC = false: the per-section build (asm sections, compiled glue), kept behind
+// tw_debug_set_flags bit 12 as the A/B reference and for activation dumps / section stamps between the sections.
 // RFF = true (dense only): 128 random Fourier features of the conditioning positions appended to the in-MLP's input
 // (transformer_nvp_posenc.yaml); six input k-steps, the in-MLP as compiled C++ (the asm section takes two).
 // H1 = true (encoder-stack build only): the single-MFMA "fast" variant, TW_PATH_FUSED_H1 - one half-precision MFMA per
