@@ -802,3 +802,62 @@ def test_exploration_mode_range_guard_replays_on_f32(window, monkeypatch):
         got = explore(batch, m, dev, energy, 5, 6, 60.0, noise=DeviceNoise(dev, seed=21))
     assert m.demoted and not m32.demoted
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.isfinite(got[0]).all()
+
+
+def test_mh_iterations_on_the_691_atom_protein_vs_oracle():
+    """The reference's SECOND test molecule end to end (testdata/output/1hgv-traj-state0.pdb: a 46-residue, 691-atom protein;
+    topology and a frame of coordinates from the committed known-answer fixture, the pinned amber99sb-ildn + OBC tables): whole
+    MH iterations with the full-size kernel_transformer_nvp flow.  No fused layout holds 691 atoms, so the flow runs on the per-op
+    path - which refused anything above ~200 atoms until r05 (row-wise scores, tiled f32-MFMA mixing) - inside tw_mh_iteration,
+    with the AMBER energy kernel on all 691 atoms, against the oracle loop and the C energy oracle on shared host noise."""
+    from timewarp_amd.dataloader import elements_from_atom_names, single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.forcefield import ELEMENT_MASSES, amber99sbildn_obc_tables
+    from timewarp_amd.utils.evaluation_utils import MetropolisHastingsChain, sample_with_model
+
+    z = np.load(H.GOLDEN + "/energy_kat_1hgv.npz")
+    names = [str(n) for n in z["atom_names"]]
+    tables = amber99sbildn_obc_tables(names, [str(r) for r in z["residue_names"]], [int(i) for i in z["residue_ids"]],
+                                      improper_neighbour_order="pyset")
+    V = len(names)
+    assert V == 691
+    types = elements_from_atom_names(names)
+    coords = torch.from_numpy(z["positions"][0].astype(np.float32))
+    masses = torch.tensor([ELEMENT_MASSES[next(ch for ch in n if ch.isalpha())] for n in names], dtype=torch.float32)
+    energy = AmberPotentialEnergyTorch(tables)
+    # (2 073 degrees of freedom against stiff bonded terms: output layers scaled by 1e-6 and a coordinate prior of e^-9.5 nm give
+    # acceptance probabilities between 0 and 1 - three accepted moves in these iterations)
+    sd = H.mh_state_dict("scaled", True, out_scale=1e-6, coords_log_scale=-9.5)
+    S, N = 4, 9
+    kw = dict(accept=True, num_proposal_steps=S, random_velocs=True, resample_velocs=True)
+    ref = mo.sample_with_model(types[None], coords[None], torch.zeros(1, V, 3), torch.zeros(1, V, dtype=torch.bool),
+                               mo.OracleModel(sd, H.FULL_KERNEL_SPEC), H.OracleAmberEnergy(tables), masses, N, H.HostNoise(5), **kw)
+    dev = torch.device("cuda")
+    model = H.tw_kernel_model(sd, path=None)     # the constructor's default: split-fp16 where a layout exists, else the f32 kernels
+    assert model._path_for(V) == 0               # TW_PATH_AUTO -> the per-op path at this size
+    chain = MetropolisHastingsChain(single_state_batch("1hgv", types, coords), model, dev, energy, masses, noise=H.HostNoise(5, "cuda"), **kw)
+    assert chain._fused                          # the whole iteration as one C-ABI call
+    got = sample_with_model(single_state_batch("1hgv", types, coords), model, dev, energy, masses, N, disable_tqdm=True,
+                            noise=H.HostNoise(5, "cuda"), **kw)
+    print("691-atom protein: accepted", ref[2], "of", len(ref[3].acceptance), "emitted states")
+    assert ref[2] >= 1
+    (gc, gv, gacc, gs), (rc, rv, racc, rs) = got, ref
+    assert gc.shape == rc.shape and gacc == racc
+    assert np.array_equal(np.asarray(gs.acceptance_indicator).astype(bool), np.asarray(rs.acceptance_indicator).astype(bool))
+    assert H.rel_err(gc, rc) < 1e-5 and H.rel_err(gv, rv) < 1e-5
+    for f in ("p_xy", "p_yx", "energies_pot", "energies_kin"):
+        a, b = np.asarray(getattr(gs, f), np.float64), np.asarray(getattr(rs, f), np.float64)
+        assert H.rel_err(a, b) < 2e-4, (f, H.rel_err(a, b))
+    for f, big in (("energies_pot_delta", "energies_pot"), ("energies_kin_delta", "energies_kin")):
+        # differences of two fp32 values of the magnitude of `big` (E_pot / kT ~ -1000): a few ulps of THAT
+        a, b = np.asarray(getattr(gs, f), np.float64), np.asarray(getattr(rs, f), np.float64)
+        mag = float(np.abs(np.asarray(getattr(rs, big), np.float64)).max())
+        assert np.abs(a - b).max() < 3e-6 * mag + 1e-6, (f, np.abs(a - b).max(), mag)
+    # The exponent is a difference of fp32 quantities of ~2e4 (log-densities of 2 073 coordinates; one ulp = 2e-3) and ~1e3
+    # (E / kT): it is resolved to a few ulps of the LARGER terms on either side - the reference's arithmetic included - and the
+    # acceptance probability e^-exponent inherits that as a relative error.  Held to 3e-6 of the log-density's magnitude.
+    scale = float(np.abs(np.asarray(rs.p_xy, np.float64)).max())
+    d_exp = np.abs(np.asarray(gs.exponent, np.float64) - np.asarray(rs.exponent, np.float64)).max()
+    print("exponent: max abs difference", d_exp, "of log-densities ~", scale)
+    assert d_exp < 3e-6 * scale, (d_exp, scale)
+    assert np.allclose(np.asarray(gs.acceptance), np.asarray(rs.acceptance), rtol=0, atol=3 * d_exp + 1e-6)
