@@ -384,7 +384,7 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *              workgroup; r05) - the wide layout's 48-token waves instead, one molecule per workgroup; same results up to the
  *              last bits (A/B switch and tests).  The paired layout exists as the encoder-stack build only: bits 2 / 4 / 12
  *              (without 13) and tw_debug_netblock take the 48-token wide layout as well
- *   bit 21 (2097152) per-op path: the row-wise scores kernel and the tiled MFMA mixing kernel (what molecules above ~200 / 128
+ *   bit 21 (2097152) per-op path: the row-wise scores kernel and the tiled MFMA mixing kernel (what molecules above ~200 / 64
  *              atoms take) at every size; same scores bit for bit, the mixing in another summation order (A/B switch and tests) */
 int tw_debug_set_flags(int flags);
 

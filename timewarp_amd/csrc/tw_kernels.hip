@@ -1,7 +1,7 @@
 // Glue kernels (scores, centring, coupling, prior log-prob, kinetic energy, MH accept, chirality)
 // and the SIMPLE flow path: one plain HIP kernel per reference torch op.  The simple path is the
-// always-available HIP implementation (all variants; kernel attention on molecules of any size since r05 - above ~128 atoms the
-// scores and the mixing take tiled kernels instead of one V x V tile in the LDS; the dense softmax variant up to ~190 atoms,
+// always-available HIP implementation (all variants; kernel attention on molecules of any size since r05 - above 64 / ~200 atoms the
+// mixing / the scores take tiled kernels instead of one V x V tile in the LDS; the dense softmax variant up to ~190 atoms,
 // larger ones are refused with a message, TW_LDS_LIMIT); the fused f32-MFMA path
 // (tw_netblock.hip) is the fast one for the kernel variant.
 #include <stdarg.h>
@@ -779,8 +779,9 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
           return rc;
       }
       if ((rc = launch_linear(w.h, lb + L.layer.wv, nullptr, w.vals, M, HD, d.d_model, ACT_NONE, s))) return rc;
-      if ((size_t)V * V * 4 > (size_t)64 * 1024 || (g_debug_flags & 2097152)) {
-        // above 128 atoms: the tiled MFMA form (no V x V tile in the LDS: any molecule size; and faster from there on)
+      if (V > 64 || (g_debug_flags & 2097152)) {
+        // above 64 atoms: the tiled MFMA form (no V x V tile in the LDS: any molecule size; the scalar kernel below took 12 ms
+        // per call at 100 atoms x 512 rows - 78 % of a per-op pass, profiles/r05_paired_kernel_stats.csv)
         const int64_t blocks = a.n_rows * d.n_heads * ((V + LIN_BM - 1) / LIN_BM) * ((d.d_model + LIN_BN - 1) / LIN_BN);
         TW_REQUIRE(blocks < (int64_t)1 << 31, "attend: %lld workgroups", (long long)blocks);
         hipLaunchKernelGGL(attend_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w.scores, w.vals, w.att, a.n_cond, d.n_heads,

@@ -1,3 +1,4 @@
+"""Encoder-stack build (default) against the per-section build (tw_debug_set_flags 4096) of the dense softmax model over\n(position features, encoder layers, coupling layers, rows): which combinations demote / differ.  Used in r05 to isolate the\n%[cur] / %[ring] register sharing of the position-feature build (DESIGN_LOG.md, round 5)."""
 import sys, os, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from tests import helpers as H

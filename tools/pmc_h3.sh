@@ -3,6 +3,7 @@
 #   bash tools/pmc_h3.sh h1       the single-MFMA fast mode (path 4)                                       -> pmc_h1_*
 #   bash tools/pmc_h3.sh 4aa      BASELINE configs[3]: wide layout, NNQQ, 512 proposals (bench.py --config 4aa) -> pmc_4aa_*
 #   bash tools/pmc_h3.sh nnqq     the wide layout: NNQQ (65 atoms, 96-slot stride, three-group windows), 512 proposals  -> pmc_nnqq_*
+#   bash tools/pmc_h3.sh paired   the paired 64-token layout: 100 atoms x 512 proposals (tools/time_sizes.py)           -> pmc_paired_*
 #   bash tools/pmc_h3.sh dense    BASELINE configs[4]: dense softmax flow (bench.py --config dense)        -> pmc_dense_*
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -13,6 +14,7 @@ case $W in
   4aa) CMD="python $R/bench.py --config 4aa --steps 2 --warmup 1";;
   dense) CMD="python $R/bench.py --config dense --steps 2 --warmup 1";;
   nnqq) CMD="python $R/bench.py --config 4aa-nnqq --steps 2 --warmup 1";;
+  paired) CMD="python $R/tools/time_sizes.py 100x512";;   # r05: the paired 64-token layout (97-128 atoms), reverse passes
 esac
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_RD"; do

@@ -68,7 +68,8 @@ def sq(dirs, out):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     # waves per launch: 2 nets x ceil(rows / molecules per workgroup) workgroups x 4 waves - 1000 for the 1000-proposal
     # alanine-dipeptide launches (250 workgroups), 2048 for NNQQ x 512 proposals on the wide layout (2 molecules per workgroup)
-    waves = 2048.0 if ("4aa" in dirs[0] or "nnqq" in dirs[0]) else 1000.0
+    # (paired layout, 100 atoms x 512 proposals: 256 workgroups per net as well)
+    waves = 2048.0 if ("4aa" in dirs[0] or "nnqq" in dirs[0] or "paired" in dirs[0]) else 1000.0
     names = sorted({r["Kernel_Name"] for d in dirs for r in counters(d) if "netblock_h3" in r["Kernel_Name"]})
     lines = [f"# SQ counters, {', '.join('`' + n.split('(')[0].replace('void ', '') + '`' for n in names)}", "",
              f"`bash tools/pmc_h3.sh` on the GPU box ({os.path.basename(dirs[0])[:-2]}): four `rocprofv3 --kernel-trace --pmc <4 counters> "
