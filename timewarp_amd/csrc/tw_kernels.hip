@@ -497,32 +497,48 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
   const bool k_vec = (K % 4) == 0;  // rows of X / W are 16-byte aligned: stage with float4 loads
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    // 4 consecutive k of one row per thread-iteration
-    for (int i = threadIdx.x; i < (LIN_BM + LIN_BN) * 4; i += 256) {
+  // One K = 16 slice of the tile is (128 + 64) rows x 4 float4 = 3 float4 per thread.  The NEXT slice's global loads are issued
+  // before the current slice's MFMAs and parked in registers (r05: without that every slice paid a global round trip in the
+  // open - 43 % of the f32 MFMA line at 192 atoms, where this kernel is 77 % of a per-op pass); same values, same order of
+  // operations, bit-identical results.
+  lin_f4 nxt[3];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int i = threadIdx.x + 256 * t;
       const bool is_x = i < LIN_BM * 4;
       const int r = (is_x ? i : i - LIN_BM * 4) / 4, kq = 4 * (i % 4);
       const int64_t row = is_x ? m0 + r : (int64_t)n0 + r;
       const bool row_ok = is_x ? row < M : row < N;
       const float* src = (is_x ? X : W) + row * K + k0 + kq;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      lin_f4 v = (lin_f4){0.f, 0.f, 0.f, 0.f};
       if (row_ok) {
         if (k_vec && k0 + kq + 3 < K) {
-          const lin_f4 q = *(const lin_f4*)src;
-          v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+          v = *(const lin_f4*)src;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (k0 + kq + e < K) v[e] = src[e];
         }
       }
+      nxt[t] = v;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int i = threadIdx.x + 256 * t;
+      const bool is_x = i < LIN_BM * 4;
+      const int r = (is_x ? i : i - LIN_BM * 4) / 4, kq = 4 * (i % 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (is_x) xs[kq + e][r] = v[e];
-        else wsh[kq + e][r] = v[e];
+        if (is_x) xs[kq + e][r] = nxt[t][e];
+        else wsh[kq + e][r] = nxt[t][e];
       }
     }
     __syncthreads();
+    if (k0 + 16 < K) fetch(k0 + 16);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       // A fragment: lane (i16, g) holds X[m][k = 4 ks + g]; B fragment: W[n = 16 j + i16][k = 4 ks + g]
@@ -613,16 +629,34 @@ __global__ void __launch_bounds__(256) attend_mfma_kernel(const float* __restric
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < V; k0 += 16) {
-    for (int i = threadIdx.x; i < LIN_BM * 16; i += 256) {   // scores: 16 consecutive k of a query row are contiguous
-      const int r = i / 16, k = i % 16;
-      ss[k][r] = (q0 + r < V && k0 + k < V) ? S[(int64_t)(q0 + r) * V + k0 + k] : 0.f;
+  // (the next K = 16 slice is fetched into registers before the current slice's MFMAs, as in linear_kernel)
+  float ns[8], nv[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {   // scores: 16 consecutive k of a query row are contiguous
+      const int i = threadIdx.x + 256 * t, r = i / 16, k = i % 16;
+      ns[t] = (q0 + r < V && k0 + k < V) ? S[(int64_t)(q0 + r) * V + k0 + k] : 0.f;
     }
-    for (int i = threadIdx.x; i < LIN_BN * 16; i += 256) {   // values: the feature index is contiguous
-      const int k = i / LIN_BN, dd = i % LIN_BN;
-      vs[k][dd] = (k0 + k < V && d0 + dd < D) ? Vv[(int64_t)(k0 + k) * vstride + d0 + dd] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {   // values: the feature index is contiguous
+      const int i = threadIdx.x + 256 * t, k = i / LIN_BN, dd = i % LIN_BN;
+      nv[t] = (k0 + k < V && d0 + dd < D) ? Vv[(int64_t)(k0 + k) * vstride + d0 + dd] : 0.f;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < V; k0 += 16) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = threadIdx.x + 256 * t;
+      ss[i % 16][i / 16] = ns[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = threadIdx.x + 256 * t;
+      vs[i / LIN_BN][i % LIN_BN] = nv[t];
     }
     __syncthreads();
+    if (k0 + 16 < V) fetch(k0 + 16);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       float a[2], b[4];

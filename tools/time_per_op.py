@@ -1,0 +1,23 @@
+"""Reverse-pass time of the kernel flow on the PER-OP path at given (atoms, proposals) pairs - the path every molecule above 192
+atoms takes: `python tools/time_per_op.py 192x256 691x16` (under `rocprofv3 --kernel-trace --stats` for the per-kernel shares)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import helpers as H
+
+m = H.tw_kernel_model(H.full_kernel_sd(), path=2)
+g = torch.Generator().manual_seed(0)
+for spec in sys.argv[1:] or ["192x256"]:
+    V, S = (int(t) for t in spec.split("x"))
+    at = torch.randint(0, 5, (1, V), generator=g).cuda()
+    xc = (torch.randn(1, V, 3, generator=g) * 0.8).cuda()
+    xv = torch.randn(1, V, 3, generator=g).cuda()
+    mk = torch.zeros(1, V, dtype=torch.bool).cuda()
+    f = lambda: m.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None, edge_batch_idx=None,
+                                               masked_elements=mk, num_samples=S)
+    f(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3 * 1e3
+    flop = 16 * V * (4478976 + 4608 * V) * S
+    print(f"per-op path V={V} S={S}: {dt:.1f} ms per reverse pass, {flop / dt / 1e9:.1f} TFLOP/s algorithmic", flush=True)
