@@ -36,7 +36,12 @@ def disturb(it):
 
 
 for label, dense, V, B, S in (("alanine dipeptide, kernel attention", False, 22, 1000, 1000), ("60 atoms (64-token waves)", False, 60, 512, 512),
-                              ("44 atoms (48-token waves, one molecule each)", False, 44, 400, 400), ("dense softmax model", True, 22, 1000, 1000)):
+                              ("44 atoms (48-token waves, one molecule each)", False, 44, 400, 400), ("dense softmax model", True, 22, 1000, 1000),
+                              # r05: the statements that are new this round
+                              ("65 atoms (wide layout, three-group windows)", False, 65, 512, 512),
+                              ("110 atoms (paired 64-token waves)", False, 110, 256, 256),
+                              ("150 atoms (wide layout, five-group windows)", False, 150, 200, 200),
+                              ("176 atoms (wide layout, six-group windows)", False, 176, 128, 128)):
     sd = H.full_dense_sd() if dense else H.full_kernel_sd()
     c = batch(V, B, 11 + V)
     at, x_c, x_v, y_c, y_v, mask = c
