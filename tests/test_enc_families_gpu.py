@@ -443,3 +443,35 @@ def test_paired_64_token_layout_fast_mode():
     e_ref, e_wide = H.rel_err(paired, ref), H.rel_err(paired, wide)
     print("fast mode, paired layout: vs oracle", e_ref, "vs wide layout", e_wide)
     assert e_ref < 1.5e-3 and e_wide < 1.5e-3 and e_ref > 1e-6, (e_ref, e_wide)
+
+
+# ---- the dense softmax model on 64-token waves (49-64 atoms; per-section build: asm MLP sections, compiled-C++ attention block) ----
+@pytest.mark.parametrize("V,lens", [(52, [52, 52, 41, 52, 52]), (61, [61, 61, 61, 48, 61, 61, 61]), (64, [64, 50])])
+def test_dense_model_on_64_token_waves_vs_oracle(V, lens):
+    """r05: the dense model above 48 atoms ran the exact-f32 fused kernel (3x slower) on the default path until now.  Forward pass
+    on a ragged batch of more than one workgroup and the reverse pass of one conditioning state against the oracle; the instantiation
+    that ran; a repeated run bit-identical; the fast mode (which has no such build) falls back per call."""
+    from timewarp_amd import _lib
+
+    lib = _lib.load()
+    sd = H.full_dense_sd()
+    (at, x_c, x_v, y_c, y_v, mask, zc, zv), ref, rs = _dense_case(sd, H.FULL_DENSE_SPEC, V, lens, 5500 + V, S=6)
+    m = H.tw_dense_model(sd, path=None)           # the constructor's default must land on the split-fp16 kernel
+    assert m._path_for(V) == H3
+
+    def run():
+        return (_loglik(m, at, x_c, x_v, y_c, y_v, mask),) + _sample(m, at[:1], x_c[:1], x_v[:1], mask[:1], zc, zv)
+
+    out, again = run(), run()
+    assert lib.tw_last_netblock_kernel().decode() == "tw::netblock_h3_kernel<4, true, true, false, false, false, false, false>"
+    H.assert_not_demoted(m)
+    for a, b in zip(out, again):
+        assert torch.equal(a, b)
+    keep = ~mask[0]
+    errs = (H.rel_err(out[0], ref), H.rel_err(out[1][:, :, keep], rs[0][:, :, keep]), H.rel_err(out[2][:, :, keep], rs[1][:, :, keep]),
+            H.rel_err(out[3], rs[2]))
+    print(f"dense, 64-token waves, V = {V}:", errs)
+    assert max(errs) < TOL, errs
+    fast = H.tw_dense_model(sd, path=H1)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        _loglik(fast, at, x_c, x_v, y_c, y_v, mask)

@@ -223,7 +223,8 @@ def test_preferred_split_fp16_path_falls_back_per_call(monkeypatch):
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)  # r04: 1e-5 above 25 atoms too (tw_cdist_mm reproduces torch.cdist's rounding sequence)
     assert m._dev_weights["f32"] is None  # 60 atoms run on the split-fp16 kernel too (wide layout)
     dense = H.tw_dense_model(H.full_dense_sd(), path=None)
-    assert dense._path_for(22) == H3 and dense._path_for(60) == 0  # the dense flow has a split-fp16 kernel of its own
+    # the dense flow has split-fp16 kernels of its own: 48-token waves, and (r05) 64-token waves for 49-64 atoms
+    assert dense._path_for(22) == H3 and dense._path_for(60) == H3 and dense._path_for(64) == H3 and dense._path_for(65) == 0
 
 
 @pytest.mark.parametrize("path", [SIMPLE, FUSED, 0, H3])
@@ -269,7 +270,8 @@ def test_full_dense_padded_golden(path):
 
 
 @pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22]), (7, [7, 5, 6, 7, 7, 3, 7, 7, 7]), (30, [30, 28, 25]),
-                                    (16, [16, 13, 16, 16, 16, 10, 16]), (48, [48, 40, 33]), (60, [60, 44]), (64, [64, 51])])
+                                    (16, [16, 13, 16, 16, 16, 10, 16]), (48, [48, 40, 33]), (60, [60, 44]), (64, [64, 51]),
+                                    (49, [49, 49, 31, 49, 49, 49]), (57, [57, 50, 57, 57, 57, 57, 57, 57, 40])])
 def test_fused_dense_batched_padding_vs_oracle(V, lens):
     """Ragged batches on the fused dense kernel against the oracle: 3- and 4-tile waves, several molecules per wave,
     padded keys, one molecule filling the whole wave."""
@@ -285,7 +287,7 @@ def test_fused_dense_batched_padding_vs_oracle(V, lens):
     for b, n in enumerate(lens):
         mask[b, n:] = True
     ref = fo.log_likelihood(sd, H.FULL_DENSE_SPEC, at, x_c, x_v, y_c, y_v, mask)
-    for path in (FUSED, SIMPLE) + ((H3,) if V <= H3_MAX_ATOMS else ()):
+    for path in (FUSED, SIMPLE, H3):   # (r05: 49-64 atoms on the split-fp16 path too - 64-token waves, attention block compiled C++)
         m = H.tw_dense_model(sd, path=path)
         out = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
                                y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda()).cpu()

@@ -72,6 +72,7 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3D_SIDE_LDS_BYTES 5120       // five 1 KiB LDS-DMA chunks
 #define H3D_LDS_BYTES (H3D_SIDE_LDS_OFFSET + H3D_SIDE_LDS_BYTES)
 #define H3D_ENC_LDS_BYTES (H3D_LDS_BYTES + H3D_SIDE_LDS_BYTES)  // encoder-stack statement: the side block double-buffered
+#define H3D4_LDS_BYTES (H3N4_SIDE_LDS_OFFSET + H3D_SIDE_LDS_BYTES)  // dense model on 64-token waves: three-slot ring + 4 x 32 KiB + 5 KiB = 160 KiB
 #define H3D_INB 656
 #define H3D_OUTB 1040
 // "wide" layout (49 .. 160 atoms): a workgroup's 4 x 48 token slots hold floor(192 / V) whole molecules back to back, the
@@ -243,11 +244,14 @@ static bool h3_wide_ok(int V) {
 // tw_debug_set_flags bit 16 (65536): always where it exists; bit 17 (131072): never (A/B, tests).
 #define H3N4_COST 1.25
 static bool h3_nt4_ok(const tw_flow_desc& d, int V, bool h1) {
-  (void)h1;  // both the split-fp16 and the single-MFMA stream have a 64-token build
+  // kernel attention: both the split-fp16 and the single-MFMA stream have a 64-token build; dense softmax model (r05): the
+  // split-fp16 per-section build only, no position features
+  if (d.variant == 1) return !h1 && d.d_rff == 0 && V > 16 * H3_NT && V <= 16 * H3N4_NT;
   return d.variant == 0 && V > 16 * H3_NT && V <= 16 * H3N4_NT && h3_sf_lds_bytes(d.n_heads, V, 1) <= H3_SF_LDS_MAX;
 }
 static int64_t h3_rounds(int64_t wgs_per_net) { return (8 * ((wgs_per_net + 3) / 4) + H3_CUS - 1) / H3_CUS; }
 static bool h3_nt4_choice(const tw_flow_desc& d, int V, int64_t n_rows, bool h1) {
+  if (d.variant == 1) return h3_nt4_ok(d, V, h1);  // the dense model has no other layout above 48 atoms
   if (!h3_nt4_ok(d, V, h1) || (g_debug_flags & 131072)) return false;
   if (g_debug_flags & 65536) return true;
   H3Wide wd;
@@ -280,14 +284,17 @@ bool h3_supported(const tw_flow_desc& d, int n_atoms) {
   if (d.variant == 1)  // dense softmax attention: 8 heads of 16 = one MFMA tile each; input width <= 64, or 32 + 9 + 128
                        // random Fourier position features (192 columns: the in-MLP then runs as compiled C++)
     return d.d_model == 128 && d.n_heads == 8 && d.d_hidden % 32 == 0 && d.d_ff % 32 == 0 &&
-           ((d.d_rff == 0 && d.d_emb + 9 <= 64) || (d.d_rff == 128 && d.d_emb == 32)) && fused_geom_nt(n_atoms, H3_NT, &fg);
+           ((d.d_rff == 0 && d.d_emb + 9 <= 64) || (d.d_rff == 128 && d.d_emb == 32)) &&
+           (fused_geom_nt(n_atoms, H3_NT, &fg) || h3_nt4_ok(d, n_atoms, false));
   return false;
 }
 
 // the single-MFMA variant exists for kernel attention (the 48-token encoder-stack build and the wide layout) and for the dense
 // model without position features (in / FFN / out sections single-MFMA, the softmax attention block in split form)
 bool h1_supported(const tw_flow_desc& d, int n_atoms) {
-  return (d.variant == 0 || (d.variant == 1 && d.d_rff == 0)) && h3_supported(d, n_atoms);
+  FusedGeom fg;
+  if (d.variant == 1) return d.d_rff == 0 && h3_supported(d, n_atoms) && fused_geom_nt(n_atoms, H3_NT, &fg);  // (48-token waves only)
+  return d.variant == 0 && h3_supported(d, n_atoms);
 }
 
 // ================================================================================================
@@ -1256,19 +1263,22 @@ netblock_h3_kernel(const H3Params p) {
   static_assert(!RFF || DENSE, "position features belong to the dense model");
   static_assert(!ENC || ASM, "the encoder-stack statement embeds the generated asm sections");
   static_assert(!(ENC && DENSE) || NT == 3, "dense encoder-stack statement: 48-token waves");
-  static_assert(NT == 3 || (NT == 4 && !DENSE && !RFF && (!WIDE || (ENC && !NG6))),
+  static_assert(NT == 3 || (NT == 4 && !RFF && (!WIDE || (ENC && !NG6)) && (!DENSE || (ASM && !WIDE && !ENC && !H1))),
                 "64-token waves: the kernel-attention variant - one molecule of 49-64 atoms per wave, or (WIDE: the paired layout, "
-                "encoder-stack statement only) one of 97-128 atoms per pair of waves");
+                "encoder-stack statement only) one of 97-128 atoms per pair of waves; the dense softmax model on one molecule of "
+                "49-64 atoms per wave as the per-section build with its attention block compiled C++ (r05)");
   constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
   // 64-token build: all four GEMM sections are generated asm (tools/gen_h3_ffn_asm.py / gen_h3_attn_asm.py --nt=4), the glue
   // between them compiled C++ (the per-section build)
-  constexpr bool ASM_IO = ASM, ASM_ATT = ASM;
+  // (dense model at 64 tokens: the generated softmax block exists for 48 tokens only - r03 measured the compiled block within
+  // 0.4 % of it in wall time - so that instantiation runs the MLP sections as asm and the attention block as compiled C++)
+  constexpr bool ASM_IO = ASM, ASM_ATT = ASM && !(DENSE && NT == 4);
   constexpr int RING = NT == 4 ? H3N4_RING : H3_RING;
   constexpr int XT_IMG = NT == 4 ? H3N4_XT_IMG : H3_XT_IMG;
   constexpr int SF_BYTES = NT == 4 ? H3N4_SF_BYTES : H3_SF_BYTES;
-  constexpr int WAVE_LDS = DENSE ? H3D_WAVE_LDS : (NT == 4 ? H3N4_WAVE_LDS : (WIDE ? H3W_WAVE_LDS : H3_WAVE_LDS));
-  constexpr int SIDE_LDS_OFFSET = DENSE ? H3D_SIDE_LDS_OFFSET
-                                        : (NT == 4 ? H3N4_SIDE_LDS_OFFSET : (WIDE ? H3W_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET));
+  constexpr int WAVE_LDS = NT == 4 ? H3N4_WAVE_LDS : (DENSE ? H3D_WAVE_LDS : (WIDE ? H3W_WAVE_LDS : H3_WAVE_LDS));
+  constexpr int SIDE_LDS_OFFSET = NT == 4 ? H3N4_SIDE_LDS_OFFSET
+                                          : (DENSE ? H3D_SIDE_LDS_OFFSET : (WIDE ? H3W_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET));
   constexpr int SIDE_CHUNKS = DENSE ? 5 : 3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -2010,7 +2020,7 @@ netblock_h3_kernel(const H3Params p) {
       for (int jt = 0; jt < NT; ++jt) y[ot][jt] = (f4){0.f, 0.f, 0.f, 0.f};
 
     stamp(40 + 4 * l + 0);
-    if constexpr (DENSE && ASM) {
+    if constexpr (DENSE && ASM_ATT) {
       // Hand-scheduled dense-softmax attention block (tools/gen_h3_dense_attn_asm.py): the split activations in through the
       // wave-private LDS block, y back the same way; biases and the in_proj scale from the layer's side block in LDS
       // (landed: the first stage hand-off inside the block lies between its DMA and the first read).
@@ -2050,7 +2060,7 @@ netblock_h3_kernel(const H3Params p) {
     } else if constexpr (DENSE) {
       // compiled-C++ statement of the same block (tw_debug_set_flags bit 3), same stage order:
       //   q_0 k_0 | per head h: v_h, [head h], q_{h+1} k_{h+1}, after an odd h the out_proj k-step of the pair
-      static_assert(NT == 3, "key tiles 0, 1 form the K = 32 part of P.V, tile 2 the K = 16 part");
+      // (NT = 3: key tiles 0, 1 form the K = 32 part of P.V, tile 2 the K = 16 part; NT = 4: tiles 2, 3 a second K = 32 part)
       BOp<NT> xb[4];
       to_bop<NT, 4>(x, xb);
       constexpr float LOG2E = 1.44269504088896340736f;
@@ -2095,7 +2105,7 @@ netblock_h3_kernel(const H3Params p) {
         {
           // scale, bias, 1 / sqrt(16) on q; fp16 hi / lo operands
           h4 qh[NT], ql[NT], kh[NT], kl[NT], vh2, vl2;
-          h8 vh01, vl01;
+          h8 vh01, vl01, vh23, vl23;
           {
             const f4 bq = *(const f4*)(sl + H3D_INB + 16 * h + 4 * g);
             const f4 bk = *(const f4*)(sl + H3D_INB + 128 + 16 * h + 4 * g);
@@ -2108,7 +2118,8 @@ netblock_h3_kernel(const H3Params p) {
               va[jt] = va[jt] * sc_in + bv;
             }
             split8(va[0], va[1], vh01, vl01);
-            split4(va[2], vh2, vl2);
+            if constexpr (NT == 4) split8(va[2], va[NT - 1], vh23, vl23);
+            else split4(va[2], vh2, vl2);
           }
           if (TW_EXPERIMENT(p.debug & 2048)) {  // timing experiment (results WRONG): no scores / softmax / P.V - what the GEMM stages alone cost
 #pragma unroll
@@ -2147,8 +2158,20 @@ netblock_h3_kernel(const H3Params p) {
               }
             sum = h3_quad_sum(sum);
             h8 ph01, pl01;
-            h4 ph2, pl2;
             split8(sc[0], sc[1], ph01, pl01);
+            if constexpr (NT == 4) {
+              // 64 keys = two K = 32 operands of the same shape: two accumulation chains, summed on the VALU
+              h8 ph23, pl23;
+              split8(sc[2], sc[NT - 1], ph23, pl23);
+              f4 oa = mfma32(vh01, ph01, (f4){0.f, 0.f, 0.f, 0.f});
+              f4 ob = mfma32(vh23, ph23, (f4){0.f, 0.f, 0.f, 0.f});
+              oa = mfma32(vh01, pl01, oa);
+              ob = mfma32(vh23, pl23, ob);
+              oa = mfma32(vl01, ph01, oa);
+              ob = mfma32(vl23, ph23, ob);
+              oh[hh][jt] = (oa + ob) * __builtin_amdgcn_rcpf(sum);
+            } else {
+            h4 ph2, pl2;
             split4(sc[2], ph2, pl2);
             // O^T[feature][query]; the K = 32 and the K = 16 part in separate accumulators (mixed-shape chains, see above)
             f4 o32 = mfma32(vh01, ph01, (f4){0.f, 0.f, 0.f, 0.f});
@@ -2158,6 +2181,7 @@ netblock_h3_kernel(const H3Params p) {
             o32 = mfma32(vl01, ph01, o32);
             o16 = mfma16(vl2, ph2, o16);
             oh[hh][jt] = (o32 + o16) * __builtin_amdgcn_rcpf(sum);
+            }
           }
         }
         if (h + 1 < p.H) {
@@ -2682,7 +2706,7 @@ int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms) {
   int64_t b = 0;
   for (int layout = 0; layout < 3; ++layout)
     if (d.variant == 0 ? (layout == 0 ? h3_narrow_ok(d, n_atoms) : layout == 1 ? h3_wide_ok(n_atoms) : h3_nt4_ok(d, n_atoms, false))
-                       : layout == 0) {
+                       : (layout == 0 ? !h3_nt4_ok(d, n_atoms, false) : layout == 2 && h3_nt4_ok(d, n_atoms, false))) {
       const int64_t x = h3_ws(d, n_rows, n_atoms, nullptr, false, layout).bytes;
       if (x > b) b = x;
     }
@@ -2764,6 +2788,10 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
     TW_REQUIRE(d.variant == 0 && !per_section && !cpp, "paired 64-token layout: the encoder-stack statement only");
     if (h1) H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, true, false, true, true, false);
     else H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, true, false, true, false, false);
+  } else if (!wide && fg.nt == H3N4_NT && d.variant == 1) {
+    // r05: the dense softmax model on one molecule of 49-64 atoms per wave (MLP sections asm, attention block compiled C++)
+    TW_REQUIRE(!h1 && d.d_rff == 0, "dense model on 64-token waves: the split-fp16 build without position features");
+    H3_LAUNCH(H3D4_LDS_BYTES, 4, true, true, false, false, false, false, false);
   } else if (!wide && fg.nt == H3N4_NT) {
     TW_REQUIRE(d.variant == 0, "64-token waves: kernel attention");
     if (h1 && per_section) H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, false, false, false, true, false);
