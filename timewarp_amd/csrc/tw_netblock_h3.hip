@@ -2063,6 +2063,16 @@ netblock_h3_kernel(const H3Params p) {
       // (NT = 3: key tiles 0, 1 form the K = 32 part of P.V, tile 2 the K = 16 part; NT = 4: tiles 2, 3 a second K = 32 part)
       BOp<NT> xb[4];
       to_bop<NT, 4>(x, xb);
+      if constexpr (NT == 4) {
+        // 64-token waves: x (128 fp32 registers per lane, needed again only for the residual behind the block) waits in the
+        // wave-private LDS block, which nothing uses while this compiled block runs - x + y + xb + the head's operands do not
+        // fit 512 registers, and what hipcc spilled instead cost the block 75 % (section profile: 142 k cycles per layer)
+        char* priv = (char*)xt_hi;
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) *(f4*)(priv + (ft * NT + jt) * 1024 + lane * 16) = x[ft][jt];
+      }
       constexpr float LOG2E = 1.44269504088896340736f;
       f4 qa[NT], ka[NT], va[NT];
       f4 oh[2][NT];
@@ -2206,6 +2216,13 @@ netblock_h3_kernel(const H3Params p) {
             pipe.advance();
           }
         }
+      }
+      if constexpr (NT == 4) {
+        const char* priv = (const char*)xt_hi;
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) x[ft][jt] = *(const f4*)(priv + (ft * NT + jt) * 1024 + lane * 16);
       }
       stamp(40 + 4 * l + 1);
     } else if constexpr (ASM_ATT) {
