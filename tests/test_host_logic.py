@@ -386,6 +386,9 @@ def test_generated_asm_includes_are_current(tmp_path):
                  ["tools/gen_h3_ffn_asm.py", "--shape=in", "--h1"], ["tools/gen_h3_ffn_asm.py", "--shape=out", "--h1"],
                  ["tools/gen_h3_enc_asm.py", "--h1"], ["tools/gen_h3_enc_asm.py", "--mode=windowed", "--h1"],
                  ["tools/gen_h3_ffn_asm.py", "--shape=ffn", "--h1"], ["tools/gen_h3_attn_wide_asm.py", "--h1"],
+                 # ... on the six-slot ring (one barrier per pair of FFN stages): tw_h1r_*
+                 ["tools/gen_h3_ffn_asm.py", "--shape=in", "--h1", "--ring6"], ["tools/gen_h3_ffn_asm.py", "--shape=out", "--h1", "--ring6"],
+                 ["tools/gen_h3_enc_asm.py", "--h1", "--ring6"], ["tools/gen_h3_enc_asm.py", "--mode=windowed", "--h1", "--ring6"],
                  # wide layout, 65-96 atoms at the 96-slot stride: three-group windows, tw_h?_attns3_*
                  ["tools/gen_h3_attn_wide_asm.py", "--ng=3"], ["tools/gen_h3_attn_wide_asm.py", "--ng=3", "--h1"],
                  # ... 161-192 atoms, one molecule per workgroup: six-group windows, tw_h?_attns6_*
@@ -408,7 +411,7 @@ def test_generated_asm_includes_are_current(tmp_path):
         subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
                        stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 76
+    assert len(names) == 83
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n

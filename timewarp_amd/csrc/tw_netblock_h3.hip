@@ -53,6 +53,14 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define H3_SIDE_LDS_OFFSET (H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS)
 #define H3_SIDE_LDS_BYTES 3072        // three 1 KiB LDS-DMA chunks (the block is 2624 B; the rest of LDS up to 160 KiB)
 #define H3_LDS_BYTES (H3_SIDE_LDS_OFFSET + H3_SIDE_LDS_BYTES)
+// instantiations on the six-slot ring (netblock_h3_kernel R6): + one stage buffer = 153 KiB
+// (-DTW_H1_RING5: A/B builds of the five-slot arrangement, tools/ab_ring6.sh)
+#ifdef TW_H1_RING5
+#define H3_R6(NT, DENSE, WIDE, RFF, ENC, H1) false
+#else
+#define H3_R6(NT, DENSE, WIDE, RFF, ENC, H1) ((ENC) && (H1) && (NT) == 3 && !(DENSE) && !(WIDE) && !(RFF))
+#endif
+#define H3_R6_LDS_BYTES (H3_LDS_BYTES + H3_STAGE_BYTES)
 // 64-token waves (NT = 4): one molecule of 49 .. 64 atoms per wave, so BASELINE config 3 (60 atoms x 512 proposals) is 128
 // workgroups per net = ONE round of the chip instead of the wide layout's 1.34.  The wave-private block grows to 32 KiB (the
 // 128 x 64 transposed tile, hi + lo; equally the 32 register images the sections exchange), which leaves room for a ring of
@@ -352,6 +360,8 @@ __device__ __forceinline__ void store_pair(char* pair, int lane, int e, float v)
   ((_Float16*)(pair + 1024 + lane * 16))[e] = lo;
 }
 
+__global__ void h3_unit_scale_kernel(float* __restrict__ up, float* __restrict__ down) { up[0] = down[0] = 1.0f; }
+
 // tile pairs ordered ot-major over (n_ot, n_ks); src row-major [rows, cols] (ld)
 // h1: hi tiles only, 1 KiB each, in the same (ot, ks) order
 __global__ void h3_pack_block_kernel(const float* __restrict__ src, int ld, int rows_valid, int cols_valid, int row0,
@@ -533,6 +543,13 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         st += (int64_t)(h1 ? 4 : 8) * d.n_heads * H3_STAGE_BYTES;
         }
         if ((rc = absmax(lb + L.layer.w1, (int64_t)d.d_ff * 128, up, lsc + 1))) return rc;
+        if (h1) {
+          // Fast mode: W1 goes in UNSCALED (there is no lo half whose exponent range the scale protects), so the hidden
+          // pre-activation is the accumulator itself and the FFN's epilogue needs neither the multiply nor - with the bias as
+          // the chain's start value - the add (tools/gen_h3_ffn_asm.py fold()).  The scale slots carry 1.0.
+          hipLaunchKernelGGL(h3_unit_scale_kernel, dim3(1), dim3(1), 0, s, up, lsc + 1);
+          TW_LAUNCH_CHECK();
+        }
         const int fa = h1 ? 1 : 2;  // A stages per chunk of the FFN / out-MLP (h1: both o in one stage, tile 4 o + ks)
         for (int ch = 0; ch < g.ff_chunks; ++ch)
           for (int o = 0; o < fa; ++o) {
@@ -1273,12 +1290,17 @@ netblock_h3_kernel(const H3Params p) {
   // (dense model at 64 tokens: the generated softmax block exists for 48 tokens only - r03 measured the compiled block within
   // 0.4 % of it in wall time - so that instantiation runs the MLP sections as asm and the attention block as compiled C++)
   constexpr bool ASM_IO = ASM, ASM_ATT = ASM && !(DENSE && NT == 4);
-  constexpr int RING = NT == 4 ? H3N4_RING : H3_RING;
+  // Six stage buffers and one barrier per PAIR of FFN stages (tools/gen_h3_ffn_asm.py --ring6) where the LDS has the 9 KiB:
+  // the 48-token kernel-attention layout.  Built for the fast mode's encoder-stack build, whose 24-MFMA stages pay most per
+  // hand-off.  The stream, the five stages requested ahead and the prologue are the five-slot ring's.
+  constexpr bool R6 = H3_R6(NT, DENSE, WIDE, RFF, ENC, H1);
+  constexpr int RING = NT == 4 ? H3N4_RING : (R6 ? H3_RING + 1 : H3_RING);
   constexpr int XT_IMG = NT == 4 ? H3N4_XT_IMG : H3_XT_IMG;
   constexpr int SF_BYTES = NT == 4 ? H3N4_SF_BYTES : H3_SF_BYTES;
   constexpr int WAVE_LDS = NT == 4 ? H3N4_WAVE_LDS : (DENSE ? H3D_WAVE_LDS : (WIDE ? H3W_WAVE_LDS : H3_WAVE_LDS));
   constexpr int SIDE_LDS_OFFSET = NT == 4 ? H3N4_SIDE_LDS_OFFSET
-                                          : (DENSE ? H3D_SIDE_LDS_OFFSET : (WIDE ? H3W_SIDE_LDS_OFFSET : H3_SIDE_LDS_OFFSET));
+                                          : (DENSE ? H3D_SIDE_LDS_OFFSET : (WIDE ? H3W_SIDE_LDS_OFFSET
+                                                                                  : H3_SIDE_LDS_OFFSET + (R6 ? H3_STAGE_BYTES : 0)));
   constexpr int SIDE_CHUNKS = DENSE ? 5 : 3;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1574,6 +1596,14 @@ netblock_h3_kernel(const H3Params p) {
             :
 #include "tw_h3n4_in_clobbers.inc"
         );
+      } else if constexpr (R6) {
+        asm volatile(
+#include "tw_h1r_in_asm.inc"
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+            :
+#include "tw_h1r_in_clobbers.inc"
+        );
       } else if constexpr (H1) {
         asm volatile(
 #include "tw_h1_in_asm.inc"
@@ -1856,6 +1886,31 @@ netblock_h3_kernel(const H3Params p) {
 #include "tw_h3n4_enc_clobbers.inc"
         );
       }
+    } else
+    if constexpr (R6) {
+    if (p.windowed) {
+      asm volatile(
+#include "tw_h1r_encw_asm.inc"
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+            [layers] "s"(layers), [sf] "v"(sfp), [sfstride] "s"(sfstride), [side] "v"(sidep), [sidestride] "s"(sidestride),
+            [sl] "s"(sl_lds), [scales] "s"(scp), [eps] "s"(eps), [padm] "v"(padmask), [padt] "s"(pad_tiles),
+            [dump] "v"(stamp_base), [stampen] "s"(stampen)
+          :
+#include "tw_h1r_enc_clobbers.inc"
+      );
+    } else {
+      asm volatile(
+#include "tw_h1r_enc_asm.inc"
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [heads] "s"(heads), [chunks] "s"(chunks),
+            [layers] "s"(layers), [sf] "v"(sfp), [sfstride] "s"(sfstride), [side] "v"(sidep), [sidestride] "s"(sidestride),
+            [sl] "s"(sl_lds), [scales] "s"(scp), [eps] "s"(eps), [padm] "v"(padmask), [padt] "s"(pad_tiles),
+            [dump] "v"(stamp_base), [stampen] "s"(stampen)
+          :
+#include "tw_h1r_enc_clobbers.inc"
+      );
+    }
     } else
     if constexpr (H1) {
     if (p.windowed) {
@@ -2588,6 +2643,14 @@ netblock_h3_kernel(const H3Params p) {
             :
 #include "tw_h3n4_out_clobbers.inc"
         );
+      } else if constexpr (R6) {
+        asm volatile(
+#include "tw_h1r_out_asm.inc"
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+            :
+#include "tw_h1r_out_clobbers.inc"
+        );
       } else if constexpr (H1) {
         asm volatile(
 #include "tw_h1_out_asm.inc"
@@ -2830,7 +2893,7 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
       else H3_LAUNCH(H3W_LDS_BYTES, 3, true, false, true, false, true, true, false);
     } else {
       TW_REQUIRE(dump == nullptr || (g_debug_flags & 16), "single-MFMA path: no activation dumps (section stamps only)");
-      H3_LAUNCH(H3_LDS_BYTES, 3, true, false, false, false, true, true, false);
+      H3_LAUNCH(H3_R6(3, false, false, false, true, true) ? H3_R6_LDS_BYTES : H3_LDS_BYTES, 3, true, false, false, false, true, true, false);
     }
   } else if (wide) {
     // r05: the wide layout's encoder stack as one statement (tools/gen_h3_enc_asm.py --wide [--ng=3|6]): no compiled glue, no scratch

@@ -43,7 +43,12 @@ NT4 = "--nt=4" in sys.argv
 PAIR = "--pair" in sys.argv
 assert not PAIR or NT4
 NT = 4 if NT4 else 3
-RING = 3 if NT4 else 5
+AHEAD = 3 if NT4 else 5    # stages requested ahead of the one being read
+# --ring6: six stage buffers, a hand-off refills the slot of the stage BEFORE the current one (gen_h3_ffn_asm.py R6; every stage
+# of this block keeps its barrier - the FFN is where stages pair up)
+R6 = "--ring6" in sys.argv
+assert not (R6 and NT4)
+RING = AHEAD + (1 if R6 else 0)
 STAGE, TILES = 9216, 8192
 # Transposed copy of x in the wave-private block (csrc: "x -> transposed", H3_XT_IMG): per feature tile ft and part
 # (hi, lo) one 1536-byte image = [T0 | T1] 16 B per lane (K = 32 operand) + T2 8 B per lane (K = 16 operand); every lane
@@ -263,11 +268,11 @@ def handoff(next_reads, label, aux_cnt=1):
         f"s_add_u32 s{S_OFF}, s{S_OFF}, {STAGE}",
         [f"s_cmp_eq_u32 s{S_OFF}, s{S_END}", f"s_cselect_b32 s{S_OFF}, %[ring], s{S_OFF}"],
     ]
+    if R6:   # s{S_REL} is persistent: the slot of the stage before this one is the one refilled
+        h = [f"s_add_u32 m0, s{S_REL}, s{S_W2048}"] + h
     if next_reads:
         h += [f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}"] + tile_reads(0) + tile_reads(1)
-    h += [
-        f"s_add_u32 m0, s{S_REL}, s{S_W2048}",
-        "s_nop 0",
+    h += ([] if R6 else [f"s_add_u32 m0, s{S_REL}, s{S_W2048}", "s_nop 0"]) + [
         f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off",
         f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off offset:1024",
         # Only the FFN's A0 stages carry a bias/scale block; the hand-offs that fetch them (five ahead) all belong to the
@@ -277,7 +282,7 @@ def handoff(next_reads, label, aux_cnt=1):
          f"s_cmp_lg_u32 s{S_CNT}, 1" if aux_cnt == 1 else f"s_cmp_gt_u32 s{S_CNT}, {aux_cnt}",
          f"s_cbranch_scc1 .Lh3att_noaux_{label}_%=",
          f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
-         f"s_add_u32 m0, s{S_REL}, {TILES}",
+         f"s_add_u32 m0, m0, {TILES}" if R6 else f"s_add_u32 m0, s{S_REL}, {TILES}",   # (R6: wave 0's share offset is 0)
          "s_nop 0",
          f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off",
          f".Lh3att_noaux_{label}_%=:"],
@@ -433,6 +438,10 @@ def generate():
     A(f"v_lshl_add_u64 {vr(V_GN, 2)}, %[gn], 0, s[{S_W2048}:{S_W2048 + 1}]")
     A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
     A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
+    if R6:   # the slot before the current one
+        A("s_cmp_eq_u32 %[cur], 0")
+        A(f"s_cselect_b32 s{S_REL}, s{S_END}, s{S_OFF}")
+        A(f"s_sub_u32 s{S_REL}, s{S_REL}, {STAGE}")
     A(f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}")
     if not FUSED:
         for i in range(N_A):
@@ -461,7 +470,7 @@ def generate():
                 # head (the buffer has one head of slack): the s_waitcnt vmcnt counts below assume these loads.
                 L += sf_loads()
             n_sf = (2 if H1 else 4) * NT * (2 if PAIR else 1) if NT4 else sum((3 if tail else 2) - (1 if H1 else 0) for _, tail in sf_tiles())
-            base_vm = 2 * (RING - 2)          # stages s + 2 .. s + RING - 1 may stay in flight, two DMAs each
+            base_vm = 2 * (AHEAD - 2)         # stages s + 2 .. s + AHEAD - 1 may stay in flight, two DMAs each
             vm = n_sf + base_vm if ks == 2 else base_vm   # the fragment loads (full: 9, windowed: 7) sit in the same queue behind the stage DMAs
         else:
             # mixing of (h + 1, 0): needs the new score fragments; skipped after the last head.  Newer than the
@@ -472,7 +481,7 @@ def generate():
             A("s_waitcnt vmcnt(2)" if H1 else "s_waitcnt vmcnt(4)")   # H1: one hand-off (2 DMAs) is newer than the fragment loads
             L += mixing_part(0, True)
             A(".Lh3att_nomix_%=:")
-            vm = 2 * (RING - 2)
+            vm = 2 * (AHEAD - 2)
         split = split_ops(nbuf)
         nxt = (ks + 2) % 4   # k-step whose mixing runs at the start of the next step
         if H1:

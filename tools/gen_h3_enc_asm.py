@@ -86,6 +86,10 @@ WIDE = "--wide" in sys.argv
 # With --h1 the MLP sections are the single-MFMA ones, the attention block stays in split form (csrc: "MLP sections only").
 DENSE = "--dense" in sys.argv
 STATELESS = NT4 or WIDE or DENSE  # the glue keeps nothing in VGPRs across the embedded blocks; pointers in SGPRs
+# --ring6 (48-token kernel-attention build only - the one layout with 9 KiB of LDS to spare): six stage buffers, the FFN's
+# stages pair up under one barrier (gen_h3_ffn_asm.py R6; the embedded generators read the same flag)
+R6 = "--ring6" in sys.argv
+assert not (R6 and STATELESS)
 EXPERIMENT = set(filter(None, os.environ.get("H3_ENC_EXPERIMENT", "").split(",")))
 # The section stamps are compiled into every statement (r05; r04: the fast-mode ones only): five scalar compare-and-branch
 # pairs per layer when off.  bench.py reads the attention block's share of a launch from the PRODUCT build that way
@@ -823,8 +827,9 @@ def main():
             out_dir = a.split("=", 1)[1]
     ng = getattr(attn, "NG", 5)
     mode = (" --mode=windowed" if WINDOWED else "") + (" --nt=4" if NT4 else "") + (" --pair" if PAIR else "") + \
-        ((" --wide" + (f" --ng={ng}" if ng != 5 else "")) if WIDE else "") + (" --dense" if DENSE else "") + (" --h1" if H1 else "")
-    fam = ("h1" if H1 else "h3") + ("n4" if NT4 else "") + ("p" if PAIR else "") + ((f"w{ng}" if ng != 5 else "w") if WIDE else "") + ("d" if DENSE else "")
+        ((" --wide" + (f" --ng={ng}" if ng != 5 else "")) if WIDE else "") + (" --dense" if DENSE else "") + (" --h1" if H1 else "") + \
+        (" --ring6" if R6 else "")
+    fam = ("h1" if H1 else "h3") + ("r" if R6 else "") + ("n4" if NT4 else "") + ("p" if PAIR else "") + ((f"w{ng}" if ng != 5 else "w") if WIDE else "") + ("d" if DENSE else "")
     base = os.path.join(out_dir, f"tw_{fam}_encw_asm.inc" if WINDOWED else f"tw_{fam}_enc_asm.inc")
     out = [f"// GENERATED by tools/gen_h3_enc_asm.py{mode} - do not edit.  Body of the encoder-stack asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]

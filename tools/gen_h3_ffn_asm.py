@@ -22,8 +22,8 @@ import os
 import sys
 
 # experiments: comma-separated flags in H3_FFN_EXPERIMENT.  noepi, nobarrier, nodma: timing only (results become wrong).
-# pairsync: one barrier per PAIR of stages, both slots refilled after it - correct, but measured 2.5 % slower (the
-# refill then runs only two stages ahead of its use and the LDS-DMA latency shows).
+# (r01's `pairsync` - one barrier per pair of stages on the five-slot ring, both slots refilled after it - measured 2.5 %
+# slower: the refill ran two stages ahead of its use.  --ring6 below is the version with the slack to afford it.)
 EXPERIMENT = set(filter(None, os.environ.get("H3_FFN_EXPERIMENT", "").split(",")))
 # FFN: the epilogue of chunk c + 1 (96 VALU ops) is spread over the second A stage of chunk c + 1 and both B stages of
 # chunk c, in gaps that hold nothing else (`nospread`: the r01 placement - all of it in the B stages, beside the LDS
@@ -50,7 +50,16 @@ H1 = "--h1" in sys.argv
 NT4 = "--nt=4" in sys.argv
 
 NT = 4 if NT4 else 3
-RING = 3 if NT4 else 5
+AHEAD = 3 if NT4 else 5    # stages requested ahead of the one being read (two LDS-DMA pieces per wave each)
+# --ring6 (48-token waves only: the LDS has 9 KiB to spare there): a ring of SIX stage buffers and ONE workgroup barrier per
+# PAIR of stages.  A hand-off refills the slot of the stage BEFORE the current one (with the same stage of the stream as the
+# five-slot ring: five ahead), so a "light" stage - no barrier, no DMA wait - is legal right behind a "heavy" one whose
+# barrier (a) saw every wave finish its reads of the stage before it and (b) had every wave wait for its shares of the NEXT
+# TWO stages (vmcnt one stage tighter).  The DMA issue stays spread one stage's share per stage; what halves is the number of
+# barriers - on the fast mode's 24-MFMA stages the hand-off was 30 % of a stage (tools/probe/h1_stage_probe.hip).
+R6 = "--ring6" in sys.argv
+assert not (R6 and NT4)
+RING = AHEAD + (1 if R6 else 0)
 # Shapes of the three chunked MLPs (same schedule, one generated file each):
 #   ffn : 128 -> 32-unit chunk (ReLU) -> 128     A = 2 stages (o = 0, 1; 4 k-steps),  B = 2 stages (ot 0-3, 4-7)
 #   in  :  64 -> 32-unit chunk (SiLU) -> 128     A = 1 stage  (pairs = o x 2 k-steps), B = 2 stages
@@ -84,7 +93,6 @@ if NT4:
     HACC = lambda o, jt: 64 + 4 * (4 * o + jt)
     N_VGPR, N_AGPR = 224, 192
 S_SC = 95
-S_PREV = 93   # pair-sync: slot of the first stage of a pair, released together with the second
 S_ROT = 83    # auxrot: the wave that moves the next bias/scale block (rotates 0..3 so no wave is always the slowest)
 # scratch SGPRs (clobbered)
 S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_CNT = 84, 85, 86, 88, 90, 92, 94  # pairs are even-aligned
@@ -99,10 +107,20 @@ def ar(base, n=4):
     return f"a[{base}:{base + n - 1}]"
 
 
-def mfma(d, a, b, zero=False, dst="a", bsrc="v"):
+def mfma(d, a, b, zero=False, dst="a", bsrc="v", seed=None):
+    """`seed`: VGPR quad the chain starts from instead of zero (the folded bias of the fast mode's FFN)."""
     dd = ar(d) if dst == "a" else vr(d)
     bb = ar(b) if bsrc == "a" else vr(b)
-    return f"v_mfma_f32_16x16x32_f16 {dd}, {vr(a)}, {bb}, {'0' if zero else dd}"
+    return f"v_mfma_f32_16x16x32_f16 {dd}, {vr(a)}, {bb}, {(vr(seed) if seed is not None else '0') if zero else dd}"
+
+
+def fold():
+    """Fast mode, ReLU shape (the FFN): W1 is packed UNSCALED (no lo half to keep normal: h3_pack_weights), so the hidden
+    pre-activation is the accumulator itself once the chain starts from the bias (the MFMA's C operand) - the epilogue of a
+    unit is two packs and the ReLU on the packed pairs, 4 VALU ops instead of 8.  The deletion matrix of the six-slot-ring
+    build put 13 % of the FFN into those 8 (profiles/r05_h1_ffn_deletion_matrix.txt).  The bias quads are read by the
+    hand-off in front of an A stage (nothing else reads them any more)."""
+    return H1 and not SHAPE["silu"]
 
 
 def pair_mfmas(acc_of_jt, slot, bop_of_jt, first=False, dst="a", bsrc="v"):
@@ -140,9 +158,11 @@ def epi_unit(o, jt, buf, relu=True, tset=None):
     hh = HB(buf, jt, "h") + 2 * o
     ll = HB(buf, jt, "l") + 2 * o
     if H1:
-        # no lo half; ReLU after the rounding (max(rne(v), 0) == rne(max(v, 0))) on the packed pair: 8 ops per unit
+        # no lo half; ReLU after the rounding (max(rne(v), 0) == rne(max(v, 0))) on the packed pair: 8 ops per unit ...
         if not SHAPE["silu"]:
             ops = ops[:4]
+        if fold():   # ... 4 with the bias in the chain's start value and W1 unscaled
+            ops, t = [], [src(r) for r in range(4)]
         ops += [f"v_cvt_pk_f16_f32 v{hh}, v{t[0]}, v{t[1]}", f"v_cvt_pk_f16_f32 v{hh + 1}, v{t[2]}, v{t[3]}"]
         if not SHAPE["silu"]:
             ops += [f"v_pk_max_f16 v{hh}, v{hh}, 0", f"v_pk_max_f16 v{hh + 1}, v{hh + 1}, 0"]
@@ -164,11 +184,18 @@ def tile_reads(pair):
 
 def aux_reads():
     return [f"ds_read_b128 {vr(BIAS(0))}, v{V_AUX} offset:{TILES}",
-            f"ds_read_b128 {vr(BIAS(1))}, v{V_AUX} offset:{TILES + 64}",
-            f"ds_read_b32 v{V_SC}, v{V_SCADDR} offset:{TILES + 128}"]
+            f"ds_read_b128 {vr(BIAS(1))}, v{V_AUX} offset:{TILES + 64}"] + \
+           ([] if fold() else [f"ds_read_b32 v{V_SC}, v{V_SCADDR} offset:{TILES + 128}"])
 
 
-def handoff(next_reads, with_aux, label):
+def next_stage_reads(next_bias):
+    r = []
+    if next_bias:   # fold(): the next stage is an A stage - its bias quads seed its first MFMAs (in front of the tiles:
+        r += [f"v_add_u32 v{V_AUX}, s{S_OFF}, v{V_G16}"] + aux_reads()   # the stage's entry wait counts from the end)
+    return r + [f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}"] + tile_reads(0) + tile_reads(1)
+
+
+def handoff(next_reads, with_aux, label, next_bias=False):
     """Everything after the stage barrier: advance the ring, start reading the next stage, refill the
     released slot by LDS-DMA.  A list of items to be woven between MFMAs in order; an item that is itself
     a list is atomic (the wave-0-only branch).  `with_aux`: the stage being fetched (5 ahead) may carry a
@@ -180,12 +207,12 @@ def handoff(next_reads, with_aux, label):
         f"s_add_u32 s{S_OFF}, s{S_OFF}, {STAGE}",
         [f"s_cmp_eq_u32 s{S_OFF}, s{S_END}", f"s_cselect_b32 s{S_OFF}, %[ring], s{S_OFF}"],
     ]
+    if R6:
+        # six-slot ring: s{S_REL} is persistent = the slot of the stage before this one, which is what gets refilled
+        h = [f"s_add_u32 m0, s{S_REL}, s{S_W2048}"] + h
     if next_reads:
-        h += [f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}"]
-        h += tile_reads(0) + tile_reads(1)
-    h += [
-        f"s_add_u32 m0, s{S_REL}, s{S_W2048}",
-        f"s_nop 0",
+        h += next_stage_reads(next_bias)
+    h += ([] if R6 else [f"s_add_u32 m0, s{S_REL}, s{S_W2048}", "s_nop 0"]) + [
         f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off",
         f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off offset:1024",
     ]
@@ -203,7 +230,8 @@ def handoff(next_reads, with_aux, label):
         h += [[f"s_cmp_lg_u32 %[wave], {who}",
                f"s_cbranch_scc1 .Lh3mlp_noaux_{label}_%="] + tail_only + [
                f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
-               f"s_add_u32 m0, s{S_REL}, {TILES}",
+               # (six-slot ring: m0 still holds the refilled slot + this wave's share offset, and this is wave 0: offset 0)
+               f"s_add_u32 m0, m0, {TILES}" if R6 else f"s_add_u32 m0, s{S_REL}, {TILES}",
                "s_nop 0",
                f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off",
                f".Lh3mlp_noaux_{label}_%=:"]]
@@ -211,47 +239,22 @@ def handoff(next_reads, with_aux, label):
     return h
 
 
-def handoff_light(label):
-    """Pair-sync, first stage of a pair: no barrier and no refill - remember the slot, move on, start reading the
-    partner stage (its DMA shares landed before the previous pair's barrier)."""
-    return [
-        f"s_mov_b32 s{S_PREV}, s{S_OFF}",
-        f"s_add_u32 s{S_OFF}, s{S_OFF}, {STAGE}",
-        [f"s_cmp_eq_u32 s{S_OFF}, s{S_END}", f"s_cselect_b32 s{S_OFF}, %[ring], s{S_OFF}"],
-        f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}",
-    ] + tile_reads(0) + tile_reads(1)
+def sync(light, before_light):
+    """The middle of a stage.  Heavy: every read of this slot has returned, this wave's shares of the next stage (six-slot ring,
+    in front of a light stage: of the next two) have landed, workgroup barrier.  Light (six-slot ring only): the stage before
+    did all of that for this one as well."""
+    if light:
+        assert R6
+        return ["s_waitcnt lgkmcnt(0)"]
+    out = [f"s_waitcnt vmcnt({2 * (AHEAD - (3 if before_light else 2))}) lgkmcnt(0)"]
+    if "nobarrier" not in EXPERIMENT:
+        out.append("s_barrier")
+    return out
 
 
-def handoff_heavy(next_reads, label):
-    """Pair-sync, second stage of a pair (after the barrier): both slots of the pair are refilled."""
-    h = [
-        f"s_mov_b32 s{S_REL}, s{S_OFF}",
-        f"s_add_u32 s{S_OFF}, s{S_OFF}, {STAGE}",
-        [f"s_cmp_eq_u32 s{S_OFF}, s{S_END}", f"s_cselect_b32 s{S_OFF}, %[ring], s{S_OFF}"],
-    ]
-    if next_reads:
-        h += [f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}"] + tile_reads(0) + tile_reads(1)
-    for k, slot in enumerate((S_PREV, S_REL)):
-        h += [
-            f"s_add_u32 m0, s{slot}, s{S_W2048}",
-            "s_nop 0",
-            f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off",
-            f"global_load_lds_dwordx4 {vr(V_GN, 2)}, off offset:1024",
-            ["s_cmp_lg_u32 %[wave], 0",
-             f"s_cbranch_scc1 .Lh3mlp_noaux_{label}{k}_%=",
-             f"v_lshl_add_u64 {vr(V_TMP, 2)}, {vr(V_GN, 2)}, 0, s[{S_AUXOFF}:{S_AUXOFF + 1}]",
-             f"s_add_u32 m0, s{slot}, {TILES}",
-             "s_nop 0",
-             f"global_load_lds_dwordx4 {vr(V_TMP, 2)}, off",
-             f".Lh3mlp_noaux_{label}{k}_%=:"],
-            f"v_lshl_add_u64 {vr(V_GN, 2)}, {vr(V_GN, 2)}, 0, s[{S_STRIDE}:{S_STRIDE + 1}]",
-        ]
-    return h
-
-
-def weave(mfmas, valu, misc, valu_per=2, misc_per=2):
-    """Each MFMA is followed by up to `valu_per` VALU ops and `misc_per` other items, spread so the queues
-    empty by the last MFMA (leftovers are appended)."""
+def weave(mfmas, valu, misc, valu_per=2, misc_per=2, skip=0):
+    """Each MFMA (after the first `skip`) is followed by up to `valu_per` VALU ops and `misc_per` other items, spread so
+    the queues empty by the last MFMA (leftovers are appended)."""
     out = []
     valu, misc = list(valu), list(misc)
     n = len(mfmas)
@@ -261,6 +264,8 @@ def weave(mfmas, valu, misc, valu_per=2, misc_per=2):
 
     for i, m in enumerate(mfmas):
         out.append(m)
+        if i < skip:
+            continue
         left = n - i
         for _ in range(min(valu_per, -(-len(valu) // left)) if valu else 0):
             emit(valu.pop(0))
@@ -308,13 +313,13 @@ def place_valu(lines, valu, cap_empty=2, skip_gaps=0):
     return out
 
 
-def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
+def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0, light=False, before_light=False, next_is_a=False):
     """One 4-pair stage.  kind 'A': hacc[o] += W1tile . xb[ks] (ks_in = 4: stage = one o, pairs = k-steps; ks_in = 2:
     the single A stage holds both o, pair = 2 o + ks);  kind 'B': yacc[4b+p] += W2tile(p) . hb (pairs beyond ot_out
     do not exist: no MFMAs, no tile reads)."""
     ks_in, ot_out = SHAPE["ks_in"], SHAPE["ot_out"]
     if H1:
-        return stage_h1(kind, hb_cur, epi_ops, next_reads, with_aux, label)
+        return stage_h1(kind, hb_cur, epi_ops, next_reads, with_aux, label, light, before_light, next_is_a)
     groups = []
     for p in range(4):
         if kind == "A":
@@ -343,21 +348,8 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     out += weave(groups[0], parts[0], first_misc, misc_per=3)
     out.append(f"s_waitcnt lgkmcnt({2 + aux})" if aux else "s_waitcnt lgkmcnt(2)")
     out += weave(groups[1], parts[1], tile_reads(3) if live[3] else [])
-    pairsync = "pairsync" in EXPERIMENT and SHAPE["tag"] == "ffn"
-    if pairsync and o_or_b == 0:
-        out.append("s_waitcnt lgkmcnt(0)")
-        h = handoff_light(label)
-    elif pairsync:
-        # the two stages of the next pair must have landed; one younger stage may be in flight (2 DMAs, 3 for wave 0)
-        out += ["s_cmp_eq_u32 %[wave], 0", f"s_cbranch_scc1 .Lh3mlp_w0_{label}_%=", "s_waitcnt vmcnt(2) lgkmcnt(0)",
-                f"s_branch .Lh3mlp_w1_{label}_%=", f".Lh3mlp_w0_{label}_%=:", "s_waitcnt vmcnt(3) lgkmcnt(0)",
-                f".Lh3mlp_w1_{label}_%=:", "s_barrier"]
-        h = handoff_heavy(next_reads, label)
-    else:
-        out.append(f"s_waitcnt vmcnt({2 * (RING - 2)}) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
-        if "nobarrier" not in EXPERIMENT:
-            out.append("s_barrier")
-        h = handoff(next_reads, with_aux, label)
+    out += sync(light, before_light)   # all my reads of this slot returned; next stage's DMA share landed
+    h = handoff(next_reads, with_aux, label)
     if is_a0:
         h = [f"v_readfirstlane_b32 s{S_SC}, v{V_SC}"] + h   # aux block landed (lgkmcnt(0) above)
     out += weave(groups[2], parts[2], h, misc_per=3)
@@ -367,7 +359,7 @@ def stage(kind, o_or_b, hb_cur, epi_ops, next_reads, with_aux, label, is_a0):
     return out
 
 
-def stage_h1(kind, hb_cur, epi_ops, next_reads, with_aux, label):
+def stage_h1(kind, hb_cur, epi_ops, next_reads, with_aux, label, light=False, before_light=False, next_is_a=False):
     """One 8-tile stage of the single-MFMA variant.  kind 'A' (always carries the chunk's bias / scale block):
     ks_in = 4: pair p = tiles (o = p // 2, ks = 2 (p % 2) + j), so hacc[0] is complete after pair 1 and its epilogue units
     (`epi_ops`) run under pairs 2, 3; ks_in = 2: pairs 0, 1 = tiles (o = p, ks = j), pairs 2, 3 do not exist.
@@ -384,14 +376,15 @@ def stage_h1(kind, hb_cur, epi_ops, next_reads, with_aux, label):
                     o, ks = p, j
                 else:
                     continue
-                g += [mfma(HACC(o, jt), SLOT(p, part), XB(ks, jt, "h"), zero=(ks == 0), dst="v", bsrc=XB_SRC(ks)) for jt in range(NT)]
+                g += [mfma(HACC(o, jt), SLOT(p, part), XB(ks, jt, "h"), zero=(ks == 0), dst="v", bsrc=XB_SRC(ks),
+                           seed=BIAS(o) if fold() else None) for jt in range(NT)]
             else:
                 ot = 2 * p + j
                 if ot < ot_out:
                     g += [mfma(YACC(ot, jt), SLOT(p, part), HB(hb_cur, jt, "h")) for jt in range(NT)]
         groups.append(g)
     live = [bool(g) for g in groups]
-    is_a0 = kind == "A"
+    is_a0 = kind == "A" and not fold()   # (fold(): the bias quads came with the hand-off before this stage, no scale)
     aux = 3 if is_a0 else 0
     epi = [] if "noepi" in EXPERIMENT else list(epi_ops)
     first = ["s_waitcnt lgkmcnt(2)"]
@@ -401,14 +394,15 @@ def stage_h1(kind, hb_cur, epi_ops, next_reads, with_aux, label):
     first += weave(groups[0], [], first_misc, misc_per=3)
     first.append(f"s_waitcnt lgkmcnt({(2 if live[2] else 0) + aux})")
     first += weave(groups[1], [], tile_reads(3) if live[3] else [])
-    first.append(f"s_waitcnt vmcnt({2 * (RING - 2)}) lgkmcnt(0)")   # all my reads of this slot returned; next stage's DMA share landed
-    if "nobarrier" not in EXPERIMENT:
-        first.append("s_barrier")
-    h = handoff(next_reads, with_aux, label)
+    first += sync(light, before_light)   # all my reads of this slot returned; next stage's DMA share landed
+    # fold(), an A stage in front of an A stage (the prologue's): this stage's second half still starts chains from the bias
+    # quads the next stage's reads overwrite - those reads (and the tile reads behind them) wait for the last pair
+    late = fold() and next_is_a and kind == "A" and next_reads
+    h = handoff(next_reads and not late, with_aux, label, next_bias=fold() and next_is_a)
     if is_a0:
         h = [f"v_readfirstlane_b32 s{S_SC}, v{V_SC}"] + h   # aux block landed (lgkmcnt(0) above)
     second = weave(groups[2], [], h, misc_per=3)
-    second += weave(groups[3], [], [])
+    second += weave(groups[3], [], next_stage_reads(True) if late else [], skip=NT if late else 0)
     if kind == "A" and ks_in == 4:
         # epilogue of hacc[0] (complete after pair 1) under pairs 2, 3; two MFMAs of distance to its last writer
         return first + place_valu(second, epi, skip_gaps=2)
@@ -441,6 +435,11 @@ def generate():
     A(f"v_lshl_add_u64 {vr(V_GN, 2)}, %[gn], 0, s[{S_W2048}:{S_W2048 + 1}]")
     A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
     A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
+    if R6:   # the slot before the current one (the last slot of the ring in front of slot 0)
+        assert "auxrot" not in EXPERIMENT
+        A("s_cmp_eq_u32 %[cur], 0")
+        A(f"s_cselect_b32 s{S_REL}, s{S_END}, s{S_OFF}")
+        A(f"s_sub_u32 s{S_REL}, s{S_REL}, {STAGE}")
     A(f"v_add_u32 v{V_TILE}, s{S_OFF}, v{V_LANE16}")
     ks_in, ot_out = SHAPE["ks_in"], SHAPE["ot_out"]
     ffn = SHAPE["tag"] == "ffn"
@@ -462,13 +461,31 @@ def generate():
             A(f"v_accvgpr_write_b32 a{i}, 0")
         A("s_waitcnt lgkmcnt(0)")
     # first stage's reads
+    if fold():
+        A(f"v_add_u32 v{V_AUX}, s{S_OFF}, v{V_G16}")
+        for r in aux_reads():
+            A(r)
     for r in tile_reads(0) + tile_reads(1):
         A(r)
 
-    def a_stages(buf, tag, aux_of, epi_of=None):
+    def sync_mode(kind, idx, where):
+        """(light, before_light) of a stage on the six-slot ring (FFN only: the short in / out MLPs keep a barrier per stage).
+        Fast mode, A(c+1) B(c) per trip: A light, B heavy - the prologue's A(0) and the tail's B(n-1) heavy.  Split form, A0 A1 B0
+        B1 per chunk: the second stage of each pair is light.  A statement starts and may end either way: heavy stages have
+        no precondition, and nothing outside this loop is ever light."""
+        if not (R6 and ffn):
+            return dict(light=False, before_light=False)
+        if H1:
+            if "r6swap" in EXPERIMENT:   # A heavy, B light
+                return dict(light=(kind == "B" and where == "loop"), before_light=(kind == "A" and where == "loop"))
+            return dict(light=(kind == "A" and where == "loop"), before_light=(kind == "A" or where == "loop"))
+        return dict(light=(idx == 1), before_light=(idx == 0))
+
+    def a_stages(buf, tag, aux_of, epi_of=None, where="loop"):
         out = []
         for o in range(n_a):
-            out += stage("A", o, buf, epi_of[o] if epi_of else [], True, aux_of("A", o), f"{tag}a{o}", o == 0)
+            out += stage("A", o, buf, epi_of[o] if epi_of else [], True, aux_of("A", o), f"{tag}a{o}", o == 0,
+                         next_is_a=(where == "prologue"), **sync_mode("A", o, where))
         return out
 
     def b_stages(buf, tag, epi, aux_of, last=False):
@@ -476,7 +493,7 @@ def generate():
         per = -(-len(epi) // n_b)
         for b_ in range(n_b):
             out += stage("B", b_, buf, epi[b_ * per:(b_ + 1) * per], not (last and b_ == n_b - 1), aux_of("B", b_),
-                         f"{tag}b{b_}", False)
+                         f"{tag}b{b_}", False, next_is_a=not last, **sync_mode("B", b_, "tail" if last else "loop"))
         return out
 
     always = lambda kind, idx: True
@@ -502,7 +519,7 @@ def generate():
         return u_[3][4:] + u_[4][4:] + u_[5][4:]
 
     # ---- prologue: A(0), epilogue of chunk 0 (not hidden)
-    L += a_stages(0, "p", always)
+    L += a_stages(0, "p", always, where="prologue")
     A("s_nop 7")
     spread4 = ffn and SPREAD and "spread4" in EXPERIMENT
     if iotail:
@@ -609,6 +626,8 @@ def main():
     SHAPE = SHAPES[shape]
     lines = generate()
     fam, flag = ("h1n4", " --h1 --nt=4") if H1 and NT4 else ("h1", " --h1") if H1 else ("h3n4", " --nt=4") if NT4 else ("h3", "")
+    if R6:
+        fam, flag = fam + "r", flag + " --ring6"
     base = os.path.join(out_dir, f"tw_{fam}_{SHAPE['tag']}_asm.inc")
     out = [f"// GENERATED by tools/gen_h3_ffn_asm.py --shape={shape}{flag} - do not edit.  Body of the {shape} MLP asm statement",
            "// (see the generator for the register map and the schedule)."]

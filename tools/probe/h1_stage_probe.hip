@@ -40,6 +40,9 @@ __global__ void __launch_bounds__(256) k(long long* out, int idx, int iters, con
   const unsigned lane16 = lane * 16;
   int slot = 0, rslot = 0;
   const int wrap = (4 << 20) / STAGE;                       // the hi-only stream of one net: 4.2 MiB
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  u4 srd;                                                    // raw buffer over the whole source (MODE 6)
+  srd.x = (unsigned)(size_t)src; srd.y = (unsigned)((size_t)src >> 32); srd.z = 32u << 20; srd.w = 0x00020000;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\t" : "=s"(t0));
   for (int it = 0; it < iters; ++it) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane(ring + slot * STAGE + wave * SHARE);
@@ -57,7 +60,7 @@ __global__ void __launch_bounds__(256) k(long long* out, int idx, int iters, con
       asm volatile(P0("0", "") P1("1024", "") P2("2048", "") P3("3072", "") P0("4096", "") P1("5120", "") P2("6144", "") P3("7168", "") :: [tile] "v"(tile) : CLOB);
     }
     if constexpr (VALU >= 8) asm volatile(VA("76") VA("77") VA("78") VA("79") ::: "v76", "v77", "v78", "v79");
-    if constexpr (MODE == 0 || MODE == 4 || MODE == 2) {
+    if constexpr (MODE == 0 || MODE == 4 || MODE == 2 || MODE == 5 || MODE == 6) {
       if constexpr (INFLIGHT * NDMA == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
       else if constexpr (INFLIGHT * NDMA == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
       else if constexpr (INFLIGHT * NDMA == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
@@ -73,6 +76,19 @@ __global__ void __launch_bounds__(256) k(long long* out, int idx, int iters, con
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(m0v) : "memory");
       if constexpr (NDMA >= 2) asm volatile("global_load_lds_dwordx4 %0, off offset:1024" :: "v"(g) : "memory");
       if constexpr (NDMA >= 4) asm volatile("global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072" :: "v"(g) : "memory");
+    } else if constexpr (MODE == 5) {
+      // saddr form: uniform 64-bit base in an SGPR pair + one 32-bit lane offset (half the address registers per piece)
+      const char* gs = src + (size_t)(blockIdx.x & 1) * ((size_t)8 << 20) + (size_t)(it % wrap) * STAGE;
+      const unsigned voff = wave * SHARE + lane * 16;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(voff), "s"(m0v), "s"(gs) : "memory");
+      if constexpr (NDMA >= 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(voff), "s"(gs) : "memory");
+      if constexpr (NDMA >= 4) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(voff), "s"(gs) : "memory");
+    } else if constexpr (MODE == 6) {
+      // buffer form: SRD in four SGPRs, lane offset in a VGPR, stage offset in an SGPR (soffset)
+      const unsigned voff = wave * SHARE + lane * 16;
+      const unsigned soff = (unsigned)((size_t)(blockIdx.x & 1) * ((size_t)8 << 20) + (size_t)(it % wrap) * STAGE);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" :: "v"(voff), "s"(m0v), "s"(srd), "s"(soff) : "memory");
+      if constexpr (NDMA >= 2) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds" :: "v"(voff), "s"(srd), "s"(soff) : "memory");
     } else if constexpr (MODE == 4) {
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(g), "s"(m0v) : "memory");
       if constexpr (NDMA >= 2) asm volatile("global_load_lds_dwordx4 %0, off offset:1024 nt" :: "v"(g) : "memory");
@@ -163,6 +179,8 @@ int main() {
   RUN(8, 1, 0, 5, 3, "8 pairs/stage (24 MFMAs), no DMA, barrier")
   RUN(8, 0, 0, 5, 3, "8 pairs/stage, LDS-DMA 8 KiB/stage, barrier, ring 5, 3 in flight")
   RUN(8, 2, 0, 5, 3, "  ... no barrier")
+  RUN(8, 5, 0, 5, 3, "  ... saddr form (SGPR base + 32-bit lane offset)")
+  RUN(8, 6, 0, 5, 3, "  ... buffer_load ... lds (SRD + soffset)")
   RUN(8, 0, 16, 5, 3, "  ... + 16 VALU fillers")
   RUN(8, 0, 0, 5, 2, "  ... 2 in flight")
   RUN(8, 0, 0, 9, 6, "  ... ring 9, 6 in flight")
