@@ -455,9 +455,9 @@ int tw_probe_mfma_clock(int32_t workgroups, int32_t iters, int64_t* cycles, doub
   TW_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
   long long c = 0;
   TW_HIP_CHECK(hipMemcpy(&c, dev, sizeof(c), hipMemcpyDeviceToHost));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  hipFree(dev);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(dev);
   *cycles = (int64_t)c;
   *ms = (double)t;
   return TW_OK;

@@ -32,7 +32,7 @@ _lib.load().tw_debug_set_flags(16 | extra)
 for rep in range(3):
     acts, out = m.debug_netblock(0, 0, at.cuda(), xc.cuda(), x_v.cuda(), mask.cuda(), zo.cuda(), PATH)
 torch.cuda.synchronize()
-ts = acts.reshape(-1)[:128].contiguous().view(torch.int64).cpu().tolist()
+ts = acts.reshape(-1)[:160].contiguous().view(torch.int64).cpu().tolist()
 L = 3
 names = ["start", "in_mlp"]
 for l in range(L):
@@ -44,6 +44,8 @@ print(f"total {total} cycles")
 if ts[60]:
     print(f"  prologue in front of the first stamp (token bookkeeping, embedding gather, previous coupling update, first weight "
           f"stages): {t[0] - ts[60]} cycles")
+    if ts[64]:
+        print(f"    (fine: weight-stage requests {ts[64] - ts[60]}, token loop + load issue {ts[65] - ts[64]}, coupling update {ts[66] - ts[65]}, log-det {ts[61] - ts[66]})")
     if ts[61]:
         print(f"    token bookkeeping + z loads {ts[61] - ts[60]}, input features {ts[62] - ts[61]}, LDS zeroing + bias loads {ts[63] - ts[62]}, "
               f"wait for the first stages {t[0] - ts[63]}")
