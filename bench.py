@@ -601,11 +601,12 @@ def main():
         distributed.all_reduce_counters([0.0, 0.0, 0.0], device)
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    # HIP events around every 5th launch of the dominant kernel (two event records per launch cost ~3 us of stream time
-    # each).  5 is coprime with the 16 net-block launches of an iteration, so over the timed region every position of the
-    # pass is sampled equally often - the first launch of a pass has no coupling prologue, a stride of 4 would have
-    # bracketed it in half of the samples.
-    os.environ.setdefault("TW_PROFILE_STRIDE", "5")
+    # HIP events around every 17th launch of the dominant kernel.  A bracketed launch costs the stream two bubbles of 6-8 us
+    # (profiles/r05_iteration_timeline.txt: the gaps in front of and behind launches 1, 6, 11, 16 of an iteration at r04's stride
+    # of 5 - 45 us of a 6.5 ms iteration that the product never pays).  17 is coprime with the 16 net-block launches of an
+    # iteration, so over the timed region every position of the pass is sampled equally often - the first launch of a pass has
+    # no coupling prologue, a stride of 4 would have bracketed it in half of the samples.
+    os.environ.setdefault("TW_PROFILE_STRIDE", "17")
     lib.tw_profile_begin()
     t0 = time.perf_counter()
     with torch.no_grad():
