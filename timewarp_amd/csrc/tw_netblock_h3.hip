@@ -446,6 +446,10 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
       char* st = pn;
       // ---- IN
       if ((rc = absmax(nb + L.net.in0_w, (int64_t)d.d_hidden * L.d_in, up, scales + 0))) return rc;
+      if (h1 && !d.d_rff) {  // fast mode: first-layer weights unscaled (see the FFN below); the RFF in-MLP is compiled, split form
+        hipLaunchKernelGGL(h3_unit_scale_kernel, dim3(1), dim3(1), 0, s, up, scales + 0);
+        TW_LAUNCH_CHECK();
+      }
       const int ia = g.in_a_stages, ks_in = 2 * ia;  // k-steps of the first GEMM: 2 or 6
       const int ib = h1 ? 1 : 2;                      // B stages per chunk of the in-MLP / FFN
       if (h1) {
@@ -578,6 +582,10 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
       // ---- OUT
       float* osc = scales + 2 + 3 * d.n_layers;
       if ((rc = absmax(nb + L.net.out0_w, (int64_t)d.d_hidden * 128, up, osc + 0))) return rc;
+      if (h1) {
+        hipLaunchKernelGGL(h3_unit_scale_kernel, dim3(1), dim3(1), 0, s, up, osc + 0);
+        TW_LAUNCH_CHECK();
+      }
       const int oa = h1 ? 1 : 2;
       for (int ch = 0; ch < g.hid_chunks; ++ch)
         for (int o = 0; o < oa; ++o) {

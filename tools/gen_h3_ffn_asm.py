@@ -115,12 +115,14 @@ def mfma(d, a, b, zero=False, dst="a", bsrc="v", seed=None):
 
 
 def fold():
-    """Fast mode, ReLU shape (the FFN): W1 is packed UNSCALED (no lo half to keep normal: h3_pack_weights), so the hidden
-    pre-activation is the accumulator itself once the chain starts from the bias (the MFMA's C operand) - the epilogue of a
-    unit is two packs and the ReLU on the packed pairs, 4 VALU ops instead of 8.  The deletion matrix of the six-slot-ring
+    """Fast mode: the first-layer weights of every chunked MLP are packed UNSCALED (no lo half to keep normal:
+    h3_pack_weights), so the hidden pre-activation is the accumulator itself once the chain starts from the bias (the MFMA's
+    C operand) - the FFN's epilogue of a unit is two packs and the ReLU on the packed pairs, 4 VALU ops instead of 8; the
+    SiLU shapes drop their four scale / bias fmas.  The deletion matrix of the six-slot-ring
     build put 13 % of the FFN into those 8 (profiles/r05_h1_ffn_deletion_matrix.txt).  The bias quads are read by the
     hand-off in front of an A stage (nothing else reads them any more)."""
-    return H1 and not SHAPE["silu"]
+    assert not (H1 and IOTAIL)
+    return H1
 
 
 def pair_mfmas(acc_of_jt, slot, bop_of_jt, first=False, dst="a", bsrc="v"):
@@ -145,14 +147,17 @@ def epi_unit(o, jt, buf, relu=True, tset=None):
     # scratch registers instead of the B operands of the second GEMM - is it the op count or the MFMA <-> VALU register traffic?
     src = (lambda r: BIAS(o) + r) if "episrc" in EXPERIMENT else (lambda r: HACC(o, jt) + r)
     ops = [f"v_fma_f32 v{t[r]}, v{src(r)}, s{S_SC}, v{BIAS(o) + r}" for r in range(4)]
+    pre = t      # registers holding the pre-activation
+    if fold():   # ... it is the accumulator itself (bias in the chain's start value, first-layer weights unscaled)
+        ops, pre = [], [src(r) for r in range(4)]
     if SHAPE["silu"]:
         # v * 1 / (1 + 2^(-v log2 e)) with the hardware exp2 / rcp
         u = [V_U + r for r in range(4)]
-        ops += [f"v_mul_f32 v{u[r]}, 0xbfb8aa3b, v{t[r]}" for r in range(4)]
+        ops += [f"v_mul_f32 v{u[r]}, 0xbfb8aa3b, v{pre[r]}" for r in range(4)]
         ops += [f"v_exp_f32 v{u[r]}, v{u[r]}" for r in range(4)]
         ops += [f"v_add_f32 v{u[r]}, 1.0, v{u[r]}" for r in range(4)]
         ops += [f"v_rcp_f32 v{u[r]}, v{u[r]}" for r in range(4)]
-        ops += [f"v_mul_f32 v{t[r]}, v{t[r]}, v{u[r]}" for r in range(4)]
+        ops += [f"v_mul_f32 v{t[r]}, v{pre[r]}, v{u[r]}" for r in range(4)]
     else:
         ops += [f"v_max_f32 v{t[r]}, v{t[r]}, 0" for r in range(4)]
     hh = HB(buf, jt, "h") + 2 * o
@@ -160,9 +165,7 @@ def epi_unit(o, jt, buf, relu=True, tset=None):
     if H1:
         # no lo half; ReLU after the rounding (max(rne(v), 0) == rne(max(v, 0))) on the packed pair: 8 ops per unit ...
         if not SHAPE["silu"]:
-            ops = ops[:4]
-        if fold():   # ... 4 with the bias in the chain's start value and W1 unscaled
-            ops, t = [], [src(r) for r in range(4)]
+            ops, t = ops[:-4], pre          # ... 4 with fold()
         ops += [f"v_cvt_pk_f16_f32 v{hh}, v{t[0]}, v{t[1]}", f"v_cvt_pk_f16_f32 v{hh + 1}, v{t[2]}, v{t[3]}"]
         if not SHAPE["silu"]:
             ops += [f"v_pk_max_f16 v{hh}, v{hh}, 0", f"v_pk_max_f16 v{hh + 1}, v{hh + 1}, 0"]
