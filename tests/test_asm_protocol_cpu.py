@@ -1,0 +1,239 @@
+"""The weight-stage hand-off of the generated FFN statements (tools/gen_h3_ffn_asm.py) under ADVERSARIAL completion of the
+asynchronous memory operations, on the CPU (tools/asm_emu.py `late_vmem` / `late_lds`).
+
+A statement streams its weights through a ring of LDS stage buffers: LDS-DMA pieces land whenever they land, every wave
+reads every buffer, and the only things that order the two are counted `s_waitcnt`s and workgroup barriers.  r04's stress
+runs found a hole in exactly this protocol after every functional test had passed.  Here the four waves of a workgroup run
+the whole statement - prologue, chunk loop, both tails - over a real stage stream in (emulated) global memory, while
+  * every LDS-DMA piece and register load lands only when the issuing wave's own `vmcnt` wait forces it, or
+  * every ds_read is sampled only when the wave's own `lgkmcnt` wait forces it (so a refill that overtakes it shows),
+with the waves advanced to each barrier in both orders (wave 0 far ahead / far behind).  The result must equal a numpy
+restatement of the chunked MLP computed from the same packed stream.  Covered: the split-fp16 and the single-MFMA statements on
+48- and 64-token waves, and the six-slot ring with its barrier-free stages (r05).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import asm_emu as E  # noqa: E402
+from test_asm_glue_cpu import load_gen  # noqa: E402
+
+STAGE, TILES = 9216, 8192
+RING_LDS, PRIV_LDS, PRIV_STRIDE = 0, 64 * 1024, 40 * 1024   # ring base; wave-private blocks (<= 32 images of 1 KiB each)
+OPS = {"cur": "s40", "gn": "v[252:253]", "ring": "s41", "wave": "s42", "priv": "s43", "chunks": "s44"}
+GBASE = 1 << 20
+
+
+def f16(x):
+    return np.asarray(x, np.float32).astype(np.float16)
+
+
+def split(x):
+    hi = f16(x)
+    lo = f16(np.asarray(x, np.float32) - hi.astype(np.float32))
+    return hi, lo
+
+
+def tile_bytes(W, row0, col0):
+    """One 16 x 32 fp16 tile in the A-operand lane order of the packed stream (csrc h3_pack_block_kernel): element (lane, e)
+    = W[row0 + lane % 16][col0 + 16 (e / 4) + 4 (lane / 16) + e % 4]."""
+    out = np.zeros((64, 8), np.float16)
+    for l in range(64):
+        for e in range(8):
+            out[l, e] = W[row0 + l % 16, col0 + 16 * (e // 4) + 4 * (l // 16) + e % 4]
+    return out.view(np.uint8).reshape(-1)
+
+
+def image_bytes(X, k0, t0):
+    """One B-operand image (16 bytes per lane) of activations X[feature][token]: (lane, e) = X[k0 + 16 (e / 4) + 4 (lane / 16)
+    + e % 4][t0 + lane % 16]."""
+    out = np.zeros((64, 8), np.float16)
+    for l in range(64):
+        for e in range(8):
+            out[l, e] = X[k0 + 16 * (e // 4) + 4 * (l // 16) + e % 4, t0 + l % 16]
+    return out.view(np.uint8).reshape(-1)
+
+
+class Case:
+    """A chunked MLP  y = W2 . act(scale (W1q . x) + b1)  of `chunks` 32-unit chunks, packed as the stage stream the statement
+    reads (csrc h3_pack_weights: A(0) | A(c+1) B(c) ... | B(n-1)).  Shapes (gen_h3_ffn_asm.py SHAPES): ffn 128 -> ReLU -> 128,
+    in 64 -> SiLU -> 128, out 128 -> SiLU -> 16."""
+
+    def __init__(self, gen, chunks, seed, shape="ffn"):
+        self.gen, self.n, self.shape = gen, chunks, shape
+        self.H1, self.NT = gen.H1, gen.NT
+        self.ks_in, self.ot_out, self.silu = (gen.SHAPES[shape][k] for k in ("ks_in", "ot_out", "silu"))
+        ks_in, ot_out = self.ks_in, self.ot_out
+        rng = np.random.default_rng(seed)
+        F = 32 * chunks
+        self.scale = np.float32(1.0 if gen.H1 else 2.0 ** -3)
+        W1 = rng.standard_normal((F, 32 * ks_in)).astype(np.float32) * (0.1 if gen.H1 else 0.8)
+        W2 = rng.standard_normal((16 * ot_out, F)).astype(np.float32) * 0.5
+        self.b1 = rng.standard_normal(F).astype(np.float32) * 0.3
+        self.W1h, self.W1l = split(W1)
+        self.W2h, self.W2l = split(W2)
+        T = 16 * self.NT
+        self.X = [rng.standard_normal((32 * ks_in, T)).astype(np.float32) for _ in range(4)]        # per wave
+        # ---- the stream
+        fa = 1 if (self.H1 or ks_in == 2) else 2
+        stages = []
+
+        def a_stage(ch, o):
+            st = np.zeros(STAGE, np.uint8)
+            if self.H1:     # tile ks_in o + ks, both o in one stage
+                for oo in range(2):
+                    for ks in range(ks_in):
+                        st[1024 * (ks_in * oo + ks):][:1024] = tile_bytes(self.W1h, 32 * ch + 16 * oo, 32 * ks)
+            elif ks_in == 2:   # in-MLP: one A stage, pair q = 2 o + ks
+                for q in range(4):
+                    st[2048 * q:][:1024] = tile_bytes(self.W1h, 32 * ch + 16 * (q // 2), 32 * (q % 2))
+                    st[2048 * q + 1024:][:1024] = tile_bytes(self.W1l, 32 * ch + 16 * (q // 2), 32 * (q % 2))
+            else:           # pair ks of rows 32 ch + 16 o: hi KiB, lo KiB
+                for ks in range(4):
+                    st[2048 * ks:][:1024] = tile_bytes(self.W1h, 32 * ch + 16 * o, 32 * ks)
+                    st[2048 * ks + 1024:][:1024] = tile_bytes(self.W1l, 32 * ch + 16 * o, 32 * ks)
+            if o == 0:
+                st[TILES:TILES + 128] = self.b1[32 * ch:32 * ch + 32].view(np.uint8)
+                st[TILES + 128:TILES + 132] = np.array([self.scale], np.float32).view(np.uint8)
+            return st
+
+        def b_stage(ch, hf):
+            st = np.zeros(STAGE, np.uint8)
+            if self.H1:
+                for ot in range(ot_out):
+                    st[1024 * ot:][:1024] = tile_bytes(self.W2h, 16 * ot, 32 * ch)
+            else:
+                for p in range(min(4, ot_out - 4 * hf)):
+                    st[2048 * p:][:1024] = tile_bytes(self.W2h, 16 * (4 * hf + p), 32 * ch)
+                    st[2048 * p + 1024:][:1024] = tile_bytes(self.W2l, 16 * (4 * hf + p), 32 * ch)
+            return st
+
+        nb = 1 if self.H1 else (ot_out + 3) // 4
+        for o in range(fa):
+            stages.append(a_stage(0, o))
+        for ch in range(chunks - 1):
+            for o in range(fa):
+                stages.append(a_stage(ch + 1, o))
+            for hf in range(nb):
+                stages.append(b_stage(ch, hf))
+        for hf in range(nb):
+            stages.append(b_stage(chunks - 1, hf))
+        self.n_stages = len(stages)
+        for _ in range(gen.AHEAD + 2):   # what the hand-offs of the last stages fetch: the next statement's stages
+            stages.append(rng.integers(0, 255, STAGE, dtype=np.uint8))
+        self.stream = np.concatenate(stages)
+
+    def reference(self, w):
+        xh, xl = split(self.X[w])
+        d = np.float64
+
+        def act(v):
+            if not self.silu:
+                return np.maximum(v, 0).astype(np.float32)
+            u = np.exp2((np.float32(-1.4426950408889634) * v).astype(np.float32).astype(d)).astype(np.float32)   # the statement's op sequence
+            return (v * (1.0 / (u + np.float32(1.0)).astype(d)).astype(np.float32)).astype(np.float32)
+        if self.H1:
+            pre = (self.W1h.astype(d) @ xh.astype(d)).astype(np.float32) + self.b1[:, None]      # (bias = the chains' start value)
+            hb = f16(act(pre))
+            return self.W2h.astype(d) @ hb.astype(d)
+        acc = self.W1h.astype(d) @ xh.astype(d) + self.W1h.astype(d) @ xl.astype(d) + self.W1l.astype(d) @ xh.astype(d)
+        v = act((acc.astype(np.float32) * self.scale + self.b1[:, None]).astype(np.float32))
+        hh, hl = split(v)
+        return self.W2h.astype(d) @ hh.astype(d) + self.W2h.astype(d) @ hl.astype(d) + self.W2l.astype(d) @ hh.astype(d)
+
+    def run(self, late_vmem, late_lds, order):
+        gen, NT = self.gen, self.NT
+        lds = np.zeros(256 * 1024, np.uint8)   # (roomier than the chip's: the layout here is the test's own)
+        lds[RING_LDS:RING_LDS + gen.AHEAD * STAGE] = self.stream[:gen.AHEAD * STAGE]    # the stages the kernel's prologue requested
+        gmem = self.stream
+        waves = []
+        for w in range(4):
+            wv = E.Wave(lds=lds, gmem=gmem, gbase=GBASE, wave_id=w)
+            wv.late_vmem, wv.late_lds = late_vmem, late_lds
+            priv = PRIV_LDS + w * PRIV_STRIDE
+            xh, xl = split(self.X[w])
+            for ks in range(self.ks_in):
+                for jt in range(NT):
+                    for part, src in enumerate((xh, xl)):
+                        i = 2 * (NT * ks + jt) + part
+                        lds[priv + 1024 * i:priv + 1024 * (i + 1)] = image_bytes(src.astype(np.float32), 32 * ks, 16 * jt)
+            lane = np.arange(64, dtype=np.uint64)
+            gn = np.uint64(GBASE + gen.AHEAD * STAGE) + 16 * lane
+            wv.v[252] = (gn & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+            wv.v[253] = (gn >> np.uint64(32)).astype(np.uint32)
+            wv.s[40], wv.s[41], wv.s[42], wv.s[43], wv.s[44] = 0, RING_LDS, w, priv, self.n
+            waves.append(wv)
+        gen.SHAPE = gen.SHAPES[self.shape]
+        E.run_waves(waves, gen.generate(), [OPS] * 4, order=order)
+        ys = []
+        for w, wv in enumerate(waves):
+            vm, lg = wv.in_flight()
+            assert "reg" not in vm, "a register load is still in flight when the statement ends"
+            assert not lg, "LDS operations not waited for when the statement ends"
+            # stages consumed -> ring slot and stream pointer handed to the next statement
+            assert int(wv.s[40]) == self.n_stages % gen.RING
+            gn = int(wv.v[252][0]) | (int(wv.v[253][0]) << 32)
+            assert gn == GBASE + (gen.AHEAD + self.n_stages) * STAGE
+            priv = PRIV_LDS + w * PRIV_STRIDE
+            y = np.zeros((16 * self.ot_out, 16 * NT), np.float32)
+            for ot in range(self.ot_out):
+                for jt in range(NT):
+                    img = lds[priv + 1024 * (NT * ot + jt):][:1024].view(np.float32).reshape(64, 4)
+                    for l in range(64):
+                        y[16 * ot + 4 * (l // 16):16 * ot + 4 * (l // 16) + 4, 16 * jt + l % 16] = img[l]
+            ys.append(y)
+        return ys
+
+
+VARIANTS = [(), ("--h1",), ("--h1", "--ring6"), ("--ring6",), ("--nt=4",), ("--nt=4", "--h1")]
+MODES = [(False, False, None), (True, False, None), (True, False, [3, 2, 1, 0]), (False, True, None), (False, True, [3, 2, 1, 0])]
+
+
+def check(gen, chunks, mode, seed=0, shape="ffn"):
+    case = Case(gen, chunks, seed, shape)
+    ys = case.run(*mode)
+    for w, y in enumerate(ys):
+        ref = case.reference(w)
+        err = np.abs(y - ref).max() / np.abs(ref).max()
+        # (single-MFMA form: a last-bit difference in a pre-activation can move an fp16 rounding of the hidden layer; a stale
+        # weight tile is an error of order one either way)
+        assert err < (3e-4 if gen.H1 else 1e-5), (w, err, mode)
+
+
+@pytest.mark.parametrize("argv", VARIANTS, ids=lambda a: " ".join(a) or "split-fp16")
+@pytest.mark.parametrize("mode", MODES, ids=["in-order", "dma-late", "dma-late-reversed", "reads-late", "reads-late-reversed"])
+def test_ffn_statement_under_adversarial_completion(argv, mode):
+    """Three chunks: the prologue, both halves of the loop body and the tail behind the first half."""
+    check(load_gen("gen_h3_ffn_asm", argv), 3, mode)
+
+
+@pytest.mark.parametrize("argv", [("--h1", "--ring6"), ("--h1",), ()], ids=lambda a: " ".join(a) or "split-fp16")
+@pytest.mark.parametrize("chunks", [1, 2, 4])
+def test_ffn_statement_chunk_counts(argv, chunks):
+    """One chunk (no loop trip), two (the tail behind the first half), four (the loop's back edge) - with the DMA landing late."""
+    check(load_gen("gen_h3_ffn_asm", argv), chunks, (True, False, [3, 2, 1, 0]), seed=chunks)
+
+
+def test_the_checker_sees_a_missing_wait(monkeypatch):
+    """The protocol test must be able to fail: loosen the DMA wait of the heavy stages by one stage and the result is wrong."""
+    gen = load_gen("gen_h3_ffn_asm", ("--h1", "--ring6"))
+    real = gen.sync
+
+    def loose(light, before_light):
+        return [l.replace("vmcnt(4)", "vmcnt(8)").replace("vmcnt(6)", "vmcnt(10)") for l in real(light, before_light)]
+    monkeypatch.setattr(gen, "sync", loose)
+    with pytest.raises(AssertionError):
+        check(gen, 3, (True, False, None))
+
+
+@pytest.mark.parametrize("argv", [(), ("--h1",), ("--h1", "--ring6"), ("--nt=4",)], ids=lambda a: " ".join(a) or "split-fp16")
+@pytest.mark.parametrize("shape", ["in", "out"])
+@pytest.mark.parametrize("mode", [MODES[2], MODES[3]], ids=["dma-late-reversed", "reads-late"])
+def test_in_and_out_mlp_statements(argv, shape, mode):
+    """The SiLU shapes (64 -> 256 -> 128 and 128 -> 256 -> 16 in the product; here three chunks)."""
+    check(load_gen("gen_h3_ffn_asm", argv), 3, mode, seed=5, shape=shape)

@@ -7,9 +7,21 @@ and GPU time is the scarce resource.  This runs the generated text on the CPU - 
 AGPRs, SGPRs, VCC / SCC / M0, a byte-addressed LDS, an optional flat global buffer - so the glue can be held to a numpy
 restatement of what it is meant to compute before it ever reaches the chip (tests/test_asm_glue_cpu.py).
 
-What it is NOT: a timing model.  Wait states, s_waitcnt counts, MFMA forwarding rules and races between waves are not
-checked (s_waitcnt / s_nop are no-ops; memory operations complete in program order).  Several waves can be run in lock
-step over one LDS: `run_waves` advances each wave to its next s_barrier in turn.
+What it is NOT: a timing model.  Wait states and MFMA forwarding rules are not checked; by default s_waitcnt / s_nop are
+no-ops and memory operations complete in program order.  Several waves can be run in lock step over one LDS: `run_waves`
+advances each wave to its next s_barrier in turn (in a chosen wave order).
+
+Adversarial completion (r05; tests/test_asm_protocol_cpu.py): the stage hand-off of the GEMM statements is a protocol of
+counted waits and barriers over an asynchronous LDS-DMA queue, and r04's stress runs found a hole in it that no functional
+test saw.  Two switches make the emulator complete memory operations as LATE as the program's own waits allow:
+  `late_vmem`  global_load_lds / global_load_dword* sit in a per-wave queue and land (in order) only when an
+               `s_waitcnt vmcnt(n)` forces them - a tile read that the waits do not cover reads stale bytes;
+  `late_lds`   ds_read results are sampled AND written back only when an `s_waitcnt lgkmcnt(n)` forces them (ds_writes keep
+               their place in the queue but store at once) - a slot refilled, or a register consumed, before the read was
+               waited for shows the wrong data.
+With waves run to their barriers in both orders, a statement whose result survives all four combinations has no
+read-before-landed, no refill-before-read and no use-before-wait on those schedules.  `Wave.in_flight()` lists what is still
+queued at the end: LDS-DMA pieces are expected there (the ring runs ahead across statements), register loads are a bug.
 
 Register layouts of the matrix instructions (gfx950):
   v_mfma_f32_16x16x16_f16  A: lane l holds A[l % 16][4 (l / 16) + e], e = 0..3 (two VGPRs);  B: B[4 (l / 16) + e][l % 16];
@@ -53,6 +65,21 @@ class Wave:
         self.track_uninit = False
         self.init_v = set()
         self.init_a = set()
+        self.late_vmem = False
+        self.late_lds = False
+        self.vm_q = []     # [(kind, closure)] in issue order; kind: "lds" (LDS-DMA) | "reg" (load into registers)
+        self.lgkm_q = []
+
+    def _retire(self, q, n):
+        while len(q) > n:
+            q.pop(0)[1]()
+
+    def in_flight(self):
+        return [k for k, _ in self.vm_q], [k for k, _ in self.lgkm_q]
+
+    def drain(self):
+        self._retire(self.vm_q, 0)
+        self._retire(self.lgkm_q, 0)
 
     # ---------------------------------------------------------------- operand access
     _re_rng = re.compile(r"^([vas])\[(\d+):(\d+)\]$")
@@ -213,7 +240,14 @@ class Wave:
 
     # ---- no-ops
     def i_s_nop(self, o, m): pass
-    def i_s_waitcnt(self, o, m): pass
+    def i_s_waitcnt(self, o, m):
+        txt = " ".join(o)
+        mm = re.search(r"vmcnt\((\d+)\)", txt)
+        if mm:
+            self._retire(self.vm_q, int(mm.group(1)))
+        mm = re.search(r"lgkmcnt\((\d+)\)", txt)
+        if mm:
+            self._retire(self.lgkm_q, int(mm.group(1)))
     def i_s_setprio(self, o, m): pass
 
     def i_s_barrier(self, o, m):
@@ -437,15 +471,23 @@ class Wave:
     # ---- LDS
     def _ds_rd(self, o, m, nreg):
         addr = self.rd(o[1]) + np.uint32(int(m.get("offset", 0)))
-        data = self._lds_rd(addr, 4 * nreg)
-        regs = np.ascontiguousarray(data).view(np.uint32).reshape(LANES, nreg)
-        for i in range(nreg):
-            self.wr(o[0], regs[:, i], i)
+
+        def land():
+            data = self._lds_rd(addr, 4 * nreg)
+            regs = np.ascontiguousarray(data).view(np.uint32).reshape(LANES, nreg)
+            for i in range(nreg):
+                self.wr(o[0], regs[:, i], i)
+        if self.late_lds:
+            self.lgkm_q.append(("read", land))
+        else:
+            land()
 
     def _ds_wr(self, o, m, nreg):
         addr = self.rd(o[0]) + np.uint32(int(m.get("offset", 0)))
         regs = np.stack([self.rd(o[1], i) for i in range(nreg)], axis=1)
         self._lds_wr(addr, np.ascontiguousarray(regs).view(np.uint8).reshape(LANES, 4 * nreg))
+        if self.late_lds:
+            self.lgkm_q.append(("write", lambda: None))   # (returns in order with the reads)
 
     def i_ds_read_b128(self, o, m): self._ds_rd(o, m, 4)
     def i_ds_read_b64(self, o, m): self._ds_rd(o, m, 2)
@@ -467,14 +509,24 @@ class Wave:
         a = self._gaddr(o[1:], m)
         idx = a[:, None] + np.arange(16)[None, :]
         regs = np.ascontiguousarray(self.gmem[idx]).view(np.uint32).reshape(LANES, 4)
-        for i in range(4):
-            self.wr(o[0], regs[:, i], i)
+
+        def land():
+            for i in range(4):
+                self.wr(o[0], regs[:, i], i)
+        if self.late_vmem:
+            self.vm_q.append(("reg", land))
+        else:
+            land()
 
     def i_global_load_lds_dwordx4(self, o, m):
         a = self._gaddr(o, m)
         idx = a[:, None] + np.arange(16)[None, :]
-        lds_addr = (np.int64(self.m0) + int(m.get("offset", 0)) + 16 * self.lane.astype(np.int64))
-        self._lds_wr(lds_addr, self.gmem[idx])
+        lds_addr = (np.int64(self.m0) + int(m.get("offset", 0)) + 16 * self.lane.astype(np.int64))   # (M0 is read at issue)
+        data = self.gmem[idx].copy()
+        if self.late_vmem:
+            self.vm_q.append(("lds", lambda: self._lds_wr(lds_addr, data)))
+        else:
+            self._lds_wr(lds_addr, data)
 
     def i_global_store_dwordx2(self, o, m):
         # (vaddr, vdata, saddr | off)
@@ -523,15 +575,17 @@ def run(wave, lines, operands=None, max_steps=50_000_000):
     return wave
 
 
-def run_waves(waves, lines, operands_per_wave, max_steps=200_000_000):
-    """Run several waves over one LDS in lock step: each wave runs to its next s_barrier (or the end), then the next."""
+def run_waves(waves, lines, operands_per_wave, max_steps=200_000_000, order=None):
+    """Run several waves over one LDS in lock step: each wave runs to its next s_barrier (or the end), then the next -
+    in index order, or in `order`."""
     progs = [prepare(lines, ops) for ops in operands_per_wave]
     pcs = [0] * len(waves)
     done = [False] * len(waves)
     n = 0
     while not all(done):
         at_barrier = []
-        for w, wave in enumerate(waves):
+        for w in (order if order is not None else range(len(waves))):
+            wave = waves[w]
             if done[w]:
                 continue
             code, labels = progs[w]
