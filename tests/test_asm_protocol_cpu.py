@@ -237,3 +237,133 @@ def test_the_checker_sees_a_missing_wait(monkeypatch):
 def test_in_and_out_mlp_statements(argv, shape, mode):
     """The SiLU shapes (64 -> 256 -> 128 and 128 -> 256 -> 16 in the product; here three chunks)."""
     check(load_gen("gen_h3_ffn_asm", argv), 3, mode, seed=5, shape=shape)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The kernel-attention statements (tools/gen_h3_attn_asm.py): score fragments arrive by ordinary register loads in the same
+# queue as the LDS-DMA pieces (r04's hole was one of those loads landing after the statement's exit), the X^T operands come
+# from the wave-private block.  Differential form: the in-order run of the emulator is the reference (its arithmetic is pinned
+# on the GPU and by the glue tests), the adversarial runs must reproduce it bit for bit on arbitrary finite data.
+# ---------------------------------------------------------------------------------------------------------------------------
+ATT_OPS = dict(OPS, heads="s45", sf="v[250:251]", xt="s46", win="s47")
+XT_LDS = 64 * 1024                       # wide layout: the workgroup's shared transposed tile (106 KiB), private blocks behind it
+
+
+def run_attention(gen, heads, late_vmem, late_lds, order, seed=3):
+    rng = np.random.default_rng(seed)
+    NT = gen.NT
+    wide = hasattr(gen, "NG")            # tools/gen_h3_attn_wide_asm.py
+    ahead, ring = (5, 5) if wide else (gen.AHEAD, gen.RING)
+    sf_head = gen.NG * NT * gen.FRAG_BLOCK if wide else NT * gen.SF_BYTES
+    priv0, stride = (XT_LDS + 112 * 1024, 24 * 1024) if wide else (PRIV_LDS, PRIV_STRIDE)
+    n_stages = heads * 4 * (1 if gen.H1 else 2)
+    small = lambda n: (rng.integers(-512, 512, n).astype(np.float32) / 1024).astype(np.float16).view(np.uint8)   # finite halves
+    stream = small((n_stages + ahead + 2) * STAGE // 2)
+    sf = small((heads + 2) * sf_head * 4 // 2)       # per wave: heads + the head of slack the last loads touch
+    gmem = np.concatenate([stream, sf])
+    lds = np.zeros(320 * 1024, np.uint8)
+    lds[RING_LDS:RING_LDS + ahead * STAGE] = stream[:ahead * STAGE]
+    if wide:
+        lds[XT_LDS:XT_LDS + 2 * gen.XT_LO] = small(gen.XT_LO)
+    waves = []
+    for w in range(4):
+        wv = E.Wave(lds=lds, gmem=gmem, gbase=GBASE, wave_id=w)
+        wv.late_vmem, wv.late_lds = late_vmem, late_lds
+        priv = priv0 + w * stride
+        if not wide:
+            lds[priv:priv + 32 * 1024] = small(16 * 1024)       # the transposed copy of x: hi / lo images per feature tile
+        lane = np.arange(64, dtype=np.uint64)
+        gn = np.uint64(GBASE + ahead * STAGE) + 16 * lane
+        wv.v[252], wv.v[253] = (gn & np.uint64(0xFFFFFFFF)).astype(np.uint32), (gn >> np.uint64(32)).astype(np.uint32)
+        sfp = np.uint64(GBASE + len(stream) + w * (heads + 2) * sf_head)
+        wv.v[250], wv.v[251] = np.uint32(sfp & np.uint64(0xFFFFFFFF)), np.uint32(sfp >> np.uint64(32))
+        wv.s[40], wv.s[41], wv.s[42], wv.s[43], wv.s[45] = 0, RING_LDS, w, priv, heads
+        # the wave's key window: byte offset of its first K = 32 group in a row of the tile (it never leaves the 192 tokens)
+        wv.s[46], wv.s[47] = XT_LDS, (64 * min(w, 6 - gen.NG) if wide else 0)
+        waves.append(wv)
+    E.run_waves(waves, gen.generate(), [ATT_OPS] * 4, order=order)
+    out = []
+    for w, wv in enumerate(waves):
+        vm, lg = wv.in_flight()
+        assert "reg" not in vm, "a score-fragment load is still in flight when the statement ends"
+        assert not lg
+        assert int(wv.s[40]) == n_stages % ring
+        priv = priv0 + w * stride
+        out.append(lds[priv:priv + 8 * NT * 1024].copy())
+    return out
+
+
+ATTENTION = [("gen_h3_attn_asm", a) for a in ((), ("--mode=windowed",), ("--ring6",), ("--nt=4",), ("--nt=4", "--h1"))] + \
+            [("gen_h3_attn_wide_asm", a) for a in ((), ("--h1",), ("--ng=3",), ("--ng=3", "--h1"), ("--ng=6",), ("--ng=6", "--h1"))]
+
+
+@pytest.mark.parametrize("name,argv", ATTENTION, ids=lambda a: a if isinstance(a, str) else (" ".join(a) or "full"))
+def test_attention_statement_under_adversarial_completion(name, argv):
+    gen = load_gen(name, argv)
+    ref = run_attention(gen, 2, False, False, None)
+    assert all(np.isfinite(r.view(np.float32)).all() and np.abs(r.view(np.float32)).max() > 0 for r in ref)
+    for mode in MODES[1:]:
+        got = run_attention(gen, 2, *mode)
+        for w in range(4):
+            assert np.array_equal(got[w], ref[w]), (argv, mode, w)
+
+
+def test_the_checker_sees_r04s_race(monkeypatch):
+    """r04's hole, re-opened: without the wait in front of the statement's exit the fragment loads of the head behind the last
+    are still in flight when the registers go back to the caller."""
+    gen = load_gen("gen_h3_attn_wide_asm", ("--h1",))
+    real = gen.generate
+
+    def without_exit_wait():
+        lines = real()
+        i = max(k for k, l in enumerate(lines) if l.startswith("s_waitcnt vmcnt(") and "lgkmcnt" not in l)
+        return lines[:i] + lines[i + 1:]
+    monkeypatch.setattr(gen, "generate", without_exit_wait)
+    with pytest.raises(AssertionError, match="still in flight"):
+        run_attention(gen, 2, True, False, None)
+
+
+def run_dense_attention(gen, late_vmem, late_lds, order, seed=4):
+    """The dense softmax block (tools/gen_h3_dense_attn_asm.py; 8 heads: 24 in_proj stages (q, k, v per head) + 8 out_proj stages)."""
+    rng = np.random.default_rng(seed)
+    NT, n_stages, side = 3, 32, 200 * 1024
+    small = lambda n: (rng.integers(-512, 512, n).astype(np.float32) / 1024).astype(np.float16).view(np.uint8)
+    gmem = small((n_stages + 5 + 2) * STAGE // 2)
+    lds = np.zeros(320 * 1024, np.uint8)
+    lds[RING_LDS:RING_LDS + 5 * STAGE] = gmem[:5 * STAGE]
+    sl = (rng.standard_normal(1280) * 0.1).astype(np.float32)
+    sl[640] = sl[642] = 2.0 ** -2                       # in_proj / out_proj scales
+    lds[side:side + 5120] = sl.view(np.uint8)
+    ops = dict(OPS, sl="s46", **{f"m{jt}{p}": f"v{244 + 2 * jt + k}" for jt in range(3) for k, p in enumerate("lh")})
+    waves = []
+    for w in range(4):
+        wv = E.Wave(lds=lds, gmem=gmem, gbase=GBASE, wave_id=w)
+        wv.late_vmem, wv.late_lds = late_vmem, late_lds
+        priv = PRIV_LDS + w * PRIV_STRIDE
+        lds[priv:priv + 24 * 1024] = small(12 * 1024)       # the split activations: 24 operand images
+        lane = np.arange(64, dtype=np.uint64)
+        gn = np.uint64(GBASE + 5 * STAGE) + 16 * lane
+        wv.v[252], wv.v[253] = (gn & np.uint64(0xFFFFFFFF)).astype(np.uint32), (gn >> np.uint64(32)).astype(np.uint32)
+        for r in range(244, 250):
+            wv.v[r] = np.uint32(0xFFFFFFFF if w % 2 == 0 else 0x0FFF0FFF)      # key masks (odd waves: the last four keys of a tile padded)
+        wv.s[40], wv.s[41], wv.s[42], wv.s[43], wv.s[46] = 0, RING_LDS, w, priv, side
+        waves.append(wv)
+    E.run_waves(waves, gen.generate(), [ops] * 4, order=order)
+    out = []
+    for w, wv in enumerate(waves):
+        vm, lg = wv.in_flight()
+        assert "reg" not in vm and not lg
+        assert int(wv.s[40]) == n_stages % 5
+        priv = PRIV_LDS + w * PRIV_STRIDE
+        out.append(lds[priv:priv + 8 * NT * 1024].copy())
+    return out
+
+
+def test_dense_attention_statement_under_adversarial_completion():
+    gen = load_gen("gen_h3_dense_attn_asm", ())
+    ref = run_dense_attention(gen, False, False, None)
+    assert all(np.isfinite(r.view(np.float32)).all() and np.abs(r.view(np.float32)).max() > 0 for r in ref)
+    for mode in MODES[1:]:
+        got = run_dense_attention(gen, *mode)
+        for w in range(4):
+            assert np.array_equal(got[w], ref[w]), (mode, w)

@@ -113,6 +113,10 @@ class Wave:
             raise ValueError("vcc as a 32-bit source")
         if op == "m0":
             return np.full(LANES, self.m0, np.uint32)
+        if op.startswith("-") and self._parse(op[1:]) is not None:      # float source modifier: -v12
+            return self.rd(op[1:], idx) ^ np.uint32(0x80000000)
+        if op.startswith("|") and op.endswith("|"):                       # |v12|
+            return self.rd(op[1:-1], idx) & np.uint32(0x7FFFFFFF)
         p = self._parse(op)
         if p is None:
             return np.full(LANES, self._literal(op), np.uint32)
@@ -176,25 +180,18 @@ class Wave:
         n = kper // 2
         A = self._halves(a, n)   # lane l: row l % 16, k = kper (l / 16) + e
         B = self._halves(b, n)
-        K = 4 * kper
-        Am = np.zeros((16, K), np.float32)
-        Bm = np.zeros((K, 16), np.float32)
-        for l in range(LANES):
-            Am[l % 16, kper * (l // 16):kper * (l // 16) + kper] = A[l]
-            Bm[kper * (l // 16):kper * (l // 16) + kper, l % 16] = B[l]
-        D = (Am.astype(np.float64) @ Bm.astype(np.float64))
-        if c.strip() == "0":
-            C = np.zeros((16, 16), np.float64)
-        else:
-            C = np.zeros((16, 16), np.float64)
-            for r in range(4):
-                cv = _f32(self.rd(c, r))
-                for l in range(LANES):
-                    C[4 * (l // 16) + r, l % 16] = cv[l]
-        D = (D + C).astype(np.float32)
+        # [g][row][e] -> [row][g * kper + e]
+        Am = A.reshape(4, 16, kper).transpose(1, 0, 2).reshape(16, 4 * kper)
+        Bm = B.reshape(4, 16, kper).transpose(0, 2, 1).reshape(4 * kper, 16)
+        D = Am.astype(np.float64) @ Bm.astype(np.float64)
+        if c.strip() != "0":
+            # lane l, register r: C[4 (l / 16) + r][l % 16]
+            cv = np.stack([_f32(self.rd(c, r)) for r in range(4)], axis=0)          # [r][lane]
+            D = D + cv.reshape(4, 4, 16).transpose(1, 0, 2).reshape(16, 16)
+        D = D.astype(np.float32)
+        out = D.reshape(4, 4, 16).transpose(1, 0, 2).reshape(4, LANES)              # [r][lane]
         for r in range(4):
-            out = np.array([D[4 * (l // 16) + r, l % 16] for l in range(LANES)], np.float32)
-            self.wr(d, _u32(out), r)
+            self.wr(d, _u32(np.ascontiguousarray(out[r])), r)
         self.mfma_count += 1
 
     def _lds_rd(self, addr, nbytes):
