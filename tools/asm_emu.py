@@ -330,6 +330,7 @@ class Wave:
     def i_v_lshrrev_b32(self, o, m): self.wr(o[0], self.rd(o[2]) >> (self.rd(o[1]) & np.uint32(31)))
     def i_v_add_u32(self, o, m): self.wr(o[0], self.rd(o[1]) + self.rd(o[2]))
     def i_v_sub_u32(self, o, m): self.wr(o[0], self.rd(o[1]) - self.rd(o[2]))
+    def i_v_subrev_u32(self, o, m): self.wr(o[0], self.rd(o[2]) - self.rd(o[1]))
     def i_v_and_b32(self, o, m): self.wr(o[0], self.rd(o[1]) & self.rd(o[2]))
     def i_v_or_b32(self, o, m): self.wr(o[0], self.rd(o[1]) | self.rd(o[2]))
     def i_v_add3_u32(self, o, m): self.wr(o[0], self.rd(o[1]) + self.rd(o[2]) + self.rd(o[3]))
