@@ -85,15 +85,22 @@ class Wave:
     _re_rng = re.compile(r"^([vas])\[(\d+):(\d+)\]$")
     _re_one = re.compile(r"^([vas])(\d+)$")
 
+    _parsed = {}
+
     def _parse(self, op):
-        op = op.strip()
+        try:
+            return self._parsed[op]
+        except KeyError:
+            pass
+        key, op = op, op.strip()
         m = self._re_rng.match(op)
         if m:
-            return m.group(1), int(m.group(2)), int(m.group(3)) - int(m.group(2)) + 1
-        m = self._re_one.match(op)
-        if m:
-            return m.group(1), int(m.group(2)), 1
-        return None
+            r = m.group(1), int(m.group(2)), int(m.group(3)) - int(m.group(2)) + 1
+        else:
+            m = self._re_one.match(op)
+            r = (m.group(1), int(m.group(2)), 1) if m else None
+        self._parsed[key] = r
+        return r
 
     @staticmethod
     def _literal(op):
@@ -172,7 +179,11 @@ class Wave:
     # ---------------------------------------------------------------- helpers
     def _halves(self, op, n_regs):
         """fp16 elements of an operand of n_regs registers: [64, 2 n_regs] float32."""
-        regs = np.stack([self.rd(op, i) for i in range(n_regs)], axis=1)           # [64, n]
+        p = self._parse(op)
+        if p is not None and p[0] in "va" and not self.track_uninit:
+            regs = (self.v if p[0] == "v" else self.a)[p[1]:p[1] + n_regs].T      # [64, n]
+        else:
+            regs = np.stack([self.rd(op, i) for i in range(n_regs)], axis=1)
         h = np.ascontiguousarray(regs).view(np.uint16).reshape(LANES, 2 * n_regs)  # little endian: low half first
         return h.view(np.float16).astype(np.float32)
 
@@ -203,12 +214,10 @@ class Wave:
         self.lds[idx] = data
 
     # ---------------------------------------------------------------- one instruction
-    def step(self, line, labels=None):
-        """Execute one instruction.  Returns None, ("branch", label) or ("barrier",)."""
-        line = line.strip()
-        if not line or line.endswith(":"):
-            return None
-        self.count += 1
+    _decoded = {}   # instruction text -> (opcode, operands, modifiers): statements are loops, decode each line once
+
+    @classmethod
+    def _decode(cls, line):
         toks = line.split(None, 1)
         opc = toks[0]
         rest = toks[1] if len(toks) > 1 else ""
@@ -230,6 +239,18 @@ class Wave:
                 cur += ch
         if cur.strip():
             ops.append(cur.strip())
+        return opc, ops, mods
+
+    def step(self, line, labels=None):
+        """Execute one instruction.  Returns None, ("branch", label) or ("barrier",)."""
+        line = line.strip()
+        if not line or line.endswith(":"):
+            return None
+        self.count += 1
+        d = self._decoded.get(line)
+        if d is None:
+            d = self._decoded[line] = self._decode(line)
+        opc, ops, mods = d
         f = getattr(self, "i_" + opc, None)
         if f is None:
             raise NotImplementedError(f"asm_emu: {opc}  ({line})")
