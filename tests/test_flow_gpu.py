@@ -759,7 +759,7 @@ def test_per_op_path_large_molecules():
     tile per molecule in the LDS) and refused anything larger; r05: the scores are computed row-wise and the mixing is a tiled
     f32-MFMA GEMM from 129 atoms on, so the reference's own 691-atom test protein size goes through - against the oracle at the
     bar, ragged (masked tails), forward and reverse.  The row-wise scores kernel must equal the tile kernel bit for bit (150
-    atoms fit both).  The dense softmax variant keeps its limit and says so."""
+    atoms fit both).  The dense softmax variant's attention has a row-wise form too."""
     import ctypes as C
 
     from timewarp_amd import _lib
@@ -823,14 +823,31 @@ def test_per_op_path_large_molecules():
             assert H.rel_err(out.cpu(), ref) < TOL, (flags, H.rel_err(out.cpu(), ref))
     finally:
         lib.tw_debug_set_flags(0)
-    # dense softmax variant: no tiled form of its attention
-    md_ = H.tw_dense_model(H.full_dense_sd(), path=0)
-    V = 256
-    at = torch.randint(0, 5, (1, V), generator=g)
-    xx = torch.randn(1, V, 3, generator=g)
-    with pytest.raises(RuntimeError, match="LDS"):
-        md_.log_likelihood(atom_types=at.cuda(), x_coords=xx.cuda(), x_velocs=xx.cuda(), y_coords=xx.cuda(), y_velocs=xx.cuda(),
-                           adj_list=None, edge_batch_idx=None, masked_elements=torch.zeros(1, V, dtype=torch.bool).cuda())
+    # dense softmax variant (r05: row-wise attention without a V x V tile in the LDS): 256 atoms against the oracle, and the
+    # row-wise kernel bit-identical to the tile kernel where both run (bit 21 forces it)
+    dsd = H.full_dense_sd()
+    md_ = H.tw_dense_model(dsd, path=0)
+    for V, flags in ((256, 0), (40, 0), (40, 2097152)):
+        gg = torch.Generator().manual_seed(5)
+        at = torch.randint(0, 5, (2, V), generator=gg)
+        xx = torch.randn(2, V, 3, generator=gg)
+        yy = xx + torch.randn(2, V, 3, generator=gg) * 0.02
+        vv = torch.randn(2, V, 3, generator=gg) * 0.5
+        mk = torch.zeros(2, V, dtype=torch.bool)
+        mk[1, V - 7:] = True
+        try:
+            lib.tw_debug_set_flags(flags)
+            out = md_.log_likelihood(atom_types=at.cuda(), x_coords=xx.cuda(), x_velocs=vv.cuda(), y_coords=yy.cuda(), y_velocs=vv.cuda(),
+                                     adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda()).cpu()
+        finally:
+            lib.tw_debug_set_flags(0)
+        if V == 256:
+            ref = fo.log_likelihood(dsd, H.FULL_DENSE_SPEC, at, xx, vv, yy, vv, mk)
+            assert H.rel_err(out, ref) < TOL, H.rel_err(out, ref)
+        elif flags == 0:
+            tile = out
+        else:
+            assert torch.equal(out, tile)
 
 
 @pytest.mark.parametrize("path", [SIMPLE, FUSED, H3])

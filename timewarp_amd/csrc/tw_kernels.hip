@@ -177,8 +177,7 @@ __global__ void scores_rows_kernel(const float* __restrict__ x, const uint8_t* _
 
 // The small-molecule per-op kernels hold one molecule's V x V score / distance matrix in LDS.  Up to 64 KiB of dynamic LDS
 // launches as is; up to the CU's 160 KiB after raising the kernel's limit; beyond that the kernel-attention flow takes the
-// tiled kernels (scores_rows_kernel, attend_mfma_kernel: any V); the dense flow's sdpa_kernel has no tiled form and refuses
-// with a message instead of failing at launch.
+// tiled kernels (scores_rows_kernel, attend_mfma_kernel: any V), the dense flow sdpa_rows_kernel.
 #define TW_LDS_LIMIT(kernel, bytes, V)                                                                        \
   do {                                                                                                        \
     TW_REQUIRE((bytes) <= (size_t)160 * 1024,                                                                 \
@@ -730,6 +729,50 @@ __global__ void sdpa_kernel(const float* __restrict__ qkv, const uint8_t* __rest
   }
 }
 
+// The same attention without a V x V tile in the LDS (any V; r05): one thread per query row, keys and values read from the
+// qkv buffer (every thread of a workgroup reads the same key: broadcast loads), scores recomputed in each of the three passes
+// (max, sum, normalised mixing) instead of cached.  Same operations in the same order as sdpa_kernel: bit-identical.
+template <int DH>   // head width rounded up (registers, not scratch: every loop over the head is unrolled)
+__global__ void sdpa_rows_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ masked, int64_t n_cond,
+                                 float* __restrict__ out, int V, int d, int n_head) {
+  const int dh = d / n_head;
+  const int64_t n = blockIdx.x;
+  const int h = blockIdx.y;
+  const int a = blockIdx.z * blockDim.x + threadIdx.x;
+  if (a >= V) return;
+  const int64_t c = n % n_cond;
+  const float* base = qkv + n * V * 3 * (int64_t)d;
+  const uint8_t* mk = masked + c * V;
+  float q[DH];
+#pragma unroll
+  for (int j = 0; j < DH; ++j) q[j] = j < dh ? base[(int64_t)a * 3 * d + h * dh + j] / sqrtf((float)dh) : 0.f;
+  auto score = [&](int m) {
+    const float* k = base + (int64_t)m * 3 * d + d + h * dh;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < DH; ++j)
+      if (j < dh) acc = fmaf(q[j], k[j], acc);
+    return mk[m] ? -INFINITY : acc;
+  };
+  float mx = -INFINITY;
+  for (int m = 0; m < V; ++m) mx = fmaxf(mx, score(m));
+  float sum = 0.f;
+  for (int m = 0; m < V; ++m) sum += expf(score(m) - mx);
+  float acc[DH];
+#pragma unroll
+  for (int j = 0; j < DH; ++j) acc[j] = 0.f;
+  for (int m = 0; m < V; ++m) {
+    const float pm = expf(score(m) - mx) / sum;
+    const float* v = base + (int64_t)m * 3 * d + 2 * d + h * dh;
+#pragma unroll
+    for (int j = 0; j < DH; ++j)
+      if (j < dh) acc[j] = fmaf(pm, v[j], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < DH; ++j)
+    if (j < dh) out[(n * V + a) * (int64_t)d + h * dh + j] = acc[j];
+}
+
 // h = LayerNorm(h + delta) (custom_attention_encoder.py:109-114); one wave per token
 __global__ void add_ln_kernel(float* __restrict__ h, const float* __restrict__ delta, const float* __restrict__ w,
                               const float* __restrict__ b, float eps, int D, int64_t tokens) {
@@ -829,10 +872,19 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
     } else {
       if ((rc = launch_linear(w.h, lb + L.layer.in_w, lb + L.layer.in_b, w.vals, M, 3 * d.d_model, d.d_model, ACT_NONE, s))) return rc;
       const int dh = d.d_model / d.n_heads;
-      TW_LDS_LIMIT(sdpa_kernel, (size_t)(3 * V * dh + V * V) * 4, V);
-      hipLaunchKernelGGL(sdpa_kernel, dim3((unsigned)a.n_rows, d.n_heads), dim3(128),
-                         (size_t)(3 * V * dh + V * V) * 4, s, w.vals, a.masked, a.n_cond, w.att, V, d.d_model,
-                         d.n_heads);
+      const size_t sdpa_lds = (size_t)(3 * V * dh + V * V) * 4;
+      if (sdpa_lds > (size_t)160 * 1024 || (g_debug_flags & 2097152)) {  // no room for the score tile (or bit 21): row-wise
+        TW_REQUIRE(dh <= 64, "dense attention: head width %d > 64 on the row-wise per-op kernel", dh);
+        const dim3 grid((unsigned)a.n_rows, d.n_heads, (unsigned)((V + 127) / 128));
+        if (dh <= 16)
+          hipLaunchKernelGGL(sdpa_rows_kernel<16>, grid, dim3(128), 0, s, w.vals, a.masked, a.n_cond, w.att, V, d.d_model, d.n_heads);
+        else
+          hipLaunchKernelGGL(sdpa_rows_kernel<64>, grid, dim3(128), 0, s, w.vals, a.masked, a.n_cond, w.att, V, d.d_model, d.n_heads);
+      } else {
+        TW_LDS_LIMIT(sdpa_kernel, sdpa_lds, V);
+        hipLaunchKernelGGL(sdpa_kernel, dim3((unsigned)a.n_rows, d.n_heads), dim3(128), sdpa_lds, s, w.vals, a.masked, a.n_cond,
+                           w.att, V, d.d_model, d.n_heads);
+      }
       TW_LAUNCH_CHECK();
       if ((rc = launch_linear(w.att, lb + L.layer.out_w, lb + L.layer.out_b, w.tmp, M, d.d_model, d.d_model, ACT_NONE, s))) return rc;
     }
