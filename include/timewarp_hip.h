@@ -122,9 +122,9 @@ int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_
 #define TW_PATH_FUSED_H1 4 /* "fast" mode, NOT a parity path: the same fused kernel with ONE half-precision MFMA per
                               product (fp16 operands, 11 significand bits, fp32 accumulation) and half the weight stream.
                               Kernel attention, every molecule size TW_PATH_FUSED_H3 takes (48-token waves and the wide
-                              layout); the dense softmax model without position features too (its in / FFN / out
+                              layout); the dense softmax model up to 48 atoms too (its in / FFN / out
                               sections - 88 % of the work - run single-MFMA, the softmax attention block stays in
-                              split form).  Results deviate from the reference's fp32 arithmetic by
+                              split form; with position features the in-MLP as well).  Results deviate from the reference's fp32 arithmetic by
                               ~1e-4 relative (measured per case in tests/test_flow_h1_gpu.py); proposal and reverse-move
                               densities of an MH iteration are evaluated by the same arithmetic.  `packed` must point at
                               the tw_flow_pack_h1 stream.  Only ever chosen by name. */

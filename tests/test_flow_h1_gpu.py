@@ -146,12 +146,13 @@ def test_path_selection_by_name(monkeypatch):
     lib = _lib.load()
     assert lib.tw_flow_path_supported(C.byref(desc), 22, H1) == 1 and lib.tw_flow_path_supported(C.byref(desc), 60, H1) == 1
     assert 0 < lib.tw_flow_packed_h1_bytes(C.byref(desc)) < lib.tw_flow_packed_h3_bytes(C.byref(desc)) * 0.6
-    # the dense softmax variant has one too (its MLP sections; the attention block stays in split form) - but not with
-    # position features, where the preference falls back to the split-fp16 kernel
+    # the dense softmax variant has one too (its MLP sections; the attention block stays in split form), since r05 also with
+    # position features (the 192-column in-MLP stays in split form); above 48 atoms the preference falls back
     monkeypatch.setenv("TW_EXECUTION_PATH", "h1")
     md = tw.model_constructor(synthetic.transformer_nvp_config())
     assert md._path_for(22) == H1
-    assert H.tw_dense_model(H.full_dense_posenc_sd(), rff_dim=128, path=None)._path_for(22) == H3
+    mp = H.tw_dense_model(H.full_dense_posenc_sd(), rff_dim=128, path=None)
+    assert mp._path_for(22) == H1 and mp._path_for(60) != H1
     # by name on an unsupported shape: an error, not a silent other kernel
     mm = H.tw_kernel_model(H.full_kernel_sd(), path=H1)
     g = torch.Generator().manual_seed(0)
@@ -161,14 +162,17 @@ def test_path_selection_by_name(monkeypatch):
                           adj_list=None, edge_batch_idx=None, masked_elements=torch.zeros(1, 200, dtype=torch.bool).cuda())
 
 
-@pytest.mark.parametrize("name", ["dense_full_ad", "dense_full_padded"])
+@pytest.mark.parametrize("name", ["dense_full_ad", "dense_full_padded", "dense_posenc_full_ad"])
 def test_dense_model_fast_mode_measured_error(name):
     """transformer_nvp (BASELINE config 4) on the fast path: in / FFN / out sections with one fp16 MFMA per product, the
     softmax attention block unchanged (split-fp16).  Measured against the reference's vectors: log-likelihood 5.6e-4 /
     6.5e-4 (plain / padded), proposals 1.0-1.4e-3, log-densities 1.4e-4 / 2.0e-3 - the class of the kernel-attention fast
     mode; and clearly not the parity kernel (> 1e-5)."""
     d, _ = H.load(name)
-    m = H.tw_dense_model(H.full_dense_sd(), path=H1)
+    if "posenc" in name:   # r05: random Fourier position features - the in-MLP in split form, the rest single-MFMA
+        m = H.tw_dense_model(H.full_dense_posenc_sd(), rff_dim=128, path=H1)
+    else:
+        m = H.tw_dense_model(H.full_dense_sd(), path=H1)
     out = H.run_model_case(m, d)
     keep = ~d["masked"][0]
     e = {}

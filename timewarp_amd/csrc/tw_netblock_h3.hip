@@ -133,7 +133,10 @@ static H3Geom h3_geom(const tw_flow_desc& d, bool h1 = false) {
   g.stages = (int64_t)(g.in_a_stages + 2) * g.hid_chunks + (int64_t)g.L * (att_stages + 4LL * g.ff_chunks) + 3LL * g.hid_chunks;
   // (dense model: its attention stages keep the split form - q_h k_h v_h and the out_proj half-steps, 4 H stages per layer,
   //  which happens to be the count of the single-MFMA folded attention too; only the MLP sections change)
-  if (h1) g.stages = 2LL * g.hid_chunks + (int64_t)g.L * (4LL * g.H + 2LL * g.ff_chunks) + 2LL * g.hid_chunks;
+  //  With position features the in-MLP stays in split form as well - it runs as compiled C++ on 192 input columns)
+  if (h1)
+    g.stages = (g.in_a_stages == 1 ? 2LL : g.in_a_stages + 2LL) * g.hid_chunks + (int64_t)g.L * (4LL * g.H + 2LL * g.ff_chunks) +
+               2LL * g.hid_chunks;
   int64_t o = 0;
   g.side_in2b = o; o += 128;
   g.side_layers = o;
@@ -298,10 +301,11 @@ bool h3_supported(const tw_flow_desc& d, int n_atoms) {
 }
 
 // the single-MFMA variant exists for kernel attention (the 48-token encoder-stack build and the wide layout) and for the dense
-// model without position features (in / FFN / out sections single-MFMA, the softmax attention block in split form)
+// model on 48-token waves (in / FFN / out sections single-MFMA, the softmax attention block in split form; with position
+// features the in-MLP stays in split form too - r05)
 bool h1_supported(const tw_flow_desc& d, int n_atoms) {
   FusedGeom fg;
-  if (d.variant == 1) return d.d_rff == 0 && h3_supported(d, n_atoms) && fused_geom_nt(n_atoms, H3_NT, &fg);  // (48-token waves only)
+  if (d.variant == 1) return h3_supported(d, n_atoms) && fused_geom_nt(n_atoms, H3_NT, &fg);  // (48-token waves only)
   return d.variant == 0 && h3_supported(d, n_atoms);
 }
 
@@ -405,8 +409,6 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
                     hipStream_t s, bool h1) {
   const RawLayout L = raw_layout(d);
   const H3Geom g = h3_geom(d, h1);
-  TW_REQUIRE(!h1 || d.variant == 0 || (d.variant == 1 && d.d_rff == 0),
-             "the single-MFMA stream exists for kernel attention and for the dense model without position features");
   TW_HIP_CHECK(hipMemsetAsync(packed, 0, h3_packed_bytes(d, h1), s));
   auto absmax = [&](const float* src, int64_t n, float* up, float* down) -> int {
     TW_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float), s));
@@ -452,7 +454,9 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
       }
       const int ia = g.in_a_stages, ks_in = 2 * ia;  // k-steps of the first GEMM: 2 or 6
       const int ib = h1 ? 1 : 2;                      // B stages per chunk of the in-MLP / FFN
-      if (h1) {
+      const bool in_h1 = h1 && !d.d_rff;              // (position features: the in-MLP keeps the split form, see h3_geom)
+      const int ib_in = in_h1 ? 1 : 2;
+      if (in_h1) {
         for (int ch = 0; ch < g.hid_chunks; ++ch) {
           char* a = st + a_off(ch, g.hid_chunks, 1, 1) * H3_STAGE_BYTES;
           if ((rc = block(nb + L.net.in0_w, L.d_in, d.d_hidden, L.d_in, 32 * ch, 0, 2, 2, up, a))) return rc;  // tile 2 o + ks
@@ -465,7 +469,8 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
           char* a = st + (a_off(ch, g.hid_chunks, ia, 2) + a_) * H3_STAGE_BYTES;
           for (int pp = 0; pp < H3_STAGE_PAIRS; ++pp) {  // pair q = (o, ks), four to a stage (h3_mlp_chain)
             const int q = a_ * H3_STAGE_PAIRS + pp, o = q / ks_in, ks = q % ks_in;
-            if ((rc = block(nb + L.net.in0_w, L.d_in, d.d_hidden, L.d_in, 32 * ch + 16 * o, 32 * ks, 1, 1, up, a + pp * H3_PAIR_BYTES)))
+            if ((rc = block_fmt(nb + L.net.in0_w, L.d_in, d.d_hidden, L.d_in, 32 * ch + 16 * o, 32 * ks, 1, 1, up, a + pp * H3_PAIR_BYTES,
+                                in_h1 ? 1 : 0)))
               return rc;
           }
           if (a_ == 0) {
@@ -475,11 +480,12 @@ int h3_pack_weights(const tw_flow_desc& d, const float* raw, char* packed, float
         }
       if ((rc = absmax(nb + L.net.in2_w, (int64_t)128 * d.d_hidden, up, scales + 1))) return rc;
       for (int ch = 0; ch < g.hid_chunks; ++ch)
-        for (int hf = 0; hf < ib; ++hf) {
-          char* b = st + (b_off(ch, g.hid_chunks, ia, ib) + hf) * H3_STAGE_BYTES;
-          if ((rc = block(nb + L.net.in2_w, d.d_hidden, 128, d.d_hidden, 64 * hf, 32 * ch, h1 ? 8 : 4, 1, up, b))) return rc;
+        for (int hf = 0; hf < ib_in; ++hf) {
+          char* b = st + (b_off(ch, g.hid_chunks, ia, ib_in) + hf) * H3_STAGE_BYTES;
+          if ((rc = block_fmt(nb + L.net.in2_w, d.d_hidden, 128, d.d_hidden, 64 * hf, 32 * ch, in_h1 ? 8 : 4, 1, up, b, in_h1 ? 1 : 0)))
+            return rc;
         }
-      st += (int64_t)(ia + ib) * g.hid_chunks * H3_STAGE_BYTES;
+      st += (int64_t)(ia + ib_in) * g.hid_chunks * H3_STAGE_BYTES;
       if ((rc = copy(nb + L.net.in2_b, 128, side + g.side_in2b, 128))) return rc;
       // ---- layers
       for (int l = 0; l < d.n_layers; ++l) {
@@ -2890,7 +2896,11 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   } else if (h1) {
     // single-MFMA build: the encoder-stack statements (section stamps compiled in; no activation dumps), or the per-section builds
     TW_REQUIRE(h1_supported(d, a.n_atoms) && d.n_layers >= 1, "single-MFMA path: unsupported configuration");
-    if (d.variant == 1) {
+    if (d.variant == 1 && d.d_rff > 0) {
+      // r05: position features - the in-MLP as compiled C++ in split form (192 input columns), everything behind it single-MFMA
+      TW_REQUIRE(!per_section, "single-MFMA path with position features: the encoder-stack statement only");
+      H3_LAUNCH(H3D_ENC_LDS_BYTES, 3, true, true, false, true, true, true, false);
+    } else if (d.variant == 1) {
       if (per_section) H3_LAUNCH(H3D_LDS_BYTES, 3, true, true, false, false, false, true, false);
       else H3_LAUNCH(H3D_ENC_LDS_BYTES, 3, true, true, false, false, true, true, false);
     } else if (wide) {
