@@ -194,7 +194,8 @@ class Wave:
         # [g][row][e] -> [row][g * kper + e]
         Am = A.reshape(4, 16, kper).transpose(1, 0, 2).reshape(16, 4 * kper)
         Bm = B.reshape(4, 16, kper).transpose(0, 2, 1).reshape(4 * kper, 16)
-        D = Am.astype(np.float64) @ Bm.astype(np.float64)
+        with np.errstate(invalid="ignore", over="ignore"):   # (garbage operands of the negative controls)
+            D = Am.astype(np.float64) @ Bm.astype(np.float64)
         if c.strip() != "0":
             # lane l, register r: C[4 (l / 16) + r][l % 16]
             cv = np.stack([_f32(self.rd(c, r)) for r in range(4)], axis=0)          # [r][lane]
