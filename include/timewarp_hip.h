@@ -385,7 +385,9 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *              last bits (A/B switch and tests).  The paired layout exists as the encoder-stack build only: bits 2 / 4 / 12
  *              (without 13) and tw_debug_netblock take the 48-token wide layout as well
  *   bit 21 (2097152) per-op path: the row-wise scores kernel and the tiled MFMA mixing kernel (what molecules above ~200 / 64
- *              atoms take) at every size; same scores bit for bit, the mixing in another summation order (A/B switch and tests) */
+ *              atoms take) at every size; same scores bit for bit, the mixing in another summation order (A/B switch and tests)
+ *   bit 22 (4194304) / bit 23 (8388608)  tw_mh_iteration: the energy kernel on the caller's stream / on the side stream,
+ *              whatever the launch size (default: side stream only while the flow's launches leave compute units idle) */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

@@ -335,17 +335,28 @@ int tw_mh_iteration(const tw_flow_desc* desc, const float* raw, const void* pack
   }
   hipStream_t side = sides[dev_id];
   hipEvent_t ev_y = evs[dev_id][0], ev_e = evs[dev_id][1];
-  TW_HIP_CHECK(hipEventRecord(ev_y, s));
-  TW_HIP_CHECK(hipStreamWaitEvent(side, ev_y, 0));
-  if ((rc = amber_energy(ff, zy_coords, w.e_pot, nullptr, S + 1, side))) return rc;
-  TW_HIP_CHECK(hipEventRecord(ev_e, side));
+  // Side stream or not?  The overlap pays only while the flow's launches leave compute units idle.  Once they fill the chip
+  // (from ~160 workgroups of 192 token slots per net pair on) the energy kernel merely time-shares with the first net-block
+  // launch of the forward pass, and the two event hand-offs cost the main stream 6-8 us each: measured r05
+  // (tools/ab_energy.py, one box) inline is 25 us per iteration faster on alanine dipeptide x 1000 (0.4 %), 70 us on the dense
+  // model, neutral at 61-65 atoms x 512.  Bit 22 forces the main stream, bit 23 the side stream (A/B).
+  const int dbg = g_debug_flags;
+  const bool inline_energy = (dbg & 8388608) ? false : ((dbg & 4194304) ? true : 2 * S * (int64_t)V >= (int64_t)160 * 192);
+  if (inline_energy) {
+    if ((rc = amber_energy(ff, zy_coords, w.e_pot, nullptr, S + 1, s))) return rc;
+  } else {
+    TW_HIP_CHECK(hipEventRecord(ev_y, s));
+    TW_HIP_CHECK(hipStreamWaitEvent(side, ev_y, 0));
+    if ((rc = amber_energy(ff, zy_coords, w.e_pot, nullptr, S + 1, side))) return rc;
+    TW_HIP_CHECK(hipEventRecord(ev_e, side));
+  }
   // reverse move: flow forward pass, every row conditioned on its own proposal (evaluation_utils.py:648-657)
   if ((rc = tw_flow_pass(desc, raw, (const float*)packed, w.types_rep, w.c_c, w.c_v, w.masked_rep, S, w.t_c, w.t_v, w.delta, S,
                          V, 0, path, w.flow, w.flow_bytes, stream)))
     return rc;
   hipLaunchKernelGGL(mh_pyx_kernel, dim3((unsigned)S), dim3(64), 0, s, w.t_c, w.t_v, masked, prior, w.delta, w.p_yx, V);
   TW_LAUNCH_CHECK();
-  TW_HIP_CHECK(hipStreamWaitEvent(s, ev_e, 0));
+  if (!inline_energy) TW_HIP_CHECK(hipStreamWaitEvent(s, ev_e, 0));
   hipLaunchKernelGGL(mh_accept_full_kernel, dim3(1), dim3(1024), 0, s, w.e_pot, w.ekin_y, w.ekin_x, w.chir, w.p_xy, w.p_yx, u,
                      zy_coords, zy_velocs, x_coords, x_velocs, new_coords, new_velocs, out_stats, out_accepted, result,
                      1.0f / opt->kbT, S, V);
