@@ -52,12 +52,13 @@ struct LdsLimit {
 __host__ __device__ inline size_t excl_bytes(int V) { return ((size_t)V * V + 31) / 32 * 4; }
 #ifdef __HIPCC__
 __device__ __forceinline__ bool excl_test(const unsigned* bits, int idx) { return (bits[idx >> 5] >> (idx & 31)) & 1u; }
-// all 64 lanes of the (single-wave) block; leaves the matrix complete after its last __syncthreads()
-__device__ __forceinline__ void excl_fill(const int* exc_idx, int n_exceptions, int V, unsigned* bits, int lane) {
+// all threads of the block (64: one wave, unless `nthreads` says otherwise); leaves the matrix complete after its last
+// __syncthreads()
+__device__ __forceinline__ void excl_fill(const int* exc_idx, int n_exceptions, int V, unsigned* bits, int lane, int nthreads = 64) {
   const int words = (int)(excl_bytes(V) / 4);
-  for (int i = lane; i < words; i += 64) bits[i] = 0u;
+  for (int i = lane; i < words; i += nthreads) bits[i] = 0u;
   __syncthreads();
-  for (int e = lane; e < n_exceptions; e += 64) {
+  for (int e = lane; e < n_exceptions; e += nthreads) {
     const int i = exc_idx[2 * e], j = exc_idx[2 * e + 1];
     atomicOr(&bits[(i * V + j) >> 5], 1u << ((i * V + j) & 31));
     atomicOr(&bits[(j * V + i) >> 5], 1u << ((j * V + i) & 31));

@@ -1,4 +1,6 @@
-// AMBER-style potential energy on the GPU: one wave per conformation, fp64 arithmetic.
+// AMBER-style potential energy on the GPU: one workgroup per conformation - one wave, or four for small molecules (r05: at 22
+// atoms the single wave spent most of its 27 us in the 21 serial iterations of the Born-radius loop with 22 of 64 lanes active;
+// the kernel sits on the MH iteration's critical path since the flow's launches fill the chip) - fp64 arithmetic.
 //
 // Replaces the OpenMM call chain behind OpenmmPotentialEnergyTorch.forward
 // (utils/openmm/openmm_bridge.py:281-294 -> bgflow -> Context.getState(getEnergy=True)) for Systems
@@ -19,22 +21,28 @@ __device__ __forceinline__ double wsum(double v) {
   return v;
 }
 
-__global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff, const float* __restrict__ coords,
-                                                           double* __restrict__ out, double* __restrict__ terms) {
+// W waves per conformation.  W > 1: every loop strides over the whole workgroup, and the Born-radius sums are computed pair-parallel
+// into a V x V table that one lane per atom then adds up in the single-wave kernel's order (same radii bit for bit).
+template <int W>
+__global__ void __launch_bounds__(64 * W) amber_energy_kernel(const tw_forcefield ff, const float* __restrict__ coords,
+                                                               double* __restrict__ out, double* __restrict__ terms) {
   extern __shared__ __attribute__((aligned(16))) double smd[];
+  constexpr int NTH = 64 * W;
   const int V = ff.n_atoms;
   double* x = smd;             // [V*3]
   double* born = x + 3 * V;    // [V]
-  unsigned* excl = (unsigned*)(born + V);  // [V*V] bits
+  double* part = born + V;     // [W * 5] partial sums of the waves
+  double* tmat = part + 5 * W; // [V*V] (W > 1 only)
+  unsigned* excl = (unsigned*)(tmat + (W > 1 ? V * V : 0));  // [V*V] bits
   const int64_t n = blockIdx.x;
-  const int lane = threadIdx.x;
-  for (int i = lane; i < 3 * V; i += 64) x[i] = (double)coords[n * 3 * V + i];
-  excl_fill(ff.exc_idx, ff.n_exceptions, V, excl, lane);
+  const int lane = threadIdx.x;   // (thread of the workgroup)
+  for (int i = lane; i < 3 * V; i += NTH) x[i] = (double)coords[n * 3 * V + i];
+  excl_fill(ff.exc_idx, ff.n_exceptions, V, excl, lane, NTH);
 
   double e_bond = 0, e_angle = 0, e_tors = 0, e_nb = 0, e_gb = 0;
 
   // HarmonicBondForce: 1/2 k (r - r0)^2
-  for (int b = lane; b < ff.n_bonds; b += 64) {
+  for (int b = lane; b < ff.n_bonds; b += NTH) {
     const int i = ff.bond_idx[2 * b], j = ff.bond_idx[2 * b + 1];
     const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
@@ -42,7 +50,7 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
     e_bond += 0.5 * ff.bond_par[2 * b + 1] * d * d;
   }
   // HarmonicAngleForce: 1/2 k (theta - theta0)^2
-  for (int a = lane; a < ff.n_angles; a += 64) {
+  for (int a = lane; a < ff.n_angles; a += NTH) {
     const int i = ff.angle_idx[3 * a], j = ff.angle_idx[3 * a + 1], k = ff.angle_idx[3 * a + 2];
     double v0[3], v1[3];
     for (int c = 0; c < 3; ++c) { v0[c] = x[3 * i + c] - x[3 * j + c]; v1[c] = x[3 * k + c] - x[3 * j + c]; }
@@ -55,7 +63,7 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
     e_angle += 0.5 * ff.angle_par[2 * a + 1] * d * d;
   }
   // PeriodicTorsionForce: k (1 + cos(n phi - phase))
-  for (int t = lane; t < ff.n_torsions; t += 64) {
+  for (int t = lane; t < ff.n_torsions; t += NTH) {
     const int a = ff.torsion_idx[4 * t], b = ff.torsion_idx[4 * t + 1], c = ff.torsion_idx[4 * t + 2],
               d = ff.torsion_idx[4 * t + 3];
     double r0[3], r1[3], r2[3];
@@ -78,7 +86,7 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
     e_tors += ff.torsion_par[3 * t + 2] * (1.0 + cos(ff.torsion_par[3 * t] * phi - ff.torsion_par[3 * t + 1]));
   }
   // NonbondedForce exceptions (1-4 pairs; 1-2/1-3 carry zeros): no cutoff, no reaction field
-  for (int e = lane; e < ff.n_exceptions; e += 64) {
+  for (int e = lane; e < ff.n_exceptions; e += NTH) {
     const double qq = ff.exc_par[3 * e], sig = ff.exc_par[3 * e + 1], eps = ff.exc_par[3 * e + 2];
     if (qq == 0.0 && eps == 0.0) continue;
     const int i = ff.exc_idx[2 * e], j = ff.exc_idx[2 * e + 1];
@@ -93,7 +101,7 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
   const double krf = use_cut ? (1.0 / (rc * rc * rc)) * (ff.rf_dielectric - 1.0) / (2.0 * ff.rf_dielectric + 1.0) : 0.0;
   const double crf = use_cut ? (1.0 / rc) * (3.0 * ff.rf_dielectric) / (2.0 * ff.rf_dielectric + 1.0) : 0.0;
   const int npairs = V * (V - 1) / 2;
-  for (int p = lane; p < npairs; p += 64) {
+  for (int p = lane; p < npairs; p += NTH) {
     // decode (i<j) from the linear index
     int i = (int)((sqrt(8.0 * p + 1.0) + 1.0) * 0.5);
     while (i * (i - 1) / 2 > p) --i;
@@ -118,29 +126,40 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
     const double offset = 0.009, probe = 0.14;
     const double alpha = ff.has_gbsa == 2 ? 0.8 : 1.0, beta = ff.has_gbsa == 2 ? 0.0 : 0.8,
                  gamma = ff.has_gbsa == 2 ? 2.909125 : 4.85;
-    for (int i = lane; i < V; i += 64) {
+    // one (i, j) term of atom i's pair integral (OpenMM's ReferenceObc::computeBornRadii)
+    auto born_term = [&](int i, int j, double off_i) -> double {
+      const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+      const double r = sqrt(dx * dx + dy * dy + dz * dz);
+      if (use_cut && r > rc) return 0.0;
+      const double off_j = ff.atom_par[5 * j + 3] - offset;
+      const double sr_j = off_j * ff.atom_par[5 * j + 4];
+      const double r_sr = r + sr_j;
+      if (!(off_i < r_sr)) return 0.0;
+      const double rinv = 1.0 / r;
+      const double ad = fabs(r - sr_j);
+      const double l = 1.0 / (off_i > ad ? off_i : ad);
+      const double u = 1.0 / r_sr;
+      const double l2 = l * l, u2 = u * u;
+      const double ratio = log(u / l);
+      double term = l - u + 0.25 * r * (u2 - l2) + 0.5 * rinv * ratio + 0.25 * sr_j * sr_j * rinv * (l2 - u2);
+      if (off_i < (sr_j - r)) term += 2.0 * (1.0 / off_i - l);
+      return term;
+    };
+    if constexpr (W > 1) {
+      for (int p = lane; p < V * V; p += NTH) {
+        const int i = p / V, j = p - i * V;
+        tmat[p] = i == j ? 0.0 : born_term(i, j, ff.atom_par[5 * i + 3] - offset);
+      }
+      __syncthreads();
+    }
+    for (int i = lane; i < V; i += NTH) {
       const double rad_i = ff.atom_par[5 * i + 3];
       const double off_i = rad_i - offset;
       double sum = 0.0;
       for (int j = 0; j < V; ++j) {
         if (j == i) continue;
-        const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
-        const double r = sqrt(dx * dx + dy * dy + dz * dz);
-        if (use_cut && r > rc) continue;
-        const double off_j = ff.atom_par[5 * j + 3] - offset;
-        const double sr_j = off_j * ff.atom_par[5 * j + 4];
-        const double r_sr = r + sr_j;
-        if (off_i < r_sr) {
-          const double rinv = 1.0 / r;
-          const double ad = fabs(r - sr_j);
-          const double l = 1.0 / (off_i > ad ? off_i : ad);
-          const double u = 1.0 / r_sr;
-          const double l2 = l * l, u2 = u * u;
-          const double ratio = log(u / l);
-          double term = l - u + 0.25 * r * (u2 - l2) + 0.5 * rinv * ratio + 0.25 * sr_j * sr_j * rinv * (l2 - u2);
-          if (off_i < (sr_j - r)) term += 2.0 * (1.0 / off_i - l);
-          sum += term;
-        }
+        if constexpr (W > 1) sum += tmat[i * V + j];
+        else sum += born_term(i, j, off_i);
       }
       sum *= 0.5 * off_i;
       const double s2 = sum * sum, s3 = sum * s2;
@@ -151,7 +170,7 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
     const double pre = -TW_ONE_4PI_EPS0 * (1.0 / ff.solute_dielectric - 1.0 / ff.solvent_dielectric);
     // ACE non-polar term: 4 pi * surface_area_energy * (r+probe)^2 (r/B)^6
     const double pi4a = 4.0 * 3.14159265358979323846 * ff.surface_area_energy;
-    for (int i = lane; i < V; i += 64) {
+    for (int i = lane; i < V; i += NTH) {
       const double rad = ff.atom_par[5 * i + 3];
       if (born[i] > 0.0) {
         const double rr = rad + probe;
@@ -163,7 +182,7 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
       const double q = ff.atom_par[5 * i];
       e_gb += 0.5 * pre * q * q / born[i];
     }
-    for (int p = lane; p < npairs; p += 64) {
+    for (int p = lane; p < npairs; p += NTH) {
       int i = (int)((sqrt(8.0 * p + 1.0) + 1.0) * 0.5);
       while (i * (i - 1) / 2 > p) --i;
       while ((i + 1) * i / 2 <= p) ++i;
@@ -181,6 +200,19 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
     }
   }
   e_bond = wsum(e_bond); e_angle = wsum(e_angle); e_tors = wsum(e_tors); e_nb = wsum(e_nb); e_gb = wsum(e_gb);
+  if constexpr (W > 1) {   // the waves' sums, added in wave order
+    if ((lane & 63) == 0) {
+      double* q = part + 5 * (lane >> 6);
+      q[0] = e_bond; q[1] = e_angle; q[2] = e_tors; q[3] = e_nb; q[4] = e_gb;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      e_bond = e_angle = e_tors = e_nb = e_gb = 0.0;
+      for (int w = 0; w < W; ++w) {
+        e_bond += part[5 * w]; e_angle += part[5 * w + 1]; e_tors += part[5 * w + 2]; e_nb += part[5 * w + 3]; e_gb += part[5 * w + 4];
+      }
+    }
+  }
   if (lane == 0) {
     out[n] = e_bond + e_angle + e_tors + e_nb + e_gb;
     if (terms) {
@@ -193,13 +225,19 @@ __global__ void __launch_bounds__(64) amber_energy_kernel(const tw_forcefield ff
 int amber_energy(const tw_forcefield* ff, const float* coords, double* out, double* terms, int64_t n, hipStream_t s) {
   if (n == 0) return TW_OK;
   const int V = ff->n_atoms;
-  size_t shm = (size_t)(4 * V) * sizeof(double) + excl_bytes(V);
+  const bool four = V <= 64;   // small molecules: latency-bound, four waves per conformation (+ the V x V table: <= 32 KiB)
+  const int W = four ? 4 : 1;
+  size_t shm = (size_t)(4 * V + 5 * W + (four ? V * V : 0)) * sizeof(double) + excl_bytes(V);
   shm = (shm + 15) / 16 * 16;
-  TW_REQUIRE(shm <= (size_t)160 * 1024, "energy kernel: %d atoms need %zu bytes of LDS (one conformation per wave; limit 160 KiB)", V, shm);
-  static LdsLimit lim;
+  TW_REQUIRE(shm <= (size_t)160 * 1024, "energy kernel: %d atoms need %zu bytes of LDS (one conformation per workgroup; limit 160 KiB)", V, shm);
   int rc;
-  if (shm > (size_t)64 * 1024 && (rc = lim.ensure((const void*)amber_energy_kernel, 160 * 1024))) return rc;
-  hipLaunchKernelGGL(amber_energy_kernel, dim3((unsigned)n), dim3(64), shm, s, *ff, coords, out, terms);
+  if (four) {
+    hipLaunchKernelGGL(amber_energy_kernel<4>, dim3((unsigned)n), dim3(256), shm, s, *ff, coords, out, terms);
+  } else {
+    static LdsLimit lim;
+    if (shm > (size_t)64 * 1024 && (rc = lim.ensure((const void*)amber_energy_kernel<1>, 160 * 1024))) return rc;
+    hipLaunchKernelGGL(amber_energy_kernel<1>, dim3((unsigned)n), dim3(64), shm, s, *ff, coords, out, terms);
+  }
   TW_LAUNCH_CHECK();
   return TW_OK;
 }
