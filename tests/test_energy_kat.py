@@ -237,6 +237,33 @@ def test_hip_kernels_on_segments_of_the_protein():
 
 
 @pytest.mark.gpu
+def test_hip_energy_kernel_small_molecule_build_on_short_segments():
+    """Up to 64 atoms the energy kernel runs four waves per conformation with pair-parallel Born-radius sums (r05); the
+    segments above and the peptide files are all larger.  Three-residue segments of the protein (every residue type again)
+    against the C oracle, and alanine dipeptide's own tables."""
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.forcefield import amber99sbildn_obc_tables
+
+    z = protein()
+    names, res, rid = list(z["atom_names"]), list(z["residue_names"]), list(z["residue_ids"])
+    order = list(dict.fromkeys(rid))
+    seen, sizes = set(), []
+    for start in range(0, len(order) - 2, 2):
+        keep_res = set(order[start:start + 3])
+        sel = [a for a in range(691) if rid[a] in keep_res]
+        if len(sel) > 64:
+            continue
+        sizes.append(len(sel))
+        seen |= {res[a] for a in sel}
+        t = amber99sbildn_obc_tables([names[a] for a in sel], [res[a] for a in sel], [rid[a] for a in sel])
+        x = z["positions"][:, sel]
+        e_ref, _ = H.oracle_energy(t, x)
+        en = AmberPotentialEnergyTorch(t).energy_and_forces(torch.from_numpy(x).cuda())[0]
+        assert np.allclose(en.cpu().numpy(), e_ref, rtol=0, atol=1e-6 * np.abs(e_ref).max()), (start, len(sel))
+    assert len(seen) >= 16 and min(sizes) < 40 and max(sizes) > 55, (sorted(seen), sizes)
+
+
+@pytest.mark.gpu
 def test_hip_kernels_on_the_held_out_frames():
     """Energy and analytic forces of the HIP kernels on all 86 held-out frames (see above)."""
     from timewarp_amd.energy import AmberPotentialEnergyTorch
