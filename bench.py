@@ -537,6 +537,56 @@ def whole_job_rates(accepted, proposals, states, elapsed, device):
     return accepted / elapsed, proposals / elapsed, states / elapsed, accepted
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves - re-run this same
+    command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <free>` (the form the measurement contract names), pass rank 0's JSON line through and exit with the
+    job's status.  Inside a torchrun environment whose WORLD_SIZE is not N the run is refused: a line whose `n_gpus`
+    differs from `--gpus` would be read as a measurement of N GPUs."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with --nproc-per-node {args.gpus} "
+                             f"(or unset the torchrun variables: `python bench.py --gpus {args.gpus}` starts its own ranks)")
+        return
+    if args.gpus == 1:
+        return
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    import socket
+    import subprocess
+
+    with socket.socket() as s:   # a free rendezvous port on the loopback interface (the container hostname may not resolve)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def plumbing_only(args, rank, world):
+    """--plumbing-only: the launch form and the N > 1 leg of the timed region on dummy per-rank trajectories (ragged lengths, as
+    at collection).  The line is marked and carries no metric - it exists so that the bare `python bench.py --gpus N` form can
+    be exercised without a GPU."""
+    traj = torch.full((3 + rank, V_ATOMS, 3), float(rank))
+    t0 = time.perf_counter()
+    gathered, elapsed = end_timed_region(traj, t0, "cpu", world)
+    _, _, states, _ = whole_job_rates(0.0, 0.0, float(traj.shape[0]), 1.0, "cpu")   # the counters' all-reduce: sum of the lengths
+    ok = len(gathered) == world and all(g.shape[0] == 3 + r and bool((g == r).all()) for r, g in enumerate(gathered))
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "metric": None, "value": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "per_rank_ms": [t * 1e3 for t in end_timed_region.per_rank_seconds],
+                          "gathered_ok": ok, "states_gathered": states,
+                          "backend": torch.distributed.get_backend() if world > 1 else None}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench.py --plumbing-only: the gathered trajectories are wrong")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -553,6 +603,10 @@ def main():
                     help="chains per GPU evaluated in lock-step (SURVEY 8f-1): the launch's rows (--proposals) are shared, "
                          "proposals // chains per chain and iteration.  Default 1 = the BASELINE configuration; a line of its own "
                          "otherwise (no alternative paths, no CPU baseline)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launch check, NOT a measurement: the ranks rendezvous (gloo unless TW_DIST_BACKEND says otherwise), run "
+                         "the timed region's collection leg on dummy trajectories and rank 0 prints a line marked "
+                         "\"plumbing_only\": true.  No GPU, no kernels - what tests/test_distributed_cpu.py runs")
     ap.add_argument("--path", choices=sorted(PATHS), default="h3",
                     help="flow execution path: split-fp16 fused kernel (default, the headline), exact-f32 fused kernel, or the "
                          "opt-in single-MFMA fast mode h1 (not a parity path)")
@@ -563,13 +617,19 @@ def main():
     if args.config in ("dense", "4aa", "4aa-nnqq") and args.path == "f32":
         ap.error("--config dense / 4aa are measured on the default (split-fp16) path h3 or the opt-in fast mode h1")
 
-    from timewarp_amd import _lib, distributed
+    self_launch(args)   # returns only in a process that IS one of the --gpus ranks
+
+    from timewarp_amd import distributed
 
     # TW_DIST_BACKEND=gloo + one GPU shared by all ranks is a plumbing check of the N>1 path on a 1-GPU box
     # (tools/README.md); the driver's runs use RCCL ("nccl") with one GPU per rank.
-    rank, world, local = distributed.init_from_env(os.environ.get("TW_DIST_BACKEND", "nccl"))
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    rank, world, local = distributed.init_from_env(os.environ.get("TW_DIST_BACKEND", "gloo" if args.plumbing_only else "nccl"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")   # (self_launch checked the env)
+    if args.plumbing_only:
+        return plumbing_only(args, rank, world)
+    from timewarp_amd import _lib
+
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
     backend = os.environ.get("TW_DIST_BACKEND", "nccl")

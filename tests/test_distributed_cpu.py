@@ -209,3 +209,46 @@ def test_eight_ranks_library_race_and_ragged_collection_gloo(tmp_path):
     for p in procs:
         p.join(timeout=60)
     assert results == {r: True for r in range(8)}
+
+
+def _clean_env():
+    """What a driver's bare `python3 bench.py ...` sees: no torchrun variables at all."""
+    keep = ("PATH", "HOME", "LD_LIBRARY_PATH", "PYTHONPATH", "TMPDIR", "HSA_ENABLE_IPC_MODE_LEGACY", "ROCM_PATH", "HIP_VISIBLE_DEVICES")
+    return {k: v for k, v in os.environ.items() if k in keep}
+
+
+def _json_lines(text):
+    import json
+
+    out = []
+    for line in text.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            out.append(json.loads(line))
+    return out
+
+
+def test_bare_bench_command_starts_its_own_ranks():
+    """`python bench.py --gpus N` without torchrun used to run ONE rank and print "n_gpus": 1.  The bare
+    form must start N ranks itself (re-exec under torch.distributed.run), and a torchrun environment of another size must be
+    refused.  --plumbing-only: the launch + collection leg without a GPU (the GPU suite runs the real line the same way)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1", "--plumbing-only"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600, cwd="/tmp")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout   # rank 0 only
+    line = lines[0]
+    assert line["n_gpus"] == 2 and len(line["per_rank_ms"]) == 2 and line["gathered_ok"] and line["states_gathered"] == 7.0
+    assert line["plumbing_only"] is True and line["value"] is None   # can never be mistaken for a measurement
+    # a torchrun environment that disagrees with --gpus: refused, nothing printed
+    env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--plumbing-only"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not _json_lines(r.stdout) and "WORLD_SIZE=1" in r.stderr
+    env["WORLD_SIZE"] = "2"
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--plumbing-only"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not _json_lines(r.stdout)

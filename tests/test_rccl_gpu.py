@@ -51,3 +51,42 @@ def test_single_rank_nccl_group_runs_the_paths_collectives():
     r = subprocess.run([sys.executable, "-c", _SCRIPT.format(root=root, port=port)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "RCCL_OK True" in r.stdout, r.stdout
+
+
+def _clean_env(**extra):
+    keep = ("PATH", "HOME", "LD_LIBRARY_PATH", "PYTHONPATH", "TMPDIR", "HSA_ENABLE_IPC_MODE_LEGACY", "ROCM_PATH", "HIP_VISIBLE_DEVICES")
+    env = {k: v for k, v in os.environ.items() if k in keep}
+    env.update(extra)
+    return env
+
+
+def _json_lines(text):
+    import json
+
+    return [json.loads(l) for l in (x.strip() for x in text.splitlines()) if l.startswith("{") and l.endswith("}")]
+
+
+def test_bare_bench_command_runs_n_ranks_on_the_gpu():
+    """The driver's form - `python bench.py --gpus N ...`, no torchrun variables - must measure N ranks.
+    On a 1-GPU box: (a) N = 2 with TW_DIST_BACKEND=gloo (both ranks share the GPU: a plumbing line, two per-rank times, the
+    all-gather inside the timed region); (b) N = 2 under RCCL is REFUSED (one GPU per rank or nothing) with a non-zero exit
+    and no line; (c) N = 1 prints n_gpus 1."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--chains", "2"]   # --chains: a line without the headline's companions
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"] + common, env=_clean_env(TW_DIST_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and len(lines[0]["per_rank_ms"]) == 2 and lines[0]["value"] > 0, r.stdout
+    assert lines[0]["proposals_per_s"] > 0 and lines[0]["roofline"]["frac"] > 0
+    import torch
+
+    if torch.cuda.device_count() == 1:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2"] + common, env=_clean_env(), capture_output=True, text=True, timeout=900)
+        assert r.returncode != 0 and not _json_lines(r.stdout), r.stdout[-2000:]
+        assert "one GPU per rank" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "1"] + common, env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and len(lines[0]["per_rank_ms"]) == 1
