@@ -172,11 +172,16 @@ class LockStepChains:
         self.inner.step_deferred()
 
     def flush(self):
-        self.inner.flush()
+        # lagged read-back: start copying this window's accept results, book the window before it (multichain.py)
+        self.inner.flush(lag=True)
 
-    accepted = property(lambda self: sum(self.inner.accepted))
+    def _settled(self):
+        self.inner.flush()   # everything queued so far is booked before a counter is read
+        return self.inner
+
+    accepted = property(lambda self: sum(self._settled().accepted))
     proposals = property(lambda self: self.inner.proposals)
-    chain_c = property(lambda self: [t for per_chain in self.inner.chain_c for t in per_chain])
+    chain_c = property(lambda self: [t for per_chain in self._settled().chain_c for t in per_chain])
 
     def trajectory(self):
         self.inner.flush()

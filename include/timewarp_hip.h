@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 7
+#define TW_ABI_VERSION 8
 
 typedef enum {
   TW_OK = 0,
@@ -314,6 +314,43 @@ int tw_mh_iteration(const tw_flow_desc* desc, const float* raw, const void* pack
                     float* zy_coords, float* zy_velocs, const float* u, float* new_coords, float* new_velocs,
                     float* out_stats, uint8_t* out_accepted, int32_t* result, int64_t n_proposals,
                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ABI 8 - extension (the reference runs ONE chain per process, utils/evaluation_utils.py:517): the same
+ * iteration for n_chains independent chains of one molecule in lock-step - ONE flow reverse pass over n_proposals x n_chains
+ * rows, ONE energy launch (proposals + the n_chains current states), ONE forward pass, one accept workgroup per chain.  Row
+ * order of every per-proposal array: index = proposal * n_chains + chain (the reference's [S, B] reshape, flow.py:284-296).
+ * Per chain the arithmetic is that of tw_mh_iteration on that chain alone.
+ *   atom_types / masked [n_chains, n_atoms]; x_coords / x_velocs [n_chains, n_atoms, 3]: the current states;
+ *   cur_velocs [n_chains, n_atoms, 3] OUT: the velocities the iteration ran with (x_velocs, or the resampled ones);
+ *   zy_coords [(n_proposals + 1) * n_chains, n_atoms, 3], zy_velocs [n_proposals * n_chains, n_atoms, 3]: latents IN (scaled,
+ *     as for tw_mh_iteration) / proposals OUT; the last n_chains rows of zy_coords are scratch;
+ *   u [n_proposals, n_chains]: accept uniforms; new_coords / new_velocs [n_chains, n_atoms, 3];
+ *   out_stats [8, n_proposals, n_chains], out_accepted [n_proposals, n_chains], result int32 [n_chains, 4].
+ * draws == NULL: the caller drew the latents, the (resampled) x_velocs and u - the route the oracle / trace tests take.
+ * draws != NULL: they are drawn inside the first glue kernel by a counter-based generator - Philox4x32-10 with
+ *   key = (seed & 0xffffffff, seed >> 32), counter = (element >> 2, kind | (iteration >> 32) << 4, iteration & 0xffffffff,
+ *   first_chain + chain); kind 0 coordinate latents, 1 velocity latents (element = proposal * 3 n_atoms + component), 2
+ *   resampled current velocities (element = component), 3 uniforms (element = proposal); word element & 3 of the block; normals
+ *   by Box-Muller on the word pairs (0,1), (2,3): u1 = w * 2^-32 + 2^-33, u2 = (w >> 8) * 2^-24, cos for even elements, sin for
+ *   odd; latents multiplied by exp(prior log-scale); uniforms (w >> 8) * 2^-24.  zy_* and u are then pure outputs, and a
+ *   chain's draws depend on (seed, first_chain + chain, iteration) only - not on n_chains, not on what ran before.
+ *   tw_mh_draw_chains writes exactly those draws (any of the four output pointers may be NULL) for tests and replays. */
+typedef struct {
+  uint64_t seed;
+  int64_t iteration;        /* >= 0; the caller counts iterations */
+  int32_t first_chain;      /* global id of chain 0 of this call (rank * chains_per_rank) */
+  int32_t resample_velocs;  /* draw fresh N(0,1) current velocities (the reference's --resample-velocities; needs random_velocs) */
+} tw_mh_draws;
+
+int64_t tw_mh_iteration_chains_workspace_bytes(const tw_flow_desc* desc, int64_t n_proposals, int64_t n_chains, int32_t n_atoms);
+int tw_mh_iteration_chains(const tw_flow_desc* desc, const float* raw, const void* packed, int32_t path,
+                           const tw_forcefield* ff, const tw_mh_options* opt, const tw_mh_draws* draws,
+                           const int32_t* atom_types, const uint8_t* masked, int32_t n_atoms, const float* x_coords,
+                           const float* x_velocs, float* cur_velocs, float* zy_coords, float* zy_velocs, float* u,
+                           float* new_coords, float* new_velocs, float* out_stats, uint8_t* out_accepted, int32_t* result,
+                           int64_t n_proposals, int64_t n_chains, void* workspace, int64_t workspace_bytes, void* stream);
+int tw_mh_draw_chains(const tw_flow_desc* desc, const float* raw, const tw_mh_draws* draws, float* z_coords, float* z_velocs,
+                      float* u, float* velocs, int64_t n_proposals, int64_t n_chains, int32_t n_atoms, void* stream);
 
 /* check_symmetry_change (utils/chirality.py:40-80): sign of the triple product at each
  * chirality centre vs reference_signs; out_changed [n_rows] uint8.  centres [n_centres,4] int32. */

@@ -244,3 +244,55 @@ def mh_state_dict(kind, random_velocs, out_scale=1e-4, coords_log_scale=-7.0):
     sd["coords_prior_log_scale"] = torch.tensor(float(coords_log_scale))
     sd["velocs_prior_log_scale"] = torch.tensor(0.0 if random_velocs else -3.0)
     return sd
+
+
+# ---- the counter-based generator of tw_mh_iteration_chains (include/timewarp_hip.h, tw_mh_draws), restated in numpy -----------
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) on arrays of
+    counters [..., 4] and keys [..., 2] (uint32); returns [..., 4] uint32.  Checked against the paper's known-answer vectors
+    in tests/test_host_logic.py."""
+    c = [np.asarray(ctr[..., i], dtype=np.uint64) for i in range(4)]
+    k0 = np.asarray(key[..., 0], dtype=np.uint64)
+    k1 = np.asarray(key[..., 1], dtype=np.uint64)
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & m32, p1 >> np.uint64(32), p1 & m32
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def chain_draw_words(seed, iteration, chain, kind, n_elements):
+    """The 32-bit words behind elements 0 .. n_elements - 1 of one (chain, iteration, kind) stream: [n_elements, 4] (the whole
+    block of each element) - counter = (element >> 2, kind | (iteration >> 32) << 4, iteration & 0xffffffff, chain)."""
+    e = np.arange(n_elements, dtype=np.uint64)
+    ctr = np.zeros((n_elements, 4), dtype=np.uint64)
+    ctr[:, 0] = e >> np.uint64(2)
+    ctr[:, 1] = np.uint64(kind) | (np.uint64((iteration >> 32) & 0x0FFFFFFF) << np.uint64(4))
+    ctr[:, 2] = np.uint64(iteration & 0xFFFFFFFF)
+    ctr[:, 3] = np.uint64(chain)
+    key = np.zeros((n_elements, 2), dtype=np.uint64)
+    key[:, 0], key[:, 1] = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
+    return philox4x32_10(ctr, key)
+
+
+def chain_draw_uniforms(seed, iteration, chain, n):
+    w = chain_draw_words(seed, iteration, chain, 3, n)
+    return ((w[np.arange(n), np.arange(n) & 3] >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24))
+
+
+def chain_draw_normals(seed, iteration, chain, kind, n):
+    """Standard normals of a stream in float64 (the kernel's are float32 Box-Muller: compare to ~1e-6)."""
+    w = chain_draw_words(seed, iteration, chain, kind, n).astype(np.float64)
+    e = np.arange(n)
+    pair = (e >> 1) & 1
+    w1 = w[e, 2 * pair]
+    w2 = np.floor(w[e, 2 * pair + 1] / 256.0)
+    u1 = (np.float32(w1) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)).astype(np.float64)   # the kernel's fmaf, float32 operands
+    u2 = w2 * 2.0 ** -24
+    r = np.sqrt(-2.0 * np.log(u1))
+    return np.where(e & 1, r * np.sin(2 * np.pi * u2), r * np.cos(2 * np.pi * u2))

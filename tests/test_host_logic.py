@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/timewarp_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.load().tw_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_raw_layout_matches_library_and_oracle_template():
@@ -712,3 +712,24 @@ def test_product_kernels_do_not_spill():
     assert len(enc) >= 13, sorted(rows)          # 48-token x2, 64-token x2, paired x2, wide x4, dense x3 (one with position features)
     assert all(v == 0 for v in enc.values()), {k: v for k, v in enc.items() if v}
     assert "# warnings: 0" in out.stdout, out.stdout[-1500:]
+
+
+def test_philox_restatement_known_answers():
+    """tests/helpers.philox4x32_10 - the numpy restatement the GPU suite holds tw_mh_iteration_chains' generator to - against
+    the known-answer vectors published with the algorithm (Random123 kat_vectors: philox4x32 10)."""
+    import numpy as np
+
+    def run(c, k):
+        return [int(x) for x in H.philox4x32_10(np.array([c], dtype=np.uint64), np.array([k], dtype=np.uint64))[0]]
+
+    assert run([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert run([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert run([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    # streams: distinct (chain, iteration, kind) give unrelated words; the normals are standard
+    a = H.chain_draw_words(7, 0, 0, 0, 64)
+    assert not np.array_equal(a, H.chain_draw_words(7, 0, 1, 0, 64)) and not np.array_equal(a, H.chain_draw_words(7, 1, 0, 0, 64))
+    assert not np.array_equal(a, H.chain_draw_words(7, 0, 0, 1, 64)) and not np.array_equal(a, H.chain_draw_words(8, 0, 0, 0, 64))
+    n = H.chain_draw_normals(5, 3, 1, 0, 200000)
+    assert abs(n.mean()) < 0.01 and abs(n.std() - 1) < 0.01 and abs((n ** 4).mean() - 3) < 0.1
+    u = H.chain_draw_uniforms(5, 3, 1, 100000)
+    assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.01

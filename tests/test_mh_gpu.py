@@ -174,13 +174,14 @@ def test_adaptive_parallelism_and_random_init_through_mh_iteration(path, init_ra
     _assert_chain_matches_oracle(got, ref, tol=1e-5, stat_tol=5e-4 if init_random else 2e-4)
 
 
-@pytest.mark.parametrize("mode", ["sync", "deferred", "multichain"])
+@pytest.mark.parametrize("mode", ["sync", "deferred", "multichain", "multichain-lag"])
 def test_split_fp16_overflow_is_redone_on_the_f32_kernels(mode):
     """A checkpoint whose activations leave the fp16 range must not abort a chain hours in: when the range flag is up
     at a read-back, the model is demoted to the exact-f32 kernels and the iterations since the last read-back are
     replayed there from the recorded draws.  The resulting chain is bit for bit the chain the f32 kernels produce from
     the start with the same noise - one synchronous iteration at a time, with deferred read-backs (4 iterations parked
-    when the flag is seen), and for lock-step chains."""
+    when the flag is seen), for lock-step chains, and for lock-step chains on the kernel's own draws with the lagged
+    read-back (r06: the flag is seen one window late, two windows are redone from the same counters)."""
     from tests.test_flow_gpu import _overflowing_sd
     from timewarp_amd import synthetic
     from timewarp_amd.dataloader import single_state_batch
@@ -202,11 +203,13 @@ def test_split_fp16_overflow_is_redone_on_the_f32_kernels(mode):
 
     def run(path):
         model = H.tw_kernel_model(sd, path=path)
-        if mode == "multichain":
+        if mode.startswith("multichain"):
             g = torch.Generator().manual_seed(1)
             starts = [coords + 0.0005 * torch.randn(coords.shape, generator=g) for _ in range(2)]
+            torch.cuda.manual_seed(321)   # (the initial velocities of the kernel-draws chains come from the default generator)
+            draws = dict(seed=5150) if mode == "multichain-lag" else dict(noises=[DeviceNoise(dev, seed=40 + c) for c in range(2)])
             out = sample_with_model_chains([single_state_batch("ad", types, xc) for xc in starts], model, dev, energy, masses,
-                                           N, S, noises=[DeviceNoise(dev, seed=40 + c) for c in range(2)], sync_every=3, **kw)
+                                           N, S, sync_every=3, **draws, **kw)
         else:
             noise = H.HostNoise(8, "cuda") if mode == "sync" else None  # host noise forces one read-back per iteration
             torch.cuda.manual_seed(123)
@@ -861,3 +864,137 @@ def test_mh_iterations_on_the_691_atom_protein_vs_oracle():
     print("exponent: max abs difference", d_exp, "of log-densities ~", scale)
     assert d_exp < 3e-6 * scale, (d_exp, scale)
     assert np.allclose(np.asarray(gs.acceptance), np.asarray(rs.acceptance), rtol=0, atol=3 * d_exp + 1e-6)
+
+
+# ---- tw_mh_iteration_chains (ABI 8): one C-ABI call per lock-step iteration, draws from its own counter-based generator ----
+
+class _KernelDrawsReplay:
+    """The DeviceNoise protocol fed from tw_mh_draw_chains: what the fused call draws for (seed, chain, iteration), handed to
+    the host-noise route (and to the oracle) draw by draw, in sample_with_model's order: velocities, latents, uniforms."""
+
+    def __init__(self, model, seed, chain, V, device="cuda", init_seed=0):
+        self.model, self.seed, self.chain, self.V, self.device, self.it = model, seed, chain, V, device, 0
+        self.first = True
+        self.g = torch.Generator().manual_seed(init_seed)
+
+    def _draw(self, S):
+        from timewarp_amd.utils.multichain import draw_chains
+
+        return [t.to(self.device) for t in draw_chains(self.model, "cuda", self.seed, self.it, self.chain, S, 1, self.V)]
+
+    def randn_like(self, t):
+        if self.first:   # the initial velocities of the chain (construction): not one of the iteration's draws
+            self.first = False
+            return torch.randn(t.shape, generator=self.g).to(self.device)
+        return self._draw(1)[3].reshape(t.shape)
+
+    def latents(self, S, B, V, scale_c, scale_v):
+        self.first = False
+        zc, zv, _, _ = self._draw(S)
+        return zc.reshape(S, B, V, 3), zv.reshape(S, B, V, 3)
+
+    def uniform(self, S):
+        u = self._draw(S)[2].reshape(S)
+        self.it += 1
+        return u
+
+
+def test_chain_draws_match_the_numpy_philox_restatement():
+    """tw_mh_draw_chains (= what mhc_begin_kernel generates) against tests/helpers.py's numpy Philox4x32-10 + Box-Muller:
+    uniforms bit for bit, normals to float32 rounding; a chain's draws do not depend on how many chains run beside it."""
+    from timewarp_amd.utils.multichain import draw_chains
+
+    sd = H.full_kernel_sd()
+    sd = {k: v.clone() for k, v in sd.items()}
+    model = H.tw_kernel_model(sd, path=3)
+    S, Cn, V = 37, 3, 22
+    seed, it, first = (0x1234 << 32) | 0x9ABCDEF1, (3 << 32) | 17, 5
+    zc, zv, u, v = [t.cpu().numpy() for t in draw_chains(model, "cuda", seed, it, first, S, Cn, V)]
+    std_c = float(torch.exp(model.coords_prior_log_scale.detach()))
+    std_v = float(torch.exp(model.velocs_prior_log_scale.detach()))
+    for c in range(Cn):
+        assert np.array_equal(u[:, c], H.chain_draw_uniforms(seed, it, first + c, S))
+        for arr, kind, std in ((zc, 0, std_c), (zv, 1, std_v)):
+            want = H.chain_draw_normals(seed, it, first + c, kind, S * 3 * V).reshape(S, V, 3) * std
+            assert np.abs(arr[:, c] - want).max() < 4e-6 * std, (c, kind, np.abs(arr[:, c] - want).max())
+        assert np.abs(v[c] - H.chain_draw_normals(seed, it, first + c, 2, 3 * V).reshape(V, 3)).max() < 4e-6
+    # chain `first + 1` alone, more proposals: the same stream, longer
+    zc1, _, u1, v1 = [t.cpu().numpy() for t in draw_chains(model, "cuda", seed, it, first + 1, S + 9, 1, V)]
+    assert np.array_equal(zc1[:S, 0], zc[:, 1]) and np.array_equal(u1[:S, 0], u[:, 1]) and np.array_equal(v1[0], v[1])
+    # moments over a large block
+    big = draw_chains(model, "cuda", 99, 0, 0, 1000, 8, V)
+    n = (big[1] / std_v).double()
+    assert abs(float(n.mean())) < 5e-3 and abs(float(n.std()) - 1) < 5e-3 and abs(float((n ** 4).mean()) - 3) < 0.05
+    assert abs(float(big[2].double().mean()) - 0.5) < 5e-3
+
+
+@pytest.mark.parametrize("random_velocs", [True, False])
+def test_kernel_draws_route_equals_host_noise_route(random_velocs):
+    """MetropolisHastingsChains without `noises` (draws inside tw_mh_iteration_chains) against the same chains driven through
+    the host-noise route with the draws tw_mh_draw_chains writes out - bit for bit - and each chain against a one-chain run
+    with first_chain = c (a chain's numbers do not depend on its neighbours)."""
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.utils.multichain import sample_with_model_chains
+
+    sd = synthetic.synth_state_dict(H.full_kernel_sd(), 0, calibrated=True, coords_log_scale=-7.0, velocs_log_scale=0.0)
+    model = H.tw_kernel_model(sd, path=3)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    energy = AmberPotentialEnergyTorch.alanine_dipeptide()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(1)
+    starts = [coords + 0.002 * torch.randn(coords.shape, generator=g) for _ in range(3)]
+    vel = [0.3 * torch.randn(coords.shape, generator=g) for _ in range(3)]
+    kw = dict(random_velocs=random_velocs, resample_velocs=random_velocs)
+    batches = lambda idx: [single_state_batch("ad", types, starts[c], vel[c]) for c in idx]
+    N, S, seed = 40, 16, 77123
+    a = sample_with_model_chains(batches(range(3)), model, dev, energy, masses, N, S, sync_every=3, seed=seed, first_chain=4, **kw)
+    b = sample_with_model_chains(batches(range(3)), model, dev, energy, masses, N, S, sync_every=2,
+                                 noises=[_KernelDrawsReplay(model, seed, 4 + c, 22) for c in range(3)], **kw)
+    H.assert_not_demoted(model)
+    assert sum(r[2] for r in a) > 0 or not random_velocs   # (fixed unit-scale velocities: this calibration accepts nothing)
+    for ra, rb in zip(a, b):
+        assert ra[2] == rb[2] and np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1][1:], rb[1][1:])
+        for f in ("acceptance_indicator", "acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin"):
+            assert np.array_equal(np.asarray(getattr(ra[3], f)), np.asarray(getattr(rb[3], f))), f
+    one = sample_with_model_chains(batches([1]), model, dev, energy, masses, N, S, sync_every=4, seed=seed, first_chain=5, **kw)[0]
+    assert one[2] == a[1][2] and one[0].shape == a[1][0].shape
+    assert np.allclose(one[0], a[1][0], rtol=0, atol=1e-6) and np.allclose(one[3].exponent, a[1][3].exponent, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("random_velocs,chirality", [(True, False), (False, True)])
+def test_fused_chains_iteration_equals_op_by_op_route(monkeypatch, random_velocs, chirality):
+    """tw_mh_iteration_chains against the op-by-op lock-step route (TW_MH_FUSED=0: flow sample, energies, kinetic terms,
+    chirality test, likelihood of the reverse move, tw_mh_accept_chains as separate calls) on the same per-chain noise."""
+    from timewarp_amd import synthetic
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.utils.chirality import find_chirality_centers, compute_chirality_sign
+    from timewarp_amd.utils.multichain import MetropolisHastingsChains, sample_with_model_chains
+
+    sd = synthetic.synth_state_dict(H.full_kernel_sd(), 0, calibrated=True, coords_log_scale=-7.0, velocs_log_scale=0.0)
+    model = H.tw_kernel_model(sd, path=3)
+    types, coords, masses = synthetic.alanine_dipeptide_state()
+    energy = AmberPotentialEnergyTorch.alanine_dipeptide()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    starts = [coords + 0.002 * torch.randn(coords.shape, generator=g) for _ in range(3)]
+    vel = [0.3 * torch.randn(coords.shape, generator=g) for _ in range(3)]
+    kw = dict(random_velocs=random_velocs, resample_velocs=random_velocs)
+    if chirality:
+        centres = torch.tensor([[8, 6, 10, 14]])   # CA with N, CB, C (alanine dipeptide atom order)
+        kw.update(chirality_centers=centres, reference_signs=compute_chirality_sign(coords[None], centres))
+    run = lambda: sample_with_model_chains([single_state_batch("ad", types, x, v) for x, v in zip(starts, vel)], model, dev, energy,
+                                           masses, 30, 16, noises=[H.HostNoise(900 + c, "cuda") for c in range(3)], sync_every=2, **kw)
+    fused = run()
+    monkeypatch.setenv("TW_MH_FUSED", "0")
+    probe = MetropolisHastingsChains([single_state_batch("ad", types, starts[0], vel[0])], model, dev, energy, masses, 4)
+    assert not probe._fused
+    plain = run()
+    H.assert_not_demoted(model)
+    for ra, rb in zip(fused, plain):
+        assert ra[2] == rb[2] and np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+        for f in ("acceptance_indicator", "acceptance", "p_xy", "p_yx", "exponent", "energies_pot", "energies_kin",
+                  "energies_pot_delta", "energies_kin_delta"):
+            assert np.array_equal(np.asarray(getattr(ra[3], f)), np.asarray(getattr(rb[3], f))), f

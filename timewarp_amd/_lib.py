@@ -84,7 +84,13 @@ class MHOptions(C.Structure):
     ]
 
 
-ABI_VERSION = 7
+class MHDraws(C.Structure):
+    """Mirror of `tw_mh_draws` (ABI 8)."""
+
+    _fields_ = [("seed", C.c_uint64), ("iteration", C.c_int64), ("first_chain", C.c_int32), ("resample_velocs", C.c_int32)]
+
+
+ABI_VERSION = 8
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 _DESC = C.POINTER(FlowDesc)
@@ -127,6 +133,10 @@ SIGNATURES = {
     "tw_mh_iteration_workspace_bytes": (_I64, [_DESC, _I64, _I32]),
     "tw_mh_iteration": (C.c_int, [_DESC, _P, _P, _I32, C.POINTER(ForceField), C.POINTER(MHOptions), _P, _P, _I32, _P, _P, _P, _P,
                                   _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P]),
+    "tw_mh_iteration_chains_workspace_bytes": (_I64, [_DESC, _I64, _I64, _I32]),
+    "tw_mh_iteration_chains": (C.c_int, [_DESC, _P, _P, _I32, C.POINTER(ForceField), C.POINTER(MHOptions), C.POINTER(MHDraws), _P, _P,
+                                         _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _P]),
+    "tw_mh_draw_chains": (C.c_int, [_DESC, _P, C.POINTER(MHDraws), _P, _P, _P, _P, _I64, _I64, _I32, _P]),
     "tw_flow_nonfinite": (C.c_int, [_I32, C.POINTER(C.c_int32)]),
     "tw_last_netblock_kernel": (C.c_char_p, []),
     "tw_debug_set_flags": (C.c_int, [C.c_int]),

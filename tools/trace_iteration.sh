@@ -8,9 +8,10 @@ python - <<'PY' > gpurun_out/iter_trace.txt
 import csv, glob
 f = glob.glob('gpurun_out/iter_trace/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-acc = [i for i, r in enumerate(rows) if 'mh_accept_full' in r['Kernel_Name']]
-# the 8th iteration of the headline leg (the alt paths come later in the run)
-a, b = acc[7], acc[8]
+acc = [i for i, r in enumerate(rows) if 'mh_accept_full' in r['Kernel_Name'] or 'mhc_accept' in r['Kernel_Name']]
+# the 10th and 11th iteration of the headline leg (the alt paths come later in the run): with --warmup 3 and a read-back every 8
+# iterations the host's flush - synchronisation + bookkeeping, GPU idle - sits between them
+a, b = acc[9], acc[11]
 t0 = int(rows[a]['End_Timestamp'])
 prev = t0
 busy = 0
