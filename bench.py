@@ -33,10 +33,8 @@ FLOP_PER_SAMPLE_PASS = 1.612e9  # 16 * V * F_blk(V), V = 22
 N_COUPLING = 8
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (~2.5 PF)
-# What the chip sustains (reported beside the roofline, never instead of it): a bare MFMA stream on all 256 CUs with random fp16
-# operands, measured by every run (tw_probe_mfma_clock; 1.74 GHz - r03's figure, taken 1.3 ms after idle and therefore low - is
-# only the fallback); the dominant kernel keeps a wave's matrix pipe busy for 579.5 k clocks per launch
-# (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_h3_sq_counters.md)
+# Fallback for roofline.power_bound only: the clock a bare MFMA stream sustains on all 256 CUs is measured by every run
+# (tw_probe_mfma_clock, 1.9-2.05 GHz on the boxes seen so far); this constant is used if that call fails.
 SUSTAINED_MFMA_CLOCK_GHZ = 1.74
 
 
@@ -49,15 +47,16 @@ def h3_mfma_per_wave(dims) -> int:
     hid, ff = dims.d_hidden // 32, dims.d_ff // 32
     per_layer = dims.n_heads * 4 * (24 + 72) + 144 * ff + 48
     return 108 * hid + dims.n_layers * per_layer + 81 * hid
-# execution paths of the flow (include/timewarp_hip.h): h3 and f32 hold the 1e-5 parity bar
+# execution paths of the flow (include/timewarp_hip.h): h3 and f32 hold the 1e-5 parity bar.  `kernel` is only the fallback
+# name (<NT, ASM, DENSE, WIDE, RFF, ENC, H1, NG6>): a line reports the instantiation tw_last_netblock_kernel names
 PATHS = {
     "h3": dict(path=3, dtype="f16x3 (split-fp16 operands, 3 MFMAs per fp32 product, fp32 accumulate)",
-               kernel="tw::netblock_h3_kernel<3, true, false, false, false, true>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=3),
+               kernel="tw::netblock_h3_kernel<3, true, false, false, false, true, false, false>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=3),
     "f32": dict(path=1, dtype="f32", kernel="tw::netblock_kernel<3>", peak=F32_MFMA_PEAK_TFLOPS, mfma_per_product=1),
     # opt-in fast mode, NOT a parity path and never the headline: fp16 operands (11 significand bits), one MFMA per product
     "h1": dict(path=4, dtype="f16 (fp16 operands, ONE MFMA per product, fp32 accumulate; ~1e-4 relative deviation from the "
                              "reference's fp32 arithmetic - tests/test_flow_h1_gpu.py; opt-in fast mode, not a parity path)",
-               kernel="tw::netblock_h3_kernel<3, true, false, false, false, true, true>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=1),
+               kernel="tw::netblock_h3_kernel<3, true, false, false, false, true, true, false>", peak=F16_MFMA_PEAK_TFLOPS, mfma_per_product=1),
 }
 # Synthetic-weight calibration (SURVEY section 8d idea, tuned so acceptance is non-degenerate against
 # the stiff bonded terms): identity flow (last out_mlp layer zeroed), coordinate prior std e^-7 nm,
@@ -510,6 +509,59 @@ def alt_path_record(device, seed, proposals, steps, sync_every, name="f32"):
     return rec
 
 
+def other_config_record(device, seed, config, steps, sync_every, n_chains=1):
+    """BASELINE configs[3] / configs[4] (and the lock-step mode of configs[1]) inside the default command, so that the driver's
+    record carries a line for each that somebody other than the builder timed (missing 5): a chain of its own on
+    the split-fp16 path, 2 warm-up iterations, `steps` timed ones with every 5th net-block launch bracketed by HIP events."""
+    from timewarp_amd import _lib
+
+    cfg = CONFIGS[config]
+    lib = _lib.load()
+    rows = (cfg["S"] // n_chains) * n_chains
+    chain, model = build_chain(device, seed, cfg["S"], PATHS["h3"]["path"], config, n_chains)
+    with torch.no_grad():
+        for _ in range(2):
+            chain.step_deferred()
+        chain.flush()
+    torch.cuda.synchronize()
+    acc0, prop0 = chain.accepted, chain.proposals
+    stride = os.environ.get("TW_PROFILE_STRIDE")
+    os.environ["TW_PROFILE_STRIDE"] = "5"   # short leg: more samples; coprime with the 16 launches of an iteration
+    lib.tw_profile_begin()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for it in range(steps):
+            chain.step_deferred()
+            if (it + 1) % sync_every == 0:
+                chain.flush()
+        chain.trajectory()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches = C.c_double(0.0), C.c_int64(0)
+    lib.tw_profile_end(C.byref(k_ms), C.byref(k_launches))
+    if stride is None:
+        del os.environ["TW_PROFILE_STRIDE"]
+    else:
+        os.environ["TW_PROFILE_STRIDE"] = stride
+    avg_ms = k_ms.value / max(int(k_launches.value), 1)
+    flop_per_launch = cfg["flop_sample_pass"] * rows / N_COUPLING
+    achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    kernel = live_kernel(lib)
+    bench_args = " ".join(([] if config == "ad" else [f"--config {config}"]))
+    traffic, traffic_src = committed_traffic(kernel, bench_args) if n_chains == 1 else (None, None)
+    return {
+        "workload": cfg["workload"] + ("" if n_chains == 1 else f"; {n_chains} lock-step chains per GPU sharing the launch's {rows} rows (SURVEY 8f-1)"),
+        "value": (chain.accepted - acc0) / elapsed, "unit": "MH-accepted samples/s",
+        "proposals_per_s": (chain.proposals - prop0) / elapsed,
+        "steps": steps, "warmup": 2, "ms_per_step": elapsed / steps * 1e3, "proposals_per_step": rows, "chains_per_gpu": n_chains,
+        "dtype": PATHS["h3"]["dtype"], "range_guard_fired": bool(getattr(model, "demoted", False)),
+        "roofline": {"bound": "mfma", "kernel": kernel + " (" + cfg.get("kernel_note", "both coupling nets of one coupling layer, all proposals") + ")",
+                     "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F16_MFMA_PEAK_TFLOPS,
+                     "avg_launch_ms": avg_ms, "launches": int(k_launches.value), "algorithmic_flop_per_launch": flop_per_launch,
+                     "traffic": traffic, "traffic_source": traffic_src, "mfma_per_fp32_product": 3},
+    }
+
+
 def end_timed_region(traj, t0, device, world):
     """The N > 1 leg of the measurement contract: the one collective of the path (all-gather of the trajectories, inside
     the timed region), barrier + device synchronisation on both sides of the clock, MAX of the elapsed time over ranks.
@@ -604,6 +656,8 @@ def main():
     ap.add_argument("--sync-every", type=int, default=8,
                     help="MH iterations queued per host read-back of the accept results (sample_with_model's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs on BASELINE configs[3] / configs[4] / lock-step chains that the default line carries")
     ap.add_argument("--chains", type=int, default=1,
                     help="chains per GPU evaluated in lock-step (SURVEY 8f-1): the launch's rows (--proposals) are shared, "
                          "proposals // chains per chain and iteration.  Default 1 = the BASELINE configuration; a line of its own "
@@ -723,7 +777,9 @@ def main():
                 "proposals_per_chain_and_step": rows // args.chains,
                 "weights": "name-seeded synthetic N(0,1)/sqrt(fan_in); identity flow (last out_mlp layer of every coupling net "
                            "zeroed, SURVEY 8d's idea) with coordinate prior log-scale %g and velocity prior log-scale 0 (NOT "
-                           "8d's -5 / -5: tuned so acceptance is non-degenerate against the stiff bonded terms)" % cfg["calibration"]["coords_log_scale"],
+                           "8d's -5 / -5: tuned so acceptance is non-degenerate against the stiff bonded terms).  `value` depends on this calibration "
+                           "(the first accepted proposal ends an iteration: accepted_per_step is 1 per chain); `proposals_per_s` is the "
+                           "weight-independent figure" % cfg["calibration"]["coords_log_scale"],
                 "mh_mode": "accept=True, random_velocs=True, resample_velocs=True (velocity terms of the exponent cancel)",
                 "setup_prewarm": f"{PREWARM_PASSES} untimed flow passes on throw-away inputs before the warm-up steps (GPU clock ramp)",
                 "execution_path": args.path,
@@ -811,6 +867,14 @@ def main():
             # the fast mode (SURVEY section 7 "precision contract"): reported here, beside the headline
             out["alt_path_h1"] = alt_path_record(device, distributed.chain_seed(args.seed, rank), args.proposals,
                                                  max(8, args.steps // 2), args.sync_every, "h1")
+        if world == 1 and args.path == "h3" and args.proposals == S_PROPOSALS and not args.no_other_configs:
+            seed = distributed.chain_seed(args.seed, rank)
+            out["other_configs"] = {
+                "4aa": other_config_record(device, seed, "4aa", 12, args.sync_every),       # BASELINE configs[3]
+                "dense": other_config_record(device, seed, "dense", 12, args.sync_every),   # BASELINE configs[4]
+                # the mode whole-node accepted samples/s rewards - 32 chains x 31 proposals through the headline's launches
+                "ad_chains32": other_config_record(device, seed, "ad", 24, args.sync_every, n_chains=32),
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.proposals)
         print(json.dumps(out), flush=True)
