@@ -170,9 +170,9 @@ class LockStepChains:
     def step_deferred(self):
         self.inner.step_deferred()
 
-    def flush(self):
-        # lagged read-back: start copying this window's accept results, book the window before it (multichain.py)
-        self.inner.flush(lag=True)
+    def flush(self, lag=False):
+        # lag: start copying this window's accept results, book the window before it (multichain.py)
+        self.inner.flush(lag=lag)
 
     def _settled(self):
         self.inner.flush()   # everything queued so far is booked before a counter is read
@@ -477,7 +477,7 @@ def alt_path_record(device, seed, proposals, steps, sync_every, name="f32"):
         for it in range(steps):
             chain.step_deferred()
             if (it + 1) % sync_every == 0:
-                chain.flush()
+                chain.flush(lag=True)
         chain.trajectory()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -533,7 +533,7 @@ def other_config_record(device, seed, config, steps, sync_every, n_chains=1):
         for it in range(steps):
             chain.step_deferred()
             if (it + 1) % sync_every == 0:
-                chain.flush()
+                chain.flush(lag=True)
         chain.trajectory()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -734,7 +734,7 @@ def main():
         for it in range(args.steps):
             chain.step_deferred()
             if (it + 1) % args.sync_every == 0:
-                chain.flush()
+                chain.flush(lag=True)   # as sample_with_model does: book the previous window while this one runs
         traj, _ = chain.trajectory()
         gathered, elapsed = end_timed_region(traj, t0, device, world)
     k_ms, k_launches = C.c_double(0.0), C.c_int64(0)

@@ -380,6 +380,12 @@ int tw_probe_mfma_clock(int32_t workgroups, int32_t iters, int64_t* cycles, doub
  * size, row count, tw_debug_set_flags).  A static string ("" before the first launch); never NULL. */
 const char* tw_last_netblock_kernel(void);
 
+/* ABI 8: the instantiation a flow pass over n_rows x n_atoms on `path` (TW_PATH_FUSED_H3 / TW_PATH_FUSED_H1) WOULD launch under
+ * the debug flags in force - the launch code's own branch run dry, nothing is launched and no GPU is needed.  "" when the path
+ * does not serve the shape.  tests/test_host_logic.py enumerates 1 .. 192 atoms through it and holds every kernel it names to
+ * ScratchSize 0 (one stated exception). */
+const char* tw_flow_selected_kernel(const tw_flow_desc* desc, int32_t n_atoms, int64_t n_rows, int32_t path);
+
 /* Safety net for TW_PATH_FUSED_H3 (no counterpart in the reference): *out_flag = 1 if, since the last reset, any
  * coupling net on the current device returned a non-finite scale or shift.  The split-fp16 kernel holds its operands in
  * fp16 (|value| < 65504); a checkpoint whose activations leave that range produces inf/NaN there, which the exact-f32

@@ -688,17 +688,55 @@ def test_split_fp16_workspace_covers_every_layout_a_launch_can_take():
         lib.tw_debug_set_flags(0)
 
 
+# The one instantiation a flow call can select that still spills (the dense model's 64-token build: MLP sections asm, the softmax
+# attention block compiled C++ - DESIGN.md section 4.1 table / section 8): the scratch it may use is pinned, not ignored.
+KNOWN_SPILLING = {"tw::netblock_h3_kernel<4, true, true, false, false, false, false, false>": 724}
+
+
+def selectable_netblock_kernels():
+    from timewarp_amd import _lib
+
+    """Every net-block instantiation the launch code can select WITHOUT debug flags - asked of the library itself
+    (tw_flow_selected_kernel: the launch branch run dry), for 1 .. 192 atoms x several row counts (the layout choice counts
+    rounds of the chip) x {kernel attention, dense softmax, dense + position features} x {split-fp16, single-MFMA}."""
+    import timewarp_amd as tw
+    from timewarp_amd import synthetic
+
+    lib = _lib.load()
+    lib.tw_debug_set_flags(0)
+    rff = synthetic.transformer_nvp_config()
+    rff.transformer_nvp_config.rff_position_encoder_config = tw.RFFPositionEncoderConfig(128, 1.0, 1.0)
+    picked = {}
+    for tag, cfg in (("kernel", synthetic.kernel_transformer_nvp_config()), ("dense", synthetic.transformer_nvp_config()), ("dense+rff", rff)):
+        d = tw.model_constructor(cfg).dims.to_desc()
+        for path, pn in ((_lib.TW_PATH_FUSED_H3, "h3"), (_lib.TW_PATH_FUSED_H1, "h1")):
+            for V in range(1, 193):
+                for rows in (1, 100, 512, 1000, 4096):
+                    name = lib.tw_flow_selected_kernel(C.byref(d), V, rows, path).decode()
+                    if name:
+                        picked.setdefault(name, set()).add((tag, pn, V))
+    return picked
+
+
 def test_product_kernels_do_not_spill():
-    """r05: every PRODUCT instantiation of the split-fp16 net-block kernel - the encoder-stack builds the launch code takes unless
-    a per-section build is asked for (tw_debug_set_flags bit 12, activation dumps) - compiles to ScratchSize 0 B/lane, and hipcc
-    has nothing to say about the inline asm (r04: 200-528 B/lane on the wide / dense / 64-token families, reserved s100 / s101 on
-    a clobber list).  Compiles csrc/tw_netblock_h3.hip once with -Rpass-analysis=kernel-resource-usage (~90 s, no GPU needed)."""
+    """Every instantiation of the split-fp16 / single-MFMA net-block kernel that a flow call can SELECT compiles to ScratchSize
+    0 B/lane, and hipcc has nothing to say about the inline asm.  r05 defined "product" as the ENC = true template argument and
+    so could not see the one selectable kernel that spills; now the library is asked which instantiations
+    its launch code takes (tw_flow_selected_kernel), and the exception is listed by name with its scratch size pinned.
+    Compiles csrc/tw_netblock_h3.hip once with -Rpass-analysis=kernel-resource-usage (~90 s, no GPU needed)."""
     import shutil
     import subprocess
     import sys
 
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("hipcc not available")
+    picked = selectable_netblock_kernels()
+    # the families that exist: 48-token, wide (5 / 6 groups), 64-token, paired - each on both paths; dense 48-token on both, with
+    # position features on both, dense 64-token on the split path
+    assert len(picked) >= 15, sorted(picked)
+    atoms = lambda name: sorted({v for _, _, v in picked[name]})
+    assert atoms("tw::netblock_h3_kernel<4, true, false, true, false, true, false, false>") == list(range(97, 129))      # paired
+    assert atoms("tw::netblock_h3_kernel<3, true, false, true, false, true, false, true>") == list(range(161, 193))       # six groups
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "resource_usage.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -707,10 +745,11 @@ def test_product_kernels_do_not_spill():
         m = re.match(r"\s*(\d+)\s+(\d+)\s+(-?\d+)\s+(\d+)\s+(tw::netblock_h3_kernel<[^>]*>)", line)
         if m:
             rows[m.group(5)] = int(m.group(4))
-    # <NT, ASM, DENSE, WIDE, RFF, ENC, H1, NG6>: every ENC = true instantiation
-    enc = {k: v for k, v in rows.items() if k.split(",")[5].strip() == "true"}
-    assert len(enc) >= 13, sorted(rows)          # 48-token x2, 64-token x2, paired x2, wide x4, dense x3 (one with position features)
-    assert all(v == 0 for v in enc.values()), {k: v for k, v in enc.items() if v}
+    missing = [k for k in picked if k not in rows]
+    assert not missing, missing                         # every selectable name is an instantiation the compiler reported on
+    spills = {k: rows[k] for k in picked if rows[k] != 0}
+    assert set(spills) <= set(KNOWN_SPILLING), spills
+    assert all(v <= KNOWN_SPILLING[k] for k, v in spills.items()), spills
     assert "# warnings: 0" in out.stdout, out.stdout[-1500:]
 
 
@@ -733,3 +772,29 @@ def test_philox_restatement_known_answers():
     assert abs(n.mean()) < 0.01 and abs(n.std() - 1) < 0.01 and abs((n ** 4).mean() - 3) < 0.1
     u = H.chain_draw_uniforms(5, 3, 1, 100000)
     assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
+
+
+def test_range_guard_words_do_not_travel_with_a_copied_or_saved_model():
+    """the per-device range-guard words (and the packed device weights / workspace) are process-local scratch - a
+    deep copy or a pickle of the model must not carry them, and must still hold every parameter."""
+    import copy
+    import io
+
+    import timewarp_amd as tw
+    from timewarp_amd import synthetic
+
+    m = tw.model_constructor(synthetic.kernel_transformer_nvp_config())
+    m._range_flags[0] = torch.zeros(1, dtype=torch.int32)     # stands in for the device word
+    m._workspace = torch.zeros(8, dtype=torch.uint8)
+    m._dirty = False
+    c = copy.deepcopy(m)
+    assert c._range_flags == {} and c._workspace is None and c._dev_weights is None and c._dirty
+    assert m._range_flags and m._workspace is not None        # the original keeps its own
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)
+    assert r._range_flags == {} and r._workspace is None and r._dirty
+    sd, sd_c, sd_r = m.state_dict(), c.state_dict(), r.state_dict()
+    assert list(sd) == list(sd_c) == list(sd_r) and all(torch.equal(sd[k], sd_c[k]) and torch.equal(sd[k], sd_r[k]) for k in sd)
+    assert c.dims == m.dims and r.dims == m.dims

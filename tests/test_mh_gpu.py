@@ -376,6 +376,52 @@ def test_sample_trajectory_writes_and_resumes(tmp_path):
     assert np.allclose(p2[0], p1[-1])  # resumed from the last saved row
 
 
+@pytest.mark.parametrize("scenario", ["omm_current", "omm_proposal"])
+def test_sample_trajectory_forwards_the_hybrid_move_arguments(tmp_path, scenario):
+    """sample_trajectory hands `sim`, `openmm_on_current`, `openmm_on_proposal`, `num_openmm_steps` to the sampler as the
+    reference's script does (sample_trajectory.py:218, 246-266; r05 dropped them): a segment written with a fake Simulation
+    equals the chain `sample_with_model` produces with the same options and device seed, the Simulation is driven, and it is
+    NOT handed on when neither switch is set (`sim=simulation if needs_sim else None`)."""
+    from oracle.fake_sim import FakeSimulation
+    from timewarp_amd.dataloader import single_state_batch
+    from timewarp_amd.sample_trajectory import sample_trajectory, segment_path
+    from timewarp_amd.utils.evaluation_utils import sample_with_model
+
+    z, sd = load_mh("mh_tiny_openmm.npz")
+    model = H.tw_kernel_model(sd, emb=4, d_model=8, ff=16, hidden=8, n_coupling=2, n_layers=2,
+                              lengthscales=(0.1, 0.5, 1.2), path=2)
+    x0, v0 = torch.from_numpy(z["x0"]), torch.from_numpy(z["v0"])
+    mk = lambda: single_state_batch("tiny", torch.from_numpy(z["atom_types"]), x0, v0)
+    energy = mo.SyntheticEnergy(x0.clone().cuda())
+    masses = torch.from_numpy(z["masses"])
+    opts = {k: v for k, v in OPENMM_SCENARIOS[scenario].items() if k in ("openmm_on_current", "openmm_on_proposal", "num_openmm_steps")}
+    assert opts.get("num_openmm_steps", 0) > 0 and (opts.get("openmm_on_current") or opts.get("openmm_on_proposal"))
+    dev = torch.device("cuda")
+    sim = FakeSimulation()
+    torch.cuda.manual_seed(11)
+    out = str(tmp_path / "hyb")
+    S = OPENMM_SCENARIOS[scenario]["num_proposal_steps"]   # (openmm_on_proposal: one proposal per iteration, as in the reference)
+    assert sample_trajectory(mk(), model, dev, energy, masses, out, "tiny", 30, 30, mh=True, num_proposal_steps=S, verbose=False,
+                             sim=sim, **opts) == 1
+    assert sim.calls > 0
+    ref_sim = FakeSimulation()
+    torch.cuda.manual_seed(11)
+    want, _, _, _ = sample_with_model(mk(), model, dev, energy, masses, 30, True, num_proposal_steps=S, disable_tqdm=True,
+                                      sim=ref_sim, **opts)
+    got = np.load(segment_path(out, "tiny", 0))["positions"]
+    assert ref_sim.calls == sim.calls and np.array_equal(got, want[::10])
+    # neither switch set: the Simulation stays untouched and the chain is the plain one
+    idle = FakeSimulation()
+    torch.cuda.manual_seed(11)
+    out2 = str(tmp_path / "plain")
+    sample_trajectory(mk(), model, dev, energy, masses, out2, "tiny", 30, 30, mh=True, num_proposal_steps=S, verbose=False,
+                      sim=idle, num_openmm_steps=opts["num_openmm_steps"])
+    torch.cuda.manual_seed(11)
+    plain, _, _, _ = sample_with_model(mk(), model, dev, energy, masses, 30, True, num_proposal_steps=S, disable_tqdm=True)
+    assert idle.calls == 0 and np.array_equal(np.load(segment_path(out2, "tiny", 0))["positions"], plain[::10])
+    assert not np.array_equal(got, plain[::10])
+
+
 def test_deferred_iterations_equal_synchronous_ones():
     """sample_with_model with the accept results read back every 4 iterations (the chain state moved on the
     device by tw_mh_accept) gives bit-identical chains and statistics to one read-back per iteration."""

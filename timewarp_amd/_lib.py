@@ -139,6 +139,7 @@ SIGNATURES = {
     "tw_mh_draw_chains": (C.c_int, [_DESC, _P, C.POINTER(MHDraws), _P, _P, _P, _P, _I64, _I64, _I32, _P]),
     "tw_flow_nonfinite": (C.c_int, [_I32, C.POINTER(C.c_int32)]),
     "tw_last_netblock_kernel": (C.c_char_p, []),
+    "tw_flow_selected_kernel": (C.c_char_p, [_DESC, _I32, _I64, _I32]),
     "tw_debug_set_flags": (C.c_int, [C.c_int]),
     "tw_profile_begin": (C.c_int, []),
     "tw_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

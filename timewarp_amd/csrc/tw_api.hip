@@ -375,6 +375,19 @@ int tw_chirality_changed(const float* coords, const int32_t* centres, const floa
 
 const char* tw_last_netblock_kernel(void) { return last_netblock_kernel(); }
 
+const char* tw_flow_selected_kernel(const tw_flow_desc* desc, int32_t n_atoms, int64_t n_rows, int32_t path) {
+  if (check_desc(desc) || n_atoms <= 0 || n_rows <= 0) return "";
+  const bool h1 = path == TW_PATH_FUSED_H1;
+  if (!(path == TW_PATH_FUSED_H3 || h1)) return "";
+  if (!(h1 ? h1_supported(*desc, n_atoms) : h3_supported(*desc, n_atoms))) return "";
+  const char* before = last_netblock_kernel();
+  note_netblock_kernel("");
+  const int rc = h3_selected_kernel(*desc, n_atoms, n_rows, h1);
+  const char* name = rc == TW_OK ? last_netblock_kernel() : "";
+  note_netblock_kernel(before);
+  return name;
+}
+
 int tw_flow_nonfinite(int32_t reset, int32_t* out_flag) {
   TW_REQUIRE(out_flag != nullptr, "NULL pointer argument");
   int v = 0;

@@ -282,6 +282,7 @@ int profile_mark(hipStream_t s, bool begin);
 // the net-block kernel instantiation the calling thread launched last (a string literal; tw_last_netblock_kernel)
 void note_netblock_kernel(const char* name);
 const char* last_netblock_kernel();
+int h3_selected_kernel(const tw_flow_desc& d, int n_atoms, int64_t n_rows, bool h1);  // dry run of the launch code's choice
 int profile_begin();
 int profile_end(double* total_ms, int64_t* launches);
 

@@ -183,6 +183,11 @@ static inline int64_t h3w_frag_head(const H3Wide& w) { return (int64_t)w.ng * w.
 // does tw_debug_set_flags bit 20 (1048576; A/B, tests).
 static thread_local bool t_no_pair = false;
 static bool h3_pair_enabled();
+struct NoPairScope {  // the calling thread's layout decisions inside the scope never take the paired layout (when `on`)
+  bool prev;
+  explicit NoPairScope(bool on = true) : prev(t_no_pair) { t_no_pair = prev || on; }
+  ~NoPairScope() { t_no_pair = prev; }
+};
 // Geometrically possible from 25 atoms on (below that a 48-token wave already holds two or more whole molecules and its
 // windowed mixing is cheaper).  Molecules sit back to back (slot stride V) with five-group windows - except 65 .. 96 atoms:
 // two molecules per workgroup either way, so each takes 96 slots (molecule 0 on waves 0-1, molecule 1 on waves 2-3, the
@@ -2780,7 +2785,8 @@ static H3Ws h3_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* base, bool
 std::atomic<int> g_debug_flags{0};
 static bool h3_pair_enabled() {
   const int f = g_debug_flags;
-  return !t_no_pair && !(f & 1048576) && (!(f & (4 | 16 | 4096)) || (f & 8192));
+  // (bit 3: the compiled-C++ statement exists for the 48-token layouts only - ADVICE r05)
+  return !t_no_pair && !(f & (8 | 1048576)) && (!(f & (4 | 16 | 4096)) || (f & 8192));
 }
 
 // Per-tile key windows for the mixing (gen_h3_attn_asm.py --mode=windowed): every molecule that has a token in query
@@ -2809,7 +2815,7 @@ int64_t h3_workspace_bytes(const tw_flow_desc& d, int64_t n_rows, int n_atoms) {
 
 static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg, int c, int net_sel, const float* z_other,
                      const char* sfrag, int64_t sf_variant_bytes, bool shared, float* s_out, float* t_out, float* dump,
-                     const PrevCoupling& prev = PrevCoupling{}) {
+                     const PrevCoupling& prev = PrevCoupling{}, bool dry = false) {
   const tw_flow_desc& d = *a.desc;
   const bool h1 = a.h1 != 0;
   const H3Geom g = h3_geom(d, h1);
@@ -2860,7 +2866,7 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
   const int wgs_per_net = wide ? p.nblocks : (p.nblocks + 3) / 4;  // wide: one block per workgroup
   unsigned grid = net_sel < 0 ? 8u * (unsigned)((wgs_per_net + 3) / 4) : (unsigned)wgs_per_net;
   int prc;
-  if ((prc = profile_mark(a.stream, true))) return prc;
+  if (!dry && (prc = profile_mark(a.stream, true))) return prc;
   // One launch form for every instantiation: raise the kernel's dynamic-LDS limit once per device, note its name for
   // tw_last_netblock_kernel (bench.py reports - and looks its PMC traffic up by - the instantiation that really ran), launch.
   // Template arguments: <NT, ASM, DENSE, WIDE, RFF, ENC, H1, NG6>, all eight spelled out so that the name is rocprofv3's.
@@ -2868,9 +2874,10 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
 #define H3_STR(...) H3_STR2(__VA_ARGS__)
 #define H3_LAUNCH(LDS, ...)                                                                                        \
   do {                                                                                                             \
+    note_netblock_kernel("tw::netblock_h3_kernel<" H3_STR(__VA_ARGS__) ">");                                       \
+    if (dry) return TW_OK; /* h3_selected_kernel: the name of the instantiation this call WOULD launch */          \
     static LdsLimit lim;                                                                                           \
     if ((prc = lim.ensure((const void*)netblock_h3_kernel<__VA_ARGS__>, (int)(LDS)))) return prc;                  \
-    note_netblock_kernel("tw::netblock_h3_kernel<" H3_STR(__VA_ARGS__) ">");                                       \
     hipLaunchKernelGGL((netblock_h3_kernel<__VA_ARGS__>), dim3(grid), dim3(256), (LDS), a.stream, p);              \
   } while (0)
   // the encoder-stack statements (no compiled glue, no scratch) unless activations / section stamps between the sections are
@@ -2997,6 +3004,7 @@ static int h3_score_frags(const FlowArgs& a, const RawLayout& L, const FusedGeom
 
 int flow_pass_h3(const FlowArgs& a) {
   const tw_flow_desc& d = *a.desc;
+  NoPairScope no_pair(d.n_layers < 1);  // a model without encoder layers runs the per-section build: 48-token wide layout
   FusedGeom fg;
   H3Wide wdg;
   bool wide_layout = false;
@@ -3063,11 +3071,25 @@ int flow_pass_h3(const FlowArgs& a) {
   return TW_OK;
 }
 
-struct NoPairScope {
-  bool prev;
-  NoPairScope() : prev(t_no_pair) { t_no_pair = true; }
-  ~NoPairScope() { t_no_pair = prev; }
-};
+// The instantiation a flow pass over n_rows x n_atoms would launch on the split-fp16 (h1 = false) or single-MFMA path, under the
+// debug flags in force - the launch code's own branch, run dry (tw_flow_selected_kernel: the spill guard of the CPU suite asks
+// this for every size instead of guessing which instantiations are "product").
+int h3_selected_kernel(const tw_flow_desc& d, int n_atoms, int64_t n_rows, bool h1) {
+  NoPairScope no_pair(d.n_layers < 1);
+  FlowArgs a{};
+  a.desc = &d;
+  a.n_rows = n_rows;
+  a.n_cond = 1;
+  a.n_atoms = n_atoms;
+  a.h1 = h1 ? 1 : 0;
+  FusedGeom fg;
+  H3Wide wdg;
+  bool wide_layout = false;
+  TW_REQUIRE(h3_layout(d, n_atoms, n_rows, h1, &fg, &wdg, &wide_layout) && !(wide_layout && d.variant != 0),
+             "split-fp16 path: unsupported atom count %d", n_atoms);
+  const RawLayout L = raw_layout(d);
+  return h3_launch(a, L, fg, 0, -1, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, PrevCoupling{}, true);
+}
 
 int debug_netblock_h3(const FlowArgs& a, int c, int net, const float* z_other, float* dump) {
   const tw_flow_desc& d = *a.desc;

@@ -18,12 +18,28 @@ class AmberPotentialEnergyTorch:
     def __init__(self, tables: ForceFieldTables, temperature: float = 310.0, integrator=None, md_preset: str = None):
         self.tables = tables
         # simulation preset the topology's dataset was made with (simulation/md.py:31-37): decides the integrator scheme of
-        # sample_with_model(sim="device").  Unknown origin: GBSA-OBC I is the amber14 preset's, anything else the older one's.
-        self.md_preset = md_preset or ("amber14-implicit" if tables.has_gbsa == 2 else "amber99-implicit-old")
+        # sample_with_model(sim="device").  Unknown origin (from_openmm without a usable integrator): "unknown", which runs
+        # LangevinMiddleIntegrator - what every preset of the reference uses except the oldest amber99 one (md.py:213-231); an
+        # integrator handed to from_openmm() overrides the preset with its own scheme / step / friction (`md_integrator`).
+        self.md_preset = md_preset or ("amber14-implicit" if tables.has_gbsa == 2 else "unknown")
+        self.md_integrator = self._integrator_parameters(integrator)
         self.temperature = float(temperature)
         self.num_particles = tables.n_atoms  # openmm_bridge.py:279
         self._integrator = integrator
         self._dev = {}
+
+    @staticmethod
+    def _integrator_parameters(integrator):
+        """(class name, step size ps, friction 1/ps) of an OpenMM Langevin integrator object, or None when it is absent or not
+        one of the two schemes the device integrator implements (the device route then falls back to the preset)."""
+        if integrator is None:
+            return None
+        from .forcefield import _md
+
+        name = type(integrator).__name__
+        if name not in ("LangevinMiddleIntegrator", "LangevinIntegrator") or not (hasattr(integrator, "getStepSize") and hasattr(integrator, "getFriction")):
+            return None
+        return name, _md(integrator.getStepSize()), _md(integrator.getFriction())
 
     @classmethod
     def alanine_dipeptide(cls, temperature: float = 310.0) -> "AmberPotentialEnergyTorch":

@@ -66,6 +66,16 @@ class LangevinDynamics:
 
     @classmethod
     def from_preset(cls, energy: AmberPotentialEnergyTorch, masses: torch.Tensor, preset: str = "amber14-implicit", seed: int = 0):
-        """simulation/md.py:75-93: both presets run 310 K, 0.3 / ps, 0.5 fs; "amber99-implicit-old" uses LangevinIntegrator."""
+        """simulation/md.py:75-93: both presets run 310 K, 0.3 / ps, 0.5 fs; "amber99-implicit-old" uses LangevinIntegrator,
+        everything else (the other presets, energies of unknown origin) LangevinMiddleIntegrator (md.py:213-231)."""
         integ = "LangevinIntegrator" if preset == "amber99-implicit-old" else "LangevinMiddleIntegrator"
         return cls(energy, masses, 0.0005, 0.3, integ, seed)
+
+    @classmethod
+    def for_energy(cls, energy: AmberPotentialEnergyTorch, masses: torch.Tensor, seed: int = 0):
+        """The integrator of the energy object: the scheme, step size and friction of the OpenMM integrator it was built with
+        (`AmberPotentialEnergyTorch.from_openmm(system, integrator)`), else its dataset preset's."""
+        if getattr(energy, "md_integrator", None) is not None:
+            name, dt, friction = energy.md_integrator
+            return cls(energy, masses, dt, friction, name, seed)
+        return cls.from_preset(energy, masses, preset=energy.md_preset, seed=seed)

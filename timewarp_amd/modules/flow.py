@@ -106,11 +106,40 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
             key = torch.cuda.current_device()
         flag = self._range_flags.get(key)
         if flag is None:
-            return False
+            # no word of its own on that device (a descriptor built through dims.to_desc(): raw C-ABI use of this model's
+            # weights, code written against ABI 6): such calls report to the per-device word - look there
+            out = C.c_int32(0)
+            with torch.cuda.device(key):
+                _lib.check(_lib.load().tw_flow_nonfinite(1, C.byref(out)), "tw_flow_nonfinite")
+            return out.value != 0
         if int(flag.item()) == 0:
             return False
         flag.zero_()
         return True
+
+    # the range-guard words are per-process device scratch, not state: a pickled / deep-copied model gets fresh ones lazily
+    def __getstate__(self):
+        state = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
+        state = dict(state)
+        state["_range_flags"] = {}
+        state["_dev_weights"], state["_workspace"], state["_dirty"] = None, None, True
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_range_flags":
+                new.__dict__[k] = {}
+            elif k in ("_dev_weights", "_workspace"):
+                new.__dict__[k] = None
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new.__dict__["_dirty"] = True
+        return new
 
     def demote_to_f32(self) -> None:
         """Leave the split-fp16 kernel for good: every later call runs on the exact-f32 kernels."""

@@ -45,8 +45,13 @@ def sample_trajectory(batch, model, device, energy_fn, masses, output_dir: str, 
                       saving_interval: int, mh: bool = True, random_velocities: bool = False,
                       resample_velocities: bool = False, initialize_randomly: bool = False, num_proposal_steps: int = 1,
                       adaptive_parallelism: bool = False, conserve_chirality: bool = False,
-                      sampler: Optional[Callable] = None, verbose: bool = True) -> int:
-    """Run (or resume) the chain; returns the number of segments written by this call."""
+                      sampler: Optional[Callable] = None, verbose: bool = True, sim=None, openmm_on_current: bool = False,
+                      openmm_on_proposal: bool = False, num_openmm_steps: int = 0) -> int:
+    """Run (or resume) the chain; returns the number of segments written by this call.
+    `sim`, `openmm_on_current`, `openmm_on_proposal`, `num_openmm_steps`: the hybrid-move options the reference's script hands
+    to `sample_with_model` (sample_trajectory.py:218, 258-261) - the caller's `Simulation`-like object (or a
+    `timewarp_amd.md.LangevinDynamics`, or "device") is passed on only when one of the two switches is set, as there
+    (`sim=simulation if needs_sim else None`)."""
     num_iters = num_samples // saving_interval
     assert num_iters > 0, "num_samples must be larger than saving_interval."
     sampler = sampler or sample_with_model
@@ -55,6 +60,7 @@ def sample_trajectory(batch, model, device, energy_fn, masses, output_dir: str, 
     if conserve_chirality:
         chirality_centers = find_chirality_centers(batch.adj_list, batch.atom_types)
         reference_signs = compute_chirality_sign(batch.atom_coords, chirality_centers)
+    needs_sim = openmm_on_proposal or openmm_on_current   # sample_trajectory.py:218
     done, last = resume_point(output_dir, protein)
     if last is not None:
         batch.atom_coords = last
@@ -68,7 +74,8 @@ def sample_trajectory(batch, model, device, energy_fn, masses, output_dir: str, 
         sampled_coords, _, _, _ = sampler(
             batch, model, device, energy_fn, masses, saving_interval, mh, random_velocs=random_velocities,
             resample_velocs=resample_velocities, initialize_randomly=initialize_randomly,
-            num_proposal_steps=num_proposal_steps, adaptive_parallelism=adaptive_parallelism,
+            sim=sim if needs_sim else None, openmm_on_current=openmm_on_current, openmm_on_proposal=openmm_on_proposal,
+            num_openmm_steps=num_openmm_steps, num_proposal_steps=num_proposal_steps, adaptive_parallelism=adaptive_parallelism,
             reference_signs=reference_signs, chirality_centers=chirality_centers, disable_tqdm=True)
         duration = timer() - start
         path = segment_path(output_dir, protein, i)

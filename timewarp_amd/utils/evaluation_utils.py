@@ -312,6 +312,25 @@ def openmm_step(sim, coords: torch.Tensor, velocs: Optional[torch.Tensor] = None
     return coords_new, velocs_new
 
 
+_HYBRID_WARNED = [False]
+
+
+def _warn_hybrid_moves_off(energy_fn) -> None:
+    """openmm_on_current / openmm_on_proposal with num_openmm_steps > 0 but sim=None: the reference silently runs without the
+    hybrid moves (`... and sim is not None`, evaluation_utils.py:558, 594, 623) and so does this loop - but with the HIP
+    energy there IS an integrator to be had, so say so once per process."""
+    from ..energy import AmberPotentialEnergyTorch
+
+    if _HYBRID_WARNED[0] or not isinstance(energy_fn, AmberPotentialEnergyTorch):
+        return
+    _HYBRID_WARNED[0] = True
+    import warnings
+
+    warnings.warn("timewarp_amd: openmm_on_current / openmm_on_proposal were requested with sim=None: the hybrid moves are OFF "
+                  "(as in the reference).  Pass sim='device' to integrate on the HIP force kernel, or your own Simulation.",
+                  RuntimeWarning, stacklevel=4)
+
+
 class MetropolisHastingsChain:
     """State and one-iteration `step()` of the loop in `sample_with_model` (reference
     evaluation_utils.py:517-745).  `sample_with_model` drives it until enough states are emitted;
@@ -369,10 +388,13 @@ class MetropolisHastingsChain:
             if not isinstance(energy_fn, AmberPotentialEnergyTorch):
                 raise ValueError("sim='device' needs the HIP energy (AmberPotentialEnergyTorch) as energy_fn")
             # the thermostat's Gaussian stream is keyed on (seed, step, atom): every chain draws its own seed from its own
-            # noise source, so independently seeded chains (distributed.chain_seed) stay independent
+            # noise source, so independently seeded chains (distributed.chain_seed) stay independent.  NOTE: these are TWO
+            # uniform draws from the chain's noise - a chain built with sim="device" is two draws ahead of one built without.
             u = self.noise.uniform(2).double().cpu()
             seed = (int(float(u[0]) * (1 << 26)) << 26) | int(float(u[1]) * (1 << 26))
-            self.sim = sim = LangevinDynamics.from_preset(energy_fn, masses, preset=energy_fn.md_preset, seed=seed)
+            self.sim = sim = LangevinDynamics.for_energy(energy_fn, masses, seed=seed)
+        if sim is None and (openmm_on_current or openmm_on_proposal) and self.n_omm > 0:
+            _warn_hybrid_moves_off(energy_fn)
         self.omm_current = bool(openmm_on_current) and self.n_omm > 0 and sim is not None
         self.omm_proposal = bool(openmm_on_proposal) and self.n_omm > 0 and sim is not None
         self.velocs_std = (self.kbT / self.masses.unsqueeze(0).unsqueeze(-1)).sqrt()
@@ -388,6 +410,15 @@ class MetropolisHastingsChain:
         self.S = self.s_max if not adaptive_parallelism else compute_num_proposal_steps(self.p_bar, max_num_proposal_steps=self.s_max)
         self.sgn = 1.0 if random_velocs else -1.0
         self._fused = self._fused_iteration_available()
+        # r06: without a caller's noise source the fused iteration draws its latents, resampled velocities and accept uniforms
+        # itself (tw_mh_iteration_chains with one chain: Philox4x32-10 keyed (seed, 0, iteration) inside its first glue kernel)
+        # instead of through four ATen generator launches; the seed comes from the device's default generator, so
+        # torch.cuda.manual_seed still decides the chain.  TW_MH_KERNEL_DRAWS=0: the ATen draws of r05.
+        import os as _os
+        self._kernel_draws = (self._fused and noise is None and not rotate and _os.environ.get("TW_MH_KERNEL_DRAWS", "1") != "0")
+        self._kd_seed = int(torch.randint(0, 2 ** 62, (1,), device=device).item()) if self._kernel_draws else 0
+        self._kd_iter = 0
+        self._inflight = None   # flush(lag=True): the window whose read-back is under way
 
     # ---- whole iteration in one C-ABI call (tw_mh_iteration) ----------------------------------------------------
     def _fused_iteration_available(self) -> bool:
@@ -420,7 +451,8 @@ class MetropolisHastingsChain:
                 keep["signs"] = self.reference_signs.to(dev, torch.float32).reshape(-1).contiguous()
                 opt.n_centres = int(keep["centres"].shape[0])
                 opt.centres, opt.reference_signs = keep["centres"].data_ptr(), keep["signs"].data_ptr()
-            need = lib.tw_mh_iteration_workspace_bytes(C.byref(desc), S, self.V)
+            need = max(lib.tw_mh_iteration_workspace_bytes(C.byref(desc), S, self.V),
+                       lib.tw_mh_iteration_chains_workspace_bytes(C.byref(desc), S, 1, self.V) if self._kernel_draws else 0)
             if need < 0:
                 raise RuntimeError("tw_mh_iteration_workspace_bytes failed: " + lib.tw_last_error().decode())
             self._fconst = dict(S=S, desc=desc, opt=opt, keep=keep, ws=torch.empty(int(need), dtype=torch.uint8, device=dev),
@@ -433,6 +465,8 @@ class MetropolisHastingsChain:
         S, V, dev = self.S, self.V, self.device
         noise, model = self.noise, self.model
         x_coords, x_velocs = self.x_coords, self.x_velocs
+        if self._kernel_draws:
+            return self._iteration_fused_kernel_draws()
         if self.random_velocs and self.resample_velocs:
             x_velocs = noise.randn_like(x_velocs)
         if self.rotate:
@@ -470,6 +504,38 @@ class MetropolisHastingsChain:
         self.proposals += S
         per_proposal = tuple(zip(("acc", "pxy", "pyx", "exp", "epot", "ekin", "dpot", "dkin"), stats.unbind(0)))
         return x_coords, x_velocs, zc[:S], zv[:S], new_c, new_v, acc, res, per_proposal
+
+    def _iteration_fused_kernel_draws(self):
+        """tw_mh_iteration_chains with ONE chain and its own draws: nothing is drawn through ATen, the call's first glue
+        kernel generates (and the read-back never sees) the latents, the resampled velocities and the uniforms."""
+        S, V, dev = self.S, self.V, self.device
+        model = self.model
+        x_coords, x_velocs = self.x_coords, self.x_velocs
+        fc = self._fused_constants(S)
+        at, mk, _, _, _, _ = self._constants(S)
+        f32 = torch.float32
+        zc = torch.empty((S + 1, V, 3), dtype=f32, device=dev)
+        zv = torch.empty((S, V, 3), dtype=f32, device=dev)
+        u = torch.empty(S, dtype=f32, device=dev)
+        cur_v = torch.empty_like(x_velocs)
+        new_c, new_v = torch.empty_like(x_coords), torch.empty_like(x_velocs)
+        stats = torch.empty((8, S), dtype=f32, device=dev)
+        acc = torch.empty(S, dtype=torch.uint8, device=dev)
+        res = torch.empty(4, dtype=torch.int32, device=dev)
+        draws = _lib.MHDraws(self._kd_seed, self._kd_iter, 0, int(self.random_velocs and self.resample_velocs))
+        self._kd_iter += 1
+        path = model._path_for(V)
+        raw, packed = model._weights(dev, path)
+        ff = self.energy_fn._device_ff(dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().tw_mh_iteration_chains(
+                C.byref(fc["desc"]), raw.data_ptr(), _lib.ptr(packed), path, C.byref(ff.struct), C.byref(fc["opt"]), C.byref(draws),
+                at.data_ptr(), mk.data_ptr(), V, x_coords.data_ptr(), x_velocs.data_ptr(), cur_v.data_ptr(), zc.data_ptr(),
+                zv.data_ptr(), u.data_ptr(), new_c.data_ptr(), new_v.data_ptr(), stats.data_ptr(), acc.data_ptr(), res.data_ptr(),
+                S, 1, fc["ws"].data_ptr(), fc["ws"].numel(), _lib.stream_ptr(dev)), "tw_mh_iteration_chains")
+        self.proposals += S
+        per_proposal = tuple(zip(("acc", "pxy", "pyx", "exp", "epot", "ekin", "dpot", "dkin"), stats.unbind(0)))
+        return x_coords, cur_v, zc[:S], zv, new_c, new_v, acc, res, per_proposal
 
     def _constants(self, S):
         """Per-chain constants in the dtypes / shapes the C ABI takes (int32 atom types, uint8 mask, both also
@@ -582,7 +648,7 @@ class MetropolisHastingsChain:
         self.noise.mark()
         self._sim_steps_mark = getattr(self.sim, "steps_done", None)
 
-    def _redo_on_f32(self, start_c, start_v, n_iterations: int):
+    def _redo_on_f32(self, start_c, start_v, n_iterations: int, kd_iter: Optional[int] = None):
         """The model's activations left the fp16 range somewhere in the last `n_iterations` iterations: demote the model
         to the exact-f32 kernels and run those iterations again from their starting state with the recorded draws.
         Returns their `_compute` tuples; the chain continues on the f32 kernels with its ordinary noise source."""
@@ -590,6 +656,8 @@ class MetropolisHastingsChain:
         recorder = self.noise
         self.noise = ReplayDraws(recorder.log)
         self.x_coords, self.x_velocs = start_c, start_v
+        if kd_iter is not None:
+            self._kd_iter = kd_iter   # the kernel's own draws are keyed on the iteration counter: the same draws again
         if hasattr(self.sim, "steps_done") and self._sim_steps_mark is not None:
             self.sim.steps_done = self._sim_steps_mark   # the device integrator's draws are keyed on the step count: same draws
         self.proposals -= n_iterations * self.S
@@ -609,14 +677,14 @@ class MetropolisHastingsChain:
         = num_samples - i applies the reference's clip `k = min(k, N - i)` (:680)."""
         self.flush()
         S, device = self.S, self.device
-        start_c, start_v = self.x_coords, self.x_velocs
+        start_c, start_v, start_kd = self.x_coords, self.x_velocs, self._kd_iter
         if self._guard:
             self._mark()
         if self.accept:
             out = self._compute()
             k_true, any_acc = (int(v) for v in out[0][:2].tolist())  # the one host sync of the iteration
             if self._overflowed():
-                out, = self._redo_on_f32(start_c, start_v, 1)
+                out, = self._redo_on_f32(start_c, start_v, 1, start_kd)
                 k_true, any_acc = (int(v) for v in out[0][:2].tolist())
             _, x_coords, x_velocs, new_c, new_v, acc, per_proposal = out
             self.accepted += int(any_acc)
@@ -666,29 +734,76 @@ class MetropolisHastingsChain:
         clip `k = min(k, N - i)` cannot bind (the caller keeps N - i > S)."""
         assert self.can_defer()
         if not self._pending:
-            self._pending_start = (self.x_coords, self.x_velocs)
+            self._pending_start = (self.x_coords, self.x_velocs, self._kd_iter)
             if self._guard:
                 self._mark()
         out = self._compute()
         self._pending.append(out)
         self.x_coords, self.x_velocs = out[3], out[4]
 
-    def flush(self) -> int:
+    def can_lag(self) -> bool:
+        """flush(lag=True) is honoured when a replay needs no recorded draws: the kernel's own generator (a replay runs the
+        same counters again) or a model the range guard does not watch."""
+        return self._kernel_draws or not self._guard
+
+    def inflight_states_max(self) -> int:
+        """The most chain states the window whose read-back is under way can still emit (for the caller's clip arithmetic)."""
+        return len(self._inflight["pending"]) * self.S if self._inflight is not None else 0
+
+    def _snapshot(self):
+        """Start the read-back of the parked window - 4 ints per iteration and the range-guard word, into pinned memory
+        behind the window's kernels - and hand the window over."""
+        res = torch.stack([p[0] for p in self._pending])
+        host = torch.empty(res.shape, dtype=res.dtype, pin_memory=True)
+        host.copy_(res, non_blocking=True)
+        flag_host = None
+        if self._guard:
+            key = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            flag = getattr(self.model, "_range_flags", {}).get(key)
+            if flag is not None:
+                flag_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                flag_host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        win = dict(pending=self._pending, start=self._pending_start, host=host, flag=flag_host, ev=ev)
+        self._pending = []
+        return win
+
+    def flush(self, lag: bool = False) -> int:
         """Read back the parked iterations (one D2H copy for all of them) and do their bookkeeping; returns the
-        number of chain states they emitted."""
-        if not self._pending:
-            return 0
-        results = torch.stack([p[0] for p in self._pending]).cpu().tolist()
-        if self._overflowed():  # split-fp16 range guard; the copy above already synchronised
-            self._pending = self._redo_on_f32(*self._pending_start, len(self._pending))
-            results = torch.stack([p[0] for p in self._pending]).cpu().tolist()
+        number of chain states booked by this call.
+        lag=True (r06): only START the read-back of the window just queued and book the window BEFORE it, whose results
+        arrived long ago: the host never waits for the device, the device never waits for the host's bookkeeping.  Counters and
+        the trajectory then trail the queue by one window until a plain flush()."""
+        if lag and self.can_lag():
+            newer = self._snapshot() if self._pending else None
+            older, self._inflight = self._inflight, newer
+            return self._finish(older) if older is not None else 0
+        older, self._inflight = self._inflight, None
+        n = self._finish(older) if older is not None else 0
+        if self._pending:
+            n += self._finish(self._snapshot())
+        return n
+
+    def _finish(self, win) -> int:
+        """Book one window whose read-back was started; on a range-guard trip redo it and everything queued behind it."""
+        win["ev"].synchronize()
+        pending, results = win["pending"], win["host"].tolist()
+        tripped = self._guard and (bool(getattr(self.model, "demoted", False)) or (win["flag"] is not None and int(win["flag"][0]) != 0))
+        if tripped:
+            torch.cuda.synchronize(self.device)
+            self.model.split_fp16_overflowed(self.device)   # clears the model's word
+            behind = (len(self._inflight["pending"]) if self._inflight is not None else 0) + len(self._pending)
+            self._inflight, self._pending = None, []
+            start_c, start_v, start_kd = win["start"]
+            pending = self._redo_on_f32(start_c, start_v, len(pending) + behind, start_kd)
+            results = torch.stack([p[0] for p in pending]).cpu().tolist()
         emitted = 0
-        for (k_true, any_acc, _, _), (_, old_c, old_v, new_c, new_v, acc, per_proposal) in zip(results, self._pending):
+        for (k_true, any_acc, _, _), (_, old_c, old_v, new_c, new_v, acc, per_proposal) in zip(results, pending):
             self.accepted += int(any_acc)
             self.p_bar = self.smoothing * (1 - (not any_acc)) + (1 - self.smoothing) ** k_true * self.p_bar
             self._emit(k_true, old_c, old_v, new_c, new_v, acc, per_proposal)
             emitted += k_true + 1
-        self._pending = []
         return emitted
 
     def trajectory(self):
@@ -748,14 +863,18 @@ def sample_with_model(
     # cannot bind (every iteration emits at most S states); the tail runs one synchronous iteration at a time.
     # Replayed noise (tests) is consumed exactly as recorded, so it always takes the synchronous path.
     defer = sync_every > 1 and noise is None and chain.can_defer()
+    lag = defer and chain.can_lag()   # r06: book window k - 1 while the device runs window k
     with torch.no_grad():
         while i < num_samples:
-            if defer and num_samples - i > sync_every * chain.S:
+            # (a window in flight can still emit up to S states per iteration: they count against the room the clip needs)
+            if defer and num_samples - i - chain.inflight_states_max() > sync_every * chain.S:
                 for _ in range(sync_every):
                     chain.step_deferred()
-                n = chain.flush()
+                n = chain.flush(lag=lag)
             else:
-                n = chain.step(num_samples - i)
+                n = chain.flush()       # settle what is in flight: i is exact again
+                if n == 0:
+                    n = chain.step(num_samples - i)
             i += n
             pbar.update(n)
     pbar.close()

@@ -81,7 +81,8 @@ class MetropolisHastingsChains:
         self.kernel_draws = noises is None
         self.noises = list(noises) if noises is not None else [DeviceNoise(device) for _ in range(C)]
         assert len(self.noises) == C
-        self.seed = int(seed) if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())  # follows torch.manual_seed
+        # (no seed given: from the device's default generator, so torch.cuda.manual_seed decides the chains)
+        self.seed = int(seed) if seed is not None else int(torch.randint(0, 2 ** 62, (1,), device=device).item())
         self.first_chain = int(first_chain)
         self.iteration = 0
         # split-fp16 range guard (modules/flow.py): keep the draws since the last read-back, see flush()
