@@ -376,7 +376,7 @@ def test_dense_attention_statement_under_adversarial_completion():
 # double-buffered side block.  Differential again: two layers of every product statement in the kernel's own LDS layout,
 # in-order run = reference, the adversarial runs must reproduce its operand images for the out-MLP bit for bit.
 # ---------------------------------------------------------------------------------------------------------------------------
-ENC_VARIANTS = [(), ("--mode=windowed",), ("--h1",), ("--h1", "--ring6"), ("--mode=windowed", "--h1", "--ring6"),
+ENC_VARIANTS = [(), ("--mode=windowed",), ("--ring6",), ("--mode=windowed", "--ring6"), ("--h1",), ("--h1", "--ring6"), ("--mode=windowed", "--h1", "--ring6"),
                 ("--nt=4",), ("--nt=4", "--h1"), ("--nt=4", "--pair"), ("--nt=4", "--pair", "--h1"),
                 ("--wide",), ("--wide", "--h1"), ("--wide", "--ng=3"), ("--wide", "--ng=6"), ("--wide", "--ng=6", "--h1"),
                 ("--dense",), ("--dense", "--h1")]

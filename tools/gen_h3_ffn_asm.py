@@ -150,6 +150,9 @@ def epi_unit(o, jt, buf, relu=True, tset=None):
     pre = t      # registers holding the pre-activation
     if fold():   # ... it is the accumulator itself (bias in the chain's start value, first-layer weights unscaled)
         ops, pre = [], [src(r) for r in range(4)]
+    nofma = "epinofma" in EXPERIMENT and not SHAPE["silu"] and not fold()
+    if nofma:    # timing experiment (results WRONG): the FFN epilogue without its four scale / bias fmas - what an epilogue of
+        ops = []  # 12 instead of 16 ops per unit could gain at most (profiles/r06_headline_experiments.txt)
     if SHAPE["silu"]:
         # v * 1 / (1 + 2^(-v log2 e)) with the hardware exp2 / rcp
         u = [V_U + r for r in range(4)]
@@ -159,7 +162,7 @@ def epi_unit(o, jt, buf, relu=True, tset=None):
         ops += [f"v_rcp_f32 v{u[r]}, v{u[r]}" for r in range(4)]
         ops += [f"v_mul_f32 v{t[r]}, v{pre[r]}, v{u[r]}" for r in range(4)]
     else:
-        ops += [f"v_max_f32 v{t[r]}, v{t[r]}, 0" for r in range(4)]
+        ops += [f"v_max_f32 v{t[r]}, v{src(r) if nofma else t[r]}, 0" for r in range(4)]
     hh = HB(buf, jt, "h") + 2 * o
     ll = HB(buf, jt, "l") + 2 * o
     if H1:
