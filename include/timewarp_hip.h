@@ -128,8 +128,14 @@ int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_
                               ~1e-4 relative (measured per case in tests/test_flow_h1_gpu.py); proposal and reverse-move
                               densities of an MH iteration are evaluated by the same arithmetic.  `packed` must point at
                               the tw_flow_pack_h1 stream.  Only ever chosen by name. */
+#define TW_PATH_SIMPLE_H3 5 /* ABI 8: TW_PATH_SIMPLE with its linear layers (in / out MLPs, value and output projections, q / k / v,
+                              FFN) as split-fp16 MFMA GEMMs - the arithmetic of TW_PATH_FUSED_H3 (3 half-precision MFMAs per fp32
+                              product, fp32 accumulation), one kernel per reference op, ANY molecule size and both model variants:
+                              what serves the sizes no fused layout takes (kernel attention above 192 atoms, dense above 64) at ~3x
+                              the rate of the exact-f32 per-op kernels.  Scores, softmax, mixing, LayerNorm stay fp32.  Needs
+                              |activations| < 65504 and |weights| < 256 (else non-finite outputs -> range flag); `packed` unused. */
 
-/* 1 if `path` can run this configuration on molecules of n_atoms atoms (TW_PATH_AUTO / TW_PATH_SIMPLE: always), else 0.
+/* 1 if `path` can run this configuration on molecules of n_atoms atoms (TW_PATH_AUTO / TW_PATH_SIMPLE / TW_PATH_SIMPLE_H3: always), else 0.
  * What a caller asks before it requests TW_PATH_FUSED / TW_PATH_FUSED_H3 by name (those fail with TW_ERR_INVALID on an
  * unsupported shape instead of falling back). */
 int tw_flow_path_supported(const tw_flow_desc* desc, int32_t n_atoms, int32_t path);

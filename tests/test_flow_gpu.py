@@ -754,8 +754,11 @@ def test_64_token_layout_choice_and_config_3_size():
                 H.rel_err(res[flag][2][rows], rlp) < TOL, (S, flag)
 
 
-def test_per_op_path_large_molecules():
-    """Above every fused layout (192 atoms) the flow runs on the per-op path.  r04 stopped at ~200 atoms there (one V x V score
+@pytest.mark.parametrize("path", [0, 5, -1], ids=["exact-f32", "split-fp16-linears", "model-default"])
+def test_per_op_path_large_molecules(path):
+    """r06: `path` 5 = TW_PATH_SIMPLE_H3 (the per-op path with its linear layers as split-fp16 MFMA GEMMs) and -1 = what a model
+    built without an explicit path takes at these sizes (the same) are held to the same bar as the exact-f32 per-op kernels.
+    Above every fused layout (192 atoms) the flow runs on the per-op path.  r04 stopped at ~200 atoms there (one V x V score
     tile per molecule in the LDS) and refused anything larger; r05: the scores are computed row-wise and the mixing is a tiled
     f32-MFMA GEMM from 129 atoms on, so the reference's own 691-atom test protein size goes through - against the oracle at the
     bar, ragged (masked tails), forward and reverse.  The row-wise scores kernel must equal the tile kernel bit for bit (150
@@ -767,8 +770,9 @@ def test_per_op_path_large_molecules():
     lib = _lib.load()
     sd = H.full_kernel_sd()
     g = torch.Generator().manual_seed(77)
-    m = H.tw_kernel_model(sd, path=0)
-    for V in (150, 256, 691):
+    m = H.tw_kernel_model(sd, path=path)
+    assert path != -1 or m._path_for(256) == _lib.TW_PATH_SIMPLE_H3 == 5
+    for V in ((256, 691) if path == -1 else (150, 256, 691)):   # (150 atoms: the model default is a fused layout)
         at = torch.randint(0, 5, (2, V), generator=g)
         x_c = torch.randn(2, V, 3, generator=g) * (0.8 if V < 300 else 1.5)
         x_v = torch.randn(2, V, 3, generator=g) * 0.5
@@ -790,6 +794,9 @@ def test_per_op_path_large_molecules():
             keep = ~mask[1]
             assert H.rel_err(got[0].cpu()[:, :, keep], rs[0][:, :, keep]) < TOL and H.rel_err(got[1].cpu()[:, :, keep], rs[1][:, :, keep]) < TOL
             assert H.rel_err(got[2].cpu(), rs[2]) < TOL
+    H.assert_not_demoted(m)
+    if path != 0:
+        return
     # the two scores kernels on the same 150 atoms (bit 21 forces the row-wise one), both cdist branches, Gaussian and Chebyshev:
     # bit-identical - the arithmetic of tw_cdist_mm / basis_value must not depend on the kernel it is inlined into
     V = 150

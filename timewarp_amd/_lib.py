@@ -16,7 +16,7 @@ from . import build as _build
 
 _LIB: Optional[C.CDLL] = None
 
-TW_PATH_AUTO, TW_PATH_FUSED, TW_PATH_SIMPLE, TW_PATH_FUSED_H3, TW_PATH_FUSED_H1 = 0, 1, 2, 3, 4
+TW_PATH_AUTO, TW_PATH_FUSED, TW_PATH_SIMPLE, TW_PATH_FUSED_H3, TW_PATH_FUSED_H1, TW_PATH_SIMPLE_H3 = 0, 1, 2, 3, 4, 5
 
 
 class FlowDesc(C.Structure):

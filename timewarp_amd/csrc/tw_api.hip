@@ -58,7 +58,7 @@ static int resolve_path(const tw_flow_desc& d, int n_atoms, int path, const floa
                d.variant, d.d_model, n_atoms);
     TW_REQUIRE(packed != nullptr, "fused path needs the packed weight stream (tw_flow_pack)");
   } else {
-    TW_REQUIRE(path == TW_PATH_SIMPLE, "unknown path %d", path);
+    TW_REQUIRE(path == TW_PATH_SIMPLE || path == TW_PATH_SIMPLE_H3, "unknown path %d", path);
   }
   *out = path;
   return TW_OK;
@@ -104,7 +104,8 @@ int tw_flow_path_supported(const tw_flow_desc* desc, int32_t n_atoms, int32_t pa
   if (check_desc(desc) || n_atoms <= 0) return 0;
   switch (path) {
     case TW_PATH_AUTO:
-    case TW_PATH_SIMPLE: return 1;
+    case TW_PATH_SIMPLE:
+    case TW_PATH_SIMPLE_H3: return 1;
     case TW_PATH_FUSED: return fused_supported(*desc, n_atoms) ? 1 : 0;
     case TW_PATH_FUSED_H3: return h3_supported(*desc, n_atoms) ? 1 : 0;
     case TW_PATH_FUSED_H1: return h1_supported(*desc, n_atoms) ? 1 : 0;
@@ -171,6 +172,7 @@ int tw_flow_pass(const tw_flow_desc* desc, const float* raw, const float* packed
     a.h1 = p == TW_PATH_FUSED_H1 ? 1 : 0;
     return flow_pass_h3(a);
   }
+  a.simple_h3 = p == TW_PATH_SIMPLE_H3 ? 1 : 0;
   return p == TW_PATH_FUSED ? flow_pass_fused(a) : flow_pass_simple(a);
 }
 
@@ -496,6 +498,7 @@ int tw_debug_netblock(const tw_flow_desc* desc, const float* raw, const float* p
     a.h1 = p == TW_PATH_FUSED_H1 ? 1 : 0;
     return debug_netblock_h3(a, coupling, net, z_other, dump);
   }
+  a.simple_h3 = p == TW_PATH_SIMPLE_H3 ? 1 : 0;
   return p == TW_PATH_FUSED ? debug_netblock_fused(a, coupling, net, z_other, dump)
                             : debug_netblock_simple(a, coupling, net, z_other, dump);
 }

@@ -152,6 +152,7 @@ struct FlowArgs {
   int64_t ws_bytes;
   hipStream_t stream;
   int h1 = 0;  // split-fp16 translation unit only: the single-MFMA variant (TW_PATH_FUSED_H1); `packed` is then its stream
+  int simple_h3 = 0;  // per-op path only: the linears as split-fp16 MFMA GEMMs (TW_PATH_SIMPLE_H3)
 };
 // torch.cdist's matmul formulation (what the reference gets above 25 atoms): the row [-2 x, |x|^2, 1] times
 // the column [y, 1, |y|^2], clamp_min(0), sqrt.  The result is dominated by fp32 cancellation (|x|^2 + |y|^2 - 2 x.y with

@@ -573,8 +573,154 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X
   }
 }
 
+// The same GEMM for TW_PATH_SIMPLE_H3 (r06): every fp32 product as THREE v_mfma_f32_16x16x32_f16 on fp16 hi / lo splits
+// (hi.hi + hi.lo + lo.hi, fp32 accumulate) - the arithmetic of the fused split-fp16 kernels, 16x the matrix rate of the fp32
+// form for 3x the instructions.  X and W are split while they are staged: fp32 tile -> registers -> (hi, lo) fp16 tiles in the
+// LDS, row-major [row][32 k] with rows padded to 40 halves (16-byte fragment reads of lanes (i16, g) then spread over the banks);
+// W is multiplied by 2^8 before the split so that its lo halves stay normal (|w| ~ 0.1 -> lo ~ 6e-3; 2^-8 is applied to the
+// fp32 sums, exact; |w| >= 256 overflows fp16 -> non-finite outputs -> the coupling step raises the range flag and the caller
+// falls back to the exact kernels, as for the fused split-fp16 path).  Workgroup = 4 waves = a 128 x 128 output tile, wave
+// (wm, wn) owns 64 x 64 (4 x 4 accumulators, 48 MFMAs per k-step of 32 against 16 fragment reads); the LDS tiles are double
+// buffered (one barrier per k-step) and the NEXT k-step's global loads are in flight during the MFMAs.
+typedef _Float16 lin_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lin_h4 __attribute__((ext_vector_type(4)));
+#define LH_BM 128
+#define LH_BN 128
+#define LH_ROW 40   // halves per LDS row: 32 + 8 of padding
+#define LH_WSCALE 256.0f
+template <int ACT>
+__global__ void __launch_bounds__(256) linear_h3_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ Y,
+                                                         int64_t M, int N, int K) {
+  // [buffer][X | W][hi | lo][row][k]: 80 KiB of dynamic LDS (launch_linear raises the kernel's limit)
+  extern __shared__ __attribute__((aligned(16))) char lh_lds[];
+  _Float16 (*tile)[2][2][LH_BM][LH_ROW] = (_Float16 (*)[2][2][LH_BM][LH_ROW])lh_lds;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * LH_BM;
+  const int n0 = blockIdx.x * LH_BN;
+  lin_f4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
+  const bool k_vec = (K % 4) == 0;
+  // one k-step of the tile: (128 + 128) rows x 8 float4 = 8 float4 per thread: t = 0..3 rows of X, 4..7 rows of W
+  lin_f4 nxt[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = threadIdx.x + 256 * (t & 3);
+      const bool is_x = t < 4;
+      const int r = i >> 3, kq = 4 * (i & 7);
+      const int64_t row = is_x ? m0 + r : (int64_t)n0 + r;
+      const bool row_ok = is_x ? row < M : row < N;
+      const float* src = (is_x ? X : W) + row * K + k0 + kq;
+      lin_f4 v = (lin_f4){0.f, 0.f, 0.f, 0.f};
+      if (row_ok) {
+        if (k_vec && k0 + kq + 3 < K) {
+          v = *(const lin_f4*)src;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + kq + e < K) v[e] = src[e];
+        }
+      }
+      nxt[t] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = threadIdx.x + 256 * (t & 3);
+      const int which = t < 4 ? 0 : 1;
+      const int r = i >> 3, kq = 4 * (i & 7);
+      lin_h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = which ? nxt[t][e] * LH_WSCALE : nxt[t][e];
+        const _Float16 h = (_Float16)v;
+        hi[e] = h;
+        lo[e] = (_Float16)(v - (float)h);
+      }
+      *(lin_h4*)&tile[buf][which][0][r][kq] = hi;
+      *(lin_h4*)&tile[buf][which][1][r][kq] = lo;
+    }
+  };
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    const bool more = k0 + 32 < K;
+    if (more) fetch(k0 + 32);
+    // fragments: lane (i16, g) holds k = 8 g .. 8 g + 7 of row i16 of a 16-row tile - the same k order for A and B
+    lin_h8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 64 * wm + 16 * i + i16;
+      ah[i] = *(const lin_h8*)&tile[buf][0][0][r][8 * g];
+      al[i] = *(const lin_h8*)&tile[buf][0][1][r][8 * g];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 64 * wn + 16 * j + i16;
+      bh[j] = *(const lin_h8*)&tile[buf][1][0][r][8 * g];
+      bl[j] = *(const lin_h8*)&tile[buf][1][1][r][8 * g];
+    }
+    // D = A B^T with A = X rows (tokens), B = W rows (output units): D[m][n], lane (i16, g) holds rows 4 g + r of column i16
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    if (more) stage(buf ^ 1);   // the other buffer: its last readers passed the barrier of the previous k-step
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + 64 * wn + 16 * j + i16;
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + 64 * wm + 16 * i + 4 * g + r;
+        if (m >= M) continue;
+        float v = acc[i][j][r] * (1.0f / LH_WSCALE) + bv;
+        if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+        if (ACT == ACT_SILU) v = v / (1.f + expf(-v));
+        Y[m * N + n] = v;
+      }
+  }
+}
+
 static int launch_linear(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K,
-                         int act, hipStream_t s) {
+                         int act, hipStream_t s, bool split = false) {
+  if (split && N >= 32) {   // (the 3-column head of the out-MLP stays on the fp32 form: one sixteenth of a 128-wide tile)
+    dim3 gridh((N + LH_BN - 1) / LH_BN, (unsigned)((M + LH_BM - 1) / LH_BM));
+    constexpr int lds = 2 * 2 * 2 * LH_BM * LH_ROW * (int)sizeof(_Float16);
+    static LdsLimit lim[3];
+    int lrc;
+    if (act == ACT_NONE) {
+      if ((lrc = lim[0].ensure((const void*)linear_h3_kernel<ACT_NONE>, lds))) return lrc;
+      hipLaunchKernelGGL(linear_h3_kernel<ACT_NONE>, gridh, dim3(256), lds, s, X, W, b, Y, M, N, K);
+    } else if (act == ACT_RELU) {
+      if ((lrc = lim[1].ensure((const void*)linear_h3_kernel<ACT_RELU>, lds))) return lrc;
+      hipLaunchKernelGGL(linear_h3_kernel<ACT_RELU>, gridh, dim3(256), lds, s, X, W, b, Y, M, N, K);
+    } else {
+      if ((lrc = lim[2].ensure((const void*)linear_h3_kernel<ACT_SILU>, lds))) return lrc;
+      hipLaunchKernelGGL(linear_h3_kernel<ACT_SILU>, gridh, dim3(256), lds, s, X, W, b, Y, M, N, K);
+    }
+    TW_LAUNCH_CHECK();
+    return TW_OK;
+  }
   dim3 grid((N + LIN_BN - 1) / LIN_BN, (unsigned)((M + LIN_BM - 1) / LIN_BM));
   if (act == ACT_NONE) hipLaunchKernelGGL(linear_kernel<ACT_NONE>, grid, dim3(256), 0, s, X, W, b, Y, M, N, K);
   else if (act == ACT_RELU) hipLaunchKernelGGL(linear_kernel<ACT_RELU>, grid, dim3(256), 0, s, X, W, b, Y, M, N, K);
@@ -832,6 +978,7 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
   const tw_flow_desc& d = *a.desc;
   const int V = a.n_atoms;
   const int64_t M = a.n_rows * V;
+  const bool sp = a.simple_h3 != 0;   // TW_PATH_SIMPLE_H3: the linears on split-fp16 MFMAs
   const float* nb = a.raw + net_base(L, c, net);
   hipStream_t s = a.stream;
   const float* rff = d.variant == 1 ? a.raw + L.chain + (int64_t)c * L.coupling_size + L.rff : nullptr;
@@ -839,8 +986,8 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
                      a.x_velocs, z_other, rff, d.d_rff, a.n_cond, V, d.d_emb, L.d_in, w.u, M);
   TW_LAUNCH_CHECK();
   int rc;
-  if ((rc = launch_linear(w.u, nb + L.net.in0_w, nb + L.net.in0_b, w.h0, M, d.d_hidden, L.d_in, ACT_SILU, s))) return rc;
-  if ((rc = launch_linear(w.h0, nb + L.net.in2_w, nb + L.net.in2_b, w.h, M, d.d_model, d.d_hidden, ACT_NONE, s))) return rc;
+  if ((rc = launch_linear(w.u, nb + L.net.in0_w, nb + L.net.in0_b, w.h0, M, d.d_hidden, L.d_in, ACT_SILU, s, sp))) return rc;
+  if ((rc = launch_linear(w.h0, nb + L.net.in2_w, nb + L.net.in2_b, w.h, M, d.d_model, d.d_hidden, ACT_NONE, s, sp))) return rc;
   const int64_t act_sz = M * d.d_model;
   if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump, w.h, act_sz * 4, hipMemcpyDeviceToDevice, s));
   for (int l = 0; l < d.n_layers; ++l) {
@@ -855,7 +1002,7 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
                                 d.cheb_order, d.cheb_force_zero)))
           return rc;
       }
-      if ((rc = launch_linear(w.h, lb + L.layer.wv, nullptr, w.vals, M, HD, d.d_model, ACT_NONE, s))) return rc;
+      if ((rc = launch_linear(w.h, lb + L.layer.wv, nullptr, w.vals, M, HD, d.d_model, ACT_NONE, s, sp))) return rc;
       if (V > 64 || (g_debug_flags & 2097152)) {
         // above 64 atoms: the tiled MFMA form (no V x V tile in the LDS: any molecule size; the scalar kernel below took 12 ms
         // per call at 100 atoms x 512 rows - 78 % of a per-op pass, profiles/r05_paired_kernel_stats.csv)
@@ -868,9 +1015,9 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
                            w.vals, w.att, a.n_cond, d.n_heads, V, d.d_model);
       }
       TW_LAUNCH_CHECK();
-      if ((rc = launch_linear(w.att, lb + L.layer.wo, nullptr, w.tmp, M, d.d_model, HD, ACT_NONE, s))) return rc;
+      if ((rc = launch_linear(w.att, lb + L.layer.wo, nullptr, w.tmp, M, d.d_model, HD, ACT_NONE, s, sp))) return rc;
     } else {
-      if ((rc = launch_linear(w.h, lb + L.layer.in_w, lb + L.layer.in_b, w.vals, M, 3 * d.d_model, d.d_model, ACT_NONE, s))) return rc;
+      if ((rc = launch_linear(w.h, lb + L.layer.in_w, lb + L.layer.in_b, w.vals, M, 3 * d.d_model, d.d_model, ACT_NONE, s, sp))) return rc;
       const int dh = d.d_model / d.n_heads;
       const size_t sdpa_lds = (size_t)(3 * V * dh + V * V) * 4;
       if (sdpa_lds > (size_t)160 * 1024 || (g_debug_flags & 2097152)) {  // no room for the score tile (or bit 21): row-wise
@@ -886,20 +1033,20 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
                            w.att, V, d.d_model, d.n_heads);
       }
       TW_LAUNCH_CHECK();
-      if ((rc = launch_linear(w.att, lb + L.layer.out_w, lb + L.layer.out_b, w.tmp, M, d.d_model, d.d_model, ACT_NONE, s))) return rc;
+      if ((rc = launch_linear(w.att, lb + L.layer.out_w, lb + L.layer.out_b, w.tmp, M, d.d_model, d.d_model, ACT_NONE, s, sp))) return rc;
     }
     hipLaunchKernelGGL(add_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.h, w.tmp, lb + L.layer.n1w,
                        lb + L.layer.n1b, d.ln_eps, d.d_model, M);
     TW_LAUNCH_CHECK();
-    if ((rc = launch_linear(w.h, lb + L.layer.w1, lb + L.layer.b1, w.ff, M, d.d_ff, d.d_model, ACT_RELU, s))) return rc;
-    if ((rc = launch_linear(w.ff, lb + L.layer.w2, lb + L.layer.b2, w.tmp, M, d.d_model, d.d_ff, ACT_NONE, s))) return rc;
+    if ((rc = launch_linear(w.h, lb + L.layer.w1, lb + L.layer.b1, w.ff, M, d.d_ff, d.d_model, ACT_RELU, s, sp))) return rc;
+    if ((rc = launch_linear(w.ff, lb + L.layer.w2, lb + L.layer.b2, w.tmp, M, d.d_model, d.d_ff, ACT_NONE, s, sp))) return rc;
     hipLaunchKernelGGL(add_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.h, w.tmp, lb + L.layer.n2w,
                        lb + L.layer.n2b, d.ln_eps, d.d_model, M);
     TW_LAUNCH_CHECK();
     if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump + (l + 1) * act_sz, w.h, act_sz * 4, hipMemcpyDeviceToDevice, s));
   }
-  if ((rc = launch_linear(w.h, nb + L.net.out0_w, nb + L.net.out0_b, w.h0, M, d.d_hidden, d.d_model, ACT_SILU, s))) return rc;
-  if ((rc = launch_linear(w.h0, nb + L.net.out2_w, nb + L.net.out2_b, out, M, 3, d.d_hidden, ACT_NONE, s))) return rc;
+  if ((rc = launch_linear(w.h, nb + L.net.out0_w, nb + L.net.out0_b, w.h0, M, d.d_hidden, d.d_model, ACT_SILU, s, sp))) return rc;
+  if ((rc = launch_linear(w.h0, nb + L.net.out2_w, nb + L.net.out2_b, out, M, 3, d.d_hidden, ACT_NONE, s, sp))) return rc;
   if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump + (d.n_layers + 1) * act_sz, out, M * 3 * 4, hipMemcpyDeviceToDevice, s));
   return TW_OK;
 }

@@ -36,7 +36,7 @@ def model_constructor(config) -> nn.Module:
     raise NotImplementedError(f"{model_type} is not a recognised model.")
 
 
-_PATH_NAMES = {"auto": _lib.TW_PATH_AUTO, "f32": _lib.TW_PATH_FUSED, "simple": _lib.TW_PATH_SIMPLE,
+_PATH_NAMES = {"auto": _lib.TW_PATH_AUTO, "f32": _lib.TW_PATH_FUSED, "simple": _lib.TW_PATH_SIMPLE, "simple_h3": _lib.TW_PATH_SIMPLE_H3,
                "h3": PREFER_SPLIT_FP16, "split_fp16": PREFER_SPLIT_FP16,
                # opt-in fast mode: one fp16 MFMA per product (~1e-4 relative deviation from the reference; not a parity path)
                "h1": PREFER_SINGLE_FP16, "fast": PREFER_SINGLE_FP16}

@@ -27,7 +27,7 @@ PREFER_SPLIT_FP16 = -1
 # wherever it applies, the split-fp16 kernel or AUTO for the rest.  NOT a parity mode: results deviate from the reference's
 # fp32 arithmetic by ~1e-4 relative; never the default.
 PREFER_SINGLE_FP16 = -2
-_HALF_PATHS = (_lib.TW_PATH_FUSED_H3, _lib.TW_PATH_FUSED_H1)
+_HALF_PATHS = (_lib.TW_PATH_FUSED_H3, _lib.TW_PATH_FUSED_H1, _lib.TW_PATH_SIMPLE_H3)
 
 
 class ConditionalFlowDensityModel(ConditionalDensityModel):
@@ -72,7 +72,14 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
                 path = _lib.TW_PATH_FUSED_H1
             else:
                 ok = sup(C.byref(desc), int(n_atoms), _lib.TW_PATH_FUSED_H3) == 1
-                path = _lib.TW_PATH_FUSED_H3 if ok else _lib.TW_PATH_AUTO
+                if ok:
+                    path = _lib.TW_PATH_FUSED_H3
+                elif sup(C.byref(desc), int(n_atoms), _lib.TW_PATH_FUSED) == 1:
+                    path = _lib.TW_PATH_AUTO          # the exact-f32 fused kernel serves the shape
+                else:
+                    # r06: no fused layout at all (kernel attention above 192 atoms, dense softmax above 64, other widths):
+                    # the per-op path with its linears on split-fp16 MFMAs instead of the fp32 matrix pipe
+                    path = _lib.TW_PATH_SIMPLE_H3
         if path in _HALF_PATHS:
             self.used_split_fp16 = True
         return path
@@ -225,7 +232,7 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
                                                    _lib.stream_ptr(device)), "tw_flow_pack_h3")
                 w["h3"] = buf
             return w["raw"], w["h3"]
-        if w["f32"] is None and path != _lib.TW_PATH_SIMPLE:
+        if w["f32"] is None and path not in (_lib.TW_PATH_SIMPLE, _lib.TW_PATH_SIMPLE_H3):
             n = lib.tw_flow_packed_floats(C.byref(desc))
             if n > 0:
                 buf = torch.empty(n, dtype=torch.float32, device=device)

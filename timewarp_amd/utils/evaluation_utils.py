@@ -248,7 +248,7 @@ class ReplayDraws:
 def _range_guarded(model) -> bool:
     """The model may run on the split-fp16 kernel (and so needs the range guard's recorded draws)."""
     return hasattr(model, "split_fp16_overflowed") and not getattr(model, "demoted", False) and \
-        getattr(model, "execution_path", 0) in (-1, -2, _lib.TW_PATH_FUSED_H3, _lib.TW_PATH_FUSED_H1)
+        getattr(model, "execution_path", 0) in (-1, -2, _lib.TW_PATH_FUSED_H3, _lib.TW_PATH_FUSED_H1, _lib.TW_PATH_SIMPLE_H3)
 
 
 class _no_defer:

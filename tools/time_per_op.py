@@ -4,9 +4,11 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import helpers as H
 
-m = H.tw_kernel_model(H.full_kernel_sd(), path=2)
+# --path=2 (default): the exact-f32 per-op kernels; --path=5: TW_PATH_SIMPLE_H3, the linears as split-fp16 MFMA GEMMs (r06)
+path = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--path=")), 2)
+m = H.tw_kernel_model(H.full_kernel_sd(), path=path)
 g = torch.Generator().manual_seed(0)
-for spec in sys.argv[1:] or ["192x256"]:
+for spec in [a for a in sys.argv[1:] if not a.startswith("--")] or ["192x256"]:
     V, S = (int(t) for t in spec.split("x"))
     at = torch.randint(0, 5, (1, V), generator=g).cuda()
     xc = (torch.randn(1, V, 3, generator=g) * 0.8).cuda()
@@ -20,4 +22,4 @@ for spec in sys.argv[1:] or ["192x256"]:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3 * 1e3
     flop = 16 * V * (4478976 + 4608 * V) * S
-    print(f"per-op path V={V} S={S}: {dt:.1f} ms per reverse pass, {flop / dt / 1e9:.1f} TFLOP/s algorithmic", flush=True)
+    print(f"per-op path {path} V={V} S={S}: {dt:.1f} ms per reverse pass, {flop / dt / 1e9:.1f} TFLOP/s algorithmic", flush=True)
