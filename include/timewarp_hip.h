@@ -100,6 +100,12 @@ int tw_flow_pack(const tw_flow_desc* desc, const float* raw, float* packed, void
  * (per-matrix power-of-two scaling, fp16 hi/lo tile pairs in LDS-DMA stage order). */
 int64_t tw_flow_packed_h3_bytes(const tw_flow_desc* desc);
 int tw_flow_pack_h3(const tw_flow_desc* desc, const float* raw, void* packed_h3, void* stream);
+/* ABI 8 - the pack of TW_PATH_SIMPLE_H3 (0 bytes where the model has no split-fp16 stream: that path then takes packed = NULL):
+ * the tw_flow_pack_h3 stream (its FFN stages feed the path's fused FFN launches), then - kernel attention - the per-head folded
+ * value / output projections Wc[coupling][net][layer][d_model][n_heads d_model] (fp32, folded in fp64), which let the mixing run
+ * on the layer input with ONE GEMM behind it. */
+int64_t tw_flow_packed_simple_h3_bytes(const tw_flow_desc* desc);
+int tw_flow_pack_simple_h3(const tw_flow_desc* desc, const float* raw, void* packed, void* stream);
 /* The same for TW_PATH_FUSED_H1 (fp16 hi tiles only: 8 tiles per 9 KiB stage, half as many stages). */
 int64_t tw_flow_packed_h1_bytes(const tw_flow_desc* desc);
 int tw_flow_pack_h1(const tw_flow_desc* desc, const float* raw, void* packed_h1, void* stream);
@@ -133,7 +139,11 @@ int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_
                               product, fp32 accumulation), one kernel per reference op, ANY molecule size and both model variants:
                               what serves the sizes no fused layout takes (kernel attention above 192 atoms, dense above 64) at ~3x
                               the rate of the exact-f32 per-op kernels.  Scores, softmax, mixing, LayerNorm stay fp32.  Needs
-                              |activations| < 65504 and |weights| < 256 (else non-finite outputs -> range flag); `packed` unused. */
+                              |activations| < 65504 and |weights| < 256 (else non-finite outputs -> range flag).  `packed`: NULL, or
+                              the tw_flow_pack_simple_h3 buffer where that exists (d_model 128) - the FFN of every encoder layer
+                              then runs as ONE launch of the fused kernels' chunk loop on the flat token list (hidden layer on
+                              chip) instead of two GEMMs through HBM, and kernel attention mixes the layer input itself with one
+                              folded 768 -> 128 GEMM behind it. */
 
 /* 1 if `path` can run this configuration on molecules of n_atoms atoms (TW_PATH_AUTO / TW_PATH_SIMPLE / TW_PATH_SIMPLE_H3: always), else 0.
  * What a caller asks before it requests TW_PATH_FUSED / TW_PATH_FUSED_H3 by name (those fail with TW_ERR_INVALID on an
@@ -436,7 +446,9 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *   bit 21 (2097152) per-op path: the row-wise scores kernel and the tiled MFMA mixing kernel (what molecules above ~200 / 64
  *              atoms take) at every size; same scores bit for bit, the mixing in another summation order (A/B switch and tests)
  *   bit 22 (4194304) / bit 23 (8388608)  tw_mh_iteration: the energy kernel on the caller's stream / on the side stream,
- *              whatever the launch size (default: side stream only while the flow's launches leave compute units idle) */
+ *              whatever the launch size (default: side stream only while the flow's launches leave compute units idle)
+ *   bit 24 (16777216) TW_PATH_SIMPLE_H3: the FFN as two linear launches + add_ln even when the split-fp16 stream is at hand
+ *              (default then: one launch of the fused kernels' chunk loop on the flat token list); A/B switch and tests */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

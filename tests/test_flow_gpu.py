@@ -795,6 +795,16 @@ def test_per_op_path_large_molecules(path):
             assert H.rel_err(got[0].cpu()[:, :, keep], rs[0][:, :, keep]) < TOL and H.rel_err(got[1].cpu()[:, :, keep], rs[1][:, :, keep]) < TOL
             assert H.rel_err(got[2].cpu(), rs[2]) < TOL
     H.assert_not_demoted(m)
+    if path == 5:
+        # the FFN of this path is one launch of the fused kernels' chunk loop on the flat token list (the split-fp16 stream is at
+        # hand for this model); bit 24: two GEMMs + add_ln instead - both at the bar
+        try:
+            lib.tw_debug_set_flags(16777216)
+            out2 = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                                    y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+        finally:
+            lib.tw_debug_set_flags(0)
+        assert H.rel_err(out2.cpu(), ref) < TOL
     if path != 0:
         return
     # the two scores kernels on the same 150 atoms (bit 21 forces the row-wise one), both cdist branches, Gaussian and Chebyshev:

@@ -127,3 +127,24 @@ def test_mh_iterations_on_tetra_alanine_amber14_vs_oracle(path):
     assert ref[2] >= 1
     H.assert_not_demoted(model)
     _assert_chain_matches_oracle(got, ref, tol=1e-5, stat_tol=2e-4)
+
+
+def test_amber14_preset_says_that_it_is_unpinned():
+    """an energy built from the amber14 preset carries parity = "unpinned" and warns once per process; the
+    amber99 presets (pinned on the reference's OpenMM known-answer files) do neither."""
+    import warnings
+
+    from timewarp_amd import energy as E
+    from timewarp_amd.forcefield import AD_ATOM_NAMES, AD_RESIDUES
+
+    rid = [{"ACE": 1, "ALA": 2, "NME": 3}[r] for r in AD_RESIDUES]
+    E._UNPINNED_WARNED[0] = False
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        a99 = E.AmberPotentialEnergyTorch.from_preset("alanine-dipeptide", AD_ATOM_NAMES, AD_RESIDUES, rid)
+        assert a99.parity == "pinned" and not seen
+        a14 = E.AmberPotentialEnergyTorch.from_preset("T1B-peptides", AD_ATOM_NAMES, AD_RESIDUES, rid)
+        assert a14.parity == "unpinned" and len(seen) == 1 and "UNPINNED" in str(seen[0].message)
+        E.AmberPotentialEnergyTorch.from_preset("amber14-implicit", AD_ATOM_NAMES, AD_RESIDUES, rid)
+        assert len(seen) == 1                      # once per process
+    assert E.AmberPotentialEnergyTorch.alanine_dipeptide().parity == "pinned"

@@ -104,9 +104,12 @@ def test_execution_path_from_environment(monkeypatch):
     monkeypatch.setenv("TW_EXECUTION_PATH", "fp8")
     with pytest.raises(ValueError, match="TW_EXECUTION_PATH"):
         tw.model_constructor(cfg)
-    # every molecule that fits a 48-token wave runs on the split-fp16 kernel (tw_flow_path_supported), the rest on AUTO
+    # every molecule a fused layout takes runs on the split-fp16 kernel (tw_flow_path_supported); above them (r06) the per-op path
+    # with split-fp16 linears (TW_PATH_SIMPLE_H3 = 5); a shape only the exact-f32 fused kernel serves would get AUTO
     monkeypatch.setenv("TW_EXECUTION_PATH", "h3")
-    assert [m._path_for(v) for v in (1, 7, 12, 17, 21, 30, 40, 48, 49, 64, 65, 160, 192, 193, 200)] == [3] * 13 + [0] * 2
+    assert [m._path_for(v) for v in (1, 7, 12, 17, 21, 30, 40, 48, 49, 64, 65, 160, 192, 193, 200, 691)] == [3] * 13 + [5] * 3
+    dense = tw.model_constructor(synthetic.transformer_nvp_config())
+    assert [dense._path_for(v) for v in (22, 48, 49, 64, 65, 200)] == [3, 3, 3, 3, 5, 5]
     # ... unless the score-fragment producer's LDS tile would not fit the CU: 48 atoms x 18 heads
     many = synthetic.kernel_transformer_nvp_config()
     many.custom_transformer_nvp_config.encoder_layer_config.lengthscales = [0.1 * (i + 1) for i in range(18)]

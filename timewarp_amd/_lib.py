@@ -103,6 +103,8 @@ SIGNATURES = {
     "tw_flow_raw_floats": (_I64, [_DESC]),
     "tw_flow_packed_floats": (_I64, [_DESC]),
     "tw_flow_pack": (C.c_int, [_DESC, _P, _P, _P]),
+    "tw_flow_packed_simple_h3_bytes": (_I64, [_DESC]),
+    "tw_flow_pack_simple_h3": (C.c_int, [_DESC, _P, _P, _P]),
     "tw_flow_packed_h3_bytes": (_I64, [_DESC]),
     "tw_flow_pack_h3": (C.c_int, [_DESC, _P, _P, _P]),
     "tw_flow_packed_h1_bytes": (_I64, [_DESC]),

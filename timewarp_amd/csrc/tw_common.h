@@ -284,6 +284,13 @@ int profile_mark(hipStream_t s, bool begin);
 void note_netblock_kernel(const char* name);
 const char* last_netblock_kernel();
 int h3_selected_kernel(const tw_flow_desc& d, int n_atoms, int64_t n_rows, bool h1);  // dry run of the launch code's choice
+// TW_PATH_SIMPLE_H3: h <- LayerNorm2(h + FFN(h)) of (coupling, net, layer) on a flat [n_tokens, 128] list, FFN weights from the
+// tw_flow_pack_h3 stream (csrc/tw_netblock_h3.hip)
+bool h3_ffn_tokens_supported(const tw_flow_desc& d);
+int64_t simple_h3_fold_floats(const tw_flow_desc& d);   // tw_flow_pack_simple_h3: Wc of every (coupling, net, layer) behind the stream
+int simple_h3_fold(const tw_flow_desc& d, const float* raw, float* out, hipStream_t s);
+int h3_ffn_tokens(const tw_flow_desc& d, const void* packed, int coupling, int net, int layer, float* h, int64_t n_tokens,
+                  hipStream_t stream);
 int profile_begin();
 int profile_end(double* total_ms, int64_t* launches);
 

@@ -701,6 +701,43 @@ __global__ void __launch_bounds__(256) linear_h3_kernel(const float* __restrict_
   }
 }
 
+// Wc[n][h D + k] = sum_j W_o[n][h D + j] W_v[h D + j][k]  (fp64 sums, as the fused kernels' pack does): the value and output
+// projections of kernel attention folded per head (kernel_attention.py:124-156: out_proj(flatten(A_h (x W_v,h^T)))) = sum_h (A_h x) Wc_h^T
+__global__ void fold_vo_kernel(const float* __restrict__ raw, int64_t first_net, int64_t coupling_size, int64_t net_size,
+                               int64_t layers_off, int64_t layer_size, int64_t wv_off, int64_t wo_off, int n_layers, int H, int D,
+                               float* __restrict__ out) {
+  // blockIdx.x = ((c * 2 + net) * n_layers + l) * H + h;  one thread per (n, k) of the head's D x D block
+  int64_t b = blockIdx.x;
+  const int h = (int)(b % H); b /= H;
+  const int l = (int)(b % n_layers); b /= n_layers;
+  const int net = (int)(b % 2);
+  const int64_t c = b / 2;
+  const float* lb = raw + first_net + c * coupling_size + net * net_size + layers_off + (int64_t)l * layer_size;
+  const float* wv = lb + wv_off;   // [H D, D]
+  const float* wo = lb + wo_off;   // [D, H D]
+  float* o = out + (((c * 2 + net) * n_layers + l) * (int64_t)D) * H * D;   // [D, H D]
+  for (int i = threadIdx.x; i < D * D; i += blockDim.x) {
+    const int n = i / D, k = i % D;
+    double acc = 0.0;
+    for (int j = 0; j < D; ++j) acc += (double)wo[(int64_t)n * H * D + h * D + j] * (double)wv[(int64_t)(h * D + j) * D + k];
+    o[(int64_t)n * H * D + h * D + k] = (float)acc;
+  }
+}
+
+int64_t simple_h3_fold_floats(const tw_flow_desc& d) {
+  return d.variant == 0 ? (int64_t)d.n_coupling * 2 * d.n_layers * d.d_model * d.n_heads * d.d_model : 0;
+}
+
+int simple_h3_fold(const tw_flow_desc& d, const float* raw, float* out, hipStream_t s) {
+  if (d.variant != 0) return TW_OK;
+  const RawLayout L = raw_layout(d);
+  const int64_t blocks = (int64_t)d.n_coupling * 2 * d.n_layers * d.n_heads;
+  hipLaunchKernelGGL(fold_vo_kernel, dim3((unsigned)blocks), dim3(256), 0, s, raw, L.chain + L.nets, L.coupling_size, L.net.size,
+                     L.net.layers, L.layer.size, L.layer.wv, L.layer.wo, d.n_layers, d.n_heads, d.d_model, out);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+
 static int launch_linear(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K,
                          int act, hipStream_t s, bool split = false) {
   if (split && N >= 32) {   // (the 3-column head of the out-MLP stays on the fp32 form: one sixteenth of a 128-wide tile)
@@ -745,6 +782,150 @@ __global__ void attend_kernel(const float* __restrict__ scores, const float* __r
       for (int m = 0; m < V; ++m) acc = fmaf(sc[q * V + m], vals[((n * V + m) * H + h) * (int64_t)D + d], acc);
       att[((n * V + q) * H + h) * (int64_t)D + d] = acc;
     }
+  }
+}
+
+// The mixing GEMM of TW_PATH_SIMPLE_H3 (r06): per (row n, head h)  att[q, d] = sum_m scores[q, m] * vals[m, d]  as split-fp16 MFMAs
+// (three v_mfma_f32_16x16x32_f16 per fp32 product, as linear_h3_kernel).  A operand = score rows (m contiguous: staged like
+// linear_h3_kernel's X, multiplied by 2^10 before the split - scores are in [0, 1], entries of a 200-atom row ~5e-3 would have
+// subnormal lo halves otherwise); B operand = vals^T: lane (d, g) needs eight consecutive m of ONE feature, so the 32 x 128 slice of
+// vals is transposed on its way into the LDS - each thread loads rows m, m + 1 of four features and writes (m, m + 1) half pairs.
+// Workgroup = 128 queries x 128 features, wave (wm, wn) 64 x 64.  1-D grid over (n, h, query tile, feature tile).
+#define AH_SSCALE 1024.0f
+// `vrow` / `vhead`: floats between consecutive keys of `vals` and between heads - (H D, D) for the projected values [n, m, h, d];
+// (D, 0) for the FOLDED form, where every head mixes the layer input x [n, m, d] itself and the per-head value and output
+// projections are one 768 -> 128 GEMM behind the mixing (Wc_h = W_o,h W_v,h, tw_flow_pack_simple_h3).
+__global__ void __launch_bounds__(256) attend_h3_kernel(const float* __restrict__ scores, const float* __restrict__ vals,
+                                                         float* __restrict__ att, int64_t n_cond, int H, int V, int D,
+                                                         int64_t vrow, int64_t vhead) {
+  extern __shared__ __attribute__((aligned(16))) char lh_lds[];
+  _Float16 (*tile)[2][2][LH_BM][LH_ROW] = (_Float16 (*)[2][2][LH_BM][LH_ROW])lh_lds;   // [buffer][S | vals^T][hi | lo][row][k]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (D + LH_BN - 1) / LH_BN, tiles_m = (V + LH_BM - 1) / LH_BM;
+  int64_t blk = blockIdx.x;
+  const int tn = (int)(blk % tiles_n); blk /= tiles_n;
+  const int tm = (int)(blk % tiles_m); blk /= tiles_m;
+  const int h = (int)(blk % H);
+  const int64_t n = blk / H;
+  const int64_t c = n % n_cond;
+  const int q0 = tm * LH_BM, d0 = tn * LH_BN;
+  const float* S = scores + ((c * H + h) * V) * (int64_t)V;
+  const float* Vv = vals + n * V * vrow + h * vhead;
+  const int64_t vstride = vrow;
+  lin_f4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
+  // a k-step (32 keys): scores 128 q x 32 m = 4 float4 per thread (unaligned rows: scalar loads); vals 32 m x 128 d = 16 m-pairs x
+  // 32 feature quads = 2 (pair, quad) items per thread, two float4 each
+  float ns[4][4];
+  lin_f4 nv[2][2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = threadIdx.x + 256 * t, r = i >> 3, kq = 4 * (i & 7);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ns[t][e] = (q0 + r < V && k0 + kq + e < V) ? S[(int64_t)(q0 + r) * V + k0 + kq + e] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = threadIdx.x + 256 * t, mp = i >> 5, dq = 4 * (i & 31);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int m = k0 + 2 * mp + u;
+        lin_f4 v = (lin_f4){0.f, 0.f, 0.f, 0.f};
+        if (m < V) {
+          const float* src = Vv + (int64_t)m * vstride + d0 + dq;
+          if (d0 + dq + 3 < D) v = *(const lin_f4*)src;
+          else
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (d0 + dq + e < D) v[e] = src[e];
+        }
+        nv[t][u] = v;
+      }
+    }
+  };
+  typedef _Float16 lin_h2 __attribute__((ext_vector_type(2)));
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = threadIdx.x + 256 * t, r = i >> 3, kq = 4 * (i & 7);
+      lin_h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = ns[t][e] * AH_SSCALE;
+        const _Float16 hh = (_Float16)v;
+        hi[e] = hh;
+        lo[e] = (_Float16)(v - (float)hh);
+      }
+      *(lin_h4*)&tile[buf][0][0][r][kq] = hi;
+      *(lin_h4*)&tile[buf][0][1][r][kq] = lo;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = threadIdx.x + 256 * t, mp = i >> 5, dq = 4 * (i & 31);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lin_h2 hi, lo;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float v = nv[t][u][e];
+          const _Float16 hh = (_Float16)v;
+          hi[u] = hh;
+          lo[u] = (_Float16)(v - (float)hh);
+        }
+        *(lin_h2*)&tile[buf][1][0][dq + e][2 * mp] = hi;   // vals^T: row = feature, k = key
+        *(lin_h2*)&tile[buf][1][1][dq + e][2 * mp] = lo;
+      }
+    }
+  };
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < V; k0 += 32) {
+    const bool more = k0 + 32 < V;
+    if (more) fetch(k0 + 32);
+    lin_h8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 64 * wm + 16 * i + i16;
+      ah[i] = *(const lin_h8*)&tile[buf][0][0][r][8 * g];
+      al[i] = *(const lin_h8*)&tile[buf][0][1][r][8 * g];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 64 * wn + 16 * j + i16;
+      bh[j] = *(const lin_h8*)&tile[buf][1][0][r][8 * g];
+      bl[j] = *(const lin_h8*)&tile[buf][1][1][r][8 * g];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    if (more) stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int dd = d0 + 64 * wn + 16 * j + i16;
+    if (dd >= D) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = q0 + 64 * wm + 16 * i + 4 * g + r;
+        if (q < V) att[((n * V + q) * H + h) * (int64_t)D + dd] = acc[i][j][r] * (1.0f / AH_SSCALE);
+      }
   }
 }
 
@@ -1002,8 +1183,24 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
                                 d.cheb_order, d.cheb_force_zero)))
           return rc;
       }
-      if ((rc = launch_linear(w.h, lb + L.layer.wv, nullptr, w.vals, M, HD, d.d_model, ACT_NONE, s, sp))) return rc;
-      if (V > 64 || (g_debug_flags & 2097152)) {
+      // TW_PATH_SIMPLE_H3 with its pack at hand (tw_flow_pack_simple_h3: the split-fp16 stream, then Wc of every (coupling, net,
+      // layer)): the mixing runs on the layer input itself and ONE 768 -> 128 GEMM follows it - no value projection, no [M, 768]
+      // round trip for it
+      const float* wc = (sp && a.packed && V > 64 && h3_ffn_tokens_supported(d) && !(g_debug_flags & 16777216))
+          ? (const float*)((const char*)a.packed + (h3_packed_bytes(d, false) + 255) / 256 * 256) +
+                (((int64_t)c * 2 + net) * d.n_layers + l) * (int64_t)d.d_model * HD
+          : nullptr;
+      if (!wc && (rc = launch_linear(w.h, lb + L.layer.wv, nullptr, w.vals, M, HD, d.d_model, ACT_NONE, s, sp))) return rc;
+      if (sp && V > 64) {
+        // TW_PATH_SIMPLE_H3: the mixing on split-fp16 MFMAs as well (128 x 128 tiles: worth it from ~64 keys on)
+        const int64_t blocks = a.n_rows * d.n_heads * ((V + LH_BM - 1) / LH_BM) * ((d.d_model + LH_BN - 1) / LH_BN);
+        TW_REQUIRE(blocks < (int64_t)1 << 31, "attend: %lld workgroups", (long long)blocks);
+        constexpr int lds = 2 * 2 * 2 * LH_BM * LH_ROW * (int)sizeof(_Float16);
+        static LdsLimit lim;
+        if ((rc = lim.ensure((const void*)attend_h3_kernel, lds))) return rc;
+        hipLaunchKernelGGL(attend_h3_kernel, dim3((unsigned)blocks), dim3(256), lds, s, w.scores, wc ? w.h : w.vals, w.att, a.n_cond,
+                           d.n_heads, V, d.d_model, wc ? (int64_t)d.d_model : (int64_t)HD, wc ? (int64_t)0 : (int64_t)d.d_model);
+      } else if (V > 64 || (g_debug_flags & 2097152)) {
         // above 64 atoms: the tiled MFMA form (no V x V tile in the LDS: any molecule size; the scalar kernel below took 12 ms
         // per call at 100 atoms x 512 rows - 78 % of a per-op pass, profiles/r05_paired_kernel_stats.csv)
         const int64_t blocks = a.n_rows * d.n_heads * ((V + LIN_BM - 1) / LIN_BM) * ((d.d_model + LIN_BN - 1) / LIN_BN);
@@ -1015,7 +1212,7 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
                            w.vals, w.att, a.n_cond, d.n_heads, V, d.d_model);
       }
       TW_LAUNCH_CHECK();
-      if ((rc = launch_linear(w.att, lb + L.layer.wo, nullptr, w.tmp, M, d.d_model, HD, ACT_NONE, s, sp))) return rc;
+      if ((rc = launch_linear(w.att, wc ? wc : lb + L.layer.wo, nullptr, w.tmp, M, d.d_model, HD, ACT_NONE, s, sp))) return rc;
     } else {
       if ((rc = launch_linear(w.h, lb + L.layer.in_w, lb + L.layer.in_b, w.vals, M, 3 * d.d_model, d.d_model, ACT_NONE, s, sp))) return rc;
       const int dh = d.d_model / d.n_heads;
@@ -1038,11 +1235,17 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
     hipLaunchKernelGGL(add_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.h, w.tmp, lb + L.layer.n1w,
                        lb + L.layer.n1b, d.ln_eps, d.d_model, M);
     TW_LAUNCH_CHECK();
+    if (sp && a.packed && h3_ffn_tokens_supported(d) && !(g_debug_flags & 16777216)) {
+      // TW_PATH_SIMPLE_H3 with the split-fp16 stream at hand: FFN + residual + LayerNorm 2 as ONE launch of the fused kernels' chunk
+      // loop on the flat token list - the 2048-wide hidden layer stays on the chip (tw_netblock_h3.hip: h3_ffn_tokens_kernel)
+      if ((rc = h3_ffn_tokens(d, a.packed, c, net, l, w.h, M, s))) return rc;
+    } else {
     if ((rc = launch_linear(w.h, lb + L.layer.w1, lb + L.layer.b1, w.ff, M, d.d_ff, d.d_model, ACT_RELU, s, sp))) return rc;
     if ((rc = launch_linear(w.ff, lb + L.layer.w2, lb + L.layer.b2, w.tmp, M, d.d_model, d.d_ff, ACT_NONE, s, sp))) return rc;
     hipLaunchKernelGGL(add_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.h, w.tmp, lb + L.layer.n2w,
                        lb + L.layer.n2b, d.ln_eps, d.d_model, M);
     TW_LAUNCH_CHECK();
+    }
     if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump + (l + 1) * act_sz, w.h, act_sz * 4, hipMemcpyDeviceToDevice, s));
   }
   if ((rc = launch_linear(w.h, nb + L.net.out0_w, nb + L.net.out0_b, w.h0, M, d.d_hidden, d.d_model, ACT_SILU, s, sp))) return rc;

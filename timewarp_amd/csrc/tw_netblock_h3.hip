@@ -2716,6 +2716,96 @@ netblock_h3_kernel(const H3Params p) {
 }
 
 // ================================================================================================
+// r06 - TW_PATH_SIMPLE_H3 (molecules no fused layout takes): the FFN half of an encoder layer on a FLAT token list,
+//   h <- LayerNorm2(h + W2 relu(W1 h + b1) + b2)          (custom_transformer_block.py:64-72 / transformer_block.py:62-72)
+// with the fused kernels' own machinery: the layer's FFN stages of the split-fp16 stream through the LDS ring, the generated chunk
+// loop (tw_h3_ffn_asm.inc: 64 chunks x 144 MFMAs per wave), the 2048-wide hidden layer never leaving the chip.  The per-op form
+// wrote and re-read it through HBM (403 MB per call at 192 atoms x 256 rows).  A workgroup = 4 waves x 48 consecutive tokens;
+// nothing here knows about molecules.
+// ================================================================================================
+struct H3FfnParams {
+  const char* stages;      // first FFN stage of (coupling, net, layer) in the tw_flow_pack_h3 stream
+  const float* side;       // the layer's side block: n1w n1b b2 n2w n2b [128 each], slot 641 = W2's scale
+  float* h;                // [n_tokens, 128] in / out
+  int64_t n_tokens;
+  int ff_chunks;
+  float eps;
+};
+
+__global__ void __launch_bounds__(256) h3_ffn_tokens_kernel(H3FfnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NT = H3_NT;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, i16 = lane & 15;
+  H3Pipe pipe;
+  pipe.gnext = p.stages + lane * 16;
+  pipe.lds = lds;
+  pipe.cur = 0;
+  pipe.wave = wave;
+  pipe.debug = 0;
+  pipe.ring = H3_RING;
+  pipe.start_issue();
+  char* priv = lds + H3_RING * H3_STAGE_BYTES + wave * H3_WAVE_LDS;
+  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * NT);
+  f4 x[8][NT], y[8][NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int64_t t = t0 + 16 * jt + i16;
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft)
+      x[ft][jt] = t < p.n_tokens ? *(const f4*)(p.h + t * 128 + 16 * ft + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float sc = p.side[641];
+  {
+    BOp<NT> xb[4];
+    to_bop<NT, 4>(x, xb);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        *(h8*)(priv + ((ks * NT + jt) * 2) * 1024 + lane * 16) = xb[ks].h[jt];
+        *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = xb[ks].l[jt];
+      }
+  }
+  pipe.start_wait();   // vmcnt(0) + barrier: the first five stages are in the ring (and x is in registers)
+  {
+    int cur = 0;
+    const char* gn = pipe.gnext;
+    const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
+    const int chunks = __builtin_amdgcn_readfirstlane(p.ff_chunks);
+    asm volatile(
+#include "tw_h3_ffn_asm.inc"
+        : [cur] "+&s"(cur), [gn] "+&v"(gn)
+        : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+        :
+#include "tw_h3_ffn_clobbers.inc"
+    );
+  }
+#pragma unroll
+  for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) y[ot][jt] = *(const f4*)(priv + (ot * NT + jt) * 1024 + lane * 16);
+#pragma unroll
+  for (int ot = 0; ot < 8; ++ot) {
+    const f4 bb = *(const f4*)(p.side + 256 + 4 * g + 16 * ot);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) y[ot][jt] = y[ot][jt] * sc + bb;
+  }
+  h3_add_layernorm<NT>(x, y, p.side + 384 + 4 * g, p.side + 512 + 4 * g, p.eps);
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int64_t t = t0 + 16 * jt + i16;
+    if (t >= p.n_tokens) continue;
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) *(f4*)(p.h + t * 128 + 16 * ft + 4 * g) = x[ft][jt];
+  }
+  // the statement's last hand-offs requested stages past this FFN (the stream has slack for that): they land before the LDS goes
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ================================================================================================
 // host side
 // ================================================================================================
 struct H3Ws {
@@ -3068,6 +3158,34 @@ int flow_pass_h3(const FlowArgs& a) {
   if (cur[ov] != caller[ov])
     TW_HIP_CHECK(hipMemcpyAsync(caller[ov], cur[ov], (size_t)a.n_rows * a.n_atoms * 3 * sizeof(float), hipMemcpyDeviceToDevice,
                                 a.stream));
+  return TW_OK;
+}
+
+// TW_PATH_SIMPLE_H3: can the FFN run through the split-fp16 stream (what tw_flow_pack_h3 packs: d_model 128, chunks of 32)?
+bool h3_ffn_tokens_supported(const tw_flow_desc& d) { return h3_supported(d, 22); }
+
+int h3_ffn_tokens(const tw_flow_desc& d, const void* packed, int coupling, int net, int layer, float* h, int64_t n_tokens,
+                  hipStream_t stream) {
+  TW_REQUIRE(packed && h3_ffn_tokens_supported(d), "FFN on the split-fp16 stream: unsupported model or no stream");
+  const H3Geom g = h3_geom(d);
+  const int64_t att_stages = d.variant == 1 ? 4LL * g.H : 8LL * g.H;
+  const int64_t first = (int64_t)(g.in_a_stages + 2) * g.hid_chunks + (int64_t)layer * (att_stages + 4LL * g.ff_chunks) + att_stages;
+  const char* net_base = (const char*)packed + (int64_t)(coupling * 2 + net) * g.net_stride_bytes;
+  H3FfnParams p;
+  p.stages = net_base + first * H3_STAGE_BYTES;
+  p.side = (const float*)(net_base + g.stages * H3_STAGE_BYTES) + g.side_layers + (int64_t)layer * g.side_layer_size;
+  p.h = h;
+  p.n_tokens = n_tokens;
+  p.ff_chunks = g.ff_chunks;
+  p.eps = d.ln_eps;
+  constexpr int lds = H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS;
+  static LdsLimit lim;
+  int rc;
+  if ((rc = lim.ensure((const void*)h3_ffn_tokens_kernel, lds))) return rc;
+  const int64_t wgs = (n_tokens + 4 * 16 * H3_NT - 1) / (4 * 16 * H3_NT);
+  TW_REQUIRE(wgs < (int64_t)1 << 31, "FFN: %lld workgroups", (long long)wgs);
+  hipLaunchKernelGGL(h3_ffn_tokens_kernel, dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  TW_LAUNCH_CHECK();
   return TW_OK;
 }
 

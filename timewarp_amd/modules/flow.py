@@ -221,6 +221,18 @@ class ConditionalFlowDensityModel(ConditionalDensityModel):
                                                    _lib.stream_ptr(device)), "tw_flow_pack_h1")
                 w["h1"] = buf
             return w["raw"], w["h1"]
+        if path == _lib.TW_PATH_SIMPLE_H3:
+            # the per-op path's own pack: the split-fp16 stream (fused FFN launches) + the folded attention projections
+            if "s5" not in w:
+                n = lib.tw_flow_packed_simple_h3_bytes(C.byref(desc))
+                w["s5"] = None
+                if n > 0:
+                    buf = torch.empty(n, dtype=torch.uint8, device=device)
+                    with torch.cuda.device(device):
+                        _lib.check(lib.tw_flow_pack_simple_h3(C.byref(desc), w["raw"].data_ptr(), buf.data_ptr(),
+                                                              _lib.stream_ptr(device)), "tw_flow_pack_simple_h3")
+                    w["s5"] = buf
+            return w["raw"], w["s5"]     # (None: no split-fp16 stream for this width - every linear as its own GEMM)
         if path == _lib.TW_PATH_FUSED_H3:
             if w["h3"] is None:
                 n = lib.tw_flow_packed_h3_bytes(C.byref(desc))
