@@ -209,13 +209,14 @@ def test_full_kernel_v60_golden(path):
 
 
 def test_preferred_split_fp16_path_falls_back_per_call(monkeypatch):
-    """TW_EXECUTION_PATH=h3: the split-fp16 kernel where it applies (22 atoms), the fp32 kernels elsewhere (60 atoms)."""
+    """TW_EXECUTION_PATH=h3: the split-fp16 fused kernels where a layout exists; above them (r06) the per-op path with split-fp16
+    linears (TW_PATH_SIMPLE_H3 = 5) instead of the exact-f32 per-op kernels."""
     from timewarp_amd.modules import flow
 
     monkeypatch.setenv("TW_EXECUTION_PATH", "h3")
     m = H.tw_kernel_model(H.full_kernel_sd(), path=None)
     assert m.execution_path == flow.PREFER_SPLIT_FP16
-    assert m._path_for(22) == H3 and m._path_for(30) == H3 and m._path_for(60) == H3 and m._path_for(161) == H3 and m._path_for(193) == 0
+    assert m._path_for(22) == H3 and m._path_for(30) == H3 and m._path_for(60) == H3 and m._path_for(161) == H3 and m._path_for(193) == 5
     d, _ = H.load("kernel_full_ad")
     H.assert_case_close(H.run_model_case(m, d), d, tol=TOL)
     assert m._dev_weights["h3"] is not None and m._dev_weights["f32"] is None  # the 22-atom calls ran on the h3 stream
@@ -224,7 +225,7 @@ def test_preferred_split_fp16_path_falls_back_per_call(monkeypatch):
     assert m._dev_weights["f32"] is None  # 60 atoms run on the split-fp16 kernel too (wide layout)
     dense = H.tw_dense_model(H.full_dense_sd(), path=None)
     # the dense flow has split-fp16 kernels of its own: 48-token waves, and (r05) 64-token waves for 49-64 atoms
-    assert dense._path_for(22) == H3 and dense._path_for(60) == H3 and dense._path_for(64) == H3 and dense._path_for(65) == 0
+    assert dense._path_for(22) == H3 and dense._path_for(60) == H3 and dense._path_for(64) == H3 and dense._path_for(65) == 5
 
 
 @pytest.mark.parametrize("path", [SIMPLE, FUSED, 0, H3])

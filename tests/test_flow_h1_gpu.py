@@ -141,7 +141,7 @@ def test_path_selection_by_name(monkeypatch):
     monkeypatch.setenv("TW_EXECUTION_PATH", "h1")
     m = tw.model_constructor(cfg)
     assert m.execution_path == flow.PREFER_SINGLE_FP16
-    assert [m._path_for(v) for v in (1, 22, 48, 49, 60, 80, 90, 160, 192, 193)] == [H1] * 9 + [0]   # (90: since the 96-slot stride; 161 .. 192: six-group windows)
+    assert [m._path_for(v) for v in (1, 22, 48, 49, 60, 80, 90, 160, 192, 193)] == [H1] * 9 + [5]   # (90: since the 96-slot stride; 161 .. 192: six-group windows; above: the per-op path with split-fp16 GEMMs)
     desc = m.dims.to_desc()
     lib = _lib.load()
     assert lib.tw_flow_path_supported(C.byref(desc), 22, H1) == 1 and lib.tw_flow_path_supported(C.byref(desc), 60, H1) == 1

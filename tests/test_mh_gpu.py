@@ -857,7 +857,8 @@ def test_mh_iterations_on_the_691_atom_protein_vs_oracle():
     """The reference's SECOND test molecule end to end (testdata/output/1hgv-traj-state0.pdb: a 46-residue, 691-atom protein;
     topology and a frame of coordinates from the committed known-answer fixture, the pinned amber99sb-ildn + OBC tables): whole
     MH iterations with the full-size kernel_transformer_nvp flow.  No fused layout holds 691 atoms, so the flow runs on the per-op
-    path - which refused anything above ~200 atoms until r05 (row-wise scores, tiled f32-MFMA mixing) - inside tw_mh_iteration,
+    path - which refused anything above ~200 atoms until r05 (row-wise scores, tiled MFMA mixing; r06: its split-fp16 form,
+    TW_PATH_SIMPLE_H3, is what the model takes by default) - inside tw_mh_iteration,
     with the AMBER energy kernel on all 691 atoms, against the oracle loop and the C energy oracle on shared host noise."""
     from timewarp_amd.dataloader import elements_from_atom_names, single_state_batch
     from timewarp_amd.energy import AmberPotentialEnergyTorch
@@ -882,8 +883,8 @@ def test_mh_iterations_on_the_691_atom_protein_vs_oracle():
     ref = mo.sample_with_model(types[None], coords[None], torch.zeros(1, V, 3), torch.zeros(1, V, dtype=torch.bool),
                                mo.OracleModel(sd, H.FULL_KERNEL_SPEC), H.OracleAmberEnergy(tables), masses, N, H.HostNoise(5), **kw)
     dev = torch.device("cuda")
-    model = H.tw_kernel_model(sd, path=None)     # the constructor's default: split-fp16 where a layout exists, else the f32 kernels
-    assert model._path_for(V) == 0               # TW_PATH_AUTO -> the per-op path at this size
+    model = H.tw_kernel_model(sd, path=None)     # the constructor's default: split-fp16 fused kernels where a layout exists, else ...
+    assert model._path_for(V) == 5               # ... (r06) TW_PATH_SIMPLE_H3: the per-op path with split-fp16 linears / mixing / fused FFN
     chain = MetropolisHastingsChain(single_state_batch("1hgv", types, coords), model, dev, energy, masses, noise=H.HostNoise(5, "cuda"), **kw)
     assert chain._fused                          # the whole iteration as one C-ABI call
     got = sample_with_model(single_state_batch("1hgv", types, coords), model, dev, energy, masses, N, disable_tqdm=True,
