@@ -806,6 +806,23 @@ def test_per_op_path_large_molecules(path):
         finally:
             lib.tw_debug_set_flags(0)
         assert H.rel_err(out2.cpu(), ref) < TOL
+        # the dense softmax variant above its fused layouts (65+ atoms): q / k / v and output projections, in / out MLPs on the
+        # split-fp16 GEMMs, the FFN through the fused launches, the softmax attention itself in fp32
+        dsd = H.full_dense_sd()
+        md5 = H.tw_dense_model(dsd, path=5)
+        gg = torch.Generator().manual_seed(5)
+        V = 256
+        at = torch.randint(0, 5, (2, V), generator=gg)
+        xx = torch.randn(2, V, 3, generator=gg)
+        yy = xx + torch.randn(2, V, 3, generator=gg) * 0.02
+        vv = torch.randn(2, V, 3, generator=gg) * 0.5
+        mk = torch.zeros(2, V, dtype=torch.bool)
+        mk[1, V - 7:] = True
+        outd = md5.log_likelihood(atom_types=at.cuda(), x_coords=xx.cuda(), x_velocs=vv.cuda(), y_coords=yy.cuda(), y_velocs=vv.cuda(),
+                                  adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda()).cpu()
+        refd = fo.log_likelihood(dsd, H.FULL_DENSE_SPEC, at, xx, vv, yy, vv, mk)
+        assert H.rel_err(outd, refd) < TOL, H.rel_err(outd, refd)
+        H.assert_not_demoted(md5)
     if path != 0:
         return
     # the two scores kernels on the same 150 atoms (bit 21 forces the row-wise one), both cdist branches, Gaussian and Chebyshev:

@@ -929,6 +929,138 @@ __global__ void __launch_bounds__(256) attend_h3_kernel(const float* __restrict_
   }
 }
 
+// The folded form's operands prepared ONCE instead of per workgroup (attend_h3_kernel splits the score tile again for every row n
+// that shares it and transposes the values on their way into the LDS):
+//   split_scores_kernel   scores [R, V] fp32 -> (hi, lo) fp16 [R, Vp], x 2^10, rows padded with zeros to Vp = 32 ceil(V / 32) keys -
+//                         once per flow pass (the scores are shared by every encoder layer and both nets)
+//   xt_split_kernel       x [n, V, D] fp32 -> x^T (hi, lo) fp16 [n, D, Vp] - once per (layer, net)
+//   attend_h3p_kernel     att[n, q, h, :] = sum_m S_h[q, m] x[n, m, :]: both operands arrive as 16-byte fp16 vectors, k contiguous -
+//                         no VALU work between the loads and the MFMAs
+__global__ void split_scores_kernel(const float* __restrict__ s, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t rows,
+                                    int V, int Vp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * Vp) return;
+  const int64_t r = i / Vp;
+  const int k = (int)(i - r * Vp);
+  const float v = k < V ? s[r * V + k] * AH_SSCALE : 0.f;
+  const _Float16 h = (_Float16)v;
+  hi[i] = h;
+  lo[i] = (_Float16)(v - (float)h);
+}
+
+__global__ void __launch_bounds__(256) xt_split_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                        int V, int Vp, int D) {
+  // block (row n, key tile of 32, feature tile of 32): a 32 x 32 transpose through the LDS
+  __shared__ float t[32][33];
+  const int64_t n = blockIdx.x;
+  const int m0 = blockIdx.y * 32, d0 = blockIdx.z * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per sweep
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) t[r][tx] = (m0 + r < V && d0 + tx < D) ? x[(n * V + m0 + r) * D + d0 + tx] : 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    if (d0 + r >= D) continue;
+    const float v = t[tx][r];   // key m0 + tx of feature d0 + r
+    const _Float16 h = (_Float16)v;
+    const int64_t o = (n * D + d0 + r) * Vp + m0 + tx;
+    hi[o] = h;
+    lo[o] = (_Float16)(v - (float)h);
+  }
+}
+
+__global__ void __launch_bounds__(256) attend_h3p_kernel(const _Float16* __restrict__ s_hi, const _Float16* __restrict__ s_lo,
+                                                          const _Float16* __restrict__ xt_hi, const _Float16* __restrict__ xt_lo,
+                                                          float* __restrict__ att, int64_t n_cond, int H, int V, int Vp, int D) {
+  extern __shared__ __attribute__((aligned(16))) char lh_lds[];
+  _Float16 (*tile)[2][2][LH_BM][LH_ROW] = (_Float16 (*)[2][2][LH_BM][LH_ROW])lh_lds;   // [buffer][S | x^T][hi | lo][row][k]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_m = (V + LH_BM - 1) / LH_BM;
+  int64_t blk = blockIdx.x;
+  const int tm = (int)(blk % tiles_m); blk /= tiles_m;
+  const int h = (int)(blk % H);
+  const int64_t n = blk / H;
+  const int64_t c = n % n_cond;
+  const int q0 = tm * LH_BM;
+  const _Float16* Sh = s_hi + ((c * H + h) * V) * (int64_t)Vp;
+  const _Float16* Sl = s_lo + ((c * H + h) * V) * (int64_t)Vp;
+  const _Float16* Xh = xt_hi + n * D * (int64_t)Vp;
+  const _Float16* Xl = xt_lo + n * D * (int64_t)Vp;
+  lin_f4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
+  // a k-step: four 128-row x 32-k fp16 tiles = 4 x 512 sixteen-byte pieces, 8 per thread (t = 0, 1: S hi; 2, 3: S lo; 4, 5: x^T hi; 6, 7: lo)
+  lin_h8 nx[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = threadIdx.x + 256 * (t & 1), r = i >> 2, kq = 8 * (i & 3);
+      lin_h8 v = (lin_h8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (t < 4) {
+        if (q0 + r < V) v = *(const lin_h8*)((t < 2 ? Sh : Sl) + (int64_t)(q0 + r) * Vp + k0 + kq);
+      } else if (r < D) {
+        v = *(const lin_h8*)((t < 6 ? Xh : Xl) + (int64_t)r * Vp + k0 + kq);
+      }
+      nx[t] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = threadIdx.x + 256 * (t & 1), r = i >> 2, kq = 8 * (i & 3);
+      *(lin_h8*)&tile[buf][t >> 2][(t >> 1) & 1][r][kq] = nx[t];
+    }
+  };
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < Vp; k0 += 32) {
+    const bool more = k0 + 32 < Vp;
+    if (more) fetch(k0 + 32);
+    lin_h8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 64 * wm + 16 * i + i16;
+      ah[i] = *(const lin_h8*)&tile[buf][0][0][r][8 * g];
+      al[i] = *(const lin_h8*)&tile[buf][0][1][r][8 * g];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 64 * wn + 16 * j + i16;
+      bh[j] = *(const lin_h8*)&tile[buf][1][0][r][8 * g];
+      bl[j] = *(const lin_h8*)&tile[buf][1][1][r][8 * g];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    if (more) stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int dd = 64 * wn + 16 * j + i16;
+    if (dd >= D) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = q0 + 64 * wm + 16 * i + 4 * g + r;
+        if (q < V) att[((n * V + q) * H + h) * (int64_t)D + dd] = acc[i][j][r] * (1.0f / AH_SSCALE);
+      }
+  }
+}
+
 // The same product for large molecules (r05: the V x V tile of attend_kernel stops at ~200 atoms): per (row n, head h) the GEMM
 //   att[q, d] = sum_m scores[q, m] * vals[m, d]      M = K = V, N = D
 // tiled like linear_kernel - 128 x 64 output tile per workgroup, k in steps of 16 through the LDS, v_mfma_f32_16x16x4_f32 (exact
@@ -1121,6 +1253,7 @@ __global__ void add_ln_kernel(float* __restrict__ h, const float* __restrict__ d
 
 struct SimpleWs {
   float *u, *h0, *h, *vals, *att, *ff, *tmp, *s_out, *t_out, *scores;
+  _Float16 *s_hi, *s_lo, *xt_hi, *xt_lo;   // TW_PATH_SIMPLE_H3, folded attention: pre-split scores / transposed layer input
   int64_t bytes;
 };
 
@@ -1145,6 +1278,14 @@ static SimpleWs simple_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* ba
   w.s_out = take(M * 3);
   w.t_out = take(M * 3);
   w.scores = take(n_rows * (int64_t)d.n_heads * V * V);
+  w.s_hi = w.s_lo = w.xt_hi = w.xt_lo = nullptr;
+  if (d.variant == 0 && d.d_model == 128) {   // (sized whatever path the call takes: one workspace serves them all)
+    const int64_t Vp = (V + 31) / 32 * 32;
+    w.s_hi = (_Float16*)take((n_rows * (int64_t)d.n_heads * V * Vp + 1) / 2);
+    w.s_lo = (_Float16*)take((n_rows * (int64_t)d.n_heads * V * Vp + 1) / 2);
+    w.xt_hi = (_Float16*)take((n_rows * (int64_t)d.d_model * Vp + 1) / 2);
+    w.xt_lo = (_Float16*)take((n_rows * (int64_t)d.d_model * Vp + 1) / 2);
+  }
   w.bytes = p - (char*)base;
   return w;
 }
@@ -1191,7 +1332,20 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
                 (((int64_t)c * 2 + net) * d.n_layers + l) * (int64_t)d.d_model * HD
           : nullptr;
       if (!wc && (rc = launch_linear(w.h, lb + L.layer.wv, nullptr, w.vals, M, HD, d.d_model, ACT_NONE, s, sp))) return rc;
-      if (sp && V > 64) {
+      if (wc && w.s_hi && d.d_model == LH_BN && d.cheb_order == 0) {
+        // folded form, operands prepared once: x^T of this layer's input here, the scores' split in simple_scores()
+        const int Vp = (V + 31) / 32 * 32;
+        hipLaunchKernelGGL(xt_split_kernel, dim3((unsigned)a.n_rows, (unsigned)(Vp / 32), (unsigned)((d.d_model + 31) / 32)), dim3(256), 0,
+                           s, w.h, w.xt_hi, w.xt_lo, V, Vp, d.d_model);
+        TW_LAUNCH_CHECK();
+        const int64_t blocks = a.n_rows * d.n_heads * ((V + LH_BM - 1) / LH_BM);
+        TW_REQUIRE(blocks < (int64_t)1 << 31, "attend: %lld workgroups", (long long)blocks);
+        constexpr int lds = 2 * 2 * 2 * LH_BM * LH_ROW * (int)sizeof(_Float16);
+        static LdsLimit limp;
+        if ((rc = limp.ensure((const void*)attend_h3p_kernel, lds))) return rc;
+        hipLaunchKernelGGL(attend_h3p_kernel, dim3((unsigned)blocks), dim3(256), lds, s, w.s_hi, w.s_lo, w.xt_hi, w.xt_lo, w.att,
+                           a.n_cond, d.n_heads, V, Vp, d.d_model);
+      } else if (sp && V > 64) {
         // TW_PATH_SIMPLE_H3: the mixing on split-fp16 MFMAs as well (128 x 128 tiles: worth it from ~64 keys on)
         const int64_t blocks = a.n_rows * d.n_heads * ((V + LH_BM - 1) / LH_BM) * ((d.d_model + LH_BN - 1) / LH_BN);
         TW_REQUIRE(blocks < (int64_t)1 << 31, "attend: %lld workgroups", (long long)blocks);
@@ -1271,8 +1425,18 @@ static int simple_scores(const FlowArgs& a, const RawLayout& L, const SimpleWs& 
   const tw_flow_desc& d = *a.desc;
   if (d.variant != 0 || d.cheb_order > 0) return TW_OK;  // chebyshev_kernel: per layer, in netblock_simple
   // one score matrix per flow call, shared by every encoder layer (model_constructor.py:192-195)
-  return launch_scores(a.x_coords, a.masked, a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, a.n_cond, a.n_atoms, d.normalise,
-                       a.n_atoms > 25, w.scores, a.stream);
+  int rc = launch_scores(a.x_coords, a.masked, a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, a.n_cond, a.n_atoms, d.normalise,
+                         a.n_atoms > 25, w.scores, a.stream);
+  if (rc) return rc;
+  if (a.simple_h3 && a.packed && w.s_hi && a.n_atoms > 64 && h3_ffn_tokens_supported(d) && !(g_debug_flags & 16777216)) {
+    // the folded mixing's A operand (attend_h3p_kernel): split once per flow pass, shared by every layer and both nets
+    const int V = a.n_atoms, Vp = (V + 31) / 32 * 32;
+    const int64_t rows = a.n_cond * d.n_heads * V, total = rows * Vp;
+    hipLaunchKernelGGL(split_scores_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a.stream, w.scores, w.s_hi, w.s_lo,
+                       rows, V, Vp);
+    TW_LAUNCH_CHECK();
+  }
+  return TW_OK;
 }
 
 int flow_pass_simple(const FlowArgs& a) {
