@@ -208,9 +208,9 @@ def test_hip_kernels_on_the_whole_protein_against_openmm():
 
 @pytest.mark.gpu
 def test_hip_kernels_on_segments_of_the_protein():
-    """The HIP energy / force kernels hold one conformation per wave in LDS (molecules up to ~240 atoms), so the 691-atom file
-    cannot run through them whole.  Their arithmetic is pinned on the peptide files; what the protein adds is parameter
-    TABLES of sixteen more residue types.  This test runs the kernels on those tables: five overlapping segments of the chain
+    """The HIP energy / force kernels run the whole 691-atom protein too (the test above; one bit per ordered pair of the exclusion
+    matrix in LDS since r05).  This test adds what that one cannot localise: the parameter TABLES of the sixteen residue types the
+    peptide files do not hold, segment by segment - five overlapping segments of the chain
     (cut at peptide bonds, 10 residues each, every residue type in at least one), energies and analytic forces against the C
     oracle on the same tables and coordinates."""
     from timewarp_amd.energy import AmberPotentialEnergyTorch
