@@ -102,8 +102,8 @@ int64_t tw_flow_packed_h3_bytes(const tw_flow_desc* desc);
 int tw_flow_pack_h3(const tw_flow_desc* desc, const float* raw, void* packed_h3, void* stream);
 /* ABI 8 - the pack of TW_PATH_SIMPLE_H3 (0 bytes where the model has no split-fp16 stream: that path then takes packed = NULL):
  * the tw_flow_pack_h3 stream (its FFN stages feed the path's fused FFN launches), then - kernel attention - the per-head folded
- * value / output projections Wc[coupling][net][layer][d_model][n_heads d_model] (fp32, folded in fp64), which let the mixing run
- * on the layer input with ONE GEMM behind it. */
+ * value / output projections Wc[coupling][net][layer][d_model][n_heads d_model] (fp32, folded in fp64) and their split-fp16 copies
+ * per head in MFMA-operand order, which let the mixing run on the layer input with the ONE remaining GEMM inside the same launch. */
 int64_t tw_flow_packed_simple_h3_bytes(const tw_flow_desc* desc);
 int tw_flow_pack_simple_h3(const tw_flow_desc* desc, const float* raw, void* packed, void* stream);
 /* The same for TW_PATH_FUSED_H1 (fp16 hi tiles only: 8 tiles per 9 KiB stage, half as many stages). */
@@ -447,8 +447,12 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *              atoms take) at every size; same scores bit for bit, the mixing in another summation order (A/B switch and tests)
  *   bit 22 (4194304) / bit 23 (8388608)  tw_mh_iteration: the energy kernel on the caller's stream / on the side stream,
  *              whatever the launch size (default: side stream only while the flow's launches leave compute units idle)
- *   bit 24 (16777216) TW_PATH_SIMPLE_H3: the FFN as two linear launches + add_ln even when the split-fp16 stream is at hand
- *              (default then: one launch of the fused kernels' chunk loop on the flat token list); A/B switch and tests */
+ *   bit 24 (16777216) TW_PATH_SIMPLE_H3: the FFN as two linear launches + add_ln, the attention unfolded, even when the path's pack
+ *              is at hand (default then: one launch of the fused kernels' chunk loop on the flat token list; folded attention);
+ *              A/B switch and tests
+ *   bit 25 (33554432) TW_PATH_SIMPLE_H3, folded attention: the 768 -> 128 GEMM as its own launch behind the mixing kernel instead
+ *              of inside it (attend_fold_h3_kernel); bit 26 (67108864): inside it whatever the launch size (default: from 200
+ *              workgroups on); A/B switches and tests */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

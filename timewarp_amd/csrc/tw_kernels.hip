@@ -705,7 +705,7 @@ __global__ void __launch_bounds__(256) linear_h3_kernel(const float* __restrict_
 // projections of kernel attention folded per head (kernel_attention.py:124-156: out_proj(flatten(A_h (x W_v,h^T)))) = sum_h (A_h x) Wc_h^T
 __global__ void fold_vo_kernel(const float* __restrict__ raw, int64_t first_net, int64_t coupling_size, int64_t net_size,
                                int64_t layers_off, int64_t layer_size, int64_t wv_off, int64_t wo_off, int n_layers, int H, int D,
-                               float* __restrict__ out) {
+                               float* __restrict__ out, _Float16* __restrict__ wcp_hi, _Float16* __restrict__ wcp_lo) {
   // blockIdx.x = ((c * 2 + net) * n_layers + l) * H + h;  one thread per (n, k) of the head's D x D block
   int64_t b = blockIdx.x;
   const int h = (int)(b % H); b /= H;
@@ -716,24 +716,39 @@ __global__ void fold_vo_kernel(const float* __restrict__ raw, int64_t first_net,
   const float* wv = lb + wv_off;   // [H D, D]
   const float* wo = lb + wo_off;   // [D, H D]
   float* o = out + (((c * 2 + net) * n_layers + l) * (int64_t)D) * H * D;   // [D, H D]
+  // ... and, for attend_fold_h3_kernel, as split fp16 (x 2^8) per head [H][D][D] with the k index in MFMA-operand order: position
+  // 32 ks + 8 g + e holds feature 32 ks + 16 (e / 4) + 4 g + e % 4 - the order in which a lane's accumulator registers of the mixing
+  // (feature tiles 2 ks, 2 ks + 1, rows 4 g + r) become its B operand, so the matching A operand is one 16-byte read
+  _Float16* ph = wcp_hi ? wcp_hi + ((((c * 2 + net) * n_layers + l) * (int64_t)H + h) * D) * D : nullptr;
+  _Float16* pl = wcp_lo ? wcp_lo + ((((c * 2 + net) * n_layers + l) * (int64_t)H + h) * D) * D : nullptr;
   for (int i = threadIdx.x; i < D * D; i += blockDim.x) {
     const int n = i / D, k = i % D;
     double acc = 0.0;
     for (int j = 0; j < D; ++j) acc += (double)wo[(int64_t)n * H * D + h * D + j] * (double)wv[(int64_t)(h * D + j) * D + k];
     o[(int64_t)n * H * D + h * D + k] = (float)acc;
+    if (ph) {
+      const int ks = k / 32, w = k % 32, half = w / 16, g = (w % 16) / 4, r = w % 4;
+      const int pos = 32 * ks + 8 * g + 4 * half + r;
+      const float v = (float)acc * LH_WSCALE;
+      const _Float16 hh = (_Float16)v;
+      ph[(int64_t)n * D + pos] = hh;
+      pl[(int64_t)n * D + pos] = (_Float16)(v - (float)hh);
+    }
   }
 }
 
-int64_t simple_h3_fold_floats(const tw_flow_desc& d) {
-  return d.variant == 0 ? (int64_t)d.n_coupling * 2 * d.n_layers * d.d_model * d.n_heads * d.d_model : 0;
-}
+// floats behind the split-fp16 stream in the tw_flow_pack_simple_h3 buffer: Wc fp32 [c][net][l][D][H D], then its split, permuted
+// fp16 copies (hi, lo: half as many floats each)
+static int64_t fold_wc_floats(const tw_flow_desc& d) { return (int64_t)d.n_coupling * 2 * d.n_layers * d.d_model * d.n_heads * d.d_model; }
+int64_t simple_h3_fold_floats(const tw_flow_desc& d) { return d.variant == 0 ? 2 * fold_wc_floats(d) : 0; }
 
 int simple_h3_fold(const tw_flow_desc& d, const float* raw, float* out, hipStream_t s) {
   if (d.variant != 0) return TW_OK;
   const RawLayout L = raw_layout(d);
   const int64_t blocks = (int64_t)d.n_coupling * 2 * d.n_layers * d.n_heads;
+  _Float16* hi = (_Float16*)(out + fold_wc_floats(d));
   hipLaunchKernelGGL(fold_vo_kernel, dim3((unsigned)blocks), dim3(256), 0, s, raw, L.chain + L.nets, L.coupling_size, L.net.size,
-                     L.net.layers, L.layer.size, L.layer.wv, L.layer.wo, d.n_layers, d.n_heads, d.d_model, out);
+                     L.net.layers, L.layer.size, L.layer.wv, L.layer.wo, d.n_layers, d.n_heads, d.d_model, out, hi, hi + fold_wc_floats(d));
   TW_LAUNCH_CHECK();
   return TW_OK;
 }
@@ -1061,6 +1076,150 @@ __global__ void __launch_bounds__(256) attend_h3p_kernel(const _Float16* __restr
   }
 }
 
+// Mixing AND the folded projection in one launch (r06): per (row n, 128 queries), for every head
+//   xm_h^T[d][q] = sum_m x^T[d][m] S_h[q][m]          (A = x^T rows, B = score rows: the transposed formulation of the fused kernels)
+//   y^T[c][q]   += sum_d Wc_h[c][d] xm_h[q][d]        (A = Wc_h rows; B = xm_h straight from the accumulators: lane (q, g) holds
+//                                                     features 16 t + 4 g + r of feature tile t, i.e. after the fp16 split the B operand
+//                                                     of k-step ks = tiles 2 ks, 2 ks + 1 in the element order the pack gave Wc)
+// so the [M, 768] mixing result never exists in memory (attend_h3p_kernel + the 768 -> 128 GEMM wrote and read 300 MB per call at
+// 192 x 256).  A wave owns 32 queries x all 128 features; every operand tile arrives by LDS-DMA (global_load_lds, 1 KiB per
+// instruction, unpadded [row][32 k] tiles: a fragment read of lanes (i16, g) covers one contiguous KiB) into two 32 KiB slots:
+// step s + 1 is in flight while step s computes, one vmcnt(0) + barrier per step.
+__global__ void __launch_bounds__(256) attend_fold_h3_kernel(const _Float16* __restrict__ s_hi, const _Float16* __restrict__ s_lo,
+                                                              const _Float16* __restrict__ xt_hi, const _Float16* __restrict__ xt_lo,
+                                                              const _Float16* __restrict__ wc_hi, const _Float16* __restrict__ wc_lo,
+                                                              float* __restrict__ y, int64_t n_cond, int H, int V, int Vp) {
+  extern __shared__ __attribute__((aligned(16))) char lh_lds[];   // 2 slots x [4 arrays][128 rows][32 halves]
+  constexpr int D = 128, SLOT = 4 * 128 * 64, ARR = 128 * 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i16 = lane & 15, g = lane >> 4;
+  const int tiles_m = (V + 127) / 128;
+  const int tm = (int)(blockIdx.x % tiles_m);
+  const int64_t n = blockIdx.x / tiles_m;
+  const int64_t c = n % n_cond;
+  const int q0 = tm * 128;
+  const int n1 = Vp / 32;
+  const int lrow = lane >> 2, lk = 8 * (lane & 3);
+  const _Float16* Xw = (wave == 2 ? xt_hi : xt_lo) + n * D * (int64_t)Vp;   // waves 2, 3 move x^T hi / lo
+  // issue the tiles of (head h, step st) into `slot`: st < n1: key step st of the mixing (wave 0: S hi, 1: S lo, 2: x^T hi, 3: x^T lo,
+  // eight 1 KiB pieces each); st >= n1: k-step st - n1 of the folded GEMM (waves 0, 1: Wc hi, 2, 3: Wc lo, four pieces each)
+  auto issue = [&](int h, int st, int slot) {
+    char* base = lh_lds + slot * SLOT;
+    if (st < n1) {
+      const int k0 = 32 * st;
+      char* dst = base + wave * ARR;
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        const _Float16* src;
+        if (wave < 2) {
+          int row = q0 + 16 * ch + lrow;
+          row = row < V ? row : V - 1;   // rows past the molecule: any finite row (their results are dropped)
+          src = (wave == 0 ? s_hi : s_lo) + (((c * H + h) * V) + row) * (int64_t)Vp + k0 + lk;
+        } else {
+          src = Xw + (int64_t)(16 * ch + lrow) * Vp + k0 + lk;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + ch * 1024), 16, 0, 0);
+      }
+    } else {
+      const int ks = st - n1;
+      const _Float16* W = (wave < 2 ? wc_hi : wc_lo) + (int64_t)h * D * D;
+      char* dst = base + (wave < 2 ? 0 : ARR) + (wave & 1) * 4096;
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        const _Float16* src = W + (int64_t)(64 * (wave & 1) + 16 * ch + lrow) * D + 32 * ks + lk;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + ch * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto landed = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (hipcc does not count LDS-DMA)
+    __syncthreads();
+  };
+  auto frag = [&](int slot, int arr, int tile) -> lin_h8 {
+    return *(const lin_h8*)(lh_lds + slot * SLOT + arr * ARR + (16 * tile + i16) * 64 + g * 16);
+  };
+  lin_f4 acc_y[8][2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc_y[t][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
+  const int per_head = n1 + 4;
+  const int total = H * per_head;
+  issue(0, 0, 0);
+  landed();
+  int step = 0;
+  for (int h = 0; h < H; ++h) {
+    lin_f4 xm[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xm[t][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st < n1; ++st, ++step) {
+      const int slot = step & 1;
+      if (step + 1 < total) issue(st + 1 < per_head ? h : h + 1, st + 1 < per_head ? st + 1 : 0, slot ^ 1);
+      lin_h8 sh[2], sl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        sh[j] = frag(slot, 0, 2 * wave + j);
+        sl[j] = frag(slot, 1, 2 * wave + j);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const lin_h8 xh = frag(slot, 2, t), xl = frag(slot, 3, t);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          xm[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, sh[j], xm[t][j], 0, 0, 0);
+          xm[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, sl[j], xm[t][j], 0, 0, 0);
+          xm[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, sh[j], xm[t][j], 0, 0, 0);
+        }
+      }
+      landed();
+    }
+    // xm (x 2^10 from the scores' scale) -> split B operands of the four k-steps, in the accumulators' own element order
+    lin_h8 bh[4][2], bl[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = xm[2 * ks + e / 4][j][e % 4] * (1.0f / AH_SSCALE);
+          const _Float16 hh = (_Float16)v;
+          bh[ks][j][e] = hh;
+          bl[ks][j][e] = (_Float16)(v - (float)hh);
+        }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks, ++step) {
+      const int slot = step & 1;
+      const int st = n1 + ks;
+      if (step + 1 < total) issue(st + 1 < per_head ? h : h + 1, st + 1 < per_head ? st + 1 : 0, slot ^ 1);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const lin_h8 wh = frag(slot, 0, t), wl = frag(slot, 1, t);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc_y[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[ks][j], acc_y[t][j], 0, 0, 0);
+          acc_y[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[ks][j], acc_y[t][j], 0, 0, 0);
+          acc_y[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[ks][j], acc_y[t][j], 0, 0, 0);
+        }
+      }
+      landed();
+    }
+  }
+  // y^T tiles: lane (q = i16 of query tile j, g) holds output columns 16 t + 4 g + r
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = q0 + 32 * wave + 16 * j + i16;
+    if (q >= V) continue;
+    float* row = y + (n * V + q) * (int64_t)D;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *(lin_f4*)(row + 16 * t + 4 * g) = acc_y[t][j] * (1.0f / LH_WSCALE);
+  }
+}
+
 // The same product for large molecules (r05: the V x V tile of attend_kernel stops at ~200 atoms): per (row n, head h) the GEMM
 //   att[q, d] = sum_m scores[q, m] * vals[m, d]      M = K = V, N = D
 // tiled like linear_kernel - 128 x 64 output tile per workgroup, k in steps of 16 through the LDS, v_mfma_f32_16x16x4_f32 (exact
@@ -1338,6 +1497,24 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
         hipLaunchKernelGGL(xt_split_kernel, dim3((unsigned)a.n_rows, (unsigned)(Vp / 32), (unsigned)((d.d_model + 31) / 32)), dim3(256), 0,
                            s, w.h, w.xt_hi, w.xt_lo, V, Vp, d.d_model);
         TW_LAUNCH_CHECK();
+        // (one workgroup of the fused form walks all heads of its 128 queries: worth it once there are enough of them to fill the
+        // chip - 691 atoms x 16 rows are 96 workgroups there against 576 of the per-head form: 13.7 against 12.0 ms per pass)
+        if (!(g_debug_flags & 33554432) && (a.n_rows * ((V + 127) / 128) >= 200 || (g_debug_flags & 67108864))) {
+          // ... and the folded 768 -> 128 GEMM inside the mixing launch (bit 25: as its own GEMM behind attend_h3p_kernel; bit 26:
+          // inside it whatever the launch size; A/B, tests)
+          const int64_t wcf = (int64_t)d.n_coupling * 2 * d.n_layers * d.d_model * HD;   // floats of the fp32 copy in front of the fp16 ones
+          const float* fold0 = (const float*)((const char*)a.packed + (h3_packed_bytes(d, false) + 255) / 256 * 256);
+          const _Float16* wch = (const _Float16*)(fold0 + wcf) + (((int64_t)c * 2 + net) * d.n_layers + l) * (int64_t)d.d_model * HD;
+          const int64_t blocks = a.n_rows * ((V + 127) / 128);
+          TW_REQUIRE(blocks < (int64_t)1 << 31, "attend: %lld workgroups", (long long)blocks);
+          constexpr int ldsf = 2 * 4 * 128 * 64;
+          static LdsLimit limf;
+          if ((rc = limf.ensure((const void*)attend_fold_h3_kernel, ldsf))) return rc;
+          hipLaunchKernelGGL(attend_fold_h3_kernel, dim3((unsigned)blocks), dim3(256), ldsf, s, w.s_hi, w.s_lo, w.xt_hi, w.xt_lo, wch,
+                             wch + wcf, w.tmp, a.n_cond, d.n_heads, V, Vp);
+          TW_LAUNCH_CHECK();
+          goto attention_done;
+        }
         const int64_t blocks = a.n_rows * d.n_heads * ((V + LH_BM - 1) / LH_BM);
         TW_REQUIRE(blocks < (int64_t)1 << 31, "attend: %lld workgroups", (long long)blocks);
         constexpr int lds = 2 * 2 * 2 * LH_BM * LH_ROW * (int)sizeof(_Float16);
@@ -1367,6 +1544,7 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
       }
       TW_LAUNCH_CHECK();
       if ((rc = launch_linear(w.att, wc ? wc : lb + L.layer.wo, nullptr, w.tmp, M, d.d_model, HD, ACT_NONE, s, sp))) return rc;
+    attention_done:;
     } else {
       if ((rc = launch_linear(w.h, lb + L.layer.in_w, lb + L.layer.in_b, w.vals, M, 3 * d.d_model, d.d_model, ACT_NONE, s, sp))) return rc;
       const int dh = d.d_model / d.n_heads;
