@@ -452,7 +452,8 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *              A/B switch and tests
  *   bit 25 (33554432) TW_PATH_SIMPLE_H3, folded attention: the 768 -> 128 GEMM as its own launch behind the mixing kernel instead
  *              of inside it (attend_fold_h3_kernel); bit 26 (67108864): inside it whatever the launch size (default: from 200
- *              workgroups on); A/B switches and tests */
+ *              workgroups on); bit 27 (134217728): residual + LayerNorm 1 as the add_ln launch behind that kernel instead of
+ *              in its epilogue; A/B switches and tests */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every

@@ -813,6 +813,13 @@ def test_per_op_path_large_molecules(path):
         finally:
             lib.tw_debug_set_flags(0)
         assert H.rel_err(out3.cpu(), ref) < TOL
+        try:   # ... and with residual + LayerNorm 1 as the add_ln launch behind it (bit 27) instead of in its epilogue
+            lib.tw_debug_set_flags(67108864 | 134217728)
+            out4 = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                                    y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+        finally:
+            lib.tw_debug_set_flags(0)
+        assert H.rel_err(out4.cpu(), ref) < TOL
         # the dense softmax variant above its fused layouts (65+ atoms): q / k / v and output projections, in / out MLPs on the
         # split-fp16 GEMMs, the FFN through the fused launches, the softmax attention itself in fp32
         dsd = H.full_dense_sd()

@@ -1088,7 +1088,9 @@ __global__ void __launch_bounds__(256) attend_h3p_kernel(const _Float16* __restr
 __global__ void __launch_bounds__(256) attend_fold_h3_kernel(const _Float16* __restrict__ s_hi, const _Float16* __restrict__ s_lo,
                                                               const _Float16* __restrict__ xt_hi, const _Float16* __restrict__ xt_lo,
                                                               const _Float16* __restrict__ wc_hi, const _Float16* __restrict__ wc_lo,
-                                                              float* __restrict__ y, int64_t n_cond, int H, int V, int Vp) {
+                                                              float* __restrict__ y, int64_t n_cond, int H, int V, int Vp,
+                                                              float* __restrict__ hres, const float* __restrict__ lnw,
+                                                              const float* __restrict__ lnb, float eps) {
   extern __shared__ __attribute__((aligned(16))) char lh_lds[];   // 2 slots x [4 arrays][128 rows][32 halves]
   constexpr int D = 128, SLOT = 4 * 128 * 64, ARR = 128 * 64;
   const int lane = threadIdx.x & 63;
@@ -1210,6 +1212,45 @@ __global__ void __launch_bounds__(256) attend_fold_h3_kernel(const _Float16* __r
     }
   }
   // y^T tiles: lane (q = i16 of query tile j, g) holds output columns 16 t + 4 g + r
+  if (hres) {
+    // residual + LayerNorm 1 here as well (custom_transformer_block.py:58-62): a wave holds all 128 features of its 32 queries -
+    // per query 32 values in this lane, the rest in the three lanes i16 + 16 g'.  h is read and written in place: the mixing of
+    // the other workgroups of this row reads the x^T copy, not h.
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = q0 + 32 * wave + 16 * j + i16;
+      const bool ok = q < V;
+      float* row = hres + (n * V + (ok ? q : 0)) * (int64_t)D;
+      lin_f4 v[8];
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const lin_f4 r = ok ? *(const lin_f4*)(row + 16 * t + 4 * g) : (lin_f4){0.f, 0.f, 0.f, 0.f};
+        v[t] = r + acc_y[t][j] * (1.0f / LH_WSCALE);
+        sum += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.f / 128.f);
+      float var = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        v[t] = v[t] - mean;
+        var += (v[t][0] * v[t][0] + v[t][1] * v[t][1]) + (v[t][2] * v[t][2] + v[t][3] * v[t][3]);
+      }
+      var += __shfl_xor(var, 16);
+      var += __shfl_xor(var, 32);
+      const float rstd = 1.0f / sqrtf(var * (1.f / 128.f) + eps);
+      if (ok) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const lin_f4 w = *(const lin_f4*)(lnw + 16 * t + 4 * g), b = *(const lin_f4*)(lnb + 16 * t + 4 * g);
+          *(lin_f4*)(row + 16 * t + 4 * g) = v[t] * rstd * w + b;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int q = q0 + 32 * wave + 16 * j + i16;
@@ -1510,9 +1551,13 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
           constexpr int ldsf = 2 * 4 * 128 * 64;
           static LdsLimit limf;
           if ((rc = limf.ensure((const void*)attend_fold_h3_kernel, ldsf))) return rc;
+          // (+ the residual and LayerNorm 1 in its epilogue; bit 27: as the add_ln launch behind it - A/B, tests)
+          const bool ln_in = !(g_debug_flags & 134217728) && ((uintptr_t)(lb + L.layer.n1w) % 16 == 0) && ((uintptr_t)(lb + L.layer.n1b) % 16 == 0);
           hipLaunchKernelGGL(attend_fold_h3_kernel, dim3((unsigned)blocks), dim3(256), ldsf, s, w.s_hi, w.s_lo, w.xt_hi, w.xt_lo, wch,
-                             wch + wcf, w.tmp, a.n_cond, d.n_heads, V, Vp);
+                             wch + wcf, w.tmp, a.n_cond, d.n_heads, V, Vp, ln_in ? w.h : nullptr, lb + L.layer.n1w, lb + L.layer.n1b,
+                             d.ln_eps);
           TW_LAUNCH_CHECK();
+          if (ln_in) goto ln1_done;
           goto attention_done;
         }
         const int64_t blocks = a.n_rows * d.n_heads * ((V + LH_BM - 1) / LH_BM);
@@ -1567,6 +1612,7 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
     hipLaunchKernelGGL(add_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.h, w.tmp, lb + L.layer.n1w,
                        lb + L.layer.n1b, d.ln_eps, d.d_model, M);
     TW_LAUNCH_CHECK();
+  ln1_done:;
     if (sp && a.packed && h3_ffn_tokens_supported(d) && !(g_debug_flags & 16777216)) {
       // TW_PATH_SIMPLE_H3 with the split-fp16 stream at hand: FFN + residual + LayerNorm 2 as ONE launch of the fused kernels' chunk
       // loop on the flat token list - the 2048-wide hidden layer stays on the chip (tw_netblock_h3.hip: h3_ffn_tokens_kernel)

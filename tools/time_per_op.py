@@ -22,4 +22,16 @@ for spec in [a for a in sys.argv[1:] if not a.startswith("--")] or ["192x256"]:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3 * 1e3
     flop = 16 * V * (4478976 + 4608 * V) * S
+    if "--forward" in sys.argv:
+        # the reverse move of an MH iteration: every row conditioned on its own state (n_cond = S: scores per row)
+        yc, yv, _ = f()
+        atS, mkS = at.repeat(S, 1), mk.repeat(S, 1)
+        ff = lambda: m.log_likelihood(atom_types=atS, x_coords=yc.squeeze(1), x_velocs=yv.squeeze(1), y_coords=xc.repeat(S, 1, 1),
+                                      y_velocs=xv.repeat(S, 1, 1), adj_list=None, edge_batch_idx=None, masked_elements=mkS)
+        ff(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            ff()
+        torch.cuda.synchronize()
+        dtf = (time.perf_counter() - t0) / 3 * 1e3
+        print(f"per-op path {path} V={V} S={S}: {dtf:.1f} ms per FORWARD pass (n_cond = S), {flop / dtf / 1e9:.1f} TFLOP/s algorithmic", flush=True)
     print(f"per-op path {path} V={V} S={S}: {dt:.1f} ms per reverse pass, {flop / dt / 1e9:.1f} TFLOP/s algorithmic", flush=True)
