@@ -133,7 +133,7 @@ def check_split(got_hi, got_lo, want, h1, what):
 
 
 VARIANTS = [(), ("--mode=windowed",), ("--h1",), ("--nt=4",), ("--nt=4", "--h1"), ("--wide",), ("--wide", "--h1"), ("--wide", "--ng=6"),
-            ("--dense",), ("--dense", "--h1")]
+            ("--dense",), ("--dense", "--h1"), ("--dense", "--nt=4")]
 
 
 @pytest.mark.parametrize("argv", VARIANTS, ids=lambda a: " ".join(a) or "nt3")
@@ -167,7 +167,8 @@ def xt_images(s, enc):
         for ks in range(4):
             for jt in range(s.NT):
                 for part, name in enumerate("hl"):
-                    h = halves(s.w.a[enc.attn.XB(ks, jt, name):enc.attn.XB(ks, jt, name) + 4])
+                    file = s.w.v if enc.attn.XB_CLS(ks, jt) == "v" else s.w.a   # (64-token build: one operand pair lives in VGPRs)
+                    h = halves(file[enc.attn.XB(ks, jt, name):enc.attn.XB(ks, jt, name) + 4])
                     for e in range(8):
                         out[part, jt, s.i16, 32 * ks + 16 * (e // 4) + 4 * s.g + e % 4] = h[:, e]
         return out
@@ -272,7 +273,8 @@ def test_entry_reads_x_and_builds_the_first_transposed_copy(argv):
     assert s.w.s[enc.S_IF].view(np.float32) == np.float32(1 / s.sc_f)
 
 
-@pytest.mark.parametrize("argv", [("--nt=4",), ("--nt=4", "--h1"), ("--wide",), ("--wide", "--ng=6", "--h1"), ("--dense",), ("--dense", "--h1")],
+@pytest.mark.parametrize("argv", [("--nt=4",), ("--nt=4", "--h1"), ("--wide",), ("--wide", "--ng=6", "--h1"), ("--dense",), ("--dense", "--h1"),
+                                  ("--dense", "--nt=4")],
                          ids=lambda a: " ".join(a))
 def test_the_64_token_glue_keeps_nothing_in_registers_across_the_embedded_blocks(argv):
     """Every glue phase of the 64-token statement (and of the wide / dense ones, which take the same form) must work from a

@@ -272,10 +272,12 @@ def _dense_case(sd, spec, V, lens, seed, S=7):
 
 
 @pytest.mark.parametrize("V,lens", [(22, [22, 20, 22, 17, 22, 22, 22, 22, 22]), (7, [7, 5, 6, 7, 7, 3, 7] * 5), (16, [16, 13, 16, 16, 16, 10, 16] * 2),
-                                    (30, [30, 28, 25, 30, 30]), (48, [48, 40, 33, 48, 48])])
+                                    (30, [30, 28, 25, 30, 30]), (48, [48, 40, 33, 48, 48]),
+                                    # r06: 64-token waves (tools/gen_h3_enc_asm.py --dense --nt=4: the softmax block in two query halves)
+                                    (49, [49, 49, 41, 49, 49, 33]), (60, [60, 52, 60, 60, 57, 60]), (64, [64, 64, 50, 64, 64])])
 def test_dense_encoder_stack_statement(V, lens):
-    """tools/gen_h3_enc_asm.py --dense: ragged forward pass over more than one workgroup and the reverse pass of one conditioning
-    state, against the oracle, the per-section build (bit 12) and itself."""
+    """tools/gen_h3_enc_asm.py --dense [--nt=4]: ragged forward pass over more than one workgroup and the reverse pass of one
+    conditioning state, against the oracle, the per-section build (bit 12) and itself."""
     from timewarp_amd import _lib
 
     lib = _lib.load()
@@ -445,7 +447,8 @@ def test_paired_64_token_layout_fast_mode():
     assert e_ref < 1.5e-3 and e_wide < 1.5e-3 and e_ref > 1e-6, (e_ref, e_wide)
 
 
-# ---- the dense softmax model on 64-token waves (49-64 atoms; per-section build: asm MLP sections, compiled-C++ attention block) ----
+# ---- the dense softmax model on 64-token waves (49-64 atoms): r06 the encoder-stack statement (softmax block in two query halves);
+# ---- the per-section build (asm MLP sections, compiled-C++ attention block) behind tw_debug_set_flags bit 12 ----
 @pytest.mark.parametrize("V,lens", [(52, [52, 52, 41, 52, 52]), (61, [61, 61, 61, 48, 61, 61, 61]), (64, [64, 50])])
 def test_dense_model_on_64_token_waves_vs_oracle(V, lens):
     """r05: the dense model above 48 atoms ran the exact-f32 fused kernel (3x slower) on the default path until now.  Forward pass
@@ -463,10 +466,17 @@ def test_dense_model_on_64_token_waves_vs_oracle(V, lens):
         return (_loglik(m, at, x_c, x_v, y_c, y_v, mask),) + _sample(m, at[:1], x_c[:1], x_v[:1], mask[:1], zc, zv)
 
     out, again = run(), run()
-    assert lib.tw_last_netblock_kernel().decode() == "tw::netblock_h3_kernel<4, true, true, false, false, false, false, false>"
+    assert lib.tw_last_netblock_kernel().decode() == "tw::netblock_h3_kernel<4, true, true, false, false, true, false, false>"   # ENC since r06
+    try:
+        lib.tw_debug_set_flags(PER_SECTION)
+        sections = run()
+        assert lib.tw_last_netblock_kernel().decode() == "tw::netblock_h3_kernel<4, true, true, false, false, false, false, false>"
+    finally:
+        lib.tw_debug_set_flags(0)
     H.assert_not_demoted(m)
     for a, b in zip(out, again):
         assert torch.equal(a, b)
+    assert H.rel_err(sections[0], ref) < TOL and not torch.equal(sections[0], out[0])   # the r05 build: still at the bar, a different kernel
     keep = ~mask[0]
     errs = (H.rel_err(out[0], ref), H.rel_err(out[1][:, :, keep], rs[0][:, :, keep]), H.rel_err(out[2][:, :, keep], rs[1][:, :, keep]),
             H.rel_err(out[3], rs[2]))

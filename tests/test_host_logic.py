@@ -409,12 +409,14 @@ def test_generated_asm_includes_are_current(tmp_path):
                  ["tools/gen_h3_enc_asm.py", "--wide", "--ng=6"], ["tools/gen_h3_enc_asm.py", "--wide", "--ng=6", "--h1"],
                  # ... and of the dense softmax model, tw_h?d_enc_*
                  ["tools/gen_h3_enc_asm.py", "--dense"], ["tools/gen_h3_enc_asm.py", "--dense", "--h1"],
+                 # r06: ... and on 64-token waves (49-64 atoms): tw_h3n4d_enc_*
+                 ["tools/gen_h3_enc_asm.py", "--dense", "--nt=4"],
                  # ... and of the paired 64-token layout (97-128 atoms), tw_h?n4p_enc_*
                  ["tools/gen_h3_enc_asm.py", "--nt=4", "--pair"], ["tools/gen_h3_enc_asm.py", "--nt=4", "--pair", "--h1"]):
         subprocess.run([sys.executable] + args + [f"--out-dir={tmp_path}"], cwd=root, check=True, env=env,
                        stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 83
+    assert len(names) == 85
     for n in names:
         with open(os.path.join(tmp_path, n)) as a, open(os.path.join(root, "timewarp_amd", "csrc", n)) as b:
             assert a.read() == b.read(), n
@@ -691,9 +693,10 @@ def test_split_fp16_workspace_covers_every_layout_a_launch_can_take():
         lib.tw_debug_set_flags(0)
 
 
-# The one instantiation a flow call can select that still spills (the dense model's 64-token build: MLP sections asm, the softmax
-# attention block compiled C++ - DESIGN.md section 4.1 table / section 8): the scratch it may use is pinned, not ignored.
-KNOWN_SPILLING = {"tw::netblock_h3_kernel<4, true, true, false, false, false, false, false>": 724}
+# Instantiations a flow call can select that may use scratch, by name, with the scratch they may use.  Empty since r06: the dense
+# model's 64-token build was the last one (r05: its compiled attention block, 724 B/lane) until its encoder-stack statement
+# (tools/gen_h3_enc_asm.py --dense --nt=4) replaced it.
+KNOWN_SPILLING = {}
 
 
 def selectable_netblock_kernels():
@@ -725,7 +728,7 @@ def test_product_kernels_do_not_spill():
     """Every instantiation of the split-fp16 / single-MFMA net-block kernel that a flow call can SELECT compiles to ScratchSize
     0 B/lane, and hipcc has nothing to say about the inline asm.  r05 defined "product" as the ENC = true template argument and
     so could not see the one selectable kernel that spills; now the library is asked which instantiations
-    its launch code takes (tw_flow_selected_kernel), and the exception is listed by name with its scratch size pinned.
+    its launch code takes (tw_flow_selected_kernel); exceptions would be listed by name with their scratch size pinned (none left).
     Compiles csrc/tw_netblock_h3.hip once with -Rpass-analysis=kernel-resource-usage (~90 s, no GPU needed)."""
     import shutil
     import subprocess
@@ -740,6 +743,7 @@ def test_product_kernels_do_not_spill():
     atoms = lambda name: sorted({v for _, _, v in picked[name]})
     assert atoms("tw::netblock_h3_kernel<4, true, false, true, false, true, false, false>") == list(range(97, 129))      # paired
     assert atoms("tw::netblock_h3_kernel<3, true, false, true, false, true, false, true>") == list(range(161, 193))       # six groups
+    assert atoms("tw::netblock_h3_kernel<4, true, true, false, false, true, false, false>") == list(range(49, 65))        # dense, 64-token waves
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "resource_usage.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]

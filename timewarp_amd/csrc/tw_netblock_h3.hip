@@ -1298,11 +1298,11 @@ netblock_h3_kernel(const H3Params p) {
   static_assert(!NG6 || WIDE, "six-group windows belong to the wide layout");
   static_assert(!RFF || DENSE, "position features belong to the dense model");
   static_assert(!ENC || ASM, "the encoder-stack statement embeds the generated asm sections");
-  static_assert(!(ENC && DENSE) || NT == 3, "dense encoder-stack statement: 48-token waves");
-  static_assert(NT == 3 || (NT == 4 && !RFF && (!WIDE || (ENC && !NG6)) && (!DENSE || (ASM && !WIDE && !ENC && !H1))),
+  static_assert(NT == 3 || (NT == 4 && !RFF && (!WIDE || (ENC && !NG6)) && (!DENSE || (ASM && !WIDE && !H1))),
                 "64-token waves: the kernel-attention variant - one molecule of 49-64 atoms per wave, or (WIDE: the paired layout, "
                 "encoder-stack statement only) one of 97-128 atoms per pair of waves; the dense softmax model on one molecule of "
-                "49-64 atoms per wave as the per-section build with its attention block compiled C++ (r05)");
+                "49-64 atoms per wave: the encoder-stack statement (r06, tools/gen_h3_enc_asm.py --dense --nt=4), or the per-section "
+                "build with its attention block compiled C++ (r05; activation dumps, section stamps)");
   constexpr int KIN = RFF ? 6 : 2;  // 32-column k-steps of the in-MLP's input
   // 64-token build: all four GEMM sections are generated asm (tools/gen_h3_ffn_asm.py / gen_h3_attn_asm.py --nt=4), the glue
   // between them compiled C++ (the per-section build)
@@ -1356,7 +1356,7 @@ netblock_h3_kernel(const H3Params p) {
   pipe.wave = wave;
   pipe.debug = p.debug;
   pipe.ring = RING;
-  if constexpr (ENC && DENSE) {
+  if constexpr (ENC && DENSE && NT == 3) {   // (64-token waves: single-buffered, the statement fetches every layer's block itself)
     // The dense encoder-stack statement double-buffers the layers' side blocks in the LDS (layer l in buffer l % 2, fetched
     // a whole layer ahead: its attention block reads biases and the in_proj scale at its very entry).  Layer 0's goes first,
     // older than every weight stage: start_wait()'s vmcnt(0) + barrier cover it.
@@ -1780,6 +1780,20 @@ netblock_h3_kernel(const H3Params p) {
 #include "tw_h3n4p_enc_clobbers.inc"
           );
         }
+      } else if constexpr (DENSE && NT == 4) {
+        // r06: the dense model on 64-token waves (tools/gen_h3_enc_asm.py --dense --nt=4).  One molecule per wave, so ONE pair of
+        // key-mask words serves all four query tiles: token tile 0 is always whole (49+ atoms), its lanes hold the molecule's mask
+        // (a padding query of the last tile then attends like a real one; its row is zeroed behind every LayerNorm anyway)
+        const unsigned m0l = (unsigned)kvalid[0], m0h = (unsigned)(kvalid[0] >> 32);
+        asm volatile(
+#include "tw_h3n4d_enc_asm.inc"
+            : [cur] "+&s"(cur), [gn] "+&v"(gn)
+            : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks), [layers] "s"(layers), [side] "s"(side_u),
+              [sidestride] "s"(sidestride32), [sl] "s"(sl_lds), [scales] "s"(scales_u), [eps] "s"(eps), [padm] "v"(padmask),
+              [padt] "s"(pad_tiles), [dump] "s"(dump_u), [stampen] "s"(stampen), [m0l] "v"(m0l), [m0h] "v"(m0h)
+            :
+#include "tw_h3n4d_enc_clobbers.inc"
+        );
       } else if constexpr (DENSE) {
         // dense softmax model (tools/gen_h3_enc_asm.py --dense [--h1]): no score fragments; the key masks of the softmax
         const unsigned m0l = (unsigned)kvalid[0], m0h = (unsigned)(kvalid[0] >> 32), m1l = (unsigned)kvalid[1],
@@ -2693,11 +2707,43 @@ netblock_h3_kernel(const H3Params p) {
     } else {
       h3_mlp_chain<NT, 4, 1, true>(xb, o, pipe, p.hid_chunks, lane);
     }
+    if constexpr (ENC && DENSE && NT == 4) {
+      // (see below: nothing per-lane may stay live across the encoder-stack statement of this build - the bias is loaded here)
+      int lane_b;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_b));
+      const f4 bb_late = *(const f4*)(side + p.side_out2b + 4 * (lane_b >> 4));
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) o[0][jt] = o[0][jt] * sc_out2 + bb_late;
+    } else {
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) o[0][jt] = o[0][jt] * sc_out2 + bb_out2;
+    }
   }
   stamp(2 + 4 * p.n_layers);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // drain the over-fetched stages before the workgroup retires its LDS
+  if constexpr (ENC && DENSE && NT == 4) {
+    // r06: this build's statement owns v0..v245 AND all 256 AGPRs (y + the split activations), so the compiler has ten VGPRs
+    // and no AGPR to carry values across it: the token bookkeeping of the epilogue (eight + four registers per lane in the other
+    // builds) is recomputed here from a lane id the compiler cannot connect with the prologue's - ScratchSize stays 0.
+    int lane_b;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_b));
+    if ((lane_b >> 4) == 0) {
+      float* outp = p.out[net];
+      const unsigned inv_v2 = (65536u + (unsigned)p.P - 1u) / (unsigned)p.P;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const int t = 16 * jt + (lane_b & 15);
+        const int q = (int)(((unsigned)t * inv_v2) >> 16);
+        const int64_t n = row0 + q;
+        const int atom = t - q * p.P;
+        if (!(active && q < p.mpw && n < p.n_rows && atom < p.V)) continue;
+        float* dst = outp + (n * p.V + atom) * 3;
+        dst[0] = o[0][jt][0];
+        dst[1] = o[0][jt][1];
+        dst[2] = o[0][jt][2];
+      }
+    }
+  } else
   if (g == 0) {
     float* outp = p.out[net];
 #pragma unroll
@@ -2981,8 +3027,11 @@ static int h3_launch(const FlowArgs& a, const RawLayout& L, const FusedGeom& fg,
     else H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, true, false, true, false, false);
   } else if (!wide && fg.nt == H3N4_NT && d.variant == 1) {
     // r05: the dense softmax model on one molecule of 49-64 atoms per wave (MLP sections asm, attention block compiled C++)
-    TW_REQUIRE(!h1 && d.d_rff == 0, "dense model on 64-token waves: the split-fp16 build without position features");
-    H3_LAUNCH(H3D4_LDS_BYTES, 4, true, true, false, false, false, false, false);
+    // r06: the encoder-stack statement (tools/gen_h3_enc_asm.py --dense --nt=4; no compiled block, no scratch) unless activation
+    // dumps / section stamps between the sections are asked for (the per-section build: attention block compiled C++)
+    TW_REQUIRE(!h1 && d.d_rff == 0 && !cpp, "dense model on 64-token waves: the split-fp16 build without position features");
+    if (per_section) H3_LAUNCH(H3D4_LDS_BYTES, 4, true, true, false, false, false, false, false);
+    else H3_LAUNCH(H3D4_LDS_BYTES, 4, true, true, false, false, true, false, false);
   } else if (!wide && fg.nt == H3N4_NT) {
     TW_REQUIRE(d.variant == 0, "64-token waves: kernel attention");
     if (h1 && per_section) H3_LAUNCH(H3N4_LDS_BYTES, 4, true, false, false, false, false, true, false);

@@ -30,7 +30,19 @@ Register map (private to the asm statement):
 import os
 import sys
 
-NT = 3
+# --nt=4 (r06): 64-token waves - ONE molecule of 49-64 atoms per wave (csrc H3N4_*), a ring of three stage buffers.  Keys = 64 = two
+# K = 32 groups (no K = 16 tail).  What does not fit as it stands is the score tile: 4 query tiles x 4 key tiles x 4 registers beside
+# y (a0..a127) and the split activations (a128..a255) - so a head runs in two QUERY HALVES (tiles 0, 1 then 2, 3) over 32 score
+# registers:   V(h) | S(A) | Q(h+1) + softmax(A) | P.V(A) | S(B) | K(h+1) + softmax(B) | P.V(B) | [out_proj after an odd h]
+# Register map:  v0..v31 tile slots;  v32..v79 QA KA VA[jt] (the P.V accumulators take VA's registers: v is split into operands
+# before the first P.V of the head);  v80..v111 QH QL KH KL[jt];  v112..v127 VH01 VL01 VH23 VL23;  v128..v159 SC[jl][mt] of the half in
+# flight (P operands written over them: PL01 PL23 PH01 PH23);  v160..v164 1 / sum, reduction copy;  v168..v199 OB[jt];
+# v200..v211 temporaries;  v212..v220 biases;  v221..v229 addresses;  a0..a127 y;  a128..a255 xb.  Key masks: ONE pair of words
+# (%[m0l], %[m0h]: keys 0-31, 32-63 of the wave's molecule, shifted by the lane group) serves all four query tiles.
+NT4 = "--nt=4" in sys.argv
+NT = 4 if NT4 else 3
+AHEAD = 3 if NT4 else 5
+RING = AHEAD
 STAGE, TILES = 9216, 8192
 H3D_INB = 656              # float offset of in_proj bias [384] in the layer's side block; sc_in at 640
 SLOT = lambda p, part: 8 * p + (0 if part == "h" else 4)
@@ -58,6 +70,37 @@ V_TILE, V_LANE16, V_SLQ, V_SLV, V_GN, V_TMP = 212, 213, 214, 215, 216, 218
 N_V, N_A = 220, 192
 YACC = lambda ot, jt: 4 * (3 * ot + jt)
 XB = lambda ks, jt, part: 96 + 8 * (3 * ks + jt) + (0 if part == "h" else 4)
+if NT4:
+    QA = lambda jt: 32 + 4 * jt
+    KA = lambda jt: 48 + 4 * jt
+    VA = lambda jt: 64 + 4 * jt
+    QH = lambda jt: 80 + 2 * jt
+    QL = lambda jt: 88 + 2 * jt
+    KH = lambda jt: 96 + 2 * jt
+    KL = lambda jt: 104 + 2 * jt
+    VH01, VL01, VH23, VL23 = 112, 116, 120, 124
+    SC = lambda jt, mt: 128 + 16 * (jt % 2) + 4 * mt          # the half in flight: query tiles jt % 2
+    PL01 = lambda jt: 128 + 16 * (jt % 2)
+    PL23 = lambda jt: 132 + 16 * (jt % 2)
+    PH01 = lambda jt: 136 + 16 * (jt % 2)
+    PH23 = lambda jt: 140 + 16 * (jt % 2)
+    RS = lambda jt: 160 + jt
+    V_RED = 164
+    O32 = lambda jt: VA(jt)                                   # P.V accumulators: v's registers (dead after prep_v)
+    OB = lambda jt, part: 168 + 8 * jt + (0 if part == "h" else 4)
+    V_T = 200
+    V_BQ, V_BK, V_BV = 212, 216, 220
+    V_TILE, V_LANE16, V_SLQ, V_SLV, V_GN, V_TMP = 221, 222, 223, 224, 226, 228
+    N_V, N_A = 230, 256   # (N_V: this block's own registers; the operand pair in v232.. / v240.. belongs to the caller's map)
+    YACC = lambda ot, jt: 4 * (4 * ot + jt)
+    # the split activations: a128..a247, and the LAST operand pair (k-step 3, token tile 3) in VGPRs v232..v235 / v240..v243 - registers
+    # nothing touches between the glue's operand pass and the end of this block - so that a248..a255 stay free in every statement
+    # of the kernel: hipcc parks what it carries through the prologue there; with all 256 AGPRs taken it went to scratch
+    XB = lambda ks, jt, part: ((232 if part == "h" else 240) if (ks, jt) == (3, 3) else 128 + 8 * (4 * ks + jt) + (0 if part == "h" else 4))
+    XB_CLS = lambda ks, jt: "v" if (ks, jt) == (3, 3) else "a"
+    N_A = 248
+if not NT4:
+    XB_CLS = lambda ks, jt: "a"
 S_OFF, S_REL, S_W2048, S_STRIDE, S_AUXOFF, S_END, S_PAIR = 84, 85, 86, 88, 90, 92, 93
 S_SCIN, S_SCQ, S_LOG2E, S_MASKED = 94, 95, 96, 97
 EXPERIMENT = set(filter(None, os.environ.get("H3_ATTN_EXPERIMENT", "").split(",")))
@@ -154,7 +197,7 @@ def stage(groups, valu, label, next_reads=True, aux=True, skip=0, pre_barrier=()
     out += weave(groups[0], parts[0], tile_reads(2), skip=skip, valu_per=valu_per)
     out.append("s_waitcnt lgkmcnt(2)")
     out += weave(groups[1], parts[1], tile_reads(3) + list(pre_barrier), valu_per=valu_per)
-    out.append("s_waitcnt vmcnt(6) lgkmcnt(0)")
+    out.append(f"s_waitcnt vmcnt({2 * (AHEAD - 2)}) lgkmcnt(0)")   # stages s + 2 .. s + AHEAD - 1 may stay in flight, two DMAs each
     if "nobarrier" not in EXPERIMENT:
         out.append("s_barrier")
     out += weave(groups[2], parts[2], handoff(next_reads, label, aux), valu_per=valu_per)
@@ -169,7 +212,7 @@ def qk_groups(acc):
         g = []
         for k, (ap, bp) in enumerate((("h", "h"), ("h", "l"), ("l", "h"))):
             for jt in range(NT):
-                g.append(mfma32(acc(jt), SLOT(ks, ap), XB(ks, jt, bp), zero=(ks == 0 and k == 0), bcls="a"))
+                g.append(mfma32(acc(jt), SLOT(ks, ap), XB(ks, jt, bp), zero=(ks == 0 and k == 0), bcls=XB_CLS(ks, jt)))
         groups.append(g)
     return groups
 
@@ -181,7 +224,7 @@ def v_groups():
         g = []
         for k, (xp, wp) in enumerate((("h", "h"), ("l", "h"), ("h", "l"))):
             for jt in range(NT):
-                g.append(mfma32(VA(jt), XB(ks, jt, xp), SLOT(ks, wp), zero=(ks == 0 and k == 0), acls="a"))
+                g.append(mfma32(VA(jt), XB(ks, jt, xp), SLOT(ks, wp), zero=(ks == 0 and k == 0), acls=XB_CLS(ks, jt)))
         groups.append(g)
     return groups
 
@@ -225,13 +268,17 @@ def prep_v():
     ops = []
     for jt in range(NT):
         ops += [f"v_fma_f32 v{VA(jt) + r}, v{VA(jt) + r}, s{S_SCIN}, v{V_BV}" for r in range(4)]
-    ops += split_pair(VA(0), VH01, VL01, V_T) + split_pair(VA(1), VH01 + 2, VL01 + 2, V_T + 4) + split_pair(VA(2), VH2, VL2, V_T)
+    ops += split_pair(VA(0), VH01, VL01, V_T) + split_pair(VA(1), VH01 + 2, VL01 + 2, V_T + 4)
+    if NT4:
+        return ops + split_pair(VA(2), VH23, VL23, V_T) + split_pair(VA(3), VH23 + 2, VL23 + 2, V_T + 4)
+    ops += split_pair(VA(2), VH2, VL2, V_T)
     return ops
 
 
-def s_mfmas():
+def s_mfmas(half=None):
+    """S^T[key tile mt][query tile jt] = k_h[mt] q_h[jt]^T (K = 16, three terms).  half (64-token build): query tiles 2 half, 2 half + 1."""
     out = []
-    for jt in range(NT):
+    for jt in (range(NT) if half is None else (2 * half, 2 * half + 1)):
         for k, (kp, qp) in enumerate(((KH, QH), (KH, QL), (KL, QH))):
             for mt in range(NT):
                 out.append(mfma16(SC(jt, mt), kp(mt), qp(jt), zero=(k == 0)))
@@ -304,6 +351,97 @@ def osplit(jt, hh):
     return ops
 
 
+def soft4(jt):
+    """64-token build: masked softmax of query tile jt over its 16 accumulator elements (keys 16 mt + 4 g + r) and the split of P,
+    unnormalised (1 / sum goes to RS[jt]).  Mask bits: %[m0l] bit 16 (mt % 2) + r for mt 0, 1; %[m0h] the same for mt 2, 3.
+    P operands, in place over the 16 score registers: PL01 (+0) PL23 (+4) PH01 (+8) PH23 (+12)."""
+    el = [(mt, r) for mt in range(NT) for r in range(4)]
+    m, mx, sm = V_T + 8, V_T + 9, V_T + 10
+    ops = []
+    for i, (mt, r) in enumerate(el):
+        word, bit = ("%[m0l]" if mt < 2 else "%[m0h]"), 16 * (mt % 2) + r
+        ops += [f"v_bfe_i32 v{m}, {word}, {bit}, 1", f"v_bfi_b32 v{SC(jt, mt) + r}, v{m}, v{SC(jt, mt) + r}, s{S_MASKED}"]
+        ops.append(f"v_mov_b32 v{mx}, v{SC(jt, mt) + r}" if i == 0 else f"v_max_f32 v{mx}, v{mx}, v{SC(jt, mt) + r}")
+    ops += reduce4("v_max_f32", mx)
+    ops.append(f"v_mul_f32 v{mx}, s{S_LOG2E}, v{mx}")
+    for mt, r in el:
+        x = SC(jt, mt) + r
+        ops += [f"v_fma_f32 v{x}, v{x}, s{S_LOG2E}, -v{mx}", f"v_exp_f32 v{x}, v{x}"]
+    for i, (mt, r) in enumerate(el):
+        x = SC(jt, mt) + r
+        ops.append(f"v_mov_b32 v{sm}, v{x}" if i == 0 else f"v_add_f32 v{sm}, v{sm}, v{x}")
+    ops += reduce4("v_add_f32", sm)
+    ops.append(f"v_rcp_f32 v{RS(jt)}, v{sm}")
+    # split, in place: the eight hi packs to temporaries, the sixteen residuals in place, lo packs over registers 0..7, hi packs to 8..15
+    t, base = V_T, SC(jt, 0)
+    for k in range(8):
+        ops.append(f"v_cvt_pk_f16_f32 v{t + k}, v{base + 2 * k}, v{base + 2 * k + 1}")
+    for k in range(16):
+        sel = "op_sel:[1,0,0] " if k % 2 else ""
+        ops.append(f"v_fma_mix_f32 v{base + k}, v{t + k // 2}, -1.0, v{base + k} {sel}op_sel_hi:[1,0,0]")
+    for k in range(8):
+        ops.append(f"v_cvt_pk_f16_f32 v{PL01(jt) + k}, v{base + 2 * k}, v{base + 2 * k + 1}")
+    for k in range(8):
+        ops.append(f"v_mov_b32 v{PH01(jt) + k}, v{t + k}")
+    return ops
+
+
+def pv4_mfmas(half):
+    """O^T[feature][query] of query tiles 2 half, 2 half + 1: one chain of six K = 32 MFMAs per tile (keys 0-31, 32-63 x three
+    terms), the two chains interleaved."""
+    chains = []
+    for jt in (2 * half, 2 * half + 1):
+        chains.append([mfma32(O32(jt), VH01, PH01(jt), zero=True), mfma32(O32(jt), VH23, PH23(jt)),
+                       mfma32(O32(jt), VH01, PL01(jt)), mfma32(O32(jt), VH23, PL23(jt)),
+                       mfma32(O32(jt), VL01, PH01(jt)), mfma32(O32(jt), VL23, PH23(jt))])
+    return [m for pair in zip(*chains) for m in pair]
+
+
+def osplit4(jt, hh):
+    """O / sum -> elements 4 hh .. 4 hh + 3 of OB[jt].h / .l."""
+    t = V_T + 4 * (jt % 2)
+    ops = [f"v_mul_f32 v{O32(jt) + r}, v{O32(jt) + r}, v{RS(jt)}" for r in range(4)]
+    return ops + split_pair(O32(jt), OB(jt, "h") + 2 * hh, OB(jt, "l") + 2 * hh, t)
+
+
+def head_slot4(hh, L):
+    """One head of the 64-token build (see the --nt=4 note at the top)."""
+    A = L.append
+    tag = f"h{hh}"
+    bq4 = [f"v_mul_f32 v{V_BQ + r}, 0.25, v{V_BQ + r}" for r in range(4)]
+    # ---- stage V(h) | q, k of this head: scale, bias, split (their biases were read in the K stage before)
+    L += stage(v_groups(), bq4 + prep_qk(), f"{tag}v", skip=1)
+    for half, nxt in ((0, QA), (1, KA)):
+        # ---- S(half) | half 0: v of this head (scale, bias, split); half 1: 1 / sum and split of O for the first two query tiles
+        A("s_nop 3")
+        L += weave(s_mfmas(half), prep_v() if half == 0 else osplit4(0, hh) + osplit4(1, hh), [], skip=3 if half == 0 else 8, valu_per=2)
+        # ---- stage Q(h+1) / K(h+1) | masked softmax + split of P of this half (bare after the last head)
+        sv = soft4(2 * half) + soft4(2 * half + 1)
+        if hh == 1:
+            A(f"s_cmp_eq_u32 s{S_PAIR}, 1")
+            A(f"s_cbranch_scc1 .Lh3atd_last{half}_{tag}_%=")
+        L += stage(qk_groups(nxt), sv, f"{tag}{'qk'[half]}", skip=3, pre_barrier=bias_reads() if half == 1 else (), valu_per=3)
+        if hh == 1:
+            A(f"s_branch .Lh3atd_pv{half}_{tag}_%=")
+            A(f".Lh3atd_last{half}_{tag}_%=:")
+            A("s_nop 7")
+            L += sv
+            A(f".Lh3atd_pv{half}_{tag}_%=:")
+        # ---- P.V of this half (the accumulators are v's: dead since prep_v)
+        A("s_nop 3")
+        L += pv4_mfmas(half)
+    A("s_nop 15")    # (the last P.V MFMAs are eight passes each: their results are read next)
+    A("s_nop 15")
+    A("s_nop 15")
+    L += osplit4(2, hh)
+    L += osplit4(3, hh)
+    # ---- out_proj k-step of the pair
+    if hh == 1:
+        A("s_nop 7")
+        L += stage(out_groups(0), [], f"{tag}oa")
+        L += stage(out_groups(1), [], f"{tag}ob")
+
+
 def bias_reads():
     """q / k / v bias of the head at V_SLQ / V_SLV (advanced afterwards); q's is pre-multiplied by 1/4 by the caller."""
     return [f"ds_read_b128 {vr(V_BQ)}, v{V_SLQ} offset:{4 * H3D_INB}",
@@ -374,7 +512,7 @@ def generate():
     A(f"s_mov_b32 s{S_AUXOFF + 1}, 0")
     A(f"s_mov_b32 s{S_LOG2E}, 0x3fb8aa3b")
     A(f"s_mov_b32 s{S_MASKED}, 0xc6ea6000")          # -3e4
-    A(f"s_add_u32 s{S_END}, %[ring], {5 * STAGE}")
+    A(f"s_add_u32 s{S_END}, %[ring], {RING * STAGE}")
     A(f"v_lshl_add_u64 {vr(V_GN, 2)}, %[gn], 0, s[{S_W2048}:{S_W2048 + 1}]")
     A(f"s_mul_i32 s{S_OFF}, %[cur], {STAGE}")
     A(f"s_add_u32 s{S_OFF}, s{S_OFF}, %[ring]")
@@ -398,9 +536,11 @@ def generate():
     if not FUSED:
         # split activations from the wave-private block: 24 images -> a96..a191
         A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-        for i in range(24):
-            A(f"ds_read_b128 {ar(96 + 4 * i)}, v{V_TMP} offset:{1024 * i}")
-        for i in range(96):
+        for i in range(8 * NT):
+            ks, jt, part = i // (2 * NT), (i // 2) % NT, "hl"[i % 2]
+            dst = (vr if XB_CLS(ks, jt) == "v" else ar)(XB(ks, jt, part))
+            A(f"ds_read_b128 {dst}, v{V_TMP} offset:{1024 * i}")
+        for i in range(32 * NT):
             A(f"v_accvgpr_write_b32 a{i}, 0")
     A("s_waitcnt lgkmcnt(0)")
     if FUSED:
@@ -420,15 +560,15 @@ def generate():
         scale_to_sgprs()
     A(f"s_mov_b32 s{S_PAIR}, 4")
     A(".Lh3atd_pair_%=:")
-    head_slot(0, L)
-    head_slot(1, L)
+    (head_slot4 if NT4 else head_slot)(0, L)
+    (head_slot4 if NT4 else head_slot)(1, L)
     A(f"s_sub_u32 s{S_PAIR}, s{S_PAIR}, 1")
     A(f"s_cmp_eq_u32 s{S_PAIR}, 0")
     A("s_cbranch_scc0 .Lh3atd_pair_%=")
     # ---- out: ring slot index, y through the wave-private block, DMA pointer
     A(f"s_sub_u32 s{S_REL}, s{S_OFF}, %[ring]")
     A("s_mov_b32 %[cur], 0")
-    for k in range(1, 5):
+    for k in range(1, RING):
         A(f"s_cmp_eq_u32 s{S_REL}, {k * STAGE}")
         A(f"s_cselect_b32 %[cur], {k}, %[cur]")
     A("s_waitcnt lgkmcnt(0)")
@@ -436,7 +576,7 @@ def generate():
     A("s_nop 15")
     if not FUSED:
         A(f"v_add_u32 v{V_TMP}, %[priv], v{V_LANE16}")
-        for i in range(24):
+        for i in range(8 * NT):
             for r in range(4):
                 A(f"v_accvgpr_read_b32 v{V_T + (i % 2) * 4 + r}, a{4 * i + r}")
             A(f"ds_write_b128 v{V_TMP}, {vr(V_T + (i % 2) * 4)} offset:{1024 * i}")
@@ -453,6 +593,7 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--out-dir="):
             out_dir = a.split("=", 1)[1]
+    assert not NT4 or FUSED, "--nt=4 exists inside the encoder-stack statement only (tools/gen_h3_enc_asm.py --dense --nt=4)"
     base = os.path.join(out_dir, "tw_h3_attnd_asm.inc")
     out = ["// GENERATED by tools/gen_h3_dense_attn_asm.py - do not edit.  Body of the dense-softmax attention asm statement."]
     out += ['"' + l + '\\n\\t"' for l in lines]

@@ -84,6 +84,10 @@ WIDE = "--wide" in sys.argv
 # --dense: the dense softmax model (transformer_nvp; BASELINE configs[4]): the attention block is gen_h3_dense_attn_asm.py's,
 # whose operands are the split activations themselves (B operand of q / k, A operand of v) in a96..a191 - no transposed copy.
 # With --h1 the MLP sections are the single-MFMA ones, the attention block stays in split form (csrc: "MLP sections only").
+# --dense --nt=4 (r06, tw_h3n4d_enc_asm.inc): the dense model on 64-token waves - one molecule of 49-64 atoms per wave; the
+# softmax block in two query halves (gen_h3_dense_attn_asm.py --nt=4), y in a0..a127 and the split activations in a128..a255 (all
+# 256 AGPRs), the side block SINGLE-buffered (160 KiB of LDS are full: three-slot ring + 4 x 32 KiB + 5 KiB) - fetched at the
+# top of a layer behind a barrier and waited for there, ~2 us per layer.
 DENSE = "--dense" in sys.argv
 STATELESS = NT4 or WIDE or DENSE  # the glue keeps nothing in VGPRs across the embedded blocks; pointers in SGPRs
 # --ring6 (48-token kernel-attention build only - the one layout with 9 KiB of LDS to spare): six stage buffers, the FFN's
@@ -104,12 +108,15 @@ H1A = H1 and not DENSE          # does the attention block take hi halves only?
 attn.FUSED = True
 if not (WIDE or DENSE):
     attn.WINDOWED = WINDOWED
+if not WIDE:
     assert attn.NT4 == NT4
 if not STATELESS:
     attn.XT_AGPR = 96   # the transposed copy of x lives in a96..a191 from the transposer to the end of the attention block
 ffn.FUSED = True
 ffn.SHAPE = ffn.SHAPES["ffn"]
-assert ffn.NT4 == NT4 and not (NT4 and WINDOWED) and not (WIDE and (NT4 or WINDOWED)) and not (DENSE and (NT4 or WINDOWED or WIDE))
+assert ffn.NT4 == NT4 and not (NT4 and WINDOWED) and not (WIDE and (NT4 or WINDOWED)) and not (DENSE and (WINDOWED or WIDE))
+assert not (DENSE and NT4 and H1), "dense model on 64-token waves: the split-fp16 statement only"
+DENSE1 = DENSE and NT4          # single-buffered side block
 
 NT = 4 if NT4 else 3
 SIDE_CHUNKS = 5 if DENSE else 3
@@ -163,7 +170,11 @@ if NT4:
     S_LO = 56
     PADM = "%[padm]"
     XBX = lambda ks, jt, part: 32 * (ks % 2) + 8 * jt + 4 * part        # exit staging: two k-steps of images in v0..v63
-    attn.SF_BASE = f"s[{S_SFB}:{S_SFB + 1}]"
+    if DENSE:
+        S_SLCUR, S_SLOTHER, S_OSC, S_SWAP = 56, 57, 76, 75     # (S_SFB's pair: this model has no score fragments)
+        attn.SL = f"s{S_SLCUR}"
+    else:
+        attn.SF_BASE = f"s[{S_SFB}:{S_SFB + 1}]"
 elif WIDE or DENSE:
     # the 48-token map; v224.. are scratch here, rebuilt per phase (the six-group attention statement owns v0..v239, the
     # dense one v0..v219)
@@ -328,9 +339,11 @@ def layer_norm(inv_sgpr, w_off, b_off, label, pre_bias=None):
     for jt in range(NT):
         A(f"v_mov_b32 v{S2(jt)}, 0")
         A(f"v_mov_b32 v{S2(jt) + 1}, 0")
+    # (64-token map: V_C2 shares registers with the sums S2 - the -mean pair of tile 0, written only in P2, carries the constant)
+    V_PB = NM(0) if NT4 else V_C2
     if pre_bias is not None:
-        A(f"v_mov_b32 v{V_C2}, s{inv_sgpr}")
-        A(f"v_mov_b32 v{V_C2 + 1}, s{inv_sgpr}")
+        A(f"v_mov_b32 v{V_PB}, s{inv_sgpr}")
+        A(f"v_mov_b32 v{V_PB + 1}, s{inv_sgpr}")
         A(f"ds_read_b128 {vr(PRM(0, 0), 4)}, v{V_SLG} offset:{4 * pre_bias}")
     # P1: t = acc, sums
     for ft in range(8):
@@ -345,7 +358,7 @@ def layer_norm(inv_sgpr, w_off, b_off, label, pre_bias=None):
             else:
                 A("s_waitcnt lgkmcnt(0)")
             for h in range(2):
-                A(f"v_pk_mul_f32 {vr(PRM(buf, 0) + 2 * h)}, {vr(PRM(buf, 0) + 2 * h)}, {vr(V_C2)}")
+                A(f"v_pk_mul_f32 {vr(PRM(buf, 0) + 2 * h)}, {vr(PRM(buf, 0) + 2 * h)}, {vr(V_PB)}")
             for h in range(2):
                 for jt in range(NT):
                     A(f"v_pk_fma_f32 {vr(T(ft, jt) + 2 * h)}, {vr(PRM(buf, 0) + 2 * h)}, {vr(V_ONE)}, {vr(T(ft, jt) + 2 * h)}")
@@ -557,10 +570,11 @@ def dense_operands(seed_sgpr):
         for jt in range(NT):
             hi, lo = U(jt), U(jt) + 2
             s = split_tile(T(ft, jt), hi, lo, TMP(jt), h1=False)
-            s += [f"v_accvgpr_write_b32 a{attn.XB(ks, jt, 'h') + 2 * odd + k}, v{hi + k}" for k in range(2)]
-            s += [f"v_accvgpr_write_b32 a{attn.XB(ks, jt, 'l') + 2 * odd + k}, v{lo + k}" for k in range(2)]
+            mv = "v_mov_b32 v" if attn.XB_CLS(ks, jt) == "v" else "v_accvgpr_write_b32 a"   # (64-token build: one operand pair lives in VGPRs)
+            s += [f"{mv}{attn.XB(ks, jt, 'h') + 2 * odd + k}, v{hi + k}" for k in range(2)]
+            s += [f"{mv}{attn.XB(ks, jt, 'l') + 2 * odd + k}, v{lo + k}" for k in range(2)]
             streams.append(s)
-        L += interleave(streams[0], streams[1]) + streams[2]
+        L += by_pairs(streams) if NT4 else interleave(streams[0], streams[1]) + streams[2]
         L += seed_attention(ft)
     return L
 
@@ -663,6 +677,18 @@ def layer_top():
     it is older than every weight stage of the layer, the first hand-off inside the attention block covers it)."""
     L = ["s_waitcnt lgkmcnt(0)", "s_barrier",
          "s_cmp_lg_u32 %[wave], 0", "s_cbranch_scc1 .Lenc_noside_%="]
+    if DENSE1:
+        # single buffer: THIS layer's block, now that every wave is done with the previous one's (the barrier above); wave 0 waits
+        # for it and a second barrier lets the others in - the attention block reads biases and the in_proj scale at its very entry
+        L += [f"s_mov_b32 m0, s{S_SLCUR}", "s_nop 0",
+              f"v_mbcnt_lo_u32_b32 v{TMP(0)}, -1, 0", f"v_mbcnt_hi_u32_b32 v{TMP(0)}, -1, v{TMP(0)}", f"v_lshlrev_b32 v{TMP(0)}, 4, v{TMP(0)}"]
+        for i in range(4):
+            L.append(f"global_load_lds_dwordx4 v{TMP(0)}, {sr(S_SIDE)}" + (f" offset:{1024 * i}" if i else ""))
+        L += [f"s_add_u32 m0, s{S_SLCUR}, 4096", f"v_add_u32 v{TMP(0) + 1}, 4096, v{TMP(0)}",
+              f"global_load_lds_dwordx4 v{TMP(0) + 1}, {sr(S_SIDE)}",
+              f"s_add_u32 s{S_SIDE}, s{S_SIDE}, %[sidestride]", f"s_addc_u32 s{S_SIDE + 1}, s{S_SIDE + 1}, 0",
+              "s_waitcnt vmcnt(0)", ".Lenc_noside_%=:", "s_barrier"]
+        return L
     if DENSE:
         # double-buffered: this layer's block arrived a layer ago (layer 0's: the kernel's prologue); fetch the NEXT layer's
         # into the other buffer, which every wave has finished reading (LayerNorm 2 of the previous layer; the barrier above)
@@ -688,7 +714,11 @@ def generate():
     L = []
     A = L.append
     # ---- persistent registers
-    if DENSE:
+    if DENSE1:
+        A(f"s_mov_b32 s{S_SLCUR}, %[sl]")
+        A(f"s_mov_b64 {sr(S_SIDE)}, %[side]")                              # layer_top() fetches every layer's block itself
+        L += lane_addr(V_PRIV16, "priv", 4, TMP(0))
+    elif DENSE:
         A(f"s_mov_b32 s{S_SLCUR}, %[sl]")
         A(f"s_add_u32 s{S_SLOTHER}, %[sl], {SIDE_LDS_BYTES}")
         A(f"s_mov_b64 {sr(S_SIDE)}, %[side]")                              # layer 0's block is in flight already:
@@ -806,7 +836,7 @@ def generate():
     A(f"s_mov_b32 s{S_SCA}, s{S_NA}")
     A(f"s_mov_b32 s{S_SCF}, s{S_NF}")
     A(f"s_sub_u32 s{S_IF}, 0x7f000000, s{S_SCF}")
-    if DENSE:   # the next layer's side block is the other buffer
+    if DENSE and not DENSE1:   # the next layer's side block is the other buffer
         A(f"s_mov_b32 s{S_SWAP}, s{S_SLCUR}")
         A(f"s_mov_b32 s{S_SLCUR}, s{S_SLOTHER}")
         A(f"s_mov_b32 s{S_SLOTHER}, s{S_SWAP}")
@@ -836,7 +866,7 @@ def main():
     open(base, "w").write("\n".join(out) + "\n")
     if not WINDOWED:
         # (wide: the attention block's fragments reach a159, the FFN's operands a119, nothing of the glue lives in AGPRs)
-        clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(160 if WIDE else 192)] + [f'"s{i}"' for i in range(S_LO, 100)] + \
+        clob = [f'"v{i}"' for i in range(N_V)] + [f'"a{i}"' for i in range(160 if WIDE else 248 if DENSE1 else 192)] + [f'"s{i}"' for i in range(S_LO, 100)] + \
                ['"vcc"', '"scc"', '"memory"']
         cl = [f"// GENERATED by tools/gen_h3_enc_asm.py{mode} - clobber list of the encoder-stack asm statement."]
         for i in range(0, len(clob), 12):
