@@ -372,6 +372,129 @@ def test_dense_attention_statement_under_adversarial_completion(argv):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
+# The WHOLE encoder-stack statements (tools/gen_h3_enc_asm.py): attention block, LayerNorm glue, FFN, the layer loop, the
+# per-layer side-block DMA (which nobody waits for explicitly: "the first hand-off inside the attention block covers it"),
+# the barriers that stand between one wave's X^T writes and another's reads (wide / paired layouts), the dense model's
+# double-buffered side block.  Differential again: two layers of every product statement in the kernel's own LDS layout,
+# in-order run = reference, the adversarial runs must reproduce its operand images for the out-MLP bit for bit.
+# ---------------------------------------------------------------------------------------------------------------------------
+ENC_VARIANTS = [(), ("--mode=windowed",), ("--ring6",), ("--mode=windowed", "--ring6"), ("--h1",), ("--h1", "--ring6"), ("--mode=windowed", "--h1", "--ring6"),
+                ("--nt=4",), ("--nt=4", "--h1"), ("--nt=4", "--pair"), ("--nt=4", "--pair", "--h1"),
+                ("--wide",), ("--wide", "--h1"), ("--wide", "--ng=3"), ("--wide", "--ng=6"), ("--wide", "--ng=6", "--h1"),
+                ("--dense",), ("--dense", "--h1"), ("--dense", "--nt=4")]
+
+
+def run_enc(enc, late_vmem, late_lds, order, seed=7, layers=2, heads=2, chunks=2):
+    rng = np.random.default_rng(seed)
+    NT, ffn, attn = enc.NT, enc.ffn, enc.attn
+    ring = ffn.RING
+    wave_lds = 32768 if enc.NT4 else 28672 if enc.WIDE else 24576             # csrc H3N4_WAVE_LDS / H3W_WAVE_LDS / H3(D)_WAVE_LDS
+    priv0 = ring * STAGE
+    sl = priv0 + 4 * wave_lds
+    side_stride = 1024 * enc.SIDE_CHUNKS
+    assert sl + (2 if enc.DENSE and not enc.NT4 else 1) * side_stride <= 160 * 1024   # (dense on 64-token waves: single-buffered)
+    att_stages = 32 if enc.DENSE else heads * 4 * (1 if enc.H1 else 2)
+    n_stages = layers * (att_stages + chunks * (2 if enc.H1 else 4))
+    small = lambda n: (rng.integers(-512, 512, n).astype(np.float32) / 1024).astype(np.float16).view(np.uint8)
+    stream = small((n_stages + ffn.AHEAD + 2) * STAGE // 2)
+    sf_head = 0 if enc.DENSE else (attn.NG * NT * attn.FRAG_BLOCK if enc.WIDE else NT * attn.SF_BYTES)
+    sf_layer = (heads + 2) * sf_head
+    sf = small(max(4 * (layers + 1) * sf_layer // 2, 8))
+    side = (rng.standard_normal((layers + 1) * side_stride // 4) * 0.3).astype(np.float32)
+    for l in range(layers + 1):
+        side[l * side_stride // 4 + 640:l * side_stride // 4 + 643] = 0.25      # (dense: the attention block's scales)
+    scales = np.full(64, 0.25, np.float32)
+    dump = np.zeros(4096, np.uint8)
+    parts = [stream, sf, side.view(np.uint8), scales.view(np.uint8), dump]
+    offs = np.cumsum([0] + [len(p) for p in parts])
+    gmem = np.concatenate(parts)
+    lds = np.zeros(160 * 1024, np.uint8)
+    lds[:ffn.AHEAD * STAGE] = stream[:ffn.AHEAD * STAGE]
+    if enc.DENSE:   # layer 0's side block is in flight when the statement starts (the kernel's prologue): here it has landed
+        lds[sl:sl + side_stride] = side[:side_stride // 4].view(np.uint8)
+    ops = {"cur": "s40", "gn": "v[252:253]", "ring": "s41", "wave": "s42", "priv": "s43", "chunks": "s44", "heads": "s45",
+           "layers": "s46", "sl": "s47", "eps": "s54", "padt": "s55", "padm": "v247", "stampen": "s39", "scales": "s[52:53]",
+           "xt": "s30", "win": "s31"}
+    if enc.STATELESS:
+        ops.update(sf="s[36:37]", sfstride="s48", sfstridehi="s49", side="s[34:35]", sidestride="s50", dump="s[32:33]")
+        ops.update({f"m{jt}{p}": f"v{248 + 2 * jt + k}" if jt < 2 else f"v{254 + k}" for jt in range(3) for k, p in enumerate("lh")})
+    else:
+        ops.update(sf="v[250:251]", sfstride="s[48:49]", side="v[248:249]", sidestride="s[50:51]", dump="v[254:255]")
+    waves = []
+    lane = np.arange(64, dtype=np.uint64)
+    lo, hi = (lambda a: (a & np.uint64(0xFFFFFFFF)).astype(np.uint32)), (lambda a: (a >> np.uint64(32)).astype(np.uint32))
+    for w in range(4):
+        wv = E.Wave(lds=lds, gmem=gmem, gbase=GBASE, wave_id=w)
+        wv.late_vmem, wv.late_lds = late_vmem, late_lds
+        priv = priv0 + w * wave_lds
+        lds[priv:priv + 8 * NT * 1024] = rng.standard_normal(8 * NT * 256).astype(np.float32).view(np.uint8)   # x: fp32 images
+        gn = np.uint64(GBASE + ffn.AHEAD * STAGE) + 16 * lane
+        wv.v[252], wv.v[253] = lo(gn), hi(gn)
+        sfp = np.uint64(GBASE + offs[1] + w * (layers + 1) * sf_layer)
+        sidep = np.uint64(GBASE + offs[2])
+        scp, dmp = GBASE + int(offs[3]), GBASE + int(offs[4])
+        wv.s[52], wv.s[53] = scp & 0xFFFFFFFF, scp >> 32
+        if enc.STATELESS:
+            wv.s[36], wv.s[37] = int(sfp) & 0xFFFFFFFF, int(sfp) >> 32
+            wv.s[48], wv.s[49], wv.s[50] = sf_layer, 0, side_stride
+            wv.s[34], wv.s[35] = int(sidep) & 0xFFFFFFFF, int(sidep) >> 32
+            wv.s[32], wv.s[33] = dmp & 0xFFFFFFFF, dmp >> 32
+            for r in (248, 249, 250, 251, 254, 255):
+                wv.v[r] = np.uint32(0xFFFFFFFF if w % 2 == 0 else 0x0FFF0FFF)
+        else:
+            wv.v[250], wv.v[251] = np.uint32(int(sfp) & 0xFFFFFFFF), np.uint32(int(sfp) >> 32)
+            wv.s[48], wv.s[49], wv.s[50], wv.s[51] = sf_layer, 0, side_stride, 0
+            sl_lane = sidep + 16 * lane
+            wv.v[248], wv.v[249] = lo(sl_lane), hi(sl_lane)
+            wv.v[254], wv.v[255] = np.uint32(dmp & 0xFFFFFFFF), np.uint32(dmp >> 32)
+        # padding: the last five tokens of the wave's last tile (one bit per token tile in the lane's mask word)
+        pad = np.zeros(64, np.uint32)
+        pad[(np.arange(64) % 16) >= 11] = 1 << (NT - 1)
+        wv.v[247] = pad
+        wv.s[55] = 1 << (NT - 1)
+        wv.s[54] = np.float32(1e-5).view(np.uint32)
+        wv.s[39], wv.s[40], wv.s[41], wv.s[42], wv.s[43] = 0, 0, 0, w, priv
+        wv.s[44], wv.s[45], wv.s[46], wv.s[47] = chunks, heads, layers, sl
+        if enc.WIDE and not enc.NT4:
+            wv.s[30], wv.s[31] = priv0, 32 * min(3 * w, 12 - 2 * attn.NG)
+        waves.append(wv)
+    E.run_waves(waves, enc.generate(), [ops] * 4, order=order)
+    out = []
+    for w, wv in enumerate(waves):
+        vm, lg = wv.in_flight()
+        assert "reg" not in vm, "a register load is still in flight when the statement ends"
+        assert not lg
+        assert int(wv.s[40]) == n_stages % ring
+        priv = priv0 + w * wave_lds
+        out.append(lds[priv:priv + wave_lds].copy())    # the out-MLP's operand images (and whatever else the block holds)
+    return out
+
+
+@pytest.mark.parametrize("argv", ENC_VARIANTS, ids=lambda a: " ".join(a) or "48-token")
+def test_encoder_stack_statement_under_adversarial_completion(argv):
+    enc = load_gen("gen_h3_enc_asm", argv)
+    ref = run_enc(enc, False, False, None)
+    if not enc.H1:   # 4 k-steps x NT token tiles x (hi, lo) images of LayerNorm output: finite, not all zero
+        imgs = [r[:8 * enc.NT * 1024].view(np.float16).astype(np.float32) for r in ref]
+        assert all(np.isfinite(f).all() and 0.5 < np.abs(f).max() < 50 for f in imgs)
+    for mode in (MODES[1], MODES[2], MODES[3]):   # DMA late (both wave orders), reads late
+        got = run_enc(enc, *mode)
+        for w in range(4):
+            assert np.array_equal(got[w], ref[w]), (argv, mode, w)
+
+
+def test_the_checker_sees_a_missing_barrier_between_partner_waves(monkeypatch):
+    """Paired layout: a wave mixes against its partner's X^T images, which the partner writes in the glue of the layer before;
+    the barrier at the top of a layer is what stands between the two.  Without it the runs depend on the wave order."""
+    enc = load_gen("gen_h3_enc_asm", ("--nt=4", "--pair"))
+    real = enc.layer_top
+    monkeypatch.setattr(enc, "layer_top", lambda: [l for l in real() if l != "s_barrier"])
+    a = run_enc(enc, False, False, None)
+    b = run_enc(enc, False, False, [3, 2, 1, 0])
+    assert any(not np.array_equal(a[w], b[w]) for w in range(4))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
 # r06: the dense softmax block NUMERICALLY - the differential test above says that the statement does not depend on when its
 # memory operations land, not that it computes attention.  Here one layer's block runs on the emulator over a random packed
 # stage stream and is held to a float64 restatement of nn.MultiheadAttention's arithmetic on the same operands (in_proj with
