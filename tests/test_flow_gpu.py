@@ -820,6 +820,13 @@ def test_per_op_path_large_molecules(path):
         finally:
             lib.tw_debug_set_flags(0)
         assert H.rel_err(out4.cpu(), ref) < TOL
+        try:   # bit 28: the in / out MLPs as two GEMMs each instead of one launch of the fused kernels' statements on the token list
+            lib.tw_debug_set_flags(268435456)
+            out5 = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                                    y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+        finally:
+            lib.tw_debug_set_flags(0)
+        assert H.rel_err(out5.cpu(), ref) < TOL and not torch.equal(out5, out)
         # the dense softmax variant above its fused layouts (65+ atoms): q / k / v and output projections, in / out MLPs on the
         # split-fp16 GEMMs, the FFN through the fused launches, the softmax attention itself in fp32
         dsd = H.full_dense_sd()
@@ -836,6 +843,13 @@ def test_per_op_path_large_molecules(path):
                                   adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda()).cpu()
         refd = fo.log_likelihood(dsd, H.FULL_DENSE_SPEC, at, xx, vv, yy, vv, mk)
         assert H.rel_err(outd, refd) < TOL, H.rel_err(outd, refd)
+        try:
+            lib.tw_debug_set_flags(268435456)
+            outd2 = md5.log_likelihood(atom_types=at.cuda(), x_coords=xx.cuda(), x_velocs=vv.cuda(), y_coords=yy.cuda(), y_velocs=vv.cuda(),
+                                       adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda()).cpu()
+        finally:
+            lib.tw_debug_set_flags(0)
+        assert H.rel_err(outd2, refd) < TOL, H.rel_err(outd2, refd)
         H.assert_not_demoted(md5)
     if path != 0:
         return

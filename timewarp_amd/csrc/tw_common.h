@@ -291,6 +291,10 @@ int64_t simple_h3_fold_floats(const tw_flow_desc& d);   // tw_flow_pack_simple_h
 int simple_h3_fold(const tw_flow_desc& d, const float* raw, float* out, hipStream_t s);
 int h3_ffn_tokens(const tw_flow_desc& d, const void* packed, int coupling, int net, int layer, float* h, int64_t n_tokens,
                   hipStream_t stream);
+// ... and the in-MLP (u [n_tokens, d_in <= 64] -> h [n_tokens, 128]) / out-MLP (h -> o [n_tokens, 3]) of (coupling, net)
+bool h3_io_tokens_supported(const tw_flow_desc& d);
+int h3_io_tokens(const tw_flow_desc& d, const void* packed, int coupling, int net, bool out, const float* in, float* res, int d_in,
+                 int64_t n_tokens, hipStream_t stream);
 int profile_begin();
 int profile_end(double* total_ms, int64_t* launches);
 

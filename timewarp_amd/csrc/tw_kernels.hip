@@ -1508,8 +1508,15 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
                      a.x_velocs, z_other, rff, d.d_rff, a.n_cond, V, d.d_emb, L.d_in, w.u, M);
   TW_LAUNCH_CHECK();
   int rc;
+  // TW_PATH_SIMPLE_H3 with the split-fp16 stream at hand: each of the two MLPs as ONE launch of the fused kernels' generated
+  // statement on the flat token list, its hidden layer on the chip (bit 28: as two GEMMs each - A/B, tests)
+  const bool io_tokens = sp && a.packed && h3_io_tokens_supported(d) && L.d_in <= 64 && !(g_debug_flags & (16777216 | 268435456));
+  if (io_tokens) {
+    if ((rc = h3_io_tokens(d, a.packed, c, net, false, w.u, w.h, L.d_in, M, s))) return rc;
+  } else {
   if ((rc = launch_linear(w.u, nb + L.net.in0_w, nb + L.net.in0_b, w.h0, M, d.d_hidden, L.d_in, ACT_SILU, s, sp))) return rc;
   if ((rc = launch_linear(w.h0, nb + L.net.in2_w, nb + L.net.in2_b, w.h, M, d.d_model, d.d_hidden, ACT_NONE, s, sp))) return rc;
+  }
   const int64_t act_sz = M * d.d_model;
   if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump, w.h, act_sz * 4, hipMemcpyDeviceToDevice, s));
   for (int l = 0; l < d.n_layers; ++l) {
@@ -1626,8 +1633,12 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
     }
     if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump + (l + 1) * act_sz, w.h, act_sz * 4, hipMemcpyDeviceToDevice, s));
   }
+  if (io_tokens) {
+    if ((rc = h3_io_tokens(d, a.packed, c, net, true, w.h, out, 0, M, s))) return rc;
+  } else {
   if ((rc = launch_linear(w.h, nb + L.net.out0_w, nb + L.net.out0_b, w.h0, M, d.d_hidden, d.d_model, ACT_SILU, s, sp))) return rc;
   if ((rc = launch_linear(w.h0, nb + L.net.out2_w, nb + L.net.out2_b, out, M, 3, d.d_hidden, ACT_NONE, s, sp))) return rc;
+  }
   if (dump) TW_HIP_CHECK(hipMemcpyAsync(dump + (d.n_layers + 1) * act_sz, out, M * 3 * 4, hipMemcpyDeviceToDevice, s));
   return TW_OK;
 }

@@ -2851,6 +2851,129 @@ __global__ void __launch_bounds__(256) h3_ffn_tokens_kernel(H3FfnParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The in-MLP and the out-MLP of a net block on the flat token list, the same way (tw_h3_in_asm.inc / tw_h3_out_asm.inc):
+//   IN :  h = W2 silu(W0 u + b0) + b2     u [n_tokens, d_in <= 64] (build_input_kernel)  ->  h [n_tokens, 128]
+//   OUT:  o = W2 silu(W0 h + b0) + b2     h [n_tokens, 128]                              ->  o [n_tokens, 3]
+struct H3IoParams {
+  const char* stages;   // first stage of the section in the tw_flow_pack_h3 stream
+  const float* bias2;   // second-layer bias in the net's side floats (in: 128, out: 16)
+  const float* scale2;  // second-layer output scale (a 2^-s multiplier the pack kernels wrote)
+  const float* in;      // IN: u [n_tokens, d_in];  OUT: h [n_tokens, 128]
+  float* out;           // IN: h [n_tokens, 128];   OUT: o [n_tokens, 3]
+  int64_t n_tokens;
+  int d_in, chunks;
+};
+
+template <bool OUT>
+__global__ void __launch_bounds__(256) h3_io_tokens_kernel(H3IoParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NT = H3_NT;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, i16 = lane & 15;
+  H3Pipe pipe;
+  pipe.gnext = p.stages + lane * 16;
+  pipe.lds = lds;
+  pipe.cur = 0;
+  pipe.wave = wave;
+  pipe.debug = 0;
+  pipe.ring = H3_RING;
+  pipe.start_issue();
+  char* priv = lds + H3_RING * H3_STAGE_BYTES + wave * H3_WAVE_LDS;
+  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * NT);
+  const float sc = *p.scale2;
+  if constexpr (OUT) {
+    f4 x[8][NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const int64_t t = t0 + 16 * jt + i16;
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft)
+        x[ft][jt] = t < p.n_tokens ? *(const f4*)(p.in + t * 128 + 16 * ft + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    BOp<NT> xb[4];
+    to_bop<NT, 4>(x, xb);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        *(h8*)(priv + ((ks * NT + jt) * 2) * 1024 + lane * 16) = xb[ks].h[jt];
+        *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = xb[ks].l[jt];
+      }
+  } else {
+    // u in B-operand element order: k-step ks, element e <-> column 32 ks + 16 (e / 4) + 4 g + e % 4 (columns >= d_in: zero)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const int64_t t = t0 + 16 * jt + i16;
+        f4 a = (f4){0.f, 0.f, 0.f, 0.f}, b = (f4){0.f, 0.f, 0.f, 0.f};
+        if (t < p.n_tokens) {
+          const float* row = p.in + t * p.d_in;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c0 = 32 * ks + 4 * g + r, c1 = c0 + 16;
+            a[r] = c0 < p.d_in ? row[c0] : 0.f;
+            b[r] = c1 < p.d_in ? row[c1] : 0.f;
+          }
+        }
+        h8 hi, lo;
+        split8(a, b, hi, lo);
+        *(h8*)(priv + ((ks * NT + jt) * 2) * 1024 + lane * 16) = hi;
+        *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = lo;
+      }
+  }
+  pipe.start_wait();
+  {
+    int cur = 0;
+    const char* gn = pipe.gnext;
+    const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
+    const int chunks = __builtin_amdgcn_readfirstlane(p.chunks);
+    if constexpr (OUT) {
+      asm volatile(
+#include "tw_h3_out_asm.inc"
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+          :
+#include "tw_h3_out_clobbers.inc"
+      );
+    } else {
+      asm volatile(
+#include "tw_h3_in_asm.inc"
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+          :
+#include "tw_h3_in_clobbers.inc"
+      );
+    }
+  }
+  if constexpr (OUT) {
+    const f4 bb = *(const f4*)(p.bias2 + 4 * g);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const f4 o = *(const f4*)(priv + jt * 1024 + lane * 16) * sc + bb;
+      const int64_t t = t0 + 16 * jt + i16;
+      if (g == 0 && t < p.n_tokens) {
+        p.out[t * 3 + 0] = o[0];
+        p.out[t * 3 + 1] = o[1];
+        p.out[t * 3 + 2] = o[2];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+      const f4 bb = *(const f4*)(p.bias2 + 4 * g + 16 * ot);
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const int64_t t = t0 + 16 * jt + i16;
+        if (t < p.n_tokens) *(f4*)(p.out + t * 128 + 16 * ot + 4 * g) = *(const f4*)(priv + (ot * NT + jt) * 1024 + lane * 16) * sc + bb;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-fetched stages land before the LDS goes
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -3234,6 +3357,44 @@ int h3_ffn_tokens(const tw_flow_desc& d, const void* packed, int coupling, int n
   const int64_t wgs = (n_tokens + 4 * 16 * H3_NT - 1) / (4 * 16 * H3_NT);
   TW_REQUIRE(wgs < (int64_t)1 << 31, "FFN: %lld workgroups", (long long)wgs);
   hipLaunchKernelGGL(h3_ffn_tokens_kernel, dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  TW_LAUNCH_CHECK();
+  return TW_OK;
+}
+
+// in-MLP (out == false) / out-MLP of (coupling, net) on the flat token list; d_in <= 64 (no position features)
+bool h3_io_tokens_supported(const tw_flow_desc& d) {
+  return h3_ffn_tokens_supported(d) && d.d_emb + 9 <= 64 && !(d.variant == 1 && d.d_rff > 0);
+}
+
+int h3_io_tokens(const tw_flow_desc& d, const void* packed, int coupling, int net, bool out, const float* in, float* res, int d_in,
+                 int64_t n_tokens, hipStream_t stream) {
+  TW_REQUIRE(packed && h3_io_tokens_supported(d) && d_in <= 64, "in / out MLP on the split-fp16 stream: unsupported model or no stream");
+  const H3Geom g = h3_geom(d);
+  const int64_t att_stages = d.variant == 1 ? 4LL * g.H : 8LL * g.H;
+  const int64_t first = out ? (int64_t)(g.in_a_stages + 2) * g.hid_chunks + (int64_t)g.L * (att_stages + 4LL * g.ff_chunks) : 0;
+  const char* net_base = (const char*)packed + (int64_t)(coupling * 2 + net) * g.net_stride_bytes;
+  const float* side = (const float*)(net_base + g.stages * H3_STAGE_BYTES);
+  H3IoParams p;
+  p.stages = net_base + first * H3_STAGE_BYTES;
+  p.bias2 = side + (out ? g.side_out2b : g.side_in2b);
+  p.scale2 = side + g.side_scales + (out ? 2 + 3 * g.L + 1 : 1);   // scales: in0, in2, per layer (wc, w1, w2), out0, out2
+  p.in = in;
+  p.out = res;
+  p.n_tokens = n_tokens;
+  p.d_in = d_in;
+  p.chunks = g.hid_chunks;
+  constexpr int lds = H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS;
+  static LdsLimit lim_in, lim_out;
+  int rc;
+  const int64_t wgs = (n_tokens + 4 * 16 * H3_NT - 1) / (4 * 16 * H3_NT);
+  TW_REQUIRE(wgs < (int64_t)1 << 31, "in / out MLP: %lld workgroups", (long long)wgs);
+  if (out) {
+    if ((rc = lim_out.ensure((const void*)h3_io_tokens_kernel<true>, lds))) return rc;
+    hipLaunchKernelGGL(h3_io_tokens_kernel<true>, dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  } else {
+    if ((rc = lim_in.ensure((const void*)h3_io_tokens_kernel<false>, lds))) return rc;
+    hipLaunchKernelGGL(h3_io_tokens_kernel<false>, dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  }
   TW_LAUNCH_CHECK();
   return TW_OK;
 }

@@ -7,6 +7,11 @@ from tests import helpers as H
 # --path=2 (default): the exact-f32 per-op kernels; --path=5: TW_PATH_SIMPLE_H3, the linears as split-fp16 MFMA GEMMs (r06)
 path = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--path=")), 2)
 m = H.tw_kernel_model(H.full_kernel_sd(), path=path)
+# --flags=N: tw_debug_set_flags(N) for A/B runs (e.g. 268435456: in / out MLPs as GEMM pairs)
+flags = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--flags=")), 0)
+if flags:
+    from timewarp_amd import _lib
+    _lib.load().tw_debug_set_flags(flags)
 g = torch.Generator().manual_seed(0)
 for spec in [a for a in sys.argv[1:] if not a.startswith("--")] or ["192x256"]:
     V, S = (int(t) for t in spec.split("x"))
