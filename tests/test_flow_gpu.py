@@ -827,6 +827,18 @@ def test_per_op_path_large_molecules(path):
         finally:
             lib.tw_debug_set_flags(0)
         assert H.rel_err(out5.cpu(), ref) < TOL and not torch.equal(out5, out)
+        # the FFN launch on 48-token waves (bit 29) and on 64-token waves (bit 30; the default picks whichever needs fewer rounds'
+        # worth of the chip): the same arithmetic per token, so the same bits
+        ffn = {}
+        for bit in (536870912, 1073741824):
+            try:
+                lib.tw_debug_set_flags(bit)
+                ffn[bit] = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                                            y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+            finally:
+                lib.tw_debug_set_flags(0)
+            assert H.rel_err(ffn[bit].cpu(), ref) < TOL, bit
+        assert torch.equal(ffn[536870912], out) and H.rel_err(ffn[1073741824].cpu(), out.cpu()) < 2e-6
         # the dense softmax variant above its fused layouts (65+ atoms): q / k / v and output projections, in / out MLPs on the
         # split-fp16 GEMMs, the FFN through the fused launches, the softmax attention itself in fp32
         dsd = H.full_dense_sd()

@@ -191,7 +191,10 @@ int launch_scores(const float* x, const uint8_t* masked, const float* ls, int H,
                   int normalise, int use_mm, float* out, hipStream_t s, const float* coeffs, int order, int force_zero) {
   if (B == 0) return TW_OK;
   size_t shm = (size_t)(3 * V + V * V) * sizeof(float);
-  if (shm > (size_t)160 * 1024 || (g_debug_flags & 2097152)) {  // no room for the distance tile (or bit 21): the row-wise kernel
+  // The row-wise kernel: no room for the distance tile (or bit 21) - and from 161 atoms on anyway: both kernels run one thread per
+  // (head, query) row through 2 V basis values, so a launch takes as long as one thread does; the tile kernel is one workgroup per
+  // conditioning state (200 atoms, one state: 590 us on one CU), the row-wise one H V / 256 of them (same arithmetic, bit-identical).
+  if (shm > (size_t)160 * 1024 || V > 160 || (g_debug_flags & 2097152)) {
     hipLaunchKernelGGL(scores_rows_kernel, dim3((unsigned)B, (unsigned)((H * V + 255) / 256)), dim3(256), (size_t)3 * V * sizeof(float), s,
                        x, masked, ls, H, V, normalise, use_mm, out, coeffs, order, force_zero);
     TW_LAUNCH_CHECK();
@@ -701,6 +704,16 @@ __global__ void __launch_bounds__(256) linear_h3_kernel(const float* __restrict_
   }
 }
 
+// Fragment-order layout of the split fp16 MFMA operands of the folded attention (S, x^T, Wc): a [rows (padded to 16), keys or features
+// (padded to 32)] matrix is stored as [k-tile of 32][row tile of 16][lane 16 g + i16][8 halves] - the 16 rows x 32 k of one 16 x 16 x 32
+// operand fragment are ONE contiguous KiB in which lane (i16 = row % 16, g = (k % 32) / 8) owns bytes 16 lane .. 16 lane + 15.  An
+// LDS-DMA instruction (lane l moves 16 bytes to LDS base + 16 l) then reads a KiB linearly and the fragment read is ds_read_b128 at
+// base + 16 lane.  (Against the row-major [row][32 k] tile it replaced: the same kernel time, 148 us per call at 256 atoms x 256 rows -
+// the layout is kept for its addressing, one add per piece.)
+__host__ __device__ __forceinline__ int64_t frag_off(int64_t row_tiles, int row, int k) {
+  return (((int64_t)(k >> 5) * row_tiles + (row >> 4)) * 64 + (((k & 31) >> 3) * 16 + (row & 15))) * 8 + (k & 7);
+}
+
 // Wc[n][h D + k] = sum_j W_o[n][h D + j] W_v[h D + j][k]  (fp64 sums, as the fused kernels' pack does): the value and output
 // projections of kernel attention folded per head (kernel_attention.py:124-156: out_proj(flatten(A_h (x W_v,h^T)))) = sum_h (A_h x) Wc_h^T
 __global__ void fold_vo_kernel(const float* __restrict__ raw, int64_t first_net, int64_t coupling_size, int64_t net_size,
@@ -731,8 +744,8 @@ __global__ void fold_vo_kernel(const float* __restrict__ raw, int64_t first_net,
       const int pos = 32 * ks + 8 * g + 4 * half + r;
       const float v = (float)acc * LH_WSCALE;
       const _Float16 hh = (_Float16)v;
-      ph[(int64_t)n * D + pos] = hh;
-      pl[(int64_t)n * D + pos] = (_Float16)(v - (float)hh);
+      ph[frag_off(D / 16, n, pos)] = hh;
+      pl[frag_off(D / 16, n, pos)] = (_Float16)(v - (float)hh);
     }
   }
 }
@@ -946,21 +959,26 @@ __global__ void __launch_bounds__(256) attend_h3_kernel(const float* __restrict_
 
 // The folded form's operands prepared ONCE instead of per workgroup (attend_h3_kernel splits the score tile again for every row n
 // that shares it and transposes the values on their way into the LDS):
-//   split_scores_kernel   scores [R, V] fp32 -> (hi, lo) fp16 [R, Vp], x 2^10, rows padded with zeros to Vp = 32 ceil(V / 32) keys -
-//                         once per flow pass (the scores are shared by every encoder layer and both nets)
-//   xt_split_kernel       x [n, V, D] fp32 -> x^T (hi, lo) fp16 [n, D, Vp] - once per (layer, net)
+//   split_scores_kernel   scores [B H, V, V] fp32 -> (hi, lo) fp16 [B H][Vp x Vp in fragment order (frag_off)], x 2^10, queries and
+//                         keys padded with zeros to Vp = 32 ceil(V / 32) - once per flow pass (the scores are shared by every encoder
+//                         layer and both nets)
+//   xt_split_kernel       x [n, V, D] fp32 -> x^T (hi, lo) fp16 [n][D x Vp in fragment order] - once per (layer, net)
 //   attend_h3p_kernel     att[n, q, h, :] = sum_m S_h[q, m] x[n, m, :]: both operands arrive as 16-byte fp16 vectors, k contiguous -
 //                         no VALU work between the loads and the MFMAs
 __global__ void split_scores_kernel(const float* __restrict__ s, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t rows,
                                     int V, int Vp) {
+  // rows = matrices x Vp (padded query rows included: zeros)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * Vp) return;
   const int64_t r = i / Vp;
   const int k = (int)(i - r * Vp);
-  const float v = k < V ? s[r * V + k] * AH_SSCALE : 0.f;
+  const int64_t mat = r / Vp;
+  const int q = (int)(r - mat * Vp);
+  const float v = (k < V && q < V) ? s[(mat * V + q) * V + k] * AH_SSCALE : 0.f;
   const _Float16 h = (_Float16)v;
-  hi[i] = h;
-  lo[i] = (_Float16)(v - (float)h);
+  const int64_t o = mat * Vp * Vp + frag_off(Vp / 16, q, k);
+  hi[o] = h;
+  lo[o] = (_Float16)(v - (float)h);
 }
 
 __global__ void __launch_bounds__(256) xt_split_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
@@ -978,7 +996,7 @@ __global__ void __launch_bounds__(256) xt_split_kernel(const float* __restrict__
     if (d0 + r >= D) continue;
     const float v = t[tx][r];   // key m0 + tx of feature d0 + r
     const _Float16 h = (_Float16)v;
-    const int64_t o = (n * D + d0 + r) * Vp + m0 + tx;
+    const int64_t o = n * D * (int64_t)Vp + frag_off((D + 15) / 16, d0 + r, m0 + tx);
     hi[o] = h;
     lo[o] = (_Float16)(v - (float)h);
   }
@@ -999,8 +1017,8 @@ __global__ void __launch_bounds__(256) attend_h3p_kernel(const _Float16* __restr
   const int64_t n = blk / H;
   const int64_t c = n % n_cond;
   const int q0 = tm * LH_BM;
-  const _Float16* Sh = s_hi + ((c * H + h) * V) * (int64_t)Vp;
-  const _Float16* Sl = s_lo + ((c * H + h) * V) * (int64_t)Vp;
+  const _Float16* Sh = s_hi + ((c * H + h) * Vp) * (int64_t)Vp;
+  const _Float16* Sl = s_lo + ((c * H + h) * Vp) * (int64_t)Vp;
   const _Float16* Xh = xt_hi + n * D * (int64_t)Vp;
   const _Float16* Xl = xt_lo + n * D * (int64_t)Vp;
   lin_f4 acc[4][4];
@@ -1016,9 +1034,9 @@ __global__ void __launch_bounds__(256) attend_h3p_kernel(const _Float16* __restr
       const int i = threadIdx.x + 256 * (t & 1), r = i >> 2, kq = 8 * (i & 3);
       lin_h8 v = (lin_h8){0, 0, 0, 0, 0, 0, 0, 0};
       if (t < 4) {
-        if (q0 + r < V) v = *(const lin_h8*)((t < 2 ? Sh : Sl) + (int64_t)(q0 + r) * Vp + k0 + kq);
+        if (q0 + r < V) v = *(const lin_h8*)((t < 2 ? Sh : Sl) + frag_off(Vp / 16, q0 + r, k0 + kq));
       } else if (r < D) {
-        v = *(const lin_h8*)((t < 6 ? Xh : Xl) + (int64_t)r * Vp + k0 + kq);
+        v = *(const lin_h8*)((t < 6 ? Xh : Xl) + frag_off((D + 15) / 16, r, k0 + kq));
       }
       nx[t] = v;
     }
@@ -1076,149 +1094,202 @@ __global__ void __launch_bounds__(256) attend_h3p_kernel(const _Float16* __restr
   }
 }
 
-// Mixing AND the folded projection in one launch (r06): per (row n, 128 queries), for every head
+// Mixing AND the folded projection in one launch (r06): per (row n, 64 J queries), for every head
 //   xm_h^T[d][q] = sum_m x^T[d][m] S_h[q][m]          (A = x^T rows, B = score rows: the transposed formulation of the fused kernels)
 //   y^T[c][q]   += sum_d Wc_h[c][d] xm_h[q][d]        (A = Wc_h rows; B = xm_h straight from the accumulators: lane (q, g) holds
 //                                                     features 16 t + 4 g + r of feature tile t, i.e. after the fp16 split the B operand
 //                                                     of k-step ks = tiles 2 ks, 2 ks + 1 in the element order the pack gave Wc)
 // so the [M, 768] mixing result never exists in memory (attend_h3p_kernel + the 768 -> 128 GEMM wrote and read 300 MB per call at
-// 192 x 256).  A wave owns 32 queries x all 128 features; every operand tile arrives by LDS-DMA (global_load_lds, 1 KiB per
-// instruction, unpadded [row][32 k] tiles: a fragment read of lanes (i16, g) covers one contiguous KiB) into two 32 KiB slots:
-// step s + 1 is in flight while step s computes, one vmcnt(0) + barrier per step.
-__global__ void __launch_bounds__(256) attend_fold_h3_kernel(const _Float16* __restrict__ s_hi, const _Float16* __restrict__ s_lo,
+// 192 x 256).  A wave owns 16 J queries x all 128 features (J = 2: 128 queries per workgroup, the one instantiated; J = 4: 256 - every
+// x^T / Wc fragment read from the LDS then feeds 12 MFMAs instead of 6, at one wave per SIMD).  Every operand tile arrives by LDS-DMA (global_load_lds, 1 KiB
+// per instruction, fragment-order tiles: frag_off) into a ring of NSLOT stage buffers [S hi | S lo | x^T hi | x^T lo]; NSLOT - 1 stages
+// are in flight while one computes; a counted vmcnt + barrier per step.
+// Registers: hipcc's own choice for J = 2 was 184 VGPRs + 96 AGPRs = one wave per SIMD, i.e. the two workgroups a CU's LDS holds ran
+// one after the other (256 atoms x 256 rows: 148 us per call); held to two waves per SIMD it takes 184 VGPRs, no AGPRs, no scratch.
+template <int J, int NSLOT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(J == 2 ? 2 : 1, J == 2 ? 2 : 1))) attend_fold_h3_kernel(const _Float16* __restrict__ s_hi, const _Float16* __restrict__ s_lo,
                                                               const _Float16* __restrict__ xt_hi, const _Float16* __restrict__ xt_lo,
                                                               const _Float16* __restrict__ wc_hi, const _Float16* __restrict__ wc_lo,
                                                               float* __restrict__ y, int64_t n_cond, int H, int V, int Vp,
                                                               float* __restrict__ hres, const float* __restrict__ lnw,
                                                               const float* __restrict__ lnb, float eps) {
-  extern __shared__ __attribute__((aligned(16))) char lh_lds[];   // 2 slots x [4 arrays][128 rows][32 halves]
-  constexpr int D = 128, SLOT = 4 * 128 * 64, ARR = 128 * 64;
+  extern __shared__ __attribute__((aligned(16))) char lh_lds[];
+  constexpr int D = 128, QB = 64 * J, NCH_S = QB / 16;
+  constexpr int S_ARR = NCH_S * 1024, X_ARR = 8 * 1024, X_OFF = 2 * S_ARR, SLOT = 2 * S_ARR + 2 * X_ARR;
+  constexpr int MIX_PER_WAVE = (2 * NCH_S + 16) / 4, FOLD_PER_WAVE = 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i16 = lane & 15, g = lane >> 4;
-  const int tiles_m = (V + 127) / 128;
+  const int tiles_m = (V + QB - 1) / QB;
   const int tm = (int)(blockIdx.x % tiles_m);
   const int64_t n = blockIdx.x / tiles_m;
   const int64_t c = n % n_cond;
-  const int q0 = tm * 128;
+  const int q0 = tm * QB;
   const int n1 = Vp / 32;
-  const int lrow = lane >> 2, lk = 8 * (lane & 3);
-  const _Float16* Xw = (wave == 2 ? xt_hi : xt_lo) + n * D * (int64_t)Vp;   // waves 2, 3 move x^T hi / lo
-  // issue the tiles of (head h, step st) into `slot`: st < n1: key step st of the mixing (wave 0: S hi, 1: S lo, 2: x^T hi, 3: x^T lo,
-  // eight 1 KiB pieces each); st >= n1: k-step st - n1 of the folded GEMM (waves 0, 1: Wc hi, 2, 3: Wc lo, four pieces each)
-  auto issue = [&](int h, int st, int slot) {
+  const int per_head = n1 + 4;
+  const int total = H * per_head;
+  const _Float16* Xh = xt_hi + n * D * (int64_t)Vp;
+  const _Float16* Xl = xt_lo + n * D * (int64_t)Vp;
+  // the tiles of global step t = (head, st) into `slot`; st < n1: key step st of the mixing; st >= n1: k-step st - n1 of the folded GEMM
+  // (Wc hi / lo in the x^T areas).  Piece i = wave + 4 k of the stage's list is this wave's k-th: uniform per wave.
+  auto issue = [&](int t, int slot) {
+    const int h = t / per_head, st = t - h * per_head;
     char* base = lh_lds + slot * SLOT;
     if (st < n1) {
-      const int k0 = 32 * st;
-      char* dst = base + wave * ARR;
 #pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
+      for (int k = 0; k < MIX_PER_WAVE; ++k) {
+        const int i = wave + 4 * k;
         const _Float16* src;
-        if (wave < 2) {
-          int row = q0 + 16 * ch + lrow;
-          row = row < V ? row : V - 1;   // rows past the molecule: any finite row (their results are dropped)
-          src = (wave == 0 ? s_hi : s_lo) + (((c * H + h) * V) + row) * (int64_t)Vp + k0 + lk;
+        char* dst;
+        if (i < 2 * NCH_S) {
+          const int ch = i < NCH_S ? i : i - NCH_S;
+          int rt = q0 / 16 + ch;
+          rt = rt < Vp / 16 ? rt : Vp / 16 - 1;   // query tiles past the padded molecule: any tile (their results are dropped)
+          src = (i < NCH_S ? s_hi : s_lo) + (c * H + h) * (int64_t)Vp * Vp + ((int64_t)st * (Vp / 16) + rt) * 512 + lane * 8;
+          dst = base + i * 1024;
         } else {
-          src = Xw + (int64_t)(16 * ch + lrow) * Vp + k0 + lk;
+          const int ch = (i - 2 * NCH_S) & 7;
+          src = (i - 2 * NCH_S < 8 ? Xh : Xl) + ((int64_t)st * (D / 16) + ch) * 512 + lane * 8;
+          dst = base + X_OFF + (i - 2 * NCH_S) * 1024;
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + ch * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst,
+                                         16, 0, 0);
       }
     } else {
       const int ks = st - n1;
-      const _Float16* W = (wave < 2 ? wc_hi : wc_lo) + (int64_t)h * D * D;
-      char* dst = base + (wave < 2 ? 0 : ARR) + (wave & 1) * 4096;
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        const _Float16* src = W + (int64_t)(64 * (wave & 1) + 16 * ch + lrow) * D + 32 * ks + lk;
+      for (int k = 0; k < FOLD_PER_WAVE; ++k) {
+        const int i = wave + 4 * k;   // 0 .. 7: Wc hi tile i; 8 .. 15: Wc lo tile i - 8
+        const _Float16* src = (i < 8 ? wc_hi : wc_lo) + (int64_t)h * D * D + ((int64_t)ks * (D / 16) + (i & 7)) * 512 + lane * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + ch * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(base + X_OFF + i * 1024), 16, 0, 0);
       }
     }
   };
-  auto landed = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (hipcc does not count LDS-DMA)
+  // this wave's LDS-DMA instructions of global step t (0 past the end)
+  auto pieces = [&](int t) -> int {
+    if (t >= total) return 0;
+    const int h = t / per_head;
+    return t - h * per_head < n1 ? MIX_PER_WAVE : FOLD_PER_WAVE;
+  };
+  // stage `t` has landed for every wave: at most `younger` of this wave's LDS-DMAs - the stages behind it - may still be in flight
+  // (hipcc does not count LDS-DMA; s_waitcnt takes an immediate)
+  auto landed = [&](int younger) {
+    switch (younger) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+      case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
     __syncthreads();
   };
-  auto frag = [&](int slot, int arr, int tile) -> lin_h8 {
-    return *(const lin_h8*)(lh_lds + slot * SLOT + arr * ARR + (16 * tile + i16) * 64 + g * 16);
+  auto younger_than = [&](int t) -> int {   // pieces of the stages t + 1 .. t + NSLOT - 2 (issued, not needed yet)
+    int sum = 0;
+#pragma unroll
+    for (int k = 1; k <= NSLOT - 2; ++k) sum += pieces(t + k);
+    return sum;
   };
-  lin_f4 acc_y[8][2];
+  auto frag = [&](int slot, int off, int tile) -> lin_h8 { return *(const lin_h8*)(lh_lds + slot * SLOT + off + tile * 1024 + lane * 16); };
+  lin_f4 acc_y[8][J];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc_y[t][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
-  const int per_head = n1 + 4;
-  const int total = H * per_head;
-  issue(0, 0, 0);
-  landed();
-  int step = 0;
+    for (int j = 0; j < J; ++j) acc_y[t][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
+  // a wave whose queries all lie past the molecule (the last query tile of 200 atoms: 224 .. 255) moves its share of the stages and
+  // meets the barriers, but leaves the matrix pipe to the other workgroup of its CU
+  const bool active = q0 + 16 * J * wave < V;
+#pragma unroll
+  for (int k = 0; k < NSLOT - 1; ++k)
+    if (k < total) issue(k, k);
+  landed(younger_than(0));
+  int step = 0, slot = 0;
+  auto next_slot = [&](int s_) { return s_ + 1 == NSLOT ? 0 : s_ + 1; };
+  int fill = NSLOT - 1;   // the slot the next issue goes to
   for (int h = 0; h < H; ++h) {
-    lin_f4 xm[8][2];
+    lin_f4 xm[8][J];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) xm[t][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < J; ++j) xm[t][j] = (lin_f4){0.f, 0.f, 0.f, 0.f};
     for (int st = 0; st < n1; ++st, ++step) {
-      const int slot = step & 1;
-      if (step + 1 < total) issue(st + 1 < per_head ? h : h + 1, st + 1 < per_head ? st + 1 : 0, slot ^ 1);
-      lin_h8 sh[2], sl[2];
+      if (step + NSLOT - 1 < total) issue(step + NSLOT - 1, fill);
+      fill = next_slot(fill);
+      lin_h8 sh[J], sl[J];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        sh[j] = frag(slot, 0, 2 * wave + j);
-        sl[j] = frag(slot, 1, 2 * wave + j);
+      for (int j = 0; j < J; ++j) {
+        sh[j] = frag(slot, 0, J * wave + j);
+        sl[j] = frag(slot, S_ARR, J * wave + j);
       }
+      lin_h8 xh = frag(slot, X_OFF, 0), xl = frag(slot, X_OFF + X_ARR, 0);
+      if (active)
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const lin_h8 xh = frag(slot, 2, t), xl = frag(slot, 3, t);
+        lin_h8 nh = xh, nl = xl;
+        if (t < 7) {   // the next feature tile's fragments are on their way while this one's MFMAs issue
+          nh = frag(slot, X_OFF, t + 1);
+          nl = frag(slot, X_OFF + X_ARR, t + 1);
+        }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < J; ++j) {
           xm[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, sh[j], xm[t][j], 0, 0, 0);
           xm[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, sl[j], xm[t][j], 0, 0, 0);
           xm[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, sh[j], xm[t][j], 0, 0, 0);
         }
+        xh = nh;
+        xl = nl;
       }
-      landed();
+      landed(younger_than(step + 1));
+      slot = next_slot(slot);
     }
-    // xm (x 2^10 from the scores' scale) -> split B operands of the four k-steps, in the accumulators' own element order
-    lin_h8 bh[4][2], bl[4][2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 4; ++ks, ++step) {
+      if (step + NSLOT - 1 < total) issue(step + NSLOT - 1, fill);
+      fill = next_slot(fill);
+      // xm (x 2^10 from the scores' scale) -> the split B operand of k-step ks, in the accumulators' own element order
+      lin_h8 bh[J], bl[J];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float v = xm[2 * ks + e / 4][j][e % 4] * (1.0f / AH_SSCALE);
           const _Float16 hh = (_Float16)v;
-          bh[ks][j][e] = hh;
-          bl[ks][j][e] = (_Float16)(v - (float)hh);
+          bh[j][e] = hh;
+          bl[j][e] = (_Float16)(v - (float)hh);
         }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks, ++step) {
-      const int slot = step & 1;
-      const int st = n1 + ks;
-      if (step + 1 < total) issue(st + 1 < per_head ? h : h + 1, st + 1 < per_head ? st + 1 : 0, slot ^ 1);
+      lin_h8 wh = frag(slot, X_OFF, 0), wl = frag(slot, X_OFF + X_ARR, 0);
+      if (active)
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const lin_h8 wh = frag(slot, 0, t), wl = frag(slot, 1, t);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc_y[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[ks][j], acc_y[t][j], 0, 0, 0);
-          acc_y[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[ks][j], acc_y[t][j], 0, 0, 0);
-          acc_y[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[ks][j], acc_y[t][j], 0, 0, 0);
+        lin_h8 nh = wh, nl = wl;
+        if (t < 7) {
+          nh = frag(slot, X_OFF, t + 1);
+          nl = frag(slot, X_OFF + X_ARR, t + 1);
         }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          acc_y[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[j], acc_y[t][j], 0, 0, 0);
+          acc_y[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[j], acc_y[t][j], 0, 0, 0);
+          acc_y[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[j], acc_y[t][j], 0, 0, 0);
+        }
+        wh = nh;
+        wl = nl;
       }
-      landed();
+      landed(younger_than(step + 1));
+      slot = next_slot(slot);
     }
   }
   // y^T tiles: lane (q = i16 of query tile j, g) holds output columns 16 t + 4 g + r
   if (hres) {
-    // residual + LayerNorm 1 here as well (custom_transformer_block.py:58-62): a wave holds all 128 features of its 32 queries -
+    // residual + LayerNorm 1 here as well (custom_transformer_block.py:58-62): a wave holds all 128 features of its queries -
     // per query 32 values in this lane, the rest in the three lanes i16 + 16 g'.  h is read and written in place: the mixing of
     // the other workgroups of this row reads the x^T copy, not h.
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int q = q0 + 32 * wave + 16 * j + i16;
+    for (int j = 0; j < J; ++j) {
+      const int q = q0 + 16 * J * wave + 16 * j + i16;
       const bool ok = q < V;
       float* row = hres + (n * V + (ok ? q : 0)) * (int64_t)D;
       lin_f4 v[8];
@@ -1244,7 +1315,10 @@ __global__ void __launch_bounds__(256) attend_fold_h3_kernel(const _Float16* __r
       if (ok) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const lin_f4 w = *(const lin_f4*)(lnw + 16 * t + 4 * g), b = *(const lin_f4*)(lnb + 16 * t + 4 * g);
+          // (the raw parameter vector is 4-byte aligned: element loads)
+          const float* pw = lnw + 16 * t + 4 * g;
+          const float* pb = lnb + 16 * t + 4 * g;
+          const lin_f4 w = (lin_f4){pw[0], pw[1], pw[2], pw[3]}, b = (lin_f4){pb[0], pb[1], pb[2], pb[3]};
           *(lin_f4*)(row + 16 * t + 4 * g) = v[t] * rstd * w + b;
         }
       }
@@ -1252,8 +1326,8 @@ __global__ void __launch_bounds__(256) attend_fold_h3_kernel(const _Float16* __r
     return;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = q0 + 32 * wave + 16 * j + i16;
+  for (int j = 0; j < J; ++j) {
+    const int q = q0 + 16 * J * wave + 16 * j + i16;
     if (q >= V) continue;
     float* row = y + (n * V + q) * (int64_t)D;
 #pragma unroll
@@ -1481,8 +1555,8 @@ static SimpleWs simple_ws(const tw_flow_desc& d, int64_t n_rows, int V, void* ba
   w.s_hi = w.s_lo = w.xt_hi = w.xt_lo = nullptr;
   if (d.variant == 0 && d.d_model == 128) {   // (sized whatever path the call takes: one workspace serves them all)
     const int64_t Vp = (V + 31) / 32 * 32;
-    w.s_hi = (_Float16*)take((n_rows * (int64_t)d.n_heads * V * Vp + 1) / 2);
-    w.s_lo = (_Float16*)take((n_rows * (int64_t)d.n_heads * V * Vp + 1) / 2);
+    w.s_hi = (_Float16*)take((n_rows * (int64_t)d.n_heads * Vp * Vp + 1) / 2);
+    w.s_lo = (_Float16*)take((n_rows * (int64_t)d.n_heads * Vp * Vp + 1) / 2);
     w.xt_hi = (_Float16*)take((n_rows * (int64_t)d.d_model * Vp + 1) / 2);
     w.xt_lo = (_Float16*)take((n_rows * (int64_t)d.d_model * Vp + 1) / 2);
   }
@@ -1545,24 +1619,30 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
         hipLaunchKernelGGL(xt_split_kernel, dim3((unsigned)a.n_rows, (unsigned)(Vp / 32), (unsigned)((d.d_model + 31) / 32)), dim3(256), 0,
                            s, w.h, w.xt_hi, w.xt_lo, V, Vp, d.d_model);
         TW_LAUNCH_CHECK();
-        // (one workgroup of the fused form walks all heads of its 128 queries: worth it once there are enough of them to fill the
-        // chip - 691 atoms x 16 rows are 96 workgroups there against 576 of the per-head form: 13.7 against 12.0 ms per pass)
-        if (!(g_debug_flags & 33554432) && (a.n_rows * ((V + 127) / 128) >= 200 || (g_debug_flags & 67108864))) {
+        // (one workgroup of the fused form walks all heads of its 128 queries: worth it once there are enough of them to fill half the
+        // chip - 691 atoms x 16 rows are 96 workgroups there against 576 of the per-head form: 12.7 against 12.2 ms per pass; 256 x 64
+        // are 128: 8.8 against 9.8)
+        if (!(g_debug_flags & 33554432) && (a.n_rows * ((V + 127) / 128) >= 128 || (g_debug_flags & 67108864))) {
           // ... and the folded 768 -> 128 GEMM inside the mixing launch (bit 25: as its own GEMM behind attend_h3p_kernel; bit 26:
           // inside it whatever the launch size; A/B, tests)
           const int64_t wcf = (int64_t)d.n_coupling * 2 * d.n_layers * d.d_model * HD;   // floats of the fp32 copy in front of the fp16 ones
           const float* fold0 = (const float*)((const char*)a.packed + (h3_packed_bytes(d, false) + 255) / 256 * 256);
           const _Float16* wch = (const _Float16*)(fold0 + wcf) + (((int64_t)c * 2 + net) * d.n_layers + l) * (int64_t)d.d_model * HD;
-          const int64_t blocks = a.n_rows * ((V + 127) / 128);
-          TW_REQUIRE(blocks < (int64_t)1 << 31, "attend: %lld workgroups", (long long)blocks);
-          constexpr int ldsf = 2 * 4 * 128 * 64;
-          static LdsLimit limf;
-          if ((rc = limf.ensure((const void*)attend_fold_h3_kernel, ldsf))) return rc;
           // (+ the residual and LayerNorm 1 in its epilogue; bit 27: as the add_ln launch behind it - A/B, tests)
-          const bool ln_in = !(g_debug_flags & 134217728) && ((uintptr_t)(lb + L.layer.n1w) % 16 == 0) && ((uintptr_t)(lb + L.layer.n1b) % 16 == 0);
-          hipLaunchKernelGGL(attend_fold_h3_kernel, dim3((unsigned)blocks), dim3(256), ldsf, s, w.s_hi, w.s_lo, w.xt_hi, w.xt_lo, wch,
-                             wch + wcf, w.tmp, a.n_cond, d.n_heads, V, Vp, ln_in ? w.h : nullptr, lb + L.layer.n1w, lb + L.layer.n1b,
-                             d.ln_eps);
+          const bool ln_in = !(g_debug_flags & 134217728);
+          // 128 queries per workgroup on two stage buffers, two workgroups per CU.  Measured against it (profiles/r06_attend_fold_occupancy.txt):
+          // 256 queries per workgroup (every x^T / Wc fragment read feeds 12 MFMAs instead of 6, but 489 registers = one wave per
+          // SIMD) on two or three stage buffers, and 128 queries on four - all slower.
+          {
+            constexpr int ldsf = 2 * 32 * 1024;
+            const int64_t blocks = a.n_rows * ((V + 127) / 128);
+            TW_REQUIRE(blocks < (int64_t)1 << 31, "attend: %lld workgroups", (long long)blocks);
+            static LdsLimit limf;
+            if ((rc = limf.ensure((const void*)attend_fold_h3_kernel<2, 2>, ldsf))) return rc;
+            hipLaunchKernelGGL((attend_fold_h3_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), ldsf, s, w.s_hi, w.s_lo, w.xt_hi, w.xt_lo,
+                               wch, wch + wcf, w.tmp, a.n_cond, d.n_heads, V, Vp, ln_in ? w.h : nullptr, lb + L.layer.n1w,
+                               lb + L.layer.n1b, d.ln_eps);
+          }
           TW_LAUNCH_CHECK();
           if (ln_in) goto ln1_done;
           goto attention_done;
@@ -1666,7 +1746,7 @@ static int simple_scores(const FlowArgs& a, const RawLayout& L, const SimpleWs& 
   if (a.simple_h3 && a.packed && w.s_hi && a.n_atoms > 64 && h3_ffn_tokens_supported(d) && !(g_debug_flags & 16777216)) {
     // the folded mixing's A operand (attend_h3p_kernel): split once per flow pass, shared by every layer and both nets
     const int V = a.n_atoms, Vp = (V + 31) / 32 * 32;
-    const int64_t rows = a.n_cond * d.n_heads * V, total = rows * Vp;
+    const int64_t rows = a.n_cond * d.n_heads * Vp, total = rows * Vp;
     hipLaunchKernelGGL(split_scores_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a.stream, w.scores, w.s_hi, w.s_lo,
                        rows, V, Vp);
     TW_LAUNCH_CHECK();

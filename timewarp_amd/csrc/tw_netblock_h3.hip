@@ -2778,9 +2778,13 @@ struct H3FfnParams {
   float eps;
 };
 
+// NT = 3: 48-token waves on the five-slot ring; NT = 4: 64-token waves on the three-slot ring (tw_h3n4_ffn_asm.inc) - one launch
+// is whole rounds of one workgroup per CU, so the host picks the token count per workgroup that wastes less of the last round.
+template <int NT>
 __global__ void __launch_bounds__(256) h3_ffn_tokens_kernel(H3FfnParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int NT = H3_NT;
+  constexpr int RING = NT == 4 ? H3N4_RING : H3_RING;
+  constexpr int WAVE_LDS = NT == 4 ? H3N4_WAVE_LDS : H3_WAVE_LDS;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, i16 = lane & 15;
@@ -2790,19 +2794,21 @@ __global__ void __launch_bounds__(256) h3_ffn_tokens_kernel(H3FfnParams p) {
   pipe.cur = 0;
   pipe.wave = wave;
   pipe.debug = 0;
-  pipe.ring = H3_RING;
+  pipe.ring = RING;
   pipe.start_issue();
-  char* priv = lds + H3_RING * H3_STAGE_BYTES + wave * H3_WAVE_LDS;
+  char* priv = lds + RING * H3_STAGE_BYTES + wave * WAVE_LDS;
   const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * NT);
   f4 x[8][NT], y[8][NT];
+  auto load_x = [&]() {
 #pragma unroll
-  for (int jt = 0; jt < NT; ++jt) {
-    const int64_t t = t0 + 16 * jt + i16;
+    for (int jt = 0; jt < NT; ++jt) {
+      const int64_t t = t0 + 16 * jt + i16;
 #pragma unroll
-    for (int ft = 0; ft < 8; ++ft)
-      x[ft][jt] = t < p.n_tokens ? *(const f4*)(p.h + t * 128 + 16 * ft + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
-  }
-  const float sc = p.side[641];
+      for (int ft = 0; ft < 8; ++ft)
+        x[ft][jt] = t < p.n_tokens ? *(const f4*)(p.h + t * 128 + 16 * ft + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  load_x();
   {
     BOp<NT> xb[4];
     to_bop<NT, 4>(x, xb);
@@ -2814,21 +2820,34 @@ __global__ void __launch_bounds__(256) h3_ffn_tokens_kernel(H3FfnParams p) {
         *(h8*)(priv + ((ks * NT + jt) * 2 + 1) * 1024 + lane * 16) = xb[ks].l[jt];
       }
   }
-  pipe.start_wait();   // vmcnt(0) + barrier: the first five stages are in the ring (and x is in registers)
+  pipe.start_wait();   // vmcnt(0) + barrier: the first stages are in the ring
   {
     int cur = 0;
     const char* gn = pipe.gnext;
     const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
     const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
     const int chunks = __builtin_amdgcn_readfirstlane(p.ff_chunks);
-    asm volatile(
+    if constexpr (NT == 4) {
+      asm volatile(
+#include "tw_h3n4_ffn_asm.inc"
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+          :
+#include "tw_h3n4_ffn_clobbers.inc"
+      );
+    } else {
+      asm volatile(
 #include "tw_h3_ffn_asm.inc"
-        : [cur] "+&s"(cur), [gn] "+&v"(gn)
-        : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
-        :
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+          :
 #include "tw_h3_ffn_clobbers.inc"
-    );
+      );
+    }
   }
+  // (64-token waves: the layer input is read again here instead of living in 128 registers across the statement)
+  if constexpr (NT == 4) load_x();
+  const float sc = p.side[641];
 #pragma unroll
   for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
@@ -2864,10 +2883,11 @@ struct H3IoParams {
   int d_in, chunks;
 };
 
-template <bool OUT>
+template <bool OUT, int NT>
 __global__ void __launch_bounds__(256) h3_io_tokens_kernel(H3IoParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int NT = H3_NT;
+  constexpr int RING = NT == 4 ? H3N4_RING : H3_RING;
+  constexpr int WAVE_LDS = NT == 4 ? H3N4_WAVE_LDS : H3_WAVE_LDS;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, i16 = lane & 15;
@@ -2877,9 +2897,9 @@ __global__ void __launch_bounds__(256) h3_io_tokens_kernel(H3IoParams p) {
   pipe.cur = 0;
   pipe.wave = wave;
   pipe.debug = 0;
-  pipe.ring = H3_RING;
+  pipe.ring = RING;
   pipe.start_issue();
-  char* priv = lds + H3_RING * H3_STAGE_BYTES + wave * H3_WAVE_LDS;
+  char* priv = lds + RING * H3_STAGE_BYTES + wave * WAVE_LDS;
   const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * NT);
   const float sc = *p.scale2;
   if constexpr (OUT) {
@@ -2930,13 +2950,29 @@ __global__ void __launch_bounds__(256) h3_io_tokens_kernel(H3IoParams p) {
     const unsigned ring = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
     const unsigned priv_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)priv;
     const int chunks = __builtin_amdgcn_readfirstlane(p.chunks);
-    if constexpr (OUT) {
+    if constexpr (OUT && NT == 4) {
+      asm volatile(
+#include "tw_h3n4_out_asm.inc"
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+          :
+#include "tw_h3n4_out_clobbers.inc"
+      );
+    } else if constexpr (OUT) {
       asm volatile(
 #include "tw_h3_out_asm.inc"
           : [cur] "+&s"(cur), [gn] "+&v"(gn)
           : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
           :
 #include "tw_h3_out_clobbers.inc"
+      );
+    } else if constexpr (NT == 4) {
+      asm volatile(
+#include "tw_h3n4_in_asm.inc"
+          : [cur] "+&s"(cur), [gn] "+&v"(gn)
+          : [ring] "s"(ring), [wave] "s"(wave), [priv] "s"(priv_lds), [chunks] "s"(chunks)
+          :
+#include "tw_h3n4_in_clobbers.inc"
       );
     } else {
       asm volatile(
@@ -3350,13 +3386,28 @@ int h3_ffn_tokens(const tw_flow_desc& d, const void* packed, int coupling, int n
   p.n_tokens = n_tokens;
   p.ff_chunks = g.ff_chunks;
   p.eps = d.ln_eps;
-  constexpr int lds = H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS;
-  static LdsLimit lim;
+  // One workgroup per CU (LDS), so a launch is whole rounds of the chip: 48-token waves (192 tokens per workgroup) unless 64-token
+  // waves (256 per workgroup, 4/3 the time per round) need fewer rounds' worth - 200 atoms x 256 rows: 267 workgroups = 2 rounds
+  // against 200 = 4/3; 256 x 256: 342 = 2 rounds against 256 = 4/3.  Bits 29 / 30 force either (A/B, tests).
+  const int64_t wg3 = (n_tokens + 191) / 192, wg4 = (n_tokens + 255) / 256;
+  const int cus = H3_CUS;
+  bool four = 4 * ((wg4 + cus - 1) / cus) < 3 * ((wg3 + cus - 1) / cus);
+  if (g_debug_flags & 536870912) four = false;
+  if (g_debug_flags & 1073741824) four = true;
   int rc;
-  if ((rc = lim.ensure((const void*)h3_ffn_tokens_kernel, lds))) return rc;
-  const int64_t wgs = (n_tokens + 4 * 16 * H3_NT - 1) / (4 * 16 * H3_NT);
+  const int64_t wgs = four ? wg4 : wg3;
   TW_REQUIRE(wgs < (int64_t)1 << 31, "FFN: %lld workgroups", (long long)wgs);
-  hipLaunchKernelGGL(h3_ffn_tokens_kernel, dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  if (four) {
+    constexpr int lds = H3N4_RING * H3_STAGE_BYTES + 4 * H3N4_WAVE_LDS;
+    static LdsLimit lim;
+    if ((rc = lim.ensure((const void*)h3_ffn_tokens_kernel<4>, lds))) return rc;
+    hipLaunchKernelGGL(h3_ffn_tokens_kernel<4>, dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  } else {
+    constexpr int lds = H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS;
+    static LdsLimit lim;
+    if ((rc = lim.ensure((const void*)h3_ffn_tokens_kernel<3>, lds))) return rc;
+    hipLaunchKernelGGL(h3_ffn_tokens_kernel<3>, dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  }
   TW_LAUNCH_CHECK();
   return TW_OK;
 }
@@ -3383,17 +3434,26 @@ int h3_io_tokens(const tw_flow_desc& d, const void* packed, int coupling, int ne
   p.n_tokens = n_tokens;
   p.d_in = d_in;
   p.chunks = g.hid_chunks;
-  constexpr int lds = H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS;
-  static LdsLimit lim_in, lim_out;
-  int rc;
-  const int64_t wgs = (n_tokens + 4 * 16 * H3_NT - 1) / (4 * 16 * H3_NT);
+  // (48- or 64-token waves: whichever wastes less of the last round of the chip, as h3_ffn_tokens)
+  const int64_t wg3 = (n_tokens + 191) / 192, wg4 = (n_tokens + 255) / 256;
+  bool four = 4 * ((wg4 + H3_CUS - 1) / H3_CUS) < 3 * ((wg3 + H3_CUS - 1) / H3_CUS);
+  if (g_debug_flags & 536870912) four = false;
+  if (g_debug_flags & 1073741824) four = true;
+  const int64_t wgs = four ? wg4 : wg3;
   TW_REQUIRE(wgs < (int64_t)1 << 31, "in / out MLP: %lld workgroups", (long long)wgs);
-  if (out) {
-    if ((rc = lim_out.ensure((const void*)h3_io_tokens_kernel<true>, lds))) return rc;
-    hipLaunchKernelGGL(h3_io_tokens_kernel<true>, dim3((unsigned)wgs), dim3(256), lds, stream, p);
-  } else {
-    if ((rc = lim_in.ensure((const void*)h3_io_tokens_kernel<false>, lds))) return rc;
-    hipLaunchKernelGGL(h3_io_tokens_kernel<false>, dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  constexpr int lds3 = H3_RING * H3_STAGE_BYTES + 4 * H3_WAVE_LDS, lds4 = H3N4_RING * H3_STAGE_BYTES + 4 * H3N4_WAVE_LDS;
+  static LdsLimit lim[4];
+  const void* fn[4] = {(const void*)h3_io_tokens_kernel<false, 3>, (const void*)h3_io_tokens_kernel<false, 4>,
+                       (const void*)h3_io_tokens_kernel<true, 3>, (const void*)h3_io_tokens_kernel<true, 4>};
+  const int which = (out ? 2 : 0) + (four ? 1 : 0);
+  const int lds = four ? lds4 : lds3;
+  int rc;
+  if ((rc = lim[which].ensure(fn[which], lds))) return rc;
+  switch (which) {
+    case 0: hipLaunchKernelGGL((h3_io_tokens_kernel<false, 3>), dim3((unsigned)wgs), dim3(256), lds, stream, p); break;
+    case 1: hipLaunchKernelGGL((h3_io_tokens_kernel<false, 4>), dim3((unsigned)wgs), dim3(256), lds, stream, p); break;
+    case 2: hipLaunchKernelGGL((h3_io_tokens_kernel<true, 3>), dim3((unsigned)wgs), dim3(256), lds, stream, p); break;
+    default: hipLaunchKernelGGL((h3_io_tokens_kernel<true, 4>), dim3((unsigned)wgs), dim3(256), lds, stream, p); break;
   }
   TW_LAUNCH_CHECK();
   return TW_OK;
