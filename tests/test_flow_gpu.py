@@ -762,8 +762,9 @@ def test_per_op_path_large_molecules(path):
     Above every fused layout (192 atoms) the flow runs on the per-op path.  r04 stopped at ~200 atoms there (one V x V score
     tile per molecule in the LDS) and refused anything larger; r05: the scores are computed row-wise and the mixing is a tiled
     f32-MFMA GEMM from 129 atoms on, so the reference's own 691-atom test protein size goes through - against the oracle at the
-    bar, ragged (masked tails), forward and reverse.  The row-wise scores kernel must equal the tile kernel bit for bit (150
-    atoms fit both).  The dense softmax variant's attention has a row-wise form too."""
+    bar, ragged (masked tails), forward and reverse.  The row-wise scores kernel must equal the tile kernel to one float ulp (150
+    atoms fit both; r06: a wave per row, so the double sum of a row is added in another order).  The dense softmax variant's
+    attention has a row-wise form too."""
     import ctypes as C
 
     from timewarp_amd import _lib
@@ -866,7 +867,7 @@ def test_per_op_path_large_molecules(path):
     if path != 0:
         return
     # the two scores kernels on the same 150 atoms (bit 21 forces the row-wise one), both cdist branches, Gaussian and Chebyshev:
-    # bit-identical - the arithmetic of tw_cdist_mm / basis_value must not depend on the kernel it is inlined into
+    # the same values - the arithmetic of tw_cdist_mm / basis_value must not depend on the kernel it is inlined into
     V = 150
     x = torch.randn(1, V, 3, generator=g) * 0.8
     ls = torch.tensor([0.1, 0.2, 0.5, 0.7, 1.0, 1.2])
@@ -882,7 +883,10 @@ def test_per_op_path_large_molecules(path):
                 _lib.check(lib.tw_kernel_scores_cheb(xd.data_ptr(), md.data_ptr(), ld.data_ptr(), cd.data_ptr(), 7, 1, 6, 1, V, 1, use_mm,
                                                      b.data_ptr(), None), "tw_kernel_scores_cheb")
                 outs.append((a, b))
-            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), use_mm
+            # (the row sums are the same exact sums rounded once, added in another order in double: equal floats up to a rounding tie)
+            for k in (0, 1):
+                a, b = outs[0][k], outs[1][k]
+                assert bool(((a - b).abs() <= 1.2e-7 * a.abs()).all()) and float((a != b).float().mean()) < 1e-3, (use_mm, k)
         # ... and the whole flow with the tiled kernels forced at a size the tile kernels take too
         at = torch.randint(0, 5, (3, 100), generator=g)
         xx = torch.randn(3, 100, 3, generator=g) * 0.7

@@ -139,18 +139,27 @@ __global__ void scores_kernel(const float* __restrict__ x, const uint8_t* __rest
   }
 }
 
-// Large molecules (r05): the same rows without the V x V distance tile - the coordinates (12 V bytes) are all the LDS a block
-// holds, every (head, query) row recomputes its V distances in both passes.  Same arithmetic, same order of operations per
-// row as scores_kernel: bit-identical output (tests/test_flow_gpu.py::test_per_op_path_large_molecules).  grid (B, row blocks).
-__global__ void scores_rows_kernel(const float* __restrict__ x, const uint8_t* __restrict__ masked,
-                                   const float* __restrict__ ls, int H, int V, int normalise, int use_mm,
-                                   float* __restrict__ out, const float* __restrict__ coeffs, int order, int force_zero) {
+// Large molecules (r05 / r06): the same rows without the V x V distance tile - the coordinates (12 V bytes) are all the LDS a block
+// holds.  ONE WAVE per (head, query) row, lanes over the keys: every basis value is computed once and stays in the lane's registers
+// (up to 16 per lane = 1024 atoms; beyond that they are recomputed) between the row sum and the division, reads and writes of a row are
+// coalesced, and a single conditioning state already is H V waves (the thread-per-row form this replaces took as long as one thread
+// needs for 2 V basis values whatever the launch: 210 us for one state of 256 atoms, 1.3 ms for 256 states, its stores 4 bytes per
+// lane V floats apart).  The row sum: per-lane partial sums in double in key order, then a butterfly over the wave - the same exact
+// sum rounded once up to the order of the double additions (scores_kernel adds in key order: equal floats except where the
+// exact sum lies within 2^-29 of a rounding boundary; tests/test_flow_gpu.py::test_per_op_path_large_molecules holds them to one
+// float ulp).  grid (B, blocks of 16 rows).
+#define SCORES_ROWS_PER_BLOCK 16
+#define SCORES_KEEP 16
+__global__ void __launch_bounds__(64 * SCORES_ROWS_PER_BLOCK) scores_rows_kernel(
+    const float* __restrict__ x, const uint8_t* __restrict__ masked, const float* __restrict__ ls, int H, int V, int normalise, int use_mm,
+    float* __restrict__ out, const float* __restrict__ coeffs, int order, int force_zero) {
   extern __shared__ float sm[];
   float* xs = sm;  // [V*3]
   const int64_t b = blockIdx.x;
   for (int i = threadIdx.x; i < 3 * V; i += blockDim.x) xs[i] = x[b * 3 * V + i];
   __syncthreads();
-  const int r = blockIdx.y * blockDim.x + threadIdx.x;  // one thread per (h, q) row
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.y * SCORES_ROWS_PER_BLOCK + (threadIdx.x >> 6);  // one wave per (h, q) row
   if (r >= H * V) return;
   const int h = r / V, q = r % V;
   const float l = ls[h];
@@ -160,17 +169,29 @@ __global__ void scores_rows_kernel(const float* __restrict__ x, const uint8_t* _
     for (int c = 0; c < order; ++c) cmean += cf[c];
     cmean /= (float)order;
   }
-  double sum = 0.0;
-  for (int m = 0; m < V; ++m) {
+  auto value = [&](int m) -> float {
     const float sc = pair_distance(xs, q, m, use_mm) / l;
-    const float e = masked[b * V + m] ? 0.f : basis_value(sc, cf, order, cmean);
-    sum += (double)fabsf(e);
+    return masked[b * V + m] ? 0.f : basis_value(sc, cf, order, cmean);
+  };
+  float keep[SCORES_KEEP];
+  double sum = 0.0;
+#pragma unroll
+  for (int k = 0; k < SCORES_KEEP; ++k) {
+    const int m = lane + 64 * k;
+    keep[k] = m < V ? value(m) : 0.f;
+    sum += (double)fabsf(keep[k]);
   }
+  for (int m = lane + 64 * SCORES_KEEP; m < V; m += 64) sum += (double)fabsf(value(m));
+  sum = wave_sum(sum);
   const float denom = (float)sum + 1e-5f;
   float* o = out + ((b * H + h) * V + q) * (int64_t)V;
-  for (int m = 0; m < V; ++m) {
-    const float sc = pair_distance(xs, q, m, use_mm) / l;
-    const float e = masked[b * V + m] ? 0.f : basis_value(sc, cf, order, cmean);
+#pragma unroll
+  for (int k = 0; k < SCORES_KEEP; ++k) {
+    const int m = lane + 64 * k;
+    if (m < V) o[m] = normalise ? keep[k] / denom : keep[k];
+  }
+  for (int m = lane + 64 * SCORES_KEEP; m < V; m += 64) {
+    const float e = value(m);
     o[m] = normalise ? e / denom : e;
   }
 }
@@ -191,12 +212,12 @@ int launch_scores(const float* x, const uint8_t* masked, const float* ls, int H,
                   int normalise, int use_mm, float* out, hipStream_t s, const float* coeffs, int order, int force_zero) {
   if (B == 0) return TW_OK;
   size_t shm = (size_t)(3 * V + V * V) * sizeof(float);
-  // The row-wise kernel: no room for the distance tile (or bit 21) - and from 161 atoms on anyway: both kernels run one thread per
-  // (head, query) row through 2 V basis values, so a launch takes as long as one thread does; the tile kernel is one workgroup per
-  // conditioning state (200 atoms, one state: 590 us on one CU), the row-wise one H V / 256 of them (same arithmetic, bit-identical).
+  // The row-wise kernel: no room for the distance tile (or bit 21) - and from 161 atoms on anyway: the tile kernel is one workgroup
+  // per conditioning state, one thread per (head, query) row (200 atoms, one state: 590 us on one CU); the row-wise one a wave per row.
   if (shm > (size_t)160 * 1024 || V > 160 || (g_debug_flags & 2097152)) {
-    hipLaunchKernelGGL(scores_rows_kernel, dim3((unsigned)B, (unsigned)((H * V + 255) / 256)), dim3(256), (size_t)3 * V * sizeof(float), s,
-                       x, masked, ls, H, V, normalise, use_mm, out, coeffs, order, force_zero);
+    hipLaunchKernelGGL(scores_rows_kernel, dim3((unsigned)B, (unsigned)((H * V + SCORES_ROWS_PER_BLOCK - 1) / SCORES_ROWS_PER_BLOCK)),
+                       dim3(64 * SCORES_ROWS_PER_BLOCK), (size_t)3 * V * sizeof(float), s, x, masked, ls, H, V, normalise, use_mm, out, coeffs,
+                       order, force_zero);
     TW_LAUNCH_CHECK();
     return TW_OK;
   }
