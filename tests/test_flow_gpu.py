@@ -863,6 +863,19 @@ def test_per_op_path_large_molecules(path):
         finally:
             lib.tw_debug_set_flags(0)
         assert H.rel_err(outd2, refd) < TOL, H.rel_err(outd2, refd)
+        # the softmax attention above 64 atoms runs on the fp32 matrix pipe (sdpa_mfma_kernel); bit 31: the scalar kernels - same bar,
+        # on the exact-f32 per-op path too
+        for pth in (5, SIMPLE):
+            mdp = md5 if pth == 5 else H.tw_dense_model(dsd, path=SIMPLE)
+            res = {}
+            for flag in (0, -2147483648):
+                try:
+                    lib.tw_debug_set_flags(flag)
+                    res[flag] = mdp.log_likelihood(atom_types=at.cuda(), x_coords=xx.cuda(), x_velocs=vv.cuda(), y_coords=yy.cuda(),
+                                                   y_velocs=vv.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mk.cuda()).cpu()
+                finally:
+                    lib.tw_debug_set_flags(0)
+                assert H.rel_err(res[flag], refd) < TOL, (pth, flag, H.rel_err(res[flag], refd))
         H.assert_not_demoted(md5)
     if path != 0:
         return

@@ -1527,6 +1527,81 @@ __global__ void sdpa_rows_kernel(const float* __restrict__ qkv, const uint8_t* _
     if (j < dh) out[(n * V + a) * (int64_t)d + h * dh + j] = acc[j];
 }
 
+// The same attention on the fp32 matrix pipe (r06; head width 16 - the configured dense model: 128 / 8), flash style: a workgroup
+// stages K and V of one (row, head) in the LDS once, each of its waves walks the keys in blocks of 16 for a tile of 16 queries,
+//   S^T[key][q]  = sum_j K[key][j] Q[q][j]            4 x v_mfma_f32_16x16x4_f32 (exact fp32 products)
+//   online softmax over the keys per query (running maximum and sum; the query is the lane's column: l % 16)
+//   O^T[d][q]   += sum_key V[key][d] P[q][key]        4 x MFMA, B operand = the lane's four probabilities as they stand:
+// lane (q, g) holds keys 4 g + r of the block after the first product, so k-step r of the second takes keys {4 g + r} - the sums
+// over head features and over keys do not care about the order, which spares every transpose.  sdpa_rows_kernel did this with one
+// thread per query and scalar FMAs: 855 us per call at 256 atoms x 256 rows, 76 % of a dense per-op pass.
+// LDS: K and V in fragment order (lane l of block b reads 16 bytes at (64 b + l) 16), the key mask as 0 / -inf.
+typedef float sd_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) sdpa_mfma_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ masked, int64_t n_cond,
+                                                         float* __restrict__ out, int V, int d, int n_head, int q_tiles_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) float sd_lds[];
+  const int V16 = (V + 15) / 16;
+  sd_f4* kl = (sd_f4*)sd_lds;                 // [V16][64]: lane (key % 16, g): K[key][4 g .. 4 g + 3]
+  sd_f4* vl = kl + V16 * 64;                  // [V16][64]: lane (d, g): V[16 b + 4 g + r][d], r = 0 .. 3
+  float* mk = (float*)(vl + V16 * 64);        // [16 V16]
+  const int64_t n = blockIdx.x;
+  const int h = blockIdx.y;
+  const int64_t c = n % n_cond;
+  const float* base = qkv + n * V * 3 * (int64_t)d + h * 16;
+  for (int i = threadIdx.x; i < V16 * 64; i += 256) {
+    const int key = i >> 2, j4 = i & 3;   // 16 bytes of one key row
+    sd_f4 kv = (sd_f4){0.f, 0.f, 0.f, 0.f}, vv = kv;
+    if (key < V) {
+      kv = *(const sd_f4*)(base + (int64_t)key * 3 * d + d + 4 * j4);
+      vv = *(const sd_f4*)(base + (int64_t)key * 3 * d + 2 * d + 4 * j4);
+    }
+    const int b = key >> 4, kk = key & 15;
+    kl[b * 64 + j4 * 16 + kk] = kv;
+    float* vt = (float*)(vl + b * 64);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vt[((kk >> 2) * 16 + 4 * j4 + e) * 4 + (kk & 3)] = vv[e];
+  }
+  for (int i = threadIdx.x; i < V16 * 16; i += 256) mk[i] = (i >= V || masked[c * V + i]) ? -INFINITY : 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q16 = lane & 15, g = lane >> 4;
+  const int QT = V16;
+  for (int it = 0; it < q_tiles_per_wave; ++it) {
+    const int qt = (blockIdx.z * q_tiles_per_wave + it) * 4 + wave;
+    if (qt >= QT) break;
+    const int q = 16 * qt + q16;
+    const sd_f4 qb = *(const sd_f4*)(base + (int64_t)(q < V ? q : V - 1) * 3 * d + 4 * g) * 0.25f;   // 1 / sqrt(16)
+    float m_run = -INFINITY, l_run = 0.f;
+    sd_f4 o = (sd_f4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < V16; ++b) {
+      const sd_f4 kf = kl[b * 64 + lane];
+      const sd_f4 vf = vl[b * 64 + lane];
+      const sd_f4 mb = *(const sd_f4*)(mk + 16 * b + 4 * g);
+      sd_f4 st = mb;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qb[s], st, 0, 0, 0);
+      float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float m_safe = m_new == -INFINITY ? 0.f : m_new;   // (a block of masked keys before the first real one)
+      const float alpha = expf(m_run - m_safe);
+      sd_f4 pr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[r] = expf(st[r] - m_safe);
+      float ps = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+      ps += __shfl_xor(ps, 16);
+      ps += __shfl_xor(ps, 32);
+      l_run = l_run * alpha + ps;
+      o = o * alpha;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], pr[r], o, 0, 0, 0);
+      m_run = m_new;
+    }
+    if (q < V) *(sd_f4*)(out + (n * V + q) * (int64_t)d + h * 16 + 4 * g) = o * (1.0f / l_run);
+  }
+}
+
 // h = LayerNorm(h + delta) (custom_attention_encoder.py:109-114); one wave per token
 __global__ void add_ln_kernel(float* __restrict__ h, const float* __restrict__ delta, const float* __restrict__ w,
                               const float* __restrict__ b, float eps, int D, int64_t tokens) {
@@ -1702,6 +1777,19 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
       if ((rc = launch_linear(w.h, lb + L.layer.in_w, lb + L.layer.in_b, w.vals, M, 3 * d.d_model, d.d_model, ACT_NONE, s, sp))) return rc;
       const int dh = d.d_model / d.n_heads;
       const size_t sdpa_lds = (size_t)(3 * V * dh + V * V) * 4;
+      const int V16 = (V + 15) / 16;
+      const size_t mfma_lds = (size_t)V16 * (2 * 1024 + 64);
+      if (dh == 16 && V > 64 && mfma_lds <= (size_t)160 * 1024 && !((unsigned)g_debug_flags.load() & 0x80000000u)) {
+        // fp32 matrix pipe, K / V of a (row, head) staged once per workgroup (bit 31: the scalar kernels below - A/B, tests); a
+        // workgroup's waves take q_tiles_per_wave query tiles each, as many as still leave ~1024 workgroups
+        int64_t per_wave = a.n_rows * d.n_heads * (int64_t)V16 / 4 / 1024;
+        per_wave = per_wave < 1 ? 1 : per_wave > (V16 + 3) / 4 ? (V16 + 3) / 4 : per_wave;
+        const int chunks = (int)((V16 + 4 * per_wave - 1) / (4 * per_wave));
+        TW_REQUIRE(d.n_heads <= 65535 && chunks <= 65535, "dense attention: grid %d x %d", d.n_heads, chunks);
+        TW_LDS_LIMIT(sdpa_mfma_kernel, mfma_lds, V);
+        hipLaunchKernelGGL(sdpa_mfma_kernel, dim3((unsigned)a.n_rows, d.n_heads, (unsigned)chunks), dim3(256), mfma_lds, s, w.vals, a.masked,
+                           a.n_cond, w.att, V, d.d_model, d.n_heads, (int)per_wave);
+      } else
       if (sdpa_lds > (size_t)160 * 1024 || (g_debug_flags & 2097152)) {  // no room for the score tile (or bit 21): row-wise
         TW_REQUIRE(dh <= 64, "dense attention: head width %d > 64 on the row-wise per-op kernel", dh);
         const dim3 grid((unsigned)a.n_rows, d.n_heads, (unsigned)((V + 127) / 128));

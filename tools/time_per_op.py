@@ -6,7 +6,9 @@ from tests import helpers as H
 
 # --path=2 (default): the exact-f32 per-op kernels; --path=5: TW_PATH_SIMPLE_H3, the linears as split-fp16 MFMA GEMMs (r06)
 path = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--path=")), 2)
-m = H.tw_kernel_model(H.full_kernel_sd(), path=path)
+# --dense: the dense softmax variant (transformer_nvp) instead of kernel attention
+dense = "--dense" in sys.argv
+m = H.tw_dense_model(H.full_dense_sd(), path=path) if dense else H.tw_kernel_model(H.full_kernel_sd(), path=path)
 # --flags=N: tw_debug_set_flags(N) for A/B runs (e.g. 268435456: in / out MLPs as GEMM pairs)
 flags = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--flags=")), 0)
 if flags:
@@ -26,7 +28,7 @@ for spec in [a for a in sys.argv[1:] if not a.startswith("--")] or ["192x256"]:
         f()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3 * 1e3
-    flop = 16 * V * (4478976 + 4608 * V) * S
+    flop = 16 * V * ((3692544 + 1536 * V) if dense else (4478976 + 4608 * V)) * S   # 2 x MACs per token: linears + mixing
     if "--forward" in sys.argv:
         # the reverse move of an MH iteration: every row conditioned on its own state (n_cond = S: scores per row)
         yc, yv, _ = f()
