@@ -562,6 +562,51 @@ def other_config_record(device, seed, config, steps, sync_every, n_chains=1):
     }
 
 
+def large_molecule_flow_record(device, seed, V, S, passes=4):
+    """Molecules above every fused layout (193+ atoms; the reference's own test protein has 691): FLOW PASSES ONLY of the
+    kernel-attention model on the path a model takes there by default (TW_PATH_SIMPLE_H3: per-op launches, linears / mixing /
+    FFN on split-fp16 MFMAs) - S proposals of a synthetic V-atom molecule drawn from one conditioning state (the reverse pass of an
+    MH iteration) and their log-likelihood back, every proposal its own conditioning state (the forward pass).  No energy, no
+    accept step: the line exists so that VERDICT r05's 200 x 256 / 256 x 256 figures are timed by the driver as well."""
+    import timewarp_amd as tw
+    from timewarp_amd import _lib, synthetic
+
+    model = tw.model_constructor(synthetic.kernel_transformer_nvp_config())
+    model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), base_seed=0, calibrated=True, **CALIBRATION))
+    model = model.to(device).eval()
+    path = model._path_for(V)
+    g = torch.Generator().manual_seed(seed)
+    at = torch.randint(0, 5, (1, V), generator=g).to(device)
+    xc = (torch.randn(1, V, 3, generator=g) * 0.8).to(device)
+    xv = torch.randn(1, V, 3, generator=g).to(device)
+    mk = torch.zeros(1, V, dtype=torch.bool, device=device)
+    rev = lambda: model.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None, edge_batch_idx=None,
+                                                     masked_elements=mk, num_samples=S)
+    with torch.no_grad():
+        yc, yv, _ = rev()
+        atS, mkS, xcS, xvS = at.repeat(S, 1), mk.repeat(S, 1), xc.repeat(S, 1, 1), xv.repeat(S, 1, 1)
+        fwd = lambda: model.log_likelihood(atom_types=atS, x_coords=yc.squeeze(1), x_velocs=yv.squeeze(1), y_coords=xcS, y_velocs=xvS,
+                                           adj_list=None, edge_batch_idx=None, masked_elements=mkS)
+        fwd()
+        ms = {}
+        for name, f in (("reverse", rev), ("forward", fwd)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                f()
+            torch.cuda.synchronize()
+            ms[name] = (time.perf_counter() - t0) / passes * 1e3
+    flop = 16 * V * F_BLK_KERNEL(V) * S
+    rec = {"workload": f"kernel_transformer_nvp.yaml flow passes only, synthetic {V}-atom molecule x {S} proposals (no energy, no accept step)",
+           "path": {_lib.TW_PATH_SIMPLE_H3: "TW_PATH_SIMPLE_H3 (per-op launches on split-fp16 MFMAs: the model default above 192 atoms)"}.get(path, str(path)),
+           "passes": passes, "algorithmic_flop_per_pass": flop, "dtype": PATHS["h3"]["dtype"],
+           "range_guard_fired": bool(getattr(model, "demoted", False))}
+    for name in ("reverse", "forward"):
+        tf = flop / (ms[name] * 1e-3) / 1e12
+        rec[name] = {"ms_per_pass": ms[name], "achieved": tf, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F16_MFMA_PEAK_TFLOPS}
+    return rec
+
+
 def end_timed_region(traj, t0, device, world):
     """The N > 1 leg of the measurement contract: the one collective of the path (all-gather of the trajectories, inside
     the timed region), barrier + device synchronisation on both sides of the clock, MAX of the elapsed time over ranks.
@@ -874,6 +919,9 @@ def main():
                 "dense": other_config_record(device, seed, "dense", 12, args.sync_every),   # BASELINE configs[4]
                 # the mode whole-node accepted samples/s rewards - 32 chains x 31 proposals through the headline's launches
                 "ad_chains32": other_config_record(device, seed, "ad", 24, args.sync_every, n_chains=32),
+                # above every fused layout: flow passes of 200- and 256-atom molecules x 256 proposals
+                "flow_200x256": large_molecule_flow_record(device, seed, 200, 256),
+                "flow_256x256": large_molecule_flow_record(device, seed, 256, 256),
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.proposals)
