@@ -443,17 +443,24 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *              workgroup; r05) - the wide layout's 48-token waves instead, one molecule per workgroup; same results up to the
  *              last bits (A/B switch and tests).  The paired layout exists as the encoder-stack build only: bits 2 / 4 / 12
  *              (without 13) and tw_debug_netblock take the 48-token wide layout as well
- *   bit 21 (2097152) per-op path: the row-wise scores kernel and the tiled MFMA mixing kernel (what molecules above ~200 / 64
- *              atoms take) at every size; same scores bit for bit, the mixing in another summation order (A/B switch and tests)
+ *   bit 21 (2097152) per-op path: the row-wise scores kernel and the tiled MFMA mixing kernel (what molecules above 160 / 64
+ *              atoms take) at every size; the same scores up to the order of a row sum's double additions, the mixing in another
+ *              summation order (A/B switch and tests)
  *   bit 22 (4194304) / bit 23 (8388608)  tw_mh_iteration: the energy kernel on the caller's stream / on the side stream,
  *              whatever the launch size (default: side stream only while the flow's launches leave compute units idle)
  *   bit 24 (16777216) TW_PATH_SIMPLE_H3: the FFN as two linear launches + add_ln, the attention unfolded, even when the path's pack
  *              is at hand (default then: one launch of the fused kernels' chunk loop on the flat token list; folded attention);
  *              A/B switch and tests
  *   bit 25 (33554432) TW_PATH_SIMPLE_H3, folded attention: the 768 -> 128 GEMM as its own launch behind the mixing kernel instead
- *              of inside it (attend_fold_h3_kernel); bit 26 (67108864): inside it whatever the launch size (default: from 200
+ *              of inside it (attend_fold_h3_kernel); bit 26 (67108864): inside it whatever the launch size (default: from 128
  *              workgroups on); bit 27 (134217728): residual + LayerNorm 1 as the add_ln launch behind that kernel instead of
- *              in its epilogue; A/B switches and tests */
+ *              in its epilogue; A/B switches and tests
+ *   bit 28 (268435456) TW_PATH_SIMPLE_H3: the in-MLP and the out-MLP as two linear launches each instead of one launch of the fused
+ *              kernels' statements on the flat token list (h3_io_tokens_kernel)
+ *   bit 29 (536870912) / bit 30 (1073741824)  TW_PATH_SIMPLE_H3: the FFN / MLP token launches on 48-token / on 64-token waves whatever
+ *              the launch size (default: whichever needs fewer rounds' worth of the chip); same arithmetic per token
+ *   bit 31 (pass INT_MIN) per-op paths, dense softmax variant: the scalar attention kernels above 64 atoms instead of
+ *              sdpa_mfma_kernel (fp32 matrix pipe); A/B switches and tests */
 int tw_debug_set_flags(int flags);
 
 /* Debug/inspection: run ONE net-block of the fused path and dump the activation after every
