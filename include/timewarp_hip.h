@@ -103,7 +103,9 @@ int tw_flow_pack_h3(const tw_flow_desc* desc, const float* raw, void* packed_h3,
 /* ABI 8 - the pack of TW_PATH_SIMPLE_H3 (0 bytes where the model has no split-fp16 stream: that path then takes packed = NULL):
  * the tw_flow_pack_h3 stream (its FFN stages feed the path's fused FFN launches), then - kernel attention - the per-head folded
  * value / output projections Wc[coupling][net][layer][d_model][n_heads d_model] (fp32, folded in fp64) and their split-fp16 copies
- * per head in MFMA-operand order, which let the mixing run on the layer input with the ONE remaining GEMM inside the same launch. */
+ * per head in MFMA-operand order, which let the mixing run on the layer input with the ONE remaining GEMM inside the same launch; then
+ * the FFN stages of every (coupling, net, layer) once more as four self-contained streams of a quarter of the hidden layer each (small
+ * launches spread an FFN over four workgroups per token tile). */
 int64_t tw_flow_packed_simple_h3_bytes(const tw_flow_desc* desc);
 int tw_flow_pack_simple_h3(const tw_flow_desc* desc, const float* raw, void* packed, void* stream);
 /* The same for TW_PATH_FUSED_H1 (fp16 hi tiles only: 8 tiles per 9 KiB stage, half as many stages). */
@@ -137,13 +139,13 @@ int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_
 #define TW_PATH_SIMPLE_H3 5 /* ABI 8: TW_PATH_SIMPLE with its linear layers (in / out MLPs, value and output projections, q / k / v,
                               FFN) as split-fp16 MFMA GEMMs - the arithmetic of TW_PATH_FUSED_H3 (3 half-precision MFMAs per fp32
                               product, fp32 accumulation), one kernel per reference op, ANY molecule size and both model variants:
-                              what serves the sizes no fused layout takes (kernel attention above 192 atoms, dense above 64) at ~3x
-                              the rate of the exact-f32 per-op kernels.  Scores, softmax, mixing, LayerNorm stay fp32.  Needs
+                              what serves the sizes no fused layout takes (kernel attention above 192 atoms, dense above 64) at 2-4x
+                              the rate of the exact-f32 per-op kernels.  Scores, softmax, LayerNorm stay fp32.  Needs
                               |activations| < 65504 and |weights| < 256 (else non-finite outputs -> range flag).  `packed`: NULL, or
                               the tw_flow_pack_simple_h3 buffer where that exists (d_model 128) - the FFN of every encoder layer
-                              then runs as ONE launch of the fused kernels' chunk loop on the flat token list (hidden layer on
-                              chip) instead of two GEMMs through HBM, and kernel attention mixes the layer input itself with one
-                              folded 768 -> 128 GEMM behind it. */
+                              and the in / out MLPs then run as ONE launch each of the fused kernels' statements on the flat token
+                              list (hidden layer on chip) instead of two GEMMs through HBM, and kernel attention mixes the layer
+                              input itself with the one folded 768 -> 128 GEMM inside the mixing launch. */
 
 /* 1 if `path` can run this configuration on molecules of n_atoms atoms (TW_PATH_AUTO / TW_PATH_SIMPLE / TW_PATH_SIMPLE_H3: always), else 0.
  * What a caller asks before it requests TW_PATH_FUSED / TW_PATH_FUSED_H3 by name (those fail with TW_ERR_INVALID on an

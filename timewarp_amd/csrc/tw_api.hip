@@ -126,13 +126,14 @@ int tw_flow_pack_h3(const tw_flow_desc* desc, const float* raw, void* packed_h3,
 int64_t tw_flow_packed_simple_h3_bytes(const tw_flow_desc* desc) {
   if (check_desc(desc)) return -1;
   if (!h3_supported(*desc, 22)) return 0;
-  return (h3_packed_bytes(*desc) + 255) / 256 * 256 + simple_h3_fold_floats(*desc) * 4;
+  return simple_h3_split_offset(*desc) + h3_ffn_split_bytes(*desc);
 }
 
 int tw_flow_pack_simple_h3(const tw_flow_desc* desc, const float* raw, void* packed, void* stream) {
   int rc = tw_flow_pack_h3(desc, raw, packed, stream);
   if (rc) return rc;
-  return simple_h3_fold(*desc, raw, (float*)((char*)packed + (h3_packed_bytes(*desc) + 255) / 256 * 256), (hipStream_t)stream);
+  if ((rc = simple_h3_fold(*desc, raw, (float*)((char*)packed + (h3_packed_bytes(*desc) + 255) / 256 * 256), (hipStream_t)stream))) return rc;
+  return h3_ffn_split_pack(*desc, packed, (char*)packed + simple_h3_split_offset(*desc), (hipStream_t)stream);
 }
 
 int64_t tw_flow_packed_h1_bytes(const tw_flow_desc* desc) {

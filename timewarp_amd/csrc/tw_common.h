@@ -287,10 +287,15 @@ int h3_selected_kernel(const tw_flow_desc& d, int n_atoms, int64_t n_rows, bool 
 // TW_PATH_SIMPLE_H3: h <- LayerNorm2(h + FFN(h)) of (coupling, net, layer) on a flat [n_tokens, 128] list, FFN weights from the
 // tw_flow_pack_h3 stream (csrc/tw_netblock_h3.hip)
 bool h3_ffn_tokens_supported(const tw_flow_desc& d);
+int64_t simple_h3_split_offset(const tw_flow_desc& d);  // bytes in front of the split FFN streams in that buffer
 int64_t simple_h3_fold_floats(const tw_flow_desc& d);   // tw_flow_pack_simple_h3: Wc of every (coupling, net, layer) behind the stream
 int simple_h3_fold(const tw_flow_desc& d, const float* raw, float* out, hipStream_t s);
 int h3_ffn_tokens(const tw_flow_desc& d, const void* packed, int coupling, int net, int layer, float* h, int64_t n_tokens,
-                  hipStream_t stream);
+                  hipStream_t stream, float* scratch, int64_t scratch_floats, const void* split_stages);
+// small launches: the hidden layer over four workgroups per token tile - their streams (h3_ffn_split_pack, behind the folded Wc in the
+// tw_flow_pack_simple_h3 buffer) and `scratch` for the partial sums
+int64_t h3_ffn_split_bytes(const tw_flow_desc& d);
+int h3_ffn_split_pack(const tw_flow_desc& d, const void* packed, void* dst, hipStream_t stream);
 // ... and the in-MLP (u [n_tokens, d_in <= 64] -> h [n_tokens, 128]) / out-MLP (h -> o [n_tokens, 3]) of (coupling, net)
 bool h3_io_tokens_supported(const tw_flow_desc& d);
 int h3_io_tokens(const tw_flow_desc& d, const void* packed, int coupling, int net, bool out, const float* in, float* res, int d_in,

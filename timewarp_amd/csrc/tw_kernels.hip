@@ -775,6 +775,9 @@ __global__ void fold_vo_kernel(const float* __restrict__ raw, int64_t first_net,
 // fp16 copies (hi, lo: half as many floats each)
 static int64_t fold_wc_floats(const tw_flow_desc& d) { return (int64_t)d.n_coupling * 2 * d.n_layers * d.d_model * d.n_heads * d.d_model; }
 int64_t simple_h3_fold_floats(const tw_flow_desc& d) { return d.variant == 0 ? 2 * fold_wc_floats(d) : 0; }
+int64_t simple_h3_split_offset(const tw_flow_desc& d) {
+  return ((h3_packed_bytes(d, false) + 255) / 256 * 256 + simple_h3_fold_floats(d) * 4 + 255) / 256 * 256;
+}
 
 int simple_h3_fold(const tw_flow_desc& d, const float* raw, float* out, hipStream_t s) {
   if (d.variant != 0) return TW_OK;
@@ -1812,7 +1815,7 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
     if (sp && a.packed && h3_ffn_tokens_supported(d) && !(g_debug_flags & 16777216)) {
       // TW_PATH_SIMPLE_H3 with the split-fp16 stream at hand: FFN + residual + LayerNorm 2 as ONE launch of the fused kernels' chunk
       // loop on the flat token list - the 2048-wide hidden layer stays on the chip (tw_netblock_h3.hip: h3_ffn_tokens_kernel)
-      if ((rc = h3_ffn_tokens(d, a.packed, c, net, l, w.h, M, s))) return rc;
+      if ((rc = h3_ffn_tokens(d, a.packed, c, net, l, w.h, M, s, w.ff, M * d.d_ff, (const char*)a.packed + simple_h3_split_offset(d)))) return rc;
     } else {
     if ((rc = launch_linear(w.h, lb + L.layer.w1, lb + L.layer.b1, w.ff, M, d.d_ff, d.d_model, ACT_RELU, s, sp))) return rc;
     if ((rc = launch_linear(w.ff, lb + L.layer.w2, lb + L.layer.b2, w.tmp, M, d.d_model, d.d_ff, ACT_NONE, s, sp))) return rc;

@@ -37,6 +37,7 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));  // raw 128-bit registe
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 #define H3_NT 3
+#define H3_FFN_SPLIT 4   // TW_PATH_SIMPLE_H3, small launches: workgroups per token tile of the FFN launch (h3_ffn_split_pack)
 #define H3_TOK (16 * H3_NT)
 #define H3_XT 48      // tokens of a wave
 #define H3_XT_IMG 1536  // transposed copy: bytes per (feature tile, hi | lo) = [T0 | T1] 1024 + T2 512
@@ -2774,8 +2775,10 @@ struct H3FfnParams {
   const float* side;       // the layer's side block: n1w n1b b2 n2w n2b [128 each], slot 641 = W2's scale
   float* h;                // [n_tokens, 128] in / out
   int64_t n_tokens;
-  int ff_chunks;
+  int ff_chunks;           // chunks of 32 hidden units THIS workgroup walks (all of them unless split > 1)
   float eps;
+  int split;               // small launches: `split` workgroups per token tile, each over its share of the hidden layer ...
+  float* parts;            // ... writing W2-scaled partial sums [split][n_tokens, 128] here; h3_ffn_parts_ln_kernel finishes the layer
 };
 
 // NT = 3: 48-token waves on the five-slot ring; NT = 4: 64-token waves on the three-slot ring (tw_h3n4_ffn_asm.inc) - one launch
@@ -2788,8 +2791,10 @@ __global__ void __launch_bounds__(256) h3_ffn_tokens_kernel(H3FfnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, i16 = lane & 15;
+  const int part = __builtin_amdgcn_readfirstlane(p.split > 1 ? (int)(blockIdx.x % p.split) : 0);
+  const int64_t tile = p.split > 1 ? blockIdx.x / p.split : blockIdx.x;
   H3Pipe pipe;
-  pipe.gnext = p.stages + lane * 16;
+  pipe.gnext = p.stages + (int64_t)part * p.ff_chunks * 4 * H3_STAGE_BYTES + lane * 16;   // (split: the parts' own streams, back to back)
   pipe.lds = lds;
   pipe.cur = 0;
   pipe.wave = wave;
@@ -2797,7 +2802,7 @@ __global__ void __launch_bounds__(256) h3_ffn_tokens_kernel(H3FfnParams p) {
   pipe.ring = RING;
   pipe.start_issue();
   char* priv = lds + RING * H3_STAGE_BYTES + wave * WAVE_LDS;
-  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * NT);
+  const int64_t t0 = (tile * 4 + wave) * (16 * NT);
   f4 x[8][NT], y[8][NT];
   auto load_x = [&]() {
 #pragma unroll
@@ -2845,13 +2850,25 @@ __global__ void __launch_bounds__(256) h3_ffn_tokens_kernel(H3FfnParams p) {
       );
     }
   }
-  // (64-token waves: the layer input is read again here instead of living in 128 registers across the statement)
-  if constexpr (NT == 4) load_x();
   const float sc = p.side[641];
 #pragma unroll
   for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) y[ot][jt] = *(const f4*)(priv + (ot * NT + jt) * 1024 + lane * 16);
+  if (p.split > 1) {
+    float* dst = p.parts + (int64_t)part * p.n_tokens * 128;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const int64_t t = t0 + 16 * jt + i16;
+      if (t >= p.n_tokens) continue;
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) *(f4*)(dst + t * 128 + 16 * ft + 4 * g) = y[ft][jt] * sc;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  // (64-token waves: the layer input is read again here instead of living in 128 registers across the statement)
+  if constexpr (NT == 4) load_x();
 #pragma unroll
   for (int ot = 0; ot < 8; ++ot) {
     const f4 bb = *(const f4*)(p.side + 256 + 4 * g + 16 * ot);
@@ -2868,6 +2885,31 @@ __global__ void __launch_bounds__(256) h3_ffn_tokens_kernel(H3FfnParams p) {
   }
   // the statement's last hand-offs requested stages past this FFN (the stream has slack for that): they land before the LDS goes
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ... and behind a split launch:  h <- LayerNorm2(h + sum_p parts[p] + b2), one wave per token
+__global__ void __launch_bounds__(256) h3_ffn_parts_ln_kernel(H3FfnParams p) {
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= p.n_tokens) return;
+  const int lane = threadIdx.x & 63;
+  float* row = p.h + t * 128;
+  float v0 = row[lane] + p.side[256 + lane], v1 = row[64 + lane] + p.side[320 + lane];
+  for (int q = 0; q < p.split; ++q) {
+    const float* pr = p.parts + ((int64_t)q * p.n_tokens + t) * 128;
+    v0 += pr[lane];
+    v1 += pr[64 + lane];
+  }
+  float sum = v0 + v1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum * (1.f / 128.f);
+  const float d0 = v0 - mean, d1 = v1 - mean;
+  float var = d0 * d0 + d1 * d1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+  const float rstd = 1.0f / sqrtf(var * (1.f / 128.f) + p.eps);
+  row[lane] = d0 * rstd * p.side[384 + lane] + p.side[512 + lane];
+  row[64 + lane] = d1 * rstd * p.side[448 + lane] + p.side[576 + lane];
 }
 
 // The in-MLP and the out-MLP of a net block on the flat token list, the same way (tw_h3_in_asm.inc / tw_h3_out_asm.inc):
@@ -3373,7 +3415,7 @@ int flow_pass_h3(const FlowArgs& a) {
 bool h3_ffn_tokens_supported(const tw_flow_desc& d) { return h3_supported(d, 22); }
 
 int h3_ffn_tokens(const tw_flow_desc& d, const void* packed, int coupling, int net, int layer, float* h, int64_t n_tokens,
-                  hipStream_t stream) {
+                  hipStream_t stream, float* scratch, int64_t scratch_floats, const void* split_stages) {
   TW_REQUIRE(packed && h3_ffn_tokens_supported(d), "FFN on the split-fp16 stream: unsupported model or no stream");
   const H3Geom g = h3_geom(d);
   const int64_t att_stages = d.variant == 1 ? 4LL * g.H : 8LL * g.H;
@@ -3386,6 +3428,8 @@ int h3_ffn_tokens(const tw_flow_desc& d, const void* packed, int coupling, int n
   p.n_tokens = n_tokens;
   p.ff_chunks = g.ff_chunks;
   p.eps = d.ln_eps;
+  p.split = 1;
+  p.parts = scratch;
   // One workgroup per CU (LDS), so a launch is whole rounds of the chip: 48-token waves (192 tokens per workgroup) unless 64-token
   // waves (256 per workgroup, 4/3 the time per round) need fewer rounds' worth - 200 atoms x 256 rows: 267 workgroups = 2 rounds
   // against 200 = 4/3; 256 x 256: 342 = 2 rounds against 256 = 4/3.  Bits 29 / 30 force either (A/B, tests).
@@ -3395,7 +3439,16 @@ int h3_ffn_tokens(const tw_flow_desc& d, const void* packed, int coupling, int n
   if (g_debug_flags & 536870912) four = false;
   if (g_debug_flags & 1073741824) four = true;
   int rc;
-  const int64_t wgs = four ? wg4 : wg3;
+  // Launches that fill less than half the chip (691 atoms x 16 rows: 58 workgroups, each 84 us behind the weight stream): the hidden
+  // layer over H3_FFN_SPLIT workgroups per token tile (their own streams: h3_ffn_split_pack), W2-scaled partial sums through `scratch`,
+  // the layer finished by a small launch (bit 29: never)
+  if (!four && scratch && split_stages && h3_ffn_split_bytes(d) && wg3 * 2 <= cus &&
+      (int64_t)H3_FFN_SPLIT * n_tokens * 128 <= scratch_floats && !(g_debug_flags & 536870912)) {
+    p.split = H3_FFN_SPLIT;
+    p.ff_chunks = g.ff_chunks / H3_FFN_SPLIT;
+    p.stages = (const char*)split_stages + (((int64_t)(coupling * 2 + net) * g.L + layer) * g.ff_chunks * 4) * H3_STAGE_BYTES;
+  }
+  const int64_t wgs = (four ? wg4 : wg3) * p.split;
   TW_REQUIRE(wgs < (int64_t)1 << 31, "FFN: %lld workgroups", (long long)wgs);
   if (four) {
     constexpr int lds = H3N4_RING * H3_STAGE_BYTES + 4 * H3N4_WAVE_LDS;
@@ -3408,6 +3461,53 @@ int h3_ffn_tokens(const tw_flow_desc& d, const void* packed, int coupling, int n
     if ((rc = lim.ensure((const void*)h3_ffn_tokens_kernel<3>, lds))) return rc;
     hipLaunchKernelGGL(h3_ffn_tokens_kernel<3>, dim3((unsigned)wgs), dim3(256), lds, stream, p);
   }
+  TW_LAUNCH_CHECK();
+  if (p.split > 1) {
+    hipLaunchKernelGGL(h3_ffn_parts_ln_kernel, dim3((unsigned)((n_tokens + 3) / 4)), dim3(256), 0, stream, p);
+    TW_LAUNCH_CHECK();
+  }
+  return TW_OK;
+}
+
+// TW_PATH_SIMPLE_H3, small launches: the FFN stages of every (coupling, net, layer) once more as H3_FFN_SPLIT self-contained streams of
+// ff_chunks / H3_FFN_SPLIT chunks each.  The stream is software-pipelined - A(0) | A(1) B(0) | ... | B(n - 1), A = the two W1 stages of a
+// chunk, B = the two W2 stages - so a quarter of it is not a stream; its stages in the pipelined order of 16 chunks are.  Whole stages
+// move (9 KiB each, aux included): a gather on the device behind tw_flow_pack_h3.
+__global__ void __launch_bounds__(256) h3_ffn_split_gather_kernel(const char* __restrict__ packed, char* __restrict__ dst, int64_t net_stride,
+                                                                  int64_t first_ffn_stage, int64_t layer_stages, int n_layers, int chunks) {
+  // blockIdx.x = ((net_index * n_layers + l) * chunks + ch) * 4 + piece;  piece 0, 1: the A stages of chunk ch, 2, 3: its B stages
+  int64_t b = blockIdx.x;
+  const int piece = (int)(b % 4); b /= 4;
+  const int ch = (int)(b % chunks); b /= chunks;
+  const int l = (int)(b % n_layers);
+  const int64_t ni = b / n_layers;
+  const int per = chunks / H3_FFN_SPLIT, part = ch / per, c = ch % per;
+  auto a_off = [](int k) -> int64_t { return k == 0 ? 0 : 2 + (int64_t)(k - 1) * 4; };
+  auto b_off = [](int k, int n) -> int64_t { return 2 + (int64_t)k * 4 + (k < n - 1 ? 2 : 0); };
+  const int64_t src_stage = first_ffn_stage + l * layer_stages + (piece < 2 ? a_off(ch) + piece : b_off(ch, chunks) + piece - 2);
+  const int64_t dst_stage = ((ni * n_layers + l) * chunks + (int64_t)part * per) * 4 + (piece < 2 ? a_off(c) + piece : b_off(c, per) + piece - 2);
+  const uint4* sp = (const uint4*)(packed + ni * net_stride + src_stage * H3_STAGE_BYTES);
+  uint4* dp = (uint4*)(dst + dst_stage * H3_STAGE_BYTES);
+  for (int i = threadIdx.x; i < H3_STAGE_BYTES / 16; i += 256) dp[i] = sp[i];
+}
+
+int64_t h3_ffn_split_bytes(const tw_flow_desc& d) {
+  if (!h3_ffn_tokens_supported(d)) return 0;
+  const H3Geom g = h3_geom(d);
+  if (g.ff_chunks % H3_FFN_SPLIT) return 0;
+  return ((int64_t)d.n_coupling * 2 * g.L * g.ff_chunks * 4 + H3_RING + 1) * H3_STAGE_BYTES;   // + the statements' over-fetch
+}
+
+int h3_ffn_split_pack(const tw_flow_desc& d, const void* packed, void* dst, hipStream_t stream) {
+  if (!h3_ffn_split_bytes(d)) return TW_OK;
+  const H3Geom g = h3_geom(d);
+  const int64_t att_stages = d.variant == 1 ? 4LL * g.H : 8LL * g.H;
+  const int64_t blocks = (int64_t)d.n_coupling * 2 * g.L * g.ff_chunks * 4;
+  TW_REQUIRE(blocks < (int64_t)1 << 31, "FFN split pack: %lld stages", (long long)blocks);
+  TW_HIP_CHECK(hipMemsetAsync((char*)dst + blocks * H3_STAGE_BYTES, 0, (H3_RING + 1) * H3_STAGE_BYTES, stream));
+  hipLaunchKernelGGL(h3_ffn_split_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const char*)packed, (char*)dst,
+                     g.net_stride_bytes, (int64_t)(g.in_a_stages + 2) * g.hid_chunks + att_stages, att_stages + 4LL * g.ff_chunks, g.L,
+                     g.ff_chunks);
   TW_LAUNCH_CHECK();
   return TW_OK;
 }
