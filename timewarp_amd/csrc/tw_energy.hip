@@ -1,6 +1,7 @@
-// AMBER-style potential energy on the GPU: one workgroup per conformation - one wave, or four for small molecules (r05: at 22
-// atoms the single wave spent most of its 27 us in the 21 serial iterations of the Born-radius loop with 22 of 64 lanes active;
-// the kernel sits on the MH iteration's critical path since the flow's launches fill the chip) - fp64 arithmetic.
+// AMBER-style potential energy on the GPU: one workgroup per conformation - four waves up to 64 atoms (r05: at 22 atoms a single
+// wave spent most of its 27 us in the 21 serial iterations of the Born-radius loop with 22 of 64 lanes active; the kernel sits on
+// the MH iteration's critical path since the flow's launches fill the chip), sixteen above (r06: the reference's 691-atom test
+// protein took 6.2 ms on one wave - a quarter of an MH iteration at 16 proposals) - fp64 arithmetic.
 //
 // Replaces the OpenMM call chain behind OpenmmPotentialEnergyTorch.forward
 // (utils/openmm/openmm_bridge.py:281-294 -> bgflow -> Context.getState(getEnergy=True)) for Systems
@@ -21,8 +22,10 @@ __device__ __forceinline__ double wsum(double v) {
   return v;
 }
 
-// W waves per conformation.  W > 1: every loop strides over the whole workgroup, and the Born-radius sums are computed pair-parallel
-// into a V x V table that one lane per atom then adds up in the single-wave kernel's order (same radii bit for bit).
+// W waves per conformation.  W > 1: every loop strides over the whole workgroup.  The Born-radius sums: W = 4 (small molecules)
+// computes them pair-parallel into a V x V table that one lane per atom then adds up in the single-wave kernel's order (same radii
+// bit for bit); W = 16 (no room for the table) gives every atom a wave - lanes over the partners, partial sums in partner order per
+// lane, a butterfly over the wave: the same sums up to the order of the fp64 additions.
 template <int W>
 __global__ void __launch_bounds__(64 * W) amber_energy_kernel(const tw_forcefield ff, const float* __restrict__ coords,
                                                                double* __restrict__ out, double* __restrict__ terms) {
@@ -33,7 +36,7 @@ __global__ void __launch_bounds__(64 * W) amber_energy_kernel(const tw_forcefiel
   double* born = x + 3 * V;    // [V]
   double* part = born + V;     // [W * 5] partial sums of the waves
   double* tmat = part + 5 * W; // [V*V] (W > 1 only)
-  unsigned* excl = (unsigned*)(tmat + (W > 1 ? V * V : 0));  // [V*V] bits
+  unsigned* excl = (unsigned*)(tmat + (W == 4 ? V * V : 0));  // [V*V] bits
   const int64_t n = blockIdx.x;
   const int lane = threadIdx.x;   // (thread of the workgroup)
   for (int i = lane; i < 3 * V; i += NTH) x[i] = (double)coords[n * 3 * V + i];
@@ -101,17 +104,27 @@ __global__ void __launch_bounds__(64 * W) amber_energy_kernel(const tw_forcefiel
   const double krf = use_cut ? (1.0 / (rc * rc * rc)) * (ff.rf_dielectric - 1.0) / (2.0 * ff.rf_dielectric + 1.0) : 0.0;
   const double crf = use_cut ? (1.0 / rc) * (3.0 * ff.rf_dielectric) / (2.0 * ff.rf_dielectric + 1.0) : 0.0;
   const int npairs = V * (V - 1) / 2;
-  for (int p = lane; p < npairs; p += NTH) {
-    // decode (i<j) from the linear index
-    int i = (int)((sqrt(8.0 * p + 1.0) + 1.0) * 0.5);
-    while (i * (i - 1) / 2 > p) --i;
-    while ((i + 1) * i / 2 <= p) ++i;
-    const int j = p - i * (i - 1) / 2;  // j < i
-    if (excl_test(excl, i * V + j)) continue;
+  // every pair j < i once: up to four waves a linear pair index strided over the workgroup and decoded; sixteen waves: a wave per
+  // row i, lanes over j (no decode - an fp64 square root and two loops per pair - and 238 k pairs at 691 atoms)
+  auto for_pairs = [&](auto&& body) {
+    if constexpr (W > 4) {
+      for (int i = lane >> 6; i < V; i += W)
+        for (int j = lane & 63; j < i; j += 64) body(i, j);
+    } else {
+      for (int p = lane; p < npairs; p += NTH) {
+        int i = (int)((sqrt(8.0 * p + 1.0) + 1.0) * 0.5);
+        while (i * (i - 1) / 2 > p) --i;
+        while ((i + 1) * i / 2 <= p) ++i;
+        body(i, p - i * (i - 1) / 2);  // j < i
+      }
+    }
+  };
+  for_pairs([&](int i, int j) {
+    if (excl_test(excl, i * V + j)) return;
     const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
     const double r2 = dx * dx + dy * dy + dz * dz;
     const double r = sqrt(r2);
-    if (use_cut && r >= rc) continue;
+    if (use_cut && r >= rc) return;
     const double* pi = ff.atom_par + 5 * i;
     const double* pj = ff.atom_par + 5 * j;
     const double sig = 0.5 * (pi[1] + pj[1]);
@@ -119,7 +132,7 @@ __global__ void __launch_bounds__(64 * W) amber_energy_kernel(const tw_forcefiel
     const double sr2 = (sig * sig) / r2, sr6 = sr2 * sr2 * sr2;
     e_nb += 4.0 * eps * (sr6 * sr6 - sr6);
     e_nb += TW_ONE_4PI_EPS0 * pi[0] * pj[0] * (use_cut ? (1.0 / r + krf * r2 - crf) : 1.0 / r);
-  }
+  });
   // GBSA-OBC (has_gbsa 1: OBC-II alpha=1 beta=0.8 gamma=4.85 = GBSAOBCForce / amber99_obc.xml; 2: OBC-I alpha=0.8
   // beta=0 gamma=2.909125 = implicit/obc1.xml; dielectric offset 0.009 nm, probe 0.14 nm)
   if (ff.has_gbsa) {
@@ -145,20 +158,35 @@ __global__ void __launch_bounds__(64 * W) amber_energy_kernel(const tw_forcefiel
       if (off_i < (sr_j - r)) term += 2.0 * (1.0 / off_i - l);
       return term;
     };
-    if constexpr (W > 1) {
+    if constexpr (W == 4) {
       for (int p = lane; p < V * V; p += NTH) {
         const int i = p / V, j = p - i * V;
         tmat[p] = i == j ? 0.0 : born_term(i, j, ff.atom_par[5 * i + 3] - offset);
       }
       __syncthreads();
     }
+    if constexpr (W > 4) {
+      __syncthreads();   // (x is complete)
+      for (int i = lane >> 6; i < V; i += W) {
+        const double rad_i = ff.atom_par[5 * i + 3];
+        const double off_i = rad_i - offset;
+        double sum = 0.0;
+        for (int j = lane & 63; j < V; j += 64)
+          if (j != i) sum += born_term(i, j, off_i);
+        sum = wsum(sum);
+        sum *= 0.5 * off_i;
+        const double s2 = sum * sum, s3 = sum * s2;
+        const double th = tanh(alpha * sum - beta * s2 + gamma * s3);
+        if ((lane & 63) == 0) born[i] = 1.0 / (1.0 / off_i - th / rad_i);
+      }
+    } else
     for (int i = lane; i < V; i += NTH) {
       const double rad_i = ff.atom_par[5 * i + 3];
       const double off_i = rad_i - offset;
       double sum = 0.0;
       for (int j = 0; j < V; ++j) {
         if (j == i) continue;
-        if constexpr (W > 1) sum += tmat[i * V + j];
+        if constexpr (W == 4) sum += tmat[i * V + j];
         else sum += born_term(i, j, off_i);
       }
       sum *= 0.5 * off_i;
@@ -182,14 +210,10 @@ __global__ void __launch_bounds__(64 * W) amber_energy_kernel(const tw_forcefiel
       const double q = ff.atom_par[5 * i];
       e_gb += 0.5 * pre * q * q / born[i];
     }
-    for (int p = lane; p < npairs; p += NTH) {
-      int i = (int)((sqrt(8.0 * p + 1.0) + 1.0) * 0.5);
-      while (i * (i - 1) / 2 > p) --i;
-      while ((i + 1) * i / 2 <= p) ++i;
-      const int j = p - i * (i - 1) / 2;
+    for_pairs([&](int i, int j) {
       const double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
       const double r2 = dx * dx + dy * dy + dz * dz;
-      if (use_cut && sqrt(r2) > rc) continue;
+      if (use_cut && sqrt(r2) > rc) return;
       const double a2 = born[i] * born[j];
       const double dij = r2 / (4.0 * a2);
       const double den = sqrt(r2 + a2 * exp(-dij));
@@ -197,7 +221,7 @@ __global__ void __launch_bounds__(64 * W) amber_energy_kernel(const tw_forcefiel
       double e = qq / den;
       if (use_cut) e -= qq / rc;
       e_gb += e;
-    }
+    });
   }
   e_bond = wsum(e_bond); e_angle = wsum(e_angle); e_tors = wsum(e_tors); e_nb = wsum(e_nb); e_gb = wsum(e_gb);
   if constexpr (W > 1) {   // the waves' sums, added in wave order
@@ -226,7 +250,7 @@ int amber_energy(const tw_forcefield* ff, const float* coords, double* out, doub
   if (n == 0) return TW_OK;
   const int V = ff->n_atoms;
   const bool four = V <= 64;   // small molecules: latency-bound, four waves per conformation (+ the V x V table: <= 32 KiB)
-  const int W = four ? 4 : 1;
+  const int W = four ? 4 : 16;
   size_t shm = (size_t)(4 * V + 5 * W + (four ? V * V : 0)) * sizeof(double) + excl_bytes(V);
   shm = (shm + 15) / 16 * 16;
   TW_REQUIRE(shm <= (size_t)160 * 1024, "energy kernel: %d atoms need %zu bytes of LDS (one conformation per workgroup; limit 160 KiB)", V, shm);
@@ -235,8 +259,8 @@ int amber_energy(const tw_forcefield* ff, const float* coords, double* out, doub
     hipLaunchKernelGGL(amber_energy_kernel<4>, dim3((unsigned)n), dim3(256), shm, s, *ff, coords, out, terms);
   } else {
     static LdsLimit lim;
-    if (shm > (size_t)64 * 1024 && (rc = lim.ensure((const void*)amber_energy_kernel<1>, 160 * 1024))) return rc;
-    hipLaunchKernelGGL(amber_energy_kernel<1>, dim3((unsigned)n), dim3(64), shm, s, *ff, coords, out, terms);
+    if (shm > (size_t)64 * 1024 && (rc = lim.ensure((const void*)amber_energy_kernel<16>, 160 * 1024))) return rc;
+    hipLaunchKernelGGL(amber_energy_kernel<16>, dim3((unsigned)n), dim3(1024), shm, s, *ff, coords, out, terms);
   }
   TW_LAUNCH_CHECK();
   return TW_OK;
