@@ -807,7 +807,8 @@ def test_per_op_path_large_molecules(path):
         finally:
             lib.tw_debug_set_flags(0)
         assert H.rel_err(out2.cpu(), ref) < TOL
-        try:   # bit 26: the folded GEMM inside the mixing kernel also for this small launch (default: from 200 workgroups on)
+        try:   # bit 26: the folded GEMM inside ONE mixing workgroup per query tile also for this small launch (default below 128
+            # workgroups: the heads over several workgroups per tile + a finishing launch; bit 25 would take the per-head launches)
             lib.tw_debug_set_flags(67108864)
             out3 = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
                                     y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
@@ -821,6 +822,13 @@ def test_per_op_path_large_molecules(path):
         finally:
             lib.tw_debug_set_flags(0)
         assert H.rel_err(out4.cpu(), ref) < TOL
+        try:   # bit 25: per-head mixing launches + the folded GEMM + add_ln
+            lib.tw_debug_set_flags(33554432)
+            out4b = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
+                                     y_velocs=y_v.cuda(), adj_list=None, edge_batch_idx=None, masked_elements=mask.cuda())
+        finally:
+            lib.tw_debug_set_flags(0)
+        assert H.rel_err(out4b.cpu(), ref) < TOL
         try:   # bit 28: the in / out MLPs as two GEMMs each instead of one launch of the fused kernels' statements on the token list
             lib.tw_debug_set_flags(268435456)
             out5 = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
@@ -841,7 +849,6 @@ def test_per_op_path_large_molecules(path):
                 lib.tw_debug_set_flags(0)
             assert H.rel_err(ffn[bit].cpu(), ref) < TOL, bit
         assert H.rel_err(ffn[536870912].cpu(), out.cpu()) < 2e-6 and H.rel_err(ffn[1073741824].cpu(), out.cpu()) < 2e-6
-        assert not torch.equal(ffn[536870912], out)
         # the dense softmax variant above its fused layouts (65+ atoms): q / k / v and output projections, in / out MLPs on the
         # split-fp16 GEMMs, the FFN through the fused launches, the softmax attention itself in fp32
         dsd = H.full_dense_sd()

@@ -1136,7 +1136,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(J == 2
                                                               const _Float16* __restrict__ wc_hi, const _Float16* __restrict__ wc_lo,
                                                               float* __restrict__ y, int64_t n_cond, int H, int V, int Vp,
                                                               float* __restrict__ hres, const float* __restrict__ lnw,
-                                                              const float* __restrict__ lnb, float eps) {
+                                                              const float* __restrict__ lnb, float eps, int head_parts,
+                                                              int64_t part_stride) {
+  // head_parts > 1 (small launches of big molecules: 691 atoms x 16 rows are 96 workgroups): the heads over `head_parts` workgroups
+  // per query tile, each writing its partial y to y + part * part_stride (hres == nullptr); parts_ln_kernel finishes the layer
   extern __shared__ __attribute__((aligned(16))) char lh_lds[];
   constexpr int D = 128, QB = 64 * J, NCH_S = QB / 16;
   constexpr int S_ARR = NCH_S * 1024, X_ARR = 8 * 1024, X_OFF = 2 * S_ARR, SLOT = 2 * S_ARR + 2 * X_ARR;
@@ -1145,19 +1148,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(J == 2
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i16 = lane & 15, g = lane >> 4;
   const int tiles_m = (V + QB - 1) / QB;
-  const int tm = (int)(blockIdx.x % tiles_m);
-  const int64_t n = blockIdx.x / tiles_m;
+  const int hpart = (int)(blockIdx.x % head_parts);
+  const int tm = (int)((blockIdx.x / head_parts) % tiles_m);
+  const int64_t n = blockIdx.x / head_parts / tiles_m;
   const int64_t c = n % n_cond;
+  const int h_count = H / head_parts, h_begin = hpart * h_count;
+  y += hpart * part_stride;
   const int q0 = tm * QB;
   const int n1 = Vp / 32;
   const int per_head = n1 + 4;
-  const int total = H * per_head;
+  const int total = h_count * per_head;
   const _Float16* Xh = xt_hi + n * D * (int64_t)Vp;
   const _Float16* Xl = xt_lo + n * D * (int64_t)Vp;
   // the tiles of global step t = (head, st) into `slot`; st < n1: key step st of the mixing; st >= n1: k-step st - n1 of the folded GEMM
   // (Wc hi / lo in the x^T areas).  Piece i = wave + 4 k of the stage's list is this wave's k-th: uniform per wave.
   auto issue = [&](int t, int slot) {
-    const int h = t / per_head, st = t - h * per_head;
+    const int hr = t / per_head, st = t - hr * per_head;
+    const int h = h_begin + hr;
     char* base = lh_lds + slot * SLOT;
     if (st < n1) {
 #pragma unroll
@@ -1233,7 +1240,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(J == 2
   int step = 0, slot = 0;
   auto next_slot = [&](int s_) { return s_ + 1 == NSLOT ? 0 : s_ + 1; };
   int fill = NSLOT - 1;   // the slot the next issue goes to
-  for (int h = 0; h < H; ++h) {
+  for (int h = 0; h < h_count; ++h) {
     lin_f4 xm[8][J];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -1605,6 +1612,26 @@ __global__ void __launch_bounds__(256) sdpa_mfma_kernel(const float* __restrict_
   }
 }
 
+// h = LayerNorm(h + sum_p parts[p]) for D = 128: behind a launch that left partial sums (attend_fold_h3_kernel with head_parts > 1)
+__global__ void __launch_bounds__(256) parts_ln_kernel(float* __restrict__ h, const float* __restrict__ parts, int n_parts, int64_t part_stride,
+                                                        const float* __restrict__ w, const float* __restrict__ b, float eps, int64_t tokens) {
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= tokens) return;
+  const int lane = threadIdx.x & 63;
+  float* row = h + t * 128;
+  float v0 = row[lane], v1 = row[64 + lane];
+  for (int q = 0; q < n_parts; ++q) {
+    const float* pr = parts + q * part_stride + t * 128;
+    v0 += pr[lane];
+    v1 += pr[64 + lane];
+  }
+  const float mean = wave_sum(v0 + v1) * (1.f / 128.f);
+  const float d0 = v0 - mean, d1 = v1 - mean;
+  const float rstd = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f) + eps);
+  row[lane] = d0 * rstd * w[lane] + b[lane];
+  row[64 + lane] = d1 * rstd * w[64 + lane] + b[64 + lane];
+}
+
 // h = LayerNorm(h + delta) (custom_attention_encoder.py:109-114); one wave per token
 __global__ void add_ln_kernel(float* __restrict__ h, const float* __restrict__ delta, const float* __restrict__ w,
                               const float* __restrict__ b, float eps, int D, int64_t tokens) {
@@ -1718,31 +1745,43 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
         hipLaunchKernelGGL(xt_split_kernel, dim3((unsigned)a.n_rows, (unsigned)(Vp / 32), (unsigned)((d.d_model + 31) / 32)), dim3(256), 0,
                            s, w.h, w.xt_hi, w.xt_lo, V, Vp, d.d_model);
         TW_LAUNCH_CHECK();
-        // (one workgroup of the fused form walks all heads of its 128 queries: worth it once there are enough of them to fill half the
-        // chip - 691 atoms x 16 rows are 96 workgroups there against 576 of the per-head form: 12.7 against 12.2 ms per pass; 256 x 64
-        // are 128: 8.8 against 9.8)
-        if (!(g_debug_flags & 33554432) && (a.n_rows * ((V + 127) / 128) >= 128 || (g_debug_flags & 67108864))) {
+        // (one workgroup of the fused form walks all heads of its 128 queries: from 128 of them on.  Below that - 691 atoms x 16 rows
+        // are 96 - the heads go over 2, 3 or 6 workgroups per query tile, partial sums through w.att, parts_ln_kernel behind them;
+        // bit 25: the per-head launches + a GEMM + add_ln instead, 132 us per layer at 691 x 16)
+        const int64_t fold_wgs = a.n_rows * ((V + 127) / 128);
+        int head_parts = 1;
+        if (fold_wgs < 128 && !(g_debug_flags & 67108864))
+          for (int hp : {2, 3, 6})
+            if (d.n_heads % hp == 0 && head_parts == 1 && fold_wgs * hp >= 160) head_parts = hp;
+        if (fold_wgs < 128 && head_parts == 1 && d.n_heads % 6 == 0) head_parts = 6;
+        if (!(g_debug_flags & 33554432) && (fold_wgs >= 128 || head_parts > 1 || (g_debug_flags & 67108864))) {
           // ... and the folded 768 -> 128 GEMM inside the mixing launch (bit 25: as its own GEMM behind attend_h3p_kernel; bit 26:
           // inside it whatever the launch size; A/B, tests)
           const int64_t wcf = (int64_t)d.n_coupling * 2 * d.n_layers * d.d_model * HD;   // floats of the fp32 copy in front of the fp16 ones
           const float* fold0 = (const float*)((const char*)a.packed + (h3_packed_bytes(d, false) + 255) / 256 * 256);
           const _Float16* wch = (const _Float16*)(fold0 + wcf) + (((int64_t)c * 2 + net) * d.n_layers + l) * (int64_t)d.d_model * HD;
           // (+ the residual and LayerNorm 1 in its epilogue; bit 27: as the add_ln launch behind it - A/B, tests)
-          const bool ln_in = !(g_debug_flags & 134217728);
+          const bool ln_in = !(g_debug_flags & 134217728) && head_parts == 1;
           // 128 queries per workgroup on two stage buffers, two workgroups per CU.  Measured against it (profiles/r06_attend_fold_occupancy.txt):
           // 256 queries per workgroup (every x^T / Wc fragment read feeds 12 MFMAs instead of 6, but 489 registers = one wave per
           // SIMD) on two or three stage buffers, and 128 queries on four - all slower.
           {
             constexpr int ldsf = 2 * 32 * 1024;
-            const int64_t blocks = a.n_rows * ((V + 127) / 128);
+            const int64_t blocks = fold_wgs * head_parts;
             TW_REQUIRE(blocks < (int64_t)1 << 31, "attend: %lld workgroups", (long long)blocks);
             static LdsLimit limf;
             if ((rc = limf.ensure((const void*)attend_fold_h3_kernel<2, 2>, ldsf))) return rc;
             hipLaunchKernelGGL((attend_fold_h3_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), ldsf, s, w.s_hi, w.s_lo, w.xt_hi, w.xt_lo,
-                               wch, wch + wcf, w.tmp, a.n_cond, d.n_heads, V, Vp, ln_in ? w.h : nullptr, lb + L.layer.n1w,
-                               lb + L.layer.n1b, d.ln_eps);
+                               wch, wch + wcf, head_parts > 1 ? w.att : w.tmp, a.n_cond, d.n_heads, V, Vp, ln_in ? w.h : nullptr,
+                               lb + L.layer.n1w, lb + L.layer.n1b, d.ln_eps, head_parts, M * d.d_model);
           }
           TW_LAUNCH_CHECK();
+          if (head_parts > 1) {
+            hipLaunchKernelGGL(parts_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.h, w.att, head_parts, M * d.d_model,
+                               lb + L.layer.n1w, lb + L.layer.n1b, d.ln_eps, M);
+            TW_LAUNCH_CHECK();
+            goto ln1_done;
+          }
           if (ln_in) goto ln1_done;
           goto attention_done;
         }
