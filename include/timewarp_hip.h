@@ -9,7 +9,7 @@
  *
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
  *   - all float tensors are contiguous fp32, index tensors int32, masks uint8 (1 = masked);
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing synchronises;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing synchronises the host;
  *   - return value: 0 on success, a negative tw_status otherwise; tw_last_error() gives the
  *     message of the last failure on the calling thread.  No entry point allocates or frees
  *     caller memory; workspaces are caller-provided (tw_flow_workspace_bytes);
@@ -112,7 +112,9 @@ int tw_flow_pack_simple_h3(const tw_flow_desc* desc, const float* raw, void* pac
 int64_t tw_flow_packed_h1_bytes(const tw_flow_desc* desc);
 int tw_flow_pack_h1(const tw_flow_desc* desc, const float* raw, void* packed_h1, void* stream);
 
-/* Bytes of scratch the flow entry points need for n_rows conformations of n_atoms atoms. */
+/* Bytes of scratch the flow entry points need for n_rows conformations of n_atoms atoms.  (The per-op paths run the two nets of a
+ * coupling layer side by side - the second on a library-owned side stream that waits for and is waited for by `stream` through
+ * events, so the caller sees ordinary stream order - and size the scratch for two sets of activations.) */
 int64_t tw_flow_workspace_bytes(const tw_flow_desc* desc, int64_t n_rows, int32_t n_atoms);
 
 /* Execution path selector for the flow entry points. */
@@ -460,7 +462,9 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *   bit 28 (268435456) TW_PATH_SIMPLE_H3: the in-MLP and the out-MLP as two linear launches each instead of one launch of the fused
  *              kernels' statements on the flat token list (h3_io_tokens_kernel)
  *   bit 29 (536870912) / bit 30 (1073741824)  TW_PATH_SIMPLE_H3: the FFN / MLP token launches on 48-token / on 64-token waves whatever
- *              the launch size (default: whichever needs fewer rounds' worth of the chip); same arithmetic per token
+ *              the launch size (default: whichever needs fewer rounds' worth of the chip); same arithmetic per token.  Bit 29 also
+ *              turns off what the per-op paths do for launches that do not fill the chip: the FFN's hidden layer over four workgroups
+ *              per token tile, and the second net of a coupling layer on a side stream (both nets then run on the caller's stream)
  *   bit 31 (pass INT_MIN) per-op paths, dense softmax variant: the scalar attention kernels above 64 atoms instead of
  *              sdpa_mfma_kernel (fp32 matrix pipe); A/B switches and tests */
 int tw_debug_set_flags(int flags);
