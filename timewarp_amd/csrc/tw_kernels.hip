@@ -1547,6 +1547,24 @@ __global__ void sdpa_rows_kernel(const float* __restrict__ qkv, const uint8_t* _
 // thread per query and scalar FMAs: 855 us per call at 256 atoms x 256 rows, 76 % of a dense per-op pass.
 // LDS: K and V in fragment order (lane l of block b reads 16 bytes at (64 b + l) 16), the key mask as 0 / -inf.
 typedef float sd_f4 __attribute__((ext_vector_type(4)));
+// max / sum over the four lanes that share (lane & 15) without the LDS: v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16- and
+// 32-lane blocks between two registers (the fused kernels' h3_quad_max / h3_quad_sum, csrc/tw_netblock_h3.hip)
+__device__ __forceinline__ void sd_swap16(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void sd_swap32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float sd_quad_max(float v) {
+  float a = v, b = v;
+  sd_swap16(a, b);
+  a = b = fmaxf(a, b);
+  sd_swap32(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float sd_quad_sum(float v) {
+  float a = v, b = v;
+  sd_swap16(a, b);
+  a = b = a + b;
+  sd_swap32(a, b);
+  return a + b;
+}
 __global__ void __launch_bounds__(256) sdpa_mfma_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ masked, int64_t n_cond,
                                                          float* __restrict__ out, int V, int d, int n_head, int q_tiles_per_wave) {
   extern __shared__ __attribute__((aligned(16))) float sd_lds[];
@@ -1590,18 +1608,17 @@ __global__ void __launch_bounds__(256) sdpa_mfma_kernel(const float* __restrict_
       sd_f4 st = mb;
 #pragma unroll
       for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qb[s], st, 0, 0, 0);
-      float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mx = sd_quad_max(fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
       const float m_new = fmaxf(m_run, mx);
       const float m_safe = m_new == -INFINITY ? 0.f : m_new;   // (a block of masked keys before the first real one)
-      const float alpha = expf(m_run - m_safe);
+      // e^(s - m) = 2^((s - m) log2 e): the difference first (exact near the maximum, where the weight is), one rounding in the
+      // product, v_exp_f32 (1 ulp) - relative error <= |s - m| 2^-24, i.e. largest where the probability is smallest
+      const float L2E = 1.4426950408889634f;
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_safe) * L2E);
       sd_f4 pr;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pr[r] = expf(st[r] - m_safe);
-      float ps = (pr[0] + pr[1]) + (pr[2] + pr[3]);
-      ps += __shfl_xor(ps, 16);
-      ps += __shfl_xor(ps, 32);
+      for (int r = 0; r < 4; ++r) pr[r] = __builtin_amdgcn_exp2f((st[r] - m_safe) * L2E);
+      const float ps = sd_quad_sum((pr[0] + pr[1]) + (pr[2] + pr[3]));
       l_run = l_run * alpha + ps;
       o = o * alpha;
 #pragma unroll
