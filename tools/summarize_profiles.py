@@ -1,6 +1,7 @@
 """Summaries of the rocprofv3 outputs that tools/profile_round.sh leaves under gpurun_out/ (run on the GPU box):
   --traffic  DIR_FETCH DIR_WRITE OUT.json [MERGE.json]  FETCH_SIZE / WRITE_SIZE per launch of the net-block kernels (gfx950 correction)
   --sq       DIR1 DIR2 ... OUT.md           SQ counters of netblock_h3 per wave
+  --sqk      PATTERN WAVES DIR1 ... OUT.md  the same for the kernels whose name contains PATTERN, WAVES waves per launch
   --stats    DIR OUT.csv                    copy of the kernel-stats CSV of a --kernel-trace --stats run"""
 import csv
 import glob
@@ -60,20 +61,20 @@ def traffic(d_fetch, d_write, out, merge=None, bench_args=""):
     print(json.dumps({k: v for k, v in res.items() if k.startswith("netblock")}, indent=1))
 
 
-def sq(dirs, out):
+def sq(dirs, out, pattern="netblock_h3", n_waves=None):
     acc = defaultdict(list)
     for d in dirs:
         for r in counters(d):
-            if "netblock_h3" in r["Kernel_Name"]:
+            if pattern in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     # waves per launch: 2 nets x ceil(rows / molecules per workgroup) workgroups x 4 waves - 1000 for the 1000-proposal
     # alanine-dipeptide launches (250 workgroups), 2048 for NNQQ x 512 proposals on the wide layout (2 molecules per workgroup)
     # (paired layout, 100 atoms x 512 proposals: 256 workgroups per net as well)
-    waves = 2048.0 if ("4aa" in dirs[0] or "nnqq" in dirs[0] or "paired" in dirs[0]) else 1000.0
-    names = sorted({r["Kernel_Name"] for d in dirs for r in counters(d) if "netblock_h3" in r["Kernel_Name"]})
+    waves = float(n_waves) if n_waves else (2048.0 if ("4aa" in dirs[0] or "nnqq" in dirs[0] or "paired" in dirs[0]) else 1000.0)
+    names = sorted({r["Kernel_Name"] for d in dirs for r in counters(d) if pattern in r["Kernel_Name"]})
     lines = [f"# SQ counters, {', '.join('`' + n.split('(')[0].replace('void ', '') + '`' for n in names)}", "",
              f"`bash tools/pmc_h3.sh` on the GPU box ({os.path.basename(dirs[0])[:-2]}): four `rocprofv3 --kernel-trace --pmc <4 counters> "
-             "--kernel-include-regex netblock_h3` passes (command in tools/pmc_h3.sh). "
+             f"--kernel-include-regex {pattern}` passes (command in tools/pmc_h3.sh). "
              f"Averages per launch divided by the {waves:.0f} waves of a launch; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles, "
              "SQ_VALU_MFMA_BUSY_CYCLES counts clocks.", "", "| counter | per wave |", "|---|---|"]
     vals = {k: sum(v) / len(v) / waves for k, v in acc.items()}
@@ -101,5 +102,7 @@ if __name__ == "__main__":
         traffic(*sys.argv[2:6], **({"bench_args": sys.argv[6]} if len(sys.argv) > 6 else {}))
     elif mode == "--sq":
         sq(sys.argv[2:-1], sys.argv[-1])
+    elif mode == "--sqk":
+        sq(sys.argv[4:-1], sys.argv[-1], sys.argv[2], sys.argv[3])
     elif mode == "--stats":
         stats(sys.argv[2], sys.argv[3])
