@@ -755,6 +755,40 @@ def test_64_token_layout_choice_and_config_3_size():
                 H.rel_err(res[flag][2][rows], rlp) < TOL, (S, flag)
 
 
+@pytest.mark.parametrize("variant", ["kernel", "dense"])
+def test_per_op_split_path_size_sweep_vs_exact_f32(variant):
+    """TW_PATH_SIMPLE_H3 against the exact-f32 per-op kernels (themselves held to the oracle elsewhere) over the sizes where its
+    launch forms change: token counts around the 48- / 64-token FFN launches and their four-way split, one to three query tiles of
+    the mixing launch with the heads over 1 / 2 / 3 / 6 workgroups, padded key blocks (atoms not a multiple of 16 / 32), one row and
+    odd row counts, masked tails; both passes, both nets side by side on two streams.  Conditional samples: 3 (n_atoms) coordinates
+    per row, so every token is looked at."""
+    sd = H.full_kernel_sd() if variant == "kernel" else H.full_dense_sd()
+    make = H.tw_kernel_model if variant == "kernel" else H.tw_dense_model
+    m5, m2 = make(sd, path=5), make(sd, path=SIMPLE)
+    g = torch.Generator().manual_seed(123)
+    for V, S in ((65, 1), (65, 7), (97, 3), (129, 2), (193, 5), (200, 64), (257, 1), (257, 6), (300, 33), (385, 2), (691, 3)):
+        at = torch.randint(0, 5, (1, V), generator=g).cuda()
+        xc = (torch.randn(1, V, 3, generator=g) * (0.8 if V < 300 else 1.5)).cuda()
+        xv = (torch.randn(1, V, 3, generator=g) * 0.5).cuda()
+        mk = torch.zeros(1, V, dtype=torch.bool)
+        mk[0, V - (V % 5):] = True
+        mk = mk.cuda()
+        zc = (torch.randn(S, 1, V, 3, generator=g) * 0.05).cuda()
+        zv = (torch.randn(S, 1, V, 3, generator=g) * 0.5).cuda()
+        out = [m.conditional_sample_with_logp(atom_types=at, x_coords=xc, x_velocs=xv, adj_list=None, edge_batch_idx=None, masked_elements=mk,
+                                              num_samples=S, z_coords=zc.clone(), z_velocs=zv.clone()) for m in (m5, m2)]
+        keep = ~mk[0]
+        for a, b in zip(out[0][:2], out[1][:2]):
+            assert H.rel_err(a[:, :, keep].cpu(), b[:, :, keep].cpu()) < TOL, (variant, V, S, H.rel_err(a[:, :, keep].cpu(), b[:, :, keep].cpu()))
+        assert H.rel_err(out[0][2].cpu(), out[1][2].cpu()) < TOL, (variant, V, S)
+        # ... and back: every row conditioned on its own state
+        yc, yv = out[1][0].squeeze(1), out[1][1].squeeze(1)
+        ll = [m.log_likelihood(atom_types=at.repeat(S, 1), x_coords=yc, x_velocs=yv, y_coords=xc.repeat(S, 1, 1), y_velocs=xv.repeat(S, 1, 1),
+                               adj_list=None, edge_batch_idx=None, masked_elements=mk.repeat(S, 1)) for m in (m5, m2)]
+        assert H.rel_err(ll[0].cpu(), ll[1].cpu()) < TOL, (variant, V, S, H.rel_err(ll[0].cpu(), ll[1].cpu()))
+    H.assert_not_demoted(m5)
+
+
 @pytest.mark.parametrize("path", [0, 5, -1], ids=["exact-f32", "split-fp16-linears", "model-default"])
 def test_per_op_path_large_molecules(path):
     """r06: `path` 5 = TW_PATH_SIMPLE_H3 (the per-op path with its linear layers as split-fp16 MFMA GEMMs) and -1 = what a model
