@@ -93,6 +93,11 @@ CONFIGS = {
                               "block stays split-fp16; both coupling nets of one coupling layer, all proposals",
                   workload="transformer_nvp.yaml (dense softmax attention variant), alanine-dipeptide (22 atoms), 1000-proposal "
                            "parallel MH, 1 chain per GPU (BASELINE.json configs[4])"),
+    "1hgv": dict(V=691, S=16, model="kernel", flop_sample_pass=16 * 691 * F_BLK_KERNEL(691),
+                 calibration=dict(coords_log_scale=-9.5, velocs_log_scale=0.0),
+                 workload="kernel_transformer_nvp.yaml, the reference's 691-atom test protein (testdata/output/1hgv-traj-state0.pdb: topology "
+                          "and a frame from the committed known-answer fixture, amber99sb-ildn + OBC tables pinned on its OpenMM energies and "
+                          "forces), 16-proposal parallel MH, 1 chain per GPU - above every fused layout: per-op launches on split-fp16 MFMAs"),
 }
 
 
@@ -107,6 +112,17 @@ def molecule(config):
     # NNQQ: topology, a frame of coordinates and the elements from the reference's known-answer file (data fixture)
     import numpy as np
     from timewarp_amd.forcefield import ELEMENT_MASSES, amber99sbildn_obc_tables
+
+    if config == "1hgv":
+        from timewarp_amd.dataloader import elements_from_atom_names
+
+        z = np.load(os.path.join(ROOT, "tests", "golden", "energy_kat_1hgv.npz"))
+        names = [str(n) for n in z["atom_names"]]
+        tables = amber99sbildn_obc_tables(names, [str(r) for r in z["residue_names"]], [int(i) for i in z["residue_ids"]],
+                                          improper_neighbour_order="pyset")
+        masses = torch.tensor([ELEMENT_MASSES[next(ch for ch in n if ch.isalpha())] for n in names], dtype=torch.float32)
+        assert len(names) == CONFIGS[config]["V"]
+        return "1hgv", elements_from_atom_names(names), torch.from_numpy(z["positions"][0].astype(np.float32)), masses, AmberPotentialEnergyTorch(tables)
 
     z = np.load(os.path.join(ROOT, "tests", "golden", "energy_kat_2olx.npz"))
     names, res, rid = [str(n) for n in z["atom_names"]], [str(r) for r in z["residue_names"]], [int(i) for i in z["residue_ids"]]
@@ -562,6 +578,33 @@ def other_config_record(device, seed, config, steps, sync_every, n_chains=1):
     }
 
 
+def protein_record(device, seed, steps=8):
+    """Whole MH iterations on the reference's 691-atom test protein (CONFIGS["1hgv"]): the flow on the model's default path there
+    (TW_PATH_SIMPLE_H3, both passes), the AMBER energy kernel on all 691 atoms, the accept step - one C-ABI call per iteration."""
+    from timewarp_amd import _lib
+
+    cfg = CONFIGS["1hgv"]
+    chain, model = build_chain(device, seed, cfg["S"], -1, "1hgv")   # -1: PREFER_SPLIT_FP16, the constructor's default
+    with torch.no_grad():
+        for _ in range(2):
+            chain.step_deferred()
+        chain.flush()
+        torch.cuda.synchronize()
+        acc0, prop0 = chain.accepted, chain.proposals
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            chain.step_deferred()
+        chain.flush()
+        chain.trajectory()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    return {"workload": cfg["workload"], "value": (chain.accepted - acc0) / elapsed, "unit": "MH-accepted samples/s",
+            "proposals_per_s": (chain.proposals - prop0) / elapsed, "steps": steps, "warmup": 2, "ms_per_step": elapsed / steps * 1e3,
+            "proposals_per_step": cfg["S"], "path": int(model._path_for(cfg["V"])), "dtype": PATHS["h3"]["dtype"],
+            "algorithmic_flop_per_step": 2 * cfg["flop_sample_pass"] * cfg["S"],
+            "range_guard_fired": bool(getattr(model, "demoted", False))}
+
+
 def large_molecule_flow_record(device, seed, V, S, passes=4):
     """Molecules above every fused layout (193+ atoms; the reference's own test protein has 691): FLOW PASSES ONLY of the
     kernel-attention model on the path a model takes there by default (TW_PATH_SIMPLE_H3: per-op launches, linears / mixing /
@@ -922,6 +965,8 @@ def main():
                 # above every fused layout: flow passes of 200- and 256-atom molecules x 256 proposals
                 "flow_200x256": large_molecule_flow_record(device, seed, 200, 256),
                 "flow_256x256": large_molecule_flow_record(device, seed, 256, 256),
+                # ... and whole MH iterations on the reference's own 691-atom test protein
+                "protein_1hgv": protein_record(device, seed),
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.proposals)
