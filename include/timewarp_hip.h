@@ -457,7 +457,7 @@ int tw_flow_nonfinite(int32_t reset, int32_t* out_flag);
  *              A/B switch and tests
  *   bit 25 (33554432) TW_PATH_SIMPLE_H3, folded attention: the 768 -> 128 GEMM as its own launch behind the mixing kernel instead
  *              of inside it (attend_fold_h3_kernel); bit 26 (67108864): inside it with one workgroup per query tile whatever the
- *              launch size (default below 128 workgroups: the heads over 2 / 3 / 6 workgroups per tile + a finishing launch); bit 27 (134217728): residual + LayerNorm 1 as the add_ln launch behind that kernel instead of
+ *              launch size (default below 400 workgroups: the heads over 6 / 2 workgroups per tile + a finishing launch); bit 27 (134217728): residual + LayerNorm 1 as the add_ln launch behind that kernel instead of
  *              in its epilogue; A/B switches and tests
  *   bit 28 (268435456) TW_PATH_SIMPLE_H3: the in-MLP and the out-MLP as two linear launches each instead of one launch of the fused
  *              kernels' statements on the flat token list (h3_io_tokens_kernel)

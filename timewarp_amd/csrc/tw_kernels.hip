@@ -1780,16 +1780,16 @@ static int netblock_simple(const FlowArgs& a, const RawLayout& L, const SimpleWs
         hipLaunchKernelGGL(xt_split_kernel, dim3((unsigned)a.n_rows, (unsigned)(Vp / 32), (unsigned)((d.d_model + 31) / 32)), dim3(256), 0,
                            s, w.h, w.xt_hi, w.xt_lo, V, Vp, d.d_model);
         TW_LAUNCH_CHECK();
-        // (one workgroup of the fused form walks all heads of its 128 queries: from 128 of them on.  Below that - 691 atoms x 16 rows
-        // are 96 - the heads go over 2, 3 or 6 workgroups per query tile, partial sums through w.att, parts_ln_kernel behind them;
+        // (one workgroup of the fused form walks all heads of its 128 queries: from 400 of them on.  Below that the heads go over
+        // several workgroups per query tile - six up to 128 tiles (691 atoms x 16 rows are 96), two up to 400 (691 x 32: 9.0 -> 8.3 ms
+        // per pass) - partial sums through w.att, parts_ln_kernel behind them; bit 26: one workgroup per tile whatever the size;
         // bit 25: the per-head launches + a GEMM + add_ln instead, 132 us per layer at 691 x 16)
         const int64_t fold_wgs = a.n_rows * ((V + 127) / 128);
         int head_parts = 1;
-        if (fold_wgs < 128 && !(g_debug_flags & 67108864))
-          for (int hp : {2, 3, 6})
-            if (d.n_heads % hp == 0 && head_parts == 1 && fold_wgs * hp >= 160) head_parts = hp;
-        if (fold_wgs < 128 && head_parts == 1 && d.n_heads % 6 == 0) head_parts = 6;
-        if (!(g_debug_flags & 33554432) && (fold_wgs >= 128 || head_parts > 1 || (g_debug_flags & 67108864))) {
+        if (fold_wgs < 400 && !(g_debug_flags & 67108864))
+          for (int hp : {fold_wgs < 128 ? 6 : 2, 3, 2})
+            if (d.n_heads % hp == 0 && head_parts == 1) head_parts = hp;
+        if (!(g_debug_flags & 33554432) && (fold_wgs >= 400 || head_parts > 1 || (g_debug_flags & 67108864))) {
           // ... and the folded 768 -> 128 GEMM inside the mixing launch (bit 25: as its own GEMM behind attend_h3p_kernel; bit 26:
           // inside it whatever the launch size; A/B, tests)
           const int64_t wcf = (int64_t)d.n_coupling * 2 * d.n_layers * d.d_model * HD;   // floats of the fp32 copy in front of the fp16 ones
