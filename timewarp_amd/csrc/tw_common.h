@@ -129,7 +129,8 @@ bool fused_geom_nt(int n_atoms, int nt, FusedGeom* g);
 // coeffs == nullptr / order == 0: Gaussian basis; else rational-Chebyshev basis with coeffs [H, order]
 int launch_scores(const float* x, const uint8_t* masked, const float* ls, int H, int64_t B, int V,
                   int normalise, int use_mm, float* out, hipStream_t s, const float* coeffs = nullptr, int order = 0,
-                  int force_zero = 0);
+                  int force_zero = 0, _Float16* s_hi = nullptr, _Float16* s_lo = nullptr);
+bool scores_split_direct(int V);   // launch_scores can write the split fp16 operand of the folded mixing itself (row-wise kernel)
 int launch_centre(const float* x, const uint8_t* masked, float* xc, float* com, int64_t n, int V,
                   hipStream_t s);
 

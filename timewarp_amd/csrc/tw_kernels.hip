@@ -88,6 +88,18 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Fragment-order layout of the split fp16 MFMA operands of the folded attention (S, x^T, Wc): a [rows (padded to 16), keys or features
+// (padded to 32)] matrix is stored as [k-tile of 32][row tile of 16][lane 16 g + i16][8 halves] - the 16 rows x 32 k of one 16 x 16 x 32
+// operand fragment are ONE contiguous KiB in which lane (i16 = row % 16, g = (k % 32) / 8) owns bytes 16 lane .. 16 lane + 15.  An
+// LDS-DMA instruction (lane l moves 16 bytes to LDS base + 16 l) then reads a KiB linearly and the fragment read is ds_read_b128 at
+// base + 16 lane.  (Against the row-major [row][32 k] tile it replaced: the same kernel time, 148 us per call at 256 atoms x 256 rows -
+// the layout is kept for its addressing, one add per piece.)
+__host__ __device__ __forceinline__ int64_t frag_off(int64_t row_tiles, int row, int k) {
+  return (((int64_t)(k >> 5) * row_tiles + (row >> 4)) * 64 + (((k & 31) >> 3) * 16 + (row & 15))) * 8 + (k & 7);
+}
+
+#define AH_SSCALE 1024.0f   // the scores (<= 1 in magnitude) x 2^10 before their fp16 split: lo halves stay normal
+
 // ------------------------------------------------------------------------------------------------
 // compute_kernel_attention_scores  (kernel_attention.py:69-121)
 // one workgroup per conditioning row; out [B,H,V,V]
@@ -152,7 +164,11 @@ __global__ void scores_kernel(const float* __restrict__ x, const uint8_t* __rest
 #define SCORES_KEEP 16
 __global__ void __launch_bounds__(64 * SCORES_ROWS_PER_BLOCK) scores_rows_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ masked, const float* __restrict__ ls, int H, int V, int normalise, int use_mm,
-    float* __restrict__ out, const float* __restrict__ coeffs, int order, int force_zero) {
+    float* __restrict__ out, const float* __restrict__ coeffs, int order, int force_zero, _Float16* __restrict__ hi,
+    _Float16* __restrict__ lo) {
+  // hi / lo (optional, instead of out): the scores x 2^10 as split fp16 in fragment order, keys padded to Vp = 32 ceil(V / 32) with
+  // zeros - what split_scores_kernel makes of `out`, without the fp32 round trip (padded QUERY rows stay unwritten: a query is a
+  // column of the mixing's B operand, and columns past the molecule are dropped)
   extern __shared__ float sm[];
   float* xs = sm;  // [V*3]
   const int64_t b = blockIdx.x;
@@ -184,15 +200,32 @@ __global__ void __launch_bounds__(64 * SCORES_ROWS_PER_BLOCK) scores_rows_kernel
   for (int m = lane + 64 * SCORES_KEEP; m < V; m += 64) sum += (double)fabsf(value(m));
   sum = wave_sum(sum);
   const float denom = (float)sum + 1e-5f;
-  float* o = out + ((b * H + h) * V + q) * (int64_t)V;
+  const int Vp = (V + 31) / 32 * 32;
+  const int64_t mat = (b * H + h) * (int64_t)Vp * Vp;
+  auto put = [&](int m, float v) {
+    if (hi) {
+      const float sv = v * AH_SSCALE;
+      const _Float16 hh = (_Float16)sv;
+      const int64_t off = mat + frag_off(Vp / 16, q, m);
+      hi[off] = hh;
+      lo[off] = (_Float16)(sv - (float)hh);
+    } else {
+      out[((b * H + h) * V + q) * (int64_t)V + m] = v;
+    }
+  };
 #pragma unroll
   for (int k = 0; k < SCORES_KEEP; ++k) {
     const int m = lane + 64 * k;
-    if (m < V) o[m] = normalise ? keep[k] / denom : keep[k];
+    if (m < V) put(m, normalise ? keep[k] / denom : keep[k]);
+    else if (hi && m < Vp) put(m, 0.f);
   }
-  for (int m = lane + 64 * SCORES_KEEP; m < V; m += 64) {
+  for (int m = lane + 64 * SCORES_KEEP; m < Vp; m += 64) {
+    if (m >= V) {
+      if (hi) put(m, 0.f);
+      continue;
+    }
     const float e = value(m);
-    o[m] = normalise ? e / denom : e;
+    put(m, normalise ? e / denom : e);
   }
 }
 
@@ -208,16 +241,20 @@ __global__ void __launch_bounds__(64 * SCORES_ROWS_PER_BLOCK) scores_rows_kernel
       TW_HIP_CHECK(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
   } while (0)
 
+// s_hi / s_lo (optional; the row-wise kernel only - scores_split_direct): the split fp16 operand of the folded mixing instead of `out`
+bool scores_split_direct(int V) { return V > 160 && !(g_debug_flags & 2097152); }
 int launch_scores(const float* x, const uint8_t* masked, const float* ls, int H, int64_t B, int V,
-                  int normalise, int use_mm, float* out, hipStream_t s, const float* coeffs, int order, int force_zero) {
+                  int normalise, int use_mm, float* out, hipStream_t s, const float* coeffs, int order, int force_zero, _Float16* s_hi,
+                  _Float16* s_lo) {
   if (B == 0) return TW_OK;
+  TW_REQUIRE(!s_hi || scores_split_direct(V), "scores: split output asked of the tile kernel (%d atoms)", V);
   size_t shm = (size_t)(3 * V + V * V) * sizeof(float);
   // The row-wise kernel: no room for the distance tile (or bit 21) - and from 161 atoms on anyway: the tile kernel is one workgroup
   // per conditioning state, one thread per (head, query) row (200 atoms, one state: 590 us on one CU); the row-wise one a wave per row.
   if (shm > (size_t)160 * 1024 || V > 160 || (g_debug_flags & 2097152)) {
     hipLaunchKernelGGL(scores_rows_kernel, dim3((unsigned)B, (unsigned)((H * V + SCORES_ROWS_PER_BLOCK - 1) / SCORES_ROWS_PER_BLOCK)),
                        dim3(64 * SCORES_ROWS_PER_BLOCK), (size_t)3 * V * sizeof(float), s, x, masked, ls, H, V, normalise, use_mm, out, coeffs,
-                       order, force_zero);
+                       order, force_zero, s_hi, s_lo);
     TW_LAUNCH_CHECK();
     return TW_OK;
   }
@@ -725,16 +762,6 @@ __global__ void __launch_bounds__(256) linear_h3_kernel(const float* __restrict_
   }
 }
 
-// Fragment-order layout of the split fp16 MFMA operands of the folded attention (S, x^T, Wc): a [rows (padded to 16), keys or features
-// (padded to 32)] matrix is stored as [k-tile of 32][row tile of 16][lane 16 g + i16][8 halves] - the 16 rows x 32 k of one 16 x 16 x 32
-// operand fragment are ONE contiguous KiB in which lane (i16 = row % 16, g = (k % 32) / 8) owns bytes 16 lane .. 16 lane + 15.  An
-// LDS-DMA instruction (lane l moves 16 bytes to LDS base + 16 l) then reads a KiB linearly and the fragment read is ds_read_b128 at
-// base + 16 lane.  (Against the row-major [row][32 k] tile it replaced: the same kernel time, 148 us per call at 256 atoms x 256 rows -
-// the layout is kept for its addressing, one add per piece.)
-__host__ __device__ __forceinline__ int64_t frag_off(int64_t row_tiles, int row, int k) {
-  return (((int64_t)(k >> 5) * row_tiles + (row >> 4)) * 64 + (((k & 31) >> 3) * 16 + (row & 15))) * 8 + (k & 7);
-}
-
 // Wc[n][h D + k] = sum_j W_o[n][h D + j] W_v[h D + j][k]  (fp64 sums, as the fused kernels' pack does): the value and output
 // projections of kernel attention folded per head (kernel_attention.py:124-156: out_proj(flatten(A_h (x W_v,h^T)))) = sum_h (A_h x) Wc_h^T
 __global__ void fold_vo_kernel(const float* __restrict__ raw, int64_t first_net, int64_t coupling_size, int64_t net_size,
@@ -843,7 +870,7 @@ __global__ void attend_kernel(const float* __restrict__ scores, const float* __r
 // subnormal lo halves otherwise); B operand = vals^T: lane (d, g) needs eight consecutive m of ONE feature, so the 32 x 128 slice of
 // vals is transposed on its way into the LDS - each thread loads rows m, m + 1 of four features and writes (m, m + 1) half pairs.
 // Workgroup = 128 queries x 128 features, wave (wm, wn) 64 x 64.  1-D grid over (n, h, query tile, feature tile).
-#define AH_SSCALE 1024.0f
+// (AH_SSCALE: defined with frag_off above)
 // `vrow` / `vhead`: floats between consecutive keys of `vals` and between heads - (H D, D) for the projected values [n, m, h, d];
 // (D, 0) for the FOLDED form, where every head mixes the layer input x [n, m, d] itself and the per-head value and output
 // projections are one 768 -> 128 GEMM behind the mixing (Wc_h = W_o,h W_v,h, tw_flow_pack_simple_h3).
@@ -1926,11 +1953,13 @@ static int simple_scores(const FlowArgs& a, const RawLayout& L, const SimpleWs& 
   const tw_flow_desc& d = *a.desc;
   if (d.variant != 0 || d.cheb_order > 0) return TW_OK;  // chebyshev_kernel: per layer, in netblock_simple
   // one score matrix per flow call, shared by every encoder layer (model_constructor.py:192-195)
+  const bool folded = a.simple_h3 && a.packed && w.s_hi && a.n_atoms > 64 && h3_ffn_tokens_supported(d) && !(g_debug_flags & 16777216);
+  const bool direct = folded && scores_split_direct(a.n_atoms);   // the row-wise kernel writes the mixing's split operand itself
   int rc = launch_scores(a.x_coords, a.masked, a.raw + L.lengthscales + (a.reverse ? d.n_heads : 0), d.n_heads, a.n_cond, a.n_atoms, d.normalise,
-                         a.n_atoms > 25, w.scores, a.stream);
+                         a.n_atoms > 25, w.scores, a.stream, nullptr, 0, 0, direct ? w.s_hi : nullptr, direct ? w.s_lo : nullptr);
   if (rc) return rc;
-  if (a.simple_h3 && a.packed && w.s_hi && a.n_atoms > 64 && h3_ffn_tokens_supported(d) && !(g_debug_flags & 16777216)) {
-    // the folded mixing's A operand (attend_h3p_kernel): split once per flow pass, shared by every layer and both nets
+  if (folded && !direct) {
+    // the folded mixing's A operand: split once per flow pass, shared by every layer and both nets
     const int V = a.n_atoms, Vp = (V + 31) / 32 * 32;
     const int64_t rows = a.n_cond * d.n_heads * Vp, total = rows * Vp;
     hipLaunchKernelGGL(split_scores_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a.stream, w.scores, w.s_hi, w.s_lo,
