@@ -98,6 +98,51 @@ def test_leapfrog_conserves_energy_without_friction(scheme):
     assert spread[0.00025] < 0.5 * spread[0.0005]
 
 
+def test_sixteen_wave_dynamics_above_64_atoms():
+    """Above 64 atoms a conformation's forces are shared by sixteen waves (amber_forces_block: rows of the pair matrices per wave, no
+    cross-wave atomics).  NNQQ (65 atoms, the reference's OpenMM test peptide) and the 691-atom test protein: leapfrog without
+    friction conserves the total energy; a thermostatted run is a function of its seed - bit for bit the same twice, different with
+    another seed - which is what the row-owner formulation is for."""
+    from timewarp_amd.energy import AmberPotentialEnergyTorch
+    from timewarp_amd.forcefield import ELEMENT_MASSES, amber99sbildn_obc_tables
+    from timewarp_amd.md import LangevinDynamics
+
+    z = kat()
+    e = AmberPotentialEnergyTorch(kat_tables(z))
+    masses = torch.tensor([ELEMENT_MASSES[str(el)] for el in z["elements"]], dtype=torch.float32)
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.from_numpy(z["positions"][:4].astype(np.float32)).cuda()
+    v0 = (torch.randn(4, 65, 3, generator=g) * (e.kbT / masses)[None, :, None].sqrt()).cuda()
+    dt = 0.0005
+    md = LangevinDynamics(e, masses, timestep_ps=dt, friction_per_ps=0.0)
+    x, v = md.step(x0, v0, 200)
+    ref = _total_energy(e, masses, x, v, dt)
+    worst = torch.zeros_like(ref)
+    for _ in range(10):   # 1 ps
+        x, v = md.step(x, v, 200)
+        worst = torch.maximum(worst, (_total_energy(e, masses, x, v, dt) - ref).abs())
+    print(f"NNQQ, sixteen waves, friction 0: max |E_total - E_total(0)| over 1 ps: {float(worst.max()):.3f} kJ/mol")
+    assert torch.isfinite(x).all() and float(worst.max()) < 1.5   # (65 atoms: three times alanine dipeptide's kinetic energy)
+    runs = []
+    for seed in (5, 5, 6):
+        md = LangevinDynamics(e, masses, timestep_ps=dt, friction_per_ps=0.3, seed=seed)
+        runs.append(md.step(x0, v0, 300))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert not torch.equal(runs[0][0], runs[2][0])
+    # the protein: 40 thermostatted steps twice, and the energy stays finite and close to where it started
+    zp = np.load(H.GOLDEN + "/energy_kat_1hgv.npz")
+    names = [str(n) for n in zp["atom_names"]]
+    ep = AmberPotentialEnergyTorch(amber99sbildn_obc_tables(names, [str(r) for r in zp["residue_names"]], [int(i) for i in zp["residue_ids"]],
+                                                            improper_neighbour_order="pyset"))
+    mp = torch.tensor([ELEMENT_MASSES[next(ch for ch in n if ch.isalpha())] for n in names], dtype=torch.float32)
+    xp = torch.from_numpy(zp["positions"][:2].astype(np.float32)).cuda()
+    vp = (torch.randn(2, 691, 3, generator=g) * (ep.kbT / mp)[None, :, None].sqrt()).cuda()
+    outs = [LangevinDynamics(ep, mp, timestep_ps=dt, friction_per_ps=0.3, seed=9).step(xp, vp, 40, want_energy=True) for _ in range(2)]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    e0 = ep.energy_and_forces(xp)[0]
+    assert torch.isfinite(outs[0][2]).all() and float((outs[0][2] - e0).abs().max()) < 0.05 * float(e0.abs().max())
+
+
 @pytest.mark.parametrize("scheme", ["LangevinMiddleIntegrator", "LangevinIntegrator"])
 def test_thermostat_reaches_the_target_temperature(scheme):
     """256 replicas of alanine dipeptide from rest, friction 10 / ps, 1 fs: after 6 ps the kinetic temperature over

@@ -44,3 +44,12 @@ for S in [int(a) for a in sys.argv[1:]] or [16]:
         de = (time.perf_counter() - t0) / 5 * 1e3
     print(f"1hgv (691 atoms) x {S} proposals, path {model._path_for(V)}: {dt:.2f} ms per MH iteration; energy of {S + 1} conformations alone {de:.3f} ms; "
           f"accepted {chain.accepted} of {chain.proposals // S} iterations", flush=True)
+
+# the force kernel (hybrid moves / Langevin steps run on it): energy + forces of 4 conformations
+x4 = coords.to(dev)[None].repeat(4, 1, 1).contiguous()
+with torch.no_grad():
+    energy.energy_and_forces(x4); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        energy.energy_and_forces(x4)
+    torch.cuda.synchronize()
+    print(f"1hgv: energy + forces of 4 conformations {(time.perf_counter() - t0) / 3 * 1e3:.3f} ms per launch", flush=True)
