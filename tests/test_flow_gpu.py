@@ -841,7 +841,7 @@ def test_per_op_path_large_molecules(path):
         finally:
             lib.tw_debug_set_flags(0)
         assert H.rel_err(out2.cpu(), ref) < TOL
-        try:   # bit 26: the folded GEMM inside ONE mixing workgroup per query tile also for this small launch (default below 128
+        try:   # bit 26: the folded GEMM inside ONE mixing workgroup per query tile also for this small launch (default below 400
             # workgroups: the heads over several workgroups per tile + a finishing launch; bit 25 would take the per-head launches)
             lib.tw_debug_set_flags(67108864)
             out3 = m.log_likelihood(atom_types=at.cuda(), x_coords=x_c.cuda(), x_velocs=x_v.cuda(), y_coords=y_c.cuda(),
