@@ -766,12 +766,13 @@ def test_per_op_split_path_size_sweep_vs_exact_f32(variant):
     make = H.tw_kernel_model if variant == "kernel" else H.tw_dense_model
     m5, m2 = make(sd, path=5), make(sd, path=SIMPLE)
     g = torch.Generator().manual_seed(123)
-    for V, S in ((65, 1), (65, 7), (97, 3), (129, 2), (193, 5), (200, 64), (257, 1), (257, 6), (300, 33), (385, 2), (691, 3)):
+    for V, S in ((1, 1), (5, 1), (22, 7), (64, 9), (65, 1), (65, 7), (97, 3), (129, 2), (193, 5), (200, 64), (257, 1), (257, 6), (300, 33), (385, 2), (691, 3)):
         at = torch.randint(0, 5, (1, V), generator=g).cuda()
         xc = (torch.randn(1, V, 3, generator=g) * (0.8 if V < 300 else 1.5)).cuda()
         xv = (torch.randn(1, V, 3, generator=g) * 0.5).cuda()
         mk = torch.zeros(1, V, dtype=torch.bool)
-        mk[0, V - (V % 5):] = True
+        if V > 5:
+            mk[0, V - (V % 5):] = True
         mk = mk.cuda()
         zc = (torch.randn(S, 1, V, 3, generator=g) * 0.05).cuda()
         zv = (torch.randn(S, 1, V, 3, generator=g) * 0.5).cuda()
