@@ -254,8 +254,8 @@ typedef struct {
 /* coords [n_rows,n_atoms,3] fp32 (nm) -> out_energy [n_rows] fp64 kJ/mol (fp64 like the bridge's
  * numpy round trip, openmm_bridge.py:206-221).  All tw_forcefield pointers are device pointers.
  * out_terms, if not NULL, receives [n_rows,5] = bond, angle, torsion, nonbonded, gbsa
- * (the decomposition of simulation/md.py:288-413).  One conformation per wave, coordinates and the pair-exclusion bit
- * matrix in LDS: molecules up to ~1000 atoms (TW_ERR_INVALID beyond what 160 KiB hold; the force / Langevin entry points
+ * (the decomposition of simulation/md.py:288-413).  One conformation per workgroup (four waves up to 64 atoms, sixteen above; the
+ * force / Langevin kernels one / sixteen), coordinates and the pair-exclusion bit matrix in LDS: molecules up to ~1000 atoms (TW_ERR_INVALID beyond what 160 KiB hold; the force / Langevin entry points
  * below ~850 / ~800). */
 int tw_amber_energy(const tw_forcefield* ff, const float* coords, double* out_energy,
                     double* out_terms, int64_t n_rows, void* stream);
